@@ -1,0 +1,859 @@
+/*
+ * gridpp_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, single-threaded CPU restatement of the metno/gridpp hot path
+ * (optimal interpolation, Barnes structure function, radius / nearest
+ * neighbour search, neighbourhood filters, EnSI).  It exists so that the HIP
+ * kernels can be checked against the reference algorithm.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product path (gridpp_amd + libgridpp_hip.so) never does.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the upstream repository root).  No reference source text is copied: the
+ * reference is C++ on nested std::vector + Boost R-tree + Armadillo, this file
+ * is C on flat arrays with a linear scan and an in-file LU / Jacobi.
+ *
+ * Third-party arithmetic that is NOT in the reference tree:
+ *   - Boost.Geometry index::rtree (1.71/1.72 in the reference CI / wheels):
+ *     contributes no arithmetic, only WHICH indices and in what ORDER.  Here:
+ *     linear scan in index order.  Order only matters for exact-float ties in
+ *     the top-max_points cut (src/api/oi.cpp:266 uses an unstable std::sort),
+ *     where this oracle DEFINES the tie-break: higher rho first, then lower
+ *     observation index.
+ *   - Armadillo inv()/eig_sym()/rcond() -> LAPACK dgetrf+dgetri / dsyev:
+ *     restated as partial-pivot LU inverse and cyclic Jacobi, all in double.
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this file against the
+ * known-answer values of the reference's own unit tests (tests/golden/ JSON files,
+ * each entry citing the reference test file:line).  The reference itself is
+ * unbuildable in this image (needs Boost, Armadillo, LAPACK, SWIG).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define ORC_OK 0
+#define ORC_EINVAL -1
+#define ORC_ESINGULAR -2
+
+/* include/gridpp.h:55 */
+static const double orc_radius_earth = 6.378137e6;
+
+/* src/api/util.cpp:16-18 (value != NAN is always true) */
+static int orc_valid(float v) { return !isnan(v) && !isinf(v); }
+int orc_is_valid(float v) { return orc_valid(v); }
+
+/* ------------------------------------------------------------------------ */
+/* coordinates: src/api/util.cpp:583-624                                      */
+/* ------------------------------------------------------------------------ */
+int orc_convert_coordinates(const float* lats, const float* lons, int n, int type,
+                            float* x, float* y, float* z) {
+    for(int i = 0; i < n; i++) {
+        float lat = lats[i], lon = lons[i];
+        int ok_lat = (type == 1) ? orc_valid(lat) : (orc_valid(lat) && lat >= -90.001 && lat <= 90.001);
+        if(!ok_lat || !orc_valid(lon)) return ORC_EINVAL;
+        if(type == 1) { /* Cartesian: util.cpp:601-604 */
+            x[i] = lon; y[i] = lat; z[i] = 0;
+        } else {        /* Geodetic: util.cpp:606-612, double trig, float store */
+            double lonr = M_PI / 180 * lon;
+            double latr = M_PI / 180 * lat;
+            x[i] = (float)(cos(latr) * cos(lonr) * orc_radius_earth);
+            y[i] = (float)(cos(latr) * sin(lonr) * orc_radius_earth);
+            z[i] = (float)(sin(latr) * orc_radius_earth);
+        }
+    }
+    return ORC_OK;
+}
+
+/* src/api/kdtree.cpp:192-194 -- float arithmetic, no FMA (x86-64 baseline build) */
+/* (built with -ffp-contract=off and no -march flag, see oracle/Makefile) */
+static float orc_straight_distance(float x0, float y0, float z0, float x1, float y1, float z1) {
+    return sqrtf((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1) + (z0 - z1) * (z0 - z1));
+}
+float orc_calc_straight_distance(float x0, float y0, float z0, float x1, float y1, float z1) {
+    return orc_straight_distance(x0, y0, z0, x1, y1, z1);
+}
+
+/* src/api/kdtree.cpp:107-136 */
+float orc_calc_distance(float lat1, float lon1, float lat2, float lon2, int type) {
+    if(type == 1) {
+        float dx = lon1 - lon2, dy = lat1 - lat2;
+        return sqrtf(dx * dx + dy * dy);
+    }
+    if(lat1 == lat2 && lon1 == lon2) return 0;
+    /* deg2rad returns float (kdtree.cpp:195-197) */
+    double lat1r = (float)(lat1 * M_PI / 180), lat2r = (float)(lat2 * M_PI / 180);
+    double lon1r = (float)(lon1 * M_PI / 180), lon2r = (float)(lon2 * M_PI / 180);
+    double ratio = cos(lat1r)*cos(lon1r)*cos(lat2r)*cos(lon2r) + cos(lat1r)*sin(lon1r)*cos(lat2r)*sin(lon2r) + sin(lat1r)*sin(lat2r);
+    return (float)(acos(ratio) * 6.378137e6);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Barnes structure function: src/api/structure.cpp                          */
+/* ------------------------------------------------------------------------ */
+/* structure.cpp:26-34: v float, exponent and exp in double, result float */
+float orc_barnes_rho(float dist, float length) {
+    if(!orc_valid(length) || length == 0) return 1;
+    if(!orc_valid(dist)) return 0;
+    float v = dist / length;
+    return (float)exp(-0.5 * v * v);
+}
+/* structure.cpp:143-167 (scalar ctor): m_min_rho (float) */
+float orc_barnes_min_rho(float h, float hmax) {
+    if(orc_valid(hmax)) return (float)exp(pow((double)(hmax / h), 2) / -2);
+    return 0.0013f; /* structure.cpp:5 */
+}
+/* structure.cpp:280-282: sqrt(-2*log(m_min_rho)) * h with float overloads
+ * (<math.h> is pulled in through the Boost.Math headers of gridpp.h).  The
+ * double-precision reading gives the same float for every value the reference
+ * tests pin (tests/test_barnes_structure.py:46-66,85-97). */
+float orc_barnes_localization_distance(float h, float min_rho) {
+    return sqrtf(-2 * logf(min_rho)) * h;
+}
+/* structure.cpp:185-230, non-spatial branch :215-228 */
+float orc_barnes_corr(float x1, float y1, float z1, float e1, float l1,
+                      float x2, float y2, float z2, float e2, float l2,
+                      float h, float v, float w, float loc_dist) {
+    float hdist = orc_straight_distance(x1, y1, z1, x2, y2, z2);
+    if(hdist > loc_dist) return 0;
+    float rho = orc_barnes_rho(hdist, h);
+    if(orc_valid(e1) && orc_valid(e2)) rho *= orc_barnes_rho(e1 - e2, v);
+    if(orc_valid(l1) && orc_valid(l2)) rho *= orc_barnes_rho(l1 - l2, w);
+    return rho;
+}
+
+/* ------------------------------------------------------------------------ */
+/* radius / nearest-neighbour search: src/api/kdtree.cpp:39-106,241-270       */
+/* ------------------------------------------------------------------------ */
+/* strictly-inside box test (kdtree.cpp:46,53: index::within) then
+ * within_radius (kdtree.cpp:247-260) */
+static int orc_in_radius(float qx, float qy, float qz, float px, float py, float pz,
+                         float radius, int include_match) {
+    float lox = qx - radius, hix = qx + radius;
+    float loy = qy - radius, hiy = qy + radius;
+    float loz = qz - radius, hiz = qz + radius;
+    if(!(px > lox && px < hix && py > loy && py < hiy && pz > loz && pz < hiz)) return 0;
+    float d = orc_straight_distance(px, py, pz, qx, qy, qz);
+    if(include_match) return d <= radius;
+    return d <= radius && d > 0;
+}
+/* returns count; indices in ascending index order (the oracle's traversal order) */
+int orc_get_neighbours(const float* px, const float* py, const float* pz, int n,
+                       float qx, float qy, float qz, float radius, int include_match, int* out) {
+    int c = 0;
+    for(int i = 0; i < n; i++)
+        if(orc_in_radius(qx, qy, qz, px[i], py[i], pz[i], radius, include_match)) out[c++] = i;
+    return c;
+}
+/* kdtree.cpp:82-106: k nearest by chord distance.  Ties: the R-tree's order is
+ * unspecified; the oracle takes the lowest index.  Comparison is done on the
+ * float squared distance like Boost's comparable_distance. */
+int orc_nearest_neighbour(const float* px, const float* py, const float* pz, int n,
+                          float qx, float qy, float qz, int include_match) {
+    int best = -1; float bestd = 0;
+    for(int i = 0; i < n; i++) {
+        if(!include_match && px[i] == qx && py[i] == qy && pz[i] == qz) continue; /* kdtree.cpp:265-270 */
+        float dx = px[i] - qx, dy = py[i] - qy, dz = pz[i] - qz;
+        float s = dx * dx + dy * dy + dz * dz;
+        if(best < 0 || s < bestd) { best = i; bestd = s; }
+    }
+    return best;
+}
+
+/* ------------------------------------------------------------------------ */
+/* dense double helpers (stand in for Armadillo -> LAPACK)                   */
+/* ------------------------------------------------------------------------ */
+/* inverse via LU with partial pivoting (dgetrf + dgetri semantics); returns
+ * ORC_ESINGULAR on an exactly zero pivot (arma::inv then throws). a is n*n
+ * row-major, overwritten by the inverse. */
+static int orc_inv(double* a, int n) {
+    int* piv = (int*)malloc(sizeof(int) * n);
+    double* inv = (double*)calloc((size_t)n * n, sizeof(double));
+    for(int i = 0; i < n; i++) inv[i * n + i] = 1;
+    for(int k = 0; k < n; k++) {
+        int p = k; double m = fabs(a[k * n + k]);
+        for(int i = k + 1; i < n; i++) if(fabs(a[i * n + k]) > m) { m = fabs(a[i * n + k]); p = i; }
+        if(m == 0 || isnan(m)) { free(piv); free(inv); return ORC_ESINGULAR; }
+        piv[k] = p;
+        if(p != k) for(int j = 0; j < n; j++) {
+            double t = a[k * n + j]; a[k * n + j] = a[p * n + j]; a[p * n + j] = t;
+            t = inv[k * n + j]; inv[k * n + j] = inv[p * n + j]; inv[p * n + j] = t;
+        }
+        double d = a[k * n + k];
+        for(int i = k + 1; i < n; i++) {
+            double f = a[i * n + k] / d;
+            if(f == 0) continue;
+            for(int j = k; j < n; j++) a[i * n + j] -= f * a[k * n + j];
+            for(int j = 0; j < n; j++) inv[i * n + j] -= f * inv[k * n + j];
+        }
+    }
+    for(int k = n - 1; k >= 0; k--) {
+        double d = a[k * n + k];
+        for(int j = 0; j < n; j++) inv[k * n + j] /= d;
+        for(int i = 0; i < k; i++) {
+            double f = a[i * n + k];
+            if(f == 0) continue;
+            for(int j = 0; j < n; j++) inv[i * n + j] -= f * inv[k * n + j];
+        }
+    }
+    memcpy(a, inv, sizeof(double) * n * n);
+    free(piv); free(inv);
+    return ORC_OK;
+}
+
+/* symmetric eigen-decomposition by cyclic Jacobi (stand-in for dsyev).
+ * a: n*n symmetric (destroyed), w: eigenvalues, v: eigenvectors in columns. */
+static void orc_eig_sym(double* a, int n, double* w, double* v) {
+    for(int i = 0; i < n; i++) for(int j = 0; j < n; j++) v[i * n + j] = (i == j);
+    for(int sweep = 0; sweep < 100; sweep++) {
+        double off = 0;
+        for(int i = 0; i < n; i++) for(int j = i + 1; j < n; j++) off += a[i * n + j] * a[i * n + j];
+        if(off < 1e-300) break;
+        for(int p = 0; p < n; p++) for(int q = p + 1; q < n; q++) {
+            double apq = a[p * n + q];
+            if(apq == 0) continue;
+            double theta = (a[q * n + q] - a[p * n + p]) / (2 * apq);
+            double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+            double c = 1 / sqrt(t * t + 1), s = t * c;
+            for(int k = 0; k < n; k++) {
+                double akp = a[k * n + p], akq = a[k * n + q];
+                a[k * n + p] = c * akp - s * akq; a[k * n + q] = s * akp + c * akq;
+            }
+            for(int k = 0; k < n; k++) {
+                double apk = a[p * n + k], aqk = a[q * n + k];
+                a[p * n + k] = c * apk - s * aqk; a[q * n + k] = s * apk + c * aqk;
+            }
+            for(int k = 0; k < n; k++) {
+                double vkp = v[k * n + p], vkq = v[k * n + q];
+                v[k * n + p] = c * vkp - s * vkq; v[k * n + q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    for(int i = 0; i < n; i++) w[i] = a[i * n + i];
+}
+
+/* ------------------------------------------------------------------------ */
+/* candidate selection shared by OI and EnSI                                  */
+/* src/api/oi.cpp:229-285 / src/api/oi_ensi.cpp:213-269                       */
+/* ------------------------------------------------------------------------ */
+typedef struct { float rho; int idx; } orc_pair;
+static int orc_pair_cmp(const void* a, const void* b) {
+    const orc_pair* p = (const orc_pair*)a; const orc_pair* q = (const orc_pair*)b;
+    if(p->rho > q->rho) return -1;
+    if(p->rho < q->rho) return 1;
+    return (p->idx > q->idx) - (p->idx < q->idx); /* oracle-defined tie-break */
+}
+/* Returns number selected; sel[] = observation indices, srho[] = rho (float). */
+static int orc_select(float gx, float gy, float gz, float ge, float gl,
+                      int nS, const float* ox, const float* oy, const float* oz,
+                      const float* oe, const float* ol,
+                      const float* pobs, const float* pbg /* may be NULL: EnSI */,
+                      float h, float v, float w, float loc, int max_points,
+                      orc_pair* work, int* sel, float* srho) {
+    int n = 0;
+    for(int s = 0; s < nS; s++) {
+        if(!orc_in_radius(gx, gy, gz, ox[s], oy[s], oz[s], loc, 1)) continue;      /* oi.cpp:233 */
+        float rho = orc_barnes_corr(gx, gy, gz, ge, gl, ox[s], oy[s], oz[s], oe[s], ol[s], h, v, w, loc); /* :250 */
+        if(!orc_valid(pobs[s])) continue;                                            /* :252 */
+        if(pbg && !orc_valid(pbg[s])) continue;
+        if(rho > 0) { work[n].rho = rho; work[n].idx = s; n++; }                     /* :253-255 */
+    }
+    if(max_points > 0 && n > max_points) {                                           /* :262-273 */
+        qsort(work, n, sizeof(orc_pair), orc_pair_cmp);
+        n = max_points;
+    }
+    for(int i = 0; i < n; i++) { sel[i] = work[i].idx; srho[i] = work[i].rho; }
+    return n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* optimal_interpolation_full (Points): src/api/oi.cpp:138-341                */
+/* Arrays are flat; obs x/y/z from orc_convert_coordinates.                   */
+/* out / out_var must be preallocated [nY]; they are initialised to            */
+/* background / bvariance (oi.cpp:198-199).  Range [y0,y1) lets the CPU        */
+/* baseline time a bounded sample.                                             */
+/* ------------------------------------------------------------------------ */
+int orc_oi_full_range(int y0, int y1,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* background, const float* bvariance,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* obs_variance, const float* pbackground, const float* bvariance_at_points,
+                float h, float v, float w, float min_rho,
+                int max_points, int allow_extrapolation,
+                float* out, float* out_var) {
+    if(max_points < 0) return ORC_EINVAL;
+    for(int y = y0; y < y1; y++) { out[y] = background[y]; out_var[y] = bvariance[y]; }
+    if(nS == 0) return ORC_OK;                                                     /* oi.cpp:189-190 */
+    float* pratios = (float*)malloc(sizeof(float) * nS);
+    for(int s = 0; s < nS; s++) pratios[s] = obs_variance[s] / bvariance_at_points[s]; /* :192-195 */
+    float loc = orc_barnes_localization_distance(h, min_rho);                       /* :229 */
+    orc_pair* work = (orc_pair*)malloc(sizeof(orc_pair) * nS);
+    int* sel = (int*)malloc(sizeof(int) * nS);
+    float* srho = (float*)malloc(sizeof(float) * nS);
+    int rc = ORC_OK;
+    for(int y = y0; y < y1; y++) {
+        if(!orc_valid(background[y])) continue;                                     /* :223 */
+        int lS = orc_select(gx[y], gy[y], gz[y], gelev[y], glaf[y], nS, ox, oy, oz, oelev, olaf,
+                            pobs, pbackground, h, v, w, loc, max_points, work, sel, srho);
+        if(lS == 0) continue;                                                       /* :234,284 */
+        double* A = (double*)malloc(sizeof(double) * lS * lS);
+        double* d = (double*)malloc(sizeof(double) * lS);
+        double* G = (double*)malloc(sizeof(double) * lS);
+        for(int i = 0; i < lS; i++) {                                               /* :297-314 */
+            int si = sel[i];
+            d[i] = (double)pobs[si] - (double)pbackground[si];                      /* lObs - lY in double */
+            G[i] = (double)srho[i];
+            for(int j = 0; j < lS; j++) {
+                int sj = sel[j];
+                float c = orc_barnes_corr(ox[si], oy[si], oz[si], oelev[si], olaf[si],
+                                          ox[sj], oy[sj], oz[sj], oelev[sj], olaf[sj], h, v, w, loc);
+                A[i * lS + j] = (double)c;
+            }
+            A[i * lS + i] += (double)pratios[si];                                   /* lP + lR */
+        }
+        if(orc_inv(A, lS) != ORC_OK) { rc = ORC_ESINGULAR; free(A); free(d); free(G); break; } /* :315 */
+        double dx = 0, a00 = 0; float maxInc = 0, minInc = 0;
+        for(int j = 0; j < lS; j++) {
+            double gsr = 0;
+            for(int i = 0; i < lS; i++) gsr += G[i] * A[i * lS + j];                /* lGSR = lG * inv */
+            dx += gsr * d[j];                                                       /* :316 */
+            a00 += gsr * G[j];                                                      /* :336 */
+        }
+        for(int j = 0; j < lS; j++) {                                               /* :319-320 */
+            float dj = (float)d[j];
+            if(j == 0 || dj > maxInc) maxInc = dj;
+            if(j == 0 || dj < minInc) minInc = dj;
+        }
+        float increment = (float)dx;                                                /* :317 */
+        if(!allow_extrapolation) {                                                  /* :318-334 */
+            if(maxInc > 0 && increment > maxInc) increment = maxInc;
+            else if(maxInc < 0 && increment > 0) increment = maxInc;
+            else if(minInc < 0 && increment < minInc) increment = minInc;
+            else if(minInc > 0 && increment < 0) increment = minInc;
+        }
+        out[y] = background[y] + increment;                                         /* :335 */
+        out_var[y] = (float)((double)bvariance[y] * (1 - a00));                     /* :337 */
+        free(A); free(d); free(G);
+    }
+    free(pratios); free(work); free(sel); free(srho);
+    return rc;
+}
+int orc_oi_full(int nY,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* background, const float* bvariance,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* obs_variance, const float* pbackground, const float* bvariance_at_points,
+                float h, float v, float w, float min_rho,
+                int max_points, int allow_extrapolation,
+                float* out, float* out_var) {
+    return orc_oi_full_range(0, nY, gx, gy, gz, gelev, glaf, background, bvariance, nS, ox, oy, oz, oelev, olaf,
+                             pobs, obs_variance, pbackground, bvariance_at_points, h, v, w, min_rho,
+                             max_points, allow_extrapolation, out, out_var);
+}
+/* Diagnostic for parity tests: the selected observation indices of one cell
+ * (in selection order) and the gap between the last kept and first dropped rho
+ * (0 => the top-max_points cut straddles an exact float tie, where the
+ * reference's own result is implementation-defined, oi.cpp:266). */
+int orc_oi_selection(float gx, float gy, float gz, float ge, float gl,
+                     int nS, const float* ox, const float* oy, const float* oz, const float* oe, const float* ol,
+                     const float* pobs, const float* pbg, float h, float v, float w, float min_rho,
+                     int max_points, int* sel, int* tie_at_cut) {
+    float loc = orc_barnes_localization_distance(h, min_rho);
+    orc_pair* work = (orc_pair*)malloc(sizeof(orc_pair) * (nS + 1));
+    float* srho = (float*)malloc(sizeof(float) * (nS + 1));
+    int* all = (int*)malloc(sizeof(int) * (nS + 1));
+    int n = orc_select(gx, gy, gz, ge, gl, nS, ox, oy, oz, oe, ol, pobs, pbg, h, v, w, loc, 0, work, all, srho);
+    *tie_at_cut = 0;
+    if(max_points > 0 && n > max_points) {
+        qsort(work, n, sizeof(orc_pair), orc_pair_cmp);
+        if(work[max_points - 1].rho == work[max_points].rho) *tie_at_cut = 1;
+        n = max_points;
+    }
+    for(int i = 0; i < n; i++) sel[i] = work[i].idx;
+    free(work); free(srho); free(all);
+    return n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* statistics: src/api/util.cpp:19-178                                        */
+/* ------------------------------------------------------------------------ */
+enum { ST_MEAN = 0, ST_MIN = 10, ST_MEDIAN = 20, ST_MAX = 30, ST_QUANTILE = 40, ST_STD = 50,
+       ST_VARIANCE = 60, ST_SUM = 70, ST_COUNT = 80, ST_RANDOMCHOICE = 90 };
+
+static int orc_fcmp(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+/* util.cpp:111-178; returns ORC_EINVAL via *err for q outside [0,1] */
+float orc_calc_quantile(const float* array, int T, float quantile, int* err) {
+    if(err) *err = ORC_OK;
+    if(quantile < 0 || quantile > 1) { if(err) *err = ORC_EINVAL; return NAN; }
+    if(!orc_valid(quantile)) return NAN;
+    if(T == 0) return NAN;
+    if(quantile == 0 || quantile == 1) {
+        float m = NAN;
+        for(int i = 0; i < T; i++) {
+            float val = array[i];
+            if(!orc_valid(val)) continue;
+            else if(!orc_valid(m)) m = val;
+            else if(quantile == 0 ? (val < m) : (val > m)) m = val;
+        }
+        return m;
+    }
+    float* clean = (float*)malloc(sizeof(float) * T);
+    int N = 0;
+    for(int i = 0; i < T; i++) if(orc_valid(array[i])) clean[N++] = array[i];
+    float value = NAN;
+    if(N > 0) {
+        qsort(clean, N, sizeof(float), orc_fcmp);
+        /* quantile * (N-1): float * int -> float, then floor/ceil (util.cpp:160-161) */
+        float pos = quantile * (N - 1);
+        int lowerIndex = (int)floorf(pos);
+        int upperIndex = (int)ceilf(pos);
+        float lowerQuantile = (float)lowerIndex / (N - 1);
+        float upperQuantile = (float)upperIndex / (N - 1);
+        float lowerValue = clean[lowerIndex], upperValue = clean[upperIndex];
+        if(lowerIndex == upperIndex) value = lowerValue;
+        else {
+            float f = (quantile - lowerQuantile) / (upperQuantile - lowerQuantile);
+            value = lowerValue + (upperValue - lowerValue) * f;
+        }
+    }
+    free(clean);
+    return value;
+}
+/* util.cpp:19-110 (RandomChoice omitted: depends on rand()) */
+float orc_calc_statistic(const float* array, int n, int statistic) {
+    float value = NAN;
+    if(statistic == ST_MEAN || statistic == ST_SUM || statistic == ST_COUNT) {
+        float total = 0; int count = 0;
+        for(int i = 0; i < n; i++) if(orc_valid(array[i])) { total += array[i]; count++; }
+        if(statistic == ST_COUNT) value = count;
+        else if(count > 0) value = (statistic == ST_MEAN) ? total / count : total;
+    }
+    else if(statistic == ST_STD || statistic == ST_VARIANCE) {
+        float total = 0, total2 = 0, K = NAN; int count = 0;
+        for(int i = 0; i < n; i++) if(orc_valid(array[i])) {
+            if(!orc_valid(K)) K = array[i];
+            total += array[i] - K;
+            total2 += (array[i] - K) * (array[i] - K);
+            count++;
+        }
+        if(count > 0) {
+            float mean = total / count, mean2 = total2 / count;
+            float var = mean2 - mean * mean;
+            if(var < 0) var = 0;
+            value = (statistic == ST_STD) ? sqrtf(var) : var;
+        }
+    }
+    else {
+        float q = (statistic == ST_MIN) ? 0 : (statistic == ST_MEDIAN) ? 0.5f : (statistic == ST_MAX) ? 1 : NAN;
+        if(isnan(q)) return NAN;
+        value = orc_calc_quantile(array, n, q, NULL);
+    }
+    return value;
+}
+
+/* util.cpp:339-414 */
+static int orc_lower_index(float x, const float* v, int n) {
+    int index = -1;
+    for(int i = 0; i < n; i++) {
+        float c = v[i];
+        if(orc_valid(c)) {
+            if(c < x) index = i;
+            else if(c == x) { index = i; break; }
+            else if(c > x) break;
+        }
+    }
+    return index;
+}
+static int orc_upper_index(float x, const float* v, int n) {
+    int index = -1;
+    for(int i = n - 1; i >= 0; i--) {
+        float c = v[i];
+        if(orc_valid(c)) {
+            if(c > x) index = i;
+            else if(c == x) { index = i; break; }
+            else if(c < x) break;
+        }
+    }
+    return index;
+}
+float orc_interpolate(float x, const float* iX, const float* iY, int n) {
+    if(!orc_valid(x)) return NAN;
+    if(n == 0) return NAN;
+    if(x > iX[n - 1]) return iY[n - 1];
+    if(x < iX[0]) return iY[0];
+    int i0 = orc_lower_index(x, iX, n), i1 = orc_upper_index(x, iX, n);
+    float x0 = iX[i0], x1 = iX[i1], y0 = iY[i0], y1 = iY[i1];
+    if(x0 == x1) {
+        if(i0 == 0 && i1 == n - 1) return (y0 + y1) / 2;
+        else if(i0 == 0) return y1;
+        else if(i1 == n - 1) return y0;
+        else return (y0 + y1) / 2;
+    }
+    return y0 + (y1 - y0) * (x - x0) / (x1 - x0);
+}
+
+/* util.cpp:261-338; values need not be sorted; returns count written to out (<= num) */
+int orc_calc_even_quantiles(const float* values, int size, int num, float* out) {
+    int nq = 0;
+    if(num == 0 || size == 0) return 0;
+    float* sorted = (float*)malloc(sizeof(float) * size);
+    memcpy(sorted, values, sizeof(float) * size);
+    qsort(sorted, size, sizeof(float), orc_fcmp);
+    if(num >= size) {
+        out[nq++] = sorted[0];
+        for(int i = 1; i < size; i++) if(sorted[i] != sorted[i - 1]) out[nq++] = sorted[i];
+        free(sorted); return nq;
+    }
+    float lowest = sorted[0], highest = sorted[size - 1];
+    int count_lower = 0;
+    for(int i = 0; i < size; i++) { if(sorted[i] != lowest) break; count_lower++; }
+    out[nq++] = lowest;
+    if(num == 2) { if(lowest != highest) out[nq++] = highest; free(sorted); return nq; }
+    int repeated = count_lower < size && count_lower > size / num;
+    if(repeated) out[nq++] = sorted[count_lower];
+    float last_added = out[nq - 1];
+    float* uniq = (float*)malloc(sizeof(float) * size);
+    int nu = 0;
+    for(int i = 0; i < size; i++)
+        if(sorted[i] > last_added && (nu == 0 || sorted[i] != uniq[nu - 1])) uniq[nu++] = sorted[i];
+    if(nu > 0) {
+        int num_left = num - nq;
+        for(int i = 1; i <= num_left; i++) {
+            float f = (float)i / num_left;
+            int index = (int)(nu * f - 1);   /* size_t * float -> float, -1, truncation (util.cpp:322) */
+            if(index >= 0) out[nq++] = uniq[index];
+        }
+    }
+    free(sorted); free(uniq);
+    return nq;
+}
+/* neighbourhood.cpp:243-295: valid values of a 2-D/3-D field (flattened) */
+int orc_get_neighbourhood_thresholds(const float* input, long n, int num_thresholds, float* out) {
+    if(num_thresholds <= 0) return ORC_EINVAL;
+    float* all = (float*)malloc(sizeof(float) * (n > 0 ? n : 1));
+    int c = 0;
+    for(long i = 0; i < n; i++) if(orc_valid(input[i])) all[c++] = input[i];
+    int r = orc_calc_even_quantiles(all, c, num_thresholds, out);
+    free(all);
+    return r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* neighbourhood (2-D): src/api/neighbourhood.cpp:28-242                      */
+/* ------------------------------------------------------------------------ */
+static int orc_nbh_brute(const float* in, int nY, int nX, int nE, int hw, int statistic, float quantile, float* out);
+
+int orc_neighbourhood(const float* in, int nY, int nX, int hw, int statistic, float* out) {
+    if(hw < 0) return ORC_EINVAL;
+    if(statistic == ST_QUANTILE) return ORC_EINVAL;
+    if(nY == 0 || nX == 0) return ORC_OK;
+    for(long i = 0; i < (long)nY * nX; i++) out[i] = NAN;
+    if(statistic == ST_MEAN || statistic == ST_SUM || statistic == ST_COUNT) {
+        /* summed-area table, double values + int counts (:45-99) */
+        double* values = (double*)calloc((size_t)nY * nX, sizeof(double));
+        int* counts = (int*)calloc((size_t)nY * nX, sizeof(int));
+#define V(i,j) values[(size_t)(i) * nX + (j)]
+#define Cn(i,j) counts[(size_t)(i) * nX + (j)]
+        for(int i = 0; i < nY; i++) for(int j = 0; j < nX; j++) {
+            float value = in[(size_t)i * nX + j];
+            int ok = orc_valid(value);
+            if(j == 0 && i == 0) { if(ok) { V(i,j) = value; Cn(i,j) = 1; } }
+            else if(j == 0) { V(i,j) = ok ? V(i-1,j) + value : V(i-1,j); Cn(i,j) = Cn(i-1,j) + ok; }
+            else if(i == 0) { V(i,j) = ok ? V(i,j-1) + value : V(i,j-1); Cn(i,j) = Cn(i,j-1) + ok; }
+            else {
+                V(i,j) = ok ? V(i,j-1) + V(i-1,j) - V(i-1,j-1) + value : V(i,j-1) + V(i-1,j) - V(i-1,j-1);
+                Cn(i,j) = Cn(i,j-1) + Cn(i-1,j) - Cn(i-1,j-1) + ok;
+            }
+        }
+        for(int i = 0; i < nY; i++) for(int j = 0; j < nX; j++) {        /* :101-144 */
+            int i1 = i + hw < nY - 1 ? i + hw : nY - 1;
+            int j1 = j + hw < nX - 1 ? j + hw : nX - 1;
+            int i0 = i - hw - 1, j0 = j - hw - 1;
+            double v11 = V(i1,j1), v00 = 0, v10 = 0, v01 = 0;
+            int c11 = Cn(i1,j1), c00 = 0, c10 = 0, c01 = 0;
+            if(i0 >= 0 && j0 >= 0) { v00 = V(i0,j0); v10 = V(i1,j0); v01 = V(i0,j1); c00 = Cn(i0,j0); c10 = Cn(i1,j0); c01 = Cn(i0,j1); }
+            else if(j0 >= 0) { v10 = V(i1,j0); c10 = Cn(i1,j0); }
+            else if(i0 >= 0) { v01 = V(i0,j1); c01 = Cn(i0,j1); }
+            double value = v11 + v00 - v10 - v01;
+            int count = c11 + c00 - c10 - c01;
+            float* o = &out[(size_t)i * nX + j];
+            if(statistic == ST_COUNT) *o = count;
+            else if(count > 0) { if(statistic == ST_MEAN) value /= count; *o = (float)value; }
+        }
+#undef V
+#undef Cn
+        free(values); free(counts);
+    }
+    else if(statistic == ST_MIN || statistic == ST_MAX) {
+        /* :146-210 -- the edge rows use the full window, interior rows the
+         * column-sliver then row pass; both equal the window min/max of the
+         * valid values, which is what is computed here directly. */
+        for(int i = 0; i < nY; i++) for(int j = 0; j < nX; j++) {
+            float m = NAN;
+            int ia = i - hw > 0 ? i - hw : 0, ib = i + hw < nY - 1 ? i + hw : nY - 1;
+            int ja = j - hw > 0 ? j - hw : 0, jb = j + hw < nX - 1 ? j + hw : nX - 1;
+            for(int ii = ia; ii <= ib; ii++) for(int jj = ja; jj <= jb; jj++) {
+                float val = in[(size_t)ii * nX + jj];
+                if(!orc_valid(val)) continue;
+                if(!orc_valid(m)) m = val;
+                else if(statistic == ST_MIN ? val < m : val > m) m = val;
+            }
+            out[(size_t)i * nX + j] = m;
+        }
+    }
+    else if(statistic == ST_STD || statistic == ST_VARIANCE) {           /* :211-235 */
+        float* mean = (float*)malloc(sizeof(float) * nY * nX);
+        float* mean2 = (float*)malloc(sizeof(float) * nY * nX);
+        float* in2 = (float*)malloc(sizeof(float) * nY * nX);
+        for(long i = 0; i < (long)nY * nX; i++) in2[i] = in[i] * in[i];
+        orc_neighbourhood(in, nY, nX, hw, ST_MEAN, mean);
+        orc_neighbourhood(in2, nY, nX, hw, ST_MEAN, mean2);
+        for(long i = 0; i < (long)nY * nX; i++) {
+            float var = mean2[i] - mean[i] * mean[i];
+            out[i] = (statistic == ST_STD) ? sqrtf(var) : var;
+        }
+        free(mean); free(mean2); free(in2);
+    }
+    else return orc_nbh_brute(in, nY, nX, 1, hw, statistic, 0, out);     /* :236-238 */
+    return ORC_OK;
+}
+/* neighbourhood.cpp:12-27: member statistic first, then the 2-D filter */
+int orc_neighbourhood3(const float* in, int nY, int nX, int nE, int hw, int statistic, float* out) {
+    if(nY == 0 || nX == 0) return ORC_OK;
+    float* flat = (float*)malloc(sizeof(float) * nY * nX);
+    for(long c = 0; c < (long)nY * nX; c++) flat[c] = orc_calc_statistic(in + c * nE, nE, statistic);
+    int rc = orc_neighbourhood(flat, nY, nX, hw, statistic, out);
+    free(flat);
+    return rc;
+}
+/* neighbourhood.cpp:557-654 (brute force, statistic or exact quantile); nE=1 for 2-D */
+static int orc_nbh_brute(const float* in, int nY, int nX, int nE, int hw, int statistic, float quantile, float* out) {
+    if(hw < 0) return ORC_EINVAL;
+    if(nY == 0 || nX == 0 || nE == 0) return ORC_OK;
+    size_t cap = (size_t)(2 * hw + 1) * (2 * hw + 1) * nE;
+    if(cap > (size_t)nY * nX * nE) cap = (size_t)nY * nX * nE;
+    float* hood = (float*)malloc(sizeof(float) * cap);
+    int rc = ORC_OK;
+    for(int i = 0; i < nY && rc == ORC_OK; i++) for(int j = 0; j < nX; j++) {
+        int ia = i - hw > 0 ? i - hw : 0, ib = i + hw < nY - 1 ? i + hw : nY - 1;
+        int ja = j - hw > 0 ? j - hw : 0, jb = j + hw < nX - 1 ? j + hw : nX - 1;
+        int n = 0;
+        for(int ii = ia; ii <= ib; ii++) for(int jj = ja; jj <= jb; jj++) for(int e = 0; e < nE; e++)
+            hood[n++] = in[((size_t)ii * nX + jj) * nE + e];
+        if(statistic == ST_QUANTILE) {
+            int err; out[(size_t)i * nX + j] = orc_calc_quantile(hood, n, quantile, &err);
+            if(err != ORC_OK) { rc = err; break; }
+        }
+        else out[(size_t)i * nX + j] = orc_calc_statistic(hood, n, statistic);
+    }
+    free(hood);
+    return rc;
+}
+int orc_neighbourhood_brute_force(const float* in, int nY, int nX, int nE, int hw, int statistic, float* out) {
+    return orc_nbh_brute(in, nY, nX, nE, hw, statistic, 0, out);
+}
+int orc_neighbourhood_quantile(const float* in, int nY, int nX, int nE, float quantile, int hw, float* out) {
+    return orc_nbh_brute(in, nY, nX, nE, hw, ST_QUANTILE, quantile, out);
+}
+
+/* neighbourhood.cpp:296-409 (2-D, nE==1 with is3d=0) and :411-527 (3-D).
+ * quantile: nq==1 scalar, else nY*nX field. */
+int orc_neighbourhood_quantile_fast(const float* in, int nY, int nX, int nE, int is3d,
+                                    const float* quantile, int nq, int hw,
+                                    const float* thresholds, int nT, float* out) {
+    if(hw < 0) return ORC_EINVAL;
+    if(nY == 0 || nX == 0 || nE == 0) return ORC_OK;
+    if(!(nq == 1) && !(nq == nY * nX)) return ORC_EINVAL;
+    for(int i = 0; i < nq; i++) if(orc_valid(quantile[i]) && (quantile[i] < 0 || quantile[i] > 1)) return ORC_EINVAL;
+    size_t C = (size_t)nY * nX;
+    for(size_t c = 0; c < C; c++) out[c] = NAN;
+    if(nT == 0) return ORC_OK;
+    float* stats = (float*)malloc(sizeof(float) * C * nT);
+    float* temp = (float*)malloc(sizeof(float) * C);
+    for(int t = 0; t < nT; t++) {
+        for(size_t c = 0; c < C; c++) {
+            int sum = 0, count = 0;
+            for(int e = 0; e < nE; e++) {
+                float val = in[c * nE + e];
+                if(orc_valid(val)) { if(val <= thresholds[t]) sum++; count++; }
+            }
+            temp[c] = count > 0 ? (float)sum / count : NAN;
+        }
+        orc_neighbourhood(temp, nY, nX, hw, ST_MEAN, stats + (size_t)t * C);
+    }
+    float* yarray = (float*)malloc(sizeof(float) * nT);
+    for(size_t c = 0; c < C; c++) {
+        float q = (nq == 1) ? quantile[0] : quantile[c];
+        int missing = 0;
+        for(int t = 0; t < nT; t++) {
+            float s = stats[(size_t)t * C + c];
+            float sum = 0; int count = 0;
+            if(is3d) { for(int e = 0; e < nE; e++) if(orc_valid(s)) { sum += s; count++; } } /* :494-499 */
+            else if(orc_valid(s)) { sum = s; count = 1; }                                   /* :378-381 */
+            if(count > 0) {
+                float yv = sum / count;
+                if(yv > 1) yv = 1; else if(yv < 0) yv = 0;
+                yarray[t] = yv;
+            }
+            else { yarray[t] = NAN; missing = 1; }
+        }
+        if(!missing) {
+            if(q == 1 && yarray[0] == 1) out[c] = thresholds[0];
+            else if(q == 0 && yarray[nT - 1] == 0) out[c] = thresholds[nT - 1];
+            else out[c] = orc_interpolate(q, yarray, thresholds, nT);
+        }
+    }
+    free(stats); free(temp); free(yarray);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* nearest(Grid, Points, vec2): src/api/nearest.cpp:124-144                  */
+/* ------------------------------------------------------------------------ */
+int orc_nearest(const float* gx, const float* gy, const float* gz, int nG, const float* values,
+                const float* qx, const float* qy, const float* qz, int nQ, float* out, int* out_idx) {
+    for(int i = 0; i < nQ; i++) {
+        if(nG == 0) { out[i] = NAN; if(out_idx) out_idx[i] = -1; continue; }
+        int idx = orc_nearest_neighbour(gx, gy, gz, nG, qx[i], qy[i], qz[i], 1);
+        out[i] = values[idx];
+        if(out_idx) out_idx[i] = idx;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* optimal_interpolation_ensi (Points): src/api/oi_ensi.cpp:114-568           */
+/* background [nY][nE], pbackground [nS][nE], out [nY][nE]                    */
+/* ------------------------------------------------------------------------ */
+int orc_oi_ensi_range(int y0, int y1, int nY, int nE,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* background,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* psigmas, const float* pbackground,
+                float h, float v, float w, float min_rho,
+                int max_points, int allow_extrapolation, float* out) {
+    if(max_points < 0) return ORC_EINVAL;
+    for(size_t i = (size_t)y0 * nE; i < (size_t)y1 * nE; i++) out[i] = background[i];
+    if(nS == 0) return ORC_OK;
+    /* gY / gYhat: :166-178 */
+    float* gYp = (float*)malloc(sizeof(float) * nS * nE);
+    float* gYhat = (float*)malloc(sizeof(float) * nS);
+    for(int i = 0; i < nS; i++) {
+        float mean = orc_calc_statistic(pbackground + (size_t)i * nE, nE, ST_MEAN);
+        for(int e = 0; e < nE; e++) {
+            float value = pbackground[(size_t)i * nE + e];
+            gYp[(size_t)i * nE + e] = (orc_valid(value) && orc_valid(mean)) ? value - mean : value;
+        }
+        gYhat[i] = mean;
+    }
+    /* validEns: :187-201 -- members valid over the WHOLE field */
+    int* validEns = (int*)malloc(sizeof(int) * nE);
+    int nV = 0;
+    for(int e = 0; e < nE; e++) {
+        int bad = 0;
+        for(int y = 0; y < nY && !bad; y++) if(!orc_valid(background[(size_t)y * nE + e])) bad = 1;
+        if(!bad) validEns[nV++] = e;
+    }
+    float loc = orc_barnes_localization_distance(h, min_rho);
+    orc_pair* work = (orc_pair*)malloc(sizeof(orc_pair) * nS);
+    int* sel = (int*)malloc(sizeof(int) * nS);
+    float* srho = (float*)malloc(sizeof(float) * nS);
+    double* Pinv = (double*)malloc(sizeof(double) * nV * nV);
+    double* P = (double*)malloc(sizeof(double) * nV * nV);
+    double* Aw = (double*)malloc(sizeof(double) * nV * nV);
+    double* eval = (double*)malloc(sizeof(double) * nV);
+    double* evec = (double*)malloc(sizeof(double) * nV * nV);
+    double* W = (double*)malloc(sizeof(double) * nV * nV);
+    double* wv = (double*)malloc(sizeof(double) * nV);
+    double* X = (double*)malloc(sizeof(double) * nV);
+    for(int y = y0; y < y1; y++) {
+        int lS = orc_select(gx[y], gy[y], gz[y], gelev[y], glaf[y], nS, ox, oy, oz, oelev, olaf,
+                            pobs, NULL, h, v, w, loc, max_points, work, sel, srho);   /* :213-269 */
+        if(lS == 0) continue;
+        if(nV == 0) continue;
+        double* lY = (double*)malloc(sizeof(double) * lS * nV);     /* lS x nV, arma column-major: lY[e*lS+i] */
+        double* C = (double*)malloc(sizeof(double) * nV * lS);
+        double* Rinv = (double*)malloc(sizeof(double) * lS);
+        double* dvec = (double*)malloc(sizeof(double) * lS);
+        for(int i = 0; i < lS; i++) {                                /* :282-302 */
+            int idx = sel[i];
+            for(int e = 0; e < nV; e++) lY[(size_t)e * lS + i] = (double)gYp[(size_t)idx * nE + validEns[e]];
+            float s2 = psigmas[idx] * psigmas[idx];                 /* float product (:300) */
+            Rinv[i] = (double)srho[i] / (double)s2;
+            dvec[i] = (double)pobs[idx] - (double)gYhat[idx];
+        }
+        for(int e = 0; e < nV; e++) for(int i = 0; i < lS; i++) C[(size_t)e * lS + i] = lY[(size_t)e * lS + i] * Rinv[i]; /* :380 */
+        float diag = 1 / 1.0f * (nV - 1);                            /* :383, delta = 1 */
+        for(int a = 0; a < nV; a++) for(int b = 0; b < nV; b++) {    /* :385 */
+            double s = 0;
+            for(int i = 0; i < lS; i++) s += C[(size_t)a * lS + i] * lY[(size_t)b * lS + i];
+            Pinv[a * nV + b] = s + (a == b ? (double)diag : 0.0);
+        }
+        /* rcond <= 0 -> passthrough (:386-390): only for singular / NaN matrices */
+        memcpy(P, Pinv, sizeof(double) * nV * nV);
+        if(orc_inv(P, nV) != ORC_OK) { free(lY); free(C); free(Rinv); free(dvec); continue; } /* :398 */
+        for(int i = 0; i < nV * nV; i++) Aw[i] = (nV - 1) * P[i];    /* :401 */
+        orc_eig_sym(Aw, nV, eval, evec);
+        for(int a = 0; a < nV; a++) for(int b = 0; b < nV; b++) {    /* :419-421 W = V sqrt(L) V' */
+            double s = 0;
+            for(int k = 0; k < nV; k++) s += evec[a * nV + k] * sqrt(eval[k]) * evec[b * nV + k];
+            W[a * nV + b] = s;
+        }
+        for(int a = 0; a < nV; a++) {                                /* :427-437 w = P C (lObs - lYhat) */
+            double s = 0;
+            for(int i = 0; i < lS; i++) {
+                double pc = 0;
+                for(int b = 0; b < nV; b++) pc += P[a * nV + b] * C[(size_t)b * lS + i];
+                s += pc * dvec[i];
+            }
+            wv[a] = s;
+        }
+        for(int a = 0; a < nV; a++) for(int b = 0; b < nV; b++) W[a * nV + b] += wv[a];   /* :440-444 */
+        float total = 0; int count = 0;                              /* :447-462 */
+        for(int e = 0; e < nV; e++) {
+            float value = background[(size_t)y * nE + validEns[e]];
+            if(orc_valid(value)) { X[e] = value; total += value; count++; }
+        }
+        float ensMean = total / count;
+        for(int e = 0; e < nV; e++) X[e] -= ensMean;                 /* double - float */
+        for(int e = 0; e < nV; e++) {                                /* :505-553 */
+            float tot = 0;
+            for(int k = 0; k < nV; k++) tot += X[k] * W[k * nV + e]; /* float += double product */
+            float currIncrement = tot;
+            if(!allow_extrapolation) {
+                /* :523-524 uses lY[e] (LINEAR index into the lS x nV column-major matrix) */
+                double lYe = lY[e];
+                float maxInc = 0, minInc = 0;
+                for(int i = 0; i < lS; i++) {
+                    float dv = (float)((double)pobs[sel[i]] - (lYe + (double)gYhat[sel[i]]));
+                    if(i == 0 || dv > maxInc) maxInc = dv;
+                    if(i == 0 || dv < minInc) minInc = dv;
+                }
+                float memberIncrement = currIncrement - X[e];
+                if(maxInc > 0 && memberIncrement > maxInc) currIncrement = maxInc + X[e];
+                else if(maxInc < 0 && memberIncrement > 0) currIncrement = 0 + X[e];
+                else if(minInc < 0 && memberIncrement < minInc) currIncrement = minInc + X[e];
+                else if(minInc > 0 && memberIncrement < 0) currIncrement = 0 + X[e];
+            }
+            out[(size_t)y * nE + validEns[e]] = ensMean + currIncrement;
+        }
+        free(lY); free(C); free(Rinv); free(dvec);
+    }
+    free(gYp); free(gYhat); free(validEns); free(work); free(sel); free(srho);
+    free(Pinv); free(P); free(Aw); free(eval); free(evec); free(W); free(wv); free(X);
+    return ORC_OK;
+}
+int orc_oi_ensi(int nY, int nE,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* background,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* psigmas, const float* pbackground,
+                float h, float v, float w, float min_rho,
+                int max_points, int allow_extrapolation, float* out) {
+    return orc_oi_ensi_range(0, nY, nY, nE, gx, gy, gz, gelev, glaf, background, nS, ox, oy, oz, oelev, olaf,
+                             pobs, psigmas, pbackground, h, v, w, min_rho, max_points, allow_extrapolation, out);
+}

@@ -1,0 +1,270 @@
+"""ctypes front-end of the CPU oracle (oracle/gridpp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under gridpp_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+Geodetic, Cartesian = 0, 1
+Mean, Min, Median, Max, Quantile, Std, Variance, Sum, Count, RandomChoice = 0, 10, 20, 30, 40, 50, 60, 70, 80, 90
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class OracleError(ValueError):
+    pass
+
+
+class OracleSingular(RuntimeError):
+    pass
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "gridpp_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_barnes_rho.restype = C.c_float
+        L.orc_barnes_rho.argtypes = [C.c_float, C.c_float]
+        L.orc_barnes_min_rho.restype = C.c_float
+        L.orc_barnes_min_rho.argtypes = [C.c_float, C.c_float]
+        L.orc_barnes_localization_distance.restype = C.c_float
+        L.orc_barnes_localization_distance.argtypes = [C.c_float, C.c_float]
+        L.orc_barnes_corr.restype = C.c_float
+        L.orc_barnes_corr.argtypes = [C.c_float] * 14
+        L.orc_calc_straight_distance.restype = C.c_float
+        L.orc_calc_straight_distance.argtypes = [C.c_float] * 6
+        L.orc_calc_distance.restype = C.c_float
+        L.orc_calc_distance.argtypes = [C.c_float] * 4 + [C.c_int]
+        L.orc_calc_quantile.restype = C.c_float
+        L.orc_calc_statistic.restype = C.c_float
+        L.orc_interpolate.restype = C.c_float
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _check(rc):
+    if rc == -1:
+        raise OracleError("invalid argument")
+    if rc == -2:
+        raise OracleSingular("singular matrix")
+    if rc != 0:
+        raise RuntimeError("oracle error %d" % rc)
+
+
+def convert_coordinates(lats, lons, ctype=Geodetic):
+    lats, lons = _f(lats).ravel(), _f(lons).ravel()
+    n = lats.size
+    x, y, z = (np.empty(n, np.float32) for _ in range(3))
+    rc = lib().orc_convert_coordinates(lats.ctypes, lons.ctypes, n, ctype, x.ctypes, y.ctypes, z.ctypes)
+    _check(rc)
+    return x, y, z
+
+
+class Pts:
+    """Flat point set: lat/lon -> x,y,z (float32) + elev/laf (NaN if missing)."""
+
+    def __init__(self, lats, lons, elevs=None, lafs=None, ctype=Geodetic):
+        self.lats, self.lons = _f(lats).ravel(), _f(lons).ravel()
+        n = self.lats.size
+        self.n = n
+        self.ctype = ctype
+        self.x, self.y, self.z = convert_coordinates(self.lats, self.lons, ctype)
+        self.elevs = _f(elevs).ravel() if elevs is not None and np.size(elevs) == n else np.full(n, np.nan, np.float32)
+        self.lafs = _f(lafs).ravel() if lafs is not None and np.size(lafs) == n else np.full(n, np.nan, np.float32)
+
+
+class Barnes:
+    def __init__(self, h, v=0.0, w=0.0, hmax=float("nan")):
+        self.h, self.v, self.w = float(h), float(v), float(w)
+        self.min_rho = float(lib().orc_barnes_min_rho(h, hmax))
+
+    def localization_distance(self):
+        return float(lib().orc_barnes_localization_distance(self.h, self.min_rho))
+
+    def corr(self, p1, p2):
+        """p = (x, y, z, elev, laf)"""
+        return float(lib().orc_barnes_corr(*[float(t) for t in p1], *[float(t) for t in p2],
+                                           self.h, self.v, self.w, self.localization_distance()))
+
+
+def oi_full(g, background, bvariance, p, obs, obs_variance, pbackground, bvariance_at_points,
+            st, max_points, allow_extrapolation=True, y0=0, y1=None):
+    background, bvariance = _f(background).ravel(), _f(bvariance).ravel()
+    obs, obs_variance, pbackground, bvp = _f(obs), _f(obs_variance), _f(pbackground), _f(bvariance_at_points)
+    out = np.empty(g.n, np.float32)
+    var = np.empty(g.n, np.float32)
+    if y1 is None:
+        y1 = g.n
+    L = lib()
+    rc = L.orc_oi_full_range(C.c_int(y0), C.c_int(y1), g.x.ctypes, g.y.ctypes, g.z.ctypes, g.elevs.ctypes, g.lafs.ctypes,
+                             background.ctypes, bvariance.ctypes, C.c_int(p.n), p.x.ctypes, p.y.ctypes, p.z.ctypes,
+                             p.elevs.ctypes, p.lafs.ctypes, obs.ctypes, obs_variance.ctypes, pbackground.ctypes,
+                             bvp.ctypes, C.c_float(st.h), C.c_float(st.v), C.c_float(st.w), C.c_float(st.min_rho),
+                             C.c_int(max_points), C.c_int(1 if allow_extrapolation else 0), out.ctypes, var.ctypes)
+    _check(rc)
+    return out[y0:y1], var[y0:y1]
+
+
+def oi(g, background, p, obs, ratios, pbackground, st, max_points, allow_extrapolation=True, y0=0, y1=None):
+    """optimal_interpolation(Points...) = _full with unit variances (src/api/oi.cpp:123-135)."""
+    ones_g = np.ones(g.n, np.float32)
+    ones_p = np.ones(p.n, np.float32)
+    return oi_full(g, background, ones_g, p, obs, ratios, pbackground, ones_p, st, max_points,
+                   allow_extrapolation, y0, y1)[0]
+
+
+def oi_selection(g, cell, p, obs, pbackground, st, max_points):
+    sel = np.empty(max(p.n, 1), np.int32)
+    tie = C.c_int(0)
+    obs, pbackground = _f(obs), _f(pbackground)
+    n = lib().orc_oi_selection(C.c_float(g.x[cell]), C.c_float(g.y[cell]), C.c_float(g.z[cell]),
+                               C.c_float(g.elevs[cell]), C.c_float(g.lafs[cell]), C.c_int(p.n),
+                               p.x.ctypes, p.y.ctypes, p.z.ctypes, p.elevs.ctypes, p.lafs.ctypes,
+                               obs.ctypes, pbackground.ctypes, C.c_float(st.h), C.c_float(st.v), C.c_float(st.w),
+                               C.c_float(st.min_rho), C.c_int(max_points), sel.ctypes, C.byref(tie))
+    return sel[:n].copy(), bool(tie.value)
+
+
+def oi_ensi(g, background, p, obs, sigmas, pbackground, st, max_points, allow_extrapolation=True, y0=0, y1=None):
+    background = _f(background)
+    nY, nE = background.shape
+    pbackground = _f(pbackground).reshape(p.n, nE)
+    obs, sigmas = _f(obs), _f(sigmas)
+    out = np.empty((nY, nE), np.float32)
+    if y1 is None:
+        y1 = nY
+    rc = lib().orc_oi_ensi_range(C.c_int(y0), C.c_int(y1), C.c_int(nY), C.c_int(nE), g.x.ctypes, g.y.ctypes, g.z.ctypes,
+                                 g.elevs.ctypes, g.lafs.ctypes, background.ctypes, C.c_int(p.n), p.x.ctypes, p.y.ctypes,
+                                 p.z.ctypes, p.elevs.ctypes, p.lafs.ctypes, obs.ctypes, sigmas.ctypes, pbackground.ctypes,
+                                 C.c_float(st.h), C.c_float(st.v), C.c_float(st.w), C.c_float(st.min_rho),
+                                 C.c_int(max_points), C.c_int(1 if allow_extrapolation else 0), out.ctypes)
+    _check(rc)
+    return out[y0:y1]
+
+
+def get_neighbours(p, qlat, qlon, radius, include_match=True):
+    qx, qy, qz = convert_coordinates([qlat], [qlon], p.ctype)
+    out = np.empty(max(p.n, 1), np.int32)
+    n = lib().orc_get_neighbours(p.x.ctypes, p.y.ctypes, p.z.ctypes, C.c_int(p.n), C.c_float(qx[0]), C.c_float(qy[0]),
+                                 C.c_float(qz[0]), C.c_float(radius), C.c_int(int(include_match)), out.ctypes)
+    return out[:n].copy()
+
+
+def nearest_neighbour(p, qlat, qlon, include_match=True):
+    qx, qy, qz = convert_coordinates([qlat], [qlon], p.ctype)
+    return int(lib().orc_nearest_neighbour(p.x.ctypes, p.y.ctypes, p.z.ctypes, C.c_int(p.n), C.c_float(qx[0]),
+                                           C.c_float(qy[0]), C.c_float(qz[0]), C.c_int(int(include_match))))
+
+
+def nearest_indices(g, q):
+    out = np.empty(q.n, np.float32)
+    idx = np.empty(q.n, np.int32)
+    vals = np.zeros(max(g.n, 1), np.float32)
+    lib().orc_nearest(g.x.ctypes, g.y.ctypes, g.z.ctypes, C.c_int(g.n), vals.ctypes, q.x.ctypes, q.y.ctypes, q.z.ctypes,
+                      C.c_int(q.n), out.ctypes, idx.ctypes)
+    return idx
+
+
+def nearest(g, q, values):
+    values = _f(values).ravel()
+    out = np.empty(q.n, np.float32)
+    lib().orc_nearest(g.x.ctypes, g.y.ctypes, g.z.ctypes, C.c_int(g.n), values.ctypes, q.x.ctypes, q.y.ctypes, q.z.ctypes,
+                      C.c_int(q.n), out.ctypes, None)
+    return out
+
+
+def calc_statistic(a, stat):
+    a = _f(a).ravel()
+    return float(lib().orc_calc_statistic(a.ctypes, C.c_int(a.size), C.c_int(stat)))
+
+
+def calc_quantile(a, q):
+    a = _f(a).ravel()
+    err = C.c_int(0)
+    r = float(lib().orc_calc_quantile(a.ctypes, C.c_int(a.size), C.c_float(q), C.byref(err)))
+    _check(err.value)
+    return r
+
+
+def interpolate(x, ix, iy):
+    ix, iy = _f(ix), _f(iy)
+    return float(lib().orc_interpolate(C.c_float(x), ix.ctypes, iy.ctypes, C.c_int(ix.size)))
+
+
+def calc_even_quantiles(values, num):
+    values = _f(values).ravel()
+    out = np.empty(max(num, values.size, 1), np.float32)
+    n = lib().orc_calc_even_quantiles(values.ctypes, C.c_int(values.size), C.c_int(num), out.ctypes)
+    return out[:n].copy()
+
+
+def get_neighbourhood_thresholds(field, num):
+    field = _f(field).ravel()
+    out = np.empty(max(num, 1), np.float32)
+    n = lib().orc_get_neighbourhood_thresholds(field.ctypes, C.c_long(field.size), C.c_int(num), out.ctypes)
+    if n < 0:
+        _check(n)
+    return out[:n].copy()
+
+
+def _yx(field):
+    field = _f(field)
+    if field.ndim == 2:
+        return field, field.shape[0], field.shape[1], 1, 0
+    return field, field.shape[0], field.shape[1], field.shape[2], 1
+
+
+def neighbourhood(field, hw, stat):
+    field, Y, X, E, is3d = _yx(field)
+    out = np.empty((Y, X), np.float32)
+    if is3d:
+        rc = lib().orc_neighbourhood3(field.ctypes, C.c_int(Y), C.c_int(X), C.c_int(E), C.c_int(hw), C.c_int(stat), out.ctypes)
+    else:
+        rc = lib().orc_neighbourhood(field.ctypes, C.c_int(Y), C.c_int(X), C.c_int(hw), C.c_int(stat), out.ctypes)
+    _check(rc)
+    return out
+
+
+def neighbourhood_brute_force(field, hw, stat):
+    field, Y, X, E, is3d = _yx(field)
+    out = np.empty((Y, X), np.float32)
+    _check(lib().orc_neighbourhood_brute_force(field.ctypes, C.c_int(Y), C.c_int(X), C.c_int(E), C.c_int(hw), C.c_int(stat), out.ctypes))
+    return out
+
+
+def neighbourhood_quantile(field, q, hw):
+    field, Y, X, E, is3d = _yx(field)
+    out = np.empty((Y, X), np.float32)
+    _check(lib().orc_neighbourhood_quantile(field.ctypes, C.c_int(Y), C.c_int(X), C.c_int(E), C.c_float(q), C.c_int(hw), out.ctypes))
+    return out
+
+
+def neighbourhood_quantile_fast(field, q, hw, thresholds):
+    field, Y, X, E, is3d = _yx(field)
+    q = _f(q).ravel()
+    thresholds = _f(thresholds).ravel()
+    out = np.empty((Y, X), np.float32)
+    _check(lib().orc_neighbourhood_quantile_fast(field.ctypes, C.c_int(Y), C.c_int(X), C.c_int(E), C.c_int(is3d), q.ctypes,
+                                                 C.c_int(q.size), C.c_int(hw), thresholds.ctypes, C.c_int(thresholds.size),
+                                                 out.ctypes))
+    return out

@@ -1,0 +1,390 @@
+"""Known-answer checks of the reference's own unit tests, restated against an
+API object `g` that looks like the reference's python module (tests/refapi.py
+for the oracle, gridpp_amd for the HIP path).  Expected values come from
+tests/golden/reference_known_answers.json (each entry cites the reference test
+file:line).  Every function here is called by test_oracle_golden.py (CPU) and
+test_gpu_reference_pins.py (GPU)."""
+import numpy as np
+
+
+def _values5(G):
+    values = np.reshape(np.arange(25), [5, 5]).astype(np.float32)
+    for i, j in G["neighbourhood_values"]["nan_at"]:
+        values[i, j] = np.nan
+    return values
+
+
+def pin_barnes_basic(g, G):
+    e = G["barnes_basic"]
+    s = g.BarnesStructure(e["h"])
+    for x, c in zip(e["x"], e["corr"]):
+        p1 = g.Point(0, 0, 0, 0, g.Cartesian)
+        p2 = g.Point(x, 0, 0, 0, g.Cartesian)
+        for f in (s.corr, s.corr_background):
+            assert f(p1, p2) == np.float32(c), (x, f(p1, p2), c)
+            assert f(p2, p1) == np.float32(c)
+            if not np.isnan(x):
+                assert f(p2, p2) == 1
+
+
+def pin_barnes_hmax(g, G):
+    e = G["barnes_hmax"]
+    p0 = g.Point(0, 0, 0, 0, g.Cartesian)
+    for hmax in e["hmaxs"]:
+        for dist, ans in e["dist_ans"].items():
+            s = g.BarnesStructure(e["h"], 0, 0, hmax)
+            corr = s.corr(p0, g.Point(float(dist), 0, 0, 0, g.Cartesian))
+            if float(dist) > hmax:
+                assert corr == 0
+            else:
+                assert corr == np.float32(ans), (hmax, dist, corr)
+
+
+def pin_barnes_invalid(g, G):
+    import pytest
+    for h in (-1, np.nan):
+        with pytest.raises(Exception):
+            g.BarnesStructure(h)
+    with pytest.raises(Exception):
+        g.BarnesStructure(2000, 100, 0, -1)
+
+
+def _oi_1d_setup(g, G):
+    e = G["oi_simple_1d"]
+    y, x = e["grid_y"], e["grid_x"]
+    grid = g.Grid(y, x, y, y, g.Cartesian)
+    points = g.Points(e["points_y"], e["points_x"], [0], [0], g.Cartesian)
+    structure = g.BarnesStructure(e["h"])
+    return e, grid, points, structure
+
+
+def pin_oi_simple_1d(g, G):
+    e, grid, points, structure = _oi_1d_setup(g, G)
+    background = np.zeros([1, 3])
+    out = g.optimal_interpolation(grid, background, points, e["pobs"], e["pratios"], e["pbackground"], structure, e["max_points"])
+    out = np.asarray(out)
+    assert out.dtype == np.float32 and out.shape == (1, 3)
+    np.testing.assert_array_almost_equal(out, np.array([[np.exp(-0.5) / 1.1, 1 / 1.1, np.exp(-0.5 * 9) / 1.1]]), e["decimals"])
+    np.testing.assert_array_almost_equal(out, np.array(e["expected"]), e["decimals"])
+
+
+def pin_oi_variance(g, G):
+    e, grid, points, structure = _oi_1d_setup(g, G)
+    v = G["oi_variance"]
+    out, var = g.optimal_interpolation_full(grid, np.zeros([1, 3]), np.ones([1, 3]), points, e["pobs"], [0.1], [0], [1],
+                                            structure, e["max_points"])
+    assert abs(np.asarray(var)[0, 1] - v["expected_variance_at_obs"]) < 10 ** -v["places"]
+    # points overload (tests/test_optimal_interpolation.py:86-105)
+    gp = g.Points([0, 0, 0], [0, 2500, 10000], [0, 0, 0], [0, 0, 0], g.Cartesian)
+    out, var = g.optimal_interpolation_full(gp, np.zeros(3), np.ones(3), points, np.array([1]), np.array([0.1]),
+                                            np.array([0]), np.array([1]), structure, e["max_points"])
+    assert abs(np.asarray(var)[1] - v["expected_variance_at_obs"]) < 10 ** -v["places"]
+
+
+def pin_oi_invalid_arguments(g, G):
+    import pytest
+    ok = dict(grid=g.Grid([[0, 0, 0]], [[0, 2500, 10000]], [[0, 0, 0]], [[0, 0, 0]], g.Cartesian),
+              background=np.zeros([1, 3]),
+              points=g.Points([0], [2500], [0], [0], g.Cartesian),
+              pobs=[1], pratios=[0.1], pbackground=[0], structure=g.BarnesStructure(2500), max_points=10)
+    x = np.zeros([3, 2])
+    invalid = {
+        'grid': [g.Grid(x, x, x, x, g.Cartesian), g.Grid([[0, 0, 0]], [[0, 2500, 10000]])],
+        'points': [g.Points([0, 1], [0, 2500], [0, 0], [0, 0], g.Cartesian), g.Points([0], [2500])],
+        'pratios': [np.zeros(11)], 'pobs': [np.zeros([11])], 'background': [np.zeros([2, 11])],
+        'pbackground': [np.zeros(21)], 'max_points': [-1]}
+    for key, args in invalid.items():
+        for arg in args:
+            a = dict(ok)
+            a[key] = arg
+            with pytest.raises(ValueError):
+                g.optimal_interpolation(a['grid'], a['background'], a['points'], a['pobs'], a['pratios'],
+                                        a['pbackground'], a['structure'], a['max_points'])
+
+
+def pin_oi_missing_values(g, G):
+    e = G["oi_missing_values"]
+    obs = np.array(e["obs"], np.float32)
+    N = len(obs)
+    y = np.arange(0, N * 1000, 1000)
+    background = np.zeros(N)
+    z = np.zeros(N)
+    points = g.Points(y, z, z, z, g.Cartesian)
+    ratios = np.ones(N)
+    structure = g.BarnesStructure(e["h"], e["v"])
+    analysis = g.optimal_interpolation(points, background, points, obs, ratios, background, structure, e["max_points"])
+    # the reference test keeps all points (its index set I is "y is not NaN"); the stronger statement -- NaN obs
+    # are ignored -- is what the test title says and what src/api/oi.cpp:252 does:
+    I = np.where(~np.isnan(obs))[0]
+    zI = np.zeros(len(I))
+    points1 = g.Points(y[I], zI, zI, zI, g.Cartesian)
+    analysis1 = g.optimal_interpolation(points, background, points1, obs[I], ratios[I], background[I], structure, e["max_points"])
+    np.testing.assert_array_almost_equal(analysis, analysis1)
+    assert not np.isnan(np.asarray(analysis)).any()
+
+
+def pin_oi_extrapolation(g, G):
+    e = G["oi_extrapolation"]
+    a, b, n = e["grid_y_linspace"]
+    y = np.linspace(a, b, n)
+    x = np.zeros(n)
+    grid = g.Points(y, x, x, x, g.Cartesian)
+    py = e["points_y"]
+    z4 = [0] * len(py)
+    points = g.Points(py, z4, z4, z4, g.Cartesian)
+    pratios = e["pratio"] * np.ones(len(py))
+    structure = g.BarnesStructure(e["h"])
+    background = np.zeros(n)
+    pbackground = np.zeros(len(py))
+    o0 = np.asarray(g.optimal_interpolation(grid, background, points, e["pobs"], pratios, pbackground, structure, e["max_points"], False))
+    o1 = np.asarray(g.optimal_interpolation(grid, background, points, e["pobs"], pratios, pbackground, structure, e["max_points"], True))
+    assert np.max(o0) == 1
+    assert np.max(o1) > 1
+    I = np.where(o1 < 1)[0]
+    np.testing.assert_array_almost_equal(o0[I], o1[I])
+
+
+def pin_oi_no_obs(g, G):
+    grid = g.Points([0], [0])
+    points = g.Points([], [])
+    out = g.optimal_interpolation(grid, np.zeros(1), points, [], [], [], g.BarnesStructure(500), 10)
+    np.testing.assert_almost_equal(out, np.zeros(1))
+
+
+def pin_ensi(g, G):
+    # tests/test_optimal_interpolation_ens.py:9-35
+    grid = g.Points([0], [0])
+    E = 3
+    structure = g.BarnesStructure(500000)
+    background = np.zeros([1, E])
+    out = g.optimal_interpolation_ensi(grid, background, g.Points([], []), [], [], np.zeros([0, E]), structure, 10)
+    np.testing.assert_almost_equal(out, background)
+    points = g.Points([0, 0.1], [0, 0.1])
+    out = g.optimal_interpolation_ensi(grid, background, points, [np.nan, 0], [1, 1], np.zeros([2, E]), structure, 10)
+    np.testing.assert_almost_equal(out, background)
+
+
+def pin_radius_queries(g, G):
+    for key in ("radius_match", "points_neighbours"):
+        e = G[key]
+        z = [0] * len(e["points_y"])
+        points = g.Points(e["points_y"], e["points_x"], z, z, g.Cartesian)
+        for q in e["queries"]:
+            lat, lon, r, inc = q["q"]
+            np.testing.assert_array_equal(np.sort(points.get_neighbours(lat, lon, r, inc)), q["expected"])
+        for q in e.get("nearest", []):
+            assert points.get_nearest_neighbour(*q["q"]) == q["expected"]
+    for key in ("kdtree_geodetic", "kdtree_duplicates", "kdtree_pole"):
+        e = G[key]
+        tree = g.KDTree(e["lats"], e["lons"])
+        for q in e["queries"]:
+            lat, lon, r, inc = q["q"]
+            np.testing.assert_array_equal(np.sort(tree.get_neighbours(lat, lon, r, inc)), q["expected"])
+    e = G["points_nearest_no_match"]
+    points = g.Points(e["lats"], e["lons"])
+    for c in e["cases"]:
+        lat, lon, inc = c["q"]
+        assert points.get_nearest_neighbour(lat, lon, inc) in c["expected"]
+
+
+def pin_invalid_coords(g, G):
+    import pytest
+    # tests/test_kdtree.py:167-175
+    for lat, lon in zip([91, -91, np.nan, 0], [0, 0, 0, np.nan]):
+        with pytest.raises(ValueError):
+            g.KDTree([lat], [lon], g.Geodetic)
+    # tests/test_kdtree.py:177-186
+    for lat in (90.000001, -90.0000001):
+        tree = g.KDTree([0, lat], [0, 0], g.Geodetic)
+        assert tree.get_nearest_neighbour(0, 0) == 0
+
+
+def pin_nearest(g, G):
+    e = G["nearest_grid_to_point"]
+    lons, lats = np.meshgrid(e["grid_lons"], e["grid_lats"])
+    grid = g.Grid(lats, lons)
+    values = np.reshape(np.arange(9), lons.shape)
+    points = g.Points(e["point_lats"], e["point_lons"])
+    np.testing.assert_array_equal(g.nearest(grid, points, values), e["expected"])
+    e1 = G["nearest_one_row"]
+    lons, lats = np.meshgrid(e1["grid_lons"], e1["grid_lats"])
+    grid = g.Grid(lats, lons)
+    values = np.reshape(np.arange(3), lons.shape).astype(float)
+    np.testing.assert_array_equal(g.nearest(grid, points, values), e1["expected"])
+
+
+def _rc(key):
+    i, j = key.split(",")
+    return int(i), int(j)
+
+
+def pin_neighbourhood(g, G, funcs=None):
+    values = _values5(G)
+    funcs = funcs or [g.neighbourhood, g.neighbourhood_brute_force]
+    for func in funcs:
+        e = G["neighbourhood_mean"]
+        out = np.asarray(func(values, 1, g.Mean))
+        assert out.dtype == np.float32
+        assert out[2][2] == e["hw1"]["2,2"]
+        assert abs(out[0][4] - e["hw1"]["0,4"]) < 10 ** -e["hw1_places"]
+        out = np.asarray(func(values, 100, g.Mean))
+        assert (np.abs(out - e["hw100_all"]) < e["hw100_tol"]).all()
+        out = np.asarray(func(values, 0, g.Mean)).flatten()
+        assert (np.isnan(out) == np.isnan(values.flatten())).all()
+        I = np.where(~np.isnan(out))[0]
+        assert (out[I] == values.flatten()[I]).all()
+
+        e = G["neighbourhood_count"]
+        out = np.asarray(func(values, 1, g.Count))
+        for k, v in e["hw1"].items():
+            assert out[_rc(k)] == v
+        assert (np.abs(np.asarray(func(values, 100, g.Count)) - e["hw100_all"]) < 1e-4).all()
+        np.testing.assert_array_almost_equal(func(values, 0, g.Count), e["hw0"])
+
+        for stat, key in ((g.Min, "neighbourhood_min"), (g.Max, "neighbourhood_max")):
+            e = G[key]
+            out = np.asarray(func(values, 1, stat))
+            for k, v in e["hw1"].items():
+                assert out[_rc(k)] == v
+            assert (np.asarray(func(values, 100, stat)) == e["hw100_all"]).all()
+
+        # tests/test_neighbourhood.py:48-59
+        empty = np.zeros([5, 5])
+        empty[0:3, 0:3] = np.nan
+        for stat in (g.Mean, g.Min, g.Max, g.Median, g.Std, g.Variance):
+            out = np.asarray(func(empty, 1, stat))
+            assert np.isnan(out[0:2, 0:2]).all()
+        np.testing.assert_array_almost_equal(func(empty, 1, g.Count), G["neighbourhood_missing_count"]["expected"])
+
+
+def pin_neighbourhood_invalid(g, G):
+    import pytest
+    field = np.ones([5, 5])
+    for stat in (g.Mean, g.Min, g.Max, g.Median):
+        with pytest.raises(ValueError):
+            g.neighbourhood(field, -1, stat)
+    with pytest.raises(Exception):
+        g.neighbourhood(field, 1, g.Quantile)
+    for stat in (g.Mean, g.Min, g.Max, g.Median, g.Std, g.Variance):
+        for func in (g.neighbourhood, g.neighbourhood_brute_force):
+            out = np.asarray(func([[]], 1, stat))
+            assert out.ndim == 2 and out.shape[0] == 0 and out.shape[1] == 0
+
+
+def pin_neighbourhood_3d_and_overflow(g, G):
+    # tests/test_neighbourhood.py:134-152
+    rng = np.random.RandomState(1000)
+    values = rng.rand(200, 200)
+    values3 = np.repeat(values[:, :, None], 5, axis=2)
+    for hw in (0, 1, 5):
+        for func in (g.neighbourhood,):
+            o2 = func(values, hw, g.Mean)
+            o3 = func(values3, hw, g.Mean)
+            np.testing.assert_array_almost_equal(o2, o3, 5)
+    N = 1000
+    values = np.expand_dims(np.arange(1, N) ** 3, 1).astype(float)
+    out = np.asarray(g.neighbourhood(values, 0, g.Mean))
+    np.testing.assert_array_almost_equal(np.zeros(values.shape), out / values - 1, 6)
+
+
+def pin_neighbourhood_quantile(g, G):
+    import pytest
+    values = _values5(G)
+    e = G["neighbourhood_quantile"]
+    out = np.asarray(g.neighbourhood_quantile(values, e["q"], e["hw"]))
+    for k, v in e["expected"].items():
+        assert out[_rc(k)] == v
+    for q in (-0.1, 1.1):
+        with pytest.raises(ValueError):
+            g.neighbourhood_quantile(np.ones([5, 5]), q, 1)
+    empty = np.zeros([5, 5])
+    empty[0:3, 0:3] = np.nan
+    assert np.isnan(np.asarray(g.neighbourhood_quantile(empty, 0.5, 1))[0:2, 0:2]).all()
+
+
+def pin_neighbourhood_quantile_fast(g, G):
+    import pytest
+    values = _values5(G)
+    e = G["neighbourhood_quantile_fast"]
+    thresholds = g.get_neighbourhood_thresholds(values, e["num_thresholds"])
+    out = np.asarray(g.neighbourhood_quantile_fast(values, e["q"], e["hw"], thresholds))
+    for k, v in e["expected"].items():
+        assert out[_rc(k)] == v, (k, out[_rc(k)], v)
+    out = np.asarray(g.neighbourhood_quantile_fast(np.full([100, 100], np.nan), 0.5, 1, thresholds))
+    assert np.isnan(out).all()
+    out = np.asarray(g.neighbourhood_quantile_fast(np.zeros([100, 100]), 0.5, 1, thresholds))
+    assert (out == 0).all()
+    # nan quantile -> nan field (tests/test_neighbourhood_quantile_fast.py:34-41)
+    out = np.asarray(g.neighbourhood_quantile_fast(np.ones([5, 5]), np.nan, 1, [0, 1]))
+    assert np.isnan(out).all() and out.shape == (5, 5)
+    for q in (-0.1, 1.1):
+        with pytest.raises(ValueError):
+            g.neighbourhood_quantile_fast(np.ones([5, 5]), q, 1, [0, 1])
+    # single threshold (:50-56)
+    field = np.reshape(np.arange(9), [3, 3])
+    for hw in (0, 1, 2):
+        np.testing.assert_array_equal(g.neighbourhood_quantile_fast(field, 0.9, hw, [0]), np.zeros([3, 3]))
+    # all same (:128-136)
+    a = G["quantile_fast_all_same"]
+    field = np.zeros([10, 10])
+    for q in a["quantiles"]:
+        np.testing.assert_array_almost_equal(g.neighbourhood_quantile_fast(field, q, a["hw"], a["thresholds"]), field)
+    # 2-D == 3-D (:89-101)
+    rng = np.random.RandomState(1000)
+    values = rng.rand(200, 200)
+    values3 = np.repeat(values[:, :, None], 5, axis=2)
+    for hw in (0, 1, 5):
+        o2 = g.neighbourhood_quantile_fast(values, 0.5, hw, [0, 0.25, 0.5, 0.75, 1])
+        o3 = g.neighbourhood_quantile_fast(values3, 0.5, hw, [0, 0.25, 0.5, 0.75, 1])
+        np.testing.assert_array_almost_equal(o2, o3)
+    # varying quantile (:103-125)
+    v = np.array([[0, 1], [2, 3], [4, 5]], float)
+    q = np.ones(v.shape) * 0.5
+    g.neighbourhood_quantile_fast(v, q, 1, [0, 0.25, 0.5, 0.75, 1])
+    vn = np.nan * np.zeros(v.shape)
+    np.testing.assert_array_equal(vn, g.neighbourhood_quantile_fast(vn, q, 1, [0, 0.25, 0.5, 0.75, 1]))
+
+
+def pin_thresholds(g, G):
+    import pytest
+    # tests/test_get_neighbourhood_thresholds.py:8-49
+    for num in (-1, 0):
+        with pytest.raises(ValueError):
+            g.get_neighbourhood_thresholds(np.ones([5, 5]), num)
+    field = np.reshape(np.arange(4), [2, 2])
+    for num in (4, 5, 6):
+        np.testing.assert_array_equal(g.get_neighbourhood_thresholds(field, num), [0, 1, 2, 3])
+    rng = np.random.RandomState(1000)
+    values = rng.rand(10, 10)
+    values3 = np.repeat(values[:, :, None], 5, axis=2)
+    for num in (1, 5):
+        np.testing.assert_array_almost_equal(g.get_neighbourhood_thresholds(values, num),
+                                             g.get_neighbourhood_thresholds(values3, num))
+
+
+def pin_util(g, G):
+    import pytest
+    stat = dict(Mean=g.Mean, Count=g.Count, Sum=g.Sum, Min=g.Min)
+    for c in G["calc_statistic"]["cases"]:
+        r = g.calc_statistic(np.array(c["a"], np.float32), stat[c["stat"]])
+        if isinstance(c["expected"], float) and np.isnan(c["expected"]):
+            assert np.isnan(r)
+        else:
+            assert r == c["expected"], c
+    for c in G["calc_quantile"]["cases"]:
+        r = g.calc_quantile(np.array(c["a"], np.float32), c["q"])
+        if isinstance(c["expected"], float) and np.isnan(c["expected"]):
+            assert np.isnan(r), c
+        else:
+            assert r == c["expected"], c
+    for q in G["calc_quantile"]["invalid_quantiles"]:
+        with pytest.raises(ValueError):
+            g.calc_quantile(np.array([0, 1, 2], np.float32), q)
+    for c in G["calc_even_quantiles"]["cases"]:
+        np.testing.assert_array_almost_equal(g.calc_even_quantiles(np.array(c["values"], np.float32), c["num"]), c["expected"])
+    for v in G["is_valid"]["valid"]:
+        assert g.is_valid(v)
+    assert not g.is_valid(np.nan)
+
+
+ALL_PINS = [v for k, v in sorted(globals().items()) if k.startswith("pin_")]

@@ -1,0 +1,186 @@
+"""A gridpp-shaped facade over the CPU oracle, so that the reference-style pins
+in tests/pins.py run unchanged against the oracle (CPU) and gridpp_amd (GPU)."""
+import numpy as np
+
+from oracle import oracle as O
+
+Geodetic, Cartesian = 0, 1
+Mean, Min, Median, Max, Quantile, Std, Variance, Sum, Count, RandomChoice = 0, 10, 20, 30, 40, 50, 60, 70, 80, 90
+name = "oracle"
+
+
+class Point:
+    def __init__(self, lat, lon, elev=np.nan, laf=np.nan, type=Geodetic):
+        self.lat, self.lon, self.elev, self.laf, self.type = lat, lon, elev, laf, type
+        if type == Geodetic:
+            x, y, z = O.convert_coordinates([lat], [lon], type)
+            self.x, self.y, self.z = float(x[0]), float(y[0]), float(z[0])
+        else:  # src/api/point.cpp:18-21
+            self.x, self.y, self.z = float(np.float32(lat)), float(np.float32(lon)), 0.0
+
+
+class Points:
+    def __init__(self, lats=(), lons=(), elevs=(), lafs=(), type=Geodetic):
+        lats, lons = np.asarray(lats, np.float32).ravel(), np.asarray(lons, np.float32).ravel()
+        if lats.size != lons.size:
+            raise ValueError("size")
+        try:
+            self.p = O.Pts(lats, lons, elevs if np.size(elevs) else None, lafs if np.size(lafs) else None, type)
+        except O.OracleError as e:
+            raise ValueError(str(e))
+        self.type = type
+
+    def size(self):
+        return self.p.n
+
+    def get_coordinate_type(self):
+        return self.type
+
+    def get_neighbours(self, lat, lon, radius, include_match=True):
+        return O.get_neighbours(self.p, lat, lon, radius, include_match)
+
+    def get_nearest_neighbour(self, lat, lon, include_match=True):
+        return O.nearest_neighbour(self.p, lat, lon, include_match)
+
+
+KDTree = Points
+
+
+class Grid:
+    def __init__(self, lats=((),), lons=((),), elevs=((),), lafs=((),), type=Geodetic):
+        lats = np.asarray(lats, np.float32)
+        lons = np.asarray(lons, np.float32)
+        self.shape = lats.shape if lats.ndim == 2 else (0, 0)
+        e = np.asarray(elevs, np.float32)
+        l = np.asarray(lafs, np.float32)
+        self.p = O.Pts(lats.ravel(), lons.ravel(), e.ravel() if e.size == lats.size and e.size else None,
+                       l.ravel() if l.size == lats.size and l.size else None, type)
+        self.type = type
+
+    def size(self):
+        return list(self.shape)
+
+    def get_coordinate_type(self):
+        return self.type
+
+
+class BarnesStructure:
+    def __init__(self, h, v=0, w=0, hmax=np.nan):
+        if not np.isfinite(h) or h < 0:
+            raise ValueError("h")
+        if np.isfinite(hmax) and hmax < 0:
+            raise ValueError("hmax")
+        self.s = O.Barnes(h, v, w, hmax)
+
+    def corr(self, p1, p2):
+        return self.s.corr((p1.x, p1.y, p1.z, p1.elev, p1.laf), (p2.x, p2.y, p2.z, p2.elev, p2.laf))
+
+    corr_background = corr
+
+    def localization_distance(self, p=None):
+        return self.s.localization_distance()
+
+
+def _pts(obj):
+    return obj.p
+
+
+def _validate(bg, background, points, max_points, *per_point):
+    # src/api/oi.cpp:38-63 / 100-121
+    if max_points < 0:
+        raise ValueError("max_points must be >= 0")
+    if bg.get_coordinate_type() != points.get_coordinate_type():
+        raise ValueError("coordinate type mismatch")
+    shape = tuple(bg.size()) if isinstance(bg, Grid) else (bg.size(),)
+    if tuple(np.shape(background))[:len(shape)] != shape:
+        raise ValueError("background size mismatch")
+    for a in per_point:
+        if np.shape(a)[0] != points.size():
+            raise ValueError("points size mismatch")
+
+
+def optimal_interpolation(bg, background, points, pobs, pratios, pbackground, structure, max_points, allow_extrapolation=True):
+    background = np.asarray(background, np.float32)
+    _validate(bg, background, points, max_points, pobs, pratios, pbackground)
+    out = O.oi(_pts(bg), background.ravel(), _pts(points), pobs, pratios, pbackground, structure.s, max_points, allow_extrapolation)
+    return out.reshape(background.shape)
+
+
+def optimal_interpolation_full(bg, background, bvariance, points, pobs, obs_variance, pbackground, bvariance_at_points,
+                               structure, max_points, allow_extrapolation=True):
+    background = np.asarray(background, np.float32)
+    out, var = O.oi_full(_pts(bg), background.ravel(), np.asarray(bvariance, np.float32).ravel(), _pts(points), pobs,
+                         obs_variance, pbackground, bvariance_at_points, structure.s, max_points, allow_extrapolation)
+    return out.reshape(background.shape), var.reshape(background.shape)
+
+
+def optimal_interpolation_ensi(bg, background, points, pobs, psigmas, pbackground, structure, max_points, allow_extrapolation=True):
+    background = np.asarray(background, np.float32)
+    E = background.shape[-1]
+    out = O.oi_ensi(_pts(bg), background.reshape(-1, E), _pts(points), pobs, psigmas, pbackground, structure.s, max_points,
+                    allow_extrapolation)
+    return out.reshape(background.shape)
+
+
+def nearest(grid, points, values):
+    return O.nearest(_pts(grid), _pts(points), values)
+
+
+def _wrap(fn):
+    def f(*a, **k):
+        try:
+            return fn(*a, **k)
+        except O.OracleError as e:
+            raise ValueError(str(e))
+    return f
+
+
+def _empty2(field):
+    f = np.asarray(field, np.float32)
+    return f.ndim >= 2 and (f.shape[0] == 0 or f.shape[1] == 0)
+
+
+@_wrap
+def neighbourhood(field, hw, stat):
+    if hw < 0 or stat == Quantile:
+        raise ValueError("arg")
+    if _empty2(field):
+        return np.zeros((0, 0), np.float32)
+    return O.neighbourhood(field, hw, stat)
+
+
+@_wrap
+def neighbourhood_brute_force(field, hw, stat):
+    if hw < 0:
+        raise ValueError("arg")
+    if _empty2(field):
+        return np.zeros((0, 0), np.float32)
+    return O.neighbourhood_brute_force(field, hw, stat)
+
+
+@_wrap
+def neighbourhood_quantile(field, q, hw):
+    if hw < 0:
+        raise ValueError("arg")
+    if _empty2(field):
+        return np.zeros((0, 0), np.float32)
+    return O.neighbourhood_quantile(field, q, hw)
+
+
+@_wrap
+def neighbourhood_quantile_fast(field, q, hw, thresholds):
+    if hw < 0:
+        raise ValueError("arg")
+    if _empty2(field):
+        return np.zeros((0, 0), np.float32)
+    return O.neighbourhood_quantile_fast(field, q, hw, thresholds)
+
+
+get_neighbourhood_thresholds = _wrap(O.get_neighbourhood_thresholds)
+calc_statistic = O.calc_statistic
+calc_quantile = _wrap(O.calc_quantile)
+calc_even_quantiles = O.calc_even_quantiles
+
+
+def is_valid(v):
+    return bool(O.lib().orc_is_valid(O.C.c_float(v)))
