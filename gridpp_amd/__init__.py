@@ -1,0 +1,419 @@
+"""gridpp_amd -- the python surface of the MI355X-native gridpp hot path.
+
+Mirrors the SWIG module of the reference (swig/gridpp.i %include "gridpp.h"):
+same names, argument order, defaults, output dtypes (np.float32 / np.int32) and
+exception mapping (ValueError for invalid arguments, RuntimeError otherwise), for
+the optimal-interpolation + neighbourhood path only.  Use as
+
+    import gridpp_amd as gridpp
+
+All compute goes through libgridpp_hip.so (include/gridpp_hip.h).  Field
+arguments may be anything numpy can convert (host path: staged through HBM by the
+library) or torch CUDA tensors (device path: the kernels read/write the tensors'
+HBM directly and a torch tensor is returned).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, lib
+
+__version__ = "0.8.0.dev1+mi355x.r1"
+
+# include/gridpp.h:120-123, :88-100
+Geodetic, Cartesian = 0, 1
+Mean, Min, Median, Max, Quantile, Std, Variance, Sum, Count, RandomChoice, Unknown = 0, 10, 20, 30, 40, 50, 60, 70, 80, 90, -1
+MV = np.nan
+radius_earth = 6.378137e6
+
+
+def version():
+    return lib().gpp_version().decode()
+
+
+def set_device(index):
+    """One process per GPU: call with LOCAL_RANK before anything else."""
+    check(lib().gpp_set_device(int(index)))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().gpp_device_count(C.byref(n)))
+    return n.value
+
+
+def synchronize():
+    check(lib().gpp_synchronize())
+
+
+def is_valid(value):
+    """src/api/util.cpp:16-18"""
+    v = np.float32(value)
+    return bool(not np.isnan(v) and not np.isinf(v))
+
+
+_omp_threads = 1
+
+
+def set_omp_threads(num):   # src/api/gridpp.cpp:184-207 -- meaningless on the GPU path, kept for drop-in
+    global _omp_threads
+    _omp_threads = int(num)
+
+
+def get_omp_threads():
+    return _omp_threads
+
+
+# ---- argument conversion (the SWIG typemaps of swig/vector.i) ---------------------------------
+def _is_dev(a):
+    return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
+
+
+def _vec(a, ndim, name="array"):
+    """Any dtype -> C-contiguous float32; wrong ndim raises like the typemap (swig/vector.i:39-41)."""
+    if _is_dev(a):
+        import torch
+        if a.dim() != ndim:
+            raise RuntimeError("%s must have %d dimensions" % (name, ndim))
+        return a.contiguous().to(torch.float32)
+    arr = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    if arr.ndim != ndim:
+        if arr.size == 0 and arr.ndim <= ndim:   # e.g. [] or [[]]
+            return arr.reshape((0,) * ndim)
+        raise RuntimeError("%s must have %d dimensions, got %d" % (name, ndim, arr.ndim))
+    return arr
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_dev(a):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+def _shape(a):
+    return tuple(a.shape)
+
+
+def _empty_like_field(shape, like):
+    if _is_dev(like):
+        import torch
+        return torch.empty(shape, dtype=torch.float32, device=like.device)
+    return np.empty(shape, dtype=np.float32)
+
+
+def _mem(*arrays):
+    dev = [_is_dev(a) for a in arrays if a is not None]
+    if any(dev) and not all(dev):
+        raise ValueError("either all field arguments are torch CUDA tensors or none is")
+    return _capi.MEM_DEVICE if dev and all(dev) else _capi.MEM_HOST
+
+
+# ---- Point / KDTree / Points / Grid -----------------------------------------------------------
+class Point:
+    """include/gridpp.h:1713-1743, src/api/point.cpp:5-26"""
+
+    def __init__(self, lat, lon, elev=MV, laf=MV, type=Geodetic, x=None, y=None, z=None):
+        self.lat, self.lon, self.elev, self.laf, self.type = float(lat), float(lon), float(elev), float(laf), type
+        if x is not None:
+            self.x, self.y, self.z = float(x), float(y), float(z)
+        elif type == Geodetic:
+            xs, ys, zs = convert_coordinates([lat], [lon], type)
+            self.x, self.y, self.z = float(xs[0]), float(ys[0]), float(zs[0])
+        else:   # point.cpp:18-21 (x = lat, y = lon)
+            self.x, self.y, self.z = float(np.float32(lat)), float(np.float32(lon)), 0.0
+
+    def _five(self):
+        return (C.c_float * 5)(self.x, self.y, self.z, self.elev, self.laf)
+
+
+def convert_coordinates(lats, lons, type=Geodetic):
+    """src/api/util.cpp:583-615"""
+    lats, lons = _vec(lats, 1, "lats"), _vec(lons, 1, "lons")
+    if lats.size != lons.size:
+        raise ValueError("lats and lons must have the same size")
+    n = lats.size
+    x, y, z = (np.empty(n, np.float32) for _ in range(3))
+    check(lib().gpp_convert_coordinates(_ptr(lats), _ptr(lons), n, type, _ptr(x), _ptr(y), _ptr(z)))
+    return x, y, z
+
+
+class _PointSet:
+    """Owns a gpp_points handle (x/y/z resident in HBM)."""
+    _h = None
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib().gpp_points_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _field(self, k):
+        out = np.empty(self._n, np.float32)
+        check(lib().gpp_points_get(self._h, k, _ptr(out)))
+        return out
+
+    def get_coordinate_type(self):
+        return self._type
+
+    # KDTree queries (src/api/kdtree.cpp:18-106)
+    def _neighbours(self, lat, lon, radius, include_match=True, want_dist=False):
+        cap = max(self._n, 1)
+        idx = np.empty(cap, np.int32)
+        dist = np.empty(cap, np.float32) if want_dist else None
+        cnt = C.c_int(0)
+        check(lib().gpp_points_get_neighbours(self._h, float(lat), float(lon), float(radius), int(bool(include_match)),
+                                              _ptr(idx), _ptr(dist), cap, C.byref(cnt)))
+        if want_dist:
+            return idx[:cnt.value].copy(), dist[:cnt.value].copy()
+        return idx[:cnt.value].copy()
+
+    def _nearest_flat(self, lats, lons, include_match=True):
+        lats, lons = _vec(lats, 1), _vec(lons, 1)
+        out = np.empty(lats.size, np.int32)
+        check(lib().gpp_points_nearest_neighbour(self._h, _ptr(lats), _ptr(lons), lats.size, int(bool(include_match)), _ptr(out)))
+        return out
+
+
+class Points(_PointSet):
+    """include/gridpp.h:1876-1968, src/api/points.cpp"""
+
+    def __init__(self, lats=(), lons=(), elevs=(), lafs=(), type=Geodetic):
+        lats, lons = _vec(lats, 1, "lats"), _vec(lons, 1, "lons")
+        elevs, lafs = _vec(elevs, 1, "elevs"), _vec(lafs, 1, "lafs")
+        n = lats.size
+        if lons.size != n:
+            raise ValueError("Cannot create points with unequal lat and lon sizes")
+        if elevs.size not in (0, n):
+            raise ValueError("'elevs' must either be size 0 or the same size at lats/lons")
+        if lafs.size not in (0, n):
+            raise ValueError("'lafs' must either be size 0 or the same size at lats/lons")
+        h = C.c_void_p()
+        check(lib().gpp_points_create(_ptr(lats), _ptr(lons), _ptr(elevs) if elevs.size == n and n else None,
+                                      _ptr(lafs) if lafs.size == n and n else None, n, type, C.byref(h)))
+        self._h, self._n, self._type = h, n, type
+
+    def size(self):
+        return self._n
+
+    def get_lats(self):
+        return self._field(0)
+
+    def get_lons(self):
+        return self._field(1)
+
+    def get_elevs(self):
+        return self._field(2)
+
+    def get_lafs(self):
+        return self._field(3)
+
+    def get_neighbours(self, lat, lon, radius, include_match=True):
+        return self._neighbours(lat, lon, radius, include_match)
+
+    def get_neighbours_with_distance(self, lat, lon, radius, include_match=True):
+        return self._neighbours(lat, lon, radius, include_match, True)
+
+    def get_num_neighbours(self, lat, lon, radius, include_match=True):
+        return len(self._neighbours(lat, lon, radius, include_match))
+
+    def get_nearest_neighbour(self, lat, lon, include_match=True):
+        return int(self._nearest_flat([lat], [lon], include_match)[0])
+
+    def get_point(self, index):   # src/api/points.cpp:128-130
+        f = [self._field(k)[index] for k in range(7)]
+        return Point(f[0], f[1], f[2], f[3], self._type, f[4], f[5], f[6])
+
+    def subset(self, indices):
+        indices = np.asarray(indices, np.int64)
+        if indices.size and indices.max() >= self._n:
+            raise ValueError("Index exceeds number of points")
+        return Points(self.get_lats()[indices], self.get_lons()[indices], self.get_elevs()[indices], self.get_lafs()[indices])
+
+
+class KDTree(Points):
+    """include/gridpp.h:1746-1873 (a Points without elev/laf)"""
+
+    def __init__(self, lats=(), lons=(), type=Geodetic):
+        Points.__init__(self, lats, lons, (), (), type)
+
+    @staticmethod
+    def calc_straight_distance(x0, y0, z0, x1, y1, z1):
+        f = np.float32
+        return float(np.sqrt((f(x0) - f(x1)) * (f(x0) - f(x1)) + (f(y0) - f(y1)) * (f(y0) - f(y1)) + (f(z0) - f(z1)) * (f(z0) - f(z1)), dtype=np.float32))
+
+
+class Grid(_PointSet):
+    """include/gridpp.h:1971-2060, src/api/grid.cpp"""
+
+    def __init__(self, lats=((),), lons=((),), elevs=((),), lafs=((),), type=Geodetic):
+        lats, lons = _vec(lats, 2, "lats"), _vec(lons, 2, "lons")
+        elevs, lafs = _vec(elevs, 2, "elevs"), _vec(lafs, 2, "lafs")
+        if lats.shape != lons.shape:
+            raise ValueError("lats and lons must have the same shape")
+        ny, nx = lats.shape
+        if ny * nx == 0:
+            ny = nx = 0
+        e = elevs if elevs.shape == lats.shape and elevs.size else None   # grid.cpp:41-54
+        l = lafs if lafs.shape == lats.shape and lafs.size else None
+        h = C.c_void_p()
+        check(lib().gpp_grid_create(_ptr(lats), _ptr(lons), _ptr(e), _ptr(l), ny, nx, type, C.byref(h)))
+        self._h, self._n, self._ny, self._nx, self._type = h, ny * nx, ny, nx, type
+
+    def size(self):
+        return [self._ny, self._nx]
+
+    def _f2(self, k):
+        return self._field(k).reshape(self._ny, self._nx)
+
+    def get_lats(self):
+        return self._f2(0)
+
+    def get_lons(self):
+        return self._f2(1)
+
+    def get_elevs(self):
+        return self._f2(2)
+
+    def get_lafs(self):
+        return self._f2(3)
+
+    def get_nearest_neighbour(self, lat, lon, include_match=True):   # grid.cpp:76-82,108-114
+        if self._n == 0:
+            return []
+        i = int(self._nearest_flat([lat], [lon], include_match)[0])
+        return [i // self._nx, i % self._nx]
+
+    def get_neighbours(self, lat, lon, radius, include_match=True):
+        idx = self._neighbours(lat, lon, radius, include_match)
+        return np.stack([idx // self._nx, idx % self._nx], axis=1).astype(np.int32) if idx.size else np.zeros((0, 2), np.int32)
+
+    def get_num_neighbours(self, lat, lon, radius, include_match=True):
+        return len(self._neighbours(lat, lon, radius, include_match))
+
+    def to_points(self):   # grid.cpp:131-145
+        return Points(self._field(0), self._field(1), self._field(2), self._field(3), self._type)
+
+
+# ---- structure functions (include/gridpp.h:2069-2343, src/api/structure.cpp) -----------------------
+class StructureFunction:
+    pass
+
+
+class BarnesStructure(StructureFunction):
+    """Scalar form BarnesStructure(h, v=0, w=0, hmax=MV) (src/api/structure.cpp:143-167)."""
+
+    def __init__(self, h, v=0, w=0, hmax=MV):
+        if not np.isscalar(h):
+            raise RuntimeError("the spatially varying BarnesStructure(grid, h, v, w) is outside the GPU hot path (SURVEY 8f)")
+        # structure.cpp:145-152
+        for name, val in (("v", v), ("w", w)):
+            if not is_valid(val) or val < 0:
+                raise ValueError("%s must be >= 0" % name)
+        mr = C.c_float(0)
+        check(lib().gpp_barnes_min_rho(float(h), float(hmax), C.byref(mr)))
+        self._s = _capi.gpp_structure(0, float(h), float(v), float(w), mr.value)
+
+    def localization_distance(self, p=None):
+        d = C.c_float(0)
+        check(lib().gpp_barnes_localization_distance(C.byref(self._s), C.byref(d)))
+        return d.value
+
+    def corr(self, p1, p2):
+        if isinstance(p2, (list, tuple)):
+            return np.array([self.corr(p1, q) for q in p2], np.float32)
+        r = C.c_float(0)
+        check(lib().gpp_barnes_corr(C.byref(self._s), p1._five(), p2._five(), C.byref(r)))
+        return r.value
+
+    corr_background = corr
+
+    def clone(self):
+        c = BarnesStructure.__new__(BarnesStructure)
+        c._s = _capi.gpp_structure(self._s.kind, self._s.h, self._s.v, self._s.w, self._s.min_rho)
+        return c
+
+
+def _structure(s):
+    if not isinstance(s, BarnesStructure):
+        raise RuntimeError("only BarnesStructure (scalar) is implemented on the GPU hot path")
+    return C.byref(s._s)
+
+
+# ---- optimal interpolation (include/gridpp.h:162-248, src/api/oi.cpp) -----------------------------
+def _oi_common(bg, background, bvariance, points, pobs, obs_variance, pbackground, bvariance_at_points,
+               structure, max_points, allow_extrapolation, want_variance):
+    if max_points < 0:
+        raise ValueError("max_points must be >= 0")
+    if not isinstance(bg, (Grid, Points)) or not isinstance(points, Points):
+        raise TypeError("bgrid must be a Grid or Points, points a Points")
+    if bg.get_coordinate_type() != points.get_coordinate_type():
+        raise ValueError("Both background and observations points must be of same coordinate type (lat/lon or x/y)")
+    nd = 2 if isinstance(bg, Grid) else 1
+    background = _vec(background, nd, "background")
+    shape = tuple(bg.size()) if nd == 2 else (bg.size(),)
+    if _shape(background) != shape:
+        raise ValueError("input field %s is not the same size as the grid %s" % (_shape(background), shape))
+    if bvariance is not None:
+        bvariance = _vec(bvariance, nd, "bvariance")
+        if _shape(bvariance) != shape:
+            raise ValueError("Input bvariance is not the same size as the grid")
+    S = points.size()
+    pobs, obs_variance, pbackground = _vec(pobs, 1, "obs"), _vec(obs_variance, 1, "variance"), _vec(pbackground, 1, "background_at_points")
+    for name, a in (("Observations", pobs), ("Ratios", obs_variance), ("Background", pbackground)):
+        if _shape(a)[0] != S:
+            raise ValueError("%s (%d) and points (%d) size mismatch" % (name, _shape(a)[0], S))
+    if bvariance_at_points is not None:
+        bvariance_at_points = _vec(bvariance_at_points, 1, "bvariance_at_points")
+        if _shape(bvariance_at_points)[0] != S:
+            raise ValueError("Background variance and points size mismatch")
+    mem = _mem(background, bvariance, pobs, obs_variance, pbackground, bvariance_at_points)
+    out = _empty_like_field(shape, background)
+    var = _empty_like_field(shape, background) if want_variance else None
+    check(lib().gpp_optimal_interpolation_full(bg._h, _ptr(background), _ptr(bvariance), points._h, _ptr(pobs),
+                                               _ptr(obs_variance), _ptr(pbackground), _ptr(bvariance_at_points),
+                                               _structure(structure), int(max_points), int(bool(allow_extrapolation)),
+                                               _ptr(out), _ptr(var), mem))
+    return out, var
+
+
+def optimal_interpolation(bgrid, background, points, pobs, pratios, pbackground, structure, max_points, allow_extrapolation=True):
+    """gridpp::optimal_interpolation, Grid (src/api/oi.cpp:26-87) and Points (:89-136) overloads."""
+    return _oi_common(bgrid, background, None, points, pobs, pratios, pbackground, None, structure, max_points,
+                      allow_extrapolation, False)[0]
+
+
+def optimal_interpolation_full(bgrid, background, bvariance, points, obs, obs_variance, background_at_points,
+                               bvariance_at_points, structure, max_points, allow_extrapolation=True):
+    """gridpp::optimal_interpolation_full (src/api/oi.cpp:138-412); returns (analysis, analysis_variance)."""
+    out, var = _oi_common(bgrid, background, bvariance, points, obs, obs_variance, background_at_points,
+                          bvariance_at_points, structure, max_points, allow_extrapolation, True)
+    return out, var
+
+
+def oi_last_stats():
+    s = _capi.gpp_oi_stats()
+    check(lib().gpp_oi_last_stats(C.byref(s)))
+    return dict(cells=s.cells, cells_updated=s.cells_updated, solves=s.solves, fallback_tiles=s.fallback_tiles, kernel_ms=s.kernel_ms)
+
+
+# ---- nearest (src/api/nearest.cpp:124-144) ----------------------------------------------------------
+def nearest(igrid, opoints, values):
+    nd = 2 if isinstance(igrid, Grid) else 1
+    values = _vec(values, nd, "values")
+    shape = tuple(igrid.size()) if nd == 2 else (igrid.size(),)
+    if _shape(values) != shape:
+        raise ValueError("Grid size is not the same as values")
+    if isinstance(opoints, Grid):
+        oshape = tuple(opoints.size())
+    else:
+        oshape = (opoints.size(),)
+    out = _empty_like_field(oshape, values)
+    if int(np.prod(oshape)) == 0:
+        return out
+    check(lib().gpp_nearest(igrid._h, opoints._h, _ptr(values), _ptr(out), _mem(values)))
+    return out

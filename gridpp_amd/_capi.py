@@ -1,0 +1,79 @@
+"""ctypes binding of libgridpp_hip.so (include/gridpp_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or no
+HIP device is visible when a compute entry point is called, this fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgridpp_hip.so")
+
+GPP_OK, GPP_EINVAL, GPP_ERUNTIME, GPP_ENODEVICE = 0, -1, -2, -3
+MEM_HOST, MEM_DEVICE, ASYNC = 0, 1, 2
+
+
+class gpp_structure(C.Structure):
+    _fields_ = [("kind", C.c_int), ("h", C.c_float), ("v", C.c_float), ("w", C.c_float), ("min_rho", C.c_float)]
+
+
+class gpp_oi_stats(C.Structure):
+    _fields_ = [("cells", C.c_longlong), ("cells_updated", C.c_longlong), ("solves", C.c_longlong),
+                ("fallback_tiles", C.c_longlong), ("kernel_ms", C.c_float)]
+
+
+_lib = None
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+# name -> (argtypes); every entry returns int except the two string getters
+SIGNATURES = {
+    "gpp_device_count": [ip],
+    "gpp_set_device": [C.c_int],
+    "gpp_get_stream": [C.POINTER(vp)],
+    "gpp_synchronize": [],
+    "gpp_points_create": [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)],
+    "gpp_grid_create": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+    "gpp_points_destroy": [vp],
+    "gpp_points_size": [vp, ip, ip, ip, ip],
+    "gpp_points_get": [vp, C.c_int, vp],
+    "gpp_convert_coordinates": [vp, vp, C.c_int, C.c_int, vp, vp, vp],
+    "gpp_points_get_neighbours": [vp, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp, C.c_int, ip],
+    "gpp_points_nearest_neighbour": [vp, vp, vp, C.c_int, C.c_int, vp],
+    "gpp_nearest": [vp, vp, vp, vp, C.c_int],
+    "gpp_barnes_min_rho": [C.c_float, C.c_float, fp],
+    "gpp_barnes_localization_distance": [C.POINTER(gpp_structure), fp],
+    "gpp_barnes_corr": [C.POINTER(gpp_structure), fp, fp, fp],
+    "gpp_optimal_interpolation_full": [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, vp, C.c_int],
+    "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
+}
+STRING_GETTERS = ("gpp_last_error", "gpp_version")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("gridpp_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            f = getattr(L, name)
+            f.argtypes = args
+            f.restype = C.c_int
+        for name in STRING_GETTERS:
+            getattr(L, name).restype = C.c_char_p
+            getattr(L, name).argtypes = []
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    """Error convention of swig/gridpp.i:21-40: invalid_argument -> ValueError, the rest -> RuntimeError."""
+    if rc == GPP_OK:
+        return
+    msg = lib().gpp_last_error().decode("utf-8", "replace")
+    if rc == GPP_EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,112 @@
+// Shared host-side definitions of libgridpp_hip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/gridpp_hip.h"
+
+namespace gpp {
+
+// ---- errors ---------------------------------------------------------------
+struct Error {
+    int code;
+    std::string msg;
+};
+void set_error(const char* msg);
+int fail(int code, const char* fmt, ...);
+
+#define GPP_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if(e_ != hipSuccess)                                                                       \
+            throw gpp::Error{GPP_ERUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)};     \
+    } while(0)
+
+// Wrap the body of every extern "C" entry point: no exception crosses the ABI.
+#define GPP_TRY try {
+#define GPP_CATCH                                                             \
+    }                                                                         \
+    catch(const gpp::Error& e) { gpp::set_error(e.msg.c_str()); return e.code; } \
+    catch(const std::exception& e) { gpp::set_error(e.what()); return GPP_ERUNTIME; } \
+    catch(...) { gpp::set_error("Unknown exception"); return GPP_ERUNTIME; }
+
+[[noreturn]] inline void invalid(const std::string& m) { throw Error{GPP_EINVAL, m}; }
+[[noreturn]] inline void runtime(const std::string& m) { throw Error{GPP_ERUNTIME, m}; }
+
+// ---- device runtime ----------------------------------------------------------
+hipStream_t stream();   // library stream (created on first use, after the device is chosen)
+void ensure_device();   // throws GPP_ENODEVICE when no GPU is visible
+
+template <class T>
+struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
+    T* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if(p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    T* get(size_t n) {
+        if(n > cap) {
+            if(p) GPP_HIP(hipFree(p));
+            p = nullptr;
+            GPP_HIP(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
+            cap = n;
+        }
+        return p;
+    }
+    void upload(const T* h, size_t n) {
+        get(n);
+        if(n) GPP_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, stream()));
+    }
+};
+
+// A field argument of the C-ABI resolved to a device pointer: either the caller's
+// HBM pointer (GPP_MEM_DEVICE) or a staged copy (GPP_MEM_HOST).
+struct InField {
+    DevBuf<float> staged;
+    const float* d = nullptr;
+    void bind(const float* src, size_t n, int mem) {
+        if(!src) { d = nullptr; return; }
+        if(mem & GPP_MEM_DEVICE) d = src;
+        else { staged.upload(src, n); d = staged.p; }
+    }
+};
+struct OutField {
+    DevBuf<float> staged;
+    float* d = nullptr;
+    float* host = nullptr;
+    size_t n = 0;
+    void bind(float* dst, size_t n_, int mem) {
+        n = n_;
+        if(!dst) { d = nullptr; host = nullptr; return; }
+        if(mem & GPP_MEM_DEVICE) { d = dst; host = nullptr; }
+        else { d = staged.get(n); host = dst; }
+    }
+    void finish() {
+        if(host && n) GPP_HIP(hipMemcpyAsync(host, d, n * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    }
+};
+
+inline bool is_valid(float v) { return !std::isnan(v) && !std::isinf(v); }   // src/api/util.cpp:16-18
+
+}   // namespace gpp
+
+// ---- point set ---------------------------------------------------------------
+struct gpp_obs_index;   // oi.hip: bin-sorted observation block
+struct gpp_nn_index;    // runtime.hip: uniform-cell index for nearest-neighbour queries
+
+struct gpp_points {
+    int n = 0, ny = 0, nx = 0, type = GPP_GEODETIC;
+    std::vector<float> lats, lons, elevs, lafs, x, y, z;   // host copies (float32, as the reference stores them)
+    gpp::DevBuf<float> d_x, d_y, d_z, d_elev, d_laf;       // HBM-resident SoA
+    bool on_device = false;
+    gpp_obs_index* obs_index = nullptr;
+    gpp_nn_index* nn_index = nullptr;
+    void to_device();
+    ~gpp_points();
+};

@@ -1,0 +1,545 @@
+// Optimal interpolation on MI355X (gfx950): hand-written HIP kernels + the C-ABI entry point.
+//
+// Replaces the OpenMP loop of gridpp::optimal_interpolation_full (src/api/oi.cpp:221-338):
+//   radius query (src/api/kdtree.cpp:39-60,247-260) -> Barnes rho (src/api/structure.cpp:26-34,
+//   185-230) -> filter -> top-max_points by rho (oi.cpp:251-273) -> K = G (P+R)^-1 in double
+//   (oi.cpp:289-316) -> increment, optional clamp (oi.cpp:317-335), analysis variance (:336-337).
+//
+// Mapping (wave64, one tile of 64 grid cells per wavefront, 4 tiles per workgroup):
+//   * the observation set is bin-sorted once per Points object on two projected axes
+//     (gpp_obs_index); a tile walks only the bins its bounding box +R overlaps, with the
+//     observation record read through wave-uniform (scalar) loads;
+//   * every lane owns one cell and keeps its best max_points candidates as 64-bit keys
+//     (rho bits << 32 | ~obs index) in LDS, column-per-lane so no bank conflicts;
+//   * the dense solve is wave-cooperative: lane i holds row i of (P+R) in registers, lanes
+//     N and N+1 carry the right-hand sides (obs-background and G) as extra rows of an
+//     augmented Cholesky factorisation, column broadcasts are v_readlane -> SGPR.  A lane
+//     group that shares one observation set shares the factorisation.
+// Arithmetic follows the reference: float32 coordinates/distances/rho (no FMA contraction,
+// correctly rounded sqrt/div, rho through a double-precision exp), double for the solve.
+#include "common.h"
+#include <algorithm>
+#include <memory>
+
+#pragma clang fp contract(off)
+
+using namespace gpp;
+
+// -------------------------------------------------------------------------------------------
+// observation index (host build, HBM resident)
+// -------------------------------------------------------------------------------------------
+struct gpp_obs_index {
+    int S = 0;
+    int axis_a = 0, axis_b = 1;
+    float amin = 0, bmin = 0, inv_s = 0;
+    int nbx = 1, nby = 1;
+    DevBuf<int> d_bin_start;   // [nbx*nby+1]
+    DevBuf<int> d_pos;         // orig -> sorted position
+    DevBuf<float4> d_sgeo;     // sorted: x,y,z,elev
+    DevBuf<float2> d_smeta;    // sorted: laf, orig (int bits)
+    DevBuf<float4> d_ogeo;     // original order: x,y,z,elev
+    DevBuf<float> d_olaf;      // original order: laf
+};
+void gpp_free_obs_index(gpp_obs_index* p) { delete p; }
+
+static gpp_obs_index* build_obs_index(gpp_points* pts) {
+    if(pts->obs_index) return pts->obs_index;
+    std::unique_ptr<gpp_obs_index> ix(new gpp_obs_index);
+    int S = pts->n;
+    ix->S = S;
+    const std::vector<float>* ax[3] = {&pts->x, &pts->y, &pts->z};
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for(int d = 0; d < 3; d++) {
+        for(int i = 0; i < S; i++) {
+            float v = (*ax[d])[i];
+            if(i == 0 || v < lo[d]) lo[d] = v;
+            if(i == 0 || v > hi[d]) hi[d] = v;
+        }
+    }
+    // project on the two axes with the largest extent (correctness never depends on the bins:
+    // every candidate is re-tested exactly; the bins only bound the work)
+    int order3[3] = {0, 1, 2};
+    std::sort(order3, order3 + 3, [&](int p, int q) { return (hi[p] - lo[p]) > (hi[q] - lo[q]); });
+    int a = std::min(order3[0], order3[1]), b = std::max(order3[0], order3[1]);
+    ix->axis_a = a; ix->axis_b = b;
+    double ea = std::max((double)hi[a] - lo[a], 1e-3), eb = std::max((double)hi[b] - lo[b], 1e-3);
+    double s = std::sqrt(4.0 * ea * eb / std::max(S, 1));   // ~4 observations per bin
+    s = std::max(s, std::max(ea, eb) / 2048.0);
+    int nbx = std::max(1, std::min(2048, (int)std::ceil(ea / s)));
+    int nby = std::max(1, std::min(2048, (int)std::ceil(eb / s)));
+    ix->amin = lo[a]; ix->bmin = lo[b]; ix->inv_s = (float)(1.0 / s);
+    ix->nbx = nbx; ix->nby = nby;
+    std::vector<int> bin(S), start(nbx * nby + 1, 0), order(S), pos(S);
+    for(int i = 0; i < S; i++) {
+        int bx = (int)std::floor(((*ax[a])[i] - ix->amin) * ix->inv_s);
+        int by = (int)std::floor(((*ax[b])[i] - ix->bmin) * ix->inv_s);
+        bx = std::max(0, std::min(nbx - 1, bx));
+        by = std::max(0, std::min(nby - 1, by));
+        bin[i] = by * nbx + bx;
+        start[bin[i] + 1]++;
+    }
+    for(int k = 0; k < nbx * nby; k++) start[k + 1] += start[k];
+    std::vector<int> cur(start.begin(), start.end() - 1);
+    for(int i = 0; i < S; i++) { int p = cur[bin[i]]++; order[p] = i; pos[i] = p; }   // stable: index order inside a bin
+    std::vector<float4> sgeo(S), ogeo(S);
+    std::vector<float2> smeta(S);
+    for(int p = 0; p < S; p++) {
+        int o = order[p];
+        sgeo[p] = make_float4(pts->x[o], pts->y[o], pts->z[o], pts->elevs[o]);
+        float of; memcpy(&of, &o, sizeof(float));
+        smeta[p] = make_float2(pts->lafs[o], of);
+    }
+    for(int o = 0; o < S; o++) ogeo[o] = make_float4(pts->x[o], pts->y[o], pts->z[o], pts->elevs[o]);
+    ix->d_bin_start.upload(start.data(), start.size());
+    ix->d_pos.upload(pos.data(), S);
+    ix->d_sgeo.upload(sgeo.data(), S);
+    ix->d_smeta.upload(smeta.data(), S);
+    ix->d_ogeo.upload(ogeo.data(), S);
+    ix->d_olaf.upload(pts->lafs.data(), S);
+    GPP_HIP(hipStreamSynchronize(stream()));
+    pts->obs_index = ix.release();
+    return pts->obs_index;
+}
+
+// -------------------------------------------------------------------------------------------
+// device helpers
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool d_valid(float v) { return !isnan(v) && !isinf(v); }
+
+// src/api/structure.cpp:26-34
+__device__ __forceinline__ float d_barnes_rho(float dist, float length) {
+    if(!d_valid(length) || length == 0) return 1.0f;
+    if(!d_valid(dist)) return 0.0f;
+    float v = dist / length;
+    double e = -0.5 * (double)v * (double)v;
+    return (float)exp(e);
+}
+// src/api/kdtree.cpp:192-194 (float32, no contraction, correctly rounded sqrt)
+__device__ __forceinline__ float d_chord(float x0, float y0, float z0, float x1, float y1, float z1) {
+    float dx = x0 - x1, dy = y0 - y1, dz = z0 - z1;
+    float s = dx * dx + dy * dy;
+    s = s + dz * dz;
+    return sqrtf(s);
+}
+// src/api/structure.cpp:215-228 (scalar Barnes)
+__device__ __forceinline__ float d_barnes_corr(float x1, float y1, float z1, float e1, float l1,
+                                               float x2, float y2, float z2, float e2, float l2,
+                                               float h, float v, float w, float R) {
+    float hdist = d_chord(x1, y1, z1, x2, y2, z2);
+    if(hdist > R) return 0.0f;
+    float rho = d_barnes_rho(hdist, h);
+    if(d_valid(e1) && d_valid(e2)) rho *= d_barnes_rho(e1 - e2, v);
+    if(d_valid(l1) && d_valid(l2)) rho *= d_barnes_rho(l1 - l2, w);
+    return rho;
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wave_min(float v) {
+    for(int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for(int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__global__ void k_barnes_corr(float4 p1, float l1, float4 p2, float l2, float h, float v, float w, float R, float* out) {
+    out[0] = d_barnes_corr(p1.x, p1.y, p1.z, p1.w, l1, p2.x, p2.y, p2.z, p2.w, l2, h, v, w, R);
+}
+
+// Per-call observation pack: validity (oi.cpp:252), variance ratio (oi.cpp:192-195).
+__global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const int* __restrict__ pos, const float* __restrict__ olaf,
+                           const float* __restrict__ obs, const float* __restrict__ obs_var, const float* __restrict__ pbg,
+                           const float* __restrict__ bvp, int need_pbg, float4* __restrict__ pgeo, float4* __restrict__ oaux) {
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if(o >= S) return;
+    float ob = obs[o], pb = pbg ? pbg[o] : 0.0f;
+    float bv = bvp ? bvp[o] : 1.0f;
+    float ratio = obs_var[o] / bv;
+    oaux[o] = make_float4(olaf[o], ob, pb, ratio);
+    int p = pos[o];
+    float4 g = sgeo[p];
+    bool ok = d_valid(ob) && (!need_pbg || d_valid(pb));
+    if(!ok) g.x = NAN;   // fails the box test of the radius query -> never a candidate
+    pgeo[p] = g;
+}
+
+// -------------------------------------------------------------------------------------------
+// the OI kernel
+// -------------------------------------------------------------------------------------------
+struct OiArgs {
+    const float *gx, *gy, *gz, *gelev, *glaf, *bg, *bvar;
+    float *out, *out_var;
+    int C, ny, nx, tiles_x, ntiles, tiled2d;
+    const float4* pgeo;      // sorted, per call (x = NaN when the observation is unusable)
+    const float2* smeta;     // sorted: laf, orig
+    const int* bin_start;
+    const float4* ogeo;      // original order
+    const float4* oaux;      // original order: laf, obs, pbg, ratio
+    int S, axis_a, axis_b, nbx, nby;
+    float amin, bmin, inv_s;
+    float h, v, w, R;
+    int K;                   // list capacity in use: min(max_points, N) (N if max_points == 0)
+    int max_points, allow_extrap, monotone;
+    int* err;                // bit0: list overflow (needs the large-n path), bit1: singular / not SPD
+    unsigned long long* counters;   // [0] cells updated, [1] factorisations
+};
+
+#define ERR_OVERFLOW 1
+#define ERR_SINGULAR 2
+
+template <int N>
+__global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
+    __shared__ unsigned long long s_keys[4][N][64];
+    __shared__ float s_res[4][2][64];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wid;
+    if(tile >= a.ntiles) return;
+
+    int cell = -1;
+    if(a.tiled2d) {
+        int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        int y = ty * 8 + (lane >> 3), x = tx * 8 + (lane & 7);
+        if(y < a.ny && x < a.nx) cell = y * a.nx + x;
+    }
+    else {
+        int c = tile * 64 + lane;
+        if(c < a.C) cell = c;
+    }
+    float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN, bg = NAN, bvar = 1.0f;
+    if(cell >= 0) {
+        gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell];
+        bg = a.bg[cell];
+        if(a.bvar) bvar = a.bvar[cell];
+    }
+    const bool active = cell >= 0 && d_valid(bg);   // oi.cpp:223
+    float res_out = bg, res_var = bvar;              // oi.cpp:198-199
+    unsigned long long (*keys)[64] = s_keys[wid];
+
+    int cnt = 0;
+    if(__ballot(active) != 0ull) {
+        // ---- bins overlapped by the tile's bounding box + R -------------------------------
+        const float R = a.R;
+        float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
+        float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
+        float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
+        float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
+        int bx0 = (int)floorf((amin_t - R - a.amin) * a.inv_s) - 1, bx1 = (int)floorf((amax_t + R - a.amin) * a.inv_s) + 1;
+        int by0 = (int)floorf((bmin_t - R - a.bmin) * a.inv_s) - 1, by1 = (int)floorf((bmax_t + R - a.bmin) * a.inv_s) + 1;
+        bx0 = __builtin_amdgcn_readfirstlane(max(bx0, 0)); bx1 = __builtin_amdgcn_readfirstlane(min(bx1, a.nbx - 1));
+        by0 = __builtin_amdgcn_readfirstlane(max(by0, 0)); by1 = __builtin_amdgcn_readfirstlane(min(by1, a.nby - 1));
+
+        // strictly-inside box of the radius query (kdtree.cpp:46,53)
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        const int K = a.K;
+        unsigned long long wkey = 0;   // worst key kept
+        int wslot = 0;
+        float thr2 = INFINITY;         // monotone mode: candidates with d2 > thr2 cannot enter the list
+        const float h2 = a.h * a.h;
+        bool overflow = false;
+
+        if(bx0 <= bx1) for(int by = by0; by <= by1; ++by) {
+            const int js = a.bin_start[by * a.nbx + bx0], je = a.bin_start[by * a.nbx + bx1 + 1];
+            for(int j = js; j < je; ++j) {
+                const float4 g0 = a.pgeo[j];
+                const float ox = g0.x, oy = g0.y, oz = g0.z;
+                bool in = active && ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+                float d2 = dx * dx + dy * dy;
+                d2 = d2 + dz * dz;
+                in = in && (d2 <= thr2);
+                if(in) {
+                    float dist = sqrtf(d2);
+                    if(dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
+                        const float2 m = a.smeta[j];
+                        float rho = d_barnes_rho(dist, a.h);
+                        if(d_valid(ge) && d_valid(g0.w)) rho *= d_barnes_rho(ge - g0.w, a.v);
+                        if(d_valid(gl) && d_valid(m.x)) rho *= d_barnes_rho(gl - m.x, a.w);
+                        if(rho > 0.0f) {   // oi.cpp:253
+                            unsigned orig = (unsigned)__float_as_int(m.y);
+                            unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
+                            if(cnt < K) {
+                                keys[cnt][lane] = key;
+                                if(cnt == 0 || key < wkey) { wkey = key; wslot = cnt; }
+                                cnt++;
+                            }
+                            else if(a.max_points > 0 && a.max_points <= N) {
+                                if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
+                                    keys[wslot][lane] = key;
+                                    wkey = key;
+                                    for(int s = 0; s < K; ++s) {
+                                        unsigned long long k2 = keys[s][lane];
+                                        if(k2 < wkey) { wkey = k2; wslot = s; }
+                                    }
+                                }
+                            }
+                            else overflow = true;   // more than N usable observations requested
+                            if(a.monotone && cnt == K && a.max_points > 0 && a.max_points <= N) {
+                                float wr = __uint_as_float((unsigned)(wkey >> 32));
+                                thr2 = -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if(__ballot(overflow) != 0ull) {
+            if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);
+            cnt = overflow ? 0 : cnt;
+        }
+
+        // ---- dense solves: one augmented Cholesky per cell ---------------------------------
+        unsigned long long todo = __ballot(cnt > 0);
+        int nsolve = 0;
+        bool bad = false;
+        while(todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            nsolve++;
+            const int n = __builtin_amdgcn_readlane(cnt, l);
+            // lane i < n takes the i-th selected observation of cell l
+            unsigned long long key = (lane < n) ? keys[lane][l] : 0ull;
+            float rho_i = __uint_as_float((unsigned)(key >> 32));
+            unsigned orig_i = ~(unsigned)(key & 0xffffffffull);
+            float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
+            if(lane < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
+            double row[N];
+            float maxInc = -INFINITY, minInc = INFINITY;
+#pragma unroll
+            for(int p = 0; p < N; ++p) {
+                double v = 0.0;
+                if(p < n) {
+                    float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
+                    float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
+                    float c = d_barnes_corr(o0.x, o0.y, o0.z, o0.w, o1.x, xp, yp, zp, ep, lp, a.h, a.v, a.w, a.R);   // oi.cpp:304-312
+                    v = (double)c;
+                    if(lane == p) v += (double)o1.w;                                                                 // lP + lR
+                    double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);                          // lObs - lY
+                    float gp = readlane_f(rho_i, p);
+                    float dpf = (float)dp;
+                    maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
+                    if(lane == N) v = dp;
+                    if(lane == N + 1) v = (double)gp;
+                    if(lane > N + 1 || (lane >= n && lane < N)) v = 0.0;
+                }
+                row[p] = v;
+            }
+            // right-looking Cholesky on rows-in-lanes; rows N, N+1 become L^-1 d and L^-1 g
+#pragma unroll
+            for(int j = 0; j < N; ++j) {
+                if(j < n) {
+                    double ajj = readlane_d(row[j], j);
+                    if(!(ajj > 0.0)) bad = true;
+                    double r = __builtin_amdgcn_rsq(ajj);
+                    r = r * (1.5 - 0.5 * ajj * r * r);
+                    r = r * (1.5 - 0.5 * ajj * r * r);
+                    double cj = row[j] * r;
+                    row[j] = cj;
+#pragma unroll
+                    for(int p = j + 1; p < N; ++p) {
+                        double lpj = readlane_d(cj, p);
+                        row[p] = __builtin_fma(-cj, lpj, row[p]);
+                    }
+                }
+            }
+            double inc = 0.0, a00 = 0.0;
+#pragma unroll
+            for(int p = 0; p < N; ++p) {
+                double tp = readlane_d(row[p], N);
+                inc = __builtin_fma(row[p], tp, inc);      // lGSR * (lObs - lY)   (oi.cpp:316)
+                a00 = __builtin_fma(row[p], row[p], a00);  // lGSR * lG^T          (oi.cpp:336)
+            }
+            if(lane == N + 1) {
+                float increment = (float)inc;   // oi.cpp:317
+                if(!a.allow_extrap) {           // oi.cpp:318-334
+                    if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                    else if(maxInc < 0 && increment > 0) increment = maxInc;
+                    else if(minInc < 0 && increment < minInc) increment = minInc;
+                    else if(minInc > 0 && increment < 0) increment = minInc;
+                }
+                float bgl = readlane_f(bg, l), bvl = readlane_f(bvar, l);
+                s_res[wid][0][l] = bgl + increment;                       // oi.cpp:335
+                s_res[wid][1][l] = (float)((double)bvl * (1.0 - a00));    // oi.cpp:337
+            }
+            else {
+                (void)readlane_f(bg, l); (void)readlane_f(bvar, l);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if(cnt > 0) { res_out = s_res[wid][0][lane]; res_var = s_res[wid][1][lane]; }
+        if(__ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
+        if(lane == 0 && a.counters) {
+            atomicAdd(&a.counters[0], (unsigned long long)__popcll(__ballot(cnt > 0)));
+            atomicAdd(&a.counters[1], (unsigned long long)nsolve);
+        }
+    }
+    if(cell >= 0) {
+        a.out[cell] = res_out;
+        if(a.out_var) a.out_var[cell] = res_var;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// host entry point
+// -------------------------------------------------------------------------------------------
+namespace {
+struct OiWorkspace {
+    DevBuf<float4> pgeo, oaux;
+    DevBuf<float> ones;
+    DevBuf<int> err;
+    DevBuf<unsigned long long> counters;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+thread_local OiWorkspace g_ws;
+thread_local gpp_oi_stats g_stats;
+}
+
+extern "C" int gpp_oi_last_stats(gpp_oi_stats* s) {
+    GPP_TRY
+    if(!s) invalid("stats is NULL");
+    *s = g_stats;
+    return GPP_OK;
+    GPP_CATCH
+}
+
+extern "C" int gpp_barnes_min_rho(float h, float hmax, float* min_rho) {
+    GPP_TRY
+    if(!min_rho) invalid("NULL");
+    // structure.cpp:143-159
+    if(is_valid(hmax) && hmax < 0) invalid("hmax must be >= 0");
+    if(!is_valid(h) || h < 0) invalid("h must be >= 0");
+    if(is_valid(hmax)) *min_rho = (float)std::exp(std::pow((double)(hmax / h), 2) / -2);
+    else *min_rho = 0.0013f;
+    return GPP_OK;
+    GPP_CATCH
+}
+static float loc_dist(const gpp_structure* s) { return sqrtf(-2 * logf(s->min_rho)) * s->h; }   // structure.cpp:280-282
+static void check_structure(const gpp_structure* s) {
+    if(!s) invalid("structure is NULL");
+    if(s->kind != 0) throw Error{GPP_ERUNTIME, "only the scalar BarnesStructure runs on the GPU path"};
+    if(!is_valid(s->h) || s->h < 0) invalid("h must be >= 0");
+    if(!is_valid(s->v) || s->v < 0) invalid("v must be >= 0");
+    if(!is_valid(s->w) || s->w < 0) invalid("w must be >= 0");
+}
+extern "C" int gpp_barnes_localization_distance(const gpp_structure* s, float* dist) {
+    GPP_TRY
+    check_structure(s);
+    *dist = loc_dist(s);
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_barnes_corr(const gpp_structure* s, const float p1[5], const float p2[5], float* rho) {
+    GPP_TRY
+    check_structure(s);
+    DevBuf<float> out;
+    out.get(1);
+    hipLaunchKernelGGL(k_barnes_corr, dim3(1), dim3(1), 0, stream(), make_float4(p1[0], p1[1], p1[2], p1[3]), p1[4],
+                       make_float4(p2[0], p2[1], p2[2], p2[3]), p2[4], s->h, s->v, s->w, loc_dist(s), out.p);
+    GPP_HIP(hipGetLastError());
+    GPP_HIP(hipMemcpyAsync(rho, out.p, sizeof(float), hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* background, const float* bvariance,
+                                              gpp_points* points, const float* obs, const float* obs_variance,
+                                              const float* background_at_points, const float* bvariance_at_points,
+                                              const gpp_structure* st, int max_points, int allow_extrapolation,
+                                              float* out, float* out_variance, int mem) {
+    GPP_TRY
+    // argument checks of oi.cpp:152-186 (sizes are implied by the handles; pointers must be present)
+    if(max_points < 0) invalid("max_points must be >= 0");
+    if(!bgrid || !points) invalid("grid/points handle is NULL");
+    if(bgrid->type != points->type)
+        invalid("Both background and observations points must be of same coordinate type (lat/lon or x/y)");
+    check_structure(st);
+    const int C = bgrid->n, S = points->n;
+    if(C > 0 && (!background || !out)) invalid("background/out is NULL");
+    if(S > 0 && (!obs || !obs_variance || !background_at_points)) invalid("observation arrays are NULL");
+    ensure_device();
+    g_stats = gpp_oi_stats();
+    g_stats.cells = C;
+    if(C == 0) return GPP_OK;
+
+    OiWorkspace& ws = g_ws;
+    InField f_bg, f_bvar, f_obs, f_ov, f_pbg, f_bvp;
+    OutField f_out, f_var;
+    f_bg.bind(background, C, mem);
+    f_bvar.bind(bvariance, C, mem);
+    f_out.bind(out, C, mem);
+    f_var.bind(out_variance, C, mem);
+
+    if(S == 0) {   // oi.cpp:189-190: return the background
+        GPP_HIP(hipMemcpyAsync(f_out.d, f_bg.d, sizeof(float) * C, hipMemcpyDeviceToDevice, stream()));
+        if(f_var.d) {
+            if(f_bvar.d) GPP_HIP(hipMemcpyAsync(f_var.d, f_bvar.d, sizeof(float) * C, hipMemcpyDeviceToDevice, stream()));
+            else invalid("bvariance is required when the variance is requested and there are no observations");
+        }
+        f_out.finish(); f_var.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));
+        return GPP_OK;
+    }
+    f_obs.bind(obs, S, mem);
+    f_ov.bind(obs_variance, S, mem);
+    f_pbg.bind(background_at_points, S, mem);
+    f_bvp.bind(bvariance_at_points, S, mem);
+
+    bgrid->to_device();
+    gpp_obs_index* ix = build_obs_index(points);
+
+    if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
+    ws.pgeo.get(S); ws.oaux.get(S);
+    ws.err.get(1); ws.counters.get(4);
+    GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
+    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 4, stream()));
+    hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
+                       f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p);
+    GPP_HIP(hipGetLastError());
+
+    constexpr int N = 32;
+    OiArgs a;
+    a.gx = bgrid->d_x.p; a.gy = bgrid->d_y.p; a.gz = bgrid->d_z.p; a.gelev = bgrid->d_elev.p; a.glaf = bgrid->d_laf.p;
+    a.bg = f_bg.d; a.bvar = f_bvar.d; a.out = f_out.d; a.out_var = f_var.d;
+    a.C = C; a.ny = bgrid->ny; a.nx = bgrid->nx;
+    a.tiled2d = (bgrid->nx > 0 && (long)bgrid->ny * bgrid->nx == C) ? 1 : 0;
+    if(a.tiled2d) { a.tiles_x = (a.nx + 7) / 8; a.ntiles = a.tiles_x * ((a.ny + 7) / 8); }
+    else { a.tiles_x = 0; a.ntiles = (C + 63) / 64; }
+    a.pgeo = ws.pgeo.p; a.smeta = ix->d_smeta.p; a.bin_start = ix->d_bin_start.p;
+    a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
+    a.S = S; a.axis_a = ix->axis_a; a.axis_b = ix->axis_b; a.nbx = ix->nbx; a.nby = ix->nby;
+    a.amin = ix->amin; a.bmin = ix->bmin; a.inv_s = ix->inv_s;
+    a.h = st->h; a.v = st->v; a.w = st->w; a.R = loc_dist(st);
+    a.max_points = max_points; a.allow_extrap = allow_extrapolation ? 1 : 0;
+    a.K = (max_points > 0 && max_points <= N) ? max_points : N;
+    a.monotone = (st->v == 0 && st->w == 0) ? 1 : 0;
+    a.err = ws.err.p; a.counters = ws.counters.p;
+
+    GPP_HIP(hipEventRecord(ws.e0, stream()));
+    hipLaunchKernelGGL(k_oi<N>, dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
+    GPP_HIP(hipGetLastError());
+    GPP_HIP(hipEventRecord(ws.e1, stream()));
+
+    int err = 0;
+    unsigned long long counters[4];
+    GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipMemcpyAsync(counters, ws.counters.p, sizeof(counters), hipMemcpyDeviceToHost, stream()));
+    f_out.finish(); f_var.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    float ms = 0;
+    GPP_HIP(hipEventElapsedTime(&ms, ws.e0, ws.e1));
+    g_stats.kernel_ms = ms;
+    g_stats.cells_updated = (long long)counters[0];
+    g_stats.solves = (long long)counters[1];
+    if(err & ERR_SINGULAR) runtime("optimal_interpolation: local (P+R) matrix is singular");
+    if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more than 32 observations per grid point requested (max_points == 0 or > 32): large-n path not built yet");
+    return GPP_OK;
+    GPP_CATCH
+}

@@ -1,0 +1,344 @@
+// Runtime, point sets and neighbour queries of libgridpp_hip.so.
+#include "common.h"
+#include <algorithm>
+#include <thread>
+#include <mutex>
+
+namespace gpp {
+
+static thread_local std::string g_last_error;
+void set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+static hipStream_t g_stream = nullptr;
+static int g_device = -1;
+static std::mutex g_mutex;
+
+void ensure_device() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if(g_device >= 0) return;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if(e != hipSuccess || count == 0) throw Error{GPP_ENODEVICE, "no HIP device visible (libgridpp_hip has no CPU path)"};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    g_device = dev;
+    GPP_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+}
+hipStream_t stream() {
+    ensure_device();
+    return g_stream;
+}
+
+}   // namespace gpp
+
+using namespace gpp;
+
+extern "C" const char* gpp_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* gpp_version(void) { return "0.8.0.dev1+mi355x.r1"; }
+
+extern "C" int gpp_device_count(int* count) {
+    GPP_TRY
+    if(!count) invalid("count is NULL");
+    int c = 0;
+    if(hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *count = c;
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_set_device(int device) {
+    GPP_TRY
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int count = 0;
+    if(hipGetDeviceCount(&count) != hipSuccess || count == 0) throw Error{GPP_ENODEVICE, "no HIP device visible"};
+    if(device < 0 || device >= count) invalid("device index out of range");
+    GPP_HIP(hipSetDevice(device));
+    if(g_device != device) {
+        if(g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+        g_device = device;
+        GPP_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    }
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_get_stream(void** s) {
+    GPP_TRY
+    if(!s) invalid("stream is NULL");
+    *s = (void*)stream();
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_synchronize(void) {
+    GPP_TRY
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+// ---- coordinates (src/api/util.cpp:583-624) -----------------------------------
+// Host libm on purpose: x/y/z are float32 roundings of double cos/sin products; using the
+// same libm as the reference build keeps every coordinate (and therefore every float32
+// distance, radius membership and nearest-neighbour index) bit-identical.
+static const double kRadiusEarth = 6.378137e6;   // include/gridpp.h:55
+
+static bool convert_range(const float* lats, const float* lons, int i0, int i1, int type, float* x, float* y, float* z) {
+    for(int i = i0; i < i1; i++) {
+        float lat = lats[i], lon = lons[i];
+        bool ok = (type == GPP_CARTESIAN) ? is_valid(lat) : (is_valid(lat) && lat >= -90.001 && lat <= 90.001);
+        if(!ok || !is_valid(lon)) return false;
+        if(type == GPP_CARTESIAN) { x[i] = lon; y[i] = lat; z[i] = 0; }
+        else {
+            double lonr = M_PI / 180 * lon, latr = M_PI / 180 * lat;
+            x[i] = (float)(std::cos(latr) * std::cos(lonr) * kRadiusEarth);
+            y[i] = (float)(std::cos(latr) * std::sin(lonr) * kRadiusEarth);
+            z[i] = (float)(std::sin(latr) * kRadiusEarth);
+        }
+    }
+    return true;
+}
+static void convert_all(const float* lats, const float* lons, int n, int type, float* x, float* y, float* z) {
+    if(type != GPP_GEODETIC && type != GPP_CARTESIAN) invalid("Unknown coordinate type");
+    int nt = (int)std::min<long>(std::max(1u, std::thread::hardware_concurrency()), std::max(1, n / 65536));
+    bool ok = true;
+    if(nt <= 1) ok = convert_range(lats, lons, 0, n, type, x, y, z);
+    else {
+        std::vector<std::thread> th;
+        std::vector<char> oks(nt, 1);
+        for(int t = 0; t < nt; t++) {
+            int i0 = (int)((long)n * t / nt), i1 = (int)((long)n * (t + 1) / nt);
+            th.emplace_back([=, &oks]() { oks[t] = convert_range(lats, lons, i0, i1, type, x, y, z); });
+        }
+        for(auto& t : th) t.join();
+        for(char c : oks) ok = ok && c;
+    }
+    if(!ok) invalid("Invalid coords");   // util.cpp:596-600
+}
+
+extern "C" int gpp_convert_coordinates(const float* lats, const float* lons, int n, int type, float* x, float* y, float* z) {
+    GPP_TRY
+    if(n < 0) invalid("n < 0");
+    convert_all(lats, lons, n, type, x, y, z);
+    return GPP_OK;
+    GPP_CATCH
+}
+
+// ---- point sets ---------------------------------------------------------------
+void gpp_points::to_device() {
+    if(on_device) return;
+    d_x.upload(x.data(), n);
+    d_y.upload(y.data(), n);
+    d_z.upload(z.data(), n);
+    d_elev.upload(elevs.data(), n);
+    d_laf.upload(lafs.data(), n);
+    GPP_HIP(hipStreamSynchronize(gpp::stream()));
+    on_device = true;
+}
+void gpp_free_obs_index(gpp_obs_index*);
+struct gpp_nn_index { int unused; };
+void gpp_free_nn_index(gpp_nn_index* p) { delete p; }
+gpp_points::~gpp_points() {
+    if(obs_index) gpp_free_obs_index(obs_index);
+    if(nn_index) gpp_free_nn_index(nn_index);
+}
+
+static gpp_points* make_points(const float* lats, const float* lons, const float* elevs, const float* lafs, int n, int ny, int nx, int type) {
+    if(n < 0) invalid("negative size");
+    if(n > 0 && (!lats || !lons)) invalid("lats/lons are NULL");
+    std::unique_ptr<gpp_points> p(new gpp_points);
+    p->n = n; p->ny = ny; p->nx = nx; p->type = type;
+    p->lats.assign(lats, lats + n);
+    p->lons.assign(lons, lons + n);
+    if(elevs) p->elevs.assign(elevs, elevs + n); else p->elevs.assign(n, NAN);   // points.cpp:23-30, grid.cpp:41-54
+    if(lafs) p->lafs.assign(lafs, lafs + n); else p->lafs.assign(n, NAN);
+    p->x.resize(n); p->y.resize(n); p->z.resize(n);
+    convert_all(p->lats.data(), p->lons.data(), n, type, p->x.data(), p->y.data(), p->z.data());
+    return p.release();
+}
+
+extern "C" int gpp_points_create(const float* lats, const float* lons, const float* elevs, const float* lafs, int n, int type, gpp_points** out) {
+    GPP_TRY
+    if(!out) invalid("out is NULL");
+    *out = make_points(lats, lons, elevs, lafs, n, 0, 0, type);
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_grid_create(const float* lats, const float* lons, const float* elevs, const float* lafs, int ny, int nx, int type, gpp_points** out) {
+    GPP_TRY
+    if(!out) invalid("out is NULL");
+    if(ny < 0 || nx < 0) invalid("negative grid size");
+    if((long)ny * nx > 0x7fffffffL) invalid("grid too large");
+    *out = make_points(lats, lons, elevs, lafs, ny * nx, ny, nx, type);
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_points_destroy(gpp_points* p) {
+    GPP_TRY
+    delete p;
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_points_size(const gpp_points* p, int* n, int* ny, int* nx, int* type) {
+    GPP_TRY
+    if(!p) invalid("points is NULL");
+    if(n) *n = p->n;
+    if(ny) *ny = p->ny;
+    if(nx) *nx = p->nx;
+    if(type) *type = p->type;
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_points_get(const gpp_points* p, int field, float* out) {
+    GPP_TRY
+    if(!p) invalid("points is NULL");
+    const std::vector<float>* v = nullptr;
+    switch(field) {
+        case 0: v = &p->lats; break;
+        case 1: v = &p->lons; break;
+        case 2: v = &p->elevs; break;
+        case 3: v = &p->lafs; break;
+        case 4: v = &p->x; break;
+        case 5: v = &p->y; break;
+        case 6: v = &p->z; break;
+        default: invalid("unknown field");
+    }
+    if(p->n) memcpy(out, v->data(), sizeof(float) * p->n);
+    return GPP_OK;
+    GPP_CATCH
+}
+
+// ---- radius query for a single location (host; API completeness, not the hot path) ----
+// Exact restatement of kdtree.cpp:39-60 + within_radius :247-260 on the float32 x/y/z.
+#pragma clang fp contract(off)
+static inline float chord(float x0, float y0, float z0, float x1, float y1, float z1) {
+    return sqrtf((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1) + (z0 - z1) * (z0 - z1));
+}
+extern "C" int gpp_points_get_neighbours(gpp_points* p, float lat, float lon, float radius, int include_match,
+                                         int* indices, float* distances, int cap, int* count) {
+    GPP_TRY
+    if(!p || !count) invalid("NULL argument");
+    float qx, qy, qz;
+    convert_all(&lat, &lon, 1, p->type, &qx, &qy, &qz);
+    float lox = qx - radius, hix = qx + radius, loy = qy - radius, hiy = qy + radius, loz = qz - radius, hiz = qz + radius;
+    int c = 0;
+    for(int i = 0; i < p->n; i++) {
+        float px = p->x[i], py = p->y[i], pz = p->z[i];
+        if(!(px > lox && px < hix && py > loy && py < hiy && pz > loz && pz < hiz)) continue;
+        float d = chord(px, py, pz, qx, qy, qz);
+        bool in = include_match ? (d <= radius) : (d <= radius && d > 0);
+        if(!in) continue;
+        if(c < cap) {
+            if(indices) indices[c] = i;
+            if(distances) distances[c] = d;
+        }
+        c++;
+    }
+    *count = c;
+    return GPP_OK;
+    GPP_CATCH
+}
+
+// ---- nearest neighbour (device, brute force over the point set; one wave per query) ----
+// Metric = float32 squared chord distance in the reference's operation order (Boost
+// comparable_distance on point<float,3>); ties -> lowest index (R-tree order is unspecified).
+__global__ __launch_bounds__(256) void k_nearest_bruteforce(const float* __restrict__ px, const float* __restrict__ py,
+                                                            const float* __restrict__ pz, int n,
+                                                            const float* __restrict__ qx, const float* __restrict__ qy,
+                                                            const float* __restrict__ qz, int nq, int include_match,
+                                                            int* __restrict__ out) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if(wave >= nq) return;
+    float x = qx[wave], y = qy[wave], z = qz[wave];
+    float best = INFINITY;
+    int besti = 0x7fffffff;
+    for(int i = lane; i < n; i += 64) {
+        float ax = px[i], ay = py[i], az = pz[i];
+        if(!include_match && ax == x && ay == y && az == z) continue;   // kdtree.cpp:265-270
+        float dx = ax - x, dy = ay - y, dz = az - z;
+        float s = dx * dx + dy * dy;
+        s = s + dz * dz;
+        if(s < best || (s == best && i < besti)) { best = s; besti = i; }
+    }
+    for(int off = 32; off > 0; off >>= 1) {
+        float ob = __shfl_xor(best, off);
+        int oi = __shfl_xor(besti, off);
+        if(ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if(lane == 0) out[wave] = (besti == 0x7fffffff) ? -1 : besti;
+}
+
+static void nearest_device(gpp_points* p, const float* d_qx, const float* d_qy, const float* d_qz, int nq, int include_match, int* d_out) {
+    p->to_device();
+    if(nq == 0) return;
+    int waves_per_block = 4;
+    int blocks = (nq + waves_per_block - 1) / waves_per_block;
+    hipLaunchKernelGGL(k_nearest_bruteforce, dim3(blocks), dim3(256), 0, stream(), p->d_x.p, p->d_y.p, p->d_z.p, p->n,
+                       d_qx, d_qy, d_qz, nq, include_match, d_out);
+    GPP_HIP(hipGetLastError());
+}
+
+extern "C" int gpp_points_nearest_neighbour(gpp_points* p, const float* qlats, const float* qlons, int nq, int include_match, int* indices) {
+    GPP_TRY
+    if(!p) invalid("points is NULL");
+    if(nq < 0) invalid("nq < 0");
+    if(nq == 0) return GPP_OK;
+    if(p->n == 0) { for(int i = 0; i < nq; i++) indices[i] = -1; return GPP_OK; }   // points.cpp:55-61
+    std::vector<float> qx(nq), qy(nq), qz(nq);
+    convert_all(qlats, qlons, nq, p->type, qx.data(), qy.data(), qz.data());
+    DevBuf<float> dx, dy, dz;
+    DevBuf<int> dout;
+    dx.upload(qx.data(), nq); dy.upload(qy.data(), nq); dz.upload(qz.data(), nq);
+    dout.get(nq);
+    nearest_device(p, dx.p, dy.p, dz.p, nq, include_match, dout.p);
+    GPP_HIP(hipMemcpyAsync(indices, dout.p, sizeof(int) * nq, hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+__global__ void k_gather(const float* __restrict__ values, const int* __restrict__ idx, int n, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = idx[i] >= 0 ? values[idx[i]] : NAN;
+}
+__global__ void k_fill(float* out, int n, float v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = v;
+}
+
+extern "C" int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* out, int mem) {
+    GPP_TRY
+    if(!from || !to) invalid("points is NULL");
+    if(from->type != to->type) invalid("Coordinate types must be the same");
+    int nq = to->n;
+    if(nq == 0) return GPP_OK;
+    OutField o;
+    o.bind(out, nq, mem);
+    if(from->n == 0) {   // nearest.cpp:132-134
+        hipLaunchKernelGGL(k_fill, dim3((nq + 255) / 256), dim3(256), 0, stream(), o.d, nq, NAN);
+    }
+    else {
+        InField v;
+        v.bind(values, from->n, mem);
+        to->to_device();
+        DevBuf<int> idx;
+        idx.get(nq);
+        nearest_device(from, to->d_x.p, to->d_y.p, to->d_z.p, nq, 1, idx.p);
+        hipLaunchKernelGGL(k_gather, dim3((nq + 255) / 256), dim3(256), 0, stream(), v.d, idx.p, nq, o.d);
+        GPP_HIP(hipGetLastError());
+        o.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));   // staged buffers die with this scope
+        return GPP_OK;
+    }
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}

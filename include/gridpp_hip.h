@@ -1,0 +1,142 @@
+/*
+ * gridpp_hip.h -- C-ABI of the MI355X-native gridpp hot path (libgridpp_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, int status codes, no
+ * C++ / torch types.  Each entry point names the reference interface it
+ * replaces (paths relative to the metno/gridpp repository root).  The C++ host
+ * mirror (gridpp_amd/host/gridpp.hpp) and the Python mirror (gridpp_amd/)
+ * both bind exactly these symbols; INTEGRATION.md shows the binding a gridpp
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every function returns GPP_OK or a negative error code; the message of the
+ *    last error on the calling thread is gpp_last_error().
+ *      GPP_EINVAL   -> std::invalid_argument / Python ValueError
+ *      GPP_ERUNTIME -> std::runtime_error    / Python RuntimeError
+ *  - `mem` says where the caller's field arrays live: GPP_MEM_HOST (the library
+ *    stages them through HBM) or GPP_MEM_DEVICE (pointers are HBM addresses of
+ *    the current device, e.g. torch tensor .data_ptr(); nothing is copied).
+ *    Coordinate arrays given to the *_create functions are always host arrays.
+ *  - 2-D fields are row-major [Y][X]; 3-D fields are [Y][X][E] with E fastest
+ *    (swig/vector.i:385-390).
+ *  - all work is enqueued on the library stream (gpp_get_stream) and the call
+ *    returns after the stream is synchronised, unless GPP_MEM_DEVICE |
+ *    GPP_ASYNC is given.
+ */
+#ifndef GRIDPP_HIP_H
+#define GRIDPP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPP_OK 0
+#define GPP_EINVAL -1
+#define GPP_ERUNTIME -2
+#define GPP_ENODEVICE -3
+
+#define GPP_MEM_HOST 0
+#define GPP_MEM_DEVICE 1
+#define GPP_ASYNC 2
+
+/* include/gridpp.h:120-123 */
+#define GPP_GEODETIC 0
+#define GPP_CARTESIAN 1
+
+/* include/gridpp.h:88-100 */
+#define GPP_MEAN 0
+#define GPP_MIN 10
+#define GPP_MEDIAN 20
+#define GPP_MAX 30
+#define GPP_QUANTILE 40
+#define GPP_STD 50
+#define GPP_VARIANCE 60
+#define GPP_SUM 70
+#define GPP_COUNT 80
+#define GPP_RANDOMCHOICE 90
+
+/* ---- runtime ----------------------------------------------------------- */
+const char* gpp_last_error(void);
+const char* gpp_version(void);            /* include/gridpp.h:15 GRIDPP_VERSION */
+int gpp_device_count(int* count);
+int gpp_set_device(int device);           /* one process per GPU: call once with LOCAL_RANK */
+int gpp_get_stream(void** hip_stream);    /* the hipStream_t all kernels are launched on */
+int gpp_synchronize(void);
+
+/* ---- point sets: gridpp::Points / gridpp::Grid / gridpp::KDTree ----------
+ * replaces gridpp::Points::Points (src/api/points.cpp:9-31),
+ * gridpp::Grid::Grid (src/api/grid.cpp:12-55) and KDTree::KDTree
+ * (src/api/kdtree.cpp:6-16): validates coordinates, converts lat/lon to the
+ * float32 x,y,z of src/api/util.cpp:596-612 and keeps them resident in HBM.
+ * elevs / lafs may be NULL (filled with NaN).  A grid is a point set with
+ * nx > 0 (row-major, index = y*nx + x, src/api/grid.cpp:108-114). */
+typedef struct gpp_points gpp_points;
+int gpp_points_create(const float* lats, const float* lons, const float* elevs, const float* lafs,
+                      int n, int coordinate_type, gpp_points** out);
+int gpp_grid_create(const float* lats, const float* lons, const float* elevs, const float* lafs,
+                    int ny, int nx, int coordinate_type, gpp_points** out);
+int gpp_points_destroy(gpp_points* p);
+int gpp_points_size(const gpp_points* p, int* n, int* ny, int* nx, int* coordinate_type);
+/* field: 0 lat, 1 lon, 2 elev, 3 laf, 4 x, 5 y, 6 z; copies n floats to host `out` */
+int gpp_points_get(const gpp_points* p, int field, float* out);
+
+/* gridpp::convert_coordinates (src/api/util.cpp:583-615), host arrays */
+int gpp_convert_coordinates(const float* lats, const float* lons, int n, int coordinate_type,
+                            float* x, float* y, float* z);
+
+/* KDTree::get_neighbours (src/api/kdtree.cpp:39-60): indices (ascending) of the
+ * points strictly inside the +-radius box and within `radius` chord distance of
+ * (lat, lon).  Writes at most `cap` indices; *count is the full count. */
+int gpp_points_get_neighbours(gpp_points* p, float lat, float lon, float radius, int include_match,
+                              int* indices, float* distances /* may be NULL */, int cap, int* count);
+/* KDTree::get_nearest_neighbour / Points::get_nearest_neighbour
+ * (src/api/kdtree.cpp:82-106, src/api/points.cpp:55-61) for nq query points
+ * (host arrays); index -1 when the set is empty or nothing qualifies. */
+int gpp_points_nearest_neighbour(gpp_points* p, const float* qlats, const float* qlons, int nq,
+                                 int include_match, int* indices);
+/* gridpp::nearest(Grid|Points, Points, values) (src/api/nearest.cpp:124-144):
+ * out[i] = values[nearest index of query i]; NaN if the source set is empty.
+ * values/out follow `mem`. */
+int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* out, int mem);
+
+/* ---- Barnes structure function (src/api/structure.cpp:143-282) ----------- */
+typedef struct gpp_structure {
+    int kind;        /* 0 = BarnesStructure(h, v, w, hmax) scalar form */
+    float h, v, w;   /* length scales: horizontal [m], vertical [m], land-area-fraction */
+    float min_rho;   /* m_min_rho (structure.cpp:156-159); see gpp_barnes_min_rho */
+} gpp_structure;
+int gpp_barnes_min_rho(float h, float hmax /* NaN: default 0.0013 */, float* min_rho);
+int gpp_barnes_localization_distance(const gpp_structure* s, float* dist);   /* structure.cpp:271-282 */
+/* BarnesStructure::corr (structure.cpp:185-230) for one pair of points given as
+ * (x, y, z, elev, laf) -- runs the same device code as the OI kernel */
+int gpp_barnes_corr(const gpp_structure* s, const float p1[5], const float p2[5], float* rho);
+
+/* ---- optimal interpolation ------------------------------------------------
+ * replaces gridpp::optimal_interpolation_full (src/api/oi.cpp:138-341, Points
+ * form; the Grid form :342-412 is the same call on a grid handle) and through
+ * it gridpp::optimal_interpolation (src/api/oi.cpp:26-136: bvariance == NULL
+ * and bvariance_at_points == NULL mean "all ones", out_variance may be NULL).
+ * background/bvariance/out/out_variance have bgrid-size elements; obs,
+ * obs_variance, background_at_points, bvariance_at_points have points-size
+ * elements.  Errors: GPP_EINVAL as oi.cpp:152-186; GPP_ERUNTIME if a local
+ * (P+R) matrix is singular (arma::inv throws, oi.cpp:315). */
+int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* background, const float* bvariance,
+                                   gpp_points* points, const float* obs, const float* obs_variance,
+                                   const float* background_at_points, const float* bvariance_at_points,
+                                   const gpp_structure* structure, int max_points, int allow_extrapolation,
+                                   float* out, float* out_variance, int mem);
+
+/* per-call statistics of the last OI call on this thread (diagnostics / bench) */
+typedef struct gpp_oi_stats {
+    long long cells;          /* grid cells processed */
+    long long cells_updated;  /* cells with at least one usable observation */
+    long long solves;         /* local (P+R) factorisations actually performed */
+    long long fallback_tiles; /* tiles that left the fast candidate path */
+    float kernel_ms;          /* hipEvent time of the OI kernel(s) on the library stream */
+} gpp_oi_stats;
+int gpp_oi_last_stats(gpp_oi_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

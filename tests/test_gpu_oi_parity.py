@@ -1,0 +1,147 @@
+"""HIP optimal_interpolation vs the CPU oracle on seeded inputs (through the C-ABI).
+
+Tolerance (BASELINE.json north_star): 1e-5 relative for OI floats.  Cells whose top-max_points
+cut straddles an exact float-rho tie are implementation-defined in the reference
+(src/api/oi.cpp:266, unstable std::sort); the oracle and the kernel share one tie-break
+(lower observation index), so they are compared too."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def rel_err(a, b, floor=1e-3):
+    return np.max(np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), floor))
+
+
+def make_case(seed, Y, X, S, geodetic=True, with_elev=False, nan_frac=0.0, dup=False):
+    rng = np.random.default_rng(seed)
+    if geodetic:
+        lats, lons = np.meshgrid(np.linspace(0, 1, Y), np.linspace(0, 1, X), indexing="ij")
+        plat, plon = rng.random(S), rng.random(S)
+    else:
+        lats, lons = np.meshgrid(np.linspace(0, 100000, Y), np.linspace(0, 100000, X), indexing="ij")
+        plat, plon = rng.random(S) * 100000, rng.random(S) * 100000
+    if dup and S > 4:
+        plat[1], plon[1] = plat[0], plon[0]
+    bg = rng.normal(0, 1, (Y, X)).astype(np.float32)
+    obs = rng.normal(0, 1, S).astype(np.float32)
+    pbg = rng.normal(0, 1, S).astype(np.float32)
+    ratios = rng.uniform(0.1, 1, S).astype(np.float32)
+    gelev = glaf = pelev = plaf = None
+    if with_elev:
+        gelev, glaf = rng.uniform(0, 1000, (Y, X)), rng.uniform(0, 1, (Y, X))
+        pelev, plaf = rng.uniform(0, 1000, S), rng.uniform(0, 1, S)
+    if nan_frac > 0:
+        obs[rng.random(S) < nan_frac] = np.nan
+        pbg[rng.random(S) < nan_frac] = np.nan
+        bg[rng.random((Y, X)) < nan_frac] = np.nan
+    return dict(lats=lats, lons=lons, plat=plat, plon=plon, bg=bg, obs=obs, pbg=pbg, ratios=ratios,
+                gelev=gelev, glaf=glaf, pelev=pelev, plaf=plaf, ctype=0 if geodetic else 1)
+
+
+def run_both(c, h, v, w, max_points, allow_extrap=True, full=False):
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    Y, X = c["bg"].shape
+    e = (c["gelev"], c["glaf"]) if c["gelev"] is not None else ((), ())
+    pe = (c["pelev"], c["plaf"]) if c["pelev"] is not None else ((), ())
+    grid = gridpp.Grid(c["lats"], c["lons"], e[0], e[1], c["ctype"])
+    points = gridpp.Points(c["plat"], c["plon"], pe[0], pe[1], c["ctype"])
+    st = gridpp.BarnesStructure(h, v, w)
+    og = O.Pts(c["lats"].ravel(), c["lons"].ravel(), None if c["gelev"] is None else c["gelev"].ravel(),
+               None if c["glaf"] is None else c["glaf"].ravel(), c["ctype"])
+    op = O.Pts(c["plat"], c["plon"], c["pelev"], c["plaf"], c["ctype"])
+    ost = O.Barnes(h, v, w)
+    if full:
+        rng = np.random.default_rng(7)
+        bvar = rng.uniform(0.5, 2, (Y, X)).astype(np.float32)
+        bvp = rng.uniform(0.5, 2, c["obs"].size).astype(np.float32)
+        out, var = gridpp.optimal_interpolation_full(grid, c["bg"], bvar, points, c["obs"], c["ratios"], c["pbg"], bvp, st,
+                                                     max_points, allow_extrap)
+        ref, rvar = O.oi_full(og, c["bg"].ravel(), bvar.ravel(), op, c["obs"], c["ratios"], c["pbg"], bvp, ost, max_points,
+                              allow_extrap)
+        return out, ref.reshape(Y, X), var, rvar.reshape(Y, X)
+    out = gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], st, max_points, allow_extrap)
+    ref = O.oi(og, c["bg"].ravel(), op, c["obs"], c["ratios"], c["pbg"], ost, max_points, allow_extrap).reshape(Y, X)
+    return out, ref
+
+
+def check(out, ref):
+    assert out.dtype == np.float32 and out.shape == ref.shape
+    assert (np.isnan(out) == np.isnan(ref)).all()
+    m = ~np.isnan(ref)
+    assert rel_err(out[m], ref[m]) < RTOL
+
+
+@pytest.mark.parametrize("max_points", [1, 5, 20, 30])
+def test_geodetic_benchmark_style(max_points):
+    c = make_case(1001, 64, 64, 200)
+    out, ref = run_both(c, 10000, 0, 0, max_points)
+    check(out, ref)
+    assert np.abs(out - c["bg"]).max() > 0.1   # the analysis actually moved
+
+
+def test_readme_config1():
+    # BASELINE.json configs[0]: 200x200 grid, 10 obs, BarnesStructure(10000), max_points=10
+    c = make_case(1000, 200, 200, 10)
+    c["ratios"][:] = 0.5
+    out, ref = run_both(c, 10000, 0, 0, 10)
+    check(out, ref)
+
+
+def test_odd_shapes_and_points_overload():
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    c = make_case(5, 37, 53, 150)
+    out, ref = run_both(c, 12000, 0, 0, 12)
+    check(out, ref)
+    # Points (1-D) overload on a shuffled point list: tiles have no spatial coherence
+    rng = np.random.default_rng(3)
+    n = 1000
+    blat, blon = rng.random(n), rng.random(n)
+    bgp = rng.normal(0, 1, n).astype(np.float32)
+    bpoints = gridpp.Points(blat, blon)
+    points = gridpp.Points(c["plat"], c["plon"])
+    out = gridpp.optimal_interpolation(bpoints, bgp, points, c["obs"], c["ratios"], c["pbg"], gridpp.BarnesStructure(12000), 12)
+    ref = O.oi(O.Pts(blat, blon), bgp, O.Pts(c["plat"], c["plon"]), c["obs"], c["ratios"], c["pbg"], O.Barnes(12000), 12)
+    check(out, ref)
+
+
+def test_elev_laf_structure():
+    c = make_case(11, 48, 48, 300, with_elev=True)
+    out, ref = run_both(c, 10000, 200, 0.5, 15)
+    check(out, ref)
+
+
+def test_cartesian_nan_duplicates_no_extrapolation():
+    c = make_case(21, 40, 56, 250, geodetic=False, nan_frac=0.05, dup=True)
+    out, ref = run_both(c, 9000, 0, 0, 10, allow_extrap=False)
+    check(out, ref)
+
+
+def test_full_variance():
+    c = make_case(31, 48, 40, 200, nan_frac=0.02)
+    out, ref, var, rvar = run_both(c, 10000, 0, 0, 16, full=True)
+    check(out, ref)
+    check(var, rvar)
+
+
+def test_few_obs_keep_all():
+    # fewer usable observations than max_points: all are kept (src/api/oi.cpp:274-281)
+    c = make_case(41, 32, 32, 8)
+    out, ref = run_both(c, 30000, 0, 0, 30)
+    check(out, ref)
+
+
+def test_selection_is_bit_exact_vs_oracle_neighbours():
+    """Radius membership on the device path equals the oracle's index set (bit-exact integers)."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    c = make_case(51, 8, 8, 500)
+    points = gridpp.Points(c["plat"], c["plon"])
+    op = O.Pts(c["plat"], c["plon"])
+    for lat, lon, r in [(0.5, 0.5, 20000.0), (0.1, 0.9, 36456.5), (0.0, 0.0, 5000.0)]:
+        np.testing.assert_array_equal(points.get_neighbours(lat, lon, r), O.get_neighbours(op, lat, lon, r))
