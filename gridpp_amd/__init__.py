@@ -372,6 +372,9 @@ def _oi_common(bg, background, bvariance, points, pobs, obs_variance, pbackgroun
         if _shape(bvariance_at_points)[0] != S:
             raise ValueError("Background variance and points size mismatch")
     mem = _mem(background, bvariance, pobs, obs_variance, pbackground, bvariance_at_points)
+    if mem == _capi.MEM_DEVICE:
+        import torch
+        torch.cuda.current_stream().synchronize()   # producers of the inputs ran on torch's stream
     out = _empty_like_field(shape, background)
     var = _empty_like_field(shape, background) if want_variance else None
     check(lib().gpp_optimal_interpolation_full(bg._h, _ptr(background), _ptr(bvariance), points._h, _ptr(pobs),

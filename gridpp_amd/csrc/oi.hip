@@ -195,6 +195,23 @@ struct OiArgs {
 #define ERR_OVERFLOW 1
 #define ERR_SINGULAR 2
 
+// 64-bit mixers for the order-independent signature of a selected observation set
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+// index (0..63) of the m-th set bit of mask (m < popcount(mask))
+__device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
+    int pos = 0;
+#pragma unroll
+    for(int w = 32; w > 0; w >>= 1) {
+        unsigned long long lowmask = (w == 32) ? 0xffffffffull : ((1ull << w) - 1ull);
+        int c = __popcll((mask >> pos) & lowmask);
+        if(m >= c) { m -= c; pos += w; }
+    }
+    return pos;
+}
+
 template <int N>
 __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
@@ -225,65 +242,93 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
 
     int cnt = 0;
     if(__ballot(active) != 0ull) {
-        // ---- bins overlapped by the tile's bounding box + R -------------------------------
         const float R = a.R;
+        const int K = a.K;
+        const bool bounded = a.max_points > 0 && a.max_points <= N;
+        const float h2 = a.h * a.h;
+        // ---- candidate scan: bin rows centre-out, x-extent and stop from the current worst kept rho ---------
         float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
         float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
-        float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
-        float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
-        int bx0 = (int)floorf((amin_t - R - a.amin) * a.inv_s) - 1, bx1 = (int)floorf((amax_t + R - a.amin) * a.inv_s) + 1;
-        int by0 = (int)floorf((bmin_t - R - a.bmin) * a.inv_s) - 1, by1 = (int)floorf((bmax_t + R - a.bmin) * a.inv_s) + 1;
-        bx0 = __builtin_amdgcn_readfirstlane(max(bx0, 0)); bx1 = __builtin_amdgcn_readfirstlane(min(bx1, a.nbx - 1));
-        by0 = __builtin_amdgcn_readfirstlane(max(by0, 0)); by1 = __builtin_amdgcn_readfirstlane(min(by1, a.nby - 1));
+        const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
+        const float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
+        const float sbin = 1.0f / a.inv_s;
+        int tby0 = (int)floorf((bmin_t - a.bmin) * a.inv_s), tby1 = (int)floorf((bmax_t - a.bmin) * a.inv_s);
+        tby0 = __builtin_amdgcn_readfirstlane(min(max(tby0, 0), a.nby - 1));
+        tby1 = __builtin_amdgcn_readfirstlane(min(max(tby1, tby0), a.nby - 1));
 
         // strictly-inside box of the radius query (kdtree.cpp:46,53)
         const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
-        const int K = a.K;
         unsigned long long wkey = 0;   // worst key kept
         int wslot = 0;
-        float thr2 = INFINITY;         // monotone mode: candidates with d2 > thr2 cannot enter the list
-        const float h2 = a.h * a.h;
+        // d2 > thr2 can neither be within R nor beat the worst kept rho (rho <= rho_h(d), monotone in d)
+        const float thr2_R = R * R * 1.000001f + 1e-30f;
+        float thr2 = active ? thr2_R : -1.0f;
         bool overflow = false;
 
-        if(bx0 <= bx1) for(int by = by0; by <= by1; ++by) {
-            const int js = a.bin_start[by * a.nbx + bx0], je = a.bin_start[by * a.nbx + bx1 + 1];
-            for(int j = js; j < je; ++j) {
-                const float4 g0 = a.pgeo[j];
-                const float ox = g0.x, oy = g0.y, oz = g0.z;
-                bool in = active && ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
-                float dx = ox - gx, dy = oy - gy, dz = oz - gz;
-                float d2 = dx * dx + dy * dy;
-                d2 = d2 + dz * dz;
-                in = in && (d2 <= thr2);
-                if(in) {
-                    float dist = sqrtf(d2);
-                    if(dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
-                        const float2 m = a.smeta[j];
-                        float rho = d_barnes_rho(dist, a.h);
-                        if(d_valid(ge) && d_valid(g0.w)) rho *= d_barnes_rho(ge - g0.w, a.v);
-                        if(d_valid(gl) && d_valid(m.x)) rho *= d_barnes_rho(gl - m.x, a.w);
-                        if(rho > 0.0f) {   // oi.cpp:253
-                            unsigned orig = (unsigned)__float_as_int(m.y);
-                            unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
-                            if(cnt < K) {
-                                keys[cnt][lane] = key;
-                                if(cnt == 0 || key < wkey) { wkey = key; wslot = cnt; }
-                                cnt++;
-                            }
-                            else if(a.max_points > 0 && a.max_points <= N) {
-                                if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
-                                    keys[wslot][lane] = key;
-                                    wkey = key;
-                                    for(int s = 0; s < K; ++s) {
-                                        unsigned long long k2 = keys[s][lane];
-                                        if(k2 < wkey) { wkey = k2; wslot = s; }
+        for(int r = 0;; ++r) {
+            const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
+            if(t2 < 0.0f) break;
+            const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
+            if(gap * gap > t2) break;
+            const int rowA = tby0 - r, rowB = tby1 + r;
+            if(rowA < 0 && rowB >= a.nby) break;
+            const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
+            int x0 = (int)floorf((amin_t - wx - a.amin) * a.inv_s) - 1, x1 = (int)floorf((amax_t + wx - a.amin) * a.inv_s) + 1;
+            x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), a.nbx - 1));
+            x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), a.nbx - 1));
+            const int nseg = (r == 0) ? 1 : 2;
+            for(int seg = 0; seg < nseg; ++seg) {
+                int js, je;
+                if(r == 0) { js = a.bin_start[tby0 * a.nbx + x0]; je = a.bin_start[tby1 * a.nbx + x1 + 1];
+                             if(tby1 > tby0) { js = a.bin_start[tby0 * a.nbx]; je = a.bin_start[tby1 * a.nbx + a.nbx]; } }
+                else {
+                    const int row = seg == 0 ? rowA : rowB;
+                    if(row < 0 || row >= a.nby) continue;
+                    js = a.bin_start[row * a.nbx + x0]; je = a.bin_start[row * a.nbx + x1 + 1];
+                }
+                for(int base = js; base < je; base += 64) {
+                    const int mine = base + lane;
+                    float4 rec = make_float4(NAN, 0, 0, NAN);
+                    float2 met = make_float2(NAN, 0);
+                    if(mine < je) { rec = a.pgeo[mine]; met = a.smeta[mine]; }
+                    const int nc = min(64, je - base);
+                    for(int c = 0; c < nc; ++c) {
+                        const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
+                        const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+                        float d2 = dx * dx + dy * dy;
+                        d2 = d2 + dz * dz;
+                        if(d2 <= thr2) {
+                            const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                            const float dist = sqrtf(d2);
+                            if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
+                                const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                                float rho = d_barnes_rho(dist, a.h);
+                                if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
+                                if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
+                                if(rho > 0.0f) {   // oi.cpp:253
+                                    const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
+                                    const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
+                                    if(cnt < K) {
+                                        keys[cnt][lane] = key;
+                                        if(cnt == 0 || key < wkey) { wkey = key; wslot = cnt; }
+                                        cnt++;
+                                    }
+                                    else if(bounded) {
+                                        if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
+                                            keys[wslot][lane] = key;
+                                            wkey = key;
+                                            for(int s = 0; s < K; ++s) {
+                                                const unsigned long long k2 = keys[s][lane];
+                                                if(k2 < wkey) { wkey = k2; wslot = s; }
+                                            }
+                                        }
+                                    }
+                                    else overflow = true;   // more than N usable observations requested
+                                    if(bounded && cnt == K) {
+                                        const float wr = __uint_as_float((unsigned)(wkey >> 32));
+                                        thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
                                     }
                                 }
-                            }
-                            else overflow = true;   // more than N usable observations requested
-                            if(a.monotone && cnt == K && a.max_points > 0 && a.max_points <= N) {
-                                float wr = __uint_as_float((unsigned)(wkey >> 32));
-                                thr2 = -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2;
                             }
                         }
                     }
@@ -295,56 +340,83 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             cnt = overflow ? 0 : cnt;
         }
 
-        // ---- dense solves: one augmented Cholesky per cell ---------------------------------
+        // ---- order-independent signature of every lane's selected set ------------------------------------------
+        unsigned long long h1 = 0, h2s = 0;
+        for(int s = 0; s < K; ++s) {
+            if(s < cnt) {
+                const unsigned o = ~(unsigned)(keys[s][lane] & 0xffffffffull);
+                h1 += mix64((unsigned long long)o + 0x9e3779b97f4a7c15ull);
+                h2s ^= mix64(((unsigned long long)o << 1) ^ 0xd6e8feb86659fd93ull);
+            }
+        }
+
+        // ---- dense solves: one augmented Cholesky per DISTINCT observation set -----------------------------------
         unsigned long long todo = __ballot(cnt > 0);
+        const int nupd = __popcll(todo);
         int nsolve = 0;
         bool bad = false;
+        constexpr int MEMB = 63 - N;   // lanes N+1..63 carry one member cell each
         while(todo) {
             const int l = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            nsolve++;
             const int n = __builtin_amdgcn_readlane(cnt, l);
-            // lane i < n takes the i-th selected observation of cell l
+            const unsigned long long l1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h1 >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h1, l);
+            const unsigned long long l2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h2s >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h2s, l);
+            unsigned long long members = __ballot(cnt == n && h1 == l1 && h2s == l2) & todo;
+            // at most MEMB members per pass
+            int nm = __popcll(members);
+            if(nm > MEMB) {
+                const int cut = nth_set_bit(members, MEMB);
+                members &= (1ull << cut) - 1ull;
+                nm = MEMB;
+            }
+            todo &= ~members;
+            nsolve++;
+            // lane i < n takes the i-th selected observation of the leader; lane N+1+m takes member cell m
             unsigned long long key = (lane < n) ? keys[lane][l] : 0ull;
-            float rho_i = __uint_as_float((unsigned)(key >> 32));
-            unsigned orig_i = ~(unsigned)(key & 0xffffffffull);
+            const unsigned orig_i = ~(unsigned)(key & 0xffffffffull);
             float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
             if(lane < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
+            const int mi = lane - (N + 1);
+            const bool is_g = mi >= 0 && mi < nm;
+            const int src = is_g ? nth_set_bit(members, mi) : lane;
+            // own point of this lane: observation i (matrix rows) or the member cell (G rows)
+            float px = __shfl(gx, src), py = __shfl(gy, src), pz = __shfl(gz, src), pe = __shfl(ge, src), pl = __shfl(gl, src);
+            const float cbg = __shfl(bg, src), cbv = __shfl(bvar, src);
+            if(lane < n) { px = o0.x; py = o0.y; pz = o0.z; pe = o0.w; pl = o1.x; }
             double row[N];
             float maxInc = -INFINITY, minInc = INFINITY;
 #pragma unroll
             for(int p = 0; p < N; ++p) {
                 double v = 0.0;
                 if(p < n) {
-                    float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
-                    float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
-                    float c = d_barnes_corr(o0.x, o0.y, o0.z, o0.w, o1.x, xp, yp, zp, ep, lp, a.h, a.v, a.w, a.R);   // oi.cpp:304-312
+                    const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
+                    const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
+                    // matrix rows: corr(obs_i, obs_p) (oi.cpp:304-312); G rows: corr(cell, obs_p) (oi.cpp:250)
+                    const float c = d_barnes_corr(px, py, pz, pe, pl, xp, yp, zp, ep, lp, a.h, a.v, a.w, a.R);
                     v = (double)c;
-                    if(lane == p) v += (double)o1.w;                                                                 // lP + lR
-                    double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);                          // lObs - lY
-                    float gp = readlane_f(rho_i, p);
-                    float dpf = (float)dp;
+                    if(lane == p) v += (double)o1.w;                                         // lP + lR
+                    const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);   // lObs - lY
+                    const float dpf = (float)dp;
                     maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
                     if(lane == N) v = dp;
-                    if(lane == N + 1) v = (double)gp;
-                    if(lane > N + 1 || (lane >= n && lane < N)) v = 0.0;
+                    if(!(lane < n || lane == N || is_g)) v = 0.0;
                 }
                 row[p] = v;
             }
-            // right-looking Cholesky on rows-in-lanes; rows N, N+1 become L^-1 d and L^-1 g
+            // right-looking Cholesky on rows-in-lanes; row N becomes L^-1 d, rows N+1.. become L^-1 g_m
 #pragma unroll
             for(int j = 0; j < N; ++j) {
                 if(j < n) {
-                    double ajj = readlane_d(row[j], j);
+                    const double ajj = readlane_d(row[j], j);
                     if(!(ajj > 0.0)) bad = true;
-                    double r = __builtin_amdgcn_rsq(ajj);
-                    r = r * (1.5 - 0.5 * ajj * r * r);
-                    r = r * (1.5 - 0.5 * ajj * r * r);
-                    double cj = row[j] * r;
+                    double rs = __builtin_amdgcn_rsq(ajj);
+                    rs = rs * (1.5 - 0.5 * ajj * rs * rs);
+                    rs = rs * (1.5 - 0.5 * ajj * rs * rs);
+                    const double cj = row[j] * rs;
                     row[j] = cj;
 #pragma unroll
                     for(int p = j + 1; p < N; ++p) {
-                        double lpj = readlane_d(cj, p);
+                        const double lpj = readlane_d(cj, p);
                         row[p] = __builtin_fma(-cj, lpj, row[p]);
                     }
                 }
@@ -352,11 +424,11 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             double inc = 0.0, a00 = 0.0;
 #pragma unroll
             for(int p = 0; p < N; ++p) {
-                double tp = readlane_d(row[p], N);
+                const double tp = readlane_d(row[p], N);
                 inc = __builtin_fma(row[p], tp, inc);      // lGSR * (lObs - lY)   (oi.cpp:316)
                 a00 = __builtin_fma(row[p], row[p], a00);  // lGSR * lG^T          (oi.cpp:336)
             }
-            if(lane == N + 1) {
+            if(is_g) {
                 float increment = (float)inc;   // oi.cpp:317
                 if(!a.allow_extrap) {           // oi.cpp:318-334
                     if(maxInc > 0 && increment > maxInc) increment = maxInc;
@@ -364,19 +436,15 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                     else if(minInc < 0 && increment < minInc) increment = minInc;
                     else if(minInc > 0 && increment < 0) increment = minInc;
                 }
-                float bgl = readlane_f(bg, l), bvl = readlane_f(bvar, l);
-                s_res[wid][0][l] = bgl + increment;                       // oi.cpp:335
-                s_res[wid][1][l] = (float)((double)bvl * (1.0 - a00));    // oi.cpp:337
-            }
-            else {
-                (void)readlane_f(bg, l); (void)readlane_f(bvar, l);
+                s_res[wid][0][src] = cbg + increment;                      // oi.cpp:335
+                s_res[wid][1][src] = (float)((double)cbv * (1.0 - a00));   // oi.cpp:337
             }
         }
         __builtin_amdgcn_wave_barrier();
         if(cnt > 0) { res_out = s_res[wid][0][lane]; res_var = s_res[wid][1][lane]; }
         if(__ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
         if(lane == 0 && a.counters) {
-            atomicAdd(&a.counters[0], (unsigned long long)__popcll(__ballot(cnt > 0)));
+            atomicAdd(&a.counters[0], (unsigned long long)nupd);
             atomicAdd(&a.counters[1], (unsigned long long)nsolve);
         }
     }
