@@ -420,3 +420,177 @@ def nearest(igrid, opoints, values):
         return out
     check(lib().gpp_nearest(igrid._h, opoints._h, _ptr(values), _ptr(out), _mem(values)))
     return out
+
+
+# ---- neighbourhood filters (include/gridpp.h:588-716, src/api/neighbourhood.cpp) ---------------------
+def _field23(a, name="input"):
+    """2-D or 3-D field -> (array, ny, nx, ne, is3d); [[]] -> empty."""
+    if _is_dev(a):
+        nd = a.dim()
+        arr = _vec(a, nd, name)
+    else:
+        arr = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+        nd = arr.ndim
+    if nd not in (2, 3):
+        if getattr(arr, "size", 1) == 0:
+            return arr, 0, 0, 0, 0
+        raise RuntimeError("%s must have 2 or 3 dimensions" % name)
+    shp = tuple(arr.shape)
+    ny, nx = shp[0], shp[1]
+    ne = shp[2] if nd == 3 else 1
+    return arr, ny, nx, ne, int(nd == 3)
+
+
+def _sync_if_dev(mem):
+    if mem == _capi.MEM_DEVICE:
+        import torch
+        torch.cuda.current_stream().synchronize()
+
+
+def neighbourhood(input, halfwidth, statistic):
+    """gridpp::neighbourhood for 2-D and 3-D (Y, X, E) input (src/api/neighbourhood.cpp:12-242)."""
+    arr, ny, nx, ne, is3d = _field23(input)
+    if halfwidth < 0:
+        raise ValueError("Half width must be > 0")
+    if statistic == Quantile:
+        raise ValueError("Use neighbourhood_quantile for computing neighbourhood quantiles")
+    if ny * nx * ne == 0:
+        return np.zeros((0, 0), np.float32)
+    mem = _mem(arr)
+    _sync_if_dev(mem)
+    out = _empty_like_field((ny, nx), arr)
+    check(lib().gpp_neighbourhood(_ptr(arr), ny, nx, ne, is3d, int(halfwidth), int(statistic), _ptr(out), mem))
+    return out
+
+
+def neighbourhood_brute_force(input, halfwidth, statistic):
+    arr, ny, nx, ne, is3d = _field23(input)
+    if halfwidth < 0:
+        raise ValueError("Half width must be > 0")
+    if ny * nx * ne == 0:
+        return np.zeros((0, 0), np.float32)
+    mem = _mem(arr)
+    _sync_if_dev(mem)
+    out = _empty_like_field((ny, nx), arr)
+    check(lib().gpp_neighbourhood_brute_force(_ptr(arr), ny, nx, ne, int(halfwidth), int(statistic), 0.0, _ptr(out), mem))
+    return out
+
+
+def neighbourhood_quantile(input, quantile, halfwidth):
+    """Exact neighbourhood quantile (src/api/neighbourhood.cpp:534-539)."""
+    arr, ny, nx, ne, is3d = _field23(input)
+    if halfwidth < 0:
+        raise ValueError("Half width must be > 0")
+    if ny * nx * ne == 0:
+        return np.zeros((0, 0), np.float32)
+    mem = _mem(arr)
+    _sync_if_dev(mem)
+    out = _empty_like_field((ny, nx), arr)
+    check(lib().gpp_neighbourhood_brute_force(_ptr(arr), ny, nx, ne, int(halfwidth), Quantile, float(quantile), _ptr(out), mem))
+    return out
+
+
+def neighbourhood_quantile_fast(input, quantile, halfwidth, thresholds):
+    """All four overloads of gridpp::neighbourhood_quantile_fast (src/api/neighbourhood.cpp:296-527)."""
+    arr, ny, nx, ne, is3d = _field23(input)
+    if halfwidth < 0:
+        raise ValueError("Half width must be > 0")
+    if ny * nx * ne == 0:
+        return np.zeros((0, 0), np.float32)
+    mem = _mem(arr)
+    if np.ndim(quantile) == 0 and not _is_dev(quantile):
+        q = np.array([quantile], np.float32)
+    else:
+        q = _vec(quantile, 2, "quantile")
+        if _shape(q) not in ((1, 1), (ny, nx)):
+            raise ValueError("Quantile must be the same size as input, or size (1, 1)")
+    thr = _vec(thresholds, 1, "thresholds")
+    if mem == _capi.MEM_DEVICE:
+        import torch
+        q = q if _is_dev(q) else torch.from_numpy(np.asarray(q)).to(arr.device)
+        thr = thr if _is_dev(thr) else torch.from_numpy(np.asarray(thr)).to(arr.device)
+    _sync_if_dev(mem)
+    nq = int(np.prod(_shape(q)))
+    out = _empty_like_field((ny, nx), arr)
+    check(lib().gpp_neighbourhood_quantile_fast(_ptr(arr), ny, nx, ne, is3d, _ptr(q), nq, int(halfwidth), _ptr(thr),
+                                                int(_shape(thr)[0]), _ptr(out), mem))
+    return out
+
+
+def neighbourhood_ens(input, halfwidth, statistic):   # deprecated aliases (neighbourhood.cpp:541-552)
+    return neighbourhood(input, halfwidth, statistic)
+
+
+def neighbourhood_quantile_ens(input, quantile, halfwidth):
+    return neighbourhood_quantile(input, quantile, halfwidth)
+
+
+def neighbourhood_quantile_ens_fast(input, quantile, halfwidth, thresholds):
+    return neighbourhood_quantile_fast(input, quantile, halfwidth, thresholds)
+
+
+# ---- util (include/gridpp.h:1454-1482, src/api/util.cpp) ---------------------------------------------
+def calc_statistic(array, statistic):
+    """gridpp::calc_statistic for a vector (-> float) or a 2-D array (-> one value per row)."""
+    a = np.ascontiguousarray(np.asarray(array), dtype=np.float32)
+    if a.ndim not in (1, 2):
+        raise RuntimeError("array must have 1 or 2 dimensions")
+    rows = 1 if a.ndim == 1 else a.shape[0]
+    length = a.shape[-1]
+    out = np.empty(rows, np.float32)
+    if rows:
+        check(lib().gpp_calc_statistic(_ptr(a), rows, length, int(statistic), _ptr(out), _capi.MEM_HOST))
+    return float(out[0]) if a.ndim == 1 else out
+
+
+def calc_quantile(array, quantile):
+    """gridpp::calc_quantile: (vec, q) -> float, (vec2, q) -> vec, (vec3, vec2 q) -> vec2."""
+    a = np.ascontiguousarray(np.asarray(array), dtype=np.float32)
+    q = np.ascontiguousarray(np.asarray(quantile), dtype=np.float32)
+    if a.ndim == 3:
+        if q.shape != a.shape[:2]:
+            raise ValueError("Dimension mismatch between array and quantile")
+        if a.shape[0] * a.shape[1] == 0:
+            return np.zeros((0, 0), np.float32)
+        rows, length = a.shape[0] * a.shape[1], a.shape[2]
+        out = np.empty(rows, np.float32)
+        check(lib().gpp_calc_quantile(_ptr(a), rows, length, _ptr(q), rows, _ptr(out), _capi.MEM_HOST))
+        return out.reshape(a.shape[:2])
+    if a.ndim not in (1, 2):
+        raise RuntimeError("array must have 1, 2 or 3 dimensions")
+    rows = 1 if a.ndim == 1 else a.shape[0]
+    out = np.empty(rows, np.float32)
+    qq = q.reshape(1)
+    if rows:
+        check(lib().gpp_calc_quantile(_ptr(a), rows, a.shape[-1], _ptr(qq), 1, _ptr(out), _capi.MEM_HOST))
+    return float(out[0]) if a.ndim == 1 else out
+
+
+def _even_quantiles(values, num, only_valid):
+    dev = _is_dev(values)
+    v = values.contiguous().float().reshape(-1) if dev else np.ascontiguousarray(np.asarray(values), dtype=np.float32).ravel()
+    n = int(v.numel()) if dev else v.size
+    out = np.empty(max(int(num), 1) if n else 1, np.float32)
+    if num > 0 and n > 0 and num >= n:
+        out = np.empty(n, np.float32)
+    cnt = C.c_int(0)
+    if dev:
+        import torch
+        torch.cuda.current_stream().synchronize()
+        dout = torch.empty(out.size, dtype=torch.float32, device=v.device)
+        check(lib().gpp_calc_even_quantiles(_ptr(v), n, int(num), int(only_valid), _ptr(dout), C.byref(cnt), _capi.MEM_DEVICE))
+        return dout[:cnt.value].cpu().numpy()
+    check(lib().gpp_calc_even_quantiles(_ptr(v), n, int(num), int(only_valid), _ptr(out), C.byref(cnt), _capi.MEM_HOST))
+    return out[:cnt.value].copy()
+
+
+def calc_even_quantiles(values, num):
+    """gridpp::calc_even_quantiles (src/api/util.cpp:261-338)."""
+    return _even_quantiles(values, num, 0)
+
+
+def get_neighbourhood_thresholds(input, num_thresholds):
+    """gridpp::get_neighbourhood_thresholds for 2-D / 3-D input (src/api/neighbourhood.cpp:243-295)."""
+    if num_thresholds <= 0:
+        raise ValueError("num_thresholds must be > 0")
+    return _even_quantiles(input, num_thresholds, 1)

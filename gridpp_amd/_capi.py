@@ -47,6 +47,12 @@ SIGNATURES = {
     "gpp_barnes_corr": [C.POINTER(gpp_structure), fp, fp, fp],
     "gpp_optimal_interpolation_full": [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, vp, C.c_int],
     "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
+    "gpp_calc_statistic": [vp, C.c_long, C.c_int, C.c_int, vp, C.c_int],
+    "gpp_calc_quantile": [vp, C.c_long, C.c_int, vp, C.c_long, vp, C.c_int],
+    "gpp_calc_even_quantiles": [vp, C.c_long, C.c_int, C.c_int, vp, ip, C.c_int],
+    "gpp_neighbourhood": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int],
+    "gpp_neighbourhood_brute_force": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int],
+    "gpp_neighbourhood_quantile_fast": [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int],
 }
 STRING_GETTERS = ("gpp_last_error", "gpp_version")
 
@@ -57,6 +63,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("gridpp_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback)" % LIB_PATH)
+        try:
+            # torch bundles its own HIP runtime; load it first so that both share ONE runtime
+            # (two copies of libamdhip64 in a process cannot both open the GPU)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             f = getattr(L, name)

@@ -1,0 +1,702 @@
+// Neighbourhood filters on MI355X (gfx950).
+//
+// Replaces src/api/neighbourhood.cpp:
+//   neighbourhood(vec2|vec3, halfwidth, statistic)            :12-242
+//   neighbourhood_quantile_fast(vec2|vec3, q|q-field, hw, thresholds)  :296-527
+//   neighbourhood_quantile / neighbourhood_brute_force        :528-654
+// and the per-cell statistics of src/api/util.cpp:19-178,339-414.
+//
+// Design (HBM-bound: the (Y,X,E) cube is read exactly once):
+//   * member pass: one wavefront per 64 consecutive cells; the 64*E contiguous floats are
+//     streamed with 16-byte coalesced loads into an odd-pitch LDS tile, then lane l walks row l
+//     in member order -- this keeps the reference's sequential float accumulation
+//     (util.cpp:22-38) bit-for-bit while the HBM side stays fully coalesced;
+//   * quantile_fast: the same pass emits all T threshold fractions per cell (T/8 register
+//     batches), so the cube is not re-read T times as in the reference (:453-472);
+//   * box statistics: separable row pass + column pass (double sums + int counts) instead of the
+//     reference's serial summed-area table; sums differ from the SAT only in double rounding;
+//   * min/max: separable running min/max ignoring non-finite values;
+//   * exact quantile / median / brute force: one wavefront per cell, k-th order statistic by
+//     bisection on the monotone uint32 image of the float values (no sort, no scratch).
+#include "common.h"
+#include <algorithm>
+#include <hipcub/hipcub.hpp>
+
+#pragma clang fp contract(off)
+using namespace gpp;
+
+__device__ __forceinline__ bool nv(float v) { return !isnan(v) && !isinf(v); }
+
+// -------------------------------------------------------------------------------------------
+// member pass
+// -------------------------------------------------------------------------------------------
+// src/api/util.cpp:19-110 on one row held in LDS (stride 1), sequential like the reference
+__device__ float row_statistic(const float* row, int n, int statistic) {
+    float value = NAN;
+    if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT) {
+        float total = 0; int count = 0;
+        for(int i = 0; i < n; i++) { float v = row[i]; if(nv(v)) { total += v; count++; } }
+        if(statistic == GPP_COUNT) value = (float)count;
+        else if(count > 0) value = (statistic == GPP_MEAN) ? total / (float)count : total;
+    }
+    else if(statistic == GPP_STD || statistic == GPP_VARIANCE) {
+        float total = 0, total2 = 0, K = NAN; int count = 0;
+        for(int i = 0; i < n; i++) {
+            float v = row[i];
+            if(nv(v)) {
+                if(!nv(K)) K = v;
+                float d = v - K;
+                total += d; total2 += d * d; count++;
+            }
+        }
+        if(count > 0) {
+            float mean = total / (float)count, mean2 = total2 / (float)count;
+            float var = mean2 - mean * mean;
+            if(var < 0) var = 0;
+            value = (statistic == GPP_STD) ? sqrtf(var) : var;
+        }
+    }
+    else if(statistic == GPP_MIN || statistic == GPP_MAX) {   // calc_quantile q = 0 / 1 (util.cpp:121-146)
+        float m = NAN;
+        for(int i = 0; i < n; i++) {
+            float v = row[i];
+            if(!nv(v)) continue;
+            if(!nv(m)) m = v;
+            else if(statistic == GPP_MIN ? v < m : v > m) m = v;
+        }
+        value = m;
+    }
+    return value;
+}
+
+// monotone map float -> uint32 (valid values only)
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+// util.cpp:158-176 given the two order statistics
+__device__ __forceinline__ float quantile_from_order(float q, int N, float lowerValue, float upperValue, int lowerIndex, int upperIndex) {
+    if(lowerIndex == upperIndex) return lowerValue;
+    float lowerQuantile = (float)lowerIndex / (float)(N - 1);
+    float upperQuantile = (float)upperIndex / (float)(N - 1);
+    float f = (q - lowerQuantile) / (upperQuantile - lowerQuantile);
+    return lowerValue + (upperValue - lowerValue) * f;
+}
+// k-th smallest (0-based) among the valid values of a lane-private row, by bisection on f2ord
+__device__ float row_kth(const float* row, int n, int k) {
+    unsigned lo = 0, hi = 0xffffffffu;   // smallest o with count(ord <= o) >= k+1
+    while(lo < hi) {
+        unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+        for(int i = 0; i < n; i++) { float v = row[i]; if(nv(v) && f2ord(v) <= mid) c++; }
+        if(c >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    return ord2f(lo);
+}
+__device__ float row_quantile(const float* row, int n, float q) {   // util.cpp:111-178 (q already validated)
+    if(!nv(q)) return NAN;
+    int N = 0;
+    for(int i = 0; i < n; i++) if(nv(row[i])) N++;
+    if(N == 0) return NAN;
+    if(q == 0) return row_statistic(row, n, GPP_MIN);
+    if(q == 1) return row_statistic(row, n, GPP_MAX);
+    float pos = q * (float)(N - 1);
+    int lowerIndex = (int)floorf(pos), upperIndex = (int)ceilf(pos);
+    float lv = row_kth(row, n, lowerIndex);
+    float uv = (upperIndex == lowerIndex) ? lv : row_kth(row, n, upperIndex);
+    return quantile_from_order(q, N, lv, uv, lowerIndex, upperIndex);
+}
+
+#define MEMBER_EC 128   // members staged per chunk
+#define TB 8            // thresholds per register batch
+
+// mode 0: out[c] = calc_statistic(members of c)                       (neighbourhood.cpp:21-25)
+// mode 1: out[t*C + c] = #(valid members <= thr[t]) / #valid members  (neighbourhood.cpp:456-471)
+__global__ __launch_bounds__(256) void k_member_pass(const float* __restrict__ in, long C, int E, int mode, int statistic,
+                                                     const float* __restrict__ thr, int T, float* __restrict__ out) {
+    extern __shared__ float lds[];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long cell0 = ((long)blockIdx.x * 4 + wid) * 64;
+    if(cell0 >= C) return;
+    const int ncell = (int)min((long)64, C - cell0);
+    const int EC = min(E, MEMBER_EC);
+    const int pitch = EC | 1;
+    float* tile = lds + (size_t)wid * 64 * (MEMBER_EC | 1);
+    float* myrow = tile + lane * pitch;
+    const long cell = cell0 + lane;
+
+    if(E <= MEMBER_EC) {
+        // whole rows fit: stream the contiguous 64*E block with 16-byte loads
+        const long base = cell0 * E;
+        const int total = ncell * E;
+        const bool vec4 = ((base & 3) == 0) && ((reinterpret_cast<size_t>(in) & 15) == 0);
+        if(vec4) {
+            for(int i = lane * 4; i < total; i += 256) {
+                float v[4] = {0, 0, 0, 0};
+                if(i + 3 < total) { float4 q = *reinterpret_cast<const float4*>(in + base + i); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+                else for(int k = 0; k < 4 && i + k < total; k++) v[k] = in[base + i + k];
+                int r = i / E, c = i - r * E;
+#pragma unroll
+                for(int k = 0; k < 4; k++) {
+                    if(i + k < total) tile[r * pitch + c] = v[k];
+                    if(++c >= E) { c = 0; r++; }
+                }
+            }
+        }
+        else for(int i = lane; i < total; i += 64) { int r = i / E, c = i - r * E; tile[r * pitch + c] = in[base + i]; }
+        __builtin_amdgcn_wave_barrier();
+        if(lane < ncell) {
+            if(mode == 0) out[cell] = row_statistic(myrow, E, statistic);
+            else {
+                int count = 0;
+                for(int e = 0; e < E; e++) if(nv(myrow[e])) count++;
+                for(int t0 = 0; t0 < T; t0 += TB) {
+                    float th[TB]; int sum[TB];
+#pragma unroll
+                    for(int k = 0; k < TB; k++) { th[k] = (t0 + k < T) ? thr[t0 + k] : 0.0f; sum[k] = 0; }
+                    for(int e = 0; e < E; e++) {
+                        float v = myrow[e];
+                        bool ok = nv(v);
+#pragma unroll
+                        for(int k = 0; k < TB; k++) sum[k] += (ok && v <= th[k]) ? 1 : 0;
+                    }
+#pragma unroll
+                    for(int k = 0; k < TB; k++)
+                        if(t0 + k < T) out[(long)(t0 + k) * C + cell] = count > 0 ? (float)sum[k] / (float)count : NAN;
+                }
+            }
+        }
+    }
+    else {
+        // long rows: lane-private sequential walk straight from memory (rare: E > 128)
+        if(lane < ncell) {
+            const float* row = in + cell * E;
+            if(mode == 0) out[cell] = row_statistic(row, E, statistic);
+            else {
+                int count = 0;
+                for(int e = 0; e < E; e++) if(nv(row[e])) count++;
+                for(int t = 0; t < T; t++) {
+                    int sum = 0; float th = thr[t];
+                    for(int e = 0; e < E; e++) { float v = row[e]; if(nv(v) && v <= th) sum++; }
+                    out[(long)t * C + cell] = count > 0 ? (float)sum / (float)count : NAN;
+                }
+            }
+        }
+    }
+}
+
+// Median / exact quantile over the members of each cell (rare path; one lane per cell from memory)
+__global__ void k_member_quantile(const float* __restrict__ in, long C, int E, float q, float* __restrict__ out) {
+    long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(c < C) out[c] = row_quantile(in + c * E, E, q);
+}
+
+// -------------------------------------------------------------------------------------------
+// separable box statistics (planes: blockIdx.z selects a [Y][X] plane)
+// -------------------------------------------------------------------------------------------
+// row pass: for each cell the sum (double) and count (int) of the valid values in [x-hw, x+hw]
+__global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ in, int Y, int X, int hw, double* __restrict__ rs, int* __restrict__ rc) {
+    extern __shared__ float lds[];   // 256 + 2*hwc floats
+    const long plane = (long)blockIdx.z * Y * X;
+    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * 256;
+    const int hwc = min(hw, X);   // a window wider than the row is the whole row
+    const float* row = in + plane + (long)y * X;
+    for(int i = threadIdx.x; i < 256 + 2 * hwc; i += 256) {
+        int x = x0 - hwc + i;
+        lds[i] = (x >= 0 && x < X) ? row[x] : NAN;
+    }
+    __syncthreads();
+    int x = x0 + threadIdx.x;
+    if(x >= X) return;
+    double s = 0; int c = 0;
+    for(int k = 0; k <= 2 * hwc; k++) { float v = lds[threadIdx.x + k]; if(nv(v)) { s += (double)v; c++; } }
+    rs[plane + (long)y * X + x] = s;
+    rc[plane + (long)y * X + x] = c;
+}
+// column pass + finish (neighbourhood.cpp:132-142): Mean / Sum / Count
+__global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs, const int* __restrict__ rc, int Y, int X, int hw, int statistic, float* __restrict__ out) {
+    const long plane = (long)blockIdx.z * Y * X;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(x >= X || y >= Y) return;
+    const int ya = max(0, y - hw), yb = (int)min((long)Y - 1, (long)y + hw);
+    double s = 0; int c = 0;
+    for(int yy = ya; yy <= yb; yy++) { s += rs[plane + (long)yy * X + x]; c += rc[plane + (long)yy * X + x]; }
+    float o = NAN;
+    if(statistic == GPP_COUNT) o = (float)c;
+    else if(c > 0) o = (statistic == GPP_MEAN) ? (float)(s / (double)c) : (float)s;
+    out[plane + (long)y * X + x] = o;
+}
+// separable min / max ignoring non-finite values (dir 0: along x, dir 1: along y)
+__global__ __launch_bounds__(256) void k_minmax_pass(const float* __restrict__ in, int Y, int X, int hw, int is_max, int dir, float* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(x >= X || y >= Y) return;
+    float m = NAN;
+    if(dir == 0) {
+        const int a = max(0, x - hw), b = (int)min((long)X - 1, (long)x + hw);
+        for(int k = a; k <= b; k++) { float v = in[(long)y * X + k]; if(nv(v) && (!nv(m) || (is_max ? v > m : v < m))) m = v; }
+    }
+    else {
+        const int a = max(0, y - hw), b = (int)min((long)Y - 1, (long)y + hw);
+        for(int k = a; k <= b; k++) { float v = in[(long)k * X + x]; if(nv(v) && (!nv(m) || (is_max ? v > m : v < m))) m = v; }
+    }
+    out[(long)y * X + x] = m;
+}
+__global__ void k_fill_nan(float* out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = NAN;
+}
+__global__ void k_square(const float* __restrict__ in, long n, float* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) { float v = in[i]; out[i] = v * v; }
+}
+// neighbourhood.cpp:222-233
+__global__ void k_std_finish(const float* __restrict__ mean, const float* __restrict__ mean2, long n, int is_std, float* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) { float v = mean2[i] - mean[i] * mean[i]; out[i] = is_std ? sqrtf(v) : v; }
+}
+
+// -------------------------------------------------------------------------------------------
+// brute force: one wavefront per cell, window (x members) gathered on the fly
+// -------------------------------------------------------------------------------------------
+struct Window {
+    const float* in; int X, E, ya, yb, xa, xb;
+    __device__ int count() const { return (yb - ya + 1) * (xb - xa + 1) * E; }
+    // element k of the window in the reference's gather order (neighbourhood.cpp:579-587,631-640)
+    __device__ float at(int k) const {
+        int rowlen = (xb - xa + 1) * E;
+        int r = k / rowlen, o = k - r * rowlen;
+        return in[((long)(ya + r) * X + xa) * E + o];
+    }
+};
+__device__ __forceinline__ int wave_sum_i(int v) { for(int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
+
+__device__ float wave_kth(const Window& w, int n, int k, int lane) {
+    unsigned lo = 0, hi = 0xffffffffu;
+    while(lo < hi) {
+        unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+        for(int i = lane; i < n; i += 64) { float v = w.at(i); if(nv(v) && f2ord(v) <= mid) c++; }
+        c = wave_sum_i(c);
+        if(c >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    return ord2f(lo);
+}
+// statistic over the window with the reference's semantics (calc_statistic / calc_quantile)
+__global__ __launch_bounds__(256) void k_brute(const float* __restrict__ in, int Y, int X, int E, int hw, int statistic, float q, unsigned seed, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long cell = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if(cell >= (long)Y * X) return;
+    const int y = (int)(cell / X), x = (int)(cell - (long)y * X);
+    Window w{in, X, E, max(0, y - hw), (int)min((long)Y - 1, (long)y + hw), max(0, x - hw), (int)min((long)X - 1, (long)x + hw)};
+    const int n = w.count();
+    float value = NAN;
+    if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT || statistic == GPP_STD || statistic == GPP_VARIANCE) {
+        // sequential float accumulation in gather order (util.cpp:22-38,41-72): one lane walks the window
+        if(lane == 0) {
+            float total = 0, total2 = 0, K = NAN; int count = 0;
+            const bool sv = (statistic == GPP_STD || statistic == GPP_VARIANCE);
+            for(int i = 0; i < n; i++) {
+                float v = w.at(i);
+                if(!nv(v)) continue;
+                if(sv) { if(!nv(K)) K = v; float d = v - K; total += d; total2 += d * d; }
+                else total += v;
+                count++;
+            }
+            if(statistic == GPP_COUNT) value = (float)count;
+            else if(count > 0) {
+                if(statistic == GPP_MEAN) value = total / (float)count;
+                else if(statistic == GPP_SUM) value = total;
+                else { float mean = total / (float)count, mean2 = total2 / (float)count; float var = mean2 - mean * mean; if(var < 0) var = 0; value = (statistic == GPP_STD) ? sqrtf(var) : var; }
+            }
+        }
+    }
+    else {
+        int N = 0;
+        for(int i = lane; i < n; i += 64) if(nv(w.at(i))) N++;
+        N = wave_sum_i(N);
+        if(statistic == GPP_RANDOMCHOICE) {   // util.cpp:74-95 uses rand(); any valid element is a correct draw
+            if(N > 0) {
+                unsigned h = (unsigned)cell * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                value = wave_kth(w, n, (int)(h % (unsigned)N), lane);   // rank-th smallest valid value
+            }
+        }
+        else {
+            float qq = (statistic == GPP_MIN) ? 0.0f : (statistic == GPP_MEDIAN) ? 0.5f : (statistic == GPP_MAX) ? 1.0f : q;
+            if(N > 0 && nv(qq)) {
+                if(qq == 0) value = wave_kth(w, n, 0, lane);
+                else if(qq == 1) value = wave_kth(w, n, N - 1, lane);
+                else {
+                    float pos = qq * (float)(N - 1);
+                    int li = (int)floorf(pos), ui = (int)ceilf(pos);
+                    float lv = wave_kth(w, n, li, lane);
+                    float uv = (ui == li) ? lv : wave_kth(w, n, ui, lane);
+                    value = quantile_from_order(qq, N, lv, uv, li, ui);
+                }
+            }
+        }
+    }
+    if(lane == 0) out[cell] = value;
+}
+
+// -------------------------------------------------------------------------------------------
+// quantile_fast finish: neighbourhood.cpp:483-522 + util.cpp:339-414
+// -------------------------------------------------------------------------------------------
+// stats plane -> yarray plane, in place: E-fold float accumulation then / count (3-D form :494-499), clamp to [0,1]
+__global__ void k_qf_yarray(float* __restrict__ planes, long n, int reps) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    float s = planes[i];
+    if(!nv(s)) { planes[i] = NAN; return; }
+    float yv;
+    if(reps <= 1) yv = s;   // 2-D form (:378-384): sum = s, count = 1
+    else { float sum = 0; for(int e = 0; e < reps; e++) sum += s; yv = sum / (float)reps; }
+    if(yv > 1) yv = 1; else if(yv < 0) yv = 0;
+    planes[i] = yv;
+}
+__global__ void k_qf_interp(const float* __restrict__ ya, long C, int T, const float* __restrict__ thr, const float* __restrict__ q, int qfield, float* __restrict__ out) {
+    long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(c >= C) return;
+    const float x = qfield ? q[c] : q[0];
+    bool missing = false;
+    for(int t = 0; t < T; t++) if(!nv(ya[(long)t * C + c])) missing = true;
+    float o = NAN;
+    if(!missing) {
+        const float y0a = ya[c], yLa = ya[(long)(T - 1) * C + c];
+        if(x == 1 && y0a == 1) o = thr[0];
+        else if(x == 0 && yLa == 0) o = thr[T - 1];
+        else if(!nv(x)) o = NAN;                       // interpolate(): util.cpp:378-379
+        else if(x > yLa) o = thr[T - 1];               // util.cpp:386-389
+        else if(x < y0a) o = thr[0];
+        else {
+            int i0 = -1, i1 = -1;                      // get_lower_index / get_upper_index (util.cpp:339-376)
+            for(int i = 0; i < T; i++) { float cv = ya[(long)i * C + c]; if(cv < x) i0 = i; else if(cv == x) { i0 = i; break; } else break; }
+            for(int i = T - 1; i >= 0; i--) { float cv = ya[(long)i * C + c]; if(cv > x) i1 = i; else if(cv == x) { i1 = i; break; } else break; }
+            if(i0 < 0) i0 = 0;
+            if(i1 < 0) i1 = T - 1;
+            const float x0 = ya[(long)i0 * C + c], x1 = ya[(long)i1 * C + c], y0 = thr[i0], y1 = thr[i1];
+            if(x0 == x1) {
+                if(i0 == 0 && i1 == T - 1) o = (y0 + y1) / 2;
+                else if(i0 == 0) o = y1;
+                else if(i1 == T - 1) o = y0;
+                else o = (y0 + y1) / 2;
+            }
+            else o = y0 + (y1 - y0) * (x - x0) / (x1 - x0);
+        }
+    }
+    out[c] = o;
+}
+
+// -------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------
+namespace {
+struct NbWorkspace {
+    DevBuf<float> flat, tmp, tmp2, planes, thr, qf;
+    DevBuf<double> rs;
+    DevBuf<int> rc;
+};
+thread_local NbWorkspace g_nb;
+
+void member_pass(const float* d_in, long C, int E, int mode, int statistic, const float* d_thr, int T, float* d_out) {
+    long tiles = (C + 63) / 64;
+    size_t lds = (size_t)4 * 64 * (MEMBER_EC | 1) * sizeof(float);
+    static bool attr = false;
+    if(!attr) { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(k_member_pass, dim3((unsigned)((tiles + 3) / 4)), dim3(256), lds, stream(), d_in, C, E, mode, statistic, d_thr, T, d_out);
+    GPP_HIP(hipGetLastError());
+}
+// Mean / Sum / Count of `nplanes` [Y][X] planes
+void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statistic, float* d_out) {
+    long n = (long)Y * X * nplanes;
+    double* rs = g_nb.rs.get(n);
+    int* rc = g_nb.rc.get(n);
+    int hwc = std::min(hw, X);
+    if((256 + 2 * (size_t)hwc) * sizeof(float) > 160 * 1024) runtime("neighbourhood: halfwidth too large for the row pass");
+    static size_t lds_set = 0;
+    if((256 + 2 * (size_t)hwc) * sizeof(float) > std::max<size_t>(lds_set, 64 * 1024)) {
+        lds_set = 160 * 1024;
+        GPP_HIP(hipFuncSetAttribute((const void*)k_box_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_set));
+    }
+    hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, Y, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc);
+    GPP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_box_cols, dim3((X + 63) / 64, (Y + 3) / 4, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out);
+    GPP_HIP(hipGetLastError());
+}
+void brute(const float* d_in, int Y, int X, int E, int hw, int statistic, float q, float* d_out) {
+    long C = (long)Y * X;
+    static unsigned seed = 12345u;
+    seed = seed * 1664525u + 1013904223u;
+    hipLaunchKernelGGL(k_brute, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, stream(), d_in, Y, X, E, hw, statistic, q, seed, d_out);
+    GPP_HIP(hipGetLastError());
+}
+// neighbourhood(vec2, hw, stat) on a device-resident plane (neighbourhood.cpp:28-242)
+void neighbourhood2d(const float* d_in, int Y, int X, int hw, int statistic, float* d_out) {
+    long C = (long)Y * X;
+    if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT) box_stat(d_in, Y, X, 1, hw, statistic, d_out);
+    else if(statistic == GPP_MIN || statistic == GPP_MAX) {
+        float* t = g_nb.tmp.get(C);
+        dim3 grid((X + 63) / 64, (Y + 3) / 4);
+        hipLaunchKernelGGL(k_minmax_pass, grid, dim3(256), 0, stream(), d_in, Y, X, hw, statistic == GPP_MAX, 1, t);
+        hipLaunchKernelGGL(k_minmax_pass, grid, dim3(256), 0, stream(), (const float*)t, Y, X, hw, statistic == GPP_MAX, 0, d_out);
+        GPP_HIP(hipGetLastError());
+    }
+    else if(statistic == GPP_STD || statistic == GPP_VARIANCE) {
+        float* mean = g_nb.tmp.get(C);
+        float* sq = g_nb.tmp2.get(2 * C);
+        float* mean2 = sq + C;
+        box_stat(d_in, Y, X, 1, hw, GPP_MEAN, mean);
+        hipLaunchKernelGGL(k_square, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream(), d_in, C, sq);
+        box_stat(sq, Y, X, 1, hw, GPP_MEAN, mean2);
+        hipLaunchKernelGGL(k_std_finish, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream(), (const float*)mean, (const float*)mean2, C, statistic == GPP_STD, d_out);
+        GPP_HIP(hipGetLastError());
+    }
+    else brute(d_in, Y, X, 1, hw, statistic, 0.0f, d_out);   // Median, RandomChoice (:236-238)
+}
+}   // namespace
+
+static void check_stat(int s) {
+    switch(s) {
+        case GPP_MEAN: case GPP_MIN: case GPP_MEDIAN: case GPP_MAX: case GPP_QUANTILE: case GPP_STD: case GPP_VARIANCE:
+        case GPP_SUM: case GPP_COUNT: case GPP_RANDOMCHOICE: return;
+        default: runtime("Internal error. Cannot compute statistic");
+    }
+}
+
+extern "C" int gpp_neighbourhood(const float* input, int ny, int nx, int ne, int is3d, int halfwidth, int statistic, float* out, int mem) {
+    GPP_TRY
+    if(halfwidth < 0) invalid("Half width must be > 0");                                          // :29-30
+    if(statistic == GPP_QUANTILE) invalid("Use neighbourhood_quantile for computing neighbourhood quantiles");   // :31-32
+    check_stat(statistic);
+    if(ny < 0 || nx < 0 || ne < 0) invalid("negative size");
+    if(ny == 0 || nx == 0 || ne == 0) return GPP_OK;                                                // :33-34
+    ensure_device();
+    const long C = (long)ny * nx;
+    InField in; OutField o;
+    in.bind(input, (size_t)C * ne, mem);
+    o.bind(out, C, mem);
+    const float* plane = in.d;
+    if(is3d) {   // 3-D form: member statistic first (:12-27)
+        float* flat = g_nb.flat.get(C);
+        if(statistic == GPP_MEDIAN) hipLaunchKernelGGL(k_member_quantile, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream(), in.d, C, ne, 0.5f, flat);
+        else if(statistic == GPP_RANDOMCHOICE) brute(in.d, ny, nx, ne, 0, GPP_RANDOMCHOICE, 0, flat);
+        else member_pass(in.d, C, ne, 0, statistic, nullptr, 0, flat);
+        plane = flat;
+    }
+    neighbourhood2d(plane, ny, nx, halfwidth, statistic, o.d);
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+extern "C" int gpp_neighbourhood_brute_force(const float* input, int ny, int nx, int ne, int halfwidth, int statistic, float quantile, float* out, int mem) {
+    GPP_TRY
+    if(halfwidth < 0) invalid("Half width must be > 0");   // :558-559
+    check_stat(statistic);
+    if(statistic == GPP_QUANTILE && (quantile < 0 || quantile > 1))
+        invalid("calc_quantile: Quantile must be between 0 and 1 inclusive");   // util.cpp:113-115
+    if(ny <= 0 || nx <= 0 || ne <= 0) return GPP_OK;
+    ensure_device();
+    const long C = (long)ny * nx;
+    InField in; OutField o;
+    in.bind(input, (size_t)C * ne, mem);
+    o.bind(out, C, mem);
+    brute(in.d, ny, nx, ne, halfwidth, statistic, quantile, o.d);
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int nx, int ne, int is3d, const float* quantile, int nq,
+                                               int halfwidth, const float* thresholds, int nt, float* out, int mem) {
+    GPP_TRY
+    if(halfwidth < 0) invalid("Half width must be > 0");                                   // :303-304,419-420
+    if(ny <= 0 || nx <= 0 || ne <= 0) return GPP_OK;                                        // :306-307
+    const long C = (long)ny * nx;
+    if(nq != 1 && nq != C) invalid("Quantile must be the same size as input, or size (1, 1)");   // :312-313
+    if(nt < 0) invalid("negative number of thresholds");
+    ensure_device();
+    InField in, qf, th;
+    OutField o;
+    in.bind(input, (size_t)C * ne, mem);
+    o.bind(out, C, mem);
+    // quantile validation (:315-321) needs the values on the host
+    std::vector<float> hq(nq);
+    if(mem & GPP_MEM_DEVICE) { GPP_HIP(hipMemcpyAsync(hq.data(), quantile, sizeof(float) * nq, hipMemcpyDeviceToHost, stream())); GPP_HIP(hipStreamSynchronize(stream())); }
+    else memcpy(hq.data(), quantile, sizeof(float) * nq);
+    for(int i = 0; i < nq; i++)
+        if(is_valid(hq[i]) && (hq[i] < 0 || hq[i] > 1)) invalid("All quantiles must be >= 0 and <= 1");
+    if(nt == 0) {   // :330-331: all missing
+        hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream(), o.d, C);
+        o.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));
+        return GPP_OK;
+    }
+    qf.bind(quantile, nq, mem);
+    th.bind(thresholds, nt, mem);
+    float* planes = g_nb.planes.get((size_t)nt * C);
+    float* stats = g_nb.tmp2.get((size_t)nt * C);
+    member_pass(in.d, C, ne, 1, 0, th.d, nt, planes);                 // fractions per threshold (:453-472)
+    box_stat(planes, ny, nx, nt, halfwidth, GPP_MEAN, stats);         // stats[t] = neighbourhood(temp, hw, Mean) (:473)
+    long n = (long)nt * C;
+    hipLaunchKernelGGL(k_qf_yarray, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), stats, n, is3d ? ne : 1);
+    hipLaunchKernelGGL(k_qf_interp, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream(), (const float*)stats, C, nt, th.d, qf.d, nq == 1 ? 0 : 1, o.d);
+    GPP_HIP(hipGetLastError());
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+// -------------------------------------------------------------------------------------------
+// util: calc_statistic / calc_quantile on rows, calc_even_quantiles / get_neighbourhood_thresholds
+// -------------------------------------------------------------------------------------------
+__global__ void k_rows_quantile(const float* __restrict__ in, long rows, int len, const float* __restrict__ q, int qfield, float* __restrict__ out) {
+    long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(r < rows) out[r] = row_quantile(in + r * len, len, qfield ? q[r] : q[0]);
+}
+__global__ void k_rows_statistic(const float* __restrict__ in, long rows, int len, int statistic, float* __restrict__ out) {
+    long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(r >= rows) return;
+    if(statistic == GPP_MEDIAN) out[r] = row_quantile(in + r * len, len, 0.5f);
+    else out[r] = row_statistic(in + r * len, len, statistic);
+}
+
+// gridpp::calc_statistic(vec2, statistic) (util.cpp:19-110,208-215): one value per row
+extern "C" int gpp_calc_statistic(const float* array, long rows, int len, int statistic, float* out, int mem) {
+    GPP_TRY
+    check_stat(statistic);
+    if(statistic == GPP_QUANTILE || statistic == GPP_RANDOMCHOICE) runtime("Internal error. Cannot compute statistic");
+    if(rows <= 0) return GPP_OK;
+    ensure_device();
+    InField in; OutField o;
+    in.bind(array, (size_t)rows * len, mem);
+    o.bind(out, rows, mem);
+    if(len <= MEMBER_EC && statistic != GPP_MEDIAN && len > 0) member_pass(in.d, rows, len, 0, statistic, nullptr, 0, o.d);
+    else hipLaunchKernelGGL(k_rows_statistic, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream(), in.d, rows, len, statistic, o.d);
+    GPP_HIP(hipGetLastError());
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+// gridpp::calc_quantile(vec, q) / (vec2, q) / (vec3, vec2 q) (util.cpp:111-207): nq == 1 or nq == rows
+extern "C" int gpp_calc_quantile(const float* array, long rows, int len, const float* quantile, long nq, float* out, int mem) {
+    GPP_TRY
+    if(nq != 1 && nq != rows) invalid("Dimension mismatch between array and quantile");
+    if(rows <= 0) return GPP_OK;
+    ensure_device();
+    std::vector<float> hq(nq);
+    if(mem & GPP_MEM_DEVICE) { GPP_HIP(hipMemcpyAsync(hq.data(), quantile, sizeof(float) * nq, hipMemcpyDeviceToHost, stream())); GPP_HIP(hipStreamSynchronize(stream())); }
+    else memcpy(hq.data(), quantile, sizeof(float) * nq);
+    for(long i = 0; i < nq; i++)
+        if(hq[i] < 0 || hq[i] > 1) invalid("calc_quantile: Quantile must be between 0 and 1 inclusive");   // util.cpp:113-115 (NaN passes)
+    InField in, q; OutField o;
+    in.bind(array, (size_t)rows * len, mem);
+    q.bind(quantile, nq, mem);
+    o.bind(out, rows, mem);
+    hipLaunchKernelGGL(k_rows_quantile, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream(), in.d, rows, len, q.d, nq == 1 ? 0 : 1, o.d);
+    GPP_HIP(hipGetLastError());
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+__global__ void k_count_equal(const float* __restrict__ v, long n, float x, unsigned long long* __restrict__ cnt) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool eq = i < n && v[i] == x;
+    unsigned long long m = __ballot(eq);
+    if((threadIdx.x & 63) == 0 && m) atomicAdd(cnt, (unsigned long long)__popcll(m));
+}
+struct IsValidF { __device__ bool operator()(const float& v) const { return !isnan(v) && !isinf(v); } };
+
+// gridpp::calc_even_quantiles (util.cpp:261-338) on the valid values of `values`; the global sort and the
+// unique pass run on the device (hipCUB radix sort / select), the index picks on the host.
+// out must hold `num` floats; *count is the number written.
+extern "C" int gpp_calc_even_quantiles(const float* values, long n, int num, int only_valid, float* out, int* count, int mem) {
+    GPP_TRY
+    if(!count) invalid("count is NULL");
+    *count = 0;
+    if(num <= 0 || n <= 0) return GPP_OK;
+    if(n > 0x7fffffffL) runtime("calc_even_quantiles: more than 2^31 values");
+    ensure_device();
+    InField in;
+    in.bind(values, n, mem);
+    DevBuf<float> valid, sorted, uniq;
+    DevBuf<int> dnum;
+    DevBuf<char> tmp;
+    DevBuf<unsigned long long> dcnt;
+    valid.get(n); sorted.get(n); uniq.get(n); dnum.get(1); dcnt.get(1);
+    size_t bytes = 0;
+    int nvalid = (int)n;
+    const float* src = in.d;
+    if(only_valid) {
+        GPP_HIP(hipcub::DeviceSelect::If(nullptr, bytes, in.d, valid.p, dnum.p, (int)n, IsValidF(), stream()));
+        tmp.get(bytes);
+        GPP_HIP(hipcub::DeviceSelect::If(tmp.p, bytes, in.d, valid.p, dnum.p, (int)n, IsValidF(), stream()));
+        GPP_HIP(hipMemcpyAsync(&nvalid, dnum.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipStreamSynchronize(stream()));
+        src = valid.p;
+    }
+    const int size = nvalid;
+    if(size == 0) return GPP_OK;
+    bytes = 0;
+    GPP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, src, sorted.p, size, 0, 32, stream()));
+    tmp.get(bytes);
+    GPP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, bytes, src, sorted.p, size, 0, 32, stream()));
+    bytes = 0;
+    GPP_HIP(hipcub::DeviceSelect::Unique(nullptr, bytes, sorted.p, uniq.p, dnum.p, size, stream()));
+    tmp.get(bytes);
+    GPP_HIP(hipcub::DeviceSelect::Unique(tmp.p, bytes, sorted.p, uniq.p, dnum.p, size, stream()));
+    int nu = 0;
+    GPP_HIP(hipMemcpyAsync(&nu, dnum.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    auto fetch = [&](const float* d, long i) { float v; GPP_HIP(hipMemcpyAsync(&v, d + i, sizeof(float), hipMemcpyDeviceToHost, stream())); GPP_HIP(hipStreamSynchronize(stream())); return v; };
+    std::vector<float> q;
+    if(num >= size) {   // util.cpp:271-281: all unique values
+        q.resize(nu);
+        GPP_HIP(hipMemcpyAsync(q.data(), uniq.p, sizeof(float) * nu, hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipStreamSynchronize(stream()));
+    }
+    else {
+        const float lowest = fetch(uniq.p, 0), highest = fetch(uniq.p, nu - 1);
+        GPP_HIP(hipMemsetAsync(dcnt.p, 0, sizeof(unsigned long long), stream()));
+        hipLaunchKernelGGL(k_count_equal, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, stream(), (const float*)sorted.p, (long)size, lowest, dcnt.p);
+        unsigned long long cl = 0;
+        GPP_HIP(hipMemcpyAsync(&cl, dcnt.p, sizeof(cl), hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipStreamSynchronize(stream()));
+        const long count_lower = (long)cl;
+        q.push_back(lowest);
+        if(num == 2) { if(lowest != highest) q.push_back(highest); }
+        else {
+            int first_remaining = 1;   // index into uniq of the first value > last_added
+            const bool repeated = count_lower < size && count_lower > size / num;   // util.cpp:306
+            if(repeated) { q.push_back(fetch(uniq.p, 1)); first_remaining = 2; }
+            const long nrem = nu - first_remaining;
+            if(nrem > 0) {
+                const int num_left = num - (int)q.size();
+                for(int i = 1; i <= num_left; i++) {
+                    float f = float(i) / (num_left);
+                    int index = (int)((float)nrem * f - 1);   // util.cpp:322
+                    if(index >= 0) q.push_back(fetch(uniq.p, first_remaining + index));
+                    else runtime("Internal error in calc_even_quantiles.");
+                }
+            }
+        }
+    }
+    *count = (int)q.size();
+    if(mem & GPP_MEM_DEVICE) GPP_HIP(hipMemcpyAsync(out, q.data(), sizeof(float) * q.size(), hipMemcpyHostToDevice, stream()));
+    else memcpy(out, q.data(), sizeof(float) * q.size());
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}

@@ -340,11 +340,17 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             cnt = overflow ? 0 : cnt;
         }
 
-        // ---- order-independent signature of every lane's selected set ------------------------------------------
+        // ---- order-independent signature of every lane's selected set; the 64-bit keys are compacted in place
+        //      to a u32 observation-index list (lower 8 KB), freeing the upper half for column staging ----------
         unsigned long long h1 = 0, h2s = 0;
+        unsigned (*origs)[64] = reinterpret_cast<unsigned (*)[64]>(&keys[0][0]);          // [N][64] u32
+        float (*colbuf)[64] = reinterpret_cast<float (*)[64]>(&keys[N / 2][0]);           // [N][64] f32
         for(int s = 0; s < K; ++s) {
+            const unsigned long long kk = keys[s][lane];     // all lanes read slot s ...
+            const unsigned o = ~(unsigned)(kk & 0xffffffffull);
+            __builtin_amdgcn_wave_barrier();
+            origs[s][lane] = o;                              // ... before anything of slots <= s/2 is overwritten
             if(s < cnt) {
-                const unsigned o = ~(unsigned)(keys[s][lane] & 0xffffffffull);
                 h1 += mix64((unsigned long long)o + 0x9e3779b97f4a7c15ull);
                 h2s ^= mix64(((unsigned long long)o << 1) ^ 0xd6e8feb86659fd93ull);
             }
@@ -372,8 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             todo &= ~members;
             nsolve++;
             // lane i < n takes the i-th selected observation of the leader; lane N+1+m takes member cell m
-            unsigned long long key = (lane < n) ? keys[lane][l] : 0ull;
-            const unsigned orig_i = ~(unsigned)(key & 0xffffffffull);
+            const unsigned orig_i = (lane < n) ? origs[lane][l] : 0u;
             float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
             if(lane < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
             const int mi = lane - (N + 1);
@@ -383,23 +388,28 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             float px = __shfl(gx, src), py = __shfl(gy, src), pz = __shfl(gz, src), pe = __shfl(ge, src), pl = __shfl(gl, src);
             const float cbg = __shfl(bg, src), cbv = __shfl(bvar, src);
             if(lane < n) { px = o0.x; py = o0.y; pz = o0.z; pe = o0.w; pl = o1.x; }
-            double row[N];
             float maxInc = -INFINITY, minInc = INFINITY;
+            // column p of [P ; G] across the lanes (rolled: one copy of the exp code), staged through LDS
+            for(int p = 0; p < n; ++p) {
+                const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
+                const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
+                // matrix rows: corr(obs_i, obs_p) (oi.cpp:304-312); G rows: corr(cell, obs_p) (oi.cpp:250)
+                const float c = d_barnes_corr(px, py, pz, pe, pl, xp, yp, zp, ep, lp, a.h, a.v, a.w, a.R);
+                colbuf[p][lane] = c;
+                const float dpf = (float)((double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p));
+                maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
+            }
+            double row[N];
+            const bool used = lane < n || lane == N || is_g;
 #pragma unroll
             for(int p = 0; p < N; ++p) {
                 double v = 0.0;
                 if(p < n) {
-                    const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
-                    const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
-                    // matrix rows: corr(obs_i, obs_p) (oi.cpp:304-312); G rows: corr(cell, obs_p) (oi.cpp:250)
-                    const float c = d_barnes_corr(px, py, pz, pe, pl, xp, yp, zp, ep, lp, a.h, a.v, a.w, a.R);
-                    v = (double)c;
-                    if(lane == p) v += (double)o1.w;                                         // lP + lR
-                    const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);   // lObs - lY
-                    const float dpf = (float)dp;
-                    maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
+                    v = (double)colbuf[p][lane];
+                    if(lane == p) v += (double)o1.w;                                                   // lP + lR
+                    const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);       // lObs - lY
                     if(lane == N) v = dp;
-                    if(!(lane < n || lane == N || is_g)) v = 0.0;
+                    if(!used) v = 0.0;
                 }
                 row[p] = v;
             }

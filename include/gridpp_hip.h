@@ -126,6 +126,36 @@ int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* background, c
                                    const gpp_structure* structure, int max_points, int allow_extrapolation,
                                    float* out, float* out_variance, int mem);
 
+/* ---- neighbourhood filters (src/api/neighbourhood.cpp) -------------------------
+ * input is [ny][nx] (is3d == 0, ne must be 1) or [ny][nx][ne] (is3d == 1); out is
+ * [ny][nx].  Empty input (any extent 0) returns GPP_OK and writes nothing
+ * (neighbourhood.cpp:33-34).  Windows are clipped at the domain edge; NaN / inf
+ * values are ignored (util.cpp:16-18). */
+/* gridpp::neighbourhood(vec2|vec3, halfwidth, statistic) (neighbourhood.cpp:12-242) */
+int gpp_neighbourhood(const float* input, int ny, int nx, int ne, int is3d, int halfwidth, int statistic,
+                      float* out, int mem);
+/* gridpp::neighbourhood_brute_force (statistic != GPP_QUANTILE) and
+ * gridpp::neighbourhood_quantile (statistic == GPP_QUANTILE, exact order statistics)
+ * (neighbourhood.cpp:528-539,557-654; util.cpp:19-178) */
+int gpp_neighbourhood_brute_force(const float* input, int ny, int nx, int ne, int halfwidth, int statistic,
+                                  float quantile, float* out, int mem);
+/* gridpp::neighbourhood_quantile_fast, all four overloads (neighbourhood.cpp:296-527):
+ * quantile is one value (nq == 1) or a [ny][nx] field (nq == ny*nx); thresholds[nt]. */
+int gpp_neighbourhood_quantile_fast(const float* input, int ny, int nx, int ne, int is3d,
+                                    const float* quantile, int nq, int halfwidth,
+                                    const float* thresholds, int nt, float* out, int mem);
+
+/* ---- per-row statistics (src/api/util.cpp) -------------------------------------
+ * array is [rows][len]; one result per row. */
+/* gridpp::calc_statistic(vec|vec2, statistic) (util.cpp:19-110,208-215) */
+int gpp_calc_statistic(const float* array, long rows, int len, int statistic, float* out, int mem);
+/* gridpp::calc_quantile(vec|vec2, q) and (vec3, vec2 q) (util.cpp:111-207): nq == 1 or nq == rows */
+int gpp_calc_quantile(const float* array, long rows, int len, const float* quantile, long nq, float* out, int mem);
+/* gridpp::calc_even_quantiles (util.cpp:261-338) and, with only_valid = 1,
+ * gridpp::get_neighbourhood_thresholds (neighbourhood.cpp:243-295) over the n
+ * values of a flattened field.  out holds num floats; *count = number written. */
+int gpp_calc_even_quantiles(const float* values, long n, int num, int only_valid, float* out, int* count, int mem);
+
 /* per-call statistics of the last OI call on this thread (diagnostics / bench) */
 typedef struct gpp_oi_stats {
     long long cells;          /* grid cells processed */

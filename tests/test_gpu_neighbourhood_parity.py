@@ -1,0 +1,139 @@
+"""HIP neighbourhood filters vs the CPU oracle on seeded inputs (through the C-ABI).
+Tolerance: 1e-5 relative (BASELINE.json north_star); counts and min/max are exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def field(seed, Y, X, E=None, nan_blocks=True):
+    rng = np.random.default_rng(seed)
+    shape = (Y, X) if E is None else (Y, X, E)
+    f = rng.uniform(0, 10, shape).astype(np.float32)
+    if nan_blocks:
+        f[3:9, 5:20] = np.nan
+        f[rng.random(shape) < 0.03] = np.nan
+        if E is not None:
+            f[20:24, 30:36, :] = np.nan   # cells with no valid member
+    return f
+
+
+def close(a, b, exact=False):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == np.float32
+    assert (np.isnan(a) == np.isnan(b)).all(), (np.isnan(a).sum(), np.isnan(b).sum())
+    m = ~np.isnan(b)
+    if exact:
+        assert (a[m] == b[m]).all()
+    else:
+        err = np.abs(a[m].astype(np.float64) - b[m]) / np.maximum(np.abs(b[m]), 1e-3)
+        assert err.max() < RTOL, err.max()
+
+
+@pytest.fixture(scope="module")
+def api():
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    return gridpp, O
+
+
+@pytest.mark.parametrize("hw", [0, 1, 7, 15, 300])
+def test_2d_statistics(api, hw):
+    gridpp, O = api
+    f = field(1, 257, 193)
+    for stat in (gridpp.Mean, gridpp.Sum, gridpp.Std, gridpp.Variance):
+        out = gridpp.neighbourhood(f, hw, stat)
+        ref = O.neighbourhood(f, hw, stat)
+        if stat in (gridpp.Std, gridpp.Variance):
+            # E[x^2]-E[x]^2 in float32 cancels catastrophically and is not clamped by the reference
+            # (neighbourhood.cpp:222-233); on top of that the reference's summed-area table carries an
+            # absolute double-rounding noise of ~1e-16 * (sum of the whole field) that the separable box sums
+            # do not have.  Parity is therefore 1e-5 relative to the magnitude of the cancelling terms
+            # (E[x^2] <= 100 here), and the sign of a ~0 variance (NaN std) is not compared.
+            both = ~np.isnan(ref) & ~np.isnan(out)
+            assert both.sum() > 0.9 * (~np.isnan(f)).sum()
+            if stat == gridpp.Variance:
+                assert np.abs(out[both] - ref[both]).max() < 1e-5 * 100
+            else:
+                big = both & (ref > 0.1)
+                if big.any():
+                    assert (np.abs(out[big] - ref[big]) / ref[big]).max() < 1e-3
+        else:
+            close(out, ref)
+    for stat in (gridpp.Count, gridpp.Min, gridpp.Max):
+        close(gridpp.neighbourhood(f, hw, stat), O.neighbourhood(f, hw, stat), exact=True)
+
+
+@pytest.mark.parametrize("E", [1, 5, 100, 130])
+def test_3d_statistics(api, E):
+    gridpp, O = api
+    f = field(2 + E, 70, 90, E)
+    for stat in (gridpp.Mean, gridpp.Sum):
+        close(gridpp.neighbourhood(f, 3, stat), O.neighbourhood(f, 3, stat))
+    for stat in (gridpp.Count, gridpp.Min, gridpp.Max):
+        close(gridpp.neighbourhood(f, 3, stat), O.neighbourhood(f, 3, stat), exact=True)
+
+
+def test_median_and_brute_force(api):
+    gridpp, O = api
+    f = field(5, 40, 33)
+    close(gridpp.neighbourhood(f, 2, gridpp.Median), O.neighbourhood(f, 2, O.Median), exact=True)
+    for stat in (gridpp.Mean, gridpp.Sum, gridpp.Std, gridpp.Variance):
+        close(gridpp.neighbourhood_brute_force(f, 2, stat), O.neighbourhood_brute_force(f, 2, stat), exact=True)
+    for stat in (gridpp.Min, gridpp.Max, gridpp.Median, gridpp.Count):
+        close(gridpp.neighbourhood_brute_force(f, 2, stat), O.neighbourhood_brute_force(f, 2, stat), exact=True)
+    f3 = field(6, 20, 18, 4)
+    close(gridpp.neighbourhood_brute_force(f3, 1, gridpp.Mean), O.neighbourhood_brute_force(f3, 1, O.Mean), exact=True)
+
+
+@pytest.mark.parametrize("q", [0.0, 0.1, 0.5, 0.9, 1.0])
+def test_exact_quantile(api, q):
+    gridpp, O = api
+    f = field(7, 64, 64)
+    close(gridpp.neighbourhood_quantile(f, q, 3), O.neighbourhood_quantile(f, q, 3), exact=True)
+    f3 = field(8, 24, 20, 5)
+    close(gridpp.neighbourhood_quantile(f3, q, 2), O.neighbourhood_quantile(f3, q, 2), exact=True)
+
+
+@pytest.mark.parametrize("T", [1, 2, 11, 100])
+def test_quantile_fast(api, T):
+    gridpp, O = api
+    thr = np.linspace(0, 10, T).astype(np.float32)
+    f2 = field(9, 120, 96)
+    f3 = field(10, 60, 72, 20)
+    rng = np.random.default_rng(3)
+    for f in (f2, f3):
+        Y, X = f.shape[:2]
+        for q in (0.0, 0.5, 0.9, 1.0):
+            out = gridpp.neighbourhood_quantile_fast(f, q, 4, thr)
+            ref = O.neighbourhood_quantile_fast(f, [q], 4, thr)
+            close(out, ref)
+        qf = rng.random((Y, X)).astype(np.float32)
+        qf[0, 0], qf[1, 1], qf[2, 2] = 0.0, 1.0, np.nan
+        close(gridpp.neighbourhood_quantile_fast(f, qf, 4, thr), O.neighbourhood_quantile_fast(f, qf, 4, thr))
+
+
+def test_thresholds_match_oracle(api):
+    gridpp, O = api
+    f = field(11, 50, 60, 7)
+    for num in (1, 2, 5, 11, 100):
+        np.testing.assert_array_equal(gridpp.get_neighbourhood_thresholds(f, num), O.get_neighbourhood_thresholds(f, num))
+    g = np.round(field(12, 30, 30, nan_blocks=False))   # many duplicates
+    g[:20] = 0
+    for num in (2, 3, 4, 7):
+        np.testing.assert_array_equal(gridpp.get_neighbourhood_thresholds(g, num), O.get_neighbourhood_thresholds(g, num))
+
+
+def test_device_resident_path(api):
+    """torch CUDA tensors in, torch tensor out: same numbers as the host path."""
+    import torch
+    gridpp, O = api
+    f = field(13, 64, 80, 10)
+    d = torch.from_numpy(f).cuda()
+    out = gridpp.neighbourhood(d, 5, gridpp.Mean)
+    assert out.is_cuda
+    np.testing.assert_array_equal(out.cpu().numpy(), gridpp.neighbourhood(f, 5, gridpp.Mean))
+    thr = np.linspace(0, 10, 11).astype(np.float32)
+    out = gridpp.neighbourhood_quantile_fast(d, 0.5, 5, thr)
+    np.testing.assert_array_equal(out.cpu().numpy(), gridpp.neighbourhood_quantile_fast(f, 0.5, 5, thr))
