@@ -594,3 +594,48 @@ def get_neighbourhood_thresholds(input, num_thresholds):
     if num_thresholds <= 0:
         raise ValueError("num_thresholds must be > 0")
     return _even_quantiles(input, num_thresholds, 1)
+
+
+# ---- ensemble OI (include/gridpp.h:263-294, src/api/oi_ensi.cpp) ----------------------------------------
+def optimal_interpolation_ensi(bgrid, background, points, pobs, psigmas, pbackground, structure, max_points, allow_extrapolation=True):
+    """gridpp::optimal_interpolation_ensi, Grid (background (Y, X, E)) and Points (background (N, E)) overloads."""
+    if max_points < 0:
+        raise ValueError("max_points must be >= 0")
+    if not isinstance(bgrid, (Grid, Points)) or not isinstance(points, Points):
+        raise TypeError("bgrid must be a Grid or Points, points a Points")
+    nd = 3 if isinstance(bgrid, Grid) else 2
+    background = _vec(background, nd, "background")
+    S = points.size()
+    if S == 0:   # src/api/oi_ensi.cpp:48-50,135-137: returns the background before any other check
+        return background.clone() if _is_dev(background) else background.copy()
+    if bgrid.get_coordinate_type() != points.get_coordinate_type():
+        raise ValueError("Both background and observations points must be of same coordinate type (lat/lon or x/y)")
+    shape = tuple(bgrid.size()) if nd == 3 else (bgrid.size(),)
+    if nd == 3 and shape[0] * shape[1] == 0:
+        raise ValueError("Grid size cannot be zero")
+    if _shape(background)[:nd - 1] != shape:
+        raise ValueError("Input field is not the same size as the grid")
+    E = _shape(background)[-1]
+    pobs, psigmas = _vec(pobs, 1, "obs"), _vec(psigmas, 1, "sigmas")
+    pbackground = _vec(pbackground, 2, "background_at_points")
+    if _shape(pobs)[0] != S:
+        raise ValueError("Observations and points size mismatch")
+    if _shape(psigmas)[0] != S:
+        raise ValueError("Sigmas and points size mismatch")
+    if _shape(pbackground)[0] != S:
+        raise ValueError("Background and points size mismatch")
+    if _shape(pbackground)[1] != E:
+        raise ValueError("Ensemble members in gridded background is not the same as in the point background")
+    mem = _mem(background, pobs, psigmas, pbackground)
+    _sync_if_dev(mem)
+    out = _empty_like_field(_shape(background), background)
+    check(lib().gpp_optimal_interpolation_ensi(bgrid._h, _ptr(background), int(E), points._h, _ptr(pobs), _ptr(psigmas),
+                                               _ptr(pbackground), _structure(structure), int(max_points),
+                                               int(bool(allow_extrapolation)), _ptr(out), mem))
+    return out
+
+
+def ensi_last_kernel_ms():
+    ms = C.c_float(0)
+    check(lib().gpp_ensi_last_kernel_ms(C.byref(ms)))
+    return ms.value

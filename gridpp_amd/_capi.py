@@ -47,6 +47,8 @@ SIGNATURES = {
     "gpp_barnes_corr": [C.POINTER(gpp_structure), fp, fp, fp],
     "gpp_optimal_interpolation_full": [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, vp, C.c_int],
     "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
+    "gpp_optimal_interpolation_ensi": [vp, vp, C.c_int, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],
+    "gpp_ensi_last_kernel_ms": [fp],
     "gpp_calc_statistic": [vp, C.c_long, C.c_int, C.c_int, vp, C.c_int],
     "gpp_calc_quantile": [vp, C.c_long, C.c_int, vp, C.c_long, vp, C.c_int],
     "gpp_calc_even_quantiles": [vp, C.c_long, C.c_int, C.c_int, vp, ip, C.c_int],

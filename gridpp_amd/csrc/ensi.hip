@@ -1,0 +1,413 @@
+// Ensemble optimal interpolation (EnSI) on MI355X (gfx950).
+//
+// Replaces the serial loop of gridpp::optimal_interpolation_ensi (src/api/oi_ensi.cpp:114-568).
+//
+// Per grid cell the reference forms the E x E matrix Pinv = Y^T R^-1 Y + (E-1) I, inverts it, takes the
+// symmetric square root of (E-1) Pinv^-1 by eig_sym, and applies W = sqrt + w 1^T to the ensemble
+// perturbations (:379-553).  With A = R^-1/2 Y (n x E, n <= max_points selected observations) all of that is a
+// function of the n x n matrix B = A A^T = U S U^T  (c = E - 1):
+//     P      = I/c + A^T [-(1/c)(cI + B)^-1] A          (Woodbury)
+//     W_sym  = I   + A^T [U diag(-1 / (sqrt(c+S)(sqrt(c+S)+sqrt(c)))) U^T] A
+//     w      = P Y^T R^-1 d = A^T (cI + B)^-1 R^-1/2 d
+// so only an n x n (<= 32 x 32) symmetric eigenproblem is solved per cell instead of an E x E inverse plus an
+// E x E eigenproblem.  One wavefront per tile of 64 cells: the candidate scan is shared with the OI kernel
+// (oi_common.h), then the wave walks its cells; B, U live in LDS, the Jacobi sweeps use the round-robin
+// ordering (n/2 disjoint rotations per step, applied to rows, then columns of B and U by all 64 lanes).
+// The final member update reproduces the reference's float accumulation over k (:508-511) term by term.
+#include "oi_common.h"
+#include <algorithm>
+
+#pragma clang fp contract(off)
+using namespace gpp;
+
+#define EN 32          // max selected observations per cell
+#define EMAXV 64       // max valid ensemble members (one lane per member)
+#define BP (EN + 1)    // pitch of B / U (doubles)
+
+struct EnsiArgs {
+    const float *gx, *gy, *gz, *gelev, *glaf;
+    const float* bg;          // [C][E]
+    float* out;               // [C][E]
+    int C, E, ny, nx, tiles_x, ntiles, tiled2d;
+    ScanArgs s;
+    const float4* ogeo;       // original order: x,y,z,elev
+    const float4* oaux;       // original order: laf, obs, gYhat, sigma
+    const float* gY;          // [S][nV] perturbations of the valid members (float)
+    const int* validIdx;      // [nV]
+    int nV;
+    int allow_extrap;
+    int* err;
+    unsigned long long* counters;
+};
+
+// member validity over the whole field (oi_ensi.cpp:187-201): flags[e] = 0 if any cell is invalid
+__global__ void k_ensi_member_flags(const float* __restrict__ bg, long n, int E, int* __restrict__ flags) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n && !d_valid(bg[i])) flags[(int)(i % E)] = 0;
+}
+// gYhat / gY (oi_ensi.cpp:166-178): row mean with calc_statistic(Mean) semantics over ALL members
+__global__ void k_ensi_obs_prep(const float* __restrict__ pbg, int S, int E, const int* __restrict__ validIdx, int nV,
+                                float* __restrict__ gYhat, float* __restrict__ gY) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if(s >= S) return;
+    const float* row = pbg + (long)s * E;
+    float total = 0; int count = 0;
+    for(int e = 0; e < E; e++) { float v = row[e]; if(d_valid(v)) { total += v; count++; } }
+    float mean = count > 0 ? total / (float)count : NAN;
+    gYhat[s] = mean;
+    for(int k = 0; k < nV; k++) {
+        float v = row[validIdx[k]];
+        gY[(long)s * nV + k] = (d_valid(v) && d_valid(mean)) ? v - mean : v;
+    }
+}
+__global__ void k_copy(const float* __restrict__ in, long n, float* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = in[i];
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for(int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
+    __shared__ unsigned long long s_keys[EN][64];        // 16 KB: keys, then origs (u32) + Y tile (f32)
+    __shared__ double s_B[EN * BP];                       // B, later M_W
+    __shared__ double s_U[EN * BP];
+    __shared__ double s_sD[EN], s_r[EN], s_z[EN], s_S[EN], s_t[EN], s_dw[EN];
+    __shared__ double s_rot[2 * (EN / 2)];
+    __shared__ int s_pq[2 * (EN / 2)];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+
+    int cell = -1;
+    if(a.tiled2d) {
+        int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        int y = ty * 8 + (lane >> 3), x = tx * 8 + (lane & 7);
+        if(y < a.ny && x < a.nx) cell = y * a.nx + x;
+    }
+    else {
+        int c = tile * 64 + lane;
+        if(c < a.C) cell = c;
+    }
+    float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN;
+    if(cell >= 0) { gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell]; }
+    const bool active = cell >= 0;   // no background validity test here (oi_ensi.cpp:207-213)
+    if(__ballot(active) == 0ull) return;
+    const int nV = a.nV, E = a.E;
+
+    bool overflow, truncated;
+    int cnt = scan_tile<EN, true>(a.s, active, gx, gy, gz, ge, gl, s_keys, lane, overflow, truncated);
+    if(__ballot(overflow) != 0ull) {
+        if(lane == 0) atomicOr(a.err, 1);
+        cnt = overflow ? 0 : cnt;
+    }
+    // compact keys -> u32 observation lists in place (lower 8 KB); the upper 8 KB become the Y tile [EN][64] f32
+    unsigned (*origs)[64] = reinterpret_cast<unsigned (*)[64]>(&s_keys[0][0]);
+    float (*Yt)[64] = reinterpret_cast<float (*)[64]>(&s_keys[EN / 2][0]);
+    for(int s = 0; s < a.s.K; ++s) {
+        const unsigned long long kk = s_keys[s][lane];
+        __builtin_amdgcn_wave_barrier();
+        origs[s][lane] = ~(unsigned)(kk & 0xffffffffull);
+    }
+    __syncthreads();
+
+    const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
+    const double sqc = sqrt(c);
+    unsigned long long todo = __ballot(cnt > 0);
+    int ndone = 0;
+    while(todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int n = __builtin_amdgcn_readlane(cnt, l);
+        if(nV <= 1) continue;   // Pinv is the zero matrix: rcond <= 0 -> raw values (oi_ensi.cpp:386-390)
+        ndone++;
+        const int cell_l = __builtin_amdgcn_readlane(cell, l);
+        const float cx = readlane_f(gx, l), cy = readlane_f(gy, l), cz = readlane_f(gz, l), ce = readlane_f(ge, l), cl = readlane_f(gl, l);
+        // ---- per-observation quantities (lane i < n) ----------------------------------------------------------
+        const unsigned orig_i = (lane < n) ? origs[lane][l] : 0u;
+        float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 1);
+        if(lane < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
+        const float rho = d_barnes_corr(cx, cy, cz, ce, cl, o0.x, o0.y, o0.z, o0.w, o1.x, a.s.h, a.s.v, a.s.w, a.s.R);   // :227
+        const float sig2 = o1.w * o1.w;                                    // float product (:300)
+        const double D = (double)rho / (double)sig2;                       // Rinv(i,i)
+        const double sD = sqrt(D);
+        const double dobs = (double)o1.y - (double)o1.z;                   // lObs - lYhat (:437)
+        if(lane < n) { s_sD[lane] = sD; s_r[lane] = sD * dobs; }
+        // ---- Y tile: Yt[i][k] = gY[obs_i][k] (coalesced over k) -----------------------------------------------
+        for(int i = 0; i < n; ++i) {
+            const unsigned oi = (unsigned)__builtin_amdgcn_readlane((int)orig_i, i);
+            Yt[i][lane] = (lane < nV) ? a.gY[(long)oi * nV + lane] : 0.0f;
+        }
+        for(int i = n; i < EN; ++i) Yt[i][lane] = 0.0f;   // rows beyond n are multiplied by q[i] = 0 below: keep them finite
+        __syncthreads();
+        // ---- B = (sD sD^T) o (Y Y^T), U = I ---------------------------------------------------------------------
+        for(int idx = lane; idx < n * n; idx += 64) {
+            const int i = idx / n, j = idx - i * n;
+            double acc = 0.0;
+            if(j <= i) {
+                for(int k = 0; k < nV; ++k) acc = __builtin_fma((double)Yt[i][k], (double)Yt[j][k], acc);
+                acc *= s_sD[i] * s_sD[j];
+                s_B[i * BP + j] = acc; s_B[j * BP + i] = acc;
+            }
+            s_U[i * BP + j] = (i == j) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        // ---- cyclic Jacobi, round-robin ordering -----------------------------------------------------------------
+        const int m = n + (n & 1);
+        const int half = m >> 1;
+        double tr = 0.0;
+        for(int i = lane; i < n; i += 64) tr += fabs(s_B[i * BP + i]);
+        tr = wave_sum_d(tr);
+        for(int sweep = 0; sweep < 30 && n > 1; ++sweep) {
+            double off = 0.0;
+            for(int idx = lane; idx < n * n; idx += 64) { const int i = idx / n, j = idx - i * n; if(j < i) { double v = s_B[i * BP + j]; off += v * v; } }
+            off = wave_sum_d(off);
+            if(!(off > 1e-34 * tr * tr)) break;
+            for(int step = 0; step < m - 1; ++step) {
+                if(lane < half) {
+                    int p, q;
+                    if(lane == 0) { p = m - 1; q = step; }
+                    else { p = (step + lane) % (m - 1); q = (step - lane + (m - 1)) % (m - 1); }
+                    if(p > q) { int t = p; p = q; q = t; }
+                    double cs = 1.0, sn = 0.0;
+                    if(q < n) {
+                        const double apq = s_B[p * BP + q];
+                        if(apq != 0.0) {
+                            const double theta = (s_B[q * BP + q] - s_B[p * BP + p]) / (2.0 * apq);
+                            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                            cs = 1.0 / sqrt(t * t + 1.0); sn = t * cs;
+                        }
+                    }
+                    else q = p;   // dummy partner: identity
+                    s_rot[2 * lane] = cs; s_rot[2 * lane + 1] = sn;
+                    s_pq[2 * lane] = p; s_pq[2 * lane + 1] = q;
+                }
+                __syncthreads();
+                // columns: B <- B J, U <- U J
+                for(int idx = lane; idx < half * n; idx += 64) {
+                    const int k = idx / n, row = idx - k * n;
+                    const int p = s_pq[2 * k], q = s_pq[2 * k + 1];
+                    if(p != q) {
+                        const double cs = s_rot[2 * k], sn = s_rot[2 * k + 1];
+                        double x = s_B[row * BP + p], y = s_B[row * BP + q];
+                        s_B[row * BP + p] = cs * x - sn * y; s_B[row * BP + q] = sn * x + cs * y;
+                        x = s_U[row * BP + p]; y = s_U[row * BP + q];
+                        s_U[row * BP + p] = cs * x - sn * y; s_U[row * BP + q] = sn * x + cs * y;
+                    }
+                }
+                __syncthreads();
+                // rows: B <- J^T B
+                for(int idx = lane; idx < half * n; idx += 64) {
+                    const int k = idx / n, col = idx - k * n;
+                    const int p = s_pq[2 * k], q = s_pq[2 * k + 1];
+                    if(p != q) {
+                        const double cs = s_rot[2 * k], sn = s_rot[2 * k + 1];
+                        const double x = s_B[p * BP + col], y = s_B[q * BP + col];
+                        s_B[p * BP + col] = cs * x - sn * y; s_B[q * BP + col] = sn * x + cs * y;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- spectral functions -----------------------------------------------------------------------------------
+        if(lane < n) {
+            double S = s_B[lane * BP + lane];
+            if(S < 0.0) S = 0.0;
+            s_S[lane] = S;
+            const double rt = sqrt(c + S);
+            s_dw[lane] = -1.0 / (rt * (rt + sqc));      // W_sym = I + A^T U diag(dw) U^T A
+        }
+        __syncthreads();
+        // z = U diag(1/(c+S)) U^T r
+        double ur = 0.0;   // lane j: (U^T r)_j / (c + S_j)
+        if(lane < n) { for(int i = 0; i < n; ++i) ur = __builtin_fma(s_U[i * BP + lane], s_r[i], ur); ur /= (c + s_S[lane]); }
+        __syncthreads();
+        if(lane < n) s_t[lane] = ur;
+        __syncthreads();
+        if(lane < n) { double zz = 0.0; for(int j = 0; j < n; ++j) zz = __builtin_fma(s_U[lane * BP + j], s_t[j], zz); s_z[lane] = zz; }
+        // M_W = U diag(dw) U^T  -> overwrite B
+        __syncthreads();
+        for(int idx = lane; idx < n * n; idx += 64) {
+            const int i = idx / n, j = idx - i * n;
+            double acc = 0.0;
+            for(int k = 0; k < n; ++k) acc = __builtin_fma(s_U[i * BP + k] * s_dw[k], s_U[j * BP + k], acc);
+            s_B[i * BP + j] = acc;
+        }
+        __syncthreads();
+        // ---- ensemble side: lane k < nV owns member k -----------------------------------------------------------------
+        const int ek = (lane < nV) ? a.validIdx[lane] : 0;
+        const float value = (lane < nV) ? a.bg[(long)cell_l * E + ek] : 0.0f;
+        float total = 0; int count = 0;                      // oi_ensi.cpp:447-461: sequential float sum
+        for(int k = 0; k < nV; ++k) { const float v = readlane_f(value, k); if(d_valid(v)) { total += v; count++; } }
+        const float ensMean = total / (float)count;
+        const double X = (double)value - (double)ensMean;
+        // w_k = sum_i sD_i Y_ik z_i ;  q_i = sD_i * (M_W A)_ik  (A_jk = sD_j Y_jk)
+        double wk = 0.0;
+        double q[EN];
+#pragma unroll
+        for(int i = 0; i < EN; ++i) q[i] = 0.0;
+        for(int j = 0; j < n; ++j) {
+            const double ajk = s_sD[j] * (double)Yt[j][lane];
+            wk = __builtin_fma(ajk, s_z[j], wk);
+#pragma unroll
+            for(int i = 0; i < EN; ++i) q[i] = __builtin_fma(s_B[j * BP + i], ajk, q[i]);   // M_W symmetric: row j
+        }
+#pragma unroll
+        for(int i = 0; i < EN; ++i) q[i] = (i < n) ? q[i] * s_sD[i] : 0.0;
+        // total_e = sum_k X_k W(k,e), float accumulation in k order (oi_ensi.cpp:505-511)
+        float acc = 0.0f;
+        for(int k = 0; k < nV; ++k) {
+            double wke = (k == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for(int i = 0; i < EN; ++i) wke = __builtin_fma((double)Yt[i][k], q[i], wke);
+            wke += readlane_d(wk, k);
+            const double xk = readlane_d(X, k);
+            acc = (float)((double)acc + xk * wke);
+        }
+        float currIncrement = acc;
+        if(!a.allow_extrap) {   // oi_ensi.cpp:520-552; lY[e] is a LINEAR index into the n x nV column-major matrix,
+            // so it depends on the ORDER of the selected observations: rho descending when the reference sorted
+            // (more usable observations than max_points), candidate (= index) order otherwise.
+            const bool tr_l = (__ballot(truncated) >> l) & 1ull;
+            const unsigned long long okey = (tr_l ? ((unsigned long long)__float_as_uint(rho) << 32) : 0ull) | (unsigned)(~orig_i);
+            int rank = 0;
+            for(int j = 0; j < n; ++j) {
+                const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(okey >> 32), j) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane((int)okey, j);
+                rank += (kj > okey) ? 1 : 0;
+            }
+            int* perm = s_pq;   // rank -> lane (s_pq is free outside the Jacobi sweeps)
+            if(lane < n) perm[rank] = lane;
+            __syncthreads();
+            const int li = perm[lane % n], lk = lane / n;
+            const double lYe = (lane < nV) ? (double)Yt[li][lk] : 0.0;
+            float maxInc = -INFINITY, minInc = INFINITY;
+            for(int i = 0; i < n; ++i) {
+                const float ob = readlane_f(o1.y, i), yh = readlane_f(o1.z, i);
+                const float dv = (float)((double)ob - (lYe + (double)yh));
+                maxInc = fmaxf(maxInc, dv); minInc = fminf(minInc, dv);
+            }
+            const float memberIncrement = (float)((double)currIncrement - X);
+            if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + X);
+            else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + X);
+            else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + X);
+            else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + X);
+        }
+        if(lane < nV) a.out[(long)cell_l * E + ek] = ensMean + currIncrement;   // :553
+        __syncthreads();
+    }
+    if(lane == 0 && a.counters) atomicAdd(&a.counters[1], (unsigned long long)ndone);
+}
+
+namespace {
+struct EnsiWorkspace {
+    DevBuf<float4> pgeo, oaux;
+    DevBuf<float> gYhat, gY;
+    DevBuf<int> flags, validIdx, err;
+    DevBuf<unsigned long long> counters;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+thread_local EnsiWorkspace g_ews;
+thread_local float g_ensi_ms = 0;
+}
+
+static float loc_dist_e(const gpp_structure* s) { return sqrtf(-2 * logf(s->min_rho)) * s->h; }
+
+extern "C" int gpp_ensi_last_kernel_ms(float* ms) {
+    GPP_TRY
+    if(!ms) invalid("NULL");
+    *ms = g_ensi_ms;
+    return GPP_OK;
+    GPP_CATCH
+}
+
+extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* background, int ne, gpp_points* points,
+                                              const float* obs, const float* sigmas, const float* background_at_points,
+                                              const gpp_structure* st, int max_points, int allow_extrapolation,
+                                              float* out, int mem) {
+    GPP_TRY
+    if(max_points < 0) invalid("max_points must be >= 0");                                       // oi_ensi.cpp:123-124
+    if(!bgrid || !points) invalid("grid/points handle is NULL");
+    if(bgrid->type != points->type)
+        invalid("Both background and observations points must be of same coorindate type (lat/lon or x/y)");
+    if(!st) invalid("structure is NULL");
+    if(st->kind != 0) runtime("only the scalar BarnesStructure runs on the GPU path");
+    if(ne < 0) invalid("negative ensemble size");
+    const int C = bgrid->n, S = points->n, E = ne;
+    ensure_device();
+    g_ensi_ms = 0;
+    if(C == 0 || E == 0) return GPP_OK;
+    EnsiWorkspace& ws = g_ews;
+    InField f_bg, f_obs, f_sig, f_pbg;
+    OutField f_out;
+    f_bg.bind(background, (size_t)C * E, mem);
+    f_out.bind(out, (size_t)C * E, mem);
+    const long nbg = (long)C * E;
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)((nbg + 255) / 256)), dim3(256), 0, stream(), f_bg.d, nbg, f_out.d);   // output = background (:146)
+    GPP_HIP(hipGetLastError());
+    if(S == 0) {   // oi_ensi.cpp:135-137
+        f_out.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));
+        return GPP_OK;
+    }
+    f_obs.bind(obs, S, mem);
+    f_sig.bind(sigmas, S, mem);
+    f_pbg.bind(background_at_points, (size_t)S * E, mem);
+    bgrid->to_device();
+    gpp_obs_index* ix = gpp_build_obs_index(points);
+
+    // valid members (host list; E is small)
+    std::vector<int> flags(E, 1);
+    ws.flags.upload(flags.data(), E);
+    hipLaunchKernelGGL(k_ensi_member_flags, dim3((unsigned)((nbg + 255) / 256)), dim3(256), 0, stream(), f_bg.d, nbg, E, ws.flags.p);
+    GPP_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, sizeof(int) * E, hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    std::vector<int> valid;
+    for(int e = 0; e < E; e++) if(flags[e]) valid.push_back(e);
+    const int nV = (int)valid.size();
+    if(nV > EMAXV) runtime("optimal_interpolation_ensi: more than 64 valid ensemble members are not supported on the GPU path yet");
+    if(nV == 0) { f_out.finish(); GPP_HIP(hipStreamSynchronize(stream())); return GPP_OK; }
+    ws.validIdx.upload(valid.data(), nV);
+    ws.gYhat.get(S); ws.gY.get((size_t)S * nV);
+    hipLaunchKernelGGL(k_ensi_obs_prep, dim3((S + 127) / 128), dim3(128), 0, stream(), f_pbg.d, S, E, ws.validIdx.p, nV, ws.gYhat.p, ws.gY.p);
+    ws.pgeo.get(S); ws.oaux.get(S);
+    // oaux = (laf, obs, gYhat, sigma); only the observation itself must be valid (oi_ensi.cpp:235)
+    hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
+                       f_obs.d, f_sig.d, (const float*)ws.gYhat.p, (const float*)nullptr, 0, ws.pgeo.p, ws.oaux.p);
+    GPP_HIP(hipGetLastError());
+    ws.err.get(1); ws.counters.get(4);
+    GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
+    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 4, stream()));
+    if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
+
+    EnsiArgs a;
+    a.gx = bgrid->d_x.p; a.gy = bgrid->d_y.p; a.gz = bgrid->d_z.p; a.gelev = bgrid->d_elev.p; a.glaf = bgrid->d_laf.p;
+    a.bg = f_bg.d; a.out = f_out.d;
+    a.C = C; a.E = E; a.ny = bgrid->ny; a.nx = bgrid->nx;
+    a.tiled2d = (bgrid->nx > 0 && (long)bgrid->ny * bgrid->nx == C) ? 1 : 0;
+    if(a.tiled2d) { a.tiles_x = (a.nx + 7) / 8; a.ntiles = a.tiles_x * ((a.ny + 7) / 8); }
+    else { a.tiles_x = 0; a.ntiles = (C + 63) / 64; }
+    a.s.pgeo = ws.pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
+    a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
+    a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
+    a.s.h = st->h; a.s.v = st->v; a.s.w = st->w; a.s.R = loc_dist_e(st);
+    a.s.max_points = max_points;
+    a.s.K = (max_points > 0 && max_points <= EN) ? max_points : EN;
+    a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
+    a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;
+    a.allow_extrap = allow_extrapolation ? 1 : 0;
+    a.err = ws.err.p; a.counters = ws.counters.p;
+    GPP_HIP(hipEventRecord(ws.e0, stream()));
+    hipLaunchKernelGGL(k_ensi, dim3(a.ntiles), dim3(64), 0, stream(), a);
+    GPP_HIP(hipGetLastError());
+    GPP_HIP(hipEventRecord(ws.e1, stream()));
+    int err = 0;
+    GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    f_out.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    GPP_HIP(hipEventElapsedTime(&g_ensi_ms, ws.e0, ws.e1));
+    if(err & 1) runtime("optimal_interpolation_ensi: more than 32 observations per grid point requested (max_points == 0 or > 32): large-n path not built yet");
+    return GPP_OK;
+    GPP_CATCH
+}

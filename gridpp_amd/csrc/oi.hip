@@ -17,7 +17,7 @@
 //     group that shares one observation set shares the factorisation.
 // Arithmetic follows the reference: float32 coordinates/distances/rho (no FMA contraction,
 // correctly rounded sqrt/div, rho through a double-precision exp), double for the solve.
-#include "common.h"
+#include "oi_common.h"
 #include <algorithm>
 #include <memory>
 
@@ -25,24 +25,9 @@
 
 using namespace gpp;
 
-// -------------------------------------------------------------------------------------------
-// observation index (host build, HBM resident)
-// -------------------------------------------------------------------------------------------
-struct gpp_obs_index {
-    int S = 0;
-    int axis_a = 0, axis_b = 1;
-    float amin = 0, bmin = 0, inv_s = 0;
-    int nbx = 1, nby = 1;
-    DevBuf<int> d_bin_start;   // [nbx*nby+1]
-    DevBuf<int> d_pos;         // orig -> sorted position
-    DevBuf<float4> d_sgeo;     // sorted: x,y,z,elev
-    DevBuf<float2> d_smeta;    // sorted: laf, orig (int bits)
-    DevBuf<float4> d_ogeo;     // original order: x,y,z,elev
-    DevBuf<float> d_olaf;      // original order: laf
-};
 void gpp_free_obs_index(gpp_obs_index* p) { delete p; }
 
-static gpp_obs_index* build_obs_index(gpp_points* pts) {
+gpp_obs_index* gpp_build_obs_index(gpp_points* pts) {
     if(pts->obs_index) return pts->obs_index;
     std::unique_ptr<gpp_obs_index> ix(new gpp_obs_index);
     int S = pts->n;
@@ -101,74 +86,8 @@ static gpp_obs_index* build_obs_index(gpp_points* pts) {
     return pts->obs_index;
 }
 
-// -------------------------------------------------------------------------------------------
-// device helpers
-// -------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool d_valid(float v) { return !isnan(v) && !isinf(v); }
-
-// src/api/structure.cpp:26-34
-__device__ __forceinline__ float d_barnes_rho(float dist, float length) {
-    if(!d_valid(length) || length == 0) return 1.0f;
-    if(!d_valid(dist)) return 0.0f;
-    float v = dist / length;
-    double e = -0.5 * (double)v * (double)v;
-    return (float)exp(e);
-}
-// src/api/kdtree.cpp:192-194 (float32, no contraction, correctly rounded sqrt)
-__device__ __forceinline__ float d_chord(float x0, float y0, float z0, float x1, float y1, float z1) {
-    float dx = x0 - x1, dy = y0 - y1, dz = z0 - z1;
-    float s = dx * dx + dy * dy;
-    s = s + dz * dz;
-    return sqrtf(s);
-}
-// src/api/structure.cpp:215-228 (scalar Barnes)
-__device__ __forceinline__ float d_barnes_corr(float x1, float y1, float z1, float e1, float l1,
-                                               float x2, float y2, float z2, float e2, float l2,
-                                               float h, float v, float w, float R) {
-    float hdist = d_chord(x1, y1, z1, x2, y2, z2);
-    if(hdist > R) return 0.0f;
-    float rho = d_barnes_rho(hdist, h);
-    if(d_valid(e1) && d_valid(e2)) rho *= d_barnes_rho(e1 - e2, v);
-    if(d_valid(l1) && d_valid(l2)) rho *= d_barnes_rho(l1 - l2, w);
-    return rho;
-}
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ float wave_min(float v) {
-    for(int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-    for(int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-
 __global__ void k_barnes_corr(float4 p1, float l1, float4 p2, float l2, float h, float v, float w, float R, float* out) {
     out[0] = d_barnes_corr(p1.x, p1.y, p1.z, p1.w, l1, p2.x, p2.y, p2.z, p2.w, l2, h, v, w, R);
-}
-
-// Per-call observation pack: validity (oi.cpp:252), variance ratio (oi.cpp:192-195).
-__global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const int* __restrict__ pos, const float* __restrict__ olaf,
-                           const float* __restrict__ obs, const float* __restrict__ obs_var, const float* __restrict__ pbg,
-                           const float* __restrict__ bvp, int need_pbg, float4* __restrict__ pgeo, float4* __restrict__ oaux) {
-    int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if(o >= S) return;
-    float ob = obs[o], pb = pbg ? pbg[o] : 0.0f;
-    float bv = bvp ? bvp[o] : 1.0f;
-    float ratio = obs_var[o] / bv;
-    oaux[o] = make_float4(olaf[o], ob, pb, ratio);
-    int p = pos[o];
-    float4 g = sgeo[p];
-    bool ok = d_valid(ob) && (!need_pbg || d_valid(pb));
-    if(!ok) g.x = NAN;   // fails the box test of the radius query -> never a candidate
-    pgeo[p] = g;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -178,16 +97,10 @@ struct OiArgs {
     const float *gx, *gy, *gz, *gelev, *glaf, *bg, *bvar;
     float *out, *out_var;
     int C, ny, nx, tiles_x, ntiles, tiled2d;
-    const float4* pgeo;      // sorted, per call (x = NaN when the observation is unusable)
-    const float2* smeta;     // sorted: laf, orig
-    const int* bin_start;
+    ScanArgs s;
     const float4* ogeo;      // original order
     const float4* oaux;      // original order: laf, obs, pbg, ratio
-    int S, axis_a, axis_b, nbx, nby;
-    float amin, bmin, inv_s;
-    float h, v, w, R;
-    int K;                   // list capacity in use: min(max_points, N) (N if max_points == 0)
-    int max_points, allow_extrap, monotone;
+    int S, allow_extrap;
     int* err;                // bit0: list overflow (needs the large-n path), bit1: singular / not SPD
     unsigned long long* counters;   // [0] cells updated, [1] factorisations
 };
@@ -242,99 +155,9 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
 
     int cnt = 0;
     if(__ballot(active) != 0ull) {
-        const float R = a.R;
-        const int K = a.K;
-        const bool bounded = a.max_points > 0 && a.max_points <= N;
-        const float h2 = a.h * a.h;
-        // ---- candidate scan: bin rows centre-out, x-extent and stop from the current worst kept rho ---------
-        float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
-        float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
-        const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
-        const float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
-        const float sbin = 1.0f / a.inv_s;
-        int tby0 = (int)floorf((bmin_t - a.bmin) * a.inv_s), tby1 = (int)floorf((bmax_t - a.bmin) * a.inv_s);
-        tby0 = __builtin_amdgcn_readfirstlane(min(max(tby0, 0), a.nby - 1));
-        tby1 = __builtin_amdgcn_readfirstlane(min(max(tby1, tby0), a.nby - 1));
-
-        // strictly-inside box of the radius query (kdtree.cpp:46,53)
-        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
-        unsigned long long wkey = 0;   // worst key kept
-        int wslot = 0;
-        // d2 > thr2 can neither be within R nor beat the worst kept rho (rho <= rho_h(d), monotone in d)
-        const float thr2_R = R * R * 1.000001f + 1e-30f;
-        float thr2 = active ? thr2_R : -1.0f;
-        bool overflow = false;
-
-        for(int r = 0;; ++r) {
-            const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
-            if(t2 < 0.0f) break;
-            const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
-            if(gap * gap > t2) break;
-            const int rowA = tby0 - r, rowB = tby1 + r;
-            if(rowA < 0 && rowB >= a.nby) break;
-            const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
-            int x0 = (int)floorf((amin_t - wx - a.amin) * a.inv_s) - 1, x1 = (int)floorf((amax_t + wx - a.amin) * a.inv_s) + 1;
-            x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), a.nbx - 1));
-            x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), a.nbx - 1));
-            const int nseg = (r == 0) ? 1 : 2;
-            for(int seg = 0; seg < nseg; ++seg) {
-                int js, je;
-                if(r == 0) { js = a.bin_start[tby0 * a.nbx + x0]; je = a.bin_start[tby1 * a.nbx + x1 + 1];
-                             if(tby1 > tby0) { js = a.bin_start[tby0 * a.nbx]; je = a.bin_start[tby1 * a.nbx + a.nbx]; } }
-                else {
-                    const int row = seg == 0 ? rowA : rowB;
-                    if(row < 0 || row >= a.nby) continue;
-                    js = a.bin_start[row * a.nbx + x0]; je = a.bin_start[row * a.nbx + x1 + 1];
-                }
-                for(int base = js; base < je; base += 64) {
-                    const int mine = base + lane;
-                    float4 rec = make_float4(NAN, 0, 0, NAN);
-                    float2 met = make_float2(NAN, 0);
-                    if(mine < je) { rec = a.pgeo[mine]; met = a.smeta[mine]; }
-                    const int nc = min(64, je - base);
-                    for(int c = 0; c < nc; ++c) {
-                        const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
-                        const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
-                        float d2 = dx * dx + dy * dy;
-                        d2 = d2 + dz * dz;
-                        if(d2 <= thr2) {
-                            const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
-                            const float dist = sqrtf(d2);
-                            if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
-                                const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                                float rho = d_barnes_rho(dist, a.h);
-                                if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
-                                if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
-                                if(rho > 0.0f) {   // oi.cpp:253
-                                    const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
-                                    const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
-                                    if(cnt < K) {
-                                        keys[cnt][lane] = key;
-                                        if(cnt == 0 || key < wkey) { wkey = key; wslot = cnt; }
-                                        cnt++;
-                                    }
-                                    else if(bounded) {
-                                        if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
-                                            keys[wslot][lane] = key;
-                                            wkey = key;
-                                            for(int s = 0; s < K; ++s) {
-                                                const unsigned long long k2 = keys[s][lane];
-                                                if(k2 < wkey) { wkey = k2; wslot = s; }
-                                            }
-                                        }
-                                    }
-                                    else overflow = true;   // more than N usable observations requested
-                                    if(bounded && cnt == K) {
-                                        const float wr = __uint_as_float((unsigned)(wkey >> 32));
-                                        thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        const int K = a.s.K;
+        bool overflow, truncated;
+        cnt = scan_tile<N>(a.s, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
         if(__ballot(overflow) != 0ull) {
             if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);
             cnt = overflow ? 0 : cnt;
@@ -394,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                 const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
                 const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
                 // matrix rows: corr(obs_i, obs_p) (oi.cpp:304-312); G rows: corr(cell, obs_p) (oi.cpp:250)
-                const float c = d_barnes_corr(px, py, pz, pe, pl, xp, yp, zp, ep, lp, a.h, a.v, a.w, a.R);
+                const float c = d_barnes_corr(px, py, pz, pe, pl, xp, yp, zp, ep, lp, a.s.h, a.s.v, a.s.w, a.s.R);
                 colbuf[p][lane] = c;
                 const float dpf = (float)((double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p));
                 maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
@@ -571,7 +394,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     f_bvp.bind(bvariance_at_points, S, mem);
 
     bgrid->to_device();
-    gpp_obs_index* ix = build_obs_index(points);
+    gpp_obs_index* ix = gpp_build_obs_index(points);
 
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
     ws.pgeo.get(S); ws.oaux.get(S);
@@ -590,14 +413,13 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     a.tiled2d = (bgrid->nx > 0 && (long)bgrid->ny * bgrid->nx == C) ? 1 : 0;
     if(a.tiled2d) { a.tiles_x = (a.nx + 7) / 8; a.ntiles = a.tiles_x * ((a.ny + 7) / 8); }
     else { a.tiles_x = 0; a.ntiles = (C + 63) / 64; }
-    a.pgeo = ws.pgeo.p; a.smeta = ix->d_smeta.p; a.bin_start = ix->d_bin_start.p;
+    a.s.pgeo = ws.pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
-    a.S = S; a.axis_a = ix->axis_a; a.axis_b = ix->axis_b; a.nbx = ix->nbx; a.nby = ix->nby;
-    a.amin = ix->amin; a.bmin = ix->bmin; a.inv_s = ix->inv_s;
-    a.h = st->h; a.v = st->v; a.w = st->w; a.R = loc_dist(st);
-    a.max_points = max_points; a.allow_extrap = allow_extrapolation ? 1 : 0;
-    a.K = (max_points > 0 && max_points <= N) ? max_points : N;
-    a.monotone = (st->v == 0 && st->w == 0) ? 1 : 0;
+    a.S = S; a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
+    a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
+    a.s.h = st->h; a.s.v = st->v; a.s.w = st->w; a.s.R = loc_dist(st);
+    a.s.max_points = max_points; a.allow_extrap = allow_extrapolation ? 1 : 0;
+    a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
     a.err = ws.err.p; a.counters = ws.counters.p;
 
     GPP_HIP(hipEventRecord(ws.e0, stream()));

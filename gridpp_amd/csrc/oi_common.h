@@ -1,0 +1,226 @@
+// Shared by oi.hip and ensi.hip: observation index, Barnes device functions, the per-tile candidate scan.
+#pragma once
+#include "common.h"
+
+#pragma clang fp contract(off)
+using gpp::DevBuf;
+
+// -------------------------------------------------------------------------------------------
+// observation index (host build, HBM resident)
+// -------------------------------------------------------------------------------------------
+struct gpp_obs_index {
+    int S = 0;
+    int axis_a = 0, axis_b = 1;
+    float amin = 0, bmin = 0, inv_s = 0;
+    int nbx = 1, nby = 1;
+    DevBuf<int> d_bin_start;   // [nbx*nby+1]
+    DevBuf<int> d_pos;         // orig -> sorted position
+    DevBuf<float4> d_sgeo;     // sorted: x,y,z,elev
+    DevBuf<float2> d_smeta;    // sorted: laf, orig (int bits)
+    DevBuf<float4> d_ogeo;     // original order: x,y,z,elev
+    DevBuf<float> d_olaf;      // original order: laf
+};
+
+gpp_obs_index* gpp_build_obs_index(gpp_points* pts);   // oi.hip
+
+// -------------------------------------------------------------------------------------------
+// device helpers
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool d_valid(float v) { return !isnan(v) && !isinf(v); }
+
+// src/api/structure.cpp:26-34
+__device__ __forceinline__ float d_barnes_rho(float dist, float length) {
+    if(!d_valid(length) || length == 0) return 1.0f;
+    if(!d_valid(dist)) return 0.0f;
+    float v = dist / length;
+    double e = -0.5 * (double)v * (double)v;
+    return (float)exp(e);
+}
+// src/api/kdtree.cpp:192-194 (float32, no contraction, correctly rounded sqrt)
+__device__ __forceinline__ float d_chord(float x0, float y0, float z0, float x1, float y1, float z1) {
+    float dx = x0 - x1, dy = y0 - y1, dz = z0 - z1;
+    float s = dx * dx + dy * dy;
+    s = s + dz * dz;
+    return sqrtf(s);
+}
+// src/api/structure.cpp:215-228 (scalar Barnes)
+__device__ __forceinline__ float d_barnes_corr(float x1, float y1, float z1, float e1, float l1,
+                                               float x2, float y2, float z2, float e2, float l2,
+                                               float h, float v, float w, float R) {
+    float hdist = d_chord(x1, y1, z1, x2, y2, z2);
+    if(hdist > R) return 0.0f;
+    float rho = d_barnes_rho(hdist, h);
+    if(d_valid(e1) && d_valid(e2)) rho *= d_barnes_rho(e1 - e2, v);
+    if(d_valid(l1) && d_valid(l2)) rho *= d_barnes_rho(l1 - l2, w);
+    return rho;
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wave_min(float v) {
+    for(int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for(int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// Per-call observation pack: validity (oi.cpp:252), variance ratio (oi.cpp:192-195).
+static __global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const int* __restrict__ pos, const float* __restrict__ olaf,
+                           const float* __restrict__ obs, const float* __restrict__ obs_var, const float* __restrict__ pbg,
+                           const float* __restrict__ bvp, int need_pbg, float4* __restrict__ pgeo, float4* __restrict__ oaux) {
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if(o >= S) return;
+    float ob = obs[o], pb = pbg ? pbg[o] : 0.0f;
+    float bv = bvp ? bvp[o] : 1.0f;
+    float ratio = obs_var[o] / bv;
+    oaux[o] = make_float4(olaf[o], ob, pb, ratio);
+    int p = pos[o];
+    float4 g = sgeo[p];
+    bool ok = d_valid(ob) && (!need_pbg || d_valid(pb));
+    if(!ok) g.x = NAN;   // fails the box test of the radius query -> never a candidate
+    pgeo[p] = g;
+}
+
+
+// What the candidate scan needs: the bin-sorted observation block and the structure function
+struct ScanArgs {
+    const float4* pgeo;      // sorted, per call (x = NaN when the observation is unusable)
+    const float2* smeta;     // sorted: laf, orig
+    const int* bin_start;
+    int axis_a, axis_b, nbx, nby;
+    float amin, bmin, inv_s;
+    float h, v, w, R;
+    int K;                   // list capacity in use: min(max_points, N) (N if max_points == 0)
+    int max_points;
+};
+
+// Per-tile candidate scan (src/api/oi.cpp:229-273 for 64 cells at once).  On return every lane holds `cnt` 64-bit
+// keys (rho bits << 32 | ~observation index) in keys[0..cnt)[lane]: the observations the reference would keep for
+// that cell (all usable ones if there are at most max_points, otherwise the max_points with the largest rho,
+// ties -> lower observation index).  Must be called by the whole wave with at least one active lane.
+template <int N, bool WANT_TRUNC = false>
+__device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, const float gx, const float gy, const float gz,
+                                         const float ge, const float gl, unsigned long long (*keys)[64], const int lane, bool& overflow,
+                                         bool& truncated) {
+    // truncated: more usable observations than max_points existed, i.e. the reference took its sorted branch
+    // (oi.cpp:262-273); only the EnSI anti-extrapolation quirk depends on it (oi_ensi.cpp:523-524)
+    int cnt = 0;
+    overflow = false;
+    truncated = false;
+    {
+        const float R = a.R;
+        const int K = a.K;
+        const bool bounded = a.max_points > 0 && a.max_points <= N;
+        const float h2 = a.h * a.h;
+        // ---- candidate scan: bin rows centre-out, x-extent and stop from the current worst kept rho ---------
+        float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
+        float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
+        const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
+        const float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
+        const float sbin = 1.0f / a.inv_s;
+        int tby0 = (int)floorf((bmin_t - a.bmin) * a.inv_s), tby1 = (int)floorf((bmax_t - a.bmin) * a.inv_s);
+        tby0 = __builtin_amdgcn_readfirstlane(min(max(tby0, 0), a.nby - 1));
+        tby1 = __builtin_amdgcn_readfirstlane(min(max(tby1, tby0), a.nby - 1));
+
+        // strictly-inside box of the radius query (kdtree.cpp:46,53)
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        unsigned long long wkey = 0;   // worst key kept
+        int wslot = 0;
+        // d2 > thr2 can neither be within R nor beat the worst kept rho (rho <= rho_h(d), monotone in d)
+        const float thr2_R = R * R * 1.000001f + 1e-30f;
+        float thr2 = active ? thr2_R : -1.0f;
+
+        for(int r = 0;; ++r) {
+            const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
+            if(t2 < 0.0f) break;
+            const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
+            if(gap * gap > t2) break;
+            const int rowA = tby0 - r, rowB = tby1 + r;
+            if(rowA < 0 && rowB >= a.nby) break;
+            const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
+            int x0 = (int)floorf((amin_t - wx - a.amin) * a.inv_s) - 1, x1 = (int)floorf((amax_t + wx - a.amin) * a.inv_s) + 1;
+            x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), a.nbx - 1));
+            x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), a.nbx - 1));
+            const int nseg = (r == 0) ? 1 : 2;
+            for(int seg = 0; seg < nseg; ++seg) {
+                int js, je;
+                if(r == 0) { js = a.bin_start[tby0 * a.nbx + x0]; je = a.bin_start[tby1 * a.nbx + x1 + 1];
+                             if(tby1 > tby0) { js = a.bin_start[tby0 * a.nbx]; je = a.bin_start[tby1 * a.nbx + a.nbx]; } }
+                else {
+                    const int row = seg == 0 ? rowA : rowB;
+                    if(row < 0 || row >= a.nby) continue;
+                    js = a.bin_start[row * a.nbx + x0]; je = a.bin_start[row * a.nbx + x1 + 1];
+                }
+                for(int base = js; base < je; base += 64) {
+                    const int mine = base + lane;
+                    float4 rec = make_float4(NAN, 0, 0, NAN);
+                    float2 met = make_float2(NAN, 0);
+                    if(mine < je) { rec = a.pgeo[mine]; met = a.smeta[mine]; }
+                    const int nc = min(64, je - base);
+                    for(int c = 0; c < nc; ++c) {
+                        const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
+                        const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+                        float d2 = dx * dx + dy * dy;
+                        d2 = d2 + dz * dz;
+                        if(d2 <= thr2) {
+                            const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                            const float dist = sqrtf(d2);
+                            if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
+                                const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                                float rho = d_barnes_rho(dist, a.h);
+                                if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
+                                if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
+                                if(rho > 0.0f) {   // oi.cpp:253
+                                    const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
+                                    const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
+                                    if(cnt < K) {
+                                        keys[cnt][lane] = key;
+                                        if(cnt == 0 || key < wkey) { wkey = key; wslot = cnt; }
+                                        cnt++;
+                                    }
+                                    else if(bounded) {
+                                        truncated = true;
+                                        if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
+                                            keys[wslot][lane] = key;
+                                            wkey = key;
+                                            for(int s = 0; s < K; ++s) {
+                                                const unsigned long long k2 = keys[s][lane];
+                                                if(k2 < wkey) { wkey = k2; wslot = s; }
+                                            }
+                                        }
+                                    }
+                                    else overflow = true;   // more than N usable observations requested
+                                    if(bounded && cnt == K) {
+                                        const float wr = __uint_as_float((unsigned)(wkey >> 32));
+                                        thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
+                                    }
+                                }
+                            }
+                        }
+                        else if(WANT_TRUNC && !truncated && cnt == K && d2 <= thr2_R) {
+                            // pruned by the rho threshold: does it still count as a usable observation?
+                            const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                            const float dist = sqrtf(d2);
+                            if(inbox && dist <= R) {
+                                const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                                float rho = d_barnes_rho(dist, a.h);
+                                if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
+                                if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
+                                if(rho > 0.0f) truncated = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return cnt;
+}

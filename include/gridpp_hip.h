@@ -126,6 +126,18 @@ int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* background, c
                                    const gpp_structure* structure, int max_points, int allow_extrapolation,
                                    float* out, float* out_variance, int mem);
 
+/* ---- ensemble optimal interpolation (EnSI) ----------------------------------------
+ * replaces gridpp::optimal_interpolation_ensi (src/api/oi_ensi.cpp:114-568, Points
+ * form; the Grid form :33-112 is the same call on a grid handle).  background and out
+ * are [bgrid-size][ne], background_at_points is [points-size][ne]; obs and sigmas have
+ * points-size elements.  Members that are invalid anywhere in the field are left
+ * untouched (oi_ensi.cpp:187-201). */
+int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* background, int ne, gpp_points* points,
+                                   const float* obs, const float* sigmas, const float* background_at_points,
+                                   const gpp_structure* structure, int max_points, int allow_extrapolation,
+                                   float* out, int mem);
+int gpp_ensi_last_kernel_ms(float* ms);   /* hipEvent time of the last EnSI kernel (diagnostics / bench) */
+
 /* ---- neighbourhood filters (src/api/neighbourhood.cpp) -------------------------
  * input is [ny][nx] (is3d == 0, ne must be 1) or [ny][nx][ne] (is3d == 1); out is
  * [ny][nx].  Empty input (any extent 0) returns GPP_OK and writes nothing
