@@ -111,78 +111,59 @@ __device__ float row_quantile(const float* row, int n, float q) {   // util.cpp:
     return quantile_from_order(q, N, lv, uv, lowerIndex, upperIndex);
 }
 
-#define MEMBER_EC 128   // members staged per chunk
+#define MEMBER_EC 160   // rows up to this many members are staged through LDS
 #define TB 8            // thresholds per register batch
 
 // mode 0: out[c] = calc_statistic(members of c)                       (neighbourhood.cpp:21-25)
 // mode 1: out[t*C + c] = #(valid members <= thr[t]) / #valid members  (neighbourhood.cpp:456-471)
-__global__ __launch_bounds__(256) void k_member_pass(const float* __restrict__ in, long C, int E, int mode, int statistic,
-                                                     const float* __restrict__ thr, int T, float* __restrict__ out) {
+// One wavefront per workgroup, grid-stride over tiles of 64 consecutive cells.  The 64*E contiguous floats of a
+// tile are copied linearly HBM -> LDS with 16-byte accesses (fully coalesced, no index arithmetic); lane l then
+// walks row l in member order (ds_read_b32, 4-way bank conflict at E = 100: LDS time stays below the HBM time).
+__global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in, long C, int E, int mode, int statistic,
+                                                    const float* __restrict__ thr, int T, float* __restrict__ out) {
     extern __shared__ float lds[];
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long cell0 = ((long)blockIdx.x * 4 + wid) * 64;
-    if(cell0 >= C) return;
-    const int ncell = (int)min((long)64, C - cell0);
-    const int EC = min(E, MEMBER_EC);
-    const int pitch = EC | 1;
-    float* tile = lds + (size_t)wid * 64 * (MEMBER_EC | 1);
-    float* myrow = tile + lane * pitch;
-    const long cell = cell0 + lane;
-
-    if(E <= MEMBER_EC) {
-        // whole rows fit: stream the contiguous 64*E block with 16-byte loads
-        const long base = cell0 * E;
-        const int total = ncell * E;
-        const bool vec4 = ((base & 3) == 0) && ((reinterpret_cast<size_t>(in) & 15) == 0);
-        if(vec4) {
-            for(int i = lane * 4; i < total; i += 256) {
-                float v[4] = {0, 0, 0, 0};
-                if(i + 3 < total) { float4 q = *reinterpret_cast<const float4*>(in + base + i); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-                else for(int k = 0; k < 4 && i + k < total; k++) v[k] = in[base + i + k];
-                int r = i / E, c = i - r * E;
-#pragma unroll
-                for(int k = 0; k < 4; k++) {
-                    if(i + k < total) tile[r * pitch + c] = v[k];
-                    if(++c >= E) { c = 0; r++; }
+    const int lane = threadIdx.x;
+    const long ntiles = (C + 63) / 64;
+    const bool staged = E <= MEMBER_EC;
+    const bool al16 = (reinterpret_cast<size_t>(in) & 15) == 0;
+    for(long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long cell0 = tile * 64;
+        const int ncell = (int)min((long)64, C - cell0);
+        const long cell = cell0 + lane;
+        const float* row;
+        if(staged) {
+            const long base = cell0 * E;   // multiple of 64 floats: 16-byte aligned whenever `in` is
+            const int total = ncell * E;
+            __syncthreads();               // previous tile fully consumed
+            if(al16) {
+                for(int i = lane * 4; i < total; i += 256) {
+                    if(i + 3 < total) *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(in + base + i);
+                    else for(int k = 0; i + k < total; k++) lds[i + k] = in[base + i + k];
                 }
             }
+            else for(int i = lane; i < total; i += 64) lds[i] = in[base + i];
+            __syncthreads();
+            row = lds + lane * E;
         }
-        else for(int i = lane; i < total; i += 64) { int r = i / E, c = i - r * E; tile[r * pitch + c] = in[base + i]; }
-        __builtin_amdgcn_wave_barrier();
+        else row = in + cell * E;          // long rows: lane-private walk straight from memory
         if(lane < ncell) {
-            if(mode == 0) out[cell] = row_statistic(myrow, E, statistic);
+            if(mode == 0) out[cell] = row_statistic(row, E, statistic);
             else {
                 int count = 0;
-                for(int e = 0; e < E; e++) if(nv(myrow[e])) count++;
+                for(int e = 0; e < E; e++) if(nv(row[e])) count++;
                 for(int t0 = 0; t0 < T; t0 += TB) {
                     float th[TB]; int sum[TB];
 #pragma unroll
                     for(int k = 0; k < TB; k++) { th[k] = (t0 + k < T) ? thr[t0 + k] : 0.0f; sum[k] = 0; }
                     for(int e = 0; e < E; e++) {
-                        float v = myrow[e];
-                        bool ok = nv(v);
+                        const float v = row[e];
+                        const bool ok = nv(v);
 #pragma unroll
                         for(int k = 0; k < TB; k++) sum[k] += (ok && v <= th[k]) ? 1 : 0;
                     }
 #pragma unroll
                     for(int k = 0; k < TB; k++)
                         if(t0 + k < T) out[(long)(t0 + k) * C + cell] = count > 0 ? (float)sum[k] / (float)count : NAN;
-                }
-            }
-        }
-    }
-    else {
-        // long rows: lane-private sequential walk straight from memory (rare: E > 128)
-        if(lane < ncell) {
-            const float* row = in + cell * E;
-            if(mode == 0) out[cell] = row_statistic(row, E, statistic);
-            else {
-                int count = 0;
-                for(int e = 0; e < E; e++) if(nv(row[e])) count++;
-                for(int t = 0; t < T; t++) {
-                    int sum = 0; float th = thr[t];
-                    for(int e = 0; e < E; e++) { float v = row[e]; if(nv(v) && v <= th) sum++; }
-                    out[(long)t * C + cell] = count > 0 ? (float)sum / (float)count : NAN;
                 }
             }
         }
@@ -218,19 +199,32 @@ __global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ in, 
     rs[plane + (long)y * X + x] = s;
     rc[plane + (long)y * X + x] = c;
 }
-// column pass + finish (neighbourhood.cpp:132-142): Mean / Sum / Count
+// column pass + finish (neighbourhood.cpp:132-142): Mean / Sum / Count.  Each thread owns one column of a strip of
+// COL_STRIP rows and slides the window down it (2 reads per cell instead of 2*hw+1).
+#define COL_STRIP 32
 __global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs, const int* __restrict__ rc, int Y, int X, int hw, int statistic, float* __restrict__ out) {
     const long plane = (long)blockIdx.z * Y * X;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if(x >= X || y >= Y) return;
-    const int ya = max(0, y - hw), yb = (int)min((long)Y - 1, (long)y + hw);
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y0 = blockIdx.y * COL_STRIP;
+    if(x >= X || y0 >= Y) return;
+    const int y1 = min(Y, y0 + COL_STRIP);
+    const double* cs = rs + plane + x;
+    const int* cc = rc + plane + x;
     double s = 0; int c = 0;
-    for(int yy = ya; yy <= yb; yy++) { s += rs[plane + (long)yy * X + x]; c += rc[plane + (long)yy * X + x]; }
-    float o = NAN;
-    if(statistic == GPP_COUNT) o = (float)c;
-    else if(c > 0) o = (statistic == GPP_MEAN) ? (float)(s / (double)c) : (float)s;
-    out[plane + (long)y * X + x] = o;
+    int lo = max(0, y0 - hw), hi = (int)min((long)Y - 1, (long)y0 + hw);   // current window [lo, hi]
+    for(int yy = lo; yy <= hi; yy++) { s += cs[(long)yy * X]; c += cc[(long)yy * X]; }
+    for(int y = y0; y < y1; y++) {
+        if(y > y0) {
+            const long add = (long)y + hw;
+            const int sub = y - hw - 1;
+            if(add <= (long)Y - 1) { s += cs[add * X]; c += cc[add * X]; }
+            if(sub >= 0) { s -= cs[(long)sub * X]; c -= cc[(long)sub * X]; }
+        }
+        float o = NAN;
+        if(statistic == GPP_COUNT) o = (float)c;
+        else if(c > 0) o = (statistic == GPP_MEAN) ? (float)(s / (double)c) : (float)s;
+        out[plane + (long)y * X + x] = o;
+    }
 }
 // separable min / max ignoring non-finite values (dir 0: along x, dir 1: along y)
 __global__ __launch_bounds__(256) void k_minmax_pass(const float* __restrict__ in, int Y, int X, int hw, int is_max, int dir, float* __restrict__ out) {
@@ -405,11 +399,13 @@ struct NbWorkspace {
 thread_local NbWorkspace g_nb;
 
 void member_pass(const float* d_in, long C, int E, int mode, int statistic, const float* d_thr, int T, float* d_out) {
-    long tiles = (C + 63) / 64;
-    size_t lds = (size_t)4 * 64 * (MEMBER_EC | 1) * sizeof(float);
+    const long tiles = (C + 63) / 64;
+    const size_t lds = (E <= MEMBER_EC) ? (size_t)64 * E * sizeof(float) + 16 : 16;
     static bool attr = false;
-    if(!attr) { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL(k_member_pass, dim3((unsigned)((tiles + 3) / 4)), dim3(256), lds, stream(), d_in, C, E, mode, statistic, d_thr, T, d_out);
+    if(!attr) { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * MEMBER_EC * 4 + 16)); attr = true; }
+    const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+    const long grid = std::min<long>(tiles, (long)256 * waves_per_cu * 2);
+    hipLaunchKernelGGL(k_member_pass, dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, mode, statistic, d_thr, T, d_out);
     GPP_HIP(hipGetLastError());
 }
 // Mean / Sum / Count of `nplanes` [Y][X] planes
@@ -426,7 +422,7 @@ void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statisti
     }
     hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, Y, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc);
     GPP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_box_cols, dim3((X + 63) / 64, (Y + 3) / 4, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out);
+    hipLaunchKernelGGL(k_box_cols, dim3((X + 255) / 256, (Y + COL_STRIP - 1) / COL_STRIP, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out);
     GPP_HIP(hipGetLastError());
 }
 void brute(const float* d_in, int Y, int X, int E, int hw, int statistic, float q, float* d_out) {
