@@ -1,0 +1,54 @@
+"""Multi-GPU layer of the OI path: one process per GPU, the output grid is cut into contiguous row
+tiles, the observation values of each analysis step are broadcast from rank 0 (RCCL when the tensors live in HBM,
+gloo in the CPU tests) and there is no cross-tile dependence.
+
+Nothing here touches the reference's single-process API: a rank simply calls gridpp_amd.optimal_interpolation on
+its own tile Grid."""
+import numpy as np
+
+
+def row_tile(ny, rank, world):
+    """Rows [row0, row1) of a ny-row grid owned by `rank` (contiguous, balanced to within one row)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return ny * rank // world, ny * (rank + 1) // world
+
+
+def all_tiles(ny, world):
+    return [row_tile(ny, r, world) for r in range(world)]
+
+
+def broadcast_observations(values, src=0, group=None):
+    """In-place broadcast of the packed per-step observation block (e.g. a (3, S) tensor holding obs, ratios,
+    background-at-points) from `src`.  `values` is a torch tensor on every rank (CUDA -> RCCL, CPU -> gloo)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(values, src=src, group=group)
+    return values
+
+
+def tiled_optimal_interpolation(lats, lons, background, plats, plons, values, structure_args, max_points,
+                                rank, world, compute, allow_extrapolation=True):
+    """Runs this rank's row tile of an optimal_interpolation call.
+
+    lats/lons/background: the FULL (Y, X) arrays (every rank can generate or map them; only the tile is touched)
+    values: (3, S) tensor [obs, ratios, background_at_points]; only rank 0's content matters, it is broadcast
+    compute(lats_tile, lons_tile, bg_tile, plats, plons, obs, ratios, pbg, structure_args, max_points, allow) -> tile
+        the single-GPU entry point (gridpp_amd on a GPU box; the CPU tests inject the oracle here)
+    returns (row0, row1, analysis_tile)
+    """
+    row0, row1 = row_tile(np.shape(lats)[0], rank, world)
+    values = broadcast_observations(values)
+    v = values.detach().cpu().numpy() if hasattr(values, "detach") else np.asarray(values)
+    tile = compute(lats[row0:row1], lons[row0:row1], background[row0:row1], plats, plons, v[0], v[1], v[2],
+                   structure_args, max_points, allow_extrapolation)
+    return row0, row1, tile
+
+
+def gpu_compute(lats, lons, bg, plats, plons, obs, ratios, pbg, structure_args, max_points, allow_extrapolation=True):
+    """The real single-GPU stage: gridpp_amd on the current device."""
+    import gridpp_amd as gridpp
+    grid = gridpp.Grid(lats, lons)
+    points = gridpp.Points(plats, plons)
+    return gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, gridpp.BarnesStructure(*structure_args),
+                                        max_points, allow_extrapolation)

@@ -1,0 +1,365 @@
+// gridpp.hpp -- C++ host mirror of the reference's public API (include/gridpp.h) for the hot path only,
+// header-only over the C-ABI of libgridpp_hip.so (include/gridpp_hip.h).
+//
+// Same namespace, type names, signatures, defaults and exception types as the reference, so code written
+// against gridpp.h for this path compiles unchanged:
+//   vec/vec2/vec3/ivec                         include/gridpp.h:25-41
+//   Statistic, CoordinateType, MV              :49,88-100,120-123
+//   Points, Grid, KDTree (queries)             :1746-2060
+//   BarnesStructure (scalar form)              :2160-2185
+//   optimal_interpolation(_full)(_ensi)        :162-294
+//   neighbourhood*, get_neighbourhood_thresholds :588-716
+//   nearest(Grid|Points, Points, vec2|vec)     :895
+//   calc_statistic / calc_quantile             :1454-1482
+// Nested vectors are flattened once, handed to the C-ABI as host buffers (GPP_MEM_HOST) and un-flattened,
+// exactly where the reference flattens them itself (src/api/oi.cpp:69-86).  Errors: GPP_EINVAL ->
+// std::invalid_argument, everything else -> std::runtime_error (swig/gridpp.i:21-40 maps these to python).
+#pragma once
+#include <cmath>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/gridpp_hip.h"
+
+namespace gridpp {
+typedef std::vector<float> vec;
+typedef std::vector<vec> vec2;
+typedef std::vector<vec2> vec3;
+typedef std::vector<int> ivec;
+typedef std::vector<ivec> ivec2;
+static const float MV = NAN;
+static const double radius_earth = 6.378137e6;
+
+enum Statistic { Mean = 0, Min = 10, Median = 20, Max = 30, Quantile = 40, Std = 50, Variance = 60, Sum = 70, Count = 80, RandomChoice = 90, Unknown = -1 };
+enum CoordinateType { Geodetic = 0, Cartesian = 1 };
+
+namespace detail {
+inline void check(int rc) {
+    if(rc == GPP_OK) return;
+    std::string msg = gpp_last_error();
+    if(rc == GPP_EINVAL) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);
+}
+inline vec flatten(const vec2& a, size_t& Y, size_t& X) {
+    Y = a.size(); X = Y ? a[0].size() : 0;
+    vec f; f.reserve(Y * X);
+    for(const auto& r : a) { if(r.size() != X) throw std::invalid_argument("ragged 2-D array"); f.insert(f.end(), r.begin(), r.end()); }
+    return f;
+}
+inline vec flatten(const vec3& a, size_t& Y, size_t& X, size_t& E) {
+    Y = a.size(); X = Y ? a[0].size() : 0; E = (Y && X) ? a[0][0].size() : 0;
+    vec f; f.reserve(Y * X * E);
+    for(const auto& r : a) { if(r.size() != X) throw std::invalid_argument("ragged 3-D array");
+        for(const auto& c : r) { if(c.size() != E) throw std::invalid_argument("ragged 3-D array"); f.insert(f.end(), c.begin(), c.end()); } }
+    return f;
+}
+inline vec2 unflatten(const vec& f, size_t Y, size_t X) {
+    vec2 o(Y);
+    for(size_t y = 0; y < Y; y++) o[y].assign(f.begin() + y * X, f.begin() + (y + 1) * X);
+    return o;
+}
+inline vec3 unflatten(const vec& f, size_t Y, size_t X, size_t E) {
+    vec3 o(Y);
+    for(size_t y = 0; y < Y; y++) { o[y].resize(X); for(size_t x = 0; x < X; x++) o[y][x].assign(f.begin() + (y * X + x) * E, f.begin() + (y * X + x + 1) * E); }
+    return o;
+}
+struct Handle {
+    gpp_points* p = nullptr;
+    ~Handle() { if(p) gpp_points_destroy(p); }
+};
+}   // namespace detail
+
+inline bool is_valid(float value) { return !std::isnan(value) && !std::isinf(value); }   // src/api/util.cpp:16-18
+inline std::string version() { return gpp_version(); }
+inline void set_omp_threads(int) {}        // src/api/gridpp.cpp:184-207: no meaning on the GPU path
+inline int get_omp_threads() { return 1; }
+
+class Points {
+  public:
+    Points() : Points(vec(), vec()) {}
+    Points(vec lats, vec lons, vec elevs = vec(), vec lafs = vec(), CoordinateType type = Geodetic) : mType(type) {
+        size_t N = lats.size();
+        if(lons.size() != N) throw std::invalid_argument("Cannot create points with unequal lat and lon sizes");
+        if(elevs.size() != 0 && elevs.size() != N) throw std::invalid_argument("'elevs' must either be size 0 or the same size at lats/lons");
+        if(lafs.size() != 0 && lafs.size() != N) throw std::invalid_argument("'lafs' must either be size 0 or the same size at lats/lons");
+        mH = std::make_shared<detail::Handle>();
+        detail::check(gpp_points_create(lats.data(), lons.data(), elevs.size() == N && N ? elevs.data() : nullptr,
+                                        lafs.size() == N && N ? lafs.data() : nullptr, (int)N, (int)type, &mH->p));
+        mN = (int)N;
+    }
+    int size() const { return mN; }
+    CoordinateType get_coordinate_type() const { return mType; }
+    vec get_lats() const { return field(0); }
+    vec get_lons() const { return field(1); }
+    vec get_elevs() const { return field(2); }
+    vec get_lafs() const { return field(3); }
+    ivec get_neighbours(float lat, float lon, float radius, bool include_match = true) const {
+        ivec idx(mN > 0 ? mN : 1); int count = 0;
+        detail::check(gpp_points_get_neighbours(mH->p, lat, lon, radius, include_match, idx.data(), nullptr, (int)idx.size(), &count));
+        idx.resize(count);
+        return idx;
+    }
+    int get_num_neighbours(float lat, float lon, float radius, bool include_match = true) const { return (int)get_neighbours(lat, lon, radius, include_match).size(); }
+    int get_nearest_neighbour(float lat, float lon, bool include_match = true) const {
+        int i = -1;
+        detail::check(gpp_points_nearest_neighbour(mH->p, &lat, &lon, 1, include_match, &i));
+        return i;
+    }
+    gpp_points* handle() const { return mH->p; }
+  protected:
+    vec field(int k) const { vec o(mN); detail::check(gpp_points_get(mH->p, k, o.data())); return o; }
+    std::shared_ptr<detail::Handle> mH;
+    int mN = 0;
+    CoordinateType mType = Geodetic;
+};
+typedef Points KDTree;
+
+class Grid {
+  public:
+    Grid() : Grid(vec2(), vec2()) {}
+    Grid(vec2 lats, vec2 lons, vec2 elevs = vec2(), vec2 lafs = vec2(), CoordinateType type = Geodetic) : mType(type) {
+        size_t Y, X, Y2, X2;
+        vec la = detail::flatten(lats, Y, X), lo = detail::flatten(lons, Y2, X2);
+        if(Y != Y2 || X != X2) throw std::invalid_argument("lats and lons must have the same shape");
+        size_t Ye, Xe, Yl, Xl;
+        vec el = detail::flatten(elevs, Ye, Xe), lf = detail::flatten(lafs, Yl, Xl);
+        if(Y * X == 0) Y = X = 0;
+        mH = std::make_shared<detail::Handle>();
+        detail::check(gpp_grid_create(la.data(), lo.data(), (Ye == Y && Xe == X && Y * X) ? el.data() : nullptr,   // grid.cpp:41-54
+                                      (Yl == Y && Xl == X && Y * X) ? lf.data() : nullptr, (int)Y, (int)X, (int)type, &mH->p));
+        mY = (int)Y; mX = (int)X;
+    }
+    ivec size() const { return ivec{mY, mX}; }
+    CoordinateType get_coordinate_type() const { return mType; }
+    ivec get_nearest_neighbour(float lat, float lon, bool include_match = true) const {   // grid.cpp:76-82,108-114
+        if(mY * mX == 0) return ivec();
+        int i = -1;
+        detail::check(gpp_points_nearest_neighbour(mH->p, &lat, &lon, 1, include_match, &i));
+        return ivec{i / mX, i % mX};
+    }
+    gpp_points* handle() const { return mH->p; }
+  private:
+    std::shared_ptr<detail::Handle> mH;
+    int mY = 0, mX = 0;
+    CoordinateType mType = Geodetic;
+};
+
+class StructureFunction {
+  public:
+    virtual ~StructureFunction() {}
+    virtual const gpp_structure* c_struct() const = 0;
+};
+class BarnesStructure : public StructureFunction {
+  public:
+    BarnesStructure(float h, float v = 0, float w = 0, float hmax = MV) {   // src/api/structure.cpp:143-167
+        if(!is_valid(v) || v < 0) throw std::invalid_argument("v must be >= 0");
+        if(!is_valid(w) || w < 0) throw std::invalid_argument("w must be >= 0");
+        mS.kind = 0; mS.h = h; mS.v = v; mS.w = w;
+        detail::check(gpp_barnes_min_rho(h, hmax, &mS.min_rho));
+    }
+    float localization_distance() const { float d; detail::check(gpp_barnes_localization_distance(&mS, &d)); return d; }
+    const gpp_structure* c_struct() const override { return &mS; }
+  private:
+    gpp_structure mS;
+};
+
+// ---- optimal interpolation (include/gridpp.h:162-248) -------------------------------------------------
+inline vec optimal_interpolation_full(const Points& bpoints, const vec& background, const vec& bvariance, const Points& points,
+                                      const vec& obs, const vec& obs_variance, const vec& background_at_points,
+                                      const vec& bvariance_at_points, const StructureFunction& structure, int max_points,
+                                      vec& analysis_variance, bool allow_extrapolation = true) {
+    if(max_points < 0) throw std::invalid_argument("max_points must be >= 0");
+    if(bpoints.get_coordinate_type() != points.get_coordinate_type())
+        throw std::invalid_argument("Both background points and observations points must be of same coordinate type (lat/lon or x/y)");
+    if((int)background.size() != bpoints.size()) throw std::invalid_argument("Input field is not the same size as the grid");
+    if(background.size() != bvariance.size()) throw std::invalid_argument("Input bvariance is not the same size as the grid");
+    if((int)obs.size() != points.size()) throw std::invalid_argument("Observations and points size mismatch");
+    if((int)obs_variance.size() != points.size()) throw std::invalid_argument("Obs variance and points size mismatch");
+    if((int)background_at_points.size() != points.size()) throw std::invalid_argument("Background and points size mismatch");
+    if((int)bvariance_at_points.size() != points.size()) throw std::invalid_argument("Background variance and points size mismatch");
+    if(points.size() == 0) return background;   // oi.cpp:189-190 (analysis_variance left untouched)
+    vec out(background.size());
+    analysis_variance.assign(background.size(), 0);
+    detail::check(gpp_optimal_interpolation_full(bpoints.handle(), background.data(), bvariance.data(), points.handle(), obs.data(),
+                                                 obs_variance.data(), background_at_points.data(), bvariance_at_points.data(),
+                                                 structure.c_struct(), max_points, allow_extrapolation, out.data(),
+                                                 analysis_variance.data(), GPP_MEM_HOST));
+    return out;
+}
+inline vec optimal_interpolation(const Points& bpoints, const vec& background, const Points& points, const vec& pobs, const vec& pratios,
+                                 const vec& pbackground, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    if(max_points < 0) throw std::invalid_argument("max_points must be >= 0");
+    if(bpoints.get_coordinate_type() != points.get_coordinate_type())
+        throw std::invalid_argument("Both background points and observations points must be of same coordinate type (lat/lon or x/y)");
+    if((int)background.size() != bpoints.size()) throw std::invalid_argument("Input field is not the same size as the grid");
+    if((int)pobs.size() != points.size()) throw std::invalid_argument("Observations and points size mismatch");
+    if((int)pratios.size() != points.size()) throw std::invalid_argument("Ratios and points size mismatch");
+    if((int)pbackground.size() != points.size()) throw std::invalid_argument("Background and points size mismatch");
+    vec out(background.size());
+    if(background.empty()) return out;
+    detail::check(gpp_optimal_interpolation_full(bpoints.handle(), background.data(), nullptr, points.handle(), pobs.data(), pratios.data(),
+                                                 pbackground.data(), nullptr, structure.c_struct(), max_points, allow_extrapolation,
+                                                 out.data(), nullptr, GPP_MEM_HOST));
+    return out;
+}
+namespace detail {
+inline void check_grid_field(const Grid& g, size_t Y, size_t X) {
+    if((int)Y != g.size()[0] || (int)X != g.size()[1]) throw std::invalid_argument("input field is not the same size as the grid");
+}
+}
+inline vec2 optimal_interpolation(const Grid& bgrid, const vec2& background, const Points& points, const vec& pobs, const vec& pratios,
+                                  const vec& pbackground, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    if(max_points < 0) throw std::invalid_argument("max_points must be >= 0");
+    if(bgrid.get_coordinate_type() != points.get_coordinate_type())
+        throw std::invalid_argument("Both background grid and observations points must be of same coordinate type (lat/lon or x/y)");
+    size_t Y, X;
+    vec bg = detail::flatten(background, Y, X);
+    detail::check_grid_field(bgrid, Y, X);
+    if((int)pobs.size() != points.size() || (int)pratios.size() != points.size() || (int)pbackground.size() != points.size())
+        throw std::invalid_argument("Observations / ratios / background and points size mismatch");
+    vec out(bg.size());
+    if(!bg.empty())
+        detail::check(gpp_optimal_interpolation_full(bgrid.handle(), bg.data(), nullptr, points.handle(), pobs.data(), pratios.data(),
+                                                     pbackground.data(), nullptr, structure.c_struct(), max_points, allow_extrapolation,
+                                                     out.data(), nullptr, GPP_MEM_HOST));
+    return detail::unflatten(out, Y, X);
+}
+inline vec2 optimal_interpolation_full(const Grid& bgrid, const vec2& background, const vec2& bvariance, const Points& points, const vec& obs,
+                                       const vec& obs_variance, const vec& background_at_points, const vec& bvariance_at_points,
+                                       const StructureFunction& structure, int max_points, vec2& analysis_variance, bool allow_extrapolation = true) {
+    if(max_points < 0) throw std::invalid_argument("max_points must be >= 0");
+    if(bgrid.get_coordinate_type() != points.get_coordinate_type())
+        throw std::invalid_argument("Both background grid and observations points must be of same coordinate type (lat/lon or x/y)");
+    size_t Y, X, Yv, Xv;
+    vec bg = detail::flatten(background, Y, X), bv = detail::flatten(bvariance, Yv, Xv);
+    detail::check_grid_field(bgrid, Y, X);
+    if(Y != Yv || X != Xv) throw std::invalid_argument("Input bvariance is not the same size as the grid");
+    if((int)obs.size() != points.size() || (int)obs_variance.size() != points.size() || (int)background_at_points.size() != points.size() ||
+       (int)bvariance_at_points.size() != points.size())
+        throw std::invalid_argument("Observation arrays and points size mismatch");
+    if(points.size() == 0) { analysis_variance = bvariance; return background; }
+    vec out(bg.size()), var(bg.size());
+    detail::check(gpp_optimal_interpolation_full(bgrid.handle(), bg.data(), bv.data(), points.handle(), obs.data(), obs_variance.data(),
+                                                 background_at_points.data(), bvariance_at_points.data(), structure.c_struct(), max_points,
+                                                 allow_extrapolation, out.data(), var.data(), GPP_MEM_HOST));
+    analysis_variance = detail::unflatten(var, Y, X);
+    return detail::unflatten(out, Y, X);
+}
+// include/gridpp.h:263-294
+inline vec2 optimal_interpolation_ensi(const Points& bpoints, const vec2& background, const Points& points, const vec& pobs, const vec& psigmas,
+                                       const vec2& pbackground, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    if(max_points < 0) throw std::invalid_argument("max_points must be >= 0");
+    if(points.size() == 0) return background;
+    if(bpoints.get_coordinate_type() != points.get_coordinate_type())
+        throw std::invalid_argument("Both background and observations points must be of same coorindate type (lat/lon or x/y)");
+    size_t N, E, S, E2;
+    vec bg = detail::flatten(background, N, E), pbg = detail::flatten(pbackground, S, E2);
+    if((int)N != bpoints.size()) throw std::invalid_argument("Input field is not the same size as the grid");
+    if((int)pobs.size() != points.size() || (int)psigmas.size() != points.size() || (int)S != points.size())
+        throw std::invalid_argument("Observations / sigmas / background and points size mismatch");
+    if(E != E2) throw std::invalid_argument("Ensemble size mismatch");
+    vec out(bg.size());
+    detail::check(gpp_optimal_interpolation_ensi(bpoints.handle(), bg.data(), (int)E, points.handle(), pobs.data(), psigmas.data(), pbg.data(),
+                                                 structure.c_struct(), max_points, allow_extrapolation, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, N, E);
+}
+inline vec3 optimal_interpolation_ensi(const Grid& bgrid, const vec3& background, const Points& points, const vec& pobs, const vec& psigmas,
+                                       const vec2& pbackground, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    if(max_points < 0) throw std::invalid_argument("max_points must be >= 0");
+    if(points.size() == 0) return background;
+    if(bgrid.size()[0] == 0 || bgrid.size()[1] == 0) throw std::invalid_argument("Grid size cannot be zero");
+    if(bgrid.get_coordinate_type() != points.get_coordinate_type())
+        throw std::invalid_argument("Both background grid and observations points must be of same coordinate type (lat/lon or x/y)");
+    size_t Y, X, E, S, E2;
+    vec bg = detail::flatten(background, Y, X, E), pbg = detail::flatten(pbackground, S, E2);
+    detail::check_grid_field(bgrid, Y, X);
+    if((int)pobs.size() != points.size() || (int)psigmas.size() != points.size() || (int)S != points.size())
+        throw std::invalid_argument("Observations / sigmas / background and points size mismatch");
+    if(E != E2) throw std::invalid_argument("Ensemble members in gridded background is not the same as in the point background");
+    vec out(bg.size());
+    detail::check(gpp_optimal_interpolation_ensi(bgrid.handle(), bg.data(), (int)E, points.handle(), pobs.data(), psigmas.data(), pbg.data(),
+                                                 structure.c_struct(), max_points, allow_extrapolation, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, Y, X, E);
+}
+
+// ---- neighbourhood (include/gridpp.h:588-716) ---------------------------------------------------------------
+namespace detail {
+inline vec2 nb(const vec& f, size_t Y, size_t X, size_t E, int is3d, int halfwidth, Statistic statistic) {
+    if(halfwidth < 0) throw std::invalid_argument("Half width must be > 0");
+    if(statistic == Quantile) throw std::invalid_argument("Use neighbourhood_quantile for computing neighbourhood quantiles");
+    if(Y * X * E == 0) return vec2();
+    vec out(Y * X);
+    check(gpp_neighbourhood(f.data(), (int)Y, (int)X, (int)E, is3d, halfwidth, (int)statistic, out.data(), GPP_MEM_HOST));
+    return unflatten(out, Y, X);
+}
+inline vec2 brute(const vec& f, size_t Y, size_t X, size_t E, int halfwidth, int statistic, float q) {
+    if(halfwidth < 0) throw std::invalid_argument("Half width must be > 0");
+    if(Y * X * E == 0) return vec2();
+    vec out(Y * X);
+    check(gpp_neighbourhood_brute_force(f.data(), (int)Y, (int)X, (int)E, halfwidth, statistic, q, out.data(), GPP_MEM_HOST));
+    return unflatten(out, Y, X);
+}
+inline vec2 qfast(const vec& f, size_t Y, size_t X, size_t E, int is3d, const vec2& quantile, int halfwidth, const vec& thresholds) {
+    if(halfwidth < 0) throw std::invalid_argument("Half width must be > 0");
+    if(Y * X * E == 0) return vec2();
+    size_t Yq, Xq;
+    vec q = flatten(quantile, Yq, Xq);
+    if(!(Yq == 1 && Xq == 1) && !(Yq == Y && Xq == X)) throw std::invalid_argument("Quantile must be the same size as input, or size (1, 1)");
+    vec out(Y * X);
+    check(gpp_neighbourhood_quantile_fast(f.data(), (int)Y, (int)X, (int)E, is3d, q.data(), (int)q.size(), halfwidth, thresholds.data(),
+                                          (int)thresholds.size(), out.data(), GPP_MEM_HOST));
+    return unflatten(out, Y, X);
+}
+}
+inline vec2 neighbourhood(const vec2& input, int halfwidth, Statistic statistic) { size_t Y, X; vec f = detail::flatten(input, Y, X); return detail::nb(f, Y, X, 1, 0, halfwidth, statistic); }
+inline vec2 neighbourhood(const vec3& input, int halfwidth, Statistic statistic) { size_t Y, X, E; vec f = detail::flatten(input, Y, X, E); return detail::nb(f, Y, X, E, 1, halfwidth, statistic); }
+inline vec2 neighbourhood_brute_force(const vec2& input, int halfwidth, Statistic statistic) { size_t Y, X; vec f = detail::flatten(input, Y, X); return detail::brute(f, Y, X, 1, halfwidth, statistic, 0); }
+inline vec2 neighbourhood_brute_force(const vec3& input, int halfwidth, Statistic statistic) { size_t Y, X, E; vec f = detail::flatten(input, Y, X, E); return detail::brute(f, Y, X, E, halfwidth, statistic, 0); }
+inline vec2 neighbourhood_quantile(const vec2& input, float quantile, int halfwidth) { size_t Y, X; vec f = detail::flatten(input, Y, X); return detail::brute(f, Y, X, 1, halfwidth, Quantile, quantile); }
+inline vec2 neighbourhood_quantile(const vec3& input, float quantile, int halfwidth) { size_t Y, X, E; vec f = detail::flatten(input, Y, X, E); return detail::brute(f, Y, X, E, halfwidth, Quantile, quantile); }
+inline vec2 neighbourhood_quantile_fast(const vec2& input, const vec2& quantile, int halfwidth, const vec& thresholds) { size_t Y, X; vec f = detail::flatten(input, Y, X); return detail::qfast(f, Y, X, 1, 0, quantile, halfwidth, thresholds); }
+inline vec2 neighbourhood_quantile_fast(const vec2& input, float quantile, int halfwidth, const vec& thresholds) { return neighbourhood_quantile_fast(input, vec2(1, vec(1, quantile)), halfwidth, thresholds); }
+inline vec2 neighbourhood_quantile_fast(const vec3& input, const vec2& quantile, int halfwidth, const vec& thresholds) { size_t Y, X, E; vec f = detail::flatten(input, Y, X, E); return detail::qfast(f, Y, X, E, 1, quantile, halfwidth, thresholds); }
+inline vec2 neighbourhood_quantile_fast(const vec3& input, float quantile, int halfwidth, const vec& thresholds) { return neighbourhood_quantile_fast(input, vec2(1, vec(1, quantile)), halfwidth, thresholds); }
+namespace detail {
+inline vec thresholds(const vec& f, int num) {
+    if(num <= 0) throw std::invalid_argument("num_thresholds must be > 0");
+    if(f.empty()) return vec();
+    vec out(num >= (int)f.size() ? f.size() : num); int count = 0;
+    check(gpp_calc_even_quantiles(f.data(), (long)f.size(), num, 1, out.data(), &count, GPP_MEM_HOST));
+    out.resize(count);
+    return out;
+}
+}
+inline vec get_neighbourhood_thresholds(const vec2& input, int num_thresholds) { size_t Y, X; return detail::thresholds(detail::flatten(input, Y, X), num_thresholds); }
+inline vec get_neighbourhood_thresholds(const vec3& input, int num_thresholds) { size_t Y, X, E; return detail::thresholds(detail::flatten(input, Y, X, E), num_thresholds); }
+
+// ---- nearest (include/gridpp.h:895; src/api/nearest.cpp:124-144) ------------------------------------------------
+inline vec nearest(const Grid& igrid, const Points& opoints, const vec2& ivalues) {
+    size_t Y, X;
+    vec v = detail::flatten(ivalues, Y, X);
+    if((int)Y != igrid.size()[0] || (int)X != igrid.size()[1]) throw std::invalid_argument("Grid size is not the same as values");
+    vec out(opoints.size(), MV);
+    if(opoints.size()) detail::check(gpp_nearest(igrid.handle(), opoints.handle(), v.data(), out.data(), GPP_MEM_HOST));
+    return out;
+}
+inline vec nearest(const Points& ipoints, const Points& opoints, const vec& ivalues) {
+    if((int)ivalues.size() != ipoints.size()) throw std::invalid_argument("Points size is not the same as values");
+    vec out(opoints.size(), MV);
+    if(opoints.size()) detail::check(gpp_nearest(ipoints.handle(), opoints.handle(), ivalues.data(), out.data(), GPP_MEM_HOST));
+    return out;
+}
+
+// ---- util (include/gridpp.h:1454-1482) -----------------------------------------------------------------------------
+inline float calc_statistic(const vec& array, Statistic statistic) {
+    float out = MV;
+    detail::check(gpp_calc_statistic(array.data(), 1, (int)array.size(), (int)statistic, &out, GPP_MEM_HOST));
+    return out;
+}
+inline float calc_quantile(const vec& array, float quantile) {
+    float out = MV;
+    detail::check(gpp_calc_quantile(array.data(), 1, (int)array.size(), &quantile, 1, &out, GPP_MEM_HOST));
+    return out;
+}
+}   // namespace gridpp

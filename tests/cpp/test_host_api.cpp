@@ -1,0 +1,59 @@
+// C++ caller of the host mirror (gridpp_amd/host/gridpp.hpp): the reference's own known-answer cases, written the way
+// a gridpp.h user writes them (tests/test_optimal_interpolation.py:50-63, tests/test_neighbourhood.py:75-88,
+// tests/test_barnes_structure.py, tests/test_kdtree.py:149-161).  Built and run by tests/test_gpu_cpp_host.py.
+#include <cstdio>
+#include <cstdlib>
+#include "gridpp.hpp"
+
+#define CHECK(cond) do { if(!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while(0)
+
+int main() {
+    using namespace gridpp;
+    // OI analytic case
+    vec2 y = {{0, 0, 0}}, x = {{0, 2500, 10000}};
+    Grid grid(y, x, y, y, Cartesian);
+    Points points(vec{0}, vec{2500}, vec{0}, vec{0}, Cartesian);
+    BarnesStructure structure(2500);
+    vec2 background = {{0, 0, 0}};
+    vec2 out = optimal_interpolation(grid, background, points, vec{1}, vec{0.1f}, vec{0}, structure, 10);
+    CHECK(std::fabs(out[0][0] - std::exp(-0.5) / 1.1) < 1e-6);
+    CHECK(std::fabs(out[0][1] - 1 / 1.1) < 1e-6);
+    CHECK(std::fabs(out[0][2] - std::exp(-4.5) / 1.1) < 1e-6);
+    vec2 variance;
+    vec2 bvar = {{1, 1, 1}};
+    optimal_interpolation_full(grid, background, bvar, points, vec{1}, vec{0.1f}, vec{0}, vec{1}, structure, 10, variance);
+    CHECK(std::fabs(variance[0][1] - 0.1 / 1.1) < 1e-6);
+    // invalid arguments -> std::invalid_argument
+    bool threw = false;
+    try { optimal_interpolation(grid, background, points, vec{1}, vec{0.1f}, vec{0}, structure, -1); } catch(const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { Points bad(vec{91}, vec{0}); } catch(const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    // radius edge
+    Points p3(vec{0, 1000, 2000}, vec{0, 0, 0}, vec{0, 0, 0}, vec{0, 0, 0}, Cartesian);
+    CHECK(p3.get_neighbours(0, 0, 1000) == ivec{0});
+    CHECK((p3.get_neighbours(0, 0, 1001) == ivec{0, 1}));
+    CHECK(p3.get_nearest_neighbour(900, 0) == 1);
+    // neighbourhood 5x5 with two NaNs
+    vec2 values(5, vec(5));
+    for(int i = 0; i < 5; i++) for(int j = 0; j < 5; j++) values[i][j] = i * 5 + j;
+    values[1][3] = NAN; values[2][4] = NAN;
+    vec2 m = neighbourhood(values, 1, Mean);
+    CHECK(m[2][2] == 12.5f);
+    CHECK(std::fabs(m[0][4] - 5.3333f) < 1e-4);
+    CHECK(neighbourhood(values, 1, Max)[2][2] == 18);
+    CHECK(neighbourhood_quantile(values, 0.5f, 1)[2][3] == 13);
+    vec thr = get_neighbourhood_thresholds(values, 100);
+    CHECK(neighbourhood_quantile_fast(values, 0.5f, 1, thr)[2][2] == 12);
+    CHECK(calc_statistic(vec{0, 1, NAN}, Mean) == 0.5f);
+    CHECK(calc_quantile(vec{0, NAN, 2}, 0.5f) == 1);
+    // EnSI pass-through (tests/test_optimal_interpolation_ens.py:9-35)
+    Points g1(vec{0}, vec{0});
+    vec2 bg3 = {{0, 0, 0}};
+    Points p2(vec{0, 0.1f}, vec{0, 0.1f});
+    vec2 o3 = optimal_interpolation_ensi(g1, bg3, p2, vec{NAN, 0}, vec{1, 1}, vec2{{0, 0, 0}, {0, 0, 0}}, BarnesStructure(500000), 10);
+    CHECK(o3[0][0] == 0 && o3[0][2] == 0);
+    std::printf("gridpp.hpp host API: all checks passed (version %s)\n", version().c_str());
+    return 0;
+}

@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: two gloo ranks, row tiles + observation broadcast (gridpp_amd/dist.py), with the single-GPU
+compute stage replaced by the oracle.  The assembled tiles must equal the single-process result bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from gridpp_amd import dist as gdist
+
+
+def test_row_tiles_cover_the_grid():
+    for ny in (1, 7, 8, 4000, 4001):
+        for world in (1, 2, 3, 8):
+            tiles = gdist.all_tiles(ny, world)
+            assert tiles[0][0] == 0 and tiles[-1][1] == ny
+            assert all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))
+            sizes = [b - a for a, b in tiles]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        gdist.row_tile(10, 2, 2)
+
+
+def _oracle_compute(lats, lons, bg, plats, plons, obs, ratios, pbg, structure_args, max_points, allow=True):
+    from oracle import oracle as O
+    g = O.Pts(np.ravel(lats), np.ravel(lons))
+    p = O.Pts(plats, plons)
+    return O.oi(g, np.ravel(bg), p, obs, ratios, pbg, O.Barnes(*structure_args), max_points, allow).reshape(np.shape(bg))
+
+
+def _workload():
+    rng = np.random.default_rng(77)
+    Y, X, S = 21, 16, 60
+    lats, lons = np.meshgrid(np.linspace(0, 1, Y), np.linspace(0, 1, X), indexing="ij")
+    bg = rng.normal(0, 1, (Y, X)).astype(np.float32)
+    plats, plons = rng.random(S), rng.random(S)
+    vals = np.stack([rng.normal(0, 1, S), rng.uniform(0.1, 1, S), rng.normal(0, 1, S)]).astype(np.float32)
+    return lats, lons, bg, plats, plons, vals
+
+
+def _worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lats, lons, bg, plats, plons, vals = _workload()
+    # only rank 0 owns the observation values of this step; the others start from garbage
+    t = torch.from_numpy(vals.copy()) if rank == 0 else torch.full((3, vals.shape[1]), float("nan"))
+    row0, row1, tile = gdist.tiled_optimal_interpolation(lats, lons, bg, plats, plons, t, (30000.0,), 8, rank, world,
+                                                         _oracle_compute)
+    assert torch.equal(t, torch.from_numpy(vals)), "broadcast did not deliver the observation block"
+    np.save(os.path.join(outdir, "tile%d.npy" % rank), tile)
+    np.save(os.path.join(outdir, "rows%d.npy" % rank), np.array([row0, row1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_tiles_equal_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 2
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    lats, lons, bg, plats, plons, vals = _workload()
+    ref = _oracle_compute(lats, lons, bg, plats, plons, vals[0], vals[1], vals[2], (30000.0,), 8)
+    out = np.full_like(ref, np.nan)
+    for r in range(world):
+        row0, row1 = np.load(tmp_path / ("rows%d.npy" % r))
+        out[row0:row1] = np.load(tmp_path / ("tile%d.npy" % r))
+    np.testing.assert_array_equal(out, ref)
+    assert np.abs(ref - bg).max() > 0.05
