@@ -393,6 +393,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
     a.s.h = st->h; a.s.v = st->v; a.s.w = st->w; a.s.R = loc_dist_e(st);
     a.s.max_points = max_points;
+    a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr;
     a.s.K = (max_points > 0 && max_points <= EN) ? max_points : EN;
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
     a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;

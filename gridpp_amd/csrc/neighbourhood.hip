@@ -114,59 +114,108 @@ __device__ float row_quantile(const float* row, int n, float q) {   // util.cpp:
 #define MEMBER_EC 160   // rows up to this many members are staged through LDS
 #define TB 8            // thresholds per register batch
 
+// Mean / Sum / Count of one LDS row with 16-byte reads issued ahead of the (sequential, reference-order) float adds
+__device__ __forceinline__ float row_mean_sum_count_v4(const float* row, int E, int statistic) {
+    float total = 0; int count = 0;
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+    const int n4 = E >> 2;
+#pragma unroll 5
+    for(int i = 0; i < n4; i++) {
+        const float4 q = r4[i];
+        if(nv(q.x)) { total += q.x; count++; }
+        if(nv(q.y)) { total += q.y; count++; }
+        if(nv(q.z)) { total += q.z; count++; }
+        if(nv(q.w)) { total += q.w; count++; }
+    }
+    for(int i = n4 * 4; i < E; i++) { const float v = row[i]; if(nv(v)) { total += v; count++; } }
+    if(statistic == GPP_COUNT) return (float)count;
+    if(count == 0) return NAN;
+    return (statistic == GPP_MEAN) ? total / (float)count : total;
+}
+
+// per-lane work on one row (members of one cell); forceinlined separately for LDS rows and global rows so that the
+// LDS path keeps address space 3 (a pointer that may be either becomes a slow flat access)
+template <int MODE>
+__device__ __forceinline__ void member_row_work(const float* row, const int E, const bool vec_ok, const int statistic,
+                                                const float* __restrict__ thr, const int T, float* __restrict__ out, const long C, const long cell) {
+    if(MODE == 0) {
+        if(vec_ok && (statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT))
+            out[cell] = row_mean_sum_count_v4(row, E, statistic);
+        else out[cell] = row_statistic(row, E, statistic);
+    }
+    else {
+        int count = 0;
+        for(int e = 0; e < E; e++) if(nv(row[e])) count++;
+        for(int t0 = 0; t0 < T; t0 += TB) {
+            float th[TB]; int sum[TB];
+#pragma unroll
+            for(int k = 0; k < TB; k++) { th[k] = (t0 + k < T) ? thr[t0 + k] : 0.0f; sum[k] = 0; }
+#pragma unroll 4
+            for(int e = 0; e < E; e++) {
+                const float v = row[e];
+                const bool ok = nv(v);
+#pragma unroll
+                for(int k = 0; k < TB; k++) sum[k] += (ok && v <= th[k]) ? 1 : 0;
+            }
+#pragma unroll
+            for(int k = 0; k < TB; k++)
+                if(t0 + k < T) out[(long)(t0 + k) * C + cell] = count > 0 ? (float)sum[k] / (float)count : NAN;
+        }
+    }
+}
+
 // mode 0: out[c] = calc_statistic(members of c)                       (neighbourhood.cpp:21-25)
 // mode 1: out[t*C + c] = #(valid members <= thr[t]) / #valid members  (neighbourhood.cpp:456-471)
-// One wavefront per workgroup, grid-stride over tiles of 64 consecutive cells.  The 64*E contiguous floats of a
-// tile are copied linearly HBM -> LDS with 16-byte accesses (fully coalesced, no index arithmetic); lane l then
-// walks row l in member order (ds_read_b32, 4-way bank conflict at E = 100: LDS time stays below the HBM time).
-__global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in, long C, int E, int mode, int statistic,
-                                                    const float* __restrict__ thr, int T, float* __restrict__ out) {
-    extern __shared__ float lds[];
+// One wavefront per workgroup, grid-stride over tiles of 64 consecutive cells.  The 64*E contiguous floats (16*E
+// float4) of a tile go HBM -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, linear layout, no
+// VGPR round trip) into one half of a double buffer while lane l walks row l of the previous tile in member order
+// out of the other half.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in, long C, int E, int statistic,
+                                                    const float* __restrict__ thr, int T, float* __restrict__ out, int use_dma) {
+    extern __shared__ float4 lds4[];
     const int lane = threadIdx.x;
     const long ntiles = (C + 63) / 64;
-    const bool staged = E <= MEMBER_EC;
-    const bool al16 = (reinterpret_cast<size_t>(in) & 15) == 0;
-    for(long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long cell0 = tile * 64;
-        const int ncell = (int)min((long)64, C - cell0);
-        const long cell = cell0 + lane;
-        const float* row;
-        if(staged) {
-            const long base = cell0 * E;   // multiple of 64 floats: 16-byte aligned whenever `in` is
-            const int total = ncell * E;
-            __syncthreads();               // previous tile fully consumed
-            if(al16) {
-                for(int i = lane * 4; i < total; i += 256) {
-                    if(i + 3 < total) *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(in + base + i);
-                    else for(int k = 0; i + k < total; k++) lds[i + k] = in[base + i + k];
-                }
+    const long nfull = C / 64;                       // tiles with 64 cells
+    const int nf4 = 16 * E;                          // float4 per full tile
+    const int nchunk = (nf4 + 63) / 64;              // 1 KiB wave-loads per tile
+    const int bufstride = nchunk * 64;               // float4 per buffer (padded to whole chunks)
+    if(use_dma) {
+        const float4* in4 = reinterpret_cast<const float4*>(in);
+        auto issue = [&](long tile, int b) {
+            const float4* src = in4 + tile * nf4;
+            float4* dst = lds4 + b * bufstride;
+            for(int k = 0; k < nchunk; k++) {
+                const int idx = k * 64 + lane;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (idx < nf4 ? idx : nf4 - 1)), (lds_void_t*)(dst + k * 64), 16, 0, 0);
             }
-            else for(int i = lane; i < total; i += 64) lds[i] = in[base + i];
+        };
+        int b = 0;
+        if((long)blockIdx.x < nfull) issue(blockIdx.x, 0);
+        for(long tile = blockIdx.x; tile < nfull; tile += gridDim.x) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed in buffer b
             __syncthreads();
-            row = lds + lane * E;
+            const long nxt = tile + gridDim.x;
+            if(nxt < nfull) issue(nxt, b ^ 1);                   // next tile flies during the row walk
+            const float* row = reinterpret_cast<const float*>(lds4 + b * bufstride) + lane * E;
+            member_row_work<MODE>(row, E, (E & 3) == 0, statistic, thr, T, out, C, tile * 64 + lane);
+            b ^= 1;
         }
-        else row = in + cell * E;          // long rows: lane-private walk straight from memory
-        if(lane < ncell) {
-            if(mode == 0) out[cell] = row_statistic(row, E, statistic);
-            else {
-                int count = 0;
-                for(int e = 0; e < E; e++) if(nv(row[e])) count++;
-                for(int t0 = 0; t0 < T; t0 += TB) {
-                    float th[TB]; int sum[TB];
-#pragma unroll
-                    for(int k = 0; k < TB; k++) { th[k] = (t0 + k < T) ? thr[t0 + k] : 0.0f; sum[k] = 0; }
-                    for(int e = 0; e < E; e++) {
-                        const float v = row[e];
-                        const bool ok = nv(v);
-#pragma unroll
-                        for(int k = 0; k < TB; k++) sum[k] += (ok && v <= th[k]) ? 1 : 0;
-                    }
-#pragma unroll
-                    for(int k = 0; k < TB; k++)
-                        if(t0 + k < T) out[(long)(t0 + k) * C + cell] = count > 0 ? (float)sum[k] / (float)count : NAN;
-                }
-            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the last, partial tile (if any): lane-private walk straight from memory, on block 0
+        if(nfull < ntiles && blockIdx.x == 0) {
+            const long cell = nfull * 64 + lane;
+            if(cell < C) member_row_work<MODE>(in + cell * E, E, false, statistic, thr, T, out, C, cell);
         }
+        return;
+    }
+    // generic path (long rows or unaligned input): lane-private walk straight from memory
+    for(long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long cell = tile * 64 + lane;
+        if(cell < C) member_row_work<MODE>(in + cell * E, E, false, statistic, thr, T, out, C, cell);
     }
 }
 
@@ -398,15 +447,22 @@ struct NbWorkspace {
 };
 thread_local NbWorkspace g_nb;
 
-void member_pass(const float* d_in, long C, int E, int mode, int statistic, const float* d_thr, int T, float* d_out) {
+template <int MODE>
+void member_pass_launch(const float* d_in, long C, int E, int statistic, const float* d_thr, int T, float* d_out) {
     const long tiles = (C + 63) / 64;
-    const size_t lds = (E <= MEMBER_EC) ? (size_t)64 * E * sizeof(float) + 16 : 16;
+    const int nchunk = (16 * E + 63) / 64;
+    const bool dma = E <= MEMBER_EC && (reinterpret_cast<size_t>(d_in) & 15) == 0;
+    const size_t lds = dma ? (size_t)2 * nchunk * 1024 : 16;   // double buffer of whole 1 KiB chunks
     static bool attr = false;
-    if(!attr) { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * MEMBER_EC * 4 + 16)); attr = true; }
-    const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
-    const long grid = std::min<long>(tiles, (long)256 * waves_per_cu * 2);
-    hipLaunchKernelGGL(k_member_pass, dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, mode, statistic, d_thr, T, d_out);
+    if(!attr) { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((16 * MEMBER_EC + 63) / 64) * 1024)); attr = true; }
+    const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds, 1)));
+    const long grid = std::min<long>(tiles, (long)256 * waves_per_cu);
+    hipLaunchKernelGGL((k_member_pass<MODE>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, statistic, d_thr, T, d_out, dma ? 1 : 0);
     GPP_HIP(hipGetLastError());
+}
+void member_pass(const float* d_in, long C, int E, int mode, int statistic, const float* d_thr, int T, float* d_out) {
+    if(mode == 0) member_pass_launch<0>(d_in, C, E, statistic, d_thr, T, d_out);
+    else member_pass_launch<1>(d_in, C, E, statistic, d_thr, T, d_out);
 }
 // Mean / Sum / Count of `nplanes` [Y][X] planes
 void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statistic, float* d_out) {

@@ -418,7 +418,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     a.S = S; a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
     a.s.h = st->h; a.s.v = st->v; a.s.w = st->w; a.s.R = loc_dist(st);
-    a.s.max_points = max_points; a.allow_extrap = allow_extrapolation ? 1 : 0;
+    a.s.max_points = max_points;
+    a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
     a.err = ws.err.p; a.counters = ws.counters.p;
 
@@ -438,6 +439,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     g_stats.kernel_ms = ms;
     g_stats.cells_updated = (long long)counters[0];
     g_stats.solves = (long long)counters[1];
+    if(getenv("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);
     if(err & ERR_SINGULAR) runtime("optimal_interpolation: local (P+R) matrix is singular");
     if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more than 32 observations per grid point requested (max_points == 0 or > 32): large-n path not built yet");
     return GPP_OK;

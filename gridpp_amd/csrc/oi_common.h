@@ -100,6 +100,7 @@ struct ScanArgs {
     float h, v, w, R;
     int K;                   // list capacity in use: min(max_points, N) (N if max_points == 0)
     int max_points;
+    unsigned long long* scan_stats;   // optional: [0] candidates iterated, [1] wave-level survivor-branch executions
 };
 
 // Per-tile candidate scan (src/api/oi.cpp:229-273 for 64 cells at once).  On return every lane holds `cnt` 64-bit
@@ -165,11 +166,13 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
                     float2 met = make_float2(NAN, 0);
                     if(mine < je) { rec = a.pgeo[mine]; met = a.smeta[mine]; }
                     const int nc = min(64, je - base);
+                    if(a.scan_stats && lane == 0) atomicAdd(&a.scan_stats[0], (unsigned long long)nc);
                     for(int c = 0; c < nc; ++c) {
                         const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
                         const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
                         float d2 = dx * dx + dy * dy;
                         d2 = d2 + dz * dz;
+                        if(a.scan_stats && __ballot(d2 <= thr2) != 0ull && lane == 0) atomicAdd(&a.scan_stats[1], 1ull);
                         if(d2 <= thr2) {
                             const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
                             const float dist = sqrtf(d2);
