@@ -145,18 +145,39 @@ __device__ __forceinline__ void member_row_work(const float* row, const int E, c
     }
     else {
         int count = 0;
-        for(int e = 0; e < E; e++) if(nv(row[e])) count++;
         for(int t0 = 0; t0 < T; t0 += TB) {
             float th[TB]; int sum[TB];
 #pragma unroll
             for(int k = 0; k < TB; k++) { th[k] = (t0 + k < T) ? thr[t0 + k] : 0.0f; sum[k] = 0; }
-#pragma unroll 4
-            for(int e = 0; e < E; e++) {
-                const float v = row[e];
-                const bool ok = nv(v);
+            int cnt = 0;
+            if(vec_ok) {   // 16-byte LDS reads, 4 members per read, issued ahead of the compares
+                const float4* r4 = reinterpret_cast<const float4*>(row);
+                const int n4 = E >> 2;
+#pragma unroll 2
+                for(int i = 0; i < n4; i++) {
+                    const float4 q = r4[i];
+                    const float vv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                for(int k = 0; k < TB; k++) sum[k] += (ok && v <= th[k]) ? 1 : 0;
+                    for(int j = 0; j < 4; j++) {
+                        const bool ok = nv(vv[j]);
+                        const float v = ok ? vv[j] : NAN;   // NaN compares false against every threshold
+                        cnt += ok ? 1 : 0;
+#pragma unroll
+                        for(int k = 0; k < TB; k++) sum[k] += (v <= th[k]) ? 1 : 0;
+                    }
+                }
             }
+            else {
+#pragma unroll 4
+                for(int e = 0; e < E; e++) {
+                    const bool ok = nv(row[e]);
+                    const float v = ok ? row[e] : NAN;
+                    cnt += ok ? 1 : 0;
+#pragma unroll
+                    for(int k = 0; k < TB; k++) sum[k] += (v <= th[k]) ? 1 : 0;
+                }
+            }
+            count = cnt;
 #pragma unroll
             for(int k = 0; k < TB; k++)
                 if(t0 + k < T) out[(long)(t0 + k) * C + cell] = count > 0 ? (float)sum[k] / (float)count : NAN;
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ in, 
 // column pass + finish (neighbourhood.cpp:132-142): Mean / Sum / Count.  Each thread owns one column of a strip of
 // COL_STRIP rows and slides the window down it (2 reads per cell instead of 2*hw+1).
 #define COL_STRIP 32
-__global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs, const int* __restrict__ rc, int Y, int X, int hw, int statistic, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs, const int* __restrict__ rc, int Y, int X, int hw, int statistic, float* __restrict__ out, int qf_reps) {
     const long plane = (long)blockIdx.z * Y * X;
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y0 = blockIdx.y * COL_STRIP;
@@ -272,6 +293,11 @@ __global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs,
         float o = NAN;
         if(statistic == GPP_COUNT) o = (float)c;
         else if(c > 0) o = (statistic == GPP_MEAN) ? (float)(s / (double)c) : (float)s;
+        if(qf_reps > 0 && nv(o)) {   // quantile_fast epilogue (neighbourhood.cpp:378-389 / 494-506): E-fold float sum / E, clamp
+            float yv = o;
+            if(qf_reps > 1) { float sum = 0; for(int e = 0; e < qf_reps; e++) sum += o; yv = sum / (float)qf_reps; }
+            o = yv > 1 ? 1.0f : (yv < 0 ? 0.0f : yv);
+        }
         out[plane + (long)y * X + x] = o;
     }
 }
@@ -465,7 +491,7 @@ void member_pass(const float* d_in, long C, int E, int mode, int statistic, cons
     else member_pass_launch<1>(d_in, C, E, statistic, d_thr, T, d_out);
 }
 // Mean / Sum / Count of `nplanes` [Y][X] planes
-void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statistic, float* d_out) {
+void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statistic, float* d_out, int qf_reps = 0) {
     long n = (long)Y * X * nplanes;
     double* rs = g_nb.rs.get(n);
     int* rc = g_nb.rc.get(n);
@@ -478,7 +504,7 @@ void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statisti
     }
     hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, Y, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc);
     GPP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_box_cols, dim3((X + 255) / 256, (Y + COL_STRIP - 1) / COL_STRIP, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out);
+    hipLaunchKernelGGL(k_box_cols, dim3((X + 255) / 256, (Y + COL_STRIP - 1) / COL_STRIP, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out, qf_reps);
     GPP_HIP(hipGetLastError());
 }
 void brute(const float* d_in, int Y, int X, int E, int hw, int statistic, float q, float* d_out) {
@@ -597,9 +623,8 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
     float* planes = g_nb.planes.get((size_t)nt * C);
     float* stats = g_nb.tmp2.get((size_t)nt * C);
     member_pass(in.d, C, ne, 1, 0, th.d, nt, planes);                 // fractions per threshold (:453-472)
-    box_stat(planes, ny, nx, nt, halfwidth, GPP_MEAN, stats);         // stats[t] = neighbourhood(temp, hw, Mean) (:473)
-    long n = (long)nt * C;
-    hipLaunchKernelGGL(k_qf_yarray, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), stats, n, is3d ? ne : 1);
+    // stats[t] = neighbourhood(temp, hw, Mean) (:473) with the yarray epilogue (:494-506) fused into the column pass
+    box_stat(planes, ny, nx, nt, halfwidth, GPP_MEAN, stats, is3d ? ne : 1);
     hipLaunchKernelGGL(k_qf_interp, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream(), (const float*)stats, C, nt, th.d, qf.d, nq == 1 ? 0 : 1, o.d);
     GPP_HIP(hipGetLastError());
     o.finish();
