@@ -393,6 +393,9 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
     a.s.h = st->h; a.s.v = st->v; a.s.w = st->w; a.s.R = loc_dist_e(st);
     a.s.max_points = max_points;
+    { const double occ = (double)S / ((double)ix->nbx * ix->nby);
+      const int kk = (max_points > 0 && max_points <= 32) ? max_points : 32;
+      a.s.q0 = std::max(1, std::min(8, (int)std::ceil(0.5 * (std::sqrt(1.6 * kk / std::max(occ, 1e-3)) - 1.0)))); }
     a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr;
     a.s.K = (max_points > 0 && max_points <= EN) ? max_points : EN;
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;

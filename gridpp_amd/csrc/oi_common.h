@@ -29,12 +29,36 @@ gpp_obs_index* gpp_build_obs_index(gpp_points* pts);   // oi.hip
 __device__ __forceinline__ bool d_valid(float v) { return !isnan(v) && !isinf(v); }
 
 // src/api/structure.cpp:26-34
+// exp(x) for x <= 0, accurate to < 1 ulp(double) (the result is only used rounded to float32, where the reference's
+// libm exp gives the same value except when exp(x) lies within ~1e-16 relative of a float32 rounding boundary).
+// Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial in Horner form, exact 2^k scaling.
+__device__ __forceinline__ double d_exp_nonpos(double x) {
+    if(x < -110.0) return 0.0;   // (float)exp(x) == 0 below -103.98
+    const double kf = rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;            // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878680989792e-09);
+    p = __builtin_fma(p, r, 2.50521083854417187751e-08);
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
 __device__ __forceinline__ float d_barnes_rho(float dist, float length) {
     if(!d_valid(length) || length == 0) return 1.0f;
     if(!d_valid(dist)) return 0.0f;
     float v = dist / length;
     double e = -0.5 * (double)v * (double)v;
-    return (float)exp(e);
+    return (float)d_exp_nonpos(e);
 }
 // src/api/kdtree.cpp:192-194 (float32, no contraction, correctly rounded sqrt)
 __device__ __forceinline__ float d_chord(float x0, float y0, float z0, float x1, float y1, float z1) {
@@ -100,6 +124,7 @@ struct ScanArgs {
     float h, v, w, R;
     int K;                   // list capacity in use: min(max_points, N) (N if max_points == 0)
     int max_points;
+    int q0;                  // half-width (in bins) of the phase-1 square of the candidate scan
     unsigned long long* scan_stats;   // optional: [0] candidates iterated, [1] wave-level survivor-branch executions
 };
 
@@ -107,6 +132,11 @@ struct ScanArgs {
 // keys (rho bits << 32 | ~observation index) in keys[0..cnt)[lane]: the observations the reference would keep for
 // that cell (all usable ones if there are at most max_points, otherwise the max_points with the largest rho,
 // ties -> lower observation index).  Must be called by the whole wave with at least one active lane.
+//
+// Order of the walk (it only affects the amount of work, never the result): phase 1 visits the (2q+1)^2 bins around
+// the tile first -- they almost always contain the final selection, so the pruning thresholds are tight before
+// anything far away is looked at; phase 2 walks the bin rows centre-out with the x-extent and the stop test taken
+// from the largest threshold in the wave, skipping the bins phase 1 already did.
 template <int N, bool WANT_TRUNC = false>
 __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, const float gx, const float gy, const float gz,
                                          const float ge, const float gl, unsigned long long (*keys)[64], const int lane, bool& overflow,
@@ -116,113 +146,125 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
     int cnt = 0;
     overflow = false;
     truncated = false;
-    {
-        const float R = a.R;
-        const int K = a.K;
-        const bool bounded = a.max_points > 0 && a.max_points <= N;
-        const float h2 = a.h * a.h;
-        // ---- candidate scan: bin rows centre-out, x-extent and stop from the current worst kept rho ---------
-        float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
-        float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
-        const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
-        const float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
-        const float sbin = 1.0f / a.inv_s;
-        int tby0 = (int)floorf((bmin_t - a.bmin) * a.inv_s), tby1 = (int)floorf((bmax_t - a.bmin) * a.inv_s);
-        tby0 = __builtin_amdgcn_readfirstlane(min(max(tby0, 0), a.nby - 1));
-        tby1 = __builtin_amdgcn_readfirstlane(min(max(tby1, tby0), a.nby - 1));
+    const float R = a.R;
+    const int K = a.K;
+    const bool bounded = a.max_points > 0 && a.max_points <= N;
+    const float h2 = a.h * a.h;
+    float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
+    float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
+    const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
+    const float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
+    const float sbin = 1.0f / a.inv_s;
+    int tby0 = (int)floorf((bmin_t - a.bmin) * a.inv_s), tby1 = (int)floorf((bmax_t - a.bmin) * a.inv_s);
+    tby0 = __builtin_amdgcn_readfirstlane(min(max(tby0, 0), a.nby - 1));
+    tby1 = __builtin_amdgcn_readfirstlane(min(max(tby1, tby0), a.nby - 1));
+    int tbx0 = (int)floorf((amin_t - a.amin) * a.inv_s), tbx1 = (int)floorf((amax_t - a.amin) * a.inv_s);
+    tbx0 = __builtin_amdgcn_readfirstlane(min(max(tbx0, 0), a.nbx - 1));
+    tbx1 = __builtin_amdgcn_readfirstlane(min(max(tbx1, tbx0), a.nbx - 1));
 
-        // strictly-inside box of the radius query (kdtree.cpp:46,53)
-        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
-        unsigned long long wkey = 0;   // worst key kept
-        int wslot = 0;
-        // d2 > thr2 can neither be within R nor beat the worst kept rho (rho <= rho_h(d), monotone in d)
-        const float thr2_R = R * R * 1.000001f + 1e-30f;
-        float thr2 = active ? thr2_R : -1.0f;
+    // strictly-inside box of the radius query (kdtree.cpp:46,53)
+    const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+    unsigned long long wkey = 0;   // worst key kept
+    int wslot = 0;
+    // d2 > thr2 can neither be within R nor beat the worst kept rho (rho <= rho_h(d), monotone in d)
+    const float thr2_R = R * R * 1.000001f + 1e-30f;
+    float thr2 = active ? thr2_R : -1.0f;
 
-        for(int r = 0;; ++r) {
-            const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
-            if(t2 < 0.0f) break;
-            const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
-            if(gap * gap > t2) break;
-            const int rowA = tby0 - r, rowB = tby1 + r;
-            if(rowA < 0 && rowB >= a.nby) break;
-            const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
-            int x0 = (int)floorf((amin_t - wx - a.amin) * a.inv_s) - 1, x1 = (int)floorf((amax_t + wx - a.amin) * a.inv_s) + 1;
-            x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), a.nbx - 1));
-            x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), a.nbx - 1));
-            const int nseg = (r == 0) ? 1 : 2;
-            for(int seg = 0; seg < nseg; ++seg) {
-                int js, je;
-                if(r == 0) { js = a.bin_start[tby0 * a.nbx + x0]; je = a.bin_start[tby1 * a.nbx + x1 + 1];
-                             if(tby1 > tby0) { js = a.bin_start[tby0 * a.nbx]; je = a.bin_start[tby1 * a.nbx + a.nbx]; } }
-                else {
-                    const int row = seg == 0 ? rowA : rowB;
-                    if(row < 0 || row >= a.nby) continue;
-                    js = a.bin_start[row * a.nbx + x0]; je = a.bin_start[row * a.nbx + x1 + 1];
-                }
-                for(int base = js; base < je; base += 64) {
-                    const int mine = base + lane;
-                    float4 rec = make_float4(NAN, 0, 0, NAN);
-                    float2 met = make_float2(NAN, 0);
-                    if(mine < je) { rec = a.pgeo[mine]; met = a.smeta[mine]; }
-                    const int nc = min(64, je - base);
-                    if(a.scan_stats && lane == 0) atomicAdd(&a.scan_stats[0], (unsigned long long)nc);
-                    for(int c = 0; c < nc; ++c) {
-                        const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
-                        const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
-                        float d2 = dx * dx + dy * dy;
-                        d2 = d2 + dz * dz;
-                        if(a.scan_stats && __ballot(d2 <= thr2) != 0ull && lane == 0) atomicAdd(&a.scan_stats[1], 1ull);
-                        if(d2 <= thr2) {
-                            const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
-                            const float dist = sqrtf(d2);
-                            if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
-                                const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                                float rho = d_barnes_rho(dist, a.h);
-                                if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
-                                if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
-                                if(rho > 0.0f) {   // oi.cpp:253
-                                    const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
-                                    const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
-                                    if(cnt < K) {
-                                        keys[cnt][lane] = key;
-                                        if(cnt == 0 || key < wkey) { wkey = key; wslot = cnt; }
-                                        cnt++;
-                                    }
-                                    else if(bounded) {
-                                        truncated = true;
-                                        if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
-                                            keys[wslot][lane] = key;
-                                            wkey = key;
-                                            for(int s = 0; s < K; ++s) {
-                                                const unsigned long long k2 = keys[s][lane];
-                                                if(k2 < wkey) { wkey = k2; wslot = s; }
-                                            }
-                                        }
-                                    }
-                                    else overflow = true;   // more than N usable observations requested
-                                    if(bounded && cnt == K) {
-                                        const float wr = __uint_as_float((unsigned)(wkey >> 32));
-                                        thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
+    // all observations of bins [xa, xb] of bin row `row`
+    auto process_row = [&](const int row, const int xa, const int xb) {
+        if(row < 0 || row >= a.nby || xa > xb) return;
+        const int js = a.bin_start[row * a.nbx + xa], je = a.bin_start[row * a.nbx + xb + 1];
+        for(int base = js; base < je; base += 64) {
+            const int mine = base + lane;
+            float4 rec = make_float4(NAN, 0, 0, NAN);
+            float2 met = make_float2(NAN, 0);
+            if(mine < je) { rec = a.pgeo[mine]; met = a.smeta[mine]; }
+            const int nc = min(64, je - base);
+            if(a.scan_stats && lane == 0) atomicAdd(&a.scan_stats[0], (unsigned long long)nc);
+            for(int c = 0; c < nc; ++c) {
+                const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
+                const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+                float d2 = dx * dx + dy * dy;
+                d2 = d2 + dz * dz;
+                if(a.scan_stats && __ballot(d2 <= thr2) != 0ull && lane == 0) atomicAdd(&a.scan_stats[1], 1ull);
+                if(d2 <= thr2) {
+                    const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                    const float dist = sqrtf(d2);
+                    if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
+                        const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                        float rho = d_barnes_rho(dist, a.h);
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
+                        if(rho > 0.0f) {   // oi.cpp:253
+                            const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
+                            if(cnt < K) {
+                                keys[cnt][lane] = key;
+                                if(cnt == 0 || key < wkey) { wkey = key; wslot = cnt; }
+                                cnt++;
+                            }
+                            else if(bounded) {
+                                truncated = true;
+                                if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
+                                    keys[wslot][lane] = key;
+                                    wkey = key;
+                                    for(int s = 0; s < K; ++s) {
+                                        const unsigned long long k2 = keys[s][lane];
+                                        if(k2 < wkey) { wkey = k2; wslot = s; }
                                     }
                                 }
                             }
-                        }
-                        else if(WANT_TRUNC && !truncated && cnt == K && d2 <= thr2_R) {
-                            // pruned by the rho threshold: does it still count as a usable observation?
-                            const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
-                            const float dist = sqrtf(d2);
-                            if(inbox && dist <= R) {
-                                const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                                float rho = d_barnes_rho(dist, a.h);
-                                if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
-                                if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
-                                if(rho > 0.0f) truncated = true;
+                            else overflow = true;   // more than N usable observations requested
+                            if(bounded && cnt == K) {
+                                const float wr = __uint_as_float((unsigned)(wkey >> 32));
+                                thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
                             }
                         }
                     }
                 }
+                else if(WANT_TRUNC && !truncated && cnt == K && d2 <= thr2_R) {
+                    // pruned by the rho threshold: does it still count as a usable observation?
+                    const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                    const float dist = sqrtf(d2);
+                    if(inbox && dist <= R) {
+                        const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                        float rho = d_barnes_rho(dist, a.h);
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
+                        if(rho > 0.0f) truncated = true;
+                    }
+                }
             }
+        }
+    };
+
+    // ---- phase 1: the square of bins around the tile, rows centre-out ------------------------------------------
+    const int q = a.q0;
+    const int sx0 = max(tbx0 - q, 0), sx1 = min(tbx1 + q, a.nbx - 1);
+    const int sy0 = tby0 - q, sy1 = tby1 + q;
+    for(int row = tby0; row <= tby1; ++row) process_row(row, sx0, sx1);
+    for(int r = 1; r <= q; ++r) { process_row(tby0 - r, sx0, sx1); process_row(tby1 + r, sx0, sx1); }
+
+    // ---- phase 2: every remaining bin that can still matter, rows centre-out ------------------------------------
+    for(int r = 0;; ++r) {
+        const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
+        if(t2 < 0.0f) break;
+        const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
+        if(gap * gap > t2) break;
+        const int rowA = tby0 - r, rowB = tby1 + r;
+        if(rowA < 0 && rowB >= a.nby) break;
+        const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
+        int x0 = (int)floorf((amin_t - wx - a.amin) * a.inv_s) - 1, x1 = (int)floorf((amax_t + wx - a.amin) * a.inv_s) + 1;
+        x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), a.nbx - 1));
+        x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), a.nbx - 1));
+        const int nrows = (r == 0) ? (tby1 - tby0 + 1) : 2;
+        for(int k = 0; k < nrows; ++k) {
+            const int row = (r == 0) ? tby0 + k : (k == 0 ? rowA : rowB);
+            if(row >= sy0 && row <= sy1) {   // phase 1 did [sx0, sx1] of this row
+                process_row(row, x0, min(x1, sx0 - 1));
+                process_row(row, max(x0, sx1 + 1), x1);
+            }
+            else process_row(row, x0, x1);
         }
     }
     return cnt;
