@@ -103,7 +103,8 @@ def main():
     torch.cuda.set_device(local_rank)
     gridpp.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run, also for N = 1
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -119,13 +120,13 @@ def main():
     d_vals = torch.from_numpy(np.stack([obs, ratios, pbg])).to(dev) if rank == 0 else torch.empty((3, S), dtype=torch.float32, device=dev)
 
     def step():
-        if world > 1:
+        if dist is not None:
             dist.broadcast(d_vals, src=0)
         return gridpp.optimal_interpolation(grid, d_bg, points, d_vals[0], d_vals[1], d_vals[2], structure, args.max_points)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -140,7 +141,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     stats = gridpp.oi_last_stats()
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -180,7 +181,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(ny, nx, S, seed, args.h, args.max_points, args.cpu_seconds)
             res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -159,6 +159,17 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         double tr = 0.0;
         for(int i = lane; i < n; i += 64) tr += fabs(s_B[i * BP + i]);
         tr = wave_sum_d(tr);
+        // work items of one Jacobi step: (pair k, index t) for k < half, t < n -> at most 8 per lane; the mapping is
+        // fixed for the cell, so the integer divisions are done once
+        constexpr int IT = (EN / 2) * EN / 64;   // 8
+        int itk[IT], itt[IT];
+#pragma unroll
+        for(int it = 0; it < IT; ++it) {
+            const int idx = lane + 64 * it;
+            const int k = idx / n;
+            itk[it] = (idx < half * n) ? k : -1;
+            itt[it] = idx - k * n;
+        }
         for(int sweep = 0; sweep < 30 && n > 1; ++sweep) {
             double off = 0.0;
             for(int idx = lane; idx < n * n; idx += 64) { const int i = idx / n, j = idx - i * n; if(j < i) { double v = s_B[i * BP + j]; off += v * v; } }
@@ -184,27 +195,45 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
                     s_pq[2 * lane] = p; s_pq[2 * lane + 1] = q;
                 }
                 __syncthreads();
-                // columns: B <- B J, U <- U J
-                for(int idx = lane; idx < half * n; idx += 64) {
-                    const int k = idx / n, row = idx - k * n;
-                    const int p = s_pq[2 * k], q = s_pq[2 * k + 1];
-                    if(p != q) {
-                        const double cs = s_rot[2 * k], sn = s_rot[2 * k + 1];
-                        double x = s_B[row * BP + p], y = s_B[row * BP + q];
-                        s_B[row * BP + p] = cs * x - sn * y; s_B[row * BP + q] = sn * x + cs * y;
-                        x = s_U[row * BP + p]; y = s_U[row * BP + q];
-                        s_U[row * BP + p] = cs * x - sn * y; s_U[row * BP + q] = sn * x + cs * y;
+                // this lane's rotations of the step
+                int ip[IT], iq[IT]; double ics[IT], isn[IT];
+#pragma unroll
+                for(int it = 0; it < IT; ++it) {
+                    const int k = itk[it] < 0 ? 0 : itk[it];
+                    ip[it] = s_pq[2 * k]; iq[it] = s_pq[2 * k + 1];
+                    ics[it] = s_rot[2 * k]; isn[it] = s_rot[2 * k + 1];
+                    if(itk[it] < 0) iq[it] = ip[it];   // no work
+                }
+                // columns: B <- B J, U <- U J   (all loads first, then the arithmetic, then the stores)
+                {
+                    double bx[IT], by[IT], ux[IT], uy[IT];
+#pragma unroll
+                    for(int it = 0; it < IT; ++it) {
+                        const int row = itt[it];
+                        bx[it] = s_B[row * BP + ip[it]]; by[it] = s_B[row * BP + iq[it]];
+                        ux[it] = s_U[row * BP + ip[it]]; uy[it] = s_U[row * BP + iq[it]];
+                    }
+#pragma unroll
+                    for(int it = 0; it < IT; ++it) {
+                        if(ip[it] != iq[it]) {
+                            const int row = itt[it];
+                            s_B[row * BP + ip[it]] = ics[it] * bx[it] - isn[it] * by[it]; s_B[row * BP + iq[it]] = isn[it] * bx[it] + ics[it] * by[it];
+                            s_U[row * BP + ip[it]] = ics[it] * ux[it] - isn[it] * uy[it]; s_U[row * BP + iq[it]] = isn[it] * ux[it] + ics[it] * uy[it];
+                        }
                     }
                 }
                 __syncthreads();
                 // rows: B <- J^T B
-                for(int idx = lane; idx < half * n; idx += 64) {
-                    const int k = idx / n, col = idx - k * n;
-                    const int p = s_pq[2 * k], q = s_pq[2 * k + 1];
-                    if(p != q) {
-                        const double cs = s_rot[2 * k], sn = s_rot[2 * k + 1];
-                        const double x = s_B[p * BP + col], y = s_B[q * BP + col];
-                        s_B[p * BP + col] = cs * x - sn * y; s_B[q * BP + col] = sn * x + cs * y;
+                {
+                    double bx[IT], by[IT];
+#pragma unroll
+                    for(int it = 0; it < IT; ++it) { const int col = itt[it]; bx[it] = s_B[ip[it] * BP + col]; by[it] = s_B[iq[it] * BP + col]; }
+#pragma unroll
+                    for(int it = 0; it < IT; ++it) {
+                        if(ip[it] != iq[it]) {
+                            const int col = itt[it];
+                            s_B[ip[it] * BP + col] = ics[it] * bx[it] - isn[it] * by[it]; s_B[iq[it] * BP + col] = isn[it] * bx[it] + ics[it] * by[it];
+                        }
                     }
                 }
                 __syncthreads();
