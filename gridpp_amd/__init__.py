@@ -300,47 +300,117 @@ class Grid(_PointSet):
 
 
 # ---- structure functions (include/gridpp.h:2069-2343, src/api/structure.cpp) -----------------------
+_SK = dict(Barnes=0, Cressman=1, Soar=2, Toar=3, Powerlaw=4, Linear=5)
+_ST_HAS_LOC, _ST_CV = 1, 2
+
+
 class StructureFunction:
-    pass
+    """Base of the scalar structure functions; owns the gpp_structure descriptor handed to the C-ABI."""
+    _s = None
 
-
-class BarnesStructure(StructureFunction):
-    """Scalar form BarnesStructure(h, v=0, w=0, hmax=MV) (src/api/structure.cpp:143-167)."""
-
-    def __init__(self, h, v=0, w=0, hmax=MV):
-        if not np.isscalar(h):
-            raise RuntimeError("the spatially varying BarnesStructure(grid, h, v, w) is outside the GPU hot path (SURVEY 8f)")
-        # structure.cpp:145-152
-        for name, val in (("v", v), ("w", w)):
-            if not is_valid(val) or val < 0:
-                raise ValueError("%s must be >= 0" % name)
-        mr = C.c_float(0)
-        check(lib().gpp_barnes_min_rho(float(h), float(hmax), C.byref(mr)))
-        self._s = _capi.gpp_structure(0, float(h), float(v), float(w), mr.value)
+    def _copy_struct(self):
+        t = _capi.gpp_structure()
+        C.memmove(C.byref(t), C.byref(self._s), C.sizeof(t))
+        return t
 
     def localization_distance(self, p=None):
         d = C.c_float(0)
-        check(lib().gpp_barnes_localization_distance(C.byref(self._s), C.byref(d)))
+        check(lib().gpp_structure_localization_distance(C.byref(self._s), C.byref(d)))
         return d.value
 
-    def corr(self, p1, p2):
+    def _corr(self, p1, p2, background):
         if isinstance(p2, (list, tuple)):
-            return np.array([self.corr(p1, q) for q in p2], np.float32)
+            return np.array([self._corr(p1, q, background) for q in p2], np.float32)
         r = C.c_float(0)
-        check(lib().gpp_barnes_corr(C.byref(self._s), p1._five(), p2._five(), C.byref(r)))
+        check(lib().gpp_structure_corr(C.byref(self._s), p1._five(), p2._five(), int(background), C.byref(r)))
         return r.value
 
-    corr_background = corr
+    def corr(self, p1, p2):
+        return self._corr(p1, p2, 0)
+
+    def corr_background(self, p1, p2):
+        return self._corr(p1, p2, 1)
 
     def clone(self):
-        c = BarnesStructure.__new__(BarnesStructure)
-        c._s = _capi.gpp_structure(self._s.kind, self._s.h, self._s.v, self._s.w, self._s.min_rho)
+        c = StructureFunction.__new__(type(self))
+        c._s = self._copy_struct()
         return c
 
 
+def _scalar_structure(obj, kind, h, v, w, hmax):
+    if not np.isscalar(h):
+        raise RuntimeError("the spatially varying structure functions (grid, h, v, w) are outside the GPU hot path (SURVEY 8f)")
+    for name, val in (("v", v), ("w", w)):   # e.g. structure.cpp:147-152
+        if not is_valid(val) or val < 0:
+            raise ValueError("%s must be >= 0" % name)
+    mr = C.c_float(0)
+    check(lib().gpp_structure_min_rho(kind, float(h), float(hmax), C.byref(mr)))
+    obj._s = _capi.gpp_structure(kind, float(h), float(v), float(w), mr.value, 0, 0, 0.0, 0.0, 0)
+
+
+class BarnesStructure(StructureFunction):
+    """BarnesStructure(h, v=0, w=0, hmax=MV) (src/api/structure.cpp:143-167)"""
+
+    def __init__(self, h, v=0, w=0, hmax=MV):
+        _scalar_structure(self, _SK["Barnes"], h, v, w, hmax)
+
+
+class CressmanStructure(StructureFunction):
+    """CressmanStructure(h, v=0, w=0) (src/api/structure.cpp:287-312)"""
+
+    def __init__(self, h, v=0, w=0):
+        if not is_valid(h) or h < 0:   # StructureFunction(localization_distance) base ctor, structure.cpp:7-12
+            raise ValueError("Structure function initizlied with invalid localization distance")
+        _scalar_structure(self, _SK["Cressman"], h, v, w, MV)
+
+
+class SoarStructure(StructureFunction):
+    def __init__(self, h, v=0, w=0, hmax=MV):   # structure.cpp:317-341
+        _scalar_structure(self, _SK["Soar"], h, v, w, hmax)
+
+
+class ToarStructure(StructureFunction):
+    def __init__(self, h, v=0, w=0, hmax=MV):   # structure.cpp:467-491
+        _scalar_structure(self, _SK["Toar"], h, v, w, hmax)
+
+
+class PowerlawStructure(StructureFunction):
+    def __init__(self, h, v=0, w=0, hmax=MV):   # structure.cpp:618-642
+        _scalar_structure(self, _SK["Powerlaw"], h, v, w, hmax)
+
+
+class LinearStructure(StructureFunction):
+    def __init__(self, h, v=0, w=0, hmax=MV):   # structure.cpp:765-789
+        _scalar_structure(self, _SK["Linear"], h, v, w, hmax)
+
+
+class MultipleStructure(StructureFunction):
+    """MultipleStructure(structure_h, structure_v, structure_w) (src/api/structure.cpp:90-138): the horizontal factor
+    (and the localization distance) comes from structure_h, the vertical one from structure_v, the land-area-fraction
+    one from structure_w."""
+
+    def __init__(self, structure_h, structure_v, structure_w):
+        sh, sv, sw = structure_h._s, structure_v._s, structure_w._s
+        kv = sv.kind_v - 1 if sv.kind_v else sv.kind
+        kw = sw.kind_w - 1 if sw.kind_w else sw.kind
+        loc = structure_h.localization_distance()
+        self._s = _capi.gpp_structure(sh.kind, sh.h, sv.v, sw.w, sh.min_rho, kv + 1, kw + 1, loc, 0.0, _ST_HAS_LOC)
+
+
+class CrossValidation(StructureFunction):
+    """CrossValidation(structure, dist) (src/api/structure.cpp:910-944)"""
+
+    def __init__(self, structure, dist):
+        if not is_valid(dist) or dist < 0:
+            raise ValueError("Invalid 'dist' in CrossValidation structure")
+        self._s = structure._copy_struct()
+        self._s.flags |= _ST_CV
+        self._s.cv_dist = float(dist)
+
+
 def _structure(s):
-    if not isinstance(s, BarnesStructure):
-        raise RuntimeError("only BarnesStructure (scalar) is implemented on the GPU hot path")
+    if not isinstance(s, StructureFunction) or s._s is None:
+        raise RuntimeError("structure must be one of the gridpp_amd structure functions")
     return C.byref(s._s)
 
 

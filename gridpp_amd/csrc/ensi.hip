@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         const unsigned orig_i = (lane < n) ? origs[lane][l] : 0u;
         float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 1);
         if(lane < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
-        const float rho = d_barnes_corr(cx, cy, cz, ce, cl, o0.x, o0.y, o0.z, o0.w, o1.x, a.s.h, a.s.v, a.s.w, a.s.R);   // :227
+        const float rho = d_corr(a.s.st, cx, cy, cz, ce, cl, o0.x, o0.y, o0.z, o0.w, o1.x, true);   // :227
         const float sig2 = o1.w * o1.w;                                    // float product (:300)
         const double D = (double)rho / (double)sig2;                       // Rinv(i,i)
         const double sD = sqrt(D);
@@ -341,7 +341,6 @@ thread_local EnsiWorkspace g_ews;
 thread_local float g_ensi_ms = 0;
 }
 
-static float loc_dist_e(const gpp_structure* s) { return sqrtf(-2 * logf(s->min_rho)) * s->h; }
 
 extern "C" int gpp_ensi_last_kernel_ms(float* ms) {
     GPP_TRY
@@ -361,7 +360,6 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     if(bgrid->type != points->type)
         invalid("Both background and observations points must be of same coorindate type (lat/lon or x/y)");
     if(!st) invalid("structure is NULL");
-    if(st->kind != 0) runtime("only the scalar BarnesStructure runs on the GPU path");
     if(ne < 0) invalid("negative ensemble size");
     const int C = bgrid->n, S = points->n, E = ne;
     ensure_device();
@@ -420,7 +418,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.s.pgeo = ws.pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
     a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
-    a.s.h = st->h; a.s.v = st->v; a.s.w = st->w; a.s.R = loc_dist_e(st);
+    a.s.st = gpp_resolve_structure(st);
     a.s.max_points = max_points;
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
       const int kk = (max_points > 0 && max_points <= 32) ? max_points : 32;

@@ -86,8 +86,8 @@ gpp_obs_index* gpp_build_obs_index(gpp_points* pts) {
     return pts->obs_index;
 }
 
-__global__ void k_barnes_corr(float4 p1, float l1, float4 p2, float l2, float h, float v, float w, float R, float* out) {
-    out[0] = d_barnes_corr(p1.x, p1.y, p1.z, p1.w, l1, p2.x, p2.y, p2.z, p2.w, l2, h, v, w, R);
+__global__ void k_structure_corr(DevStructure st, float4 p1, float l1, float4 p2, float l2, int background, float* out) {
+    out[0] = d_corr(st, p1.x, p1.y, p1.z, p1.w, l1, p2.x, p2.y, p2.z, p2.w, l2, background != 0);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -125,7 +125,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
     return pos;
 }
 
-template <int N>
+template <int N, bool LU>
 __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
@@ -217,61 +217,144 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                 const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
                 const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
                 // matrix rows: corr(obs_i, obs_p) (oi.cpp:304-312); G rows: corr(cell, obs_p) (oi.cpp:250)
-                const float c = d_barnes_corr(px, py, pz, pe, pl, xp, yp, zp, ep, lp, a.s.h, a.s.v, a.s.w, a.s.R);
+                const float c = d_corr(a.s.st, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
                 colbuf[p][lane] = c;
                 const float dpf = (float)((double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p));
                 maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
             }
-            double row[N];
-            const bool used = lane < n || lane == N || is_g;
+            if constexpr(LU) {
+                // General (possibly non-symmetric or indefinite) system: the reference inverts P+R with LAPACK's pivoted
+                // LU (oi.cpp:315).  K = G (P+R)^-1  <=>  (P+R)^T k = g, so lane i holds row i of A^T = column i of A,
+                // the factorisation (partial pivoting, multipliers stored in place) is done once per observation set
+                // and every member cell costs one forward + one backward substitution.
+                double rowT[N];
 #pragma unroll
-            for(int p = 0; p < N; ++p) {
-                double v = 0.0;
-                if(p < n) {
-                    v = (double)colbuf[p][lane];
-                    if(lane == p) v += (double)o1.w;                                                   // lP + lR
-                    const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);       // lObs - lY
-                    if(lane == N) v = dp;
-                    if(!used) v = 0.0;
+                for(int p = 0; p < N; ++p) {
+                    double v = 0.0;
+                    if(p < n && lane < n) {
+                        v = (double)colbuf[lane][p];                       // A[p][lane]: computed by lane p for observation `lane`
+                        if(lane == p) v += (double)o1.w;
+                    }
+                    rowT[p] = v;
                 }
-                row[p] = v;
-            }
-            // right-looking Cholesky on rows-in-lanes; row N becomes L^-1 d, rows N+1.. become L^-1 g_m
+                const double dmine = (double)o1.y - (double)o1.z;         // d of observation `lane`
+                int mystep = 64;                                           // column this row became the pivot of
 #pragma unroll
-            for(int j = 0; j < N; ++j) {
-                if(j < n) {
-                    const double ajj = readlane_d(row[j], j);
-                    if(!(ajj > 0.0)) bad = true;
-                    double rs = __builtin_amdgcn_rsq(ajj);
-                    rs = rs * (1.5 - 0.5 * ajj * rs * rs);
-                    rs = rs * (1.5 - 0.5 * ajj * rs * rs);
-                    const double cj = row[j] * rs;
-                    row[j] = cj;
+                for(int j = 0; j < N; ++j) {
+                    if(j < n) {
+                        double av = (lane < n && mystep == 64) ? fabs(rowT[j]) : -1.0;
+                        int al = lane;
+                        for(int off = 32; off > 0; off >>= 1) {
+                            const double oav = __shfl_xor(av, off);
+                            const int oal = __shfl_xor(al, off);
+                            if(oav > av || (oav == av && oal < al)) { av = oav; al = oal; }
+                        }
+                        const int piv = __builtin_amdgcn_readfirstlane(al);
+                        if(!(av > 0.0)) bad = true;                        // exactly singular (arma::inv throws)
+                        const double pjj = readlane_d(rowT[j], piv);
+                        const bool elim = lane < n && mystep == 64 && lane != piv;
+                        const double f = elim ? rowT[j] / pjj : 0.0;
+                        if(lane == piv) mystep = j;
 #pragma unroll
-                    for(int p = j + 1; p < N; ++p) {
-                        const double lpj = readlane_d(cj, p);
-                        row[p] = __builtin_fma(-cj, lpj, row[p]);
+                        for(int p = j + 1; p < N; ++p) {
+                            const double pp = readlane_d(rowT[p], piv);
+                            rowT[p] = __builtin_fma(-f, pp, rowT[p]);
+                        }
+                        if(elim) rowT[j] = f;                              // multiplier in place of the eliminated entry
+                    }
+                }
+                unsigned long long mm = members;
+                while(mm) {
+                    const int ml = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const int mi2 = __popcll(members & ((1ull << ml) - 1ull));   // index of this member among the G rows
+                    const double g0 = (lane < n) ? (double)colbuf[lane][N + 1 + mi2] : 0.0;   // corr_background(cell, obs `lane`)
+                    double bvec = g0;
+#pragma unroll
+                    for(int j = 0; j < N; ++j) {                           // forward: L y = P g
+                        if(j < n) {
+                            const int piv = __builtin_ctzll(__ballot(mystep == j));
+                            const double bp = readlane_d(bvec, piv);
+                            if(lane < n && mystep > j) bvec = __builtin_fma(-rowT[j], bp, bvec);
+                        }
+                    }
+                    double inc = 0.0, a00 = 0.0;
+#pragma unroll
+                    for(int j = N - 1; j >= 0; --j) {                      // backward: U k = y
+                        if(j < n) {
+                            const int piv = __builtin_ctzll(__ballot(mystep == j));
+                            const double xj = readlane_d(bvec, piv) / readlane_d(rowT[j], piv);
+                            if(lane < n && mystep < j) bvec = __builtin_fma(-rowT[j], xj, bvec);
+                            inc = __builtin_fma(xj, readlane_d(dmine, j), inc);    // k . (lObs - lY)   (oi.cpp:316)
+                            a00 = __builtin_fma(xj, readlane_d(g0, j), a00);       // k . G             (oi.cpp:336)
+                        }
+                    }
+                    float increment = (float)inc;
+                    if(!a.allow_extrap) {
+                        if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                        else if(maxInc < 0 && increment > 0) increment = maxInc;
+                        else if(minInc < 0 && increment < minInc) increment = minInc;
+                        else if(minInc > 0 && increment < 0) increment = minInc;
+                    }
+                    const float bgm = readlane_f(bg, ml), bvm = readlane_f(bvar, ml);
+                    if(lane == 0) {
+                        s_res[wid][0][ml] = bgm + increment;
+                        s_res[wid][1][ml] = (float)((double)bvm * (1.0 - a00));
                     }
                 }
             }
-            double inc = 0.0, a00 = 0.0;
-#pragma unroll
-            for(int p = 0; p < N; ++p) {
-                const double tp = readlane_d(row[p], N);
-                inc = __builtin_fma(row[p], tp, inc);      // lGSR * (lObs - lY)   (oi.cpp:316)
-                a00 = __builtin_fma(row[p], row[p], a00);  // lGSR * lG^T          (oi.cpp:336)
-            }
-            if(is_g) {
-                float increment = (float)inc;   // oi.cpp:317
-                if(!a.allow_extrap) {           // oi.cpp:318-334
-                    if(maxInc > 0 && increment > maxInc) increment = maxInc;
-                    else if(maxInc < 0 && increment > 0) increment = maxInc;
-                    else if(minInc < 0 && increment < minInc) increment = minInc;
-                    else if(minInc > 0 && increment < 0) increment = minInc;
+            else {
+                double row[N];
+                const bool used = lane < n || lane == N || is_g;
+    #pragma unroll
+                for(int p = 0; p < N; ++p) {
+                    double v = 0.0;
+                    if(p < n) {
+                        v = (double)colbuf[p][lane];
+                        if(lane == p) v += (double)o1.w;                                                   // lP + lR
+                        const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);       // lObs - lY
+                        if(lane == N) v = dp;
+                        if(!used) v = 0.0;
+                    }
+                    row[p] = v;
                 }
-                s_res[wid][0][src] = cbg + increment;                      // oi.cpp:335
-                s_res[wid][1][src] = (float)((double)cbv * (1.0 - a00));   // oi.cpp:337
-            }
+                // right-looking Cholesky on rows-in-lanes; row N becomes L^-1 d, rows N+1.. become L^-1 g_m
+    #pragma unroll
+                for(int j = 0; j < N; ++j) {
+                    if(j < n) {
+                        const double ajj = readlane_d(row[j], j);
+                        if(!(ajj > 0.0)) bad = true;
+                        double rs = __builtin_amdgcn_rsq(ajj);
+                        rs = rs * (1.5 - 0.5 * ajj * rs * rs);
+                        rs = rs * (1.5 - 0.5 * ajj * rs * rs);
+                        const double cj = row[j] * rs;
+                        row[j] = cj;
+    #pragma unroll
+                        for(int p = j + 1; p < N; ++p) {
+                            const double lpj = readlane_d(cj, p);
+                            row[p] = __builtin_fma(-cj, lpj, row[p]);
+                        }
+                    }
+                }
+                double inc = 0.0, a00 = 0.0;
+    #pragma unroll
+                for(int p = 0; p < N; ++p) {
+                    const double tp = readlane_d(row[p], N);
+                    inc = __builtin_fma(row[p], tp, inc);      // lGSR * (lObs - lY)   (oi.cpp:316)
+                    a00 = __builtin_fma(row[p], row[p], a00);  // lGSR * lG^T          (oi.cpp:336)
+                }
+                if(is_g) {
+                    float increment = (float)inc;   // oi.cpp:317
+                    if(!a.allow_extrap) {           // oi.cpp:318-334
+                        if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                        else if(maxInc < 0 && increment > 0) increment = maxInc;
+                        else if(minInc < 0 && increment < minInc) increment = minInc;
+                        else if(minInc > 0 && increment < 0) increment = minInc;
+                    }
+                    s_res[wid][0][src] = cbg + increment;                      // oi.cpp:335
+                    s_res[wid][1][src] = (float)((double)cbv * (1.0 - a00));   // oi.cpp:337
+                }
+                    }
         }
         __builtin_amdgcn_wave_barrier();
         if(cnt > 0) { res_out = s_res[wid][0][lane]; res_var = s_res[wid][1][lane]; }
@@ -310,39 +393,67 @@ extern "C" int gpp_oi_last_stats(gpp_oi_stats* s) {
     GPP_CATCH
 }
 
-extern "C" int gpp_barnes_min_rho(float h, float hmax, float* min_rho) {
-    GPP_TRY
-    if(!min_rho) invalid("NULL");
-    // structure.cpp:143-159
-    if(is_valid(hmax) && hmax < 0) invalid("hmax must be >= 0");
-    if(!is_valid(h) || h < 0) invalid("h must be >= 0");
-    if(is_valid(hmax)) *min_rho = (float)std::exp(std::pow((double)(hmax / h), 2) / -2);
-    else *min_rho = 0.0013f;
-    return GPP_OK;
-    GPP_CATCH
+// ---- structure functions, host side (float semantics of the C++ overloads the reference gets) -------------------
+static float st_localization(int kind, float h, float min_rho) {
+    switch(kind) {
+        case GPP_SK_BARNES: return sqrtf(-2 * logf(min_rho)) * h;                                  // structure.cpp:280-282
+        case GPP_SK_CRESSMAN: return h;                                                            // :7-12,87-89
+        case GPP_SK_SOAR: { float lm = logf(min_rho); return (-lm + logf(-lm)) * h; }              // :454-459
+        case GPP_SK_TOAR: { float lm = logf(min_rho); float ll = logf(-logf(min_rho)); return (float)(((double)(-lm + ll) + 0.5 * ll) * h); }   // :604-610
+        case GPP_SK_POWERLAW: return sqrtf(2 * (1 - min_rho) / min_rho) * h;                       // :755-757
+        default: return 0;                                                                         // Linear :902-904
+    }
 }
-static float loc_dist(const gpp_structure* s) { return sqrtf(-2 * logf(s->min_rho)) * s->h; }   // structure.cpp:280-282
-static void check_structure(const gpp_structure* s) {
+static bool st_kind_ok(int k) { return k >= GPP_SK_BARNES && k <= GPP_SK_LINEAR; }
+DevStructure gpp_resolve_structure(const gpp_structure* s) {
     if(!s) invalid("structure is NULL");
-    if(s->kind != 0) throw Error{GPP_ERUNTIME, "only the scalar BarnesStructure runs on the GPU path"};
+    if(!st_kind_ok(s->kind)) runtime("unknown structure function kind");
+    const int kv = s->kind_v ? s->kind_v - 1 : s->kind, kw = s->kind_w ? s->kind_w - 1 : s->kind;
+    if(!st_kind_ok(kv) || !st_kind_ok(kw)) runtime("unknown structure function kind");
     if(!is_valid(s->h) || s->h < 0) invalid("h must be >= 0");
     if(!is_valid(s->v) || s->v < 0) invalid("v must be >= 0");
     if(!is_valid(s->w) || s->w < 0) invalid("w must be >= 0");
+    DevStructure d;
+    d.kh = s->kind; d.kv = kv; d.kw = kw;
+    d.h = s->h; d.v = s->v; d.w = s->w;
+    d.R = (s->flags & GPP_ST_HAS_LOC) ? s->loc : st_localization(s->kind, s->h, s->min_rho);
+    d.cv = (s->flags & GPP_ST_CV) ? 1 : 0;
+    d.cv_dist = s->cv_dist;
+    if(d.cv && (!is_valid(d.cv_dist) || d.cv_dist < 0)) invalid("Invalid 'dist' in CrossValidation structure");   // :912-913
+    return d;
 }
-extern "C" int gpp_barnes_localization_distance(const gpp_structure* s, float* dist) {
+extern "C" int gpp_structure_min_rho(int kind, float h, float hmax, float* min_rho) {
     GPP_TRY
-    check_structure(s);
+    if(!min_rho) invalid("NULL");
+    if(!st_kind_ok(kind)) runtime("unknown structure function kind");
+    if(kind != GPP_SK_CRESSMAN && is_valid(hmax) && hmax < 0) invalid("hmax must be >= 0");
+    if(!is_valid(h) || h < 0) invalid("h must be >= 0");
+    float r = 0.0013f;   // structure.cpp:5
+    if(is_valid(hmax)) switch(kind) {
+        case GPP_SK_BARNES: r = (float)std::exp(std::pow((double)(hmax / h), 2) / -2); break;                       // :154-155
+        case GPP_SK_SOAR: r = (1 + hmax / h) * expf(-hmax / h); break;                                                // :328-329
+        case GPP_SK_TOAR: r = (float)((1 + hmax / h + std::pow((double)(hmax / h), 2) / 3) * expf(-hmax / h)); break; // :478-479
+        case GPP_SK_POWERLAW: r = (float)(1 / (1 + 0.5 * std::pow((double)(hmax / h), 2))); break;                    // :629-630
+        default: break;
+    }
+    *min_rho = r;
+    return GPP_OK;
+    GPP_CATCH
+}
+static float loc_dist(const gpp_structure* s) { return gpp_resolve_structure(s).R; }
+extern "C" int gpp_structure_localization_distance(const gpp_structure* s, float* dist) {
+    GPP_TRY
     *dist = loc_dist(s);
     return GPP_OK;
     GPP_CATCH
 }
-extern "C" int gpp_barnes_corr(const gpp_structure* s, const float p1[5], const float p2[5], float* rho) {
+extern "C" int gpp_structure_corr(const gpp_structure* s, const float p1[5], const float p2[5], int background, float* rho) {
     GPP_TRY
-    check_structure(s);
+    DevStructure d = gpp_resolve_structure(s);
     DevBuf<float> out;
     out.get(1);
-    hipLaunchKernelGGL(k_barnes_corr, dim3(1), dim3(1), 0, stream(), make_float4(p1[0], p1[1], p1[2], p1[3]), p1[4],
-                       make_float4(p2[0], p2[1], p2[2], p2[3]), p2[4], s->h, s->v, s->w, loc_dist(s), out.p);
+    hipLaunchKernelGGL(k_structure_corr, dim3(1), dim3(1), 0, stream(), d, make_float4(p1[0], p1[1], p1[2], p1[3]), p1[4],
+                       make_float4(p2[0], p2[1], p2[2], p2[3]), p2[4], background, out.p);
     GPP_HIP(hipGetLastError());
     GPP_HIP(hipMemcpyAsync(rho, out.p, sizeof(float), hipMemcpyDeviceToHost, stream()));
     GPP_HIP(hipStreamSynchronize(stream()));
@@ -361,7 +472,6 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     if(!bgrid || !points) invalid("grid/points handle is NULL");
     if(bgrid->type != points->type)
         invalid("Both background and observations points must be of same coordinate type (lat/lon or x/y)");
-    check_structure(st);
     const int C = bgrid->n, S = points->n;
     if(C > 0 && (!background || !out)) invalid("background/out is NULL");
     if(S > 0 && (!obs || !obs_variance || !background_at_points)) invalid("observation arrays are NULL");
@@ -417,7 +527,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
     a.S = S; a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
-    a.s.h = st->h; a.s.v = st->v; a.s.w = st->w; a.s.R = loc_dist(st);
+    a.s.st = gpp_resolve_structure(st);
     a.s.max_points = max_points;
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
       const int kk = (max_points > 0 && max_points <= 32) ? max_points : 32;
@@ -427,14 +537,30 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     a.err = ws.err.p; a.counters = ws.counters.p;
 
     GPP_HIP(hipEventRecord(ws.e0, stream()));
-    hipLaunchKernelGGL(k_oi<N>, dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
-    GPP_HIP(hipGetLastError());
-    GPP_HIP(hipEventRecord(ws.e1, stream()));
-
+    // Cholesky needs a symmetric positive definite P+R: true for every kernel on distances and for the even vertical / laf
+    // kernels (Barnes, Powerlaw, Linear); Cressman / SOAR / TOAR factors on SIGNED elevation / laf differences make P
+    // non-symmetric (structure.cpp:35-64), and a truncated kernel can be indefinite -> pivoted LU like the reference.
+    auto odd = [](int k) { return k == GPP_SK_CRESSMAN || k == GPP_SK_SOAR || k == GPP_SK_TOAR; };
+    bool use_lu = (a.s.st.v != 0 && odd(a.s.st.kv)) || (a.s.st.w != 0 && odd(a.s.st.kw)) || getenv("GPP_OI_FORCE_LU");
     int err = 0;
     unsigned long long counters[4];
-    GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    GPP_HIP(hipMemcpyAsync(counters, ws.counters.p, sizeof(counters), hipMemcpyDeviceToHost, stream()));
+    for(int attempt = 0; attempt < 2; ++attempt) {
+        if(use_lu) hipLaunchKernelGGL((k_oi<N, true>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
+        else hipLaunchKernelGGL((k_oi<N, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
+        GPP_HIP(hipGetLastError());
+        GPP_HIP(hipEventRecord(ws.e1, stream()));
+        GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipMemcpyAsync(counters, ws.counters.p, sizeof(counters), hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipStreamSynchronize(stream()));
+        if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
+            use_lu = true;
+            g_stats.fallback_tiles = a.ntiles;
+            GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
+            GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 4, stream()));
+            continue;
+        }
+        break;
+    }
     f_out.finish(); f_var.finish();
     GPP_HIP(hipStreamSynchronize(stream()));
     float ms = 0;

@@ -22,6 +22,8 @@ struct gpp_obs_index {
 };
 
 gpp_obs_index* gpp_build_obs_index(gpp_points* pts);   // oi.hip
+struct DevStructure;
+DevStructure gpp_resolve_structure(const gpp_structure* s);   // oi.hip: validation + localization distance
 
 // -------------------------------------------------------------------------------------------
 // device helpers
@@ -78,6 +80,54 @@ __device__ __forceinline__ float d_barnes_corr(float x1, float y1, float z1, flo
     if(d_valid(l1) && d_valid(l2)) rho *= d_barnes_rho(l1 - l2, w);
     return rho;
 }
+// ---- generic structure functions (src/api/structure.cpp:26-86,90-138,287-944), scalar forms -------------------
+#define SK_BARNES 0
+#define SK_CRESSMAN 1
+#define SK_SOAR 2
+#define SK_TOAR 3
+#define SK_POWERLAW 4
+#define SK_LINEAR 5
+struct DevStructure {
+    int kh, kv, kw;       // kernel of the horizontal / vertical / land-area-fraction factor (MultipleStructure mixes them)
+    float h, v, w;        // scales
+    float R;              // localization distance (of the horizontal structure)
+    int cv;               // CrossValidation wrapper active
+    float cv_dist;
+};
+// exp(x) rounded to float32 for any sign of x (soar / toar use exp(float), structure.cpp:53,63)
+__device__ __forceinline__ float d_expf_cr(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float d_rho(const int kind, const float dist, const float length) {
+    if(kind == SK_BARNES) return d_barnes_rho(dist, length);
+    if(kind == SK_LINEAR) {                                     // structure.cpp:76-86 (length = min_corr)
+        if(!d_valid(length) || length < 0) return 1.0f;
+        if(!d_valid(dist)) return 0.0f;
+        float absdiff = fabsf(dist);
+        if(absdiff > 1) absdiff = 1;
+        return 1.0f - (1.0f - length) * absdiff;
+    }
+    if(!d_valid(length) || length == 0) return 1.0f;
+    if(!d_valid(dist)) return 0.0f;
+    if(kind == SK_CRESSMAN) {                                   // :35-44
+        if(dist >= length) return 0.0f;
+        return (length * length - dist * dist) / (length * length + dist * dist);
+    }
+    const float v = dist / length;
+    if(kind == SK_SOAR) return (1.0f + v) * d_expf_cr(-v);      // :46-54
+    if(kind == SK_TOAR) return (1.0f + v + (v * v) / 3.0f) * d_expf_cr(-v);   // :56-64
+    return (float)(1.0 / (1.0 + 0.5 * (double)v * (double)v));  // powerlaw :66-74
+}
+// corr(p1, p2) / corr_background(p1, p2) of a scalar (possibly Multiple / CrossValidation-wrapped) structure
+__device__ __forceinline__ float d_corr(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
+                                        float x2, float y2, float z2, float e2, float l2, const bool background) {
+    const float hdist = d_chord(x1, y1, z1, x2, y2, z2);
+    if(background && s.cv && hdist <= s.cv_dist) return 0.0f;   // structure.cpp:918-925
+    if(s.kh != SK_CRESSMAN && hdist > s.R) return 0.0f;         // :216-217 (Cressman has no cut, :300-312)
+    float rho = d_rho(s.kh, hdist, s.h);
+    if(d_valid(e1) && d_valid(e2)) rho *= d_rho(s.kv, e1 - e2, s.v);
+    if(d_valid(l1) && d_valid(l2)) rho *= d_rho(s.kw, l1 - l2, s.w);
+    return rho;
+}
+
 __device__ __forceinline__ double readlane_d(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -121,7 +171,7 @@ struct ScanArgs {
     const int* bin_start;
     int axis_a, axis_b, nbx, nby;
     float amin, bmin, inv_s;
-    float h, v, w, R;
+    DevStructure st;
     int K;                   // list capacity in use: min(max_points, N) (N if max_points == 0)
     int max_points;
     int q0;                  // half-width (in bins) of the phase-1 square of the candidate scan
@@ -146,10 +196,11 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
     int cnt = 0;
     overflow = false;
     truncated = false;
-    const float R = a.R;
+    const float R = a.st.R;
     const int K = a.K;
     const bool bounded = a.max_points > 0 && a.max_points <= N;
-    const float h2 = a.h * a.h;
+    const float h2 = a.st.h * a.st.h;
+    const bool prune = bounded && a.st.kh == SK_BARNES;   // rho <= rho_h(d) with the closed-form inverse of the Barnes kernel
     float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
     float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
     const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
@@ -192,9 +243,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
                         const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        float rho = d_barnes_rho(dist, a.h);
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
+                        float rho = (a.st.cv && dist <= a.st.cv_dist) ? 0.0f : d_rho(a.st.kh, dist, a.st.h);   // corr_background
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho(a.st.kv, ge - oe, a.st.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho(a.st.kw, gl - ol, a.st.w);
                         if(rho > 0.0f) {   // oi.cpp:253
                             const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
                             const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
@@ -215,7 +266,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
                                 }
                             }
                             else overflow = true;   // more than N usable observations requested
-                            if(bounded && cnt == K) {
+                            if(prune && cnt == K) {
                                 const float wr = __uint_as_float((unsigned)(wkey >> 32));
                                 thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
                             }
@@ -228,9 +279,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {
                         const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        float rho = d_barnes_rho(dist, a.h);
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_barnes_rho(ge - oe, a.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_barnes_rho(gl - ol, a.w);
+                        float rho = (a.st.cv && dist <= a.st.cv_dist) ? 0.0f : d_rho(a.st.kh, dist, a.st.h);   // corr_background
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho(a.st.kv, ge - oe, a.st.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho(a.st.kw, gl - ol, a.st.w);
                         if(rho > 0.0f) truncated = true;
                     }
                 }

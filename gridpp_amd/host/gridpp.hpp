@@ -145,23 +145,50 @@ class Grid {
     CoordinateType mType = Geodetic;
 };
 
+// ---- structure functions (include/gridpp.h:2069-2343), scalar forms -------------------------------------------
 class StructureFunction {
   public:
     virtual ~StructureFunction() {}
-    virtual const gpp_structure* c_struct() const = 0;
-};
-class BarnesStructure : public StructureFunction {
-  public:
-    BarnesStructure(float h, float v = 0, float w = 0, float hmax = MV) {   // src/api/structure.cpp:143-167
+    const gpp_structure* c_struct() const { return &mS; }
+    float localization_distance() const { float d; detail::check(gpp_structure_localization_distance(&mS, &d)); return d; }
+  protected:
+    StructureFunction() { mS = gpp_structure(); }
+    void init(int kind, float h, float v, float w, float hmax) {
         if(!is_valid(v) || v < 0) throw std::invalid_argument("v must be >= 0");
         if(!is_valid(w) || w < 0) throw std::invalid_argument("w must be >= 0");
-        mS.kind = 0; mS.h = h; mS.v = v; mS.w = w;
-        detail::check(gpp_barnes_min_rho(h, hmax, &mS.min_rho));
+        mS = gpp_structure();
+        mS.kind = kind; mS.h = h; mS.v = v; mS.w = w;
+        detail::check(gpp_structure_min_rho(kind, h, hmax, &mS.min_rho));
     }
-    float localization_distance() const { float d; detail::check(gpp_barnes_localization_distance(&mS, &d)); return d; }
-    const gpp_structure* c_struct() const override { return &mS; }
-  private:
     gpp_structure mS;
+};
+class BarnesStructure : public StructureFunction { public: BarnesStructure(float h, float v = 0, float w = 0, float hmax = MV) { init(GPP_SK_BARNES, h, v, w, hmax); } };
+class CressmanStructure : public StructureFunction { public: CressmanStructure(float h, float v = 0, float w = 0) { init(GPP_SK_CRESSMAN, h, v, w, MV); } };
+class SoarStructure : public StructureFunction { public: SoarStructure(float h, float v = 0, float w = 0, float hmax = MV) { init(GPP_SK_SOAR, h, v, w, hmax); } };
+class ToarStructure : public StructureFunction { public: ToarStructure(float h, float v = 0, float w = 0, float hmax = MV) { init(GPP_SK_TOAR, h, v, w, hmax); } };
+class PowerlawStructure : public StructureFunction { public: PowerlawStructure(float h, float v = 0, float w = 0, float hmax = MV) { init(GPP_SK_POWERLAW, h, v, w, hmax); } };
+class LinearStructure : public StructureFunction { public: LinearStructure(float h, float v = 0, float w = 0, float hmax = MV) { init(GPP_SK_LINEAR, h, v, w, hmax); } };
+class MultipleStructure : public StructureFunction {   // src/api/structure.cpp:90-138
+  public:
+    MultipleStructure(const StructureFunction& sh, const StructureFunction& sv, const StructureFunction& sw) {
+        const gpp_structure *h = sh.c_struct(), *v = sv.c_struct(), *w = sw.c_struct();
+        mS = *h;
+        mS.v = v->v; mS.w = w->w;
+        mS.kind_v = (v->kind_v ? v->kind_v - 1 : v->kind) + 1;
+        mS.kind_w = (w->kind_w ? w->kind_w - 1 : w->kind) + 1;
+        mS.loc = sh.localization_distance();
+        mS.flags = GPP_ST_HAS_LOC;
+        mS.cv_dist = 0;
+    }
+};
+class CrossValidation : public StructureFunction {     // src/api/structure.cpp:910-944
+  public:
+    CrossValidation(const StructureFunction& structure, float dist) {
+        if(!is_valid(dist) || dist < 0) throw std::invalid_argument("Invalid 'dist' in CrossValidation structure");
+        mS = *structure.c_struct();
+        mS.flags |= GPP_ST_CV;
+        mS.cv_dist = dist;
+    }
 };
 
 // ---- optimal interpolation (include/gridpp.h:162-248) -------------------------------------------------

@@ -99,17 +99,37 @@ int gpp_points_nearest_neighbour(gpp_points* p, const float* qlats, const float*
  * values/out follow `mem`. */
 int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* out, int mem);
 
-/* ---- Barnes structure function (src/api/structure.cpp:143-282) ----------- */
+/* ---- structure functions (src/api/structure.cpp) -----------------------------
+ * Scalar forms of BarnesStructure, CressmanStructure, SoarStructure, ToarStructure,
+ * PowerlawStructure, LinearStructure (structure.cpp:143-167,287-299,317-341,467-491,
+ * 618-642,765-789), MultipleStructure (:90-138: horizontal / vertical / laf factors taken
+ * from three structures) and the CrossValidation wrapper (:910-944).  The spatially
+ * varying forms (per-grid-point h, v, w) are not on the GPU path yet. */
+#define GPP_SK_BARNES 0
+#define GPP_SK_CRESSMAN 1
+#define GPP_SK_SOAR 2
+#define GPP_SK_TOAR 3
+#define GPP_SK_POWERLAW 4
+#define GPP_SK_LINEAR 5
+#define GPP_ST_HAS_LOC 1   /* `loc` holds the localization distance (else derived from kind, h, min_rho) */
+#define GPP_ST_CV 2        /* CrossValidation: corr_background = 0 within cv_dist */
 typedef struct gpp_structure {
-    int kind;        /* 0 = BarnesStructure(h, v, w, hmax) scalar form */
-    float h, v, w;   /* length scales: horizontal [m], vertical [m], land-area-fraction */
-    float min_rho;   /* m_min_rho (structure.cpp:156-159); see gpp_barnes_min_rho */
+    int kind;        /* kernel of the horizontal factor (GPP_SK_*) */
+    float h, v, w;   /* scales: horizontal [m], vertical [m], land-area-fraction */
+    float min_rho;   /* m_min_rho of the horizontal structure; see gpp_structure_min_rho */
+    int kind_v;      /* kernel of the vertical factor + 1; 0 = same as `kind` (MultipleStructure sets these) */
+    int kind_w;      /* kernel of the laf factor + 1;      0 = same as `kind` */
+    float loc;       /* localization distance if flags & GPP_ST_HAS_LOC */
+    float cv_dist;   /* CrossValidation distance if flags & GPP_ST_CV */
+    int flags;
 } gpp_structure;
-int gpp_barnes_min_rho(float h, float hmax /* NaN: default 0.0013 */, float* min_rho);
-int gpp_barnes_localization_distance(const gpp_structure* s, float* dist);   /* structure.cpp:271-282 */
-/* BarnesStructure::corr (structure.cpp:185-230) for one pair of points given as
- * (x, y, z, elev, laf) -- runs the same device code as the OI kernel */
-int gpp_barnes_corr(const gpp_structure* s, const float p1[5], const float p2[5], float* rho);
+/* m_min_rho of the scalar constructors from hmax (NaN: default 0.0013); validates h >= 0, hmax >= 0 */
+int gpp_structure_min_rho(int kind, float h, float hmax, float* min_rho);
+/* StructureFunction::localization_distance (structure.cpp:87-89,271-282,454-459,604-610,755-757,902-904) */
+int gpp_structure_localization_distance(const gpp_structure* s, float* dist);
+/* corr (background = 0) / corr_background (background = 1) for one pair of points given as
+ * (x, y, z, elev, laf) -- runs the same device code as the OI kernels */
+int gpp_structure_corr(const gpp_structure* s, const float p1[5], const float p2[5], int background, float* rho);
 
 /* ---- optimal interpolation ------------------------------------------------
  * replaces gridpp::optimal_interpolation_full (src/api/oi.cpp:138-341, Points

@@ -124,6 +124,77 @@ float orc_barnes_corr(float x1, float y1, float z1, float e1, float l1,
 }
 
 /* ------------------------------------------------------------------------ */
+/* generic structure functions: src/api/structure.cpp:26-86 (rho kernels),     */
+/* :90-138 (MultipleStructure), :287-312 (Cressman), :317-459 (SOAR), :467-612 */
+/* (TOAR), :618-759 (Powerlaw), :765-904 (Linear), :910-944 (CrossValidation). */
+/* Scalar forms only.  float/double follow the C++ overloads the reference     */
+/* gets with <math.h> in scope (exp(float) -> expf, abs(float) -> fabsf).       */
+/* ------------------------------------------------------------------------ */
+enum { SK_BARNES = 0, SK_CRESSMAN = 1, SK_SOAR = 2, SK_TOAR = 3, SK_POWERLAW = 4, SK_LINEAR = 5 };
+typedef struct {
+    int kh, kv, kw;      /* kernel of the horizontal / vertical / laf factor */
+    float h, v, w;       /* scales */
+    float loc;           /* localization distance of the horizontal structure */
+    int cv; float cv_dist;   /* CrossValidation */
+} orc_struct;
+
+float orc_rho(int kind, float dist, float length) {
+    if(kind == SK_LINEAR) {                                   /* structure.cpp:76-86 */
+        if(!orc_valid(length) || length < 0) return 1;
+        if(!orc_valid(dist)) return 0;
+        float absdiff = fabsf(dist);
+        if(absdiff > 1) absdiff = 1;
+        return (1 - (1 - length) * absdiff);
+    }
+    if(!orc_valid(length) || length == 0) return 1;
+    if(!orc_valid(dist)) return 0;
+    if(kind == SK_BARNES) { float v = dist / length; return (float)exp(-0.5 * v * v); }
+    if(kind == SK_CRESSMAN) {                                 /* :35-44 */
+        if(dist >= length) return 0;
+        return (length * length - dist * dist) / (length * length + dist * dist);
+    }
+    float v = dist / length;
+    if(kind == SK_SOAR) return (1 + v) * expf(-v);            /* :46-54 */
+    if(kind == SK_TOAR) return (1 + v + (v * v) / 3) * expf(-v);   /* :56-64 */
+    if(kind == SK_POWERLAW) return (float)(1 / (1 + 0.5 * v * v)); /* :66-74 */
+    return NAN;
+}
+/* m_min_rho of the scalar constructors (:154-157,328-331,478-481,629-632,776-779) */
+float orc_structure_min_rho(int kind, float h, float hmax) {
+    if(!orc_valid(hmax) || kind == SK_LINEAR || kind == SK_CRESSMAN) return 0.0013f;
+    if(kind == SK_BARNES) return (float)exp(pow((double)(hmax / h), 2) / -2);
+    if(kind == SK_SOAR) return (1 + hmax / h) * expf(-hmax / h);
+    if(kind == SK_TOAR) return (float)((1 + hmax / h + pow((double)(hmax / h), 2) / 3) * expf(-hmax / h));
+    if(kind == SK_POWERLAW) return (float)(1 / (1 + 0.5 * pow((double)(hmax / h), 2)));
+    return 0.0013f;
+}
+/* localization_distance(h) (:280-282, 7-12 [Cressman: base class, = h], 454-459, 604-610, 755-757, 902-904) */
+float orc_structure_localization_distance(int kind, float h, float min_rho) {
+    if(kind == SK_BARNES) return sqrtf(-2 * logf(min_rho)) * h;
+    if(kind == SK_CRESSMAN) return h;
+    if(kind == SK_SOAR) { float lm = logf(min_rho); return (-lm + logf(-lm)) * h; }
+    if(kind == SK_TOAR) { float lm = logf(min_rho); float ll = logf(-logf(min_rho)); return (float)(((double)(-lm + ll) + 0.5 * ll) * h); }
+    if(kind == SK_POWERLAW) return sqrtf(2 * (1 - min_rho) / min_rho) * h;
+    return 0;
+}
+/* corr / corr_background of a (Multiple / CrossValidation-wrapped) scalar structure */
+float orc_corr_g(const orc_struct* s, float x1, float y1, float z1, float e1, float l1,
+                 float x2, float y2, float z2, float e2, float l2, int background) {
+    float hdist = orc_straight_distance(x1, y1, z1, x2, y2, z2);
+    if(background && s->cv && hdist <= s->cv_dist) return 0;           /* :918-925 */
+    if(s->kh != SK_CRESSMAN && hdist > s->loc) return 0;               /* e.g. :216-217; Cressman has no cut (:300-312) */
+    float rho = orc_rho(s->kh, hdist, s->h);
+    if(orc_valid(e1) && orc_valid(e2)) rho *= orc_rho(s->kv, e1 - e2, s->v);
+    if(orc_valid(l1) && orc_valid(l2)) rho *= orc_rho(s->kw, l1 - l2, s->w);
+    return rho;
+}
+float orc_corr_generic(int kh, int kv, int kw, float h, float v, float w, float loc, int cv, float cv_dist, int background,
+                       float x1, float y1, float z1, float e1, float l1, float x2, float y2, float z2, float e2, float l2) {
+    orc_struct s = {kh, kv, kw, h, v, w, loc, cv, cv_dist};
+    return orc_corr_g(&s, x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, background);
+}
+
+/* ------------------------------------------------------------------------ */
 /* radius / nearest-neighbour search: src/api/kdtree.cpp:39-106,241-270       */
 /* ------------------------------------------------------------------------ */
 /* strictly-inside box test (kdtree.cpp:46,53: index::within) then
@@ -351,6 +422,81 @@ int orc_oi_full(int nY,
                              pobs, obs_variance, pbackground, bvariance_at_points, h, v, w, min_rho,
                              max_points, allow_extrapolation, out, out_var);
 }
+/* ------------------------------------------------------------------------ */
+/* optimal_interpolation_full with a generic scalar structure (same loop as   */
+/* orc_oi_full_range; P is filled with corr(obs_i, obs_j) and may be           */
+/* non-symmetric, e.g. SOAR/TOAR/Cressman vertical factors on signed           */
+/* elevation differences, so the general inverse is what matters)              */
+/* ------------------------------------------------------------------------ */
+int orc_oi_full_generic(int nY,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* background, const float* bvariance,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* obs_variance, const float* pbackground, const float* bvariance_at_points,
+                int kh, int kv, int kw, float h, float v, float w, float loc, int cv, float cv_dist,
+                int max_points, int allow_extrapolation, float* out, float* out_var) {
+    if(max_points < 0) return ORC_EINVAL;
+    orc_struct st = {kh, kv, kw, h, v, w, loc, cv, cv_dist};
+    for(int y = 0; y < nY; y++) { out[y] = background[y]; out_var[y] = bvariance[y]; }
+    if(nS == 0) return ORC_OK;
+    float* pratios = (float*)malloc(sizeof(float) * nS);
+    for(int s = 0; s < nS; s++) pratios[s] = obs_variance[s] / bvariance_at_points[s];
+    orc_pair* work = (orc_pair*)malloc(sizeof(orc_pair) * nS);
+    int rc = ORC_OK;
+    for(int y = 0; y < nY && rc == ORC_OK; y++) {
+        if(!orc_valid(background[y])) continue;
+        int n = 0;
+        for(int s = 0; s < nS; s++) {
+            if(!orc_in_radius(gx[y], gy[y], gz[y], ox[s], oy[s], oz[s], loc, 1)) continue;
+            float rho = orc_corr_g(&st, gx[y], gy[y], gz[y], gelev[y], glaf[y], ox[s], oy[s], oz[s], oelev[s], olaf[s], 1);
+            if(!orc_valid(pobs[s]) || !orc_valid(pbackground[s])) continue;
+            if(rho > 0) { work[n].rho = rho; work[n].idx = s; n++; }
+        }
+        if(max_points > 0 && n > max_points) { qsort(work, n, sizeof(orc_pair), orc_pair_cmp); n = max_points; }
+        int lS = n;
+        if(lS == 0) continue;
+        double* A = (double*)malloc(sizeof(double) * lS * lS);
+        double* d = (double*)malloc(sizeof(double) * lS);
+        double* G = (double*)malloc(sizeof(double) * lS);
+        for(int i = 0; i < lS; i++) {
+            int si = work[i].idx;
+            d[i] = (double)pobs[si] - (double)pbackground[si];
+            G[i] = (double)work[i].rho;
+            for(int j = 0; j < lS; j++) {
+                int sj = work[j].idx;
+                A[i * lS + j] = (double)orc_corr_g(&st, ox[si], oy[si], oz[si], oelev[si], olaf[si],
+                                                  ox[sj], oy[sj], oz[sj], oelev[sj], olaf[sj], 0);
+            }
+            A[i * lS + i] += (double)pratios[si];
+        }
+        if(orc_inv(A, lS) != ORC_OK) { rc = ORC_ESINGULAR; free(A); free(d); free(G); break; }
+        double dx = 0, a00 = 0; float maxInc = 0, minInc = 0;
+        for(int j = 0; j < lS; j++) {
+            double gsr = 0;
+            for(int i = 0; i < lS; i++) gsr += G[i] * A[i * lS + j];
+            dx += gsr * d[j];
+            a00 += gsr * G[j];
+        }
+        for(int j = 0; j < lS; j++) {
+            float dj = (float)d[j];
+            if(j == 0 || dj > maxInc) maxInc = dj;
+            if(j == 0 || dj < minInc) minInc = dj;
+        }
+        float increment = (float)dx;
+        if(!allow_extrapolation) {
+            if(maxInc > 0 && increment > maxInc) increment = maxInc;
+            else if(maxInc < 0 && increment > 0) increment = maxInc;
+            else if(minInc < 0 && increment < minInc) increment = minInc;
+            else if(minInc > 0 && increment < 0) increment = minInc;
+        }
+        out[y] = background[y] + increment;
+        out_var[y] = (float)((double)bvariance[y] * (1 - a00));
+        free(A); free(d); free(G);
+    }
+    free(pratios); free(work);
+    return rc;
+}
+
 /* Diagnostic for parity tests: the selected observation indices of one cell
  * (in selection order) and the gap between the last kept and first dropped rho
  * (0 => the top-max_points cut straddles an exact float tie, where the

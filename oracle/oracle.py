@@ -107,6 +107,61 @@ class Barnes:
                                            self.h, self.v, self.w, self.localization_distance()))
 
 
+class Struct:
+    """Generic scalar structure (Barnes/Cressman/Soar/Toar/Powerlaw/Linear kernels, Multiple mix, CrossValidation)."""
+    KINDS = dict(Barnes=0, Cressman=1, Soar=2, Toar=3, Powerlaw=4, Linear=5)
+
+    def __init__(self, kind, h, v=0.0, w=0.0, hmax=float("nan")):
+        L = lib()
+        L.orc_structure_min_rho.restype = C.c_float
+        L.orc_structure_localization_distance.restype = C.c_float
+        k = self.KINDS[kind] if isinstance(kind, str) else kind
+        self.kh = self.kv = self.kw = k
+        self.h, self.v, self.w = float(h), float(v), float(w)
+        self.min_rho = float(L.orc_structure_min_rho(C.c_int(k), C.c_float(h), C.c_float(hmax)))
+        self.loc = float(L.orc_structure_localization_distance(C.c_int(k), C.c_float(h), C.c_float(self.min_rho)))
+        self.cv, self.cv_dist = 0, 0.0
+
+    @staticmethod
+    def multiple(sh, sv, sw):
+        m = Struct(sh.kh, sh.h)
+        m.kh, m.kv, m.kw = sh.kh, sv.kv, sw.kw
+        m.h, m.v, m.w, m.min_rho, m.loc = sh.h, sv.v, sw.w, sh.min_rho, sh.loc
+        return m
+
+    def cross_validation(self, dist):
+        import copy
+        c = copy.copy(self)
+        c.cv, c.cv_dist = 1, float(dist)
+        return c
+
+    def localization_distance(self):
+        return self.loc
+
+    def corr(self, p1, p2, background=False):
+        L = lib()
+        L.orc_corr_generic.restype = C.c_float
+        return float(L.orc_corr_generic(C.c_int(self.kh), C.c_int(self.kv), C.c_int(self.kw), C.c_float(self.h), C.c_float(self.v),
+                                        C.c_float(self.w), C.c_float(self.loc), C.c_int(self.cv), C.c_float(self.cv_dist),
+                                        C.c_int(int(background)), *[C.c_float(float(t)) for t in p1], *[C.c_float(float(t)) for t in p2]))
+
+
+def oi_full_generic(g, background, bvariance, p, obs, obs_variance, pbackground, bvariance_at_points, st, max_points,
+                    allow_extrapolation=True):
+    background, bvariance = _f(background).ravel(), _f(bvariance).ravel()
+    obs, obs_variance, pbackground, bvp = _f(obs), _f(obs_variance), _f(pbackground), _f(bvariance_at_points)
+    out = np.empty(g.n, np.float32)
+    var = np.empty(g.n, np.float32)
+    rc = lib().orc_oi_full_generic(C.c_int(g.n), g.x.ctypes, g.y.ctypes, g.z.ctypes, g.elevs.ctypes, g.lafs.ctypes,
+                                   background.ctypes, bvariance.ctypes, C.c_int(p.n), p.x.ctypes, p.y.ctypes, p.z.ctypes,
+                                   p.elevs.ctypes, p.lafs.ctypes, obs.ctypes, obs_variance.ctypes, pbackground.ctypes, bvp.ctypes,
+                                   C.c_int(st.kh), C.c_int(st.kv), C.c_int(st.kw), C.c_float(st.h), C.c_float(st.v), C.c_float(st.w),
+                                   C.c_float(st.loc), C.c_int(st.cv), C.c_float(st.cv_dist), C.c_int(max_points),
+                                   C.c_int(1 if allow_extrapolation else 0), out.ctypes, var.ctypes)
+    _check(rc)
+    return out, var
+
+
 def oi_full(g, background, bvariance, p, obs, obs_variance, pbackground, bvariance_at_points,
             st, max_points, allow_extrapolation=True, y0=0, y1=None):
     background, bvariance = _f(background).ravel(), _f(bvariance).ravel()

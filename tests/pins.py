@@ -387,4 +387,69 @@ def pin_util(g, G):
     assert not g.is_valid(np.nan)
 
 
+def pin_structures(g, G):
+    """tests/test_barnes_structure.py:8-33 (Cressman, CrossValidation rows) and tests/test_structure.py:63-154"""
+    import pytest
+    e = G["structures"]
+    x = e["x"]
+    barnes = g.BarnesStructure(e["h"])
+    table = [(g.CressmanStructure(e["h"]), e["cressman"], False), (g.CrossValidation(barnes, e["cv_dist"]), e["cv"], True)]
+    for structure, corr, is_cv in table:
+        for xi, c in zip(x, corr):
+            p1 = g.Point(0, 0, 0, 0, g.Cartesian)
+            p2 = g.Point(xi, 0, 0, 0, g.Cartesian)
+            funcs = [structure.corr_background] if is_cv else [structure.corr, structure.corr_background]
+            for f in funcs:
+                assert abs(f(p1, p2) - c) < 1e-7, (type(structure).__name__, xi, f(p1, p2), c)
+                assert abs(f(p2, p1) - c) < 1e-7
+    for dist in (-1, np.nan):
+        with pytest.raises(Exception):
+            g.CrossValidation(barnes, dist)
+    # MultipleStructure (tests/test_structure.py:63-91)
+    s = g.MultipleStructure(g.CressmanStructure(2000, 2000, 2000), g.CressmanStructure(200, 200, 200), g.CressmanStructure(2, 2, 2))
+    p0 = g.Point(0, 0, 0, 0, g.Cartesian)
+    for args, expo in (((1000, 0, 0, 0), 1), ((0, 0, 100, 0), 1), ((0, 0, 0, 1), 1), ((1000, 0, 100, 1), 3)):
+        assert abs(s.corr(p0, g.Point(*args, g.Cartesian)) - 0.6 ** expo) < 1e-6
+    # corr(vec) through OI (tests/test_structure.py:93-124)
+    s = g.MultipleStructure(g.CressmanStructure(5000, 11, 22), g.CressmanStructure(33, 200, 44), g.CressmanStructure(55, 66, 2))
+    assert abs(s.corr(p0, g.Point(0, 2500, 0, 0, g.Cartesian)) - 0.6) < 1e-6
+    assert abs(s.corr(p0, g.Point(0, 2500, 100, 1, g.Cartesian)) - 0.6 ** 3) < 1e-6
+    grid = g.Points([0, 0, 0], [0, 0, 0], [0, 0, 100], [0, 0, 1], g.Cartesian)
+    points = g.Points([0], [2500], [0], [0], g.Cartesian)
+    out = g.optimal_interpolation(grid, np.zeros(3), points, [1], [1], [0], s, 10)
+    np.testing.assert_array_almost_equal(out, [0.3, 0.3, 0.6 ** 3 / 2])
+    # clone keeps the correlations (tests/test_structure.py:135-154)
+    h, v, w = 850, 92, 0.44
+    structures = [g.BarnesStructure(h, v, w), g.CressmanStructure(h, v, w),
+                  g.MultipleStructure(g.BarnesStructure(1.3 * h, v, w), g.BarnesStructure(h, 1.3 * v, w), g.BarnesStructure(h, v, 1.3 * w)),
+                  g.CrossValidation(g.BarnesStructure(h, v, w), 1000)]
+    p1, p2 = g.Point(0, 0, 0, 0, g.Cartesian), g.Point(500, 0, 50, 0.25, g.Cartesian)
+    for st in structures:
+        c = st.clone()
+        assert st.corr(p1, p2) == c.corr(p1, p2)
+        assert st.corr_background(p1, p2) == c.corr_background(p1, p2)
+
+
+def pin_oi_cross_validation(g, G):
+    """tests/test_optimal_interpolation.py:127-152: the CrossValidation structure equals leave-one-out"""
+    y, x = np.meshgrid(np.arange(0, 3500, 500), np.arange(0, 3500, 500))
+    grid = g.Grid(y, x, np.zeros(x.shape), np.zeros(x.shape), g.Cartesian)
+    background = np.zeros(y.shape)
+    obs = np.array([10, 20, 30])
+    x_o = np.array([1000, 2000, 3000])
+    y_o = np.array([1000, 2000, 3000])
+    N = len(obs)
+    points = g.Points(y_o, x_o, np.zeros(N), np.zeros(N), g.Cartesian)
+    background_o = np.asarray(g.nearest(grid, points, background))
+    ratios = np.ones(N)
+    k = 0
+    ii = np.arange(N) != k
+    points_cv = g.Points(y_o[ii], x_o[ii], np.zeros(N - 1), np.zeros(N - 1), g.Cartesian)
+    structure = g.BarnesStructure(1000, 0)
+    structure_cv = g.CrossValidation(structure, 750)
+    analysis = g.optimal_interpolation(grid, background, points_cv, obs[ii], ratios[ii], background_o[ii], structure, 100)
+    analysis_cv = g.optimal_interpolation(points, background_o, points, obs, ratios, background_o, structure_cv, 100)
+    assert abs(float(np.asarray(g.nearest(grid, points, analysis))[k]) - float(np.asarray(analysis_cv)[k])) < 1e-6
+
+
 ALL_PINS = [v for k, v in sorted(globals().items()) if k.startswith("pin_")]

@@ -64,21 +64,74 @@ class Grid:
         return self.type
 
 
-class BarnesStructure:
+class _Structure:
+    kind = "Barnes"
+
     def __init__(self, h, v=0, w=0, hmax=np.nan):
         if not np.isfinite(h) or h < 0:
             raise ValueError("h")
         if np.isfinite(hmax) and hmax < 0:
             raise ValueError("hmax")
-        self.s = O.Barnes(h, v, w, hmax)
+        self.g = O.Struct(self.kind, h, v, w, hmax)
+        # the Barnes-only oracle entry points (orc_oi_full_range, EnSI) take (h, v, w, min_rho)
+        self.s = O.Barnes(h, v, w, hmax) if self.kind == "Barnes" else None
+
+    def _p(self, p):
+        return (p.x, p.y, p.z, p.elev, p.laf)
 
     def corr(self, p1, p2):
-        return self.s.corr((p1.x, p1.y, p1.z, p1.elev, p1.laf), (p2.x, p2.y, p2.z, p2.elev, p2.laf))
+        return self.g.corr(self._p(p1), self._p(p2), False)
 
-    corr_background = corr
+    def corr_background(self, p1, p2):
+        return self.g.corr(self._p(p1), self._p(p2), True)
 
     def localization_distance(self, p=None):
-        return self.s.localization_distance()
+        return self.g.localization_distance()
+
+    def clone(self):
+        import copy
+        return copy.copy(self)
+
+
+class BarnesStructure(_Structure):
+    kind = "Barnes"
+
+
+class CressmanStructure(_Structure):
+    kind = "Cressman"
+
+    def __init__(self, h, v=0, w=0):
+        _Structure.__init__(self, h, v, w)
+
+
+class SoarStructure(_Structure):
+    kind = "Soar"
+
+
+class ToarStructure(_Structure):
+    kind = "Toar"
+
+
+class PowerlawStructure(_Structure):
+    kind = "Powerlaw"
+
+
+class LinearStructure(_Structure):
+    kind = "Linear"
+
+
+class MultipleStructure(_Structure):
+    def __init__(self, sh, sv, sw):
+        self.g = O.Struct.multiple(sh.g, sv.g, sw.g)
+        self.s = None
+
+
+class CrossValidation(_Structure):
+    def __init__(self, structure, dist):
+        if not np.isfinite(dist) or dist < 0:
+            raise ValueError("dist")
+        self.g = structure.g.cross_validation(dist)
+        self.s = None
 
 
 def _pts(obj):
@@ -102,6 +155,11 @@ def _validate(bg, background, points, max_points, *per_point):
 def optimal_interpolation(bg, background, points, pobs, pratios, pbackground, structure, max_points, allow_extrapolation=True):
     background = np.asarray(background, np.float32)
     _validate(bg, background, points, max_points, pobs, pratios, pbackground)
+    if structure.s is None:   # generic structure: the general-inverse oracle
+        n = int(np.prod(background.shape))
+        out, _ = O.oi_full_generic(_pts(bg), background.ravel(), np.ones(n, np.float32), _pts(points), pobs, pratios, pbackground,
+                                   np.ones(points.size(), np.float32), structure.g, max_points, allow_extrapolation)
+        return out.reshape(background.shape)
     out = O.oi(_pts(bg), background.ravel(), _pts(points), pobs, pratios, pbackground, structure.s, max_points, allow_extrapolation)
     return out.reshape(background.shape)
 

@@ -145,3 +145,58 @@ def test_selection_is_bit_exact_vs_oracle_neighbours():
     op = O.Pts(c["plat"], c["plon"])
     for lat, lon, r in [(0.5, 0.5, 20000.0), (0.1, 0.9, 36456.5), (0.0, 0.0, 5000.0)]:
         np.testing.assert_array_equal(points.get_neighbours(lat, lon, r), O.get_neighbours(op, lat, lon, r))
+
+
+# ---- structure functions other than Barnes (scalar forms) ---------------------------------------
+def _generic(c, make_gpu, make_orc, max_points, full=False):
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    Y, X = c["bg"].shape
+    e = (c["gelev"], c["glaf"]) if c["gelev"] is not None else ((), ())
+    pe = (c["pelev"], c["plaf"]) if c["pelev"] is not None else ((), ())
+    grid = gridpp.Grid(c["lats"], c["lons"], e[0], e[1], c["ctype"])
+    points = gridpp.Points(c["plat"], c["plon"], pe[0], pe[1], c["ctype"])
+    og = O.Pts(c["lats"].ravel(), c["lons"].ravel(), None if c["gelev"] is None else c["gelev"].ravel(),
+               None if c["glaf"] is None else c["glaf"].ravel(), c["ctype"])
+    op = O.Pts(c["plat"], c["plon"], c["pelev"], c["plaf"], c["ctype"])
+    ones_g, ones_p = np.ones((Y, X), np.float32), np.ones(c["obs"].size, np.float32)
+    out, var = gridpp.optimal_interpolation_full(grid, c["bg"], ones_g, points, c["obs"], c["ratios"], c["pbg"], ones_p,
+                                                 make_gpu(gridpp), max_points)
+    ref, rvar = O.oi_full_generic(og, c["bg"].ravel(), ones_g.ravel(), op, c["obs"], c["ratios"], c["pbg"], ones_p, make_orc(O), max_points)
+    return np.asarray(out), ref.reshape(Y, X), np.asarray(var), rvar.reshape(Y, X)
+
+
+@pytest.mark.parametrize("kind", ["Cressman", "Soar", "Toar", "Powerlaw"])
+@pytest.mark.parametrize("elev", [False, True])
+def test_other_kernels(kind, elev):
+    """Horizontal-only (symmetric, Cholesky) and with vertical / laf factors (Cressman/SOAR/TOAR on signed differences
+    are not even functions -> non-symmetric P -> pivoted LU path, like the reference's arma::inv)."""
+    c = make_case(61, 40, 36, 120, with_elev=elev)
+    h = {"Cressman": 30000, "Soar": 4000, "Toar": 3500, "Powerlaw": 2500}[kind]
+    v, w = (300, 0.6) if elev else (0, 0)
+    out, ref, var, rvar = _generic(c, lambda g: getattr(g, kind + "Structure")(h, v, w), lambda O: O.Struct(kind, h, v, w), 12)
+    check(out, ref)
+    check(var, rvar)
+    assert np.abs(out - c["bg"]).max() > 0.05
+
+
+def test_multiple_and_cross_validation_structures():
+    c = make_case(62, 36, 40, 150, with_elev=True)
+    mk_g = lambda g: g.MultipleStructure(g.BarnesStructure(12000), g.LinearStructure(0, 0.2, 0), g.PowerlawStructure(1, 1, 0.7))
+    mk_o = lambda O: O.Struct.multiple(O.Struct("Barnes", 12000), O.Struct("Linear", 0, 0.2, 0), O.Struct("Powerlaw", 1, 1, 0.7))
+    out, ref, var, rvar = _generic(c, mk_g, mk_o, 14)
+    check(out, ref)
+    check(var, rvar)
+    out, ref, var, rvar = _generic(c, lambda g: g.CrossValidation(g.BarnesStructure(12000, 200, 0.5), 3000),
+                                   lambda O: O.Struct("Barnes", 12000, 200, 0.5).cross_validation(3000), 14)
+    check(out, ref)
+
+
+def test_pivoted_lu_equals_cholesky(monkeypatch):
+    """The LU solver variant (used for non-symmetric / indefinite systems) gives the Cholesky answer on an SPD system."""
+    c = make_case(63, 32, 32, 100)
+    out, ref = run_both(c, 10000, 0, 0, 16)
+    monkeypatch.setenv("GPP_OI_FORCE_LU", "1")
+    out_lu, _ = run_both(c, 10000, 0, 0, 16)
+    check(out_lu, ref)
+    assert np.max(np.abs(out_lu - out)) < 1e-6

@@ -12,7 +12,7 @@ IMPLEMENTED = [
     "pin_oi_simple_1d", "pin_oi_variance", "pin_oi_invalid_arguments", "pin_oi_missing_values",
     "pin_oi_extrapolation", "pin_oi_no_obs", "pin_radius_queries", "pin_invalid_coords", "pin_nearest",
     "pin_neighbourhood", "pin_neighbourhood_invalid", "pin_neighbourhood_3d_and_overflow", "pin_neighbourhood_quantile",
-    "pin_neighbourhood_quantile_fast", "pin_thresholds", "pin_util", "pin_ensi",
+    "pin_neighbourhood_quantile_fast", "pin_thresholds", "pin_util", "pin_ensi", "pin_structures", "pin_oi_cross_validation",
 ]
 
 
