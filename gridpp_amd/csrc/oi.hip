@@ -125,7 +125,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
     return pos;
 }
 
-template <int N, bool LU>
+template <int N, bool LU, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     if(__ballot(active) != 0ull) {
         const int K = a.s.K;
         bool overflow, truncated;
-        cnt = scan_tile<N>(a.s, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
+        cnt = scan_tile<N, false, PLAIN>(a.s, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
         if(__ballot(overflow) != 0ull) {
             if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);
             cnt = overflow ? 0 : cnt;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                 const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
                 const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
                 // matrix rows: corr(obs_i, obs_p) (oi.cpp:304-312); G rows: corr(cell, obs_p) (oi.cpp:250)
-                const float c = d_corr(a.s.st, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
+                const float c = d_corr_t<PLAIN>(a.s.st, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
                 colbuf[p][lane] = c;
                 const float dpf = (float)((double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p));
                 maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
@@ -545,8 +545,10 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     int err = 0;
     unsigned long long counters[4];
     for(int attempt = 0; attempt < 2; ++attempt) {
-        if(use_lu) hipLaunchKernelGGL((k_oi<N, true>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
-        else hipLaunchKernelGGL((k_oi<N, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
+        const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
+        if(use_lu) hipLaunchKernelGGL((k_oi<N, true, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
+        else if(plain) hipLaunchKernelGGL((k_oi<N, false, true>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
+        else hipLaunchKernelGGL((k_oi<N, false, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
         GPP_HIP(hipGetLastError());
         GPP_HIP(hipEventRecord(ws.e1, stream()));
         GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));

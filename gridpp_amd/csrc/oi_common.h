@@ -116,7 +116,15 @@ __device__ __forceinline__ float d_rho(const int kind, const float dist, const f
     if(kind == SK_TOAR) return (1.0f + v + (v * v) / 3.0f) * d_expf_cr(-v);   // :56-64
     return (float)(1.0 / (1.0 + 0.5 * (double)v * (double)v));  // powerlaw :66-74
 }
-// corr(p1, p2) / corr_background(p1, p2) of a scalar (possibly Multiple / CrossValidation-wrapped) structure
+// corr(p1, p2) / corr_background(p1, p2) of a scalar (possibly Multiple / CrossValidation-wrapped) structure.
+// PLAIN = true is the compile-time specialisation for an unwrapped Barnes structure (the headline configuration).
+template <bool PLAIN>
+__device__ __forceinline__ float d_rho_t(const int kind, const float dist, const float length) {
+    return PLAIN ? d_barnes_rho(dist, length) : d_rho(kind, dist, length);
+}
+template <bool PLAIN>
+__device__ __forceinline__ float d_corr_t(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
+                                          float x2, float y2, float z2, float e2, float l2, const bool background);
 __device__ __forceinline__ float d_corr(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
                                         float x2, float y2, float z2, float e2, float l2, const bool background) {
     const float hdist = d_chord(x1, y1, z1, x2, y2, z2);
@@ -164,6 +172,13 @@ static __global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const 
 }
 
 
+template <bool PLAIN>
+__device__ __forceinline__ float d_corr_t(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
+                                          float x2, float y2, float z2, float e2, float l2, const bool background) {
+    if(PLAIN) return d_barnes_corr(x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, s.h, s.v, s.w, s.R);
+    return d_corr(s, x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, background);
+}
+
 // What the candidate scan needs: the bin-sorted observation block and the structure function
 struct ScanArgs {
     const float4* pgeo;      // sorted, per call (x = NaN when the observation is unusable)
@@ -187,7 +202,7 @@ struct ScanArgs {
 // the tile first -- they almost always contain the final selection, so the pruning thresholds are tight before
 // anything far away is looked at; phase 2 walks the bin rows centre-out with the x-extent and the stop test taken
 // from the largest threshold in the wave, skipping the bins phase 1 already did.
-template <int N, bool WANT_TRUNC = false>
+template <int N, bool WANT_TRUNC = false, bool PLAIN = false>
 __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, const float gx, const float gy, const float gz,
                                          const float ge, const float gl, unsigned long long (*keys)[64], const int lane, bool& overflow,
                                          bool& truncated) {
@@ -200,7 +215,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
     const int K = a.K;
     const bool bounded = a.max_points > 0 && a.max_points <= N;
     const float h2 = a.st.h * a.st.h;
-    const bool prune = bounded && a.st.kh == SK_BARNES;   // rho <= rho_h(d) with the closed-form inverse of the Barnes kernel
+    const bool prune = bounded && (PLAIN || a.st.kh == SK_BARNES);   // rho <= rho_h(d) with the closed-form inverse of the Barnes kernel
     float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
     float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
     const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
@@ -243,9 +258,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
                         const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        float rho = (a.st.cv && dist <= a.st.cv_dist) ? 0.0f : d_rho(a.st.kh, dist, a.st.h);   // corr_background
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho(a.st.kv, ge - oe, a.st.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho(a.st.kw, gl - ol, a.st.w);
+                        float rho = (!PLAIN && a.st.cv && dist <= a.st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(a.st.kh, dist, a.st.h);   // corr_background
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(a.st.kv, ge - oe, a.st.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(a.st.kw, gl - ol, a.st.w);
                         if(rho > 0.0f) {   // oi.cpp:253
                             const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
                             const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
@@ -279,9 +294,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {
                         const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        float rho = (a.st.cv && dist <= a.st.cv_dist) ? 0.0f : d_rho(a.st.kh, dist, a.st.h);   // corr_background
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho(a.st.kv, ge - oe, a.st.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho(a.st.kw, gl - ol, a.st.w);
+                        float rho = (!PLAIN && a.st.cv && dist <= a.st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(a.st.kh, dist, a.st.h);   // corr_background
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(a.st.kv, ge - oe, a.st.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(a.st.kw, gl - ol, a.st.w);
                         if(rho > 0.0f) truncated = true;
                     }
                 }
