@@ -1,5 +1,5 @@
 // Runtime, point sets and neighbour queries of libgridpp_hip.so.
-#include "common.h"
+#include "oi_common.h"
 #include <algorithm>
 #include <thread>
 #include <mutex>
@@ -275,9 +275,62 @@ __global__ __launch_bounds__(256) void k_nearest_bruteforce(const float* __restr
     if(lane == 0) out[wave] = (besti == 0x7fffffff) ? -1 : besti;
 }
 
+// Same metric and tie rule through the bin index of the point set (gpp_obs_index): rings of bins around the query's bin are
+// visited until no unvisited bin can hold a point at least as close (points of ring r+1 are >= r bin widths away in the
+// projection, hence in 3-D).  One thread per query.
+__global__ __launch_bounds__(256) void k_nearest_binned(const float4* __restrict__ sgeo, const float2* __restrict__ smeta,
+                                                        const int* __restrict__ bin_start, int axis_a, int axis_b, int nbx, int nby,
+                                                        float amin, float bmin, float inv_s,
+                                                        const float* __restrict__ qx, const float* __restrict__ qy, const float* __restrict__ qz,
+                                                        int nq, int include_match, int* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if(q >= nq) return;
+    const float x = qx[q], y = qy[q], z = qz[q];
+    const float qa = axis_a == 0 ? x : (axis_a == 1 ? y : z);
+    const float qb = axis_b == 1 ? y : (axis_b == 2 ? z : x);
+    const int cbx = min(max((int)floorf((qa - amin) * inv_s), 0), nbx - 1);
+    const int cby = min(max((int)floorf((qb - bmin) * inv_s), 0), nby - 1);
+    const float sbin = 1.0f / inv_s;
+    float best = INFINITY;
+    int besti = 0x7fffffff;
+    auto visit = [&](int row, int xa, int xb) {
+        if(row < 0 || row >= nby) return;
+        xa = max(xa, 0); xb = min(xb, nbx - 1);
+        if(xa > xb) return;
+        const int js = bin_start[row * nbx + xa], je = bin_start[row * nbx + xb + 1];
+        for(int j = js; j < je; ++j) {
+            const float4 g = sgeo[j];
+            if(!include_match && g.x == x && g.y == y && g.z == z) continue;   // kdtree.cpp:265-270
+            const float dx = g.x - x, dy = g.y - y, dz = g.z - z;
+            float s = dx * dx + dy * dy;
+            s = s + dz * dz;
+            const int o = __float_as_int(smeta[j].y);
+            if(s < best || (s == best && o < besti)) { best = s; besti = o; }
+        }
+    };
+    const int rmax = max(max(cbx, nbx - 1 - cbx), max(cby, nby - 1 - cby));
+    for(int r = 0; r <= rmax; ++r) {
+        if(r >= 2) { const float lb = (float)(r - 1) * sbin * 0.999f; if(best < lb * lb) break; }
+        if(r == 0) visit(cby, cbx, cbx);
+        else {
+            visit(cby - r, cbx - r, cbx + r);
+            visit(cby + r, cbx - r, cbx + r);
+            for(int row = cby - r + 1; row <= cby + r - 1; ++row) { visit(row, cbx - r, cbx - r); visit(row, cbx + r, cbx + r); }
+        }
+    }
+    out[q] = (besti == 0x7fffffff) ? -1 : besti;
+}
+
 static void nearest_device(gpp_points* p, const float* d_qx, const float* d_qy, const float* d_qz, int nq, int include_match, int* d_out) {
     p->to_device();
     if(nq == 0) return;
+    if(p->n > 2048 && !getenv("GPP_NN_BRUTE")) {
+        gpp_obs_index* ix = gpp_build_obs_index(p);
+        hipLaunchKernelGGL(k_nearest_binned, dim3((nq + 255) / 256), dim3(256), 0, stream(), ix->d_sgeo.p, ix->d_smeta.p, ix->d_bin_start.p,
+                           ix->axis_a, ix->axis_b, ix->nbx, ix->nby, ix->amin, ix->bmin, ix->inv_s, d_qx, d_qy, d_qz, nq, include_match, d_out);
+        GPP_HIP(hipGetLastError());
+        return;
+    }
     int waves_per_block = 4;
     int blocks = (nq + waves_per_block - 1) / waves_per_block;
     hipLaunchKernelGGL(k_nearest_bruteforce, dim3(blocks), dim3(256), 0, stream(), p->d_x.p, p->d_y.p, p->d_z.p, p->n,
