@@ -515,7 +515,9 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                        f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p);
     GPP_HIP(hipGetLastError());
 
-    constexpr int N = 32;
+    // register-tile size of the solve: 32 rows (max_points <= 32, the common case) or 62 rows (everything up to 62
+    // usable observations per grid point; one member cell per factorisation)
+    const int N = (max_points > 0 && max_points <= 32) ? 32 : 62;
     OiArgs a;
     a.gx = bgrid->d_x.p; a.gy = bgrid->d_y.p; a.gz = bgrid->d_z.p; a.gelev = bgrid->d_elev.p; a.glaf = bgrid->d_laf.p;
     a.bg = f_bg.d; a.bvar = f_bvar.d; a.out = f_out.d; a.out_var = f_var.d;
@@ -530,7 +532,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     a.s.st = gpp_resolve_structure(st);
     a.s.max_points = max_points;
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
-      const int kk = (max_points > 0 && max_points <= 32) ? max_points : 32;
+      const int kk = a.s.K;
       a.s.q0 = std::max(1, std::min(8, (int)std::ceil(0.5 * (std::sqrt(1.6 * kk / std::max(occ, 1e-3)) - 1.0)))); }
     a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
@@ -546,9 +548,16 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     unsigned long long counters[4];
     for(int attempt = 0; attempt < 2; ++attempt) {
         const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
-        if(use_lu) hipLaunchKernelGGL((k_oi<N, true, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
-        else if(plain) hipLaunchKernelGGL((k_oi<N, false, true>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
-        else hipLaunchKernelGGL((k_oi<N, false, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, stream(), a);
+        const dim3 grid((a.ntiles + 3) / 4), block(256);
+        if(N == 32) {
+            if(use_lu) hipLaunchKernelGGL((k_oi<32, true, false>), grid, block, 0, stream(), a);
+            else if(plain) hipLaunchKernelGGL((k_oi<32, false, true>), grid, block, 0, stream(), a);
+            else hipLaunchKernelGGL((k_oi<32, false, false>), grid, block, 0, stream(), a);
+        }
+        else {
+            if(use_lu) hipLaunchKernelGGL((k_oi<62, true, false>), grid, block, 0, stream(), a);
+            else hipLaunchKernelGGL((k_oi<62, false, false>), grid, block, 0, stream(), a);
+        }
         GPP_HIP(hipGetLastError());
         GPP_HIP(hipEventRecord(ws.e1, stream()));
         GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
@@ -572,7 +581,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     g_stats.solves = (long long)counters[1];
     if(getenv("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);
     if(err & ERR_SINGULAR) runtime("optimal_interpolation: local (P+R) matrix is singular");
-    if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more than 32 observations per grid point requested (max_points == 0 or > 32): large-n path not built yet");
+    if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more than 62 usable observations per grid point requested (max_points == 0 or > 62): not supported on the GPU path yet");
     return GPP_OK;
     GPP_CATCH
 }

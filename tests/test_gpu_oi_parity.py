@@ -200,3 +200,22 @@ def test_pivoted_lu_equals_cholesky(monkeypatch):
     out_lu, _ = run_both(c, 10000, 0, 0, 16)
     check(out_lu, ref)
     assert np.max(np.abs(out_lu - out)) < 1e-6
+
+
+@pytest.mark.parametrize("max_points", [33, 48, 62, 0, 100])
+def test_more_than_32_points(max_points):
+    """max_points in 33..62 (and 0 / larger values while no cell has more than 62 usable observations) use the
+    62-row register tile."""
+    S = 150 if max_points in (33, 48, 62) else 55
+    c = make_case(70 + max_points, 24, 24, S)
+    out, ref = run_both(c, 40000, 0, 0, max_points)   # R = 146 km: every observation is in range of every cell
+    check(out, ref)
+
+
+def test_too_many_points_fails_loudly():
+    import gridpp_amd as gridpp
+    c = make_case(80, 8, 8, 200)
+    grid = gridpp.Grid(c["lats"], c["lons"])
+    points = gridpp.Points(c["plat"], c["plon"])
+    with pytest.raises(RuntimeError, match="more than 62"):
+        gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], gridpp.BarnesStructure(40000), 0)
