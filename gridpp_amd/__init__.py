@@ -125,8 +125,8 @@ class Point:
         else:   # point.cpp:18-21 (x = lat, y = lon)
             self.x, self.y, self.z = float(np.float32(lat)), float(np.float32(lon)), 0.0
 
-    def _five(self):
-        return (C.c_float * 5)(self.x, self.y, self.z, self.elev, self.laf)
+    def _seven(self):
+        return (C.c_float * 7)(self.x, self.y, self.z, self.elev, self.laf, self.lat, self.lon)
 
 
 def convert_coordinates(lats, lons, type=Geodetic):
@@ -315,14 +315,17 @@ class StructureFunction:
 
     def localization_distance(self, p=None):
         d = C.c_float(0)
-        check(lib().gpp_structure_localization_distance(C.byref(self._s), C.byref(d)))
+        lat, lon = (p.lat, p.lon) if p is not None else (0.0, 0.0)
+        if p is None and self._s.field:
+            raise ValueError("a spatially varying structure needs the point")
+        check(lib().gpp_structure_localization_distance(C.byref(self._s), float(lat), float(lon), C.byref(d)))
         return d.value
 
     def _corr(self, p1, p2, background):
         if isinstance(p2, (list, tuple)):
             return np.array([self._corr(p1, q, background) for q in p2], np.float32)
         r = C.c_float(0)
-        check(lib().gpp_structure_corr(C.byref(self._s), p1._five(), p2._five(), int(background), C.byref(r)))
+        check(lib().gpp_structure_corr(C.byref(self._s), p1._seven(), p2._seven(), int(background), C.byref(r)))
         return r.value
 
     def corr(self, p1, p2):
@@ -334,25 +337,67 @@ class StructureFunction:
     def clone(self):
         c = StructureFunction.__new__(type(self))
         c._s = self._copy_struct()
+        c._field_owner = getattr(self, "_field_owner", None)   # keeps the HBM fields (and their grid) alive
         return c
 
 
+class _Field:
+    """Owns a gpp_field (h, v, w fields of a spatially varying structure resident in HBM)."""
+
+    def __init__(self, grid, h, v, w, kind, min_rho):
+        self.grid = grid   # the field borrows the grid handle
+        self.h = C.c_void_p()
+        check(lib().gpp_field_create(grid._h, _ptr(h), _ptr(v), _ptr(w), kind, float(min_rho), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().gpp_field_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def _scalar_structure(obj, kind, h, v, w, hmax):
-    if not np.isscalar(h):
-        raise RuntimeError("the spatially varying structure functions (grid, h, v, w) are outside the GPU hot path (SURVEY 8f)")
+    if isinstance(h, Grid):   # (grid, h, v, w, min_rho): spatially varying form, e.g. src/api/structure.cpp:168-184
+        grid, hf, vf, wf = h, v, w, hmax
+        raise RuntimeError("internal: use _spatial_structure")
     for name, val in (("v", v), ("w", w)):   # e.g. structure.cpp:147-152
         if not is_valid(val) or val < 0:
             raise ValueError("%s must be >= 0" % name)
     mr = C.c_float(0)
     check(lib().gpp_structure_min_rho(kind, float(h), float(hmax), C.byref(mr)))
-    obj._s = _capi.gpp_structure(kind, float(h), float(v), float(w), mr.value, 0, 0, 0.0, 0.0, 0)
+    obj._s = _capi.gpp_structure(kind, float(h), float(v), float(w), mr.value, 0, 0, 0.0, 0.0, 0, None)
+
+
+def _spatial_structure(obj, kind, grid, h, v, w, min_rho):
+    h, v, w = _vec(h, 2, "h"), _vec(v, 2, "v"), _vec(w, 2, "w")
+    if h.shape == (1, 1) and v.shape == (1, 1) and w.shape == (1, 1):   # not spatial (structure.cpp:174-176)
+        obj._s = _capi.gpp_structure(kind, float(h[0, 0]), float(v[0, 0]), float(w[0, 0]), float(min_rho), 0, 0, 0.0, 0.0, 0, None)
+        return
+    shape = tuple(grid.size())
+    if h.shape != shape or v.shape != shape or w.shape != shape:
+        raise ValueError("Grid size not the same as scale size")
+    obj._field_owner = _Field(grid, h, v, w, kind, min_rho)
+    obj._s = _capi.gpp_structure(kind, 0.0, 0.0, 0.0, float(min_rho), 0, 0, 0.0, 0.0, 0, obj._field_owner.h)
+
+
+def _make_structure(obj, kind, args, has_hmax=True):
+    """(h, v=0, w=0, hmax=MV) or (grid, h, v, w, min_rho=0.0013)"""
+    if len(args) and isinstance(args[0], Grid):
+        if len(args) < 4:
+            raise TypeError("spatially varying structure: (grid, h, v, w, min_rho=0.0013)")
+        _spatial_structure(obj, kind, args[0], args[1], args[2], args[3], args[4] if len(args) > 4 else 0.0013)
+    else:
+        a = list(args) + [0, 0, MV][len(args) - 1:] if len(args) < 4 else list(args)
+        _scalar_structure(obj, kind, a[0], a[1], a[2], a[3] if has_hmax else MV)
 
 
 class BarnesStructure(StructureFunction):
     """BarnesStructure(h, v=0, w=0, hmax=MV) (src/api/structure.cpp:143-167)"""
 
-    def __init__(self, h, v=0, w=0, hmax=MV):
-        _scalar_structure(self, _SK["Barnes"], h, v, w, hmax)
+    def __init__(self, *args):
+        _make_structure(self, _SK["Barnes"], args)
 
 
 class CressmanStructure(StructureFunction):
@@ -365,23 +410,23 @@ class CressmanStructure(StructureFunction):
 
 
 class SoarStructure(StructureFunction):
-    def __init__(self, h, v=0, w=0, hmax=MV):   # structure.cpp:317-341
-        _scalar_structure(self, _SK["Soar"], h, v, w, hmax)
+    def __init__(self, *args):   # structure.cpp:317-341
+        _make_structure(self, _SK["Soar"], args)
 
 
 class ToarStructure(StructureFunction):
-    def __init__(self, h, v=0, w=0, hmax=MV):   # structure.cpp:467-491
-        _scalar_structure(self, _SK["Toar"], h, v, w, hmax)
+    def __init__(self, *args):   # structure.cpp:467-491
+        _make_structure(self, _SK["Toar"], args)
 
 
 class PowerlawStructure(StructureFunction):
-    def __init__(self, h, v=0, w=0, hmax=MV):   # structure.cpp:618-642
-        _scalar_structure(self, _SK["Powerlaw"], h, v, w, hmax)
+    def __init__(self, *args):   # structure.cpp:618-642
+        _make_structure(self, _SK["Powerlaw"], args)
 
 
 class LinearStructure(StructureFunction):
-    def __init__(self, h, v=0, w=0, hmax=MV):   # structure.cpp:765-789
-        _scalar_structure(self, _SK["Linear"], h, v, w, hmax)
+    def __init__(self, *args):   # structure.cpp:765-789
+        _make_structure(self, _SK["Linear"], args)
 
 
 class MultipleStructure(StructureFunction):
@@ -393,8 +438,10 @@ class MultipleStructure(StructureFunction):
         sh, sv, sw = structure_h._s, structure_v._s, structure_w._s
         kv = sv.kind_v - 1 if sv.kind_v else sv.kind
         kw = sw.kind_w - 1 if sw.kind_w else sw.kind
+        if sh.field or sv.field or sw.field:
+            raise RuntimeError("spatially varying structures inside a MultipleStructure are not on the GPU path")
         loc = structure_h.localization_distance()
-        self._s = _capi.gpp_structure(sh.kind, sh.h, sv.v, sw.w, sh.min_rho, kv + 1, kw + 1, loc, 0.0, _ST_HAS_LOC)
+        self._s = _capi.gpp_structure(sh.kind, sh.h, sv.v, sw.w, sh.min_rho, kv + 1, kw + 1, loc, 0.0, _ST_HAS_LOC, None)
 
 
 class CrossValidation(StructureFunction):
@@ -406,6 +453,7 @@ class CrossValidation(StructureFunction):
         self._s = structure._copy_struct()
         self._s.flags |= _ST_CV
         self._s.cv_dist = float(dist)
+        self._field_owner = getattr(structure, "_field_owner", None)
 
 
 def _structure(s):

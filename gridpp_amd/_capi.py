@@ -15,7 +15,8 @@ MEM_HOST, MEM_DEVICE, ASYNC = 0, 1, 2
 
 class gpp_structure(C.Structure):
     _fields_ = [("kind", C.c_int), ("h", C.c_float), ("v", C.c_float), ("w", C.c_float), ("min_rho", C.c_float),
-                ("kind_v", C.c_int), ("kind_w", C.c_int), ("loc", C.c_float), ("cv_dist", C.c_float), ("flags", C.c_int)]
+                ("kind_v", C.c_int), ("kind_w", C.c_int), ("loc", C.c_float), ("cv_dist", C.c_float), ("flags", C.c_int),
+                ("field", C.c_void_p)]
 
 
 class gpp_oi_stats(C.Structure):
@@ -44,8 +45,10 @@ SIGNATURES = {
     "gpp_points_nearest_neighbour": [vp, vp, vp, C.c_int, C.c_int, vp],
     "gpp_nearest": [vp, vp, vp, vp, C.c_int],
     "gpp_structure_min_rho": [C.c_int, C.c_float, C.c_float, fp],
-    "gpp_structure_localization_distance": [C.POINTER(gpp_structure), fp],
+    "gpp_structure_localization_distance": [C.POINTER(gpp_structure), C.c_float, C.c_float, fp],
     "gpp_structure_corr": [C.POINTER(gpp_structure), fp, fp, C.c_int, fp],
+    "gpp_field_create": [vp, vp, vp, vp, C.c_int, C.c_float, C.POINTER(vp)],
+    "gpp_field_destroy": [vp],
     "gpp_optimal_interpolation_full": [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, vp, C.c_int],
     "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
     "gpp_optimal_interpolation_ensi": [vp, vp, C.c_int, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],

@@ -100,6 +100,9 @@ inline bool is_valid(float v) { return !std::isnan(v) && !std::isinf(v); }   // 
 struct gpp_obs_index;   // oi.hip: bin-sorted observation block
 struct gpp_nn_index;    // runtime.hip: uniform-cell index for nearest-neighbour queries
 
+// runtime.hip: nearest-neighbour indices of nq device-resident query points in p (exact metric, ties -> lowest index)
+void gpp_nearest_device(gpp_points* p, const float* d_qx, const float* d_qy, const float* d_qz, int nq, int include_match, int* d_out);
+
 struct gpp_points {
     int n = 0, ny = 0, nx = 0, type = GPP_GEODETIC;
     std::vector<float> lats, lons, elevs, lafs, x, y, z;   // host copies (float32, as the reference stores them)

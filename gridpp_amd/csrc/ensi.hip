@@ -70,6 +70,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+template <bool SPATIAL>
 __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
     __shared__ unsigned long long s_keys[EN][64];        // 16 KB: keys, then origs (u32) + Y tile (f32)
     __shared__ double s_B[EN * BP];                       // B, later M_W
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
     const int nV = a.nV, E = a.E;
 
     bool overflow, truncated;
-    int cnt = scan_tile<EN, true>(a.s, active, gx, gy, gz, ge, gl, s_keys, lane, overflow, truncated);
+    DevStructure cst = a.s.st;
+    if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
+    int cnt = scan_tile<EN, true>(a.s, cst, active, gx, gy, gz, ge, gl, s_keys, lane, overflow, truncated);
     if(__ballot(overflow) != 0ull) {
         if(lane == 0) atomicOr(a.err, 1);
         cnt = overflow ? 0 : cnt;
@@ -128,7 +131,9 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         const unsigned orig_i = (lane < n) ? origs[lane][l] : 0u;
         float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 1);
         if(lane < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
-        const float rho = d_corr(a.s.st, cx, cy, cz, ce, cl, o0.x, o0.y, o0.z, o0.w, o1.x, true);   // :227
+        DevStructure lst = a.s.st;
+        if(SPATIAL) { lst.h = readlane_f(cst.h, l); lst.v = readlane_f(cst.v, l); lst.w = readlane_f(cst.w, l); lst.R = readlane_f(cst.R, l); }
+        const float rho = d_corr(lst, cx, cy, cz, ce, cl, o0.x, o0.y, o0.z, o0.w, o1.x, true);   // :227
         const float sig2 = o1.w * o1.w;                                    // float product (:300)
         const double D = (double)rho / (double)sig2;                       // Rinv(i,i)
         const double sD = sqrt(D);
@@ -333,7 +338,7 @@ namespace {
 struct EnsiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> gYhat, gY;
-    DevBuf<int> flags, validIdx, err;
+    DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
     DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -419,6 +424,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
     a.s.st = gpp_resolve_structure(st);
+    gpp_bind_field(a.s.st, st, bgrid, points, ws.cell_idx, ws.obs_idx);
     a.s.max_points = max_points;
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
       const int kk = (max_points > 0 && max_points <= 32) ? max_points : 32;
@@ -430,7 +436,8 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
     GPP_HIP(hipEventRecord(ws.e0, stream()));
-    hipLaunchKernelGGL(k_ensi, dim3(a.ntiles), dim3(64), 0, stream(), a);
+    if(a.s.st.fh) hipLaunchKernelGGL(k_ensi<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+    else hipLaunchKernelGGL(k_ensi<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
     GPP_HIP(hipGetLastError());
     GPP_HIP(hipEventRecord(ws.e1, stream()));
     int err = 0;

@@ -125,7 +125,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
     return pos;
 }
 
-template <int N, bool LU, bool PLAIN>
+template <int N, bool LU, bool PLAIN, bool SPATIAL>
 __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     if(__ballot(active) != 0ull) {
         const int K = a.s.K;
         bool overflow, truncated;
-        cnt = scan_tile<N, false, PLAIN>(a.s, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
+        DevStructure cst = a.s.st;   // this lane's structure: uniform, or the parameters at its grid point
+        if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
+        cnt = scan_tile<N, false, PLAIN>(a.s, cst, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
         if(__ballot(overflow) != 0ull) {
             if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);
             cnt = overflow ? 0 : cnt;
@@ -211,13 +213,18 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             float px = __shfl(gx, src), py = __shfl(gy, src), pz = __shfl(gz, src), pe = __shfl(ge, src), pl = __shfl(gl, src);
             const float cbg = __shfl(bg, src), cbv = __shfl(bvar, src);
             if(lane < n) { px = o0.x; py = o0.y; pz = o0.z; pe = o0.w; pl = o1.x; }
+            DevStructure pst = a.s.st;   // structure parameters of this lane's own point (p1 of corr)
+            if(SPATIAL) {
+                pst.h = __shfl(cst.h, src); pst.v = __shfl(cst.v, src); pst.w = __shfl(cst.w, src); pst.R = __shfl(cst.R, src);
+                if(lane < n) d_structure_at(pst, pst.obs_idx[orig_i]);
+            }
             float maxInc = -INFINITY, minInc = INFINITY;
             // column p of [P ; G] across the lanes (rolled: one copy of the exp code), staged through LDS
             for(int p = 0; p < n; ++p) {
                 const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
                 const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
                 // matrix rows: corr(obs_i, obs_p) (oi.cpp:304-312); G rows: corr(cell, obs_p) (oi.cpp:250)
-                const float c = d_corr_t<PLAIN>(a.s.st, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
+                const float c = d_corr_t<PLAIN>(pst, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
                 colbuf[p][lane] = c;
                 const float dpf = (float)((double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p));
                 maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
@@ -377,7 +384,7 @@ namespace {
 struct OiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> ones;
-    DevBuf<int> err;
+    DevBuf<int> err, cell_idx, obs_idx;
     DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -420,7 +427,71 @@ DevStructure gpp_resolve_structure(const gpp_structure* s) {
     d.cv = (s->flags & GPP_ST_CV) ? 1 : 0;
     d.cv_dist = s->cv_dist;
     if(d.cv && (!is_valid(d.cv_dist) || d.cv_dist < 0)) invalid("Invalid 'dist' in CrossValidation structure");   // :912-913
+    d.fh = d.fv = d.fw = d.fR = nullptr; d.cell_idx = d.obs_idx = nullptr;
+    if(s->field) {
+        const gpp_field* f = (const gpp_field*)s->field;
+        if(f->kind != s->kind || s->kind_v || s->kind_w) runtime("a spatially varying structure cannot be mixed into a MultipleStructure on the GPU path");
+        d.fh = f->d_h.p; d.fv = f->d_v.p; d.fw = f->d_w.p; d.fR = f->d_R.p;
+    }
     return d;
+}
+// field index (nearest neighbour in the field's grid, src/api/structure.cpp:190) of every point of `pts`; NULL = identity
+static const int* field_indices(const gpp_field* f, gpp_points* pts, DevBuf<int>& buf) {
+    if(f->grid == pts) return nullptr;
+    if(f->grid->n == pts->n && f->grid->type == pts->type && f->grid->x == pts->x && f->grid->y == pts->y && f->grid->z == pts->z) return nullptr;
+    pts->to_device();
+    buf.get(pts->n);
+    gpp_nearest_device(f->grid, pts->d_x.p, pts->d_y.p, pts->d_z.p, pts->n, 1, buf.p);
+    return buf.p;
+}
+void gpp_bind_field(DevStructure& d, const gpp_structure* s, gpp_points* bgrid, gpp_points* points, DevBuf<int>& cbuf, DevBuf<int>& obuf) {
+    if(!s->field) return;
+    const gpp_field* f = (const gpp_field*)s->field;
+    if(f->grid->type != bgrid->type) invalid("the structure function's grid and the background must have the same coordinate type");
+    d.cell_idx = field_indices(f, bgrid, cbuf);
+    const int* oi = field_indices(f, points, obuf);
+    if(!oi) {   // identity for the observations too: materialise it (the kernel indexes obs_idx unconditionally)
+        std::vector<int> id(points->n);
+        for(int i = 0; i < points->n; i++) id[i] = i;
+        obuf.upload(id.data(), id.size());
+        oi = obuf.p;
+    }
+    d.obs_idx = oi;
+}
+
+extern "C" int gpp_field_create(gpp_points* grid, const float* h, const float* v, const float* w, int kind, float min_rho, gpp_field** out) {
+    GPP_TRY
+    if(!grid || !out || !h || !v || !w) invalid("NULL argument");
+    if(!st_kind_ok(kind) || kind == GPP_SK_CRESSMAN) runtime("this structure function has no spatially varying form");
+    ensure_device();
+    std::unique_ptr<gpp_field> f(new gpp_field);
+    f->grid = grid; f->n = grid->n; f->kind = kind; f->min_rho = min_rho;
+    f->h.assign(h, h + grid->n); f->v.assign(v, v + grid->n); f->w.assign(w, w + grid->n);
+    f->R.resize(grid->n);
+    for(int i = 0; i < grid->n; i++) f->R[i] = st_localization(kind, f->h[i], min_rho);   // localization_distance(h), e.g. structure.cpp:280-282
+    f->d_h.upload(f->h.data(), grid->n); f->d_v.upload(f->v.data(), grid->n); f->d_w.upload(f->w.data(), grid->n); f->d_R.upload(f->R.data(), grid->n);
+    GPP_HIP(hipStreamSynchronize(stream()));
+    *out = f.release();
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_field_destroy(gpp_field* f) {
+    GPP_TRY
+    delete f;
+    return GPP_OK;
+    GPP_CATCH
+}
+// scalar structure at one location of a spatially varying one (nearest neighbour of (lat, lon) in the field's grid)
+static gpp_structure structure_at(const gpp_structure* s, float lat, float lon) {
+    gpp_structure t = *s;
+    if(!s->field) return t;
+    const gpp_field* f = (const gpp_field*)s->field;
+    int idx = -1;
+    if(gpp_points_nearest_neighbour(f->grid, &lat, &lon, 1, 1, &idx) != GPP_OK || idx < 0) runtime("structure function grid is empty");
+    t.field = nullptr;
+    t.h = f->h[idx]; t.v = f->v[idx]; t.w = f->w[idx]; t.min_rho = f->min_rho;
+    t.loc = f->R[idx]; t.flags |= GPP_ST_HAS_LOC;
+    return t;
 }
 extern "C" int gpp_structure_min_rho(int kind, float h, float hmax, float* min_rho) {
     GPP_TRY
@@ -441,15 +512,19 @@ extern "C" int gpp_structure_min_rho(int kind, float h, float hmax, float* min_r
     GPP_CATCH
 }
 static float loc_dist(const gpp_structure* s) { return gpp_resolve_structure(s).R; }
-extern "C" int gpp_structure_localization_distance(const gpp_structure* s, float* dist) {
+extern "C" int gpp_structure_localization_distance(const gpp_structure* s, float lat, float lon, float* dist) {
     GPP_TRY
-    *dist = loc_dist(s);
+    if(!s) invalid("structure is NULL");
+    gpp_structure t = structure_at(s, lat, lon);
+    *dist = loc_dist(&t);
     return GPP_OK;
     GPP_CATCH
 }
-extern "C" int gpp_structure_corr(const gpp_structure* s, const float p1[5], const float p2[5], int background, float* rho) {
+extern "C" int gpp_structure_corr(const gpp_structure* s, const float p1[7], const float p2[7], int background, float* rho) {
     GPP_TRY
-    DevStructure d = gpp_resolve_structure(s);
+    if(!s) invalid("structure is NULL");
+    gpp_structure t = structure_at(s, p1[5], p1[6]);
+    DevStructure d = gpp_resolve_structure(&t);
     DevBuf<float> out;
     out.get(1);
     hipLaunchKernelGGL(k_structure_corr, dim3(1), dim3(1), 0, stream(), d, make_float4(p1[0], p1[1], p1[2], p1[3]), p1[4],
@@ -530,6 +605,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     a.S = S; a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
     a.s.st = gpp_resolve_structure(st);
+    gpp_bind_field(a.s.st, st, bgrid, points, ws.cell_idx, ws.obs_idx);
     a.s.max_points = max_points;
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
       const int kk = a.s.K;
@@ -543,20 +619,25 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     // kernels (Barnes, Powerlaw, Linear); Cressman / SOAR / TOAR factors on SIGNED elevation / laf differences make P
     // non-symmetric (structure.cpp:35-64), and a truncated kernel can be indefinite -> pivoted LU like the reference.
     auto odd = [](int k) { return k == GPP_SK_CRESSMAN || k == GPP_SK_SOAR || k == GPP_SK_TOAR; };
-    bool use_lu = (a.s.st.v != 0 && odd(a.s.st.kv)) || (a.s.st.w != 0 && odd(a.s.st.kw)) || getenv("GPP_OI_FORCE_LU");
+    const bool spatial = a.s.st.fh != nullptr;   // per-point length scales: P is not symmetric (corr(p1, p2) uses p1's scales)
+    bool use_lu = spatial || (a.s.st.v != 0 && odd(a.s.st.kv)) || (a.s.st.w != 0 && odd(a.s.st.kw)) || getenv("GPP_OI_FORCE_LU");
     int err = 0;
     unsigned long long counters[4];
     for(int attempt = 0; attempt < 2; ++attempt) {
         const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
         const dim3 grid((a.ntiles + 3) / 4), block(256);
-        if(N == 32) {
-            if(use_lu) hipLaunchKernelGGL((k_oi<32, true, false>), grid, block, 0, stream(), a);
-            else if(plain) hipLaunchKernelGGL((k_oi<32, false, true>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_oi<32, false, false>), grid, block, 0, stream(), a);
+        if(spatial) {
+            if(N == 32) hipLaunchKernelGGL((k_oi<32, true, false, true>), grid, block, 0, stream(), a);
+            else hipLaunchKernelGGL((k_oi<62, true, false, true>), grid, block, 0, stream(), a);
+        }
+        else if(N == 32) {
+            if(use_lu) hipLaunchKernelGGL((k_oi<32, true, false, false>), grid, block, 0, stream(), a);
+            else if(plain) hipLaunchKernelGGL((k_oi<32, false, true, false>), grid, block, 0, stream(), a);
+            else hipLaunchKernelGGL((k_oi<32, false, false, false>), grid, block, 0, stream(), a);
         }
         else {
-            if(use_lu) hipLaunchKernelGGL((k_oi<62, true, false>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_oi<62, false, false>), grid, block, 0, stream(), a);
+            if(use_lu) hipLaunchKernelGGL((k_oi<62, true, false, false>), grid, block, 0, stream(), a);
+            else hipLaunchKernelGGL((k_oi<62, false, false, false>), grid, block, 0, stream(), a);
         }
         GPP_HIP(hipGetLastError());
         GPP_HIP(hipEventRecord(ws.e1, stream()));

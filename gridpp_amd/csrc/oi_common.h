@@ -22,8 +22,16 @@ struct gpp_obs_index {
 };
 
 gpp_obs_index* gpp_build_obs_index(gpp_points* pts);   // oi.hip
+struct gpp_field {   // spatially varying structure parameters resident in HBM (gpp_field_create)
+    gpp_points* grid = nullptr;
+    int n = 0, kind = 0;
+    float min_rho = 0;
+    std::vector<float> h, v, w, R;
+    gpp::DevBuf<float> d_h, d_v, d_w, d_R;
+};
 struct DevStructure;
 DevStructure gpp_resolve_structure(const gpp_structure* s);   // oi.hip: validation + localization distance
+void gpp_bind_field(DevStructure& d, const gpp_structure* s, gpp_points* bgrid, gpp_points* points, gpp::DevBuf<int>& cbuf, gpp::DevBuf<int>& obuf);
 
 // -------------------------------------------------------------------------------------------
 // device helpers
@@ -93,7 +101,16 @@ struct DevStructure {
     float R;              // localization distance (of the horizontal structure)
     int cv;               // CrossValidation wrapper active
     float cv_dist;
+    // spatially varying form (structure.cpp:168-214): h, v, w, R looked up at the FIRST point of corr(p1, p2) by nearest
+    // neighbour in the field's grid; NULL for the scalar forms
+    const float *fh, *fv, *fw, *fR;
+    const int* cell_idx;  // background point -> field index (NULL: identity)
+    const int* obs_idx;   // observation (original order) -> field index
 };
+// this point's parameters of a spatially varying structure
+__device__ __forceinline__ void d_structure_at(DevStructure& s, const int fi) {
+    s.h = s.fh[fi]; s.v = s.fv[fi]; s.w = s.fw[fi]; s.R = s.fR[fi];
+}
 // exp(x) rounded to float32 for any sign of x (soar / toar use exp(float), structure.cpp:53,63)
 __device__ __forceinline__ float d_expf_cr(float x) { return (float)exp((double)x); }
 __device__ __forceinline__ float d_rho(const int kind, const float dist, const float length) {
@@ -203,7 +220,7 @@ struct ScanArgs {
 // anything far away is looked at; phase 2 walks the bin rows centre-out with the x-extent and the stop test taken
 // from the largest threshold in the wave, skipping the bins phase 1 already did.
 template <int N, bool WANT_TRUNC = false, bool PLAIN = false>
-__device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, const float gx, const float gy, const float gz,
+__device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& st, const bool active, const float gx, const float gy, const float gz,
                                          const float ge, const float gl, unsigned long long (*keys)[64], const int lane, bool& overflow,
                                          bool& truncated) {
     // truncated: more usable observations than max_points existed, i.e. the reference took its sorted branch
@@ -211,11 +228,11 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
     int cnt = 0;
     overflow = false;
     truncated = false;
-    const float R = a.st.R;
+    const float R = st.R;
     const int K = a.K;
     const bool bounded = a.max_points > 0 && a.max_points <= N;
-    const float h2 = a.st.h * a.st.h;
-    const bool prune = bounded && (PLAIN || a.st.kh == SK_BARNES);   // rho <= rho_h(d) with the closed-form inverse of the Barnes kernel
+    const float h2 = st.h * st.h;
+    const bool prune = bounded && (PLAIN || st.kh == SK_BARNES);   // rho <= rho_h(d) with the closed-form inverse of the Barnes kernel
     float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
     float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
     const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
@@ -258,9 +275,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
                         const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        float rho = (!PLAIN && a.st.cv && dist <= a.st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(a.st.kh, dist, a.st.h);   // corr_background
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(a.st.kv, ge - oe, a.st.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(a.st.kw, gl - ol, a.st.w);
+                        float rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
                         if(rho > 0.0f) {   // oi.cpp:253
                             const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
                             const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
@@ -294,9 +311,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const bool active, c
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {
                         const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        float rho = (!PLAIN && a.st.cv && dist <= a.st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(a.st.kh, dist, a.st.h);   // corr_background
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(a.st.kv, ge - oe, a.st.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(a.st.kw, gl - ol, a.st.w);
+                        float rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
                         if(rho > 0.0f) truncated = true;
                     }
                 }

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_nearest_binned(const float4* __restrict
     out[q] = (besti == 0x7fffffff) ? -1 : besti;
 }
 
-static void nearest_device(gpp_points* p, const float* d_qx, const float* d_qy, const float* d_qz, int nq, int include_match, int* d_out) {
+void gpp_nearest_device(gpp_points* p, const float* d_qx, const float* d_qy, const float* d_qz, int nq, int include_match, int* d_out) {
     p->to_device();
     if(nq == 0) return;
     if(p->n > 2048 && !getenv("GPP_NN_BRUTE")) {
@@ -350,7 +350,7 @@ extern "C" int gpp_points_nearest_neighbour(gpp_points* p, const float* qlats, c
     DevBuf<int> dout;
     dx.upload(qx.data(), nq); dy.upload(qy.data(), nq); dz.upload(qz.data(), nq);
     dout.get(nq);
-    nearest_device(p, dx.p, dy.p, dz.p, nq, include_match, dout.p);
+    gpp_nearest_device(p, dx.p, dy.p, dz.p, nq, include_match, dout.p);
     GPP_HIP(hipMemcpyAsync(indices, dout.p, sizeof(int) * nq, hipMemcpyDeviceToHost, stream()));
     GPP_HIP(hipStreamSynchronize(stream()));
     return GPP_OK;
@@ -383,7 +383,7 @@ extern "C" int gpp_nearest(gpp_points* from, gpp_points* to, const float* values
         to->to_device();
         DevBuf<int> idx;
         idx.get(nq);
-        nearest_device(from, to->d_x.p, to->d_y.p, to->d_z.p, nq, 1, idx.p);
+        gpp_nearest_device(from, to->d_x.p, to->d_y.p, to->d_z.p, nq, 1, idx.p);
         hipLaunchKernelGGL(k_gather, dim3((nq + 255) / 256), dim3(256), 0, stream(), v.d, idx.p, nq, o.d);
         GPP_HIP(hipGetLastError());
         o.finish();

@@ -150,7 +150,7 @@ class StructureFunction {
   public:
     virtual ~StructureFunction() {}
     const gpp_structure* c_struct() const { return &mS; }
-    float localization_distance() const { float d; detail::check(gpp_structure_localization_distance(&mS, &d)); return d; }
+    float localization_distance() const { float d; detail::check(gpp_structure_localization_distance(&mS, 0.0f, 0.0f, &d)); return d; }
   protected:
     StructureFunction() { mS = gpp_structure(); }
     void init(int kind, float h, float v, float w, float hmax) {

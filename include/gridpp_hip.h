@@ -103,8 +103,8 @@ int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* ou
  * Scalar forms of BarnesStructure, CressmanStructure, SoarStructure, ToarStructure,
  * PowerlawStructure, LinearStructure (structure.cpp:143-167,287-299,317-341,467-491,
  * 618-642,765-789), MultipleStructure (:90-138: horizontal / vertical / laf factors taken
- * from three structures) and the CrossValidation wrapper (:910-944).  The spatially
- * varying forms (per-grid-point h, v, w) are not on the GPU path yet. */
+ * from three structures), the CrossValidation wrapper (:910-944) and the spatially varying
+ * forms (per-grid-point h, v, w looked up at the first point of corr(p1, p2), :168-214). */
 #define GPP_SK_BARNES 0
 #define GPP_SK_CRESSMAN 1
 #define GPP_SK_SOAR 2
@@ -122,14 +122,22 @@ typedef struct gpp_structure {
     float loc;       /* localization distance if flags & GPP_ST_HAS_LOC */
     float cv_dist;   /* CrossValidation distance if flags & GPP_ST_CV */
     int flags;
+    struct gpp_field* field;   /* spatially varying form: h, v, w fields (gpp_field_create); NULL = scalar */
 } gpp_structure;
+/* BarnesStructure(Grid, vec2 h, vec2 v, vec2 w, min_rho) and the Soar/Toar/Powerlaw/Linear equivalents
+ * (structure.cpp:168-184,342-358,...): h, v, w are host arrays with one value per point of `grid`
+ * (which must outlive the field). */
+typedef struct gpp_field gpp_field;
+int gpp_field_create(gpp_points* grid, const float* h, const float* v, const float* w, int kind, float min_rho, gpp_field** out);
+int gpp_field_destroy(gpp_field* field);
 /* m_min_rho of the scalar constructors from hmax (NaN: default 0.0013); validates h >= 0, hmax >= 0 */
 int gpp_structure_min_rho(int kind, float h, float hmax, float* min_rho);
-/* StructureFunction::localization_distance (structure.cpp:87-89,271-282,454-459,604-610,755-757,902-904) */
-int gpp_structure_localization_distance(const gpp_structure* s, float* dist);
+/* StructureFunction::localization_distance(Point) (structure.cpp:87-89,271-282,454-459,604-610,755-757,902-904);
+ * (lat, lon) only matters for the spatially varying forms */
+int gpp_structure_localization_distance(const gpp_structure* s, float lat, float lon, float* dist);
 /* corr (background = 0) / corr_background (background = 1) for one pair of points given as
- * (x, y, z, elev, laf) -- runs the same device code as the OI kernels */
-int gpp_structure_corr(const gpp_structure* s, const float p1[5], const float p2[5], int background, float* rho);
+ * (x, y, z, elev, laf, lat, lon) -- runs the same device code as the OI kernels */
+int gpp_structure_corr(const gpp_structure* s, const float p1[7], const float p2[7], int background, float* rho);
 
 /* ---- optimal interpolation ------------------------------------------------
  * replaces gridpp::optimal_interpolation_full (src/api/oi.cpp:138-341, Points

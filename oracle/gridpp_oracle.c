@@ -434,7 +434,11 @@ int orc_oi_full_generic(int nY,
                 int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
                 const float* pobs, const float* obs_variance, const float* pbackground, const float* bvariance_at_points,
                 int kh, int kv, int kw, float h, float v, float w, float loc, int cv, float cv_dist,
-                int max_points, int allow_extrapolation, float* out, float* out_var) {
+                int max_points, int allow_extrapolation, float* out, float* out_var,
+                /* spatially varying form (structure.cpp:168-214): parameters at the FIRST point of corr(p1, p2);
+                   per background point [nY] and per observation [nS]; all NULL for the scalar forms */
+                const float* c_h, const float* c_v, const float* c_w, const float* c_R,
+                const float* o_h, const float* o_v, const float* o_w, const float* o_R) {
     if(max_points < 0) return ORC_EINVAL;
     orc_struct st = {kh, kv, kw, h, v, w, loc, cv, cv_dist};
     for(int y = 0; y < nY; y++) { out[y] = background[y]; out_var[y] = bvariance[y]; }
@@ -446,9 +450,11 @@ int orc_oi_full_generic(int nY,
     for(int y = 0; y < nY && rc == ORC_OK; y++) {
         if(!orc_valid(background[y])) continue;
         int n = 0;
+        orc_struct sc = st;   /* the structure as seen from this grid point */
+        if(c_h) { sc.h = c_h[y]; sc.v = c_v[y]; sc.w = c_w[y]; sc.loc = c_R[y]; }
         for(int s = 0; s < nS; s++) {
-            if(!orc_in_radius(gx[y], gy[y], gz[y], ox[s], oy[s], oz[s], loc, 1)) continue;
-            float rho = orc_corr_g(&st, gx[y], gy[y], gz[y], gelev[y], glaf[y], ox[s], oy[s], oz[s], oelev[s], olaf[s], 1);
+            if(!orc_in_radius(gx[y], gy[y], gz[y], ox[s], oy[s], oz[s], sc.loc, 1)) continue;
+            float rho = orc_corr_g(&sc, gx[y], gy[y], gz[y], gelev[y], glaf[y], ox[s], oy[s], oz[s], oelev[s], olaf[s], 1);
             if(!orc_valid(pobs[s]) || !orc_valid(pbackground[s])) continue;
             if(rho > 0) { work[n].rho = rho; work[n].idx = s; n++; }
         }
@@ -462,9 +468,11 @@ int orc_oi_full_generic(int nY,
             int si = work[i].idx;
             d[i] = (double)pobs[si] - (double)pbackground[si];
             G[i] = (double)work[i].rho;
+            orc_struct so = st;   /* the structure as seen from observation i (oi.cpp:304-310) */
+            if(o_h) { so.h = o_h[si]; so.v = o_v[si]; so.w = o_w[si]; so.loc = o_R[si]; }
             for(int j = 0; j < lS; j++) {
                 int sj = work[j].idx;
-                A[i * lS + j] = (double)orc_corr_g(&st, ox[si], oy[si], oz[si], oelev[si], olaf[si],
+                A[i * lS + j] = (double)orc_corr_g(&so, ox[si], oy[si], oz[si], oelev[si], olaf[si],
                                                   ox[sj], oy[sj], oz[sj], oelev[sj], olaf[sj], 0);
             }
             A[i * lS + i] += (double)pratios[si];

@@ -147,7 +147,8 @@ class Struct:
 
 
 def oi_full_generic(g, background, bvariance, p, obs, obs_variance, pbackground, bvariance_at_points, st, max_points,
-                    allow_extrapolation=True):
+                    allow_extrapolation=True, cell_params=None, obs_params=None):
+    """cell_params / obs_params: (h, v, w, R) arrays per background point / per observation for the spatially varying form"""
     background, bvariance = _f(background).ravel(), _f(bvariance).ravel()
     obs, obs_variance, pbackground, bvp = _f(obs), _f(obs_variance), _f(pbackground), _f(bvariance_at_points)
     out = np.empty(g.n, np.float32)
@@ -157,9 +158,18 @@ def oi_full_generic(g, background, bvariance, p, obs, obs_variance, pbackground,
                                    p.elevs.ctypes, p.lafs.ctypes, obs.ctypes, obs_variance.ctypes, pbackground.ctypes, bvp.ctypes,
                                    C.c_int(st.kh), C.c_int(st.kv), C.c_int(st.kw), C.c_float(st.h), C.c_float(st.v), C.c_float(st.w),
                                    C.c_float(st.loc), C.c_int(st.cv), C.c_float(st.cv_dist), C.c_int(max_points),
-                                   C.c_int(1 if allow_extrapolation else 0), out.ctypes, var.ctypes)
+                                   C.c_int(1 if allow_extrapolation else 0), out.ctypes, var.ctypes,
+                                   *[(_f(a).ctypes if a is not None else None) for a in (cell_params or [None] * 4)],
+                                   *[(_f(a).ctypes if a is not None else None) for a in (obs_params or [None] * 4)])
     _check(rc)
     return out, var
+
+
+def structure_localization(kind, h, min_rho):
+    L = lib()
+    L.orc_structure_localization_distance.restype = C.c_float
+    k = Struct.KINDS[kind] if isinstance(kind, str) else kind
+    return float(L.orc_structure_localization_distance(C.c_int(k), C.c_float(h), C.c_float(min_rho)))
 
 
 def oi_full(g, background, bvariance, p, obs, obs_variance, pbackground, bvariance_at_points,

@@ -219,3 +219,66 @@ def test_too_many_points_fails_loudly():
     points = gridpp.Points(c["plat"], c["plon"])
     with pytest.raises(RuntimeError, match="more than 62"):
         gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], gridpp.BarnesStructure(40000), 0)
+
+
+# ---- spatially varying structure functions (structure.cpp:168-214) ------------------------------------------------------
+def test_spatial_barnes_pin():
+    """tests/test_barnes_structure.py:46-66"""
+    import gridpp_amd as gridpp
+    y, x = [[0, 0]], [[0, 2500]]
+    grid = gridpp.Grid(y, x, y, y, gridpp.Cartesian)
+    min_rho = 0.1
+    st = gridpp.BarnesStructure(grid, [[2500, 1]], [[0, 0]], [[0, 0]], min_rho)
+    p1 = gridpp.Point(0, 0, 0, 0, gridpp.Cartesian)
+    p2 = gridpp.Point(0, 2500, 0, 0, gridpp.Cartesian)
+    assert abs(st.localization_distance(p1) - np.sqrt(-2 * np.log(min_rho)) * 2500) < 5e-5 * 2500
+    assert abs(st.corr(p1, p2) - 0.6) < 0.05
+    assert abs(st.localization_distance(p2) - np.sqrt(-2 * np.log(min_rho)) * 1) < 5e-5
+    assert abs(st.corr(p2, p1) - 0) < 0.05
+    yy, xx = np.meshgrid(np.linspace(0, 1, 2), np.linspace(0, 1, 3))
+    g2 = gridpp.Grid(yy, xx, yy, yy, gridpp.Cartesian)
+    valid = np.ones([3, 2])
+    gridpp.BarnesStructure(g2, valid, valid, valid)
+    for inval in (np.ones([3, 4]), np.ones([2, 2]), np.ones([2, 4])):
+        for args in ((inval, valid, valid), (valid, inval, valid), (valid, valid, inval)):
+            with pytest.raises(ValueError):
+                gridpp.BarnesStructure(g2, *args)
+
+
+@pytest.mark.parametrize("kind", ["Barnes", "Soar", "Powerlaw"])
+@pytest.mark.parametrize("same_grid", [True, False])
+def test_spatially_varying_structure(kind, same_grid):
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    c = make_case(90, 30, 34, 100, with_elev=True)
+    Y, X = c["bg"].shape
+    rng = np.random.default_rng(5)
+    if same_grid:
+        flat_, flon_ = c["lats"], c["lons"]
+    else:   # a coarser field grid: nearest-neighbour lookup for every grid point and observation
+        flat_, flon_ = np.meshgrid(np.linspace(0, 1, 9), np.linspace(0, 1, 11), indexing="ij")
+    base = {"Barnes": 9000, "Soar": 2500, "Powerlaw": 2000}[kind]
+    hf = (base * rng.uniform(0.7, 1.3, flat_.shape)).astype(np.float32)
+    vf = (300 * rng.uniform(0.7, 1.3, flat_.shape)).astype(np.float32)
+    wf = (0.6 * rng.uniform(0.7, 1.3, flat_.shape)).astype(np.float32)
+    min_rho = 0.0013
+    grid = gridpp.Grid(c["lats"], c["lons"], c["gelev"], c["glaf"])
+    fgrid = grid if same_grid else gridpp.Grid(flat_, flon_)
+    points = gridpp.Points(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    st = getattr(gridpp, kind + "Structure")(fgrid, hf, vf, wf, min_rho)
+    ones_g, ones_p = np.ones((Y, X), np.float32), np.ones(c["obs"].size, np.float32)
+    out, var = gridpp.optimal_interpolation_full(grid, c["bg"], ones_g, points, c["obs"], c["ratios"], c["pbg"], ones_p, st, 10)
+    # oracle: parameters at the nearest field point of every background point / observation
+    og = O.Pts(c["lats"].ravel(), c["lons"].ravel(), c["gelev"].ravel(), c["glaf"].ravel())
+    op = O.Pts(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    of = O.Pts(flat_.ravel(), flon_.ravel())
+    ci, oi = O.nearest_indices(of, og), O.nearest_indices(of, op)
+    Rf = np.array([O.structure_localization(kind, h, min_rho) for h in hf.ravel()], np.float32)
+    cp = [a.ravel()[ci] for a in (hf, vf, wf)] + [Rf[ci]]
+    opar = [a.ravel()[oi] for a in (hf, vf, wf)] + [Rf[oi]]
+    ost = O.Struct(kind, base)
+    ref, rvar = O.oi_full_generic(og, c["bg"].ravel(), ones_g.ravel(), op, c["obs"], c["ratios"], c["pbg"], ones_p, ost, 10,
+                                  True, cp, opar)
+    check(np.asarray(out), ref.reshape(Y, X))
+    check(np.asarray(var), rvar.reshape(Y, X))
+    assert np.abs(np.asarray(out) - c["bg"]).max() > 0.05
