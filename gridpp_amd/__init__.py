@@ -172,6 +172,13 @@ class _PointSet:
             return idx[:cnt.value].copy(), dist[:cnt.value].copy()
         return idx[:cnt.value].copy()
 
+    def _closest(self, lat, lon, num, include_match=True):
+        idx = np.empty(max(int(num), 1), np.int32)
+        cnt = C.c_int(0)
+        check(lib().gpp_points_get_closest_neighbours(self._h, float(lat), float(lon), int(num), int(bool(include_match)),
+                                                      _ptr(idx), C.byref(cnt)))
+        return idx[:cnt.value].copy()
+
     def _nearest_flat(self, lats, lons, include_match=True):
         lats, lons = _vec(lats, 1), _vec(lons, 1)
         out = np.empty(lats.size, np.int32)
@@ -223,6 +230,9 @@ class Points(_PointSet):
 
     def get_nearest_neighbour(self, lat, lon, include_match=True):
         return int(self._nearest_flat([lat], [lon], include_match)[0])
+
+    def get_closest_neighbours(self, lat, lon, num, include_match=True):
+        return self._closest(lat, lon, num, include_match)
 
     def get_point(self, index):   # src/api/points.cpp:128-130
         f = [self._field(k)[index] for k in range(7)]
@@ -290,6 +300,10 @@ class Grid(_PointSet):
 
     def get_neighbours(self, lat, lon, radius, include_match=True):
         idx = self._neighbours(lat, lon, radius, include_match)
+        return np.stack([idx // self._nx, idx % self._nx], axis=1).astype(np.int32) if idx.size else np.zeros((0, 2), np.int32)
+
+    def get_closest_neighbours(self, lat, lon, num, include_match=True):   # grid.cpp:72-75
+        idx = self._closest(lat, lon, num, include_match)
         return np.stack([idx // self._nx, idx % self._nx], axis=1).astype(np.int32) if idx.size else np.zeros((0, 2), np.int32)
 
     def get_num_neighbours(self, lat, lon, radius, include_match=True):

@@ -42,6 +42,7 @@ SIGNATURES = {
     "gpp_points_get": [vp, C.c_int, vp],
     "gpp_convert_coordinates": [vp, vp, C.c_int, C.c_int, vp, vp, vp],
     "gpp_points_get_neighbours": [vp, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp, C.c_int, ip],
+    "gpp_points_get_closest_neighbours": [vp, C.c_float, C.c_float, C.c_int, C.c_int, vp, ip],
     "gpp_points_nearest_neighbour": [vp, vp, vp, C.c_int, C.c_int, vp],
     "gpp_nearest": [vp, vp, vp, vp, C.c_int],
     "gpp_structure_min_rho": [C.c_int, C.c_float, C.c_float, fp],

@@ -245,6 +245,33 @@ extern "C" int gpp_points_get_neighbours(gpp_points* p, float lat, float lon, fl
     GPP_CATCH
 }
 
+// KDTree::get_closest_neighbours (kdtree.cpp:82-103) for a single location (host; API completeness): the `num` nearest
+// points by float32 squared chord distance, nearest first, ties -> lower index (the R-tree's order is unspecified).
+extern "C" int gpp_points_get_closest_neighbours(gpp_points* p, float lat, float lon, int num, int include_match, int* indices, int* count) {
+    GPP_TRY
+    if(!p || !count) invalid("NULL argument");
+    *count = 0;
+    if(num <= 0 || p->n == 0) return GPP_OK;
+    float qx, qy, qz;
+    convert_all(&lat, &lon, 1, p->type, &qx, &qy, &qz);
+    std::vector<std::pair<float, int>> d;
+    d.reserve(p->n);
+    for(int i = 0; i < p->n; i++) {
+        const float px = p->x[i], py = p->y[i], pz = p->z[i];
+        if(!include_match && px == qx && py == qy && pz == qz) continue;   // kdtree.cpp:265-270
+        const float dx = px - qx, dy = py - qy, dz = pz - qz;
+        float s2 = dx * dx + dy * dy;
+        s2 = s2 + dz * dz;
+        d.emplace_back(s2, i);
+    }
+    const int k = std::min<int>(num, (int)d.size());
+    std::partial_sort(d.begin(), d.begin() + k, d.end());
+    for(int i = 0; i < k; i++) indices[i] = d[i].second;
+    *count = k;
+    return GPP_OK;
+    GPP_CATCH
+}
+
 // ---- nearest neighbour (device, brute force over the point set; one wave per query) ----
 // Metric = float32 squared chord distance in the reference's operation order (Boost
 // comparable_distance on point<float,3>); ties -> lowest index (R-tree order is unspecified).

@@ -89,6 +89,10 @@ int gpp_convert_coordinates(const float* lats, const float* lons, int n, int coo
  * (lat, lon).  Writes at most `cap` indices; *count is the full count. */
 int gpp_points_get_neighbours(gpp_points* p, float lat, float lon, float radius, int include_match,
                               int* indices, float* distances /* may be NULL */, int cap, int* count);
+/* KDTree::get_closest_neighbours (src/api/kdtree.cpp:82-103): the `num` nearest points, nearest first;
+ * indices must hold `num` ints, *count is the number found. */
+int gpp_points_get_closest_neighbours(gpp_points* p, float lat, float lon, int num, int include_match,
+                                      int* indices, int* count);
 /* KDTree::get_nearest_neighbour / Points::get_nearest_neighbour
  * (src/api/kdtree.cpp:82-106, src/api/points.cpp:55-61) for nq query points
  * (host arrays); index -1 when the set is empty or nothing qualifies. */

@@ -42,6 +42,9 @@ def test_host_only_entry_points_work_without_gpu(lib):
     np.testing.assert_allclose(z, [0, 6.378137e6], atol=1)
     p = gridpp.Points([0, 1000, 2000], [0, 0, 0], [0, 0, 0], [0, 0, 0], gridpp.Cartesian)
     np.testing.assert_array_equal(p.get_neighbours(0, 0, 1001), [0, 1])
+    np.testing.assert_array_equal(p.get_closest_neighbours(900, 0, 2), [1, 0])     # tests/test_points.py style k-NN
+    np.testing.assert_array_equal(p.get_closest_neighbours(900, 0, 5), [1, 0, 2])
+    np.testing.assert_array_equal(gridpp.Points().get_closest_neighbours(0, 0, 5), [])
     with pytest.raises(ValueError):
         gridpp.Points([91], [0])
     g = gridpp.Grid(np.zeros((3, 4)), np.zeros((3, 4)))
