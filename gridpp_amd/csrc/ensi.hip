@@ -413,7 +413,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 4, stream()));
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
 
-    EnsiArgs a;
+    EnsiArgs a = EnsiArgs();
     a.gx = bgrid->d_x.p; a.gy = bgrid->d_y.p; a.gz = bgrid->d_z.p; a.gelev = bgrid->d_elev.p; a.glaf = bgrid->d_laf.p;
     a.bg = f_bg.d; a.out = f_out.d;
     a.C = C; a.E = E; a.ny = bgrid->ny; a.nx = bgrid->nx;

@@ -593,7 +593,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     // register-tile size of the solve: 32 rows (max_points <= 32, the common case) or 62 rows (everything up to 62
     // usable observations per grid point; one member cell per factorisation)
     const int N = (max_points > 0 && max_points <= 32) ? 32 : 62;
-    OiArgs a;
+    OiArgs a = OiArgs();
     a.gx = bgrid->d_x.p; a.gy = bgrid->d_y.p; a.gz = bgrid->d_z.p; a.gelev = bgrid->d_elev.p; a.glaf = bgrid->d_laf.p;
     a.bg = f_bg.d; a.bvar = f_bvar.d; a.out = f_out.d; a.out_var = f_var.d;
     a.C = C; a.ny = bgrid->ny; a.nx = bgrid->nx;
@@ -608,7 +608,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     gpp_bind_field(a.s.st, st, bgrid, points, ws.cell_idx, ws.obs_idx);
     a.s.max_points = max_points;
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
-      const int kk = a.s.K;
+      const int kk = (max_points > 0 && max_points <= N) ? max_points : N;
       a.s.q0 = std::max(1, std::min(8, (int)std::ceil(0.5 * (std::sqrt(1.6 * kk / std::max(occ, 1e-3)) - 1.0)))); }
     a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
