@@ -58,7 +58,7 @@ def cpu_baseline(ny, nx, S, seed, h, max_points, target_s=12.0):
     ncal = min(nx, 64)
     O.oi(og, bg[row], op, obs, ratios, pbg, st, max_points, True, 0, ncal)
     per_cell = (time.perf_counter() - t0) / ncal
-    cells_target = int(target_s / per_cell * threads * 0.25)
+    cells_target = int(target_s / per_cell * threads * 0.1)
     nrows = max(threads, min(ny, cells_target // nx))
     rows = np.linspace(0, ny - 1, nrows).astype(int)
     sets = [(O.Pts(lats[r], lons[r]), bg[r]) for r in rows]
