@@ -214,16 +214,28 @@ __global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (idx < nf4 ? idx : nf4 - 1)), (lds_void_t*)(dst + k * 64), 16, 0, 0);
             }
         };
-        int b = 0;
-        if((long)blockIdx.x < nfull) issue(blockIdx.x, 0);
-        for(long tile = blockIdx.x; tile < nfull; tile += gridDim.x) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed in buffer b
-            __syncthreads();
-            const long nxt = tile + gridDim.x;
-            if(nxt < nfull) issue(nxt, b ^ 1);                   // next tile flies during the row walk
-            const float* row = reinterpret_cast<const float*>(lds4 + b * bufstride) + lane * E;
-            member_row_work<MODE>(row, E, (E & 3) == 0, statistic, thr, T, out, C, tile * 64 + lane);
-            b ^= 1;
+        if(MODE == 1) {
+            // threshold counting is VALU-bound (2*T*E compare/adds per cell): a single buffer doubles the resident waves
+            for(long tile = blockIdx.x; tile < nfull; tile += gridDim.x) {
+                __syncthreads();                                    // previous tile fully consumed
+                issue(tile, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                member_row_work<MODE>(reinterpret_cast<const float*>(lds4) + lane * E, E, (E & 3) == 0, statistic, thr, T, out, C, tile * 64 + lane);
+            }
+        }
+        else {
+            int b = 0;
+            if((long)blockIdx.x < nfull) issue(blockIdx.x, 0);
+            for(long tile = blockIdx.x; tile < nfull; tile += gridDim.x) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed in buffer b
+                __syncthreads();
+                const long nxt = tile + gridDim.x;
+                if(nxt < nfull) issue(nxt, b ^ 1);                   // next tile flies during the row walk
+                const float* row = reinterpret_cast<const float*>(lds4 + b * bufstride) + lane * E;
+                member_row_work<MODE>(row, E, (E & 3) == 0, statistic, thr, T, out, C, tile * 64 + lane);
+                b ^= 1;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the last, partial tile (if any): lane-private walk straight from memory, on block 0
@@ -478,7 +490,7 @@ void member_pass_launch(const float* d_in, long C, int E, int statistic, const f
     const long tiles = (C + 63) / 64;
     const int nchunk = (16 * E + 63) / 64;
     const bool dma = E <= MEMBER_EC && (reinterpret_cast<size_t>(d_in) & 15) == 0;
-    const size_t lds = dma ? (size_t)2 * nchunk * 1024 : 16;   // double buffer of whole 1 KiB chunks
+    const size_t lds = dma ? (size_t)(MODE == 1 ? 1 : 2) * nchunk * 1024 : 16;   // (double) buffer of whole 1 KiB chunks
     static bool attr = false;
     if(!attr) { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((16 * MEMBER_EC + 63) / 64) * 1024)); attr = true; }
     const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds, 1)));
