@@ -52,3 +52,24 @@ def gpu_compute(lats, lons, bg, plats, plons, obs, ratios, pbg, structure_args, 
     points = gridpp.Points(plats, plons)
     return gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, gridpp.BarnesStructure(*structure_args),
                                         max_points, allow_extrapolation)
+
+
+def halo_rows(ny, rank, world, halfwidth):
+    """Rows [lo, hi) a rank must hold to compute the neighbourhood filter on its tile [row0, row1): the tile plus a
+    read-only halo of `halfwidth` rows on each side, clipped at the true domain edge (src/api/neighbourhood.cpp:104-107
+    clips windows only there).  Returns (lo, hi, row0, row1)."""
+    row0, row1 = row_tile(ny, rank, world)
+    return max(0, row0 - halfwidth), min(ny, row1 + halfwidth), row0, row1
+
+
+def tiled_neighbourhood(field, halfwidth, statistic, rank, world, compute):
+    """This rank's row tile of neighbourhood(field, halfwidth, statistic): compute on tile + halo, keep the tile.
+
+    compute(sub_field, halfwidth, statistic) -> 2-D array is the single-GPU entry point
+    (gridpp_amd.neighbourhood on a GPU box; the CPU tests inject the oracle).  Exact for every statistic: a window
+    never reaches beyond `halfwidth` rows, and the clipped windows at the domain edge see the same rows as in the
+    single-process call.  (The separable box sums make this possible; the reference's global summed-area table has a
+    prefix dependence over the whole image.)"""
+    lo, hi, row0, row1 = halo_rows(np.shape(field)[0], rank, world, halfwidth)
+    sub = compute(field[lo:hi], halfwidth, statistic)
+    return row0, row1, sub[row0 - lo:row0 - lo + (row1 - row0)]

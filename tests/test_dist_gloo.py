@@ -71,3 +71,20 @@ def test_two_rank_gloo_tiles_equal_single_process(tmp_path):
         out[row0:row1] = np.load(tmp_path / ("tile%d.npy" % r))
     np.testing.assert_array_equal(out, ref)
     assert np.abs(ref - bg).max() > 0.05
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("hw", [0, 2, 7, 40])
+def test_neighbourhood_halo_tiles_equal_single_call(world, hw):
+    """Row tiles + halfwidth-row halo reproduce the single-call neighbourhood exactly (oracle as the compute stage)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    f = rng.uniform(0, 10, (37, 23)).astype(np.float32)
+    f[4:7, 3:9] = np.nan
+    for stat in (O.Mean, O.Max, O.Count):
+        ref = O.neighbourhood(f, hw, stat)
+        out = np.full_like(ref, -1)
+        for r in range(world):
+            row0, row1, tile = gdist.tiled_neighbourhood(f, hw, stat, r, world, O.neighbourhood)
+            out[row0:row1] = tile
+        np.testing.assert_array_equal(out, ref)
