@@ -187,20 +187,8 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
         int nsolve = 0;
         bool bad = false;
         constexpr int MEMB = 63 - N;   // lanes N+1..63 carry one member cell each
-        while(todo) {
-            const int l = __builtin_ctzll(todo);
-            const int n = __builtin_amdgcn_readlane(cnt, l);
-            const unsigned long long l1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h1 >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h1, l);
-            const unsigned long long l2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h2s >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h2s, l);
-            unsigned long long members = __ballot(cnt == n && h1 == l1 && h2s == l2) & todo;
-            // at most MEMB members per pass
-            int nm = __popcll(members);
-            if(nm > MEMB) {
-                const int cut = nth_set_bit(members, MEMB);
-                members &= (1ull << cut) - 1ull;
-                nm = MEMB;
-            }
-            todo &= ~members;
+        // one group = one distinct observation set: leader lane l (n observations), member cells `members` (nm of them)
+        auto solve_group = [&](const int l, const int n, const unsigned long long members, const int nm) {
             nsolve++;
             // lane i < n takes the i-th selected observation of the leader; lane N+1+m takes member cell m
             const unsigned orig_i = (lane < n) ? origs[lane][l] : 0u;
@@ -362,6 +350,117 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                     s_res[wid][1][src] = (float)((double)cbv * (1.0 - a00));   // oi.cpp:337
                 }
                     }
+        };
+
+        // Two single-member groups at once, one per half-wave (lanes 0-31 / 32-63): rows 0..n-1 of (P+R), row 30 = obs -
+        // background, row 31 = G of the cell; broadcasts stay inside a half (ds_bpermute instead of v_readlane).  This is
+        // the common case when every cell has its own observation set (e.g. elevation-dependent structure functions).
+        auto solve_pair = [&](const int la, const int lb) {
+            nsolve += 2;
+            const int base = lane & 32, hl = lane & 31;
+            const int lh = base ? lb : la;                       // this half's cell
+            const int na = __builtin_amdgcn_readlane(cnt, la), nb = __builtin_amdgcn_readlane(cnt, lb);
+            const int nh = base ? nb : na, nmax = max(na, nb);
+            const unsigned orig_i = (hl < nh) ? origs[hl][lh] : 0u;
+            float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
+            if(hl < nh) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
+            const bool is_g = hl == 31;
+            float px = __shfl(gx, lh), py = __shfl(gy, lh), pz = __shfl(gz, lh), pe = __shfl(ge, lh), pl = __shfl(gl, lh);
+            const float cbg = __shfl(bg, lh), cbv = __shfl(bvar, lh);
+            if(hl < nh) { px = o0.x; py = o0.y; pz = o0.z; pe = o0.w; pl = o1.x; }
+            float maxInc = -INFINITY, minInc = INFINITY;
+            for(int p = 0; p < nmax; ++p) {
+                const int sp = base + p;
+                const float xp = __shfl(o0.x, sp), yp = __shfl(o0.y, sp), zp = __shfl(o0.z, sp);
+                const float ep = __shfl(o0.w, sp), lp = __shfl(o1.x, sp);
+                const float c = d_corr_t<PLAIN>(a.s.st, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
+                colbuf[p][lane] = (p < nh) ? c : 0.0f;
+                const float dpf = (float)((double)__shfl(o1.y, sp) - (double)__shfl(o1.z, sp));
+                if(p < nh) { maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf); }
+            }
+            double row[30];
+            const bool used = hl < nh || hl >= 30;
+#pragma unroll
+            for(int p = 0; p < 30; ++p) {
+                double v = 0.0;
+                if(p < nmax) {
+                    v = (double)colbuf[p][lane];
+                    if(hl == p) v += (double)o1.w;
+                    const double dp = (double)__shfl(o1.y, base + p) - (double)__shfl(o1.z, base + p);
+                    if(hl == 30) v = dp;
+                    if(!used || p >= nh) v = 0.0;
+                }
+                row[p] = v;
+            }
+#pragma unroll
+            for(int j = 0; j < 30; ++j) {
+                if(j < nmax) {
+                    const double ajj = __shfl(row[j], base + j);
+                    const bool colok = j < nh;
+                    if(colok && !(ajj > 0.0)) bad = true;
+                    double rs = __builtin_amdgcn_rsq(colok ? ajj : 1.0);
+                    const double aj = colok ? ajj : 1.0;
+                    rs = rs * (1.5 - 0.5 * aj * rs * rs);
+                    rs = rs * (1.5 - 0.5 * aj * rs * rs);
+                    const double cj = colok ? row[j] * rs : 0.0;
+                    row[j] = cj;
+#pragma unroll
+                    for(int p = j + 1; p < 30; ++p) {
+                        const double lpj = __shfl(cj, base + p);
+                        row[p] = __builtin_fma(-cj, lpj, row[p]);
+                    }
+                }
+            }
+            double inc = 0.0, a00 = 0.0;
+#pragma unroll
+            for(int p = 0; p < 30; ++p) {
+                const double tp = __shfl(row[p], base + 30);
+                inc = __builtin_fma(row[p], tp, inc);
+                a00 = __builtin_fma(row[p], row[p], a00);
+            }
+            if(is_g) {
+                float increment = (float)inc;
+                if(!a.allow_extrap) {
+                    if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                    else if(maxInc < 0 && increment > 0) increment = maxInc;
+                    else if(minInc < 0 && increment < minInc) increment = minInc;
+                    else if(minInc > 0 && increment < 0) increment = minInc;
+                }
+                s_res[wid][0][lh] = cbg + increment;
+                s_res[wid][1][lh] = (float)((double)cbv * (1.0 - a00));
+            }
+        };
+
+        constexpr bool PAIRS = !LU && !SPATIAL && N == 32;
+        unsigned long long singles = 0ull;
+        while(todo) {
+            const int l = __builtin_ctzll(todo);
+            const int n = __builtin_amdgcn_readlane(cnt, l);
+            const unsigned long long l1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h1 >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h1, l);
+            const unsigned long long l2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h2s >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h2s, l);
+            unsigned long long members = __ballot(cnt == n && h1 == l1 && h2s == l2) & todo;
+            // at most MEMB members per pass
+            int nm = __popcll(members);
+            if(nm > MEMB) {
+                const int cut = nth_set_bit(members, MEMB);
+                members &= (1ull << cut) - 1ull;
+                nm = MEMB;
+            }
+            todo &= ~members;
+            if(PAIRS && nm == 1 && n <= 30) singles |= 1ull << l;
+            else solve_group(l, n, members, nm);
+        }
+        if constexpr(PAIRS) {
+            while(singles) {
+                const int la = __builtin_ctzll(singles);
+                singles &= singles - 1;
+                if(singles) {
+                    const int lb = __builtin_ctzll(singles);
+                    singles &= singles - 1;
+                    solve_pair(la, lb);
+                }
+                else solve_group(la, __builtin_amdgcn_readlane(cnt, la), 1ull << la, 1);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if(cnt > 0) { res_out = s_res[wid][0][lane]; res_var = s_res[wid][1][lane]; }
