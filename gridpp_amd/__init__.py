@@ -251,10 +251,72 @@ class KDTree(Points):
     def __init__(self, lats=(), lons=(), type=Geodetic):
         Points.__init__(self, lats, lons, (), (), type)
 
+    # static distance helpers (src/api/kdtree.cpp:107-200); host scalar math like the reference's
     @staticmethod
-    def calc_straight_distance(x0, y0, z0, x1, y1, z1):
+    def calc_straight_distance(*args):
+        """(p1, p2) or (x0, y0, z0, x1, y1, z1): 3-D chord length in float32 (kdtree.cpp:189-194)"""
+        if len(args) == 2:
+            p1, p2 = args
+            args = (p1.x, p1.y, p1.z, p2.x, p2.y, p2.z)
         f = np.float32
-        return float(np.sqrt((f(x0) - f(x1)) * (f(x0) - f(x1)) + (f(y0) - f(y1)) * (f(y0) - f(y1)) + (f(z0) - f(z1)) * (f(z0) - f(z1)), dtype=np.float32))
+        x0, y0, z0, x1, y1, z1 = (f(a) for a in args)
+        return float(np.sqrt((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1) + (z0 - z1) * (z0 - z1), dtype=np.float32))
+
+    @staticmethod
+    def deg2rad(deg):
+        return float(np.float32(np.float64(np.float32(deg)) * np.pi / 180))
+
+    @staticmethod
+    def rad2deg(rad):
+        return float(np.float32(np.float64(np.float32(rad)) * 180 / np.pi))
+
+    @staticmethod
+    def calc_distance(*args):
+        """(p1, p2) or (lat1, lon1, lat2, lon2, type=Geodetic): great-circle distance (kdtree.cpp:107-136,182-187)"""
+        if len(args) == 2:
+            p1, p2 = args
+            if p1.type != p2.type:
+                raise RuntimeError("Coordinate types must be the same")
+            args = (p1.lat, p1.lon, p2.lat, p2.lon, p1.type)
+        lat1, lon1, lat2, lon2 = (np.float32(a) for a in args[:4])
+        ctype = args[4] if len(args) > 4 else Geodetic
+        if ctype == Cartesian:
+            dx, dy = lon1 - lon2, lat1 - lat2
+            return float(np.sqrt(dx * dx + dy * dy, dtype=np.float32))
+        if lat1 == lat2 and lon1 == lon2:
+            return 0.0
+        r = [np.float64(np.float32(np.float64(v) * np.pi / 180)) for v in (lat1, lat2, lon1, lon2)]   # deg2rad returns float
+        lat1r, lat2r, lon1r, lon2r = r
+        ratio = (np.cos(lat1r) * np.cos(lon1r) * np.cos(lat2r) * np.cos(lon2r) + np.cos(lat1r) * np.sin(lon1r) * np.cos(lat2r) * np.sin(lon2r)
+                 + np.sin(lat1r) * np.sin(lat2r))
+        return float(np.float32(np.arccos(ratio) * 6.378137e6))
+
+    @staticmethod
+    def calc_distance_fast(*args):
+        """(p1, p2) or (lat1, lon1, lat2, lon2, type=Geodetic): equirectangular approximation (kdtree.cpp:137-181)"""
+        if len(args) == 2:
+            p1, p2 = args
+            args = (p1.lat, p1.lon, p2.lat, p2.lon, p1.type)
+        lat1, lon1, lat2, lon2 = (np.float32(a) for a in args[:4])
+        ctype = args[4] if len(args) > 4 else Geodetic
+        if ctype == Cartesian:
+            dx, dy = lon1 - lon2, lat1 - lat2
+            return float(np.sqrt(dx * dx + dy * dy, dtype=np.float32))
+        lat1r, lat2r, lon1r, lon2r = [np.float64(np.float32(np.float64(v) * np.pi / 180)) for v in (lat1, lat2, lon1, lon2)]
+        dlon = np.fmod(np.abs(lon1r - lon2r), 2 * np.pi)
+        if dlon > np.pi:
+            dlon = 2 * np.pi - dlon
+        max_lat = lat2r if np.abs(lat2r) > np.abs(lat1r) else lat1r
+        dx2 = np.float32(np.cos(max_lat) ** 2 * dlon * dlon)
+        dy2 = np.float32((lat1r - lat2r) * (lat1r - lat2r))
+        return float(np.float32(6.378137e6 * np.sqrt(np.float64(dx2 + dy2))))
+
+
+KDTree_calc_distance = KDTree.calc_distance
+KDTree_calc_distance_fast = KDTree.calc_distance_fast
+KDTree_calc_straight_distance = KDTree.calc_straight_distance
+KDTree_deg2rad = KDTree.deg2rad
+KDTree_rad2deg = KDTree.rad2deg
 
 
 class Grid(_PointSet):
