@@ -1,0 +1,121 @@
+"""Parity at the FULL sizes of BASELINE.json's configs, where the oracle cannot run the whole problem: the HIP path is
+checked on (a) a sample of cells against the oracle (cells are independent, so a sample is exact evidence for those cells),
+(b) size-independent properties: tile independence (the same cells computed as a Points list give the same bits),
+linearity in the innovations, pass-through where no observation is in range, window properties of the filters."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _headline(ny=4000, nx=4000, S=10000):
+    from bench import make_workload
+    return make_workload(ny, nx, S, 1002, 0, ny)
+
+
+def test_config3_oi_4000x4000_10k_obs():
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    lats, lons, bg, plat, plon, obs, ratios, pbg = _headline()
+    grid = gridpp.Grid(lats, lons)
+    points = gridpp.Points(plat, plon)
+    st = gridpp.BarnesStructure(10000)
+    out = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 30)
+    assert out.shape == bg.shape and np.isfinite(out).all()
+    assert np.abs(out - bg).max() > 0.5
+    # (a) oracle on a sample of cells: 3 grid rows strided + 300 random cells
+    rng = np.random.default_rng(0)
+    op, ost = O.Pts(plat, plon), O.Barnes(10000)
+    for r in (0, 1777, 3999):
+        cols = np.arange(0, 4000, 40)
+        ref = O.oi(O.Pts(lats[r, cols], lons[r, cols]), bg[r, cols], op, obs, ratios, pbg, ost, 30)
+        err = np.abs(out[r, cols].astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-3)
+        assert err.max() < 1e-5, (r, err.max())
+    iy, ix = rng.integers(0, 4000, 300), rng.integers(0, 4000, 300)
+    ref = O.oi(O.Pts(lats[iy, ix], lons[iy, ix]), bg[iy, ix], op, obs, ratios, pbg, ost, 30)
+    err = np.abs(out[iy, ix].astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-5
+    # (b) tile independence: the same cells as a Points list (different tiling, different neighbours in the wave)
+    sub = gridpp.optimal_interpolation(gridpp.Points(lats[iy, ix], lons[iy, ix]), bg[iy, ix], points, obs, ratios, pbg, st, 30)
+    np.testing.assert_array_equal(sub, out[iy, ix])
+    # (b) linearity in the innovations: with background == pbg == 0 the analysis is linear in obs
+    z_g, z_p = np.zeros_like(bg), np.zeros_like(pbg)
+    rows = slice(2000, 2008)
+    g8 = gridpp.Grid(lats[rows], lons[rows])
+    a1 = gridpp.optimal_interpolation(g8, z_g[rows], points, obs, ratios, z_p, st, 30)
+    a2 = gridpp.optimal_interpolation(g8, z_g[rows], points, 2 * obs, ratios, z_p, st, 30)
+    np.testing.assert_allclose(a2, 2 * a1, rtol=2e-6, atol=1e-6)
+
+
+def test_config2_oi_1000x1000_1k_obs():
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    from bench import make_workload
+    lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(1000, 1000, 1000, 1001, 0, 1000)
+    out = gridpp.optimal_interpolation(gridpp.Grid(lats, lons), bg, gridpp.Points(plat, plon), obs, ratios, pbg,
+                                       gridpp.BarnesStructure(10000), 20)
+    rng = np.random.default_rng(1)
+    iy, ix = rng.integers(0, 1000, 3000), rng.integers(0, 1000, 3000)
+    ref = O.oi(O.Pts(lats[iy, ix], lons[iy, ix]), bg[iy, ix], O.Pts(plat, plon), obs, ratios, pbg, O.Barnes(10000), 20)
+    np.testing.assert_array_equal(out[iy, ix], ref)   # bit-exact on every sampled cell
+
+
+def test_config4_neighbourhood_4000x4000x100():
+    import torch
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    Y = X = 4000
+    E, hw = 100, 15
+    g = torch.Generator(device="cuda").manual_seed(1003)
+    cube = torch.rand((Y, X, E), generator=g, device="cuda") * 10
+    mean = gridpp.neighbourhood(cube, hw, gridpp.Mean)
+    thr = torch.linspace(0, 10, 11, device="cuda")
+    qf = gridpp.neighbourhood_quantile_fast(cube, 0.5, hw, thr)
+    assert mean.shape == (Y, X) and bool(torch.isfinite(mean).all()) and bool(torch.isfinite(qf).all())
+    # (a) oracle on row bands: rows r-hw..r+hw of the cube give the exact answer for row r
+    for r in (0, 2000, 3999):
+        lo, hi = max(0, r - hw), min(Y, r + hw + 1)
+        cols = slice(1000, 1200)
+        band = cube[lo:hi, 1000 - hw:1200 + hw].cpu().numpy()
+        ref = O.neighbourhood(band, hw, O.Mean)[r - lo, hw:hw + 200]
+        got = mean[r, cols].cpu().numpy()
+        assert (np.abs(got - ref) / np.abs(ref)).max() < 1e-5
+        refq = O.neighbourhood_quantile_fast(band, [0.5], hw, thr.cpu().numpy())[r - lo, hw:hw + 200]
+        gotq = qf[r, cols].cpu().numpy()
+        assert (np.abs(gotq - refq) / np.maximum(np.abs(refq), 1e-3)).max() < 1e-5
+    # (b) properties: a mean of U(0,10) members over 31x31x100 values is ~5; bounded by the data range
+    assert 4.9 < float(mean[100:-100, 100:-100].mean()) < 5.1
+    assert float(mean.min()) >= 0 and float(mean.max()) <= 10
+    assert float(qf.min()) >= 0 and float(qf.max()) <= 10
+    # (b) halfwidth 0 on a 2-D field is the identity
+    f2 = cube[:, :, 0].contiguous()
+    assert torch.equal(gridpp.neighbourhood(f2, 0, gridpp.Mean), f2)
+    # (b) Min <= Mean <= Max pointwise
+    mn, mx, me = gridpp.neighbourhood(f2, 7, gridpp.Min), gridpp.neighbourhood(f2, 7, gridpp.Max), gridpp.neighbourhood(f2, 7, gridpp.Mean)
+    assert bool((mn <= me).all()) and bool((me <= mx).all())
+
+
+def test_config5_ensi_2500x2500x50_sample():
+    """Config 5 geometry (5 000 obs, 50 members, max_points 30) on a row band of the 2500x2500 grid + oracle sample."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    ny = nx = 2500
+    E, S = 50, 5000
+    rng = np.random.default_rng(1004)
+    rows = np.array([0, 1249, 2499])
+    lat1, lon1 = np.linspace(0, 1, ny)[rows], np.linspace(0, 1, nx)
+    lats, lons = np.meshgrid(lat1, lon1, indexing="ij")
+    bg = (np.sin(6 * lats) * np.cos(4 * lons) * 3)[:, :, None] + rng.normal(0, 1, (3, nx, E))
+    bg = bg.astype(np.float32)
+    plat, plon = rng.random(S), rng.random(S)
+    pbg = rng.normal(0, 1, (S, E)).astype(np.float32)
+    obs = rng.normal(0, 1, S).astype(np.float32)
+    sig = np.ones(S, np.float32)
+    out = gridpp.optimal_interpolation_ensi(gridpp.Grid(lats, lons), bg, gridpp.Points(plat, plon), obs, sig, pbg,
+                                            gridpp.BarnesStructure(10000), 30)
+    cols = np.arange(0, nx, 25)
+    for k in range(3):
+        ref = O.oi_ensi(O.Pts(lats[k, cols], lons[k, cols]), bg[k, cols], O.Pts(plat, plon), obs, sig, pbg, O.Barnes(10000), 30)
+        err = np.abs(out[k, cols].astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
+        assert err.max() < 1e-5, err.max()
+    assert np.abs(out - bg).max() > 0.1
