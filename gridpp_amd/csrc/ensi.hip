@@ -408,9 +408,9 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
                        f_obs.d, f_sig.d, (const float*)ws.gYhat.p, (const float*)nullptr, 0, ws.pgeo.p, ws.oaux.p);
     GPP_HIP(hipGetLastError());
-    ws.err.get(1); ws.counters.get(4);
+    ws.err.get(1); ws.counters.get(80);
     GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
-    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 4, stream()));
+    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 80, stream()));
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
 
     EnsiArgs a = EnsiArgs();

@@ -18,6 +18,7 @@
 // Arithmetic follows the reference: float32 coordinates/distances/rho (no FMA contraction,
 // correctly rounded sqrt/div, rho through a double-precision exp), double for the solve.
 #include "oi_common.h"
+#include "oi_union.h"
 #include <algorithm>
 #include <memory>
 
@@ -93,45 +94,19 @@ __global__ void k_structure_corr(DevStructure st, float4 p1, float l1, float4 p2
 // -------------------------------------------------------------------------------------------
 // the OI kernel
 // -------------------------------------------------------------------------------------------
-struct OiArgs {
-    const float *gx, *gy, *gz, *gelev, *glaf, *bg, *bvar;
-    float *out, *out_var;
-    int C, ny, nx, tiles_x, ntiles, tiled2d;
-    ScanArgs s;
-    const float4* ogeo;      // original order
-    const float4* oaux;      // original order: laf, obs, pbg, ratio
-    int S, allow_extrap;
-    int* err;                // bit0: list overflow (needs the large-n path), bit1: singular / not SPD
-    unsigned long long* counters;   // [0] cells updated, [1] factorisations
-};
-
-#define ERR_OVERFLOW 1
-#define ERR_SINGULAR 2
-
 // 64-bit mixers for the order-independent signature of a selected observation set
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
     return x;
 }
-// index (0..63) of the m-th set bit of mask (m < popcount(mask))
-__device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
-    int pos = 0;
-#pragma unroll
-    for(int w = 32; w > 0; w >>= 1) {
-        unsigned long long lowmask = (w == 32) ? 0xffffffffull : ((1ull << w) - 1ull);
-        int c = __popcll((mask >> pos) & lowmask);
-        if(m >= c) { m -= c; pos += w; }
-    }
-    return pos;
-}
-
 template <int N, bool LU, bool PLAIN, bool SPATIAL>
 __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wid;
-    if(tile >= a.ntiles) return;
+    const int trun = blockIdx.x * 4 + wid;
+    if(trun >= a.nrun) return;
+    const int tile = a.tile_list ? a.tile_list[trun] : trun;
 
     int cell = -1;
     if(a.tiled2d) {
@@ -483,7 +458,7 @@ namespace {
 struct OiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> ones;
-    DevBuf<int> err, cell_idx, obs_idx;
+    DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_count;
     DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -682,9 +657,9 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
 
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
     ws.pgeo.get(S); ws.oaux.get(S);
-    ws.err.get(1); ws.counters.get(4);
+    ws.err.get(1); ws.counters.get(80);
     GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
-    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 4, stream()));
+    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 80, stream()));
     hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
                        f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p);
     GPP_HIP(hipGetLastError());
@@ -713,6 +688,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
     a.err = ws.err.p; a.counters = ws.counters.p;
+    a.debug = getenv("GPP_OI_DEBUG") ? atoi(getenv("GPP_OI_DEBUG")) : 0;
 
     GPP_HIP(hipEventRecord(ws.e0, stream()));
     // Cholesky needs a symmetric positive definite P+R: true for every kernel on distances and for the even vertical / laf
@@ -722,33 +698,60 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const bool spatial = a.s.st.fh != nullptr;   // per-point length scales: P is not symmetric (corr(p1, p2) uses p1's scales)
     bool use_lu = spatial || (a.s.st.v != 0 && odd(a.s.st.kv)) || (a.s.st.w != 0 && odd(a.s.st.kw)) || getenv("GPP_OI_FORCE_LU");
     int err = 0;
-    unsigned long long counters[4];
-    for(int attempt = 0; attempt < 2; ++attempt) {
-        const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
-        const dim3 grid((a.ntiles + 3) / 4), block(256);
+    unsigned long long counters[80];
+    const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
+    auto launch_k_oi = [&](const bool lu) {   // k_oi over a.nrun tiles (all, or the fallback list of k_oi_union)
+        const dim3 grid((a.nrun + 3) / 4), block(256);
         if(spatial) {
             if(N == 32) hipLaunchKernelGGL((k_oi<32, true, false, true>), grid, block, 0, stream(), a);
             else hipLaunchKernelGGL((k_oi<62, true, false, true>), grid, block, 0, stream(), a);
         }
         else if(N == 32) {
-            if(use_lu) hipLaunchKernelGGL((k_oi<32, true, false, false>), grid, block, 0, stream(), a);
+            if(lu) hipLaunchKernelGGL((k_oi<32, true, false, false>), grid, block, 0, stream(), a);
             else if(plain) hipLaunchKernelGGL((k_oi<32, false, true, false>), grid, block, 0, stream(), a);
             else hipLaunchKernelGGL((k_oi<32, false, false, false>), grid, block, 0, stream(), a);
         }
         else {
-            if(use_lu) hipLaunchKernelGGL((k_oi<62, true, false, false>), grid, block, 0, stream(), a);
+            if(lu) hipLaunchKernelGGL((k_oi<62, true, false, false>), grid, block, 0, stream(), a);
             else hipLaunchKernelGGL((k_oi<62, false, false, false>), grid, block, 0, stream(), a);
         }
         GPP_HIP(hipGetLastError());
-        GPP_HIP(hipEventRecord(ws.e1, stream()));
+    };
+    auto fetch = [&]() {
         GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipMemcpyAsync(counters, ws.counters.p, sizeof(counters), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipStreamSynchronize(stream()));
+    };
+    // one factorisation per tile (k_oi_union) when the system is symmetric and max_points fits the 32-column tile;
+    // the tiles it declines, and every other configuration, run on k_oi (one factorisation per distinct selection)
+    const bool use_union = !use_lu && N == 32 && !getenv("GPP_OI_NO_UNION");
+    for(int attempt = 0; attempt < 2; ++attempt) {
+        a.tile_list = nullptr; a.nrun = a.ntiles;
+        if(use_union && !use_lu) {
+            ws.fb_list.get(a.ntiles); ws.fb_count.get(1);
+            GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, sizeof(int), stream()));
+            a.fb_list = ws.fb_list.p; a.fb_count = ws.fb_count.p;
+            const dim3 grid((a.ntiles + 3) / 4), block(256);
+            if(plain) hipLaunchKernelGGL((k_oi_union<true>), grid, block, 0, stream(), a);
+            else hipLaunchKernelGGL((k_oi_union<false>), grid, block, 0, stream(), a);
+            GPP_HIP(hipGetLastError());
+            int nfb = 0;
+            GPP_HIP(hipMemcpyAsync(&nfb, ws.fb_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+            GPP_HIP(hipStreamSynchronize(stream()));
+            g_stats.fallback_tiles = nfb;
+            if(nfb > 0) {
+                a.tile_list = ws.fb_list.p; a.nrun = nfb;
+                launch_k_oi(false);
+            }
+        }
+        else launch_k_oi(use_lu);
+        GPP_HIP(hipEventRecord(ws.e1, stream()));
+        fetch();
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
             g_stats.fallback_tiles = a.ntiles;
             GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
-            GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 4, stream()));
+            GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 80, stream()));
             continue;
         }
         break;
@@ -761,6 +764,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     g_stats.cells_updated = (long long)counters[0];
     g_stats.solves = (long long)counters[1];
     if(getenv("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);
+    if(getenv("GPP_SCAN_STATS")) { fprintf(stderr, "[gpp] wave-level insertions per tile histogram:"); for(int i = 0; i < 70; i++) fprintf(stderr, " %d:%llu", i, counters[4 + i]); fprintf(stderr, "\n"); }
     if(err & ERR_SINGULAR) runtime("optimal_interpolation: local (P+R) matrix is singular");
     if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more than 62 usable observations per grid point requested (max_points == 0 or > 62): not supported on the GPU path yet");
     return GPP_OK;

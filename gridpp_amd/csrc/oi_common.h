@@ -226,6 +226,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
     // truncated: more usable observations than max_points existed, i.e. the reference took its sorted branch
     // (oi.cpp:262-273); only the EnSI anti-extrapolation quirk depends on it (oi_ensi.cpp:523-524)
     int cnt = 0;
+    int nins = 0;   // GPP_SCAN_STATS only: wave-level insertion events
     overflow = false;
     truncated = false;
     const float R = st.R;
@@ -278,6 +279,8 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                         float rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
                         if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
                         if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
+                        const bool ins_ = rho > 0.0f && (cnt < K || (((unsigned long long)__float_as_uint(rho) << 32) | 0xffffffffull) > wkey);
+                        if(a.scan_stats && __ballot(ins_) != 0ull) nins++;
                         if(rho > 0.0f) {   // oi.cpp:253
                             const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
                             const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
@@ -350,5 +353,6 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
             else process_row(row, x0, x1);
         }
     }
+    if(a.scan_stats && lane == 0) atomicAdd(&a.scan_stats[2 + min(__builtin_amdgcn_readfirstlane(nins), 69)], 1ull);
     return cnt;
 }

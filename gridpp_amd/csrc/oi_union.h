@@ -1,0 +1,489 @@
+// k_oi_union: optimal interpolation with ONE factorisation per 8x8 tile of grid cells.
+//
+// The 64 cells of a tile select almost the same observations (src/api/oi.cpp:229-273): on the headline workload the
+// union U of the 64 selections has ~33 members of which ~28 (the core C) are selected by every cell.  With the core
+// ordered first, the Cholesky factor of (P+R)[S,S] for a cell's selection S = C + E_cell is
+//     L_S = | L_C   0  |      B = (P+R)[E,C] L_C^-T,   L_E L_E^T = (P+R)[E,E] - B B^T   (Schur complement)
+//           | B    L_E |
+// so the wave factorises the core once (rows in lanes, extras and obs-background as extra rows, which leaves B, the
+// Schur complement of ALL extras and L_C^-1 d behind), and then every LANE finishes its own cell: a forward substitution
+// of its G vector (the rho values kept from the scan) against L_C read from LDS, and a tiny Cholesky (<= 6 rows) on the
+// sub-block of the Schur complement that belongs to its own extras.  increment = (L^-1 g).(L^-1 d) and
+// 1 - K G^T = 1 - |L^-1 g|^2 as in k_oi (oi.cpp:315-316,336).
+//
+// A tile that does not fit (more than 44 live candidates during the scan, union > 40, more than 12 extras or more than
+// 6 per cell) is appended to a fallback list and done by k_oi (one factorisation per distinct selection).
+#pragma once
+#include "oi_common.h"
+
+#pragma clang fp contract(off)
+
+struct OiArgs {
+    const float *gx, *gy, *gz, *gelev, *glaf, *bg, *bvar;
+    float *out, *out_var;
+    int C, ny, nx, tiles_x, ntiles, tiled2d;
+    ScanArgs s;
+    const float4* ogeo;      // original order
+    const float4* oaux;      // original order: laf, obs, pbg, ratio
+    int S, allow_extrap;
+    int* err;                // bit0: list overflow (needs the large-n path), bit1: singular / not SPD
+    unsigned long long* counters;   // [0] cells updated, [1] factorisations
+    const int* tile_list;    // k_oi: run these tiles only (fallback of k_oi_union); NULL = all
+    int nrun;                // number of tiles to run
+    int* fb_list;            // k_oi_union: tiles left to k_oi
+    int* fb_count;
+    int debug;               // GPP_OI_DEBUG: bit0 = skip the solve (timing experiments only)
+};
+
+#define ERR_OVERFLOW 1
+#define ERR_SINGULAR 2
+
+// index (0..63) of the m-th set bit of mask (m < popcount(mask))
+__device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
+    int pos = 0;
+#pragma unroll
+    for(int w = 32; w > 0; w >>= 1) {
+        unsigned long long lowmask = (w == 32) ? 0xffffffffull : ((1ull << w) - 1ull);
+        int c = __popcll((mask >> pos) & lowmask);
+        if(m >= c) { m -= c; pos += w; }
+    }
+    return pos;
+}
+
+constexpr int U_WCAP = 44;     // candidate slots of a tile (live union during the scan)
+constexpr int U_MAXU = 40;     // rows of the shared factorisation: 32 register columns + 8
+constexpr int U_MAXE = 12;     // union minus core
+constexpr int U_MAXM = 6;      // extras of one cell
+constexpr int U_SOLVE = 1024;  // doubles of the shared-factor area
+
+struct UnionLds {
+    float rho[U_WCAP][64];     // rho(cell = lane, candidate slot); +inf = not (or no longer) selected by that cell
+    double solve[U_SOLVE];     // column staging of the matrix build, then L_C / 1/diag / L_C^-1 d / B / Schur / d'
+    int wpos[U_WCAP];          // slot -> sorted position of the observation
+    int worig[U_WCAP];         // slot -> observation index (tie-break); later: obs - background of the extras (float bits)
+    int rowslot[U_WCAP];       // matrix row -> slot
+};
+
+__device__ __forceinline__ double rsqrt_nr(const double a) {
+    double rs = __builtin_amdgcn_rsq(a);
+    rs = rs * (1.5 - 0.5 * a * rs * rs);
+    rs = rs * (1.5 - 0.5 * a * rs * rs);
+    return rs;
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
+    __shared__ UnionLds s_u[4];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wid;
+    if(tile >= a.ntiles) return;
+    UnionLds& L = s_u[wid];
+
+    int cell = -1;
+    if(a.tiled2d) {
+        int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        int y = ty * 8 + (lane >> 3), x = tx * 8 + (lane & 7);
+        if(y < a.ny && x < a.nx) cell = y * a.nx + x;
+    }
+    else {
+        int c = tile * 64 + lane;
+        if(c < a.C) cell = c;
+    }
+    float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN, bg = NAN, bvar = 1.0f;
+    if(cell >= 0) {
+        gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell];
+        bg = a.bg[cell];
+        if(a.bvar) bvar = a.bvar[cell];
+    }
+    const bool active = cell >= 0 && d_valid(bg);   // oi.cpp:223
+    const DevStructure& st = a.s.st;
+    const ScanArgs& sa = a.s;
+
+    // ================= candidate scan (the walk of scan_tile; selections kept as rho[slot][lane]) =================
+    const float R = st.R;
+    const int K = sa.K;
+    const float h2 = st.h * st.h;
+    const bool prune = PLAIN || st.kh == SK_BARNES;
+    const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz);
+    const float pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
+    const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
+    const float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
+    int cnt = 0;
+    unsigned long long alloc = 0ull;   // allocated slots (wave-uniform)
+    bool fb = false;                   // wave-uniform: this tile goes to k_oi
+    constexpr unsigned long long FULL = (1ull << U_WCAP) - 1ull;
+    // an empty (never used / evicted / not wanted by this cell) entry is +inf; all slot loops are static so that the
+    // 44 LDS reads issue back to back (ds_read2st64) instead of one latency per slot
+#pragma unroll
+    for(int w = 0; w < U_WCAP; ++w) L.rho[w][lane] = INFINITY;
+    auto live_mask = [&]() {   // slots some cell still holds
+        unsigned long long live = 0ull;
+        float rv[U_WCAP];
+#pragma unroll
+        for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
+#pragma unroll
+        for(int w = 0; w < U_WCAP; ++w) if(__ballot(rv[w] < INFINITY) != 0ull) live |= 1ull << w;
+        return live;
+    };
+    if(__ballot(active) != 0ull) {
+        const float sbin = 1.0f / sa.inv_s;
+        int tby0 = (int)floorf((bmin_t - sa.bmin) * sa.inv_s), tby1 = (int)floorf((bmax_t - sa.bmin) * sa.inv_s);
+        tby0 = __builtin_amdgcn_readfirstlane(min(max(tby0, 0), sa.nby - 1));
+        tby1 = __builtin_amdgcn_readfirstlane(min(max(tby1, tby0), sa.nby - 1));
+        int tbx0 = (int)floorf((amin_t - sa.amin) * sa.inv_s), tbx1 = (int)floorf((amax_t - sa.amin) * sa.inv_s);
+        tbx0 = __builtin_amdgcn_readfirstlane(min(max(tbx0, 0), sa.nbx - 1));
+        tbx1 = __builtin_amdgcn_readfirstlane(min(max(tbx1, tbx0), sa.nbx - 1));
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        float wr = 0.0f;       // worst kept rho, its slot and observation index
+        int ws = 0;
+        unsigned wo = 0u;
+        const float thr2_R = R * R * 1.000001f + 1e-30f;
+        float thr2 = active ? thr2_R : -1.0f;
+
+        auto process_row = [&](const int row, const int xa, const int xb) {
+            if(fb || row < 0 || row >= sa.nby || xa > xb) return;
+            const int js = sa.bin_start[row * sa.nbx + xa], je = sa.bin_start[row * sa.nbx + xb + 1];
+            for(int base = js; base < je; base += 64) {
+                const int mine = base + lane;
+                float4 rec = make_float4(NAN, 0, 0, NAN);
+                float2 met = make_float2(NAN, 0);
+                if(mine < je) { rec = sa.pgeo[mine]; met = sa.smeta[mine]; }
+                const int nc = min(64, je - base);
+                for(int c = 0; c < nc; ++c) {
+                    const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
+                    const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+                    float d2 = dx * dx + dy * dy;
+                    d2 = d2 + dz * dz;
+                    bool want = false;
+                    float rho = 0.0f;
+                    const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
+                    if(d2 <= thr2) {
+                        const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                        const float dist = sqrtf(d2);
+                        if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
+                            const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                            rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
+                            if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
+                            if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
+                            // oi.cpp:253 (rho > 0) and :262-273 (keep the max_points largest, ties -> lower observation index)
+                            if(rho > 0.0f) want = cnt < K || rho > wr || (rho == wr && orig < wo);
+                        }
+                    }
+                    if(__ballot(want) != 0ull) {
+                        if(alloc == FULL) alloc = live_mask();   // free the slots no cell holds any more
+                        if(alloc == FULL) { fb = true; return; }
+                        const int slot = __builtin_ctzll(~alloc);
+                        alloc |= 1ull << slot;
+                        if(lane == 0) { L.wpos[slot] = base + c; L.worig[slot] = (int)orig; }
+                        L.rho[slot][lane] = want ? rho : INFINITY;
+                        if(want) {
+                            if(cnt < K) {
+                                if(cnt == 0 || rho < wr || (rho == wr && orig > wo)) { wr = rho; ws = slot; wo = orig; }
+                                cnt++;
+                            }
+                            else {
+                                L.rho[ws][lane] = INFINITY;
+                                float rv[U_WCAP];
+#pragma unroll
+                                for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
+                                float r0 = INFINITY;
+#pragma unroll
+                                for(int w = 0; w < U_WCAP; ++w) r0 = fminf(r0, rv[w]);
+                                int s0 = 0, neq = 0;
+#pragma unroll
+                                for(int w = 0; w < U_WCAP; ++w) {
+                                    const bool eq = rv[w] == r0;
+                                    s0 = eq ? w : s0;
+                                    neq += eq ? 1 : 0;
+                                }
+                                wr = r0; ws = s0;
+                                if(neq > 1) {   // equal rho: the higher observation index is the worse one
+                                    unsigned bo = 0u;
+                                    for(unsigned long long mm = alloc; mm; mm &= mm - 1ull) {
+                                        const int w = __builtin_ctzll(mm);
+                                        if(L.rho[w][lane] == r0) {
+                                            const unsigned o = (unsigned)L.worig[w];
+                                            if(o >= bo) { bo = o; ws = w; }
+                                        }
+                                    }
+                                    wo = bo;
+                                }
+                                else wo = (unsigned)L.worig[ws];
+                            }
+                            if(prune && cnt == K) thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
+                        }
+                    }
+                }
+            }
+        };
+
+        const int q = sa.q0;
+        const int sx0 = max(tbx0 - q, 0), sx1 = min(tbx1 + q, sa.nbx - 1);
+        const int sy0 = tby0 - q, sy1 = tby1 + q;
+        for(int row = tby0; row <= tby1; ++row) process_row(row, sx0, sx1);
+        for(int r = 1; r <= q; ++r) { process_row(tby0 - r, sx0, sx1); process_row(tby1 + r, sx0, sx1); }
+        for(int r = 0; !fb; ++r) {
+            const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
+            if(t2 < 0.0f) break;
+            const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;
+            if(gap * gap > t2) break;
+            const int rowA = tby0 - r, rowB = tby1 + r;
+            if(rowA < 0 && rowB >= sa.nby) break;
+            const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
+            int x0 = (int)floorf((amin_t - wx - sa.amin) * sa.inv_s) - 1, x1 = (int)floorf((amax_t + wx - sa.amin) * sa.inv_s) + 1;
+            x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), sa.nbx - 1));
+            x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), sa.nbx - 1));
+            const int nrows = (r == 0) ? (tby1 - tby0 + 1) : 2;
+            for(int k = 0; k < nrows; ++k) {
+                const int row = (r == 0) ? tby0 + k : (k == 0 ? rowA : rowB);
+                if(row >= sy0 && row <= sy1) {
+                    process_row(row, x0, min(x1, sx0 - 1));
+                    process_row(row, max(x0, sx1 + 1), x1);
+                }
+                else process_row(row, x0, x1);
+            }
+        }
+    }
+
+    // ================= classification: union, core, extras ========================================================
+    const unsigned long long upd = __ballot(cnt > 0);
+    unsigned long long coreM = 0ull, extM = 0ull;
+    int c = 0, nE = 0, u = 0;
+    int m = 0;             // this cell's extras: count and their indices (4 bits each)
+    unsigned elist = 0u;
+    if(!fb && upd != 0ull) {
+        float rv[U_WCAP];
+#pragma unroll
+        for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
+#pragma unroll
+        for(int w = 0; w < U_WCAP; ++w) {
+            const unsigned long long mk = __ballot(rv[w] < INFINITY) & upd;
+            if(mk == upd) coreM |= 1ull << w;
+            else if(mk != 0ull) extM |= 1ull << w;
+        }
+        c = __popcll(coreM); nE = __popcll(extM); u = c + nE;
+        if(u > U_MAXU || nE > U_MAXE || c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE > U_SOLVE) fb = true;
+        else {
+            int ai = 0;
+            for(unsigned long long mm = extM; mm; mm &= mm - 1ull, ++ai) {
+                const int w = __builtin_ctzll(mm);
+                if(L.rho[w][lane] < INFINITY) { elist |= (unsigned)ai << (4 * (m & 7)); m++; }
+            }
+            if(__ballot(m > U_MAXM) != 0ull) fb = true;
+        }
+    }
+    if(fb) {
+        if(lane == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = tile;
+        return;
+    }
+    float res_out = bg, res_var = bvar;   // oi.cpp:198-199
+    if(upd != 0ull && !(a.debug & 1)) {
+        // ============= shared factorisation: rows 0..c-1 core, c..u-1 extras, lane 63 = obs - background ==========
+        const int myslot = lane < c ? nth_set_bit(coreM, lane) : (lane < u ? nth_set_bit(extM, lane - c) : 0);
+        float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
+        if(lane < u) {
+            L.rowslot[lane] = myslot;
+            const int pos = L.wpos[myslot];
+            o0 = sa.pgeo[pos];
+            const float2 met = sa.smeta[pos];
+            o1 = a.oaux[__float_as_int(met.y)];
+        }
+        const float dpf = (float)((double)o1.y - (double)o1.z);   // obs - background at the observation (oi.cpp:293)
+        __builtin_amdgcn_wave_barrier();
+        if(lane >= c && lane < u) L.worig[lane - c] = __float_as_int(dpf);
+        float* colbuf = reinterpret_cast<float*>(L.solve);   // [u][U_MAXU]
+        for(int p = 0; p < u; ++p) {
+            const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
+            const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
+            const float cv = d_corr_t<PLAIN>(st, o0.x, o0.y, o0.z, o0.w, o1.x, xp, yp, zp, ep, lp, false);   // oi.cpp:304-312
+            if(lane < u) colbuf[p * U_MAXU + lane] = cv;
+        }
+        double row[32], sx[8];
+#pragma unroll
+        for(int p = 0; p < 32; ++p) {
+            double v = 0.0;
+            if(p < u) {
+                if(lane < u) {
+                    v = (double)colbuf[p * U_MAXU + lane];
+                    if(lane == p) v += (double)o1.w;                                                       // lP + lR
+                }
+                const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);               // lObs - lY
+                if(lane == 63) v = dp;
+            }
+            row[p] = v;
+        }
+#pragma unroll
+        for(int b = 0; b < 8; ++b) {
+            double v = 0.0;
+            const int p = 32 + b;
+            if(p < u) {
+                if(lane < u) {
+                    v = (double)colbuf[p * U_MAXU + lane];
+                    if(lane == p) v += (double)o1.w;
+                }
+                const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);
+                if(lane == 63) v = dp;
+            }
+            sx[b] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // layout of the shared-factor area (doubles)
+        const int oL = 0, oI = c * (c + 1) / 2, oZ = oI + c, oB = oZ + c, bs = c | 1, oS = oB + nE * bs, oD = oS + nE * nE;
+        double* const sv = L.solve;
+        bool bad = false;
+        // right-looking Cholesky over the core columns; the trailing rows/columns end as B, the Schur complement, L_C^-1 d, d'
+#pragma unroll
+        for(int j = 0; j < 32; ++j) {
+            if(j < c) {
+                const double ajj = readlane_d(row[j], j);
+                if(!(ajj > 0.0)) bad = true;
+                const double rs = rsqrt_nr(ajj);
+                if(lane == 0) sv[oI + j] = rs;
+                const double cj = row[j] * rs;
+                row[j] = cj;
+#pragma unroll
+                for(int p = j + 1; p < 32; ++p) {
+                    const double lpj = readlane_d(cj, p);
+                    row[p] = __builtin_fma(-cj, lpj, row[p]);
+                }
+                if(u > 32) {
+#pragma unroll
+                    for(int b = 0; b < 8; ++b) {
+                        const double lpj = readlane_d(cj, 32 + b);
+                        sx[b] = __builtin_fma(-cj, lpj, sx[b]);
+                    }
+                }
+            }
+        }
+        // export: L_C rows packed, B rows (stride bs), L_C^-1 d, Schur complement, d'
+        const int ea = lane - c;   // extras row index of this lane
+#pragma unroll
+        for(int p = 0; p < 32; ++p) {
+            if(p < u) {
+                if(lane < c) { if(p <= lane) sv[oL + lane * (lane + 1) / 2 + p] = row[p]; }
+                else if(lane < u) {
+                    if(p < c) sv[oB + ea * bs + p] = row[p];
+                    else sv[oS + ea * nE + (p - c)] = row[p];
+                }
+                else if(lane == 63) {
+                    if(p < c) sv[oZ + p] = row[p];
+                    else sv[oD + (p - c)] = row[p];
+                }
+            }
+        }
+        if(u > 32) {
+#pragma unroll
+            for(int b = 0; b < 8; ++b) {
+                const int p = 32 + b;
+                if(p < u) {
+                    if(lane >= c && lane < u) sv[oS + ea * nE + (p - c)] = sx[b];
+                    else if(lane == 63) sv[oD + (p - c)] = sx[b];
+                }
+            }
+        }
+        if(lane >= c && lane < u && (c & 1) == 0) sv[oB + ea * bs + c] = 0.0;   // padding element of the odd stride
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ============= per cell (lane): forward substitution of G against L_C, then its own extras ==================
+        double z[32];
+        double inc = 0.0, a00 = 0.0;
+#pragma unroll
+        for(int k = 0; k < 32; ++k) {
+            double zk = 0.0;
+            if(k < c) {
+                const int slot = __builtin_amdgcn_readlane(myslot, k);
+                const double gk = (double)L.rho[slot][lane];        // lG(0, k) = rho (oi.cpp:296)
+                double acc0 = 0.0, acc1 = 0.0;
+                const double* lrow = sv + oL + k * (k + 1) / 2;
+#pragma unroll
+                for(int j = 0; j < k; ++j) {
+                    if(j & 1) acc1 = __builtin_fma(lrow[j], z[j], acc1);
+                    else acc0 = __builtin_fma(lrow[j], z[j], acc0);
+                }
+                zk = (gk - (acc0 + acc1)) * sv[oI + k];
+                inc = __builtin_fma(zk, sv[oZ + k], inc);
+                a00 = __builtin_fma(zk, zk, a00);
+            }
+            z[k] = zk;
+        }
+        float maxInc = -INFINITY, minInc = INFINITY;
+        if(!a.allow_extrap) {   // oi.cpp:318-334: extremes of obs - background over this cell's selection
+            maxInc = wave_max(lane < c ? dpf : -INFINITY);
+            minInc = wave_min(lane < c ? dpf : INFINITY);
+        }
+        const int mmax = __builtin_amdgcn_readfirstlane((int)wave_max((float)m));
+        if(mmax > 0) {
+            double ll[U_MAXM * (U_MAXM + 1) / 2], qv[U_MAXM], tv[U_MAXM], il[U_MAXM];
+#pragma unroll
+            for(int i = 0; i < U_MAXM; ++i) {
+                if(i < mmax) {
+                    const int ai = (elist >> (4 * i)) & 15;
+                    const bool valid = i < m;
+                    const int slot = L.rowslot[c + ai];
+                    const double gi = (double)L.rho[slot][lane];
+                    const double* brow = sv + oB + ai * bs;
+                    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                    for(int j0 = 0; j0 < 32; j0 += 4) {
+                        if(j0 < c) {   // reads at most 3 elements past the row (finite data, multiplied by z = 0)
+                            acc0 = __builtin_fma(brow[j0], z[j0], acc0);
+                            acc1 = __builtin_fma(brow[j0 + 1], z[j0 + 1], acc1);
+                            acc0 = __builtin_fma(brow[j0 + 2], z[j0 + 2], acc0);
+                            acc1 = __builtin_fma(brow[j0 + 3], z[j0 + 3], acc1);
+                        }
+                    }
+                    double gq = gi - (acc0 + acc1);
+                    double dq = sv[oD + ai];
+                    double sii = sv[oS + ai * nE + ai];
+#pragma unroll
+                    for(int jj = 0; jj < i; ++jj) {
+                        const int aj = (elist >> (4 * jj)) & 15;
+                        double sij = sv[oS + ai * nE + aj];
+#pragma unroll
+                        for(int k = 0; k < jj; ++k) sij = __builtin_fma(-ll[i * (i + 1) / 2 + k], ll[jj * (jj + 1) / 2 + k], sij);
+                        const double lij = sij * il[jj];
+                        ll[i * (i + 1) / 2 + jj] = lij;
+                        sii = __builtin_fma(-lij, lij, sii);
+                        gq = __builtin_fma(-lij, qv[jj], gq);
+                        dq = __builtin_fma(-lij, tv[jj], dq);
+                    }
+                    if(valid && !(sii > 0.0)) bad = true;
+                    const double rs = rsqrt_nr(valid ? sii : 1.0);
+                    il[i] = rs;
+                    qv[i] = gq * rs;
+                    tv[i] = dq * rs;
+                    if(valid) {
+                        inc = __builtin_fma(qv[i], tv[i], inc);
+                        a00 = __builtin_fma(qv[i], qv[i], a00);
+                        if(!a.allow_extrap) {
+                            const float de = __int_as_float(L.worig[ai]);
+                            maxInc = fmaxf(maxInc, de); minInc = fminf(minInc, de);
+                        }
+                    }
+                }
+            }
+        }
+        if(cnt > 0) {
+            float increment = (float)inc;   // oi.cpp:317
+            if(!a.allow_extrap) {           // oi.cpp:318-334
+                if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                else if(maxInc < 0 && increment > 0) increment = maxInc;
+                else if(minInc < 0 && increment < minInc) increment = minInc;
+                else if(minInc > 0 && increment < 0) increment = minInc;
+            }
+            res_out = bg + increment;                               // oi.cpp:335
+            res_var = (float)((double)bvar * (1.0 - a00));          // oi.cpp:337
+        }
+        if(__ballot(bad && cnt > 0) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
+        if(lane == 0 && a.counters) {
+            atomicAdd(&a.counters[0], (unsigned long long)__popcll(upd));
+            atomicAdd(&a.counters[1], 1ull);
+        }
+    }
+    if(cell >= 0) {
+        a.out[cell] = res_out;
+        if(a.out_var) a.out_var[cell] = res_var;
+    }
+}
