@@ -684,7 +684,10 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
       const int kk = (max_points > 0 && max_points <= N) ? max_points : N;
       a.s.q0 = std::max(1, std::min(8, (int)std::ceil(0.5 * (std::sqrt(1.6 * kk / std::max(occ, 1e-3)) - 1.0))));
-      if(getenv("GPP_Q0")) a.s.q0 = atoi(getenv("GPP_Q0")); }
+      if(getenv("GPP_Q0")) a.s.q0 = atoi(getenv("GPP_Q0"));
+      // expected distance of the kk-th nearest observation; the rings of k_oi_union step through 0.6, 0.8, ... of it
+      const double r_k = std::sqrt(kk / (3.14159265358979 * std::max(occ, 1e-3))) / ix->inv_s;
+      a.s.ring_r0 = (float)(0.6 * r_k); a.s.ring_dr = (float)(0.2 * r_k); }
     a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
     a.err = ws.err.p; a.counters = ws.counters.p;

@@ -207,6 +207,7 @@ struct ScanArgs {
     int K;                   // list capacity in use: min(max_points, N) (N if max_points == 0)
     int max_points;
     int q0;                  // half-width (in bins) of the phase-1 square of the candidate scan
+    float ring_r0, ring_dr;  // k_oi_union: ring radii of the phase-1 visiting order (projected distance from the tile centre)
     unsigned long long* scan_stats;   // optional: [0] candidates iterated, [1] wave-level survivor-branch executions
 };
 
@@ -293,10 +294,16 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                                 truncated = true;
                                 if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
                                     keys[wslot][lane] = key;
+                                    // new worst: static loop, so the N LDS reads issue back to back (one latency, no branches)
+                                    unsigned long long kv[N];
+#pragma unroll
+                                    for(int s = 0; s < N; ++s) kv[s] = keys[s][lane];
                                     wkey = key;
-                                    for(int s = 0; s < K; ++s) {
-                                        const unsigned long long k2 = keys[s][lane];
-                                        if(k2 < wkey) { wkey = k2; wslot = s; }
+#pragma unroll
+                                    for(int s = 0; s < N; ++s) {
+                                        const bool lt = s < K && kv[s] < wkey;
+                                        wkey = lt ? kv[s] : wkey;
+                                        wslot = lt ? s : wslot;
                                     }
                                 }
                             }

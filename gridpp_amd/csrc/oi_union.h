@@ -140,92 +140,177 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
         const float thr2_R = R * R * 1.000001f + 1e-30f;
         float thr2 = active ? thr2_R : -1.0f;
 
-        auto process_row = [&](const int row, const int xa, const int xb) {
-            if(fb || row < 0 || row >= sa.nby || xa > xb) return;
-            const int js = sa.bin_start[row * sa.nbx + xa], je = sa.bin_start[row * sa.nbx + xb + 1];
-            for(int base = js; base < je; base += 64) {
-                const int mine = base + lane;
-                float4 rec = make_float4(NAN, 0, 0, NAN);
-                float2 met = make_float2(NAN, 0);
-                if(mine < je) { rec = sa.pgeo[mine]; met = sa.smeta[mine]; }
-                const int nc = min(64, je - base);
-                for(int c = 0; c < nc; ++c) {
-                    const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
-                    const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
-                    float d2 = dx * dx + dy * dy;
-                    d2 = d2 + dz * dz;
-                    bool want = false;
-                    float rho = 0.0f;
-                    const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
-                    if(d2 <= thr2) {
-                        const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
-                        const float dist = sqrtf(d2);
-                        if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
-                            const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                            rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
-                            if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
-                            if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
-                            // oi.cpp:253 (rho > 0) and :262-273 (keep the max_points largest, ties -> lower observation index)
-                            if(rho > 0.0f) want = cnt < K || rho > wr || (rho == wr && orig < wo);
-                        }
+        // projected (bin-axis) position of the tile centre and its half diagonal: a candidate whose projected distance to
+        // the centre exceeds sqrt(largest threshold in the wave) + rad cannot be wanted by any cell (wave-level prune)
+        const float ca = 0.5f * (amin_t + amax_t), cb = 0.5f * (bmin_t + bmax_t);
+        const float rad = 0.5f * sqrtf((amax_t - amin_t) * (amax_t - amin_t) + (bmax_t - bmin_t) * (bmax_t - bmin_t)) * 1.001f + 1e-30f;
+        auto proj_d2 = [&](const float4& rec) {
+            const float ra = sa.axis_a == 0 ? rec.x : (sa.axis_a == 1 ? rec.y : rec.z);
+            const float rb = sa.axis_b == 1 ? rec.y : (sa.axis_b == 2 ? rec.z : rec.x);
+            return (ra - ca) * (ra - ca) + (rb - cb) * (rb - cb);
+        };
+        auto wave_lim2 = [&]() {   // < 0: nothing can be wanted any more
+            const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
+            if(t2 < 0.0f) return -1.0f;
+            const float lim = (sqrtf(t2) + rad) * 1.0001f;
+            return lim * lim;
+        };
+
+        // the candidates `mask` of one chunk of 64 records (lane c holds record c: rec, met, sorted position posv)
+        auto run_chunk = [&](const float4 rec, const float2 met, const int posv, unsigned long long mask) {
+            for(; mask != 0ull && !fb; mask &= mask - 1ull) {
+                const int c = __builtin_ctzll(mask);
+                const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
+                const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+                float d2 = dx * dx + dy * dy;
+                d2 = d2 + dz * dz;
+                bool want = false;
+                float rho = 0.0f;
+                const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
+                if(d2 <= thr2) {
+                    const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                    const float dist = sqrtf(d2);
+                    if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
+                        const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                        rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
+                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
+                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
+                        // oi.cpp:253 (rho > 0) and :262-273 (keep the max_points largest, ties -> lower observation index)
+                        if(rho > 0.0f) want = cnt < K || rho > wr || (rho == wr && orig < wo);
                     }
-                    if(__ballot(want) != 0ull) {
-                        if(alloc == FULL) alloc = live_mask();   // free the slots no cell holds any more
-                        if(alloc == FULL) { fb = true; return; }
-                        const int slot = __builtin_ctzll(~alloc);
-                        alloc |= 1ull << slot;
-                        if(lane == 0) { L.wpos[slot] = base + c; L.worig[slot] = (int)orig; }
-                        L.rho[slot][lane] = want ? rho : INFINITY;
-                        if(want) {
-                            if(cnt < K) {
-                                if(cnt == 0 || rho < wr || (rho == wr && orig > wo)) { wr = rho; ws = slot; wo = orig; }
-                                cnt++;
-                            }
-                            else {
-                                L.rho[ws][lane] = INFINITY;
-                                float rv[U_WCAP];
-#pragma unroll
-                                for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
-                                float r0 = INFINITY;
-#pragma unroll
-                                for(int w = 0; w < U_WCAP; ++w) r0 = fminf(r0, rv[w]);
-                                int s0 = 0, neq = 0;
-#pragma unroll
-                                for(int w = 0; w < U_WCAP; ++w) {
-                                    const bool eq = rv[w] == r0;
-                                    s0 = eq ? w : s0;
-                                    neq += eq ? 1 : 0;
-                                }
-                                wr = r0; ws = s0;
-                                if(neq > 1) {   // equal rho: the higher observation index is the worse one
-                                    unsigned bo = 0u;
-                                    for(unsigned long long mm = alloc; mm; mm &= mm - 1ull) {
-                                        const int w = __builtin_ctzll(mm);
-                                        if(L.rho[w][lane] == r0) {
-                                            const unsigned o = (unsigned)L.worig[w];
-                                            if(o >= bo) { bo = o; ws = w; }
-                                        }
-                                    }
-                                    wo = bo;
-                                }
-                                else wo = (unsigned)L.worig[ws];
-                            }
-                            if(prune && cnt == K) thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
+                }
+                if(__ballot(want) != 0ull) {
+                    if(alloc == FULL) alloc = live_mask();   // free the slots no cell holds any more
+                    if(alloc == FULL) { fb = true; return; }
+                    const int slot = __builtin_ctzll(~alloc);
+                    alloc |= 1ull << slot;
+                    if(lane == 0) { L.wpos[slot] = __builtin_amdgcn_readlane(posv, c); L.worig[slot] = (int)orig; }
+                    L.rho[slot][lane] = want ? rho : INFINITY;
+                    if(want) {
+                        if(cnt < K) {
+                            if(cnt == 0 || rho < wr || (rho == wr && orig > wo)) { wr = rho; ws = slot; wo = orig; }
+                            cnt++;
                         }
+                        else {
+                            L.rho[ws][lane] = INFINITY;
+                            float rv[U_WCAP];
+#pragma unroll
+                            for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
+                            float r0 = INFINITY;
+#pragma unroll
+                            for(int w = 0; w < U_WCAP; ++w) r0 = fminf(r0, rv[w]);
+                            int s0 = 0, neq = 0;
+#pragma unroll
+                            for(int w = 0; w < U_WCAP; ++w) {
+                                const bool eq = rv[w] == r0;
+                                s0 = eq ? w : s0;
+                                neq += eq ? 1 : 0;
+                            }
+                            wr = r0; ws = s0;
+                            if(neq > 1) {   // equal rho: the higher observation index is the worse one
+                                unsigned bo = 0u;
+                                for(unsigned long long mm = alloc; mm; mm &= mm - 1ull) {
+                                    const int w = __builtin_ctzll(mm);
+                                    if(L.rho[w][lane] == r0) {
+                                        const unsigned o = (unsigned)L.worig[w];
+                                        if(o >= bo) { bo = o; ws = w; }
+                                    }
+                                }
+                                wo = bo;
+                            }
+                            else wo = (unsigned)L.worig[ws];
+                        }
+                        if(prune && cnt == K) thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
                     }
                 }
             }
         };
 
-        const int q = sa.q0;
-        const int sx0 = max(tbx0 - q, 0), sx1 = min(tbx1 + q, sa.nbx - 1);
-        const int sy0 = tby0 - q, sy1 = tby1 + q;
-        for(int row = tby0; row <= tby1; ++row) process_row(row, sx0, sx1);
-        for(int r = 1; r <= q; ++r) { process_row(tby0 - r, sx0, sx1); process_row(tby1 + r, sx0, sx1); }
+        // ---- phase 1: the square of bins around the tile, all records loaded at once (up to 3 chunks of 64), visited in
+        //      rings of growing projected distance from the tile centre so that the thresholds tighten as early as possible.
+        //      The order only changes the amount of work, never the selection.
+        int q = sa.q0;
+        int sx0 = 0, sx1 = -1, sy0 = 1, sy1 = 0;   // the square phase 1 covered (empty: sy0 > sy1)
+        {
+            int js = 0, len = 0, pre = 0, total = 0, nrows = 0;
+            bool have = false;
+            for(;; --q) {
+                const int x0 = max(tbx0 - q, 0), x1 = min(tbx1 + q, sa.nbx - 1);
+                const int y0 = max(tby0 - q, 0), y1 = min(tby1 + q, sa.nby - 1);
+                nrows = y1 - y0 + 1;
+                if(nrows <= 64) {
+                    js = 0; len = 0;
+                    if(lane < nrows) {
+                        const int rb = (y0 + lane) * sa.nbx;
+                        js = sa.bin_start[rb + x0];
+                        len = sa.bin_start[rb + x1 + 1] - js;
+                    }
+                    pre = len;
+#pragma unroll
+                    for(int off = 1; off < 64; off <<= 1) {
+                        const int t = __shfl_up(pre, off);
+                        if(lane >= off) pre += t;
+                    }
+                    total = __builtin_amdgcn_readlane(pre, 63);
+                    pre -= len;
+                    if(total <= 192) { have = true; sx0 = x0; sx1 = x1; sy0 = y0; sy1 = y1; break; }
+                }
+                if(q == 0) break;
+            }
+            if(have && total > 0) {
+                const int nchunk = (total + 63) >> 6;
+                int row0 = 0, row1 = 0, row2 = 0;
+                for(int r = 1; r < nrows; ++r) {
+                    const int pr = __builtin_amdgcn_readlane(pre, r);
+                    if(lane >= pr) row0 = r;
+                    if(lane + 64 >= pr) row1 = r;
+                    if(lane + 128 >= pr) row2 = r;
+                }
+                float4 rec0 = make_float4(NAN, 0, 0, NAN), rec1 = rec0, rec2 = rec0;
+                float2 met0 = make_float2(NAN, 0), met1 = met0, met2 = met0;
+                int pos0 = 0, pos1 = 0, pos2 = 0;
+                float pd0 = INFINITY, pd1 = INFINITY, pd2 = INFINITY;
+                {
+                    pos0 = __shfl(js, row0) + lane - __shfl(pre, row0);
+                    if(lane < total) { rec0 = sa.pgeo[pos0]; met0 = sa.smeta[pos0]; }
+                    if(nchunk > 1) {
+                        pos1 = __shfl(js, row1) + lane + 64 - __shfl(pre, row1);
+                        if(lane + 64 < total) { rec1 = sa.pgeo[pos1]; met1 = sa.smeta[pos1]; }
+                    }
+                    if(nchunk > 2) {
+                        pos2 = __shfl(js, row2) + lane + 128 - __shfl(pre, row2);
+                        if(lane + 128 < total) { rec2 = sa.pgeo[pos2]; met2 = sa.smeta[pos2]; }
+                    }
+                    if(lane < total) pd0 = proj_d2(rec0);
+                    if(lane + 64 < total) pd1 = proj_d2(rec1);
+                    if(lane + 128 < total) pd2 = proj_d2(rec2);
+                }
+                // ring k: projected distance in [ring_r0 + (k-1) ring_dr, ring_r0 + k ring_dr), the last ring takes the rest
+                constexpr int NR = 6;
+                float lo2 = -1.0f;
+                for(int ring = 0; ring < NR && !fb; ++ring) {
+                    const float hi = sa.ring_r0 + (float)ring * sa.ring_dr;
+                    const float hi2 = (ring == NR - 1) ? INFINITY : hi * hi;
+                    const float lim2 = wave_lim2();
+                    if(lim2 < 0.0f || lo2 >= lim2) break;
+                    for(int k = 0; k < nchunk && !fb; ++k) {
+                        const float4 rec = k == 0 ? rec0 : (k == 1 ? rec1 : rec2);
+                        const float2 met = k == 0 ? met0 : (k == 1 ? met1 : met2);
+                        const int posv = k == 0 ? pos0 : (k == 1 ? pos1 : pos2);
+                        const float pd = k == 0 ? pd0 : (k == 1 ? pd1 : pd2);
+                        run_chunk(rec, met, posv, __ballot(pd > lo2 && pd <= hi2 && pd <= lim2));
+                    }
+                    lo2 = hi2;
+                }
+            }
+        }
+
+        // ---- phase 2: every remaining bin that can still matter, rows centre-out (x-extent and stop test from the largest
+        //      threshold in the wave), skipping the square phase 1 covered
         for(int r = 0; !fb; ++r) {
             const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
             if(t2 < 0.0f) break;
-            const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;
+            const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
             if(gap * gap > t2) break;
             const int rowA = tby0 - r, rowB = tby1 + r;
             if(rowA < 0 && rowB >= sa.nby) break;
@@ -233,14 +318,28 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
             int x0 = (int)floorf((amin_t - wx - sa.amin) * sa.inv_s) - 1, x1 = (int)floorf((amax_t + wx - sa.amin) * sa.inv_s) + 1;
             x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), sa.nbx - 1));
             x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), sa.nbx - 1));
+            const float lim2 = wave_lim2();
             const int nrows = (r == 0) ? (tby1 - tby0 + 1) : 2;
-            for(int k = 0; k < nrows; ++k) {
-                const int row = (r == 0) ? tby0 + k : (k == 0 ? rowA : rowB);
+            for(int k = 0; k < 2 * nrows && !fb; ++k) {   // two segments per row: left and right of the phase-1 square
+                const int kr = k >> 1, seg = k & 1;
+                const int row = (r == 0) ? tby0 + kr : (kr == 0 ? rowA : rowB);
+                if(row < 0 || row >= sa.nby) continue;
+                int xa = x0, xb = x1;
                 if(row >= sy0 && row <= sy1) {
-                    process_row(row, x0, min(x1, sx0 - 1));
-                    process_row(row, max(x0, sx1 + 1), x1);
+                    if(seg == 0) xb = min(x1, sx0 - 1);
+                    else xa = max(x0, sx1 + 1);
                 }
-                else process_row(row, x0, x1);
+                else if(seg == 1) continue;
+                if(xa > xb) continue;
+                const int js = sa.bin_start[row * sa.nbx + xa], je = sa.bin_start[row * sa.nbx + xb + 1];
+                for(int base = js; base < je && !fb; base += 64) {
+                    const int mine = base + lane;
+                    float4 rec = make_float4(NAN, 0, 0, NAN);
+                    float2 met = make_float2(NAN, 0);
+                    float pd = INFINITY;
+                    if(mine < je) { rec = sa.pgeo[mine]; met = sa.smeta[mine]; pd = proj_d2(rec); }
+                    run_chunk(rec, met, mine, __ballot(pd <= lim2));
+                }
             }
         }
     }
