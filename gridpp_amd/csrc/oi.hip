@@ -685,9 +685,10 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
       const int kk = (max_points > 0 && max_points <= N) ? max_points : N;
       a.s.q0 = std::max(1, std::min(8, (int)std::ceil(0.5 * (std::sqrt(1.6 * kk / std::max(occ, 1e-3)) - 1.0))));
       if(getenv("GPP_Q0")) a.s.q0 = atoi(getenv("GPP_Q0"));
-      // expected distance of the kk-th nearest observation; the rings of k_oi_union step through 0.6, 0.8, ... of it
+      // expected distance of the kk-th nearest observation: k_oi_union looks for its bulk disc below 1.5x that and then
+      // visits rings 0.15x wide
       const double r_k = std::sqrt(kk / (3.14159265358979 * std::max(occ, 1e-3))) / ix->inv_s;
-      a.s.ring_r0 = (float)(0.6 * r_k); a.s.ring_dr = (float)(0.2 * r_k); }
+      a.s.ring_r0 = (float)(1.5 * r_k); a.s.ring_dr = (float)(0.15 * r_k); }
     a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
     a.err = ws.err.p; a.counters = ws.counters.p;
@@ -767,6 +768,15 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     g_stats.cells_updated = (long long)counters[0];
     g_stats.solves = (long long)counters[1];
     if(getenv("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);
+#ifdef GPP_UNION_PROFILE
+    { const char* nm[12] = {"cell loads", "bbox+init", "phase-1 loads", "ring loop", "phase 2", "classify", "union records", "P build", "eliminate", "export", "per-lane", "-"};
+      double tot = 0; for(int i = 0; i < 12; i++) tot += (double)counters[20 + i];
+      fprintf(stderr, "[gpp] union phases (shader clocks per tile, %%):"); for(int i = 0; i < 11; i++) fprintf(stderr, " %s %.0f (%.1f%%);", nm[i], counters[20 + i] / (double)a.ntiles, 100.0 * counters[20 + i] / tot); fprintf(stderr, "\n"); }
+#endif
+#ifdef GPP_UNION_STATS
+    fprintf(stderr, "[gpp] union: fallback reasons: slots %llu, union>40 %llu, extras>12 %llu, layout %llu, per-cell extras>6 %llu; per tile: insertions %.1f, evictions %.1f, candidates %.1f, survivors %.1f\n",
+                            counters[4], counters[5], counters[6], counters[7], counters[8], counters[9] / (double)a.ntiles, counters[10] / (double)a.ntiles, counters[11] / (double)a.ntiles, counters[12] / (double)a.ntiles);
+#endif
     if(getenv("GPP_SCAN_STATS")) { fprintf(stderr, "[gpp] wave-level insertions per tile histogram:"); for(int i = 0; i < 70; i++) fprintf(stderr, " %d:%llu", i, counters[4 + i]); fprintf(stderr, "\n"); }
     if(err & ERR_SINGULAR) runtime("optimal_interpolation: local (P+R) matrix is singular");
     if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more than 62 usable observations per grid point requested (max_points == 0 or > 62): not supported on the GPU path yet");

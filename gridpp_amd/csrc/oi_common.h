@@ -42,8 +42,7 @@ __device__ __forceinline__ bool d_valid(float v) { return !isnan(v) && !isinf(v)
 // exp(x) for x <= 0, accurate to < 1 ulp(double) (the result is only used rounded to float32, where the reference's
 // libm exp gives the same value except when exp(x) lies within ~1e-16 relative of a float32 rounding boundary).
 // Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial in Horner form, exact 2^k scaling.
-__device__ __forceinline__ double d_exp_nonpos(double x) {
-    if(x < -110.0) return 0.0;   // (float)exp(x) == 0 below -103.98
+__device__ __forceinline__ double d_exp_core(double x) {   // -110 <= x <= 0 (no range check)
     const double kf = rint(x * 1.4426950408889634074);
     double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
     r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
@@ -62,6 +61,17 @@ __device__ __forceinline__ double d_exp_nonpos(double x) {
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return ldexp(p, (int)kf);
+}
+__device__ __forceinline__ double d_exp_nonpos(double x) {
+    if(x < -110.0) return 0.0;   // (float)exp(x) == 0 below -103.98
+    return d_exp_core(x);
+}
+// d_barnes_rho for a valid, non-zero length, without divergent branches (same values; NaN dist gives NaN)
+__device__ __forceinline__ float d_barnes_rho_flat(float dist, float length) {
+    const float v = dist / length;
+    const double e = -0.5 * (double)v * (double)v;
+    const float r = (float)d_exp_core(fmax(e, -110.0));
+    return e < -110.0 ? 0.0f : r;
 }
 __device__ __forceinline__ float d_barnes_rho(float dist, float length) {
     if(!d_valid(length) || length == 0) return 1.0f;
@@ -207,7 +217,7 @@ struct ScanArgs {
     int K;                   // list capacity in use: min(max_points, N) (N if max_points == 0)
     int max_points;
     int q0;                  // half-width (in bins) of the phase-1 square of the candidate scan
-    float ring_r0, ring_dr;  // k_oi_union: ring radii of the phase-1 visiting order (projected distance from the tile centre)
+    float ring_r0, ring_dr;  // k_oi_union: upper bound of the bulk disc / ring width of the phase-1 visiting order (projected distance from the tile centre)
     unsigned long long* scan_stats;   // optional: [0] candidates iterated, [1] wave-level survivor-branch executions
 };
 

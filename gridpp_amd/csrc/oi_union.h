@@ -50,6 +50,17 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
     return pos;
 }
 
+#ifdef GPP_UNION_STATS     // diagnostic build: event counts in counters[4..12]
+#define UNION_STATS true
+#else
+#define UNION_STATS false
+#endif
+#ifdef GPP_UNION_PROFILE   // diagnostic build: per-phase shader-clock totals in counters[20..]
+#define UPROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[i] += t_ - tprev; tprev = t_; } while(0)
+#else
+#define UPROF(i) do { } while(0)
+#endif
+
 constexpr int U_WCAP = 44;     // candidate slots of a tile (live union during the scan)
 constexpr int U_MAXU = 40;     // rows of the shared factorisation: 32 register columns + 8
 constexpr int U_MAXE = 12;     // union minus core
@@ -78,6 +89,10 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
     const int tile = blockIdx.x * 4 + wid;
     if(tile >= a.ntiles) return;
     UnionLds& L = s_u[wid];
+#ifdef GPP_UNION_PROFILE
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
 
     int cell = -1;
     if(a.tiled2d) {
@@ -100,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
     const ScanArgs& sa = a.s;
 
     // ================= candidate scan (the walk of scan_tile; selections kept as rho[slot][lane]) =================
+    UPROF(0);   // cell loads issued
     const float R = st.R;
     const int K = sa.K;
     const float h2 = st.h * st.h;
@@ -157,31 +173,54 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
         };
 
         // the candidates `mask` of one chunk of 64 records (lane c holds record c: rec, met, sorted position posv)
-        auto run_chunk = [&](const float4 rec, const float2 met, const int posv, unsigned long long mask) {
-            for(; mask != 0ull && !fb; mask &= mask - 1ull) {
-                const int c = __builtin_ctzll(mask);
-                const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
-                const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
-                float d2 = dx * dx + dy * dy;
-                d2 = d2 + dz * dz;
-                bool want = false;
-                float rho = 0.0f;
-                const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
-                if(d2 <= thr2) {
-                    const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
-                    const float dist = sqrtf(d2);
-                    if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
-                        const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
-                        // oi.cpp:253 (rho > 0) and :262-273 (keep the max_points largest, ties -> lower observation index)
-                        if(rho > 0.0f) want = cnt < K || rho > wr || (rho == wr && orig < wo);
-                    }
+        // rho(cell, candidate c of the chunk) as corr_background gives it, 0 when the candidate is not usable for this cell.
+        // PLAIN: straight-line code (selects instead of branches) so that two candidates evaluated back to back interleave.
+        const bool hv = d_valid(st.v) && st.v != 0.0f, hw = d_valid(st.w) && st.w != 0.0f, hh = d_valid(st.h) && st.h != 0.0f;
+        auto eval = [&](const float4& rec, const float2& met, const int c) {
+            const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
+            const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+            float d2 = dx * dx + dy * dy;
+            d2 = d2 + dz * dz;
+            const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;   // kdtree.cpp:46,53
+            const float dist = sqrtf(d2);
+            const bool ok = d2 <= thr2 && inbox && dist <= R;   // within_radius (kdtree.cpp:255), the cut inside corr (structure.cpp:216)
+            float rho = 0.0f;
+            if constexpr(PLAIN) {
+                rho = hh ? d_barnes_rho_flat(dist, st.h) : 1.0f;
+                if(hv) {
+                    const float oe = readlane_f(rec.w, c);
+                    if(d_valid(oe)) { const float f = d_barnes_rho_flat(ge - oe, st.v); rho = d_valid(ge) ? rho * f : rho; }
                 }
+                if(hw) {
+                    const float ol = readlane_f(met.x, c);
+                    if(d_valid(ol)) { const float f = d_barnes_rho_flat(gl - ol, st.w); rho = d_valid(gl) ? rho * f : rho; }
+                }
+                rho = ok ? rho : 0.0f;
+            }
+            else if(ok) {
+                const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                rho = (st.cv && dist <= st.cv_dist) ? 0.0f : d_rho(st.kh, dist, st.h);   // corr_background
+                if(d_valid(ge) && d_valid(oe)) rho *= d_rho(st.kv, ge - oe, st.v);
+                if(d_valid(gl) && d_valid(ol)) rho *= d_rho(st.kw, gl - ol, st.w);
+            }
+            return rho;
+        };
+
+        // the candidates `mask` of one chunk of 64 records (lane c holds record c: rec, met, sorted position posv)
+        auto run_chunk = [&](const float4 rec, const float2 met, const int posv, unsigned long long mask) {
+            while(mask != 0ull && !fb) {
+                const int c = __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const float rho = eval(rec, met, c);
+                {
+                const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
+                // oi.cpp:253 (rho > 0) and :262-273 (keep the max_points largest, ties -> lower observation index)
+                const bool want = rho > 0.0f && (cnt < K || rho > wr || (rho == wr && orig < wo));
                 if(__ballot(want) != 0ull) {
                     if(alloc == FULL) alloc = live_mask();   // free the slots no cell holds any more
-                    if(alloc == FULL) { fb = true; return; }
+                    if(UNION_STATS && lane == 0) atomicAdd(&a.counters[9], 1ull);
+                    if(UNION_STATS && __ballot(want && cnt >= K) != 0ull && lane == 0) atomicAdd(&a.counters[10], 1ull);
+                    if(alloc == FULL) { fb = true; if(UNION_STATS && lane == 0) atomicAdd(&a.counters[4], 1ull); return; }
                     const int slot = __builtin_ctzll(~alloc);
                     alloc |= 1ull << slot;
                     if(lane == 0) { L.wpos[slot] = __builtin_amdgcn_readlane(posv, c); L.worig[slot] = (int)orig; }
@@ -224,8 +263,10 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
                     }
                 }
             }
+                }
         };
 
+        UPROF(1);   // bbox reductions, LDS init
         // ---- phase 1: the square of bins around the tile, all records loaded at once (up to 3 chunks of 64), visited in
         //      rings of growing projected distance from the tile centre so that the thresholds tighten as early as possible.
         //      The order only changes the amount of work, never the selection.
@@ -285,29 +326,103 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
                     if(lane + 64 < total) pd1 = proj_d2(rec1);
                     if(lane + 128 < total) pd2 = proj_d2(rec2);
                 }
+                UPROF(2);   // bin_start, prefix, chunk loads
                 // ring k: projected distance in [ring_r0 + (k-1) ring_dr, ring_r0 + k ring_dr), the last ring takes the rest
-                constexpr int NR = 6;
+                constexpr int NR = 4;
                 float lo2 = -1.0f;
-                for(int ring = 0; ring < NR && !fb; ++ring) {
-                    const float hi = sa.ring_r0 + (float)ring * sa.ring_dr;
-                    const float hi2 = (ring == NR - 1) ? INFINITY : hi * hi;
+                // Bulk mode: while the rings visited so far hold at most max_points candidates no cell can have to choose, so
+                // a candidate simply takes the next slot (rho, or +inf where it is unusable for that cell): no selection logic.
+                int nb = 0;
+                bool bulk = true;
+                auto end_bulk = [&]() {   // worst kept entry of every cell after the bulk rings
+                    bulk = false;
+                    alloc = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+                    float rv[U_WCAP];
+#pragma unroll
+                    for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
+                    float r0 = INFINITY;
+#pragma unroll
+                    for(int w = 0; w < U_WCAP; ++w) r0 = fminf(r0, rv[w]);
+                    int s0 = 0, neq = 0;
+#pragma unroll
+                    for(int w = 0; w < U_WCAP; ++w) {
+                        const bool eq = rv[w] == r0;
+                        s0 = eq ? w : s0;
+                        neq += eq ? 1 : 0;
+                    }
+                    wr = r0; ws = s0;
+                    wo = (unsigned)L.worig[s0];
+                    if(cnt > 0 && neq > 1) {   // equal rho: the higher observation index is the worse one
+                        unsigned bo = 0u;
+                        for(unsigned long long mm = alloc; mm; mm &= mm - 1ull) {
+                            const int w = __builtin_ctzll(mm);
+                            if(L.rho[w][lane] == r0) {
+                                const unsigned o = (unsigned)L.worig[w];
+                                if(o >= bo) { bo = o; ws = w; }
+                            }
+                        }
+                        wo = bo;
+                    }
+                    if(prune && cnt == K) thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
+                };
+                // radius^2 (projected) holding at most min(max_points, slots) records: bisection with wave-wide counts
+                const int kb = min(K, U_WCAP);
+                float tlo = 0.0f;
+                {
+                    float thi = sa.ring_r0 * sa.ring_r0;   // 1.5 x the expected distance of the max_points-th nearest observation
+                    const float lim2 = wave_lim2();
+                    thi = fminf(thi, lim2);
+                    auto count_le = [&](const float t) { return __popcll(__ballot(pd0 <= t)) + __popcll(__ballot(pd1 <= t)) + __popcll(__ballot(pd2 <= t)); };
+                    if(count_le(thi) <= kb) tlo = thi;
+                    else {
+                        for(int it = 0; it < 9; ++it) {
+                            const float mid = 0.5f * (tlo + thi);
+                            if(count_le(mid) <= kb) tlo = mid; else thi = mid;
+                        }
+                    }
+                }
+                for(int ring = -1; ring < NR && !fb; ++ring) {   // ring -1: the bulk disc
+                    const float hi = sqrtf(tlo) + (float)(ring + 1) * sa.ring_dr;
+                    const float hi2 = ring < 0 ? tlo : ((ring == NR - 1) ? INFINITY : hi * hi);
                     const float lim2 = wave_lim2();
                     if(lim2 < 0.0f || lo2 >= lim2) break;
+                    const unsigned long long m0 = __ballot(pd0 > lo2 && pd0 <= hi2 && pd0 <= lim2);
+                    const unsigned long long m1 = __ballot(pd1 > lo2 && pd1 <= hi2 && pd1 <= lim2);
+                    const unsigned long long m2 = __ballot(pd2 > lo2 && pd2 <= hi2 && pd2 <= lim2);
+                    if(ring >= 0 && bulk) end_bulk();
                     for(int k = 0; k < nchunk && !fb; ++k) {
                         const float4 rec = k == 0 ? rec0 : (k == 1 ? rec1 : rec2);
                         const float2 met = k == 0 ? met0 : (k == 1 ? met1 : met2);
                         const int posv = k == 0 ? pos0 : (k == 1 ? pos1 : pos2);
-                        const float pd = k == 0 ? pd0 : (k == 1 ? pd1 : pd2);
-                        run_chunk(rec, met, posv, __ballot(pd > lo2 && pd <= hi2 && pd <= lim2));
+                        const unsigned long long mk = k == 0 ? m0 : (k == 1 ? m1 : m2);
+                        if(a.debug & 8) continue;
+                        if(bulk) {
+                            if((mk >> lane) & 1ull) {   // the holder of a candidate records where it lives
+                                const int slot = nb + __popcll(mk & ((1ull << lane) - 1ull));
+                                L.wpos[slot] = posv;
+                                L.worig[slot] = __float_as_int(met.y);
+                            }
+                            for(unsigned long long mm = mk; mm != 0ull; mm &= mm - 1ull) {
+                                const int c = __builtin_ctzll(mm);
+                                const float rho = eval(rec, met, c);
+                                const bool ok = rho > 0.0f;   // oi.cpp:253
+                                L.rho[nb][lane] = ok ? rho : INFINITY;
+                                cnt += ok ? 1 : 0;
+                                nb++;
+                            }
+                        }
+                        else run_chunk(rec, met, posv, mk);
                     }
                     lo2 = hi2;
                 }
+                if(bulk) end_bulk();
             }
         }
 
+        UPROF(3);   // ring loop
         // ---- phase 2: every remaining bin that can still matter, rows centre-out (x-extent and stop test from the largest
         //      threshold in the wave), skipping the square phase 1 covered
-        for(int r = 0; !fb; ++r) {
+        for(int r = 0; !fb && !(a.debug & 4); ++r) {
             const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
             if(t2 < 0.0f) break;
             const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
@@ -344,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
         }
     }
 
+    UPROF(4);   // phase 2
     // ================= classification: union, core, extras ========================================================
     const unsigned long long upd = __ballot(cnt > 0);
     unsigned long long coreM = 0ull, extM = 0ull;
@@ -361,20 +477,24 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
             else if(mk != 0ull) extM |= 1ull << w;
         }
         c = __popcll(coreM); nE = __popcll(extM); u = c + nE;
-        if(u > U_MAXU || nE > U_MAXE || c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE > U_SOLVE) fb = true;
+        if(u > U_MAXU || nE > U_MAXE || c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE > U_SOLVE) {
+            fb = true;
+            if(UNION_STATS && lane == 0) atomicAdd(&a.counters[u > U_MAXU ? 5 : (nE > U_MAXE ? 6 : 7)], 1ull);
+        }
         else {
             int ai = 0;
             for(unsigned long long mm = extM; mm; mm &= mm - 1ull, ++ai) {
                 const int w = __builtin_ctzll(mm);
                 if(L.rho[w][lane] < INFINITY) { elist |= (unsigned)ai << (4 * (m & 7)); m++; }
             }
-            if(__ballot(m > U_MAXM) != 0ull) fb = true;
+            if(__ballot(m > U_MAXM) != 0ull) { fb = true; if(UNION_STATS && lane == 0) atomicAdd(&a.counters[8], 1ull); }
         }
     }
     if(fb) {
         if(lane == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = tile;
         return;
     }
+    UPROF(5);   // classification
     float res_out = bg, res_var = bvar;   // oi.cpp:198-199
     if(upd != 0ull && !(a.debug & 1)) {
         // ============= shared factorisation: rows 0..c-1 core, c..u-1 extras, lane 63 = obs - background ==========
@@ -390,6 +510,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
         const float dpf = (float)((double)o1.y - (double)o1.z);   // obs - background at the observation (oi.cpp:293)
         __builtin_amdgcn_wave_barrier();
         if(lane >= c && lane < u) L.worig[lane - c] = __float_as_int(dpf);
+        UPROF(6);   // observation records of the union
         float* colbuf = reinterpret_cast<float*>(L.solve);   // [u][U_MAXU]
         for(int p = 0; p < u; ++p) {
             const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
@@ -397,6 +518,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
             const float cv = d_corr_t<PLAIN>(st, o0.x, o0.y, o0.z, o0.w, o1.x, xp, yp, zp, ep, lp, false);   // oi.cpp:304-312
             if(lane < u) colbuf[p * U_MAXU + lane] = cv;
         }
+        UPROF(7);   // P build
         double row[32], sx[8];
 #pragma unroll
         for(int p = 0; p < 32; ++p) {
@@ -454,6 +576,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
                 }
             }
         }
+        UPROF(8);   // row load + elimination
         // export: L_C rows packed, B rows (stride bs), L_C^-1 d, Schur complement, d'
         const int ea = lane - c;   // extras row index of this lane
 #pragma unroll
@@ -485,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        UPROF(9);   // export
         // ============= per cell (lane): forward substitution of G against L_C, then its own extras ==================
         double z[32];
         double inc = 0.0, a00 = 0.0;
@@ -564,6 +688,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
                 }
             }
         }
+        UPROF(10);  // per-lane finish
         if(cnt > 0) {
             float increment = (float)inc;   // oi.cpp:317
             if(!a.allow_extrap) {           // oi.cpp:318-334
@@ -581,6 +706,9 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
             atomicAdd(&a.counters[1], 1ull);
         }
     }
+#ifdef GPP_UNION_PROFILE
+    if(lane == 0) for(int i = 0; i < 12; ++i) atomicAdd(&a.counters[20 + i], prof[i]);
+#endif
     if(cell >= 0) {
         a.out[cell] = res_out;
         if(a.out_var) a.out_var[cell] = res_var;
