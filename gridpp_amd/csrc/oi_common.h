@@ -172,13 +172,26 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// Wave-wide min / max on the VALU cross-lane path (DPP row shifts + row broadcasts, then lane 63 holds the result):
+// no LDS round trips.  Must be called by all 64 lanes.
+#define GPP_DPP_STEP(OP, ctrl, rmask)                                                                                   \
+    {                                                                                                                   \
+        const int t_ = __builtin_amdgcn_update_dpp(id, x, ctrl, rmask, 0xf, false);                                      \
+        x = __float_as_int(OP(__int_as_float(x), __int_as_float(t_)));                                                  \
+    }
 __device__ __forceinline__ float wave_min(float v) {
-    for(int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
+    int x = __float_as_int(v);
+    const int id = __float_as_int(INFINITY);
+    GPP_DPP_STEP(fminf, 0x111, 0xf) GPP_DPP_STEP(fminf, 0x112, 0xf) GPP_DPP_STEP(fminf, 0x114, 0xf) GPP_DPP_STEP(fminf, 0x118, 0xf)
+    GPP_DPP_STEP(fminf, 0x142, 0xa) GPP_DPP_STEP(fminf, 0x143, 0xc)
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-    for(int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
+    int x = __float_as_int(v);
+    const int id = __float_as_int(-INFINITY);
+    GPP_DPP_STEP(fmaxf, 0x111, 0xf) GPP_DPP_STEP(fmaxf, 0x112, 0xf) GPP_DPP_STEP(fmaxf, 0x114, 0xf) GPP_DPP_STEP(fmaxf, 0x118, 0xf)
+    GPP_DPP_STEP(fmaxf, 0x142, 0xa) GPP_DPP_STEP(fmaxf, 0x143, 0xc)
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
 // Per-call observation pack: validity (oi.cpp:252), variance ratio (oi.cpp:192-195).
