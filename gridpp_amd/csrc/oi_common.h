@@ -194,6 +194,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
+// inclusive prefix sum over the 64 lanes (same DPP path)
+__device__ __forceinline__ int wave_scan_add(int x) {
+#define GPP_DPP_ADD(ctrl, rmask) x += __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false);
+    GPP_DPP_ADD(0x111, 0xf) GPP_DPP_ADD(0x112, 0xf) GPP_DPP_ADD(0x114, 0xf) GPP_DPP_ADD(0x118, 0xf)
+    GPP_DPP_ADD(0x142, 0xa) GPP_DPP_ADD(0x143, 0xc)
+#undef GPP_DPP_ADD
+    return x;
+}
+
 // Per-call observation pack: validity (oi.cpp:252), variance ratio (oi.cpp:192-195).
 static __global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const int* __restrict__ pos, const float* __restrict__ olaf,
                            const float* __restrict__ obs, const float* __restrict__ obs_var, const float* __restrict__ pbg,

@@ -11,7 +11,7 @@
 // sub-block of the Schur complement that belongs to its own extras.  increment = (L^-1 g).(L^-1 d) and
 // 1 - K G^T = 1 - |L^-1 g|^2 as in k_oi (oi.cpp:315-316,336).
 //
-// A tile that does not fit (more than 44 live candidates during the scan, union > 40, more than 12 extras or more than
+// A tile that does not fit (more than 40 live candidates during the scan, union > 40, more than 12 extras or more than
 // 6 per cell) is appended to a fallback list and done by k_oi (one factorisation per distinct selection).
 #pragma once
 #include "oi_common.h"
@@ -61,18 +61,22 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
 #define UPROF(i) do { } while(0)
 #endif
 
-constexpr int U_WCAP = 44;     // candidate slots of a tile (live union during the scan)
+constexpr int U_WCAP = 40;     // candidate slots of a tile (live union during the scan)
 constexpr int U_MAXU = 40;     // rows of the shared factorisation: 32 register columns + 8
 constexpr int U_MAXE = 12;     // union minus core
 constexpr int U_MAXM = 6;      // extras of one cell
 constexpr int U_SOLVE = 1024;  // doubles of the shared-factor area
 
 struct UnionLds {
-    float rho[U_WCAP][64];     // rho(cell = lane, candidate slot); +inf = not (or no longer) selected by that cell
-    double solve[U_SOLVE];     // column staging of the matrix build, then L_C / 1/diag / L_C^-1 d / B / Schur / d'
+    union {
+        float rho[U_WCAP][64];     // scan: rho(cell = lane, candidate slot); +inf = not (or no longer) selected by that cell
+        struct {                   // solve (the cells take their rho values into registers first)
+            double solve[U_SOLVE]; // column staging of the matrix build, then L_C / 1/diag / L_C^-1 d / B / Schur / d'
+            float erho[U_MAXE][64];// rho(cell, extras row)
+        } f;
+    };
     int wpos[U_WCAP];          // slot -> sorted position of the observation
     int worig[U_WCAP];         // slot -> observation index (tie-break); later: obs - background of the extras (float bits)
-    int rowslot[U_WCAP];       // matrix row -> slot
 };
 
 __device__ __forceinline__ double rsqrt_nr(const double a) {
@@ -83,7 +87,7 @@ __device__ __forceinline__ double rsqrt_nr(const double a) {
 }
 
 template <bool PLAIN>
-__global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
+__global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
     __shared__ UnionLds s_u[4];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + wid;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
     bool fb = false;                   // wave-uniform: this tile goes to k_oi
     constexpr unsigned long long FULL = (1ull << U_WCAP) - 1ull;
     // an empty (never used / evicted / not wanted by this cell) entry is +inf; all slot loops are static so that the
-    // 44 LDS reads issue back to back (ds_read2st64) instead of one latency per slot
+    // slot LDS reads issue back to back (ds_read2st64) instead of one latency per slot
 #pragma unroll
     for(int w = 0; w < U_WCAP; ++w) L.rho[w][lane] = INFINITY;
     auto live_mask = [&]() {   // slots some cell still holds
@@ -286,12 +290,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
                         js = sa.bin_start[rb + x0];
                         len = sa.bin_start[rb + x1 + 1] - js;
                     }
-                    pre = len;
-#pragma unroll
-                    for(int off = 1; off < 64; off <<= 1) {
-                        const int t = __shfl_up(pre, off);
-                        if(lane >= off) pre += t;
-                    }
+                    pre = wave_scan_add(len);
                     total = __builtin_amdgcn_readlane(pre, 63);
                     pre -= len;
                     if(total <= 192) { have = true; sx0 = x0; sx1 = x1; sy0 = y0; sy1 = y1; break; }
@@ -429,8 +428,9 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
             if(gap * gap > t2) break;
             const int rowA = tby0 - r, rowB = tby1 + r;
             if(rowA < 0 && rowB >= sa.nby) break;
-            const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
-            int x0 = (int)floorf((amin_t - wx - sa.amin) * sa.inv_s) - 1, x1 = (int)floorf((amax_t + wx - sa.amin) * sa.inv_s) + 1;
+            // bins are assigned with the same monotone float expression, so no extra bin is needed once wx is padded
+            const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f + 1e-3f * sbin;
+            int x0 = (int)floorf((amin_t - wx - sa.amin) * sa.inv_s), x1 = (int)floorf((amax_t + wx - sa.amin) * sa.inv_s);
             x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), sa.nbx - 1));
             x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), sa.nbx - 1));
             const float lim2 = wave_lim2();
@@ -501,17 +501,23 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
         const int myslot = lane < c ? nth_set_bit(coreM, lane) : (lane < u ? nth_set_bit(extM, lane - c) : 0);
         float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
         if(lane < u) {
-            L.rowslot[lane] = myslot;
             const int pos = L.wpos[myslot];
             o0 = sa.pgeo[pos];
             const float2 met = sa.smeta[pos];
             o1 = a.oaux[__float_as_int(met.y)];
         }
         const float dpf = (float)((double)o1.y - (double)o1.z);   // obs - background at the observation (oi.cpp:293)
+        // this cell's rho for every row of the union (lG, oi.cpp:296); afterwards the rho slots are dead and the
+        // shared-factor area takes their place
+        float gf[U_MAXU];
+#pragma unroll
+        for(int k = 0; k < U_MAXU; ++k) gf[k] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for(int k = 0; k < U_MAXU; ++k) if(k >= c && k < u) L.f.erho[k - c][lane] = gf[k];
         if(lane >= c && lane < u) L.worig[lane - c] = __float_as_int(dpf);
         UPROF(6);   // observation records of the union
-        float* colbuf = reinterpret_cast<float*>(L.solve);   // [u][U_MAXU]
+        float* colbuf = reinterpret_cast<float*>(L.f.solve);   // [u][U_MAXU]
         for(int p = 0; p < u; ++p) {
             const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
             const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
         __builtin_amdgcn_wave_barrier();
         // layout of the shared-factor area (doubles)
         const int oL = 0, oI = c * (c + 1) / 2, oZ = oI + c, oB = oZ + c, bs = c | 1, oS = oB + nE * bs, oD = oS + nE * nE;
-        double* const sv = L.solve;
+        double* const sv = L.f.solve;
         bool bad = false;
         // right-looking Cholesky over the core columns; the trailing rows/columns end as B, the Schur complement, L_C^-1 d, d'
 #pragma unroll
@@ -616,8 +622,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
         for(int k = 0; k < 32; ++k) {
             double zk = 0.0;
             if(k < c) {
-                const int slot = __builtin_amdgcn_readlane(myslot, k);
-                const double gk = (double)L.rho[slot][lane];        // lG(0, k) = rho (oi.cpp:296)
+                const double gk = (double)gf[k];
                 double acc0 = 0.0, acc1 = 0.0;
                 const double* lrow = sv + oL + k * (k + 1) / 2;
 #pragma unroll
@@ -644,8 +649,7 @@ __global__ __launch_bounds__(256, 2) void k_oi_union(OiArgs a) {
                 if(i < mmax) {
                     const int ai = (elist >> (4 * i)) & 15;
                     const bool valid = i < m;
-                    const int slot = L.rowslot[c + ai];
-                    const double gi = (double)L.rho[slot][lane];
+                    const double gi = (double)L.f.erho[ai][lane];
                     const double* brow = sv + oB + ai * bs;
                     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
