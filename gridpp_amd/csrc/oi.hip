@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int trun = blockIdx.x * 4 + wid;
     if(trun >= a.nrun) return;
-    const int tile = a.tile_list ? a.tile_list[trun] : trun;
+    // fallback list of k_oi_union: every tile is split into 8 sub-tiles of 8 cells (one wave each) so that the few listed
+    // tiles spread over the whole chip instead of running as a handful of long waves
+    const int tile = a.tile_list ? a.tile_list[trun >> 3] : trun;
+    const int sub = a.tile_list ? (trun & 7) : -1;
 
     int cell = -1;
     if(a.tiled2d) {
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
         int c = tile * 64 + lane;
         if(c < a.C) cell = c;
     }
+    if(sub >= 0 && (lane >> 3) != sub) cell = -1;
     float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN, bg = NAN, bvar = 1.0f;
     if(cell >= 0) {
         gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell];
@@ -744,7 +748,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             GPP_HIP(hipStreamSynchronize(stream()));
             g_stats.fallback_tiles = nfb;
             if(nfb > 0) {
-                a.tile_list = ws.fb_list.p; a.nrun = nfb;
+                a.tile_list = ws.fb_list.p; a.nrun = 8 * nfb;
                 launch_k_oi(false);
             }
         }

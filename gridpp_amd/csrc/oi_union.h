@@ -77,6 +77,8 @@ struct UnionLds {
     };
     int wpos[U_WCAP];          // slot -> sorted position of the observation
     int worig[U_WCAP];         // slot -> observation index (tie-break); later: obs - background of the extras (float bits)
+    float4 orec[U_MAXU];       // solve: x, y, z, elevation of the observation of every matrix row
+    float olaf[U_MAXU];        //        its land area fraction
 };
 
 __device__ __forceinline__ double rsqrt_nr(const double a) {
@@ -517,12 +519,21 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         for(int k = 0; k < U_MAXU; ++k) if(k >= c && k < u) L.f.erho[k - c][lane] = gf[k];
         if(lane >= c && lane < u) L.worig[lane - c] = __float_as_int(dpf);
         UPROF(6);   // observation records of the union
+        // lower triangle of P (oi.cpp:304-312), one entry per lane and pass: entry e = i (i + 1) / 2 + p, p <= i
+        if(lane < u) { L.orec[lane] = o0; L.olaf[lane] = o1.x; }
         float* colbuf = reinterpret_cast<float*>(L.f.solve);   // [u][U_MAXU]
-        for(int p = 0; p < u; ++p) {
-            const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
-            const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
-            const float cv = d_corr_t<PLAIN>(st, o0.x, o0.y, o0.z, o0.w, o1.x, xp, yp, zp, ep, lp, false);   // oi.cpp:304-312
-            if(lane < u) colbuf[p * U_MAXU + lane] = cv;
+        const int ntri = u * (u + 1) / 2;
+        for(int e0 = 0; e0 < ntri; e0 += 64) {
+            const int e = e0 + lane;
+            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            if(i * (i + 1) / 2 > e) i--;
+            if((i + 1) * (i + 2) / 2 <= e) i++;
+            const int pcol = e - i * (i + 1) / 2;
+            if(e < ntri) {
+                const float4 ri = L.orec[i], rp = L.orec[pcol];
+                const float cv = d_corr_t<PLAIN>(st, ri.x, ri.y, ri.z, ri.w, L.olaf[i], rp.x, rp.y, rp.z, rp.w, L.olaf[pcol], false);
+                colbuf[pcol * U_MAXU + i] = cv;
+            }
         }
         UPROF(7);   // P build
         double row[32], sx[8];
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         for(int p = 0; p < 32; ++p) {
             double v = 0.0;
             if(p < u) {
-                if(lane < u) {
+                if(lane < u && lane >= p) {   // lower triangle only (all the factorisation reads)
                     v = (double)colbuf[p * U_MAXU + lane];
                     if(lane == p) v += (double)o1.w;                                                       // lP + lR
                 }
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
             double v = 0.0;
             const int p = 32 + b;
             if(p < u) {
-                if(lane < u) {
+                if(lane < u && lane >= p) {
                     v = (double)colbuf[p * U_MAXU + lane];
                     if(lane == p) v += (double)o1.w;
                 }
