@@ -568,6 +568,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         // layout of the shared-factor area (doubles)
         const int oL = 0, oI = c * (c + 1) / 2, oZ = oI + c, oB = oZ + c, bs = c | 1, oS = oB + nE * bs, oD = oS + nE * nE;
         double* const sv = L.f.solve;
+        double* const colL = L.f.solve + (U_SOLVE - 64);   // free until the export (1/diag lives below index 600)
         bool bad = false;
         // right-looking Cholesky over the core columns; the trailing rows/columns end as B, the Schur complement, L_C^-1 d, d'
 #pragma unroll
@@ -579,17 +580,14 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
                 if(lane == 0) sv[oI + j] = rs;
                 const double cj = row[j] * rs;
                 row[j] = cj;
+                // column j of the factor goes through LDS: one write, then broadcast reads (two values per ds_read) feed
+                // the rank-1 update -- half the instructions of a v_readlane pair per multiply-add
+                colL[lane] = cj;
 #pragma unroll
-                for(int p = j + 1; p < 32; ++p) {
-                    const double lpj = readlane_d(cj, p);
-                    row[p] = __builtin_fma(-cj, lpj, row[p]);
-                }
+                for(int p = j + 1; p < 32; ++p) row[p] = __builtin_fma(-cj, colL[p], row[p]);
                 if(u > 32) {
 #pragma unroll
-                    for(int b = 0; b < 8; ++b) {
-                        const double lpj = readlane_d(cj, 32 + b);
-                        sx[b] = __builtin_fma(-cj, lpj, sx[b]);
-                    }
+                    for(int b = 0; b < 8; ++b) sx[b] = __builtin_fma(-cj, colL[32 + b], sx[b]);
                 }
             }
         }
