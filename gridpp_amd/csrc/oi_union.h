@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         // rho(cell, candidate c of the chunk) as corr_background gives it, 0 when the candidate is not usable for this cell.
         // PLAIN: straight-line code (selects instead of branches) so that two candidates evaluated back to back interleave.
         const bool hv = d_valid(st.v) && st.v != 0.0f, hw = d_valid(st.w) && st.w != 0.0f, hh = d_valid(st.h) && st.h != 0.0f;
+        const double rh = hh ? 1.0 / (double)st.h : 0.0, rv_ = hv ? 1.0 / (double)st.v : 0.0, rw_ = hw ? 1.0 / (double)st.w : 0.0;
         auto eval = [&](const float4& rec, const float2& met, const int c) {
             const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
             const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
@@ -192,14 +193,14 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
             const bool ok = d2 <= thr2 && inbox && dist <= R;   // within_radius (kdtree.cpp:255), the cut inside corr (structure.cpp:216)
             float rho = 0.0f;
             if constexpr(PLAIN) {
-                rho = hh ? d_barnes_rho_flat(dist, st.h) : 1.0f;
+                rho = hh ? d_barnes_rho_flat(dist, rh) : 1.0f;
                 if(hv) {
                     const float oe = readlane_f(rec.w, c);
-                    if(d_valid(oe)) { const float f = d_barnes_rho_flat(ge - oe, st.v); rho = d_valid(ge) ? rho * f : rho; }
+                    if(d_valid(oe)) { const float f = d_barnes_rho_flat(ge - oe, rv_); rho = d_valid(ge) ? rho * f : rho; }
                 }
                 if(hw) {
                     const float ol = readlane_f(met.x, c);
-                    if(d_valid(ol)) { const float f = d_barnes_rho_flat(gl - ol, st.w); rho = d_valid(gl) ? rho * f : rho; }
+                    if(d_valid(ol)) { const float f = d_barnes_rho_flat(gl - ol, rw_); rho = d_valid(gl) ? rho * f : rho; }
                 }
                 rho = ok ? rho : 0.0f;
             }
