@@ -595,7 +595,8 @@ def optimal_interpolation_full(bgrid, background, bvariance, points, obs, obs_va
 def oi_last_stats():
     s = _capi.gpp_oi_stats()
     check(lib().gpp_oi_last_stats(C.byref(s)))
-    return dict(cells=s.cells, cells_updated=s.cells_updated, solves=s.solves, fallback_tiles=s.fallback_tiles, kernel_ms=s.kernel_ms)
+    return dict(cells=s.cells, cells_updated=s.cells_updated, solves=s.solves, fallback_tiles=s.fallback_tiles, kernel_ms=s.kernel_ms,
+                union_kernel_ms=s.union_kernel_ms)
 
 
 # ---- nearest (src/api/nearest.cpp:124-144) ----------------------------------------------------------

@@ -108,6 +108,7 @@ struct gpp_points {
     std::vector<float> lats, lons, elevs, lafs, x, y, z;   // host copies (float32, as the reference stores them)
     gpp::DevBuf<float> d_x, d_y, d_z, d_elev, d_laf;       // HBM-resident SoA
     bool on_device = false;
+    bool elev_uniform = true, laf_uniform = true;   // every point has the same elevation / laf (or none has one)
     gpp_obs_index* obs_index = nullptr;
     gpp_nn_index* nn_index = nullptr;
     void to_device();

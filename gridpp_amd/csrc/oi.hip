@@ -104,12 +104,16 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int trun = blockIdx.x * 4 + wid;
-    if(trun >= a.nrun) return;
-    // fallback list of k_oi_union: every tile is split into 8 sub-tiles of 8 cells (one wave each) so that the few listed
-    // tiles spread over the whole chip instead of running as a handful of long waves
-    const int tile = a.tile_list ? a.tile_list[trun >> 3] : trun;
-    const int sub = a.tile_list ? (trun & 7) : -1;
+    // all tiles (one per wave), or -- as the fallback of k_oi_union -- a fixed-size grid striding over the listed tiles
+    // (the list length is read on the device, so the host does not have to synchronise between the two kernels)
+    // A short list is split into 8 sub-tiles of 8 cells per tile (one wave each) so that the few listed tiles spread
+    // over the whole chip instead of running as a handful of long waves; a long list keeps whole tiles.
+    const int nlist = a.tile_list ? *a.fb_count : 0;
+    const int split = (a.tile_list && nlist <= 4096) ? 8 : 1;
+    const int nrun = a.tile_list ? nlist * split : a.nrun;
+    for(int trun = blockIdx.x * 4 + wid; trun < nrun; trun += gridDim.x * 4) {
+    const int tile = a.tile_list ? a.tile_list[trun / split] : trun;
+    const int sub = split == 8 ? (trun & 7) : -1;
 
     int cell = -1;
     if(a.tiled2d) {
@@ -453,6 +457,8 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
         a.out[cell] = res_out;
         if(a.out_var) a.out_var[cell] = res_var;
     }
+    __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -464,7 +470,7 @@ struct OiWorkspace {
     DevBuf<float> ones;
     DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_count;
     DevBuf<unsigned long long> counters;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr;
 };
 thread_local OiWorkspace g_ws;
 thread_local gpp_oi_stats g_stats;
@@ -659,7 +665,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     bgrid->to_device();
     gpp_obs_index* ix = gpp_build_obs_index(points);
 
-    if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
+    if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); GPP_HIP(hipEventCreate(&ws.eu)); }
     ws.pgeo.get(S); ws.oaux.get(S);
     ws.err.get(1); ws.counters.get(80);
     GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
@@ -732,9 +738,16 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     };
     // one factorisation per tile (k_oi_union) when the system is symmetric and max_points fits the 32-column tile;
     // the tiles it declines, and every other configuration, run on k_oi (one factorisation per distinct selection)
-    const bool use_union = !use_lu && N == 32 && !getenv("GPP_OI_NO_UNION");
+    // (cells of a tile select nearly the same observations only when rho depends on the horizontal distance alone, i.e.
+    //  when the vertical / laf factors are switched off or constant over both point sets)
+    const bool vfac = a.s.st.v != 0 && is_valid(a.s.st.v) && !(bgrid->elev_uniform && points->elev_uniform);
+    const bool wfac = a.s.st.w != 0 && is_valid(a.s.st.w) && !(bgrid->laf_uniform && points->laf_uniform);
+    const bool want_union = getenv("GPP_OI_UNION") ? atoi(getenv("GPP_OI_UNION")) != 0 : !(vfac || wfac);
+    const bool use_union = !use_lu && N == 32 && want_union && !getenv("GPP_OI_NO_UNION");
+    bool ran_union = false;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.tile_list = nullptr; a.nrun = a.ntiles;
+        ran_union = false;
         if(use_union && !use_lu) {
             ws.fb_list.get(a.ntiles); ws.fb_count.get(1);
             GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, sizeof(int), stream()));
@@ -743,18 +756,18 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             if(plain) hipLaunchKernelGGL((k_oi_union<true>), grid, block, 0, stream(), a);
             else hipLaunchKernelGGL((k_oi_union<false>), grid, block, 0, stream(), a);
             GPP_HIP(hipGetLastError());
-            int nfb = 0;
-            GPP_HIP(hipMemcpyAsync(&nfb, ws.fb_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
-            GPP_HIP(hipStreamSynchronize(stream()));
-            g_stats.fallback_tiles = nfb;
-            if(nfb > 0) {
-                a.tile_list = ws.fb_list.p; a.nrun = 8 * nfb;
-                launch_k_oi(false);
-            }
+            GPP_HIP(hipEventRecord(ws.eu, stream()));
+            // the tiles k_oi_union declined: fixed grid, list length read on the device
+            a.tile_list = ws.fb_list.p; a.nrun = 4 * 512;
+            launch_k_oi(false);
+            ran_union = true;
         }
         else launch_k_oi(use_lu);
         GPP_HIP(hipEventRecord(ws.e1, stream()));
+        int nfb = 0;
+        if(ran_union) GPP_HIP(hipMemcpyAsync(&nfb, ws.fb_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
         fetch();
+        g_stats.fallback_tiles = nfb;
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
             g_stats.fallback_tiles = a.ntiles;
@@ -769,6 +782,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     float ms = 0;
     GPP_HIP(hipEventElapsedTime(&ms, ws.e0, ws.e1));
     g_stats.kernel_ms = ms;
+    g_stats.union_kernel_ms = 0;
+    if(ran_union) GPP_HIP(hipEventElapsedTime(&g_stats.union_kernel_ms, ws.e0, ws.eu));
     g_stats.cells_updated = (long long)counters[0];
     g_stats.solves = (long long)counters[1];
     if(getenv("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);

@@ -158,6 +158,17 @@ static gpp_points* make_points(const float* lats, const float* lons, const float
     p->lons.assign(lons, lons + n);
     if(elevs) p->elevs.assign(elevs, elevs + n); else p->elevs.assign(n, NAN);   // points.cpp:23-30, grid.cpp:41-54
     if(lafs) p->lafs.assign(lafs, lafs + n); else p->lafs.assign(n, NAN);
+    // do the vertical / land-area-fraction factors of a structure function vary over this point set at all?
+    auto uniform = [](const std::vector<float>& v) {   // all invalid, or all valid and equal
+        if(v.empty()) return true;
+        const bool inv0 = std::isnan(v[0]) || std::isinf(v[0]);
+        for(float e : v) {
+            const bool inv = std::isnan(e) || std::isinf(e);
+            if(inv != inv0 || (!inv && e != v[0])) return false;
+        }
+        return true;
+    };
+    p->elev_uniform = uniform(p->elevs); p->laf_uniform = uniform(p->lafs);
     p->x.resize(n); p->y.resize(n); p->z.resize(n);
     convert_all(p->lats.data(), p->lons.data(), n, type, p->x.data(), p->y.data(), p->z.data());
     return p.release();

@@ -205,8 +205,9 @@ typedef struct gpp_oi_stats {
     long long cells;          /* grid cells processed */
     long long cells_updated;  /* cells with at least one usable observation */
     long long solves;         /* local (P+R) factorisations actually performed */
-    long long fallback_tiles; /* tiles that left the fast candidate path */
+    long long fallback_tiles; /* tiles k_oi_union handed to k_oi (or all tiles when the call was redone with the pivoted LU) */
     float kernel_ms;          /* hipEvent time of the OI kernel(s) on the library stream */
+    float union_kernel_ms;    /* of which k_oi_union (one factorisation per tile); 0 when that kernel was not used */
 } gpp_oi_stats;
 int gpp_oi_last_stats(gpp_oi_stats* stats);
 
