@@ -104,16 +104,18 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // all tiles (one per wave), or -- as the fallback of k_oi_union -- a fixed-size grid striding over the listed tiles
-    // (the list length is read on the device, so the host does not have to synchronise between the two kernels)
-    // A short list is split into 8 sub-tiles of 8 cells per tile (one wave each) so that the few listed tiles spread
-    // over the whole chip instead of running as a handful of long waves; a long list keeps whole tiles.
-    const int nlist = a.tile_list ? *a.fb_count : 0;
-    const int split = (a.tile_list && nlist <= 4096) ? 8 : 1;
-    const int nrun = a.tile_list ? nlist * split : a.nrun;
+    // all tiles (one per wave), or -- behind k_oi_union -- a fixed-size grid striding over the list of what that kernel
+    // declined (the list length is read on the device: no host round trip between the kernels).  A list entry >= 0 is
+    // tile * 4 + sub-tile of 16 cells, done by two waves of 8 cells each so that a short list spreads over the chip; an
+    // entry < 0 is ~tile, a whole tile for one wave.
+    const int nrun = a.in_list ? 2 * *a.in_count : a.nrun;
     for(int trun = blockIdx.x * 4 + wid; trun < nrun; trun += gridDim.x * 4) {
-    const int tile = a.tile_list ? a.tile_list[trun / split] : trun;
-    const int sub = split == 8 ? (trun & 7) : -1;
+    int tile = trun, sub = -1;
+    if(a.in_list) {
+        const int entry = a.in_list[trun >> 1];
+        if(entry < 0) { if(trun & 1) continue; tile = ~entry; }
+        else { tile = entry >> 2; sub = (entry & 3) * 2 + (trun & 1); }
+    }
 
     int cell = -1;
     if(a.tiled2d) {
@@ -449,8 +451,9 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
         if(cnt > 0) { res_out = s_res[wid][0][lane]; res_var = s_res[wid][1][lane]; }
         if(__ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
         if(lane == 0 && a.counters) {
-            atomicAdd(&a.counters[0], (unsigned long long)nupd);
-            atomicAdd(&a.counters[1], (unsigned long long)nsolve);
+            unsigned long long* cs = a.counters + 80 + 2 * (blockIdx.x % GPP_NSLOT);
+            atomicAdd(&cs[0], (unsigned long long)nupd);
+            atomicAdd(&cs[1], (unsigned long long)nsolve);
         }
     }
     if(cell >= 0) {
@@ -468,7 +471,7 @@ namespace {
 struct OiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> ones;
-    DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_count;
+    DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_list2, fb_count;
     DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr;
 };
@@ -667,9 +670,9 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
 
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); GPP_HIP(hipEventCreate(&ws.eu)); }
     ws.pgeo.get(S); ws.oaux.get(S);
-    ws.err.get(1); ws.counters.get(80);
+    ws.err.get(1); ws.counters.get(80 + 2 * GPP_NSLOT);
     GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
-    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 80, stream()));
+    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * (80 + 2 * GPP_NSLOT), stream()));
     hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
                        f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p);
     GPP_HIP(hipGetLastError());
@@ -712,7 +715,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const bool spatial = a.s.st.fh != nullptr;   // per-point length scales: P is not symmetric (corr(p1, p2) uses p1's scales)
     bool use_lu = spatial || (a.s.st.v != 0 && odd(a.s.st.kv)) || (a.s.st.w != 0 && odd(a.s.st.kw)) || getenv("GPP_OI_FORCE_LU");
     int err = 0;
-    unsigned long long counters[80];
+    unsigned long long counters[80 + 2 * GPP_NSLOT];
     const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
     auto launch_k_oi = [&](const bool lu) {   // k_oi over a.nrun tiles (all, or the fallback list of k_oi_union)
         const dim3 grid((a.nrun + 3) / 4), block(256);
@@ -746,33 +749,41 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const bool use_union = !use_lu && N == 32 && want_union && !getenv("GPP_OI_NO_UNION");
     bool ran_union = false;
     for(int attempt = 0; attempt < 2; ++attempt) {
-        a.tile_list = nullptr; a.nrun = a.ntiles;
+        a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
         ran_union = false;
         if(use_union && !use_lu) {
-            ws.fb_list.get(a.ntiles); ws.fb_count.get(1);
-            GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, sizeof(int), stream()));
-            a.fb_list = ws.fb_list.p; a.fb_count = ws.fb_count.p;
-            const dim3 grid((a.ntiles + 3) / 4), block(256);
-            if(plain) hipLaunchKernelGGL((k_oi_union<true>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_oi_union<false>), grid, block, 0, stream(), a);
-            GPP_HIP(hipGetLastError());
+            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get((size_t)a.ntiles); ws.fb_count.get(2);
+            GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, 2 * sizeof(int), stream()));
+            const dim3 block(256);
+            auto launch_union = [&](const dim3 grid) {
+                if(plain) hipLaunchKernelGGL((k_oi_union<true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_oi_union<false>), grid, block, 0, stream(), a);
+                GPP_HIP(hipGetLastError());
+            };
+            // pass 1: every tile
+            a.out_list = ws.fb_list.p; a.out_count = ws.fb_count.p;
+            launch_union(dim3((a.ntiles + 3) / 4));
             GPP_HIP(hipEventRecord(ws.eu, stream()));
-            // the tiles k_oi_union declined: fixed grid, list length read on the device
-            a.tile_list = ws.fb_list.p; a.nrun = 4 * 512;
-            launch_k_oi(false);
+            // pass 2: the declined tiles as 4 sub-tiles of 16 cells (smaller unions), fixed grid
+            a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list2.p; a.out_count = ws.fb_count.p + 1;
+            if(!getenv("GPP_OI_SKIP2")) launch_union(dim3(a.ntiles / 16 + 1));   // covers every list the kernel does not forward whole
+            // pass 3: what is still left, one factorisation per distinct selection
+            a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+            if(!getenv("GPP_OI_SKIP3")) launch_k_oi(false);
             ran_union = true;
         }
         else launch_k_oi(use_lu);
         GPP_HIP(hipEventRecord(ws.e1, stream()));
-        int nfb = 0;
-        if(ran_union) GPP_HIP(hipMemcpyAsync(&nfb, ws.fb_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        int nfb[2] = {0, 0};
+        if(ran_union) GPP_HIP(hipMemcpyAsync(nfb, ws.fb_count.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
         fetch();
-        g_stats.fallback_tiles = nfb;
+        g_stats.fallback_tiles = nfb[0];
+        g_stats.fallback_subtiles = nfb[1];
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
             g_stats.fallback_tiles = a.ntiles;
             GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
-            GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 80, stream()));
+            GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * (80 + 2 * GPP_NSLOT), stream()));
             continue;
         }
         break;
@@ -784,8 +795,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     g_stats.kernel_ms = ms;
     g_stats.union_kernel_ms = 0;
     if(ran_union) GPP_HIP(hipEventElapsedTime(&g_stats.union_kernel_ms, ws.e0, ws.eu));
-    g_stats.cells_updated = (long long)counters[0];
-    g_stats.solves = (long long)counters[1];
+    g_stats.cells_updated = 0; g_stats.solves = 0;
+    for(int k = 0; k < GPP_NSLOT; k++) { g_stats.cells_updated += (long long)counters[80 + 2 * k]; g_stats.solves += (long long)counters[81 + 2 * k]; }
     if(getenv("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);
 #ifdef GPP_UNION_PROFILE
     { const char* nm[12] = {"cell loads", "bbox+init", "phase-1 loads", "ring loop", "phase 2", "classify", "union records", "P build", "eliminate", "export", "per-lane", "-"};

@@ -27,14 +27,22 @@ struct OiArgs {
     const float4* oaux;      // original order: laf, obs, pbg, ratio
     int S, allow_extrap;
     int* err;                // bit0: list overflow (needs the large-n path), bit1: singular / not SPD
-    unsigned long long* counters;   // [0] cells updated, [1] factorisations
-    const int* tile_list;    // k_oi: run these tiles only (fallback of k_oi_union); NULL = all
-    int nrun;                // number of tiles to run
-    int* fb_list;            // k_oi_union: tiles left to k_oi
-    int* fb_count;
+    unsigned long long* counters;   // [80 + 2 k], [81 + 2 k]: cells updated, factorisations -- spread over GPP_NSLOT slots (k = block
+                                    // index mod GPP_NSLOT): a quarter of a million atomics on ONE address would serialise in the L2
+    // Work lists (device resident, lengths read on the device: no host round trip between the passes).
+    //   pass 1  k_oi_union over all tiles              -> out_list: tiles it declined
+    //   pass 2  k_oi_union over in_list, 4 sub-tiles of 16 cells each -> out_list: tile * 4 + sub-tile it declined,
+    //           or ~tile (whole tile forwarded) when the list is too long for the split to pay
+    //   pass 3  k_oi over in_list (that encoding)
+    const int* in_list;      // NULL: all tiles
+    const int* in_count;
+    int* out_list;
+    int* out_count;
+    int nrun;                // tiles to run when in_list is NULL
     int debug;               // GPP_OI_DEBUG: bit0 = skip the solve (timing experiments only)
 };
 
+#define GPP_NSLOT 512
 #define ERR_OVERFLOW 1
 #define ERR_SINGULAR 2
 
@@ -79,6 +87,7 @@ struct UnionLds {
     int worig[U_WCAP];         // slot -> observation index (tie-break); later: obs - background of the extras (float bits)
     float4 orec[U_MAXU];       // solve: x, y, z, elevation of the observation of every matrix row
     float olaf[U_MAXU];        //        its land area fraction
+    double late[8][9];         //        (P+R | d) entries of columns 32..39: rows 32..39 and the obs - background row
 };
 
 __device__ __forceinline__ double rsqrt_nr(const double a) {
@@ -88,18 +97,30 @@ __device__ __forceinline__ double rsqrt_nr(const double a) {
     return rs;
 }
 
+// one wave = one tile, or (second pass, in_list set) one of the 4 sub-tiles of 16 cells of a listed tile
+// (2 rows of the 8x8 tile / 16 consecutive points)
 template <bool PLAIN>
 __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
     __shared__ UnionLds s_u[4];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wid;
-    if(tile >= a.ntiles) return;
+    int tile = blockIdx.x * 4 + wid, sub = -1;
+    if(a.in_list) {
+        const int nlist = *a.in_count;
+        if(nlist > a.ntiles / 16) {   // too many declined tiles for the 4-way split to pay: forward them whole
+            for(int i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) a.out_list[atomicAdd(a.out_count, 1)] = ~a.in_list[i];
+            return;
+        }
+        if(tile >= 4 * nlist) return;
+        sub = tile & 3;
+        tile = a.in_list[tile >> 2];
+    }
+    else if(tile >= a.ntiles) return;
+    tile = __builtin_amdgcn_readfirstlane(tile); sub = __builtin_amdgcn_readfirstlane(sub);
     UnionLds& L = s_u[wid];
 #ifdef GPP_UNION_PROFILE
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
-
     int cell = -1;
     if(a.tiled2d) {
         int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -110,6 +131,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         int c = tile * 64 + lane;
         if(c < a.C) cell = c;
     }
+    if(sub >= 0 && (lane >> 4) != sub) cell = -1;
     float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN, bg = NAN, bvar = 1.0f;
     if(cell >= 0) {
         gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell];
@@ -494,7 +516,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         }
     }
     if(fb) {
-        if(lane == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = tile;
+        if(lane == 0) a.out_list[atomicAdd(a.out_count, 1)] = sub < 0 ? tile : tile * 4 + sub;
         return;
     }
     UPROF(5);   // classification
@@ -512,12 +534,19 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         const float dpf = (float)((double)o1.y - (double)o1.z);   // obs - background at the observation (oi.cpp:293)
         // this cell's rho for every row of the union (lG, oi.cpp:296); afterwards the rho slots are dead and the
         // shared-factor area takes their place
-        float gf[U_MAXU];
+        float gf[32];
+        {
+            float gx8[U_MAXU - 32];   // rows 32.. are always extras (c <= 32): they only pass through
 #pragma unroll
-        for(int k = 0; k < U_MAXU; ++k) gf[k] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
-        __builtin_amdgcn_wave_barrier();
+            for(int k = 0; k < 32; ++k) gf[k] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
 #pragma unroll
-        for(int k = 0; k < U_MAXU; ++k) if(k >= c && k < u) L.f.erho[k - c][lane] = gf[k];
+            for(int k = 32; k < U_MAXU; ++k) gx8[k - 32] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for(int k = 0; k < 32; ++k) if(k >= c && k < u) L.f.erho[k - c][lane] = gf[k];
+#pragma unroll
+            for(int k = 32; k < U_MAXU; ++k) if(k < u) L.f.erho[k - c][lane] = gx8[k - 32];
+        }
         if(lane >= c && lane < u) L.worig[lane - c] = __float_as_int(dpf);
         UPROF(6);   // observation records of the union
         // lower triangle of P (oi.cpp:304-312), one entry per lane and pass: entry e = i (i + 1) / 2 + p, p <= i
@@ -537,7 +566,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
             }
         }
         UPROF(7);   // P build
-        double row[32], sx[8];
+        double row[32];
 #pragma unroll
         for(int p = 0; p < 32; ++p) {
             double v = 0.0;
@@ -551,19 +580,22 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
             }
             row[p] = v;
         }
+        // columns 32..u-1 do not fit the 32-column register tile: their entries (rows >= 32 and the obs - background row) wait
+        // in LDS and are reduced after the elimination
+        const int lidx = lane == 63 ? 8 : lane - 32;
 #pragma unroll
         for(int b = 0; b < 8; ++b) {
-            double v = 0.0;
             const int p = 32 + b;
             if(p < u) {
+                double v = 0.0;
                 if(lane < u && lane >= p) {
                     v = (double)colbuf[p * U_MAXU + lane];
                     if(lane == p) v += (double)o1.w;
                 }
                 const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);
                 if(lane == 63) v = dp;
+                if((lane >= p && lane < u) || lane == 63) L.late[b][lidx] = v;
             }
-            sx[b] = v;
         }
         __builtin_amdgcn_wave_barrier();
         // layout of the shared-factor area (doubles)
@@ -586,10 +618,6 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
                 colL[lane] = cj;
 #pragma unroll
                 for(int p = j + 1; p < 32; ++p) row[p] = __builtin_fma(-cj, colL[p], row[p]);
-                if(u > 32) {
-#pragma unroll
-                    for(int b = 0; b < 8; ++b) sx[b] = __builtin_fma(-cj, colL[32 + b], sx[b]);
-                }
             }
         }
         UPROF(8);   // row load + elimination
@@ -609,13 +637,17 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
                 }
             }
         }
-        if(u > 32) {
+        if(u > 32 && !(a.debug & 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
 #pragma unroll
             for(int b = 0; b < 8; ++b) {
                 const int p = 32 + b;
                 if(p < u) {
-                    if(lane >= c && lane < u) sv[oS + ea * nE + (p - c)] = sx[b];
-                    else if(lane == 63) sv[oD + (p - c)] = sx[b];
+                    const bool mine = (lane >= p && lane < u) || lane == 63;
+                    double acc = mine ? L.late[b][lidx] : 0.0;
+#pragma unroll
+                    for(int k = 0; k < 32; ++k) if(k < c) acc = __builtin_fma(-row[k], readlane_d(row[k], p), acc);
+                    if(lane >= p && lane < u) sv[oS + ea * nE + (p - c)] = acc;
+                    else if(lane == 63) sv[oD + (p - c)] = acc;
                 }
             }
         }
@@ -631,7 +663,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
 #pragma unroll
         for(int k = 0; k < 32; ++k) {
             double zk = 0.0;
-            if(k < c) {
+            if(k < c && !(a.debug & 32)) {
                 const double gk = (double)gf[k];
                 double acc0 = 0.0, acc1 = 0.0;
                 const double* lrow = sv + oL + k * (k + 1) / 2;
@@ -652,7 +684,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
             minInc = wave_min(lane < c ? dpf : INFINITY);
         }
         const int mmax = __builtin_amdgcn_readfirstlane((int)wave_max((float)m));
-        if(mmax > 0) {
+        if(mmax > 0 && !(a.debug & 64)) {
             double ll[U_MAXM * (U_MAXM + 1) / 2], qv[U_MAXM], tv[U_MAXM], il[U_MAXM];
 #pragma unroll
             for(int i = 0; i < U_MAXM; ++i) {
@@ -716,8 +748,9 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         }
         if(__ballot(bad && cnt > 0) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
         if(lane == 0 && a.counters) {
-            atomicAdd(&a.counters[0], (unsigned long long)__popcll(upd));
-            atomicAdd(&a.counters[1], 1ull);
+            unsigned long long* cs = a.counters + 80 + 2 * (blockIdx.x % GPP_NSLOT);
+            atomicAdd(&cs[0], (unsigned long long)__popcll(upd));
+            atomicAdd(&cs[1], 1ull);
         }
     }
 #ifdef GPP_UNION_PROFILE
@@ -728,3 +761,4 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         if(a.out_var) a.out_var[cell] = res_var;
     }
 }
+

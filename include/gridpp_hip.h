@@ -207,7 +207,8 @@ typedef struct gpp_oi_stats {
     long long solves;         /* local (P+R) factorisations actually performed */
     long long fallback_tiles; /* tiles k_oi_union handed to k_oi (or all tiles when the call was redone with the pivoted LU) */
     float kernel_ms;          /* hipEvent time of the OI kernel(s) on the library stream */
-    float union_kernel_ms;    /* of which k_oi_union (one factorisation per tile); 0 when that kernel was not used */
+    float union_kernel_ms;    /* of which k_oi_union, first pass (one factorisation per tile); 0 when that kernel was not used */
+    long long fallback_subtiles; /* list entries k_oi_union's second pass (16-cell sub-tiles) left to k_oi */
 } gpp_oi_stats;
 int gpp_oi_last_stats(gpp_oi_stats* stats);
 
