@@ -106,15 +106,14 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // all tiles (one per wave), or -- behind k_oi_union -- a fixed-size grid striding over the list of what that kernel
     // declined (the list length is read on the device: no host round trip between the kernels).  A list entry >= 0 is
-    // tile * 4 + sub-tile of 16 cells, done by two waves of 8 cells each so that a short list spreads over the chip; an
-    // entry < 0 is ~tile, a whole tile for one wave.
-    const int nrun = a.in_list ? 2 * *a.in_count : a.nrun;
+    // tile * 16 + 4-cell item; an entry < 0 is ~tile, a whole tile.
+    const int nrun = a.in_list ? *a.in_count : a.nrun;
     for(int trun = blockIdx.x * 4 + wid; trun < nrun; trun += gridDim.x * 4) {
     int tile = trun, sub = -1;
     if(a.in_list) {
-        const int entry = a.in_list[trun >> 1];
-        if(entry < 0) { if(trun & 1) continue; tile = ~entry; }
-        else { tile = entry >> 2; sub = (entry & 3) * 2 + (trun & 1); }
+        const int entry = a.in_list[trun];
+        if(entry < 0) tile = ~entry;
+        else { tile = entry >> 4; sub = entry & 15; }
     }
 
     int cell = -1;
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
         int c = tile * 64 + lane;
         if(c < a.C) cell = c;
     }
-    if(sub >= 0 && (lane >> 3) != sub) cell = -1;
+    if(sub >= 0 && (lane >> 2) != sub) cell = -1;
     float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN, bg = NAN, bvar = 1.0f;
     if(cell >= 0) {
         gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell];
@@ -471,7 +470,7 @@ namespace {
 struct OiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> ones;
-    DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_list2, fb_count;
+    DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_list2, fb_list3, fb_count;
     DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr;
 };
@@ -752,33 +751,38 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
         ran_union = false;
         if(use_union && !use_lu) {
-            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get((size_t)a.ntiles); ws.fb_count.get(2);
-            GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, 2 * sizeof(int), stream()));
+            // worst case per list: every tile declined and split into 4 (level 1) resp. 16 (level 2) items
+            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get((size_t)a.ntiles / 4 + 64); ws.fb_list3.get((size_t)a.ntiles + 64); ws.fb_count.get(3);
+            GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, 3 * sizeof(int), stream()));
             const dim3 block(256);
-            auto launch_union = [&](const dim3 grid) {
-                if(plain) hipLaunchKernelGGL((k_oi_union<true>), grid, block, 0, stream(), a);
-                else hipLaunchKernelGGL((k_oi_union<false>), grid, block, 0, stream(), a);
+            auto launch_union = [&](const dim3 grid, const bool list) {
+                if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<true, false>), grid, block, 0, stream(), a); }
+                else { if(list) hipLaunchKernelGGL((k_oi_union<false, true>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<false, false>), grid, block, 0, stream(), a); }
                 GPP_HIP(hipGetLastError());
             };
             // pass 1: every tile
             a.out_list = ws.fb_list.p; a.out_count = ws.fb_count.p;
-            launch_union(dim3((a.ntiles + 3) / 4));
+            launch_union(dim3((a.ntiles + 3) / 4), false);
             GPP_HIP(hipEventRecord(ws.eu, stream()));
-            // pass 2: the declined tiles as 4 sub-tiles of 16 cells (smaller unions), fixed grid
-            a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list2.p; a.out_count = ws.fb_count.p + 1;
-            if(!getenv("GPP_OI_SKIP2")) launch_union(dim3(a.ntiles / 16 + 1));   // covers every list the kernel does not forward whole
-            // pass 3: what is still left, one factorisation per distinct selection
-            a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
-            if(!getenv("GPP_OI_SKIP3")) launch_k_oi(false);
+            // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); the grid covers every list the kernel splits
+            // (longer ones are forwarded whole)
+            a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list2.p; a.out_count = ws.fb_count.p + 1; a.level = 1;
+            launch_union(dim3(a.ntiles / 16 + 1), true);
+            // pass 3: the declined 16-cell items as 4 items of 4 cells
+            a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 2;
+            launch_union(dim3(a.ntiles / 16 + 1), true);
+            // pass 4: what is still left, one factorisation per distinct selection
+            a.in_list = ws.fb_list3.p; a.in_count = ws.fb_count.p + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+            launch_k_oi(false);
             ran_union = true;
         }
         else launch_k_oi(use_lu);
         GPP_HIP(hipEventRecord(ws.e1, stream()));
-        int nfb[2] = {0, 0};
-        if(ran_union) GPP_HIP(hipMemcpyAsync(nfb, ws.fb_count.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
+        int nfb[3] = {0, 0, 0};
+        if(ran_union) GPP_HIP(hipMemcpyAsync(nfb, ws.fb_count.p, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
         fetch();
         g_stats.fallback_tiles = nfb[0];
-        g_stats.fallback_subtiles = nfb[1];
+        g_stats.fallback_subtiles = nfb[2];
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
             g_stats.fallback_tiles = a.ntiles;

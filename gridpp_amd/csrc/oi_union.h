@@ -30,15 +30,16 @@ struct OiArgs {
     unsigned long long* counters;   // [80 + 2 k], [81 + 2 k]: cells updated, factorisations -- spread over GPP_NSLOT slots (k = block
                                     // index mod GPP_NSLOT): a quarter of a million atomics on ONE address would serialise in the L2
     // Work lists (device resident, lengths read on the device: no host round trip between the passes).
-    //   pass 1  k_oi_union over all tiles              -> out_list: tiles it declined
-    //   pass 2  k_oi_union over in_list, 4 sub-tiles of 16 cells each -> out_list: tile * 4 + sub-tile it declined,
-    //           or ~tile (whole tile forwarded) when the list is too long for the split to pay
-    //   pass 3  k_oi over in_list (that encoding)
+    //   pass 1  k_oi_union<., false> over all tiles                  -> out_list: tiles it declined
+    //   pass 2  k_oi_union<., true>, level 1: 16-cell quarters        -> out_list: tile * 16 + quarter it declined
+    //   pass 3  k_oi_union<., true>, level 2: 4-cell quarters of those -> out_list: tile * 16 + 4-cell item it declined
+    //   pass 4  k_oi over that list (4 cells per wave); ~tile entries are whole tiles forwarded unsplit
     const int* in_list;      // NULL: all tiles
     const int* in_count;
     int* out_list;
     int* out_count;
     int nrun;                // tiles to run when in_list is NULL
+    int level;               // k_oi_union<., true>: 1 or 2 (see there)
     int debug;               // GPP_OI_DEBUG: bit0 = skip the solve (timing experiments only)
 };
 
@@ -97,22 +98,32 @@ __device__ __forceinline__ double rsqrt_nr(const double a) {
     return rs;
 }
 
-// one wave = one tile, or (second pass, in_list set) one of the 4 sub-tiles of 16 cells of a listed tile
-// (2 rows of the 8x8 tile / 16 consecutive points)
-template <bool PLAIN>
-__global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
+// One wave = one work item.  LIST = false (first pass): the item is a tile.  LIST = true: the items are the 4 children
+// of every entry of in_list -- a.level 1: the 16-cell quarters of a declined tile (2 rows of the 8x8 tile / 16 consecutive
+// points), a.level 2: the 4-cell quarters of a declined 16-cell item.  Smaller items have smaller unions, so almost
+// everything ends on this kernel; what it declines at level 2 goes to k_oi (one factorisation per distinct selection).
+// List entries: tile (produced by the first pass), tile * 16 + item index (levels 1 and 2), ~tile = whole tile
+// forwarded unsplit because the list was too long for the split to pay.
+template <bool PLAIN, bool LIST>
+__global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
     __shared__ UnionLds s_u[4];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int tile = blockIdx.x * 4 + wid, sub = -1;
-    if(a.in_list) {
+    int tile = blockIdx.x * 4 + wid, sub = -1;   // sub: (lane >> shift) of the lanes of this item, -1 = all
+    int shift = 0;
+    if(LIST) {
         const int nlist = *a.in_count;
-        if(nlist > a.ntiles / 16) {   // too many declined tiles for the 4-way split to pay: forward them whole
-            for(int i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) a.out_list[atomicAdd(a.out_count, 1)] = ~a.in_list[i];
+        const bool forwarded = nlist > 0 && a.in_list[0] < 0;   // the previous pass forwarded whole tiles: so does this one
+        if(forwarded || (a.level == 1 && nlist > a.ntiles / 16)) {
+            for(int i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) {
+                const int e = a.in_list[i];
+                a.out_list[atomicAdd(a.out_count, 1)] = e < 0 ? e : ~e;
+            }
             return;
         }
         if(tile >= 4 * nlist) return;
-        sub = tile & 3;
-        tile = a.in_list[tile >> 2];
+        const int child = tile & 3, e = a.in_list[tile >> 2];
+        if(a.level == 1) { tile = e; sub = child; shift = 4; }
+        else { tile = e >> 4; sub = (e & 15) * 4 + child; shift = 2; }
     }
     else if(tile >= a.ntiles) return;
     tile = __builtin_amdgcn_readfirstlane(tile); sub = __builtin_amdgcn_readfirstlane(sub);
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         int c = tile * 64 + lane;
         if(c < a.C) cell = c;
     }
-    if(sub >= 0 && (lane >> 4) != sub) cell = -1;
+    if(LIST && (lane >> shift) != sub) cell = -1;
     float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN, bg = NAN, bvar = 1.0f;
     if(cell >= 0) {
         gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell];
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(256, 3) void k_oi_union(OiArgs a) {
         }
     }
     if(fb) {
-        if(lane == 0) a.out_list[atomicAdd(a.out_count, 1)] = sub < 0 ? tile : tile * 4 + sub;
+        if(lane == 0) a.out_list[atomicAdd(a.out_count, 1)] = LIST ? tile * 16 + sub : tile;
         return;
     }
     UPROF(5);   // classification

@@ -208,7 +208,7 @@ typedef struct gpp_oi_stats {
     long long fallback_tiles; /* tiles k_oi_union handed to k_oi (or all tiles when the call was redone with the pivoted LU) */
     float kernel_ms;          /* hipEvent time of the OI kernel(s) on the library stream */
     float union_kernel_ms;    /* of which k_oi_union, first pass (one factorisation per tile); 0 when that kernel was not used */
-    long long fallback_subtiles; /* list entries k_oi_union's second pass (16-cell sub-tiles) left to k_oi */
+    long long fallback_subtiles; /* work items (4 cells, or whole tiles) k_oi_union's list passes left to k_oi */
 } gpp_oi_stats;
 int gpp_oi_last_stats(gpp_oi_stats* stats);
 
