@@ -752,7 +752,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         ran_union = false;
         if(use_union && !use_lu) {
             // worst case per list: every tile declined and split into 4 (level 1) resp. 16 (level 2) items
-            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get((size_t)a.ntiles / 4 + 64); ws.fb_list3.get((size_t)a.ntiles + 64); ws.fb_count.get(3);
+            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get((size_t)a.ntiles + 64); ws.fb_list3.get((size_t)a.ntiles + 64); ws.fb_count.get(3);
             GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, 3 * sizeof(int), stream()));
             const dim3 block(256);
             auto launch_union = [&](const dim3 grid, const bool list) {
@@ -764,16 +764,23 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             a.out_list = ws.fb_list.p; a.out_count = ws.fb_count.p;
             launch_union(dim3((a.ntiles + 3) / 4), false);
             GPP_HIP(hipEventRecord(ws.eu, stream()));
-            // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); the grid covers every list the kernel splits
-            // (longer ones are forwarded whole)
-            a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list2.p; a.out_count = ws.fb_count.p + 1; a.level = 1;
-            launch_union(dim3(a.ntiles / 16 + 1), true);
-            // pass 3: the declined 16-cell items as 4 items of 4 cells
-            a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 2;
-            launch_union(dim3(a.ntiles / 16 + 1), true);
-            // pass 4: what is still left, one factorisation per distinct selection
-            a.in_list = ws.fb_list3.p; a.in_count = ws.fb_count.p + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
-            launch_k_oi(false);
+            // How many tiles did it decline?  One small host round trip here is cheaper than launching the list passes with
+            // grids sized for the worst case (tens of thousands of empty workgroups), and usually there is nothing left to do.
+            int n1 = 0;
+            GPP_HIP(hipMemcpyAsync(&n1, ws.fb_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+            GPP_HIP(hipStreamSynchronize(stream()));
+            if(n1 > 0) {
+                // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); a list too long for the split to pay is
+                // forwarded whole by the kernel
+                a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list2.p; a.out_count = ws.fb_count.p + 1; a.level = 1;
+                launch_union(dim3(n1), true);
+                // pass 3: the declined 16-cell items as 4 items of 4 cells (at most 4 n1 of them)
+                a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 2;
+                launch_union(dim3(4 * (size_t)n1 > 0x7fffffffull ? 0x7fffffff : 4 * n1), true);
+                // pass 4: what is still left, one factorisation per distinct selection (grid-stride over the list)
+                a.in_list = ws.fb_list3.p; a.in_count = ws.fb_count.p + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                launch_k_oi(false);
+            }
             ran_union = true;
         }
         else launch_k_oi(use_lu);
