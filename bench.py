@@ -154,7 +154,7 @@ def main():
         value = cells_total * args.steps / dt
         all_ms = float(np.mean(kernel_ms))            # every kernel of the call (hipEvents on the library stream)
         k_ms = float(np.mean(union_ms))               # the dominant one: k_oi_union, first pass (all tiles)
-        k_name = "k_oi_union<true>"
+        k_name = "k_oi_union<true, false>"
         if k_ms <= 0:                                  # that kernel was not used (GPP_OI_NO_UNION): k_oi did everything
             k_ms, k_name = all_ms, "k_oi<32, false, true, false>"
         cells_rank = (row1 - row0) * nx
