@@ -1,0 +1,107 @@
+"""Randomised stress of the one-factorisation-per-tile path (k_oi_union) and its work lists against the CPU oracle:
+varying grid shapes (partial tiles), observation densities (unions from a handful to far beyond the 40-row limit, so
+that the 16-cell / 4-cell list passes and the k_oi remainder all run), clustered and duplicated observations (rho ties at
+the max_points cut), missing values, max_points 1..32, anti-extrapolation, variance output, scattered output points
+(tiles of unrelated cells)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _check(out, ref):
+    assert out.shape == ref.shape and (np.isnan(out) == np.isnan(ref)).all()
+    m = ~np.isnan(ref)
+    err = np.abs(out[m].astype(np.float64) - ref[m]) / np.maximum(np.abs(ref[m]), 1e-3)
+    assert err.max() < RTOL, err.max()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations(seed):
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(4000 + seed)
+    Y, X = int(rng.integers(5, 70)), int(rng.integers(5, 70))
+    S = int(rng.choice([3, 12, 40, 150, 600, 2500]))
+    h = float(rng.choice([3000.0, 10000.0, 40000.0]))
+    mp = int(rng.choice([1, 2, 7, 20, 30, 32]))
+    ext = 0.3 * float(rng.choice([0.2, 1.0, 3.0]))          # domain size in degrees: tile size relative to h varies
+    lats, lons = np.meshgrid(np.linspace(60, 60 + ext, Y), np.linspace(10, 10 + 2 * ext, X), indexing="ij")
+    kind = seed % 3
+    if kind == 0:      # uniform
+        plat, plon = 60 + ext * rng.random(S), 10 + 2 * ext * rng.random(S)
+    elif kind == 1:    # clustered: a few dense blobs, many near-coincident observations
+        cy, cx = 60 + ext * rng.random(4), 10 + 2 * ext * rng.random(4)
+        k = rng.integers(0, 4, S)
+        plat, plon = cy[k] + 0.01 * ext * rng.standard_normal(S), cx[k] + 0.02 * ext * rng.standard_normal(S)
+    else:              # exact duplicates: equal rho for several observations at the cut
+        base = max(1, S // 3)
+        by, bx = 60 + ext * rng.random(base), 10 + 2 * ext * rng.random(base)
+        k = rng.integers(0, base, S)
+        plat, plon = by[k], bx[k]
+    bg = rng.normal(0, 2, (Y, X)).astype(np.float32)
+    obs = rng.normal(0, 2, S).astype(np.float32)
+    pbg = rng.normal(0, 2, S).astype(np.float32)
+    ratios = rng.uniform(0.05, 2, S).astype(np.float32)
+    if seed % 4 == 1:
+        obs[rng.random(S) < 0.1] = np.nan
+        bg[rng.random((Y, X)) < 0.05] = np.nan
+    allow = bool(seed % 2)
+    grid, points, st = gridpp.Grid(lats, lons), gridpp.Points(plat, plon), gridpp.BarnesStructure(h)
+    og, op, ost = O.Pts(lats.ravel(), lons.ravel()), O.Pts(plat, plon), O.Barnes(h)
+    out = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, mp, allow)
+    ref = O.oi(og, bg.ravel(), op, obs, ratios, pbg, ost, mp, allow).reshape(Y, X)
+    _check(out, ref)
+    stats = gridpp.oi_last_stats()
+    assert stats["union_kernel_ms"] > 0          # this configuration is routed to k_oi_union
+    # variance output of the same configuration
+    bvar = rng.uniform(0.5, 2, (Y, X)).astype(np.float32)
+    bvp = rng.uniform(0.5, 2, S).astype(np.float32)
+    out2, var = gridpp.optimal_interpolation_full(grid, bg, bvar, points, obs, ratios, pbg, bvp, st, mp, allow)
+    ref2, rvar = O.oi_full(og, bg.ravel(), bvar.ravel(), op, obs, ratios, pbg, bvp, ost, mp, allow)
+    _check(out2, ref2.reshape(Y, X))
+    _check(var, rvar.reshape(Y, X))
+
+
+def test_scattered_output_points_use_the_work_lists():
+    """Output points in random order: the 64 cells of a tile are unrelated, their union is far above 40 rows, so the
+    tiles go down the 16-cell and 4-cell lists and what is left to k_oi -- and every path must give the same values."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    C, S = 5000, 3000
+    qlat, qlon = 60 + rng.random(C), 10 + 2 * rng.random(C)
+    plat, plon = 60 + rng.random(S), 10 + 2 * rng.random(S)
+    bg = rng.normal(0, 1, C).astype(np.float32)
+    obs, pbg = rng.normal(0, 1, S).astype(np.float32), rng.normal(0, 1, S).astype(np.float32)
+    ratios = rng.uniform(0.1, 1, S).astype(np.float32)
+    st = gridpp.BarnesStructure(8000)
+    out = gridpp.optimal_interpolation(gridpp.Points(qlat, qlon), bg, gridpp.Points(plat, plon), obs, ratios, pbg, st, 12)
+    stats = gridpp.oi_last_stats()
+    assert stats["fallback_tiles"] > 0
+    ref = O.oi(O.Pts(qlat, qlon), bg, O.Pts(plat, plon), obs, ratios, pbg, O.Barnes(8000), 12)
+    _check(out, ref)
+    # the same cells sorted along a space-filling order (coherent tiles): identical values, bit for bit
+    order = np.lexsort((np.floor(qlon * 40), np.floor(qlat * 40)))
+    out_s = gridpp.optimal_interpolation(gridpp.Points(qlat[order], qlon[order]), bg[order], gridpp.Points(plat, plon), obs, ratios,
+                                         pbg, st, 12)
+    _check(out_s, ref[order])
+
+
+def test_union_and_per_selection_kernels_agree_on_the_headline_geometry():
+    import os
+    import gridpp_amd as gridpp
+    from bench import make_workload
+    lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(400, 400, 1000, 1002, 0, 400)
+    grid, points, st = gridpp.Grid(lats, lons), gridpp.Points(plat, plon), gridpp.BarnesStructure(10000)
+    a = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 30)
+    assert gridpp.oi_last_stats()["union_kernel_ms"] > 0
+    os.environ["GPP_OI_NO_UNION"] = "1"
+    try:
+        b = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 30)
+        assert gridpp.oi_last_stats()["union_kernel_ms"] == 0
+    finally:
+        del os.environ["GPP_OI_NO_UNION"]
+    err = np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), 1e-3)
+    assert err.max() < 2e-6
