@@ -109,6 +109,9 @@ struct gpp_points {
     gpp::DevBuf<float> d_x, d_y, d_z, d_elev, d_laf;       // HBM-resident SoA
     bool on_device = false;
     bool elev_uniform = true, laf_uniform = true;   // every point has the same elevation / laf (or none has one)
+    // memo of the last OI call with this point set as the background: did k_oi_union pay? (same observations handle and
+    // structure scales -> same geometry -> same answer; the observation VALUES do not matter)
+    struct { const void* points = nullptr; float h = 0, v = 0, w = 0; int max_points = -1; float declined = 0; } union_memo;
     gpp_obs_index* obs_index = nullptr;
     gpp_nn_index* nn_index = nullptr;
     void to_device();

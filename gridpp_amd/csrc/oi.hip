@@ -740,12 +740,13 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     };
     // one factorisation per tile (k_oi_union) when the system is symmetric and max_points fits the 32-column tile;
     // the tiles it declines, and every other configuration, run on k_oi (one factorisation per distinct selection)
-    // (cells of a tile select nearly the same observations only when rho depends on the horizontal distance alone, i.e.
-    //  when the vertical / laf factors are switched off or constant over both point sets)
-    const bool vfac = a.s.st.v != 0 && is_valid(a.s.st.v) && !(bgrid->elev_uniform && points->elev_uniform);
-    const bool wfac = a.s.st.w != 0 && is_valid(a.s.st.w) && !(bgrid->laf_uniform && points->laf_uniform);
-    const bool want_union = getenv("GPP_OI_UNION") ? atoi(getenv("GPP_OI_UNION")) != 0 : !(vfac || wfac);
-    const bool use_union = !use_lu && N == 32 && want_union && !getenv("GPP_OI_NO_UNION");
+    // (With elevation / laf dependent rho the cells of a tile agree less; on smooth terrain most tiles still fit, on
+    //  white-noise elevations none does and the first pass costs a few per cent before the lists hand everything to k_oi.)
+    const bool want_union = getenv("GPP_OI_UNION") ? atoi(getenv("GPP_OI_UNION")) != 0 : true;
+    auto& memo = bgrid->union_memo;
+    const bool memo_hit = memo.points == (const void*)points && memo.h == a.s.st.h && memo.v == a.s.st.v && memo.w == a.s.st.w && memo.max_points == max_points;
+    const bool memo_says_no = memo_hit && memo.declined > 0.5f;   // more than half of the tiles went to k_oi last time: skip the first pass
+    const bool use_union = !use_lu && N == 32 && want_union && !memo_says_no && !getenv("GPP_OI_NO_UNION");
     bool ran_union = false;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
@@ -790,6 +791,10 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         fetch();
         g_stats.fallback_tiles = nfb[0];
         g_stats.fallback_subtiles = nfb[2];
+        if(ran_union) {
+            memo.points = points; memo.h = a.s.st.h; memo.v = a.s.st.v; memo.w = a.s.st.w; memo.max_points = max_points;
+            memo.declined = (float)nfb[0] / (float)a.ntiles;
+        }
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
             g_stats.fallback_tiles = a.ntiles;
