@@ -117,18 +117,46 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
 
     const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
     const double sqc = sqrt(c);
+    // Cells that selected the same observations are visited back to back: their B matrices differ only by the diagonal
+    // scaling with rho, so the eigenvectors of one cell are an excellent starting basis for the next (warm start below).
+    unsigned long long hsig = 0;   // order-independent signature of this lane's selection
+    for(int s = 0; s < a.s.K; ++s) {
+        unsigned long long x = (unsigned long long)origs[s][lane] + 0x9e3779b97f4a7c15ull;
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+        if(s < cnt) hsig += x;
+    }
     unsigned long long todo = __ballot(cnt > 0);
-    int ndone = 0;
+    int ndone = 0, nsweeps = 0;
+    unsigned long long cur_h = 0; int cur_n = -1;
+    unsigned prev_orig = 0xffffffffu; int prev_n = -1;   // sorted selection of the previous cell (lane i = i-th observation)
     while(todo) {
-        const int l = __builtin_ctzll(todo);
-        todo &= todo - 1;
+        unsigned long long grp = __ballot(cnt == cur_n && hsig == cur_h) & todo;
+        if(grp == 0ull) {
+            const int l0 = __builtin_ctzll(todo);
+            cur_n = __builtin_amdgcn_readlane(cnt, l0);
+            cur_h = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hsig >> 32), l0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)hsig, l0);
+            grp = __ballot(cnt == cur_n && hsig == cur_h) & todo;
+        }
+        const int l = __builtin_ctzll(grp);
+        todo &= ~(1ull << l);
         const int n = __builtin_amdgcn_readlane(cnt, l);
         if(nV <= 1) continue;   // Pinv is the zero matrix: rcond <= 0 -> raw values (oi_ensi.cpp:386-390)
         ndone++;
         const int cell_l = __builtin_amdgcn_readlane(cell, l);
         const float cx = readlane_f(gx, l), cy = readlane_f(gy, l), cz = readlane_f(gz, l), ce = readlane_f(ge, l), cl = readlane_f(gl, l);
         // ---- per-observation quantities (lane i < n) ----------------------------------------------------------
-        const unsigned orig_i = (lane < n) ? origs[lane][l] : 0u;
+        // rows in ascending observation index: a canonical order, so that equal selections give equal row orders
+        unsigned orig_i = (lane < n) ? origs[lane][l] : 0xffffffffu;
+        {
+            int rank = 0;
+            for(int j = 0; j < n; ++j) rank += ((unsigned)__builtin_amdgcn_readlane((int)orig_i, j) < orig_i) ? 1 : 0;
+            if(lane < n) s_pq[rank] = (int)orig_i;
+            __syncthreads();
+            orig_i = (lane < n) ? (unsigned)s_pq[lane] : 0u;
+            __syncthreads();
+        }
+        const bool warm = n > 1 && n == prev_n && __ballot(lane < n && orig_i != prev_orig) == 0ull;   // s_U still holds the previous cell's eigenvectors
+        prev_n = n; prev_orig = orig_i;
         float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 1);
         if(lane < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
         DevStructure lst = a.s.st;
@@ -155,9 +183,38 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
                 acc *= s_sD[i] * s_sD[j];
                 s_B[i * BP + j] = acc; s_B[j * BP + i] = acc;
             }
-            s_U[i * BP + j] = (i == j) ? 1.0 : 0.0;
+            if(!warm) s_U[i * BP + j] = (i == j) ? 1.0 : 0.0;
         }
         __syncthreads();
+        if(warm) {
+            // B <- U^T B U in place (U from the previous cell): nearly diagonal already, one or two sweeps finish it.
+            // Phase 1, two rows at a time: T = B U (row i of T needs row i of B only).
+            for(int i0 = 0; i0 < n; i0 += 2) {
+                const int ii = lane / n, j = lane - ii * n, i = i0 + ii;
+                double acc = 0.0;
+                const bool on = ii < 2 && i < n;
+                if(on) for(int k = 0; k < n; ++k) acc = __builtin_fma(s_B[i * BP + k], s_U[k * BP + j], acc);
+                __syncthreads();
+                if(on) s_B[i * BP + j] = acc;
+                __syncthreads();
+            }
+            // Phase 2, two columns at a time: B' = U^T T (column j of B' needs column j of T only).
+            for(int j0 = 0; j0 < n; j0 += 2) {
+                const int jj = lane / n, i = lane - jj * n, j = j0 + jj;
+                double acc = 0.0;
+                const bool on = jj < 2 && j < n;
+                if(on) for(int k = 0; k < n; ++k) acc = __builtin_fma(s_U[k * BP + i], s_B[k * BP + j], acc);
+                __syncthreads();
+                if(on) s_B[i * BP + j] = acc;
+                __syncthreads();
+            }
+            // symmetrise (the two one-sided products round differently)
+            for(int idx = lane; idx < n * n; idx += 64) {
+                const int i = idx / n, j = idx - i * n;
+                if(j < i) { const double v = 0.5 * (s_B[i * BP + j] + s_B[j * BP + i]); s_B[i * BP + j] = v; s_B[j * BP + i] = v; }
+            }
+            __syncthreads();
+        }
         // ---- cyclic Jacobi, round-robin ordering -----------------------------------------------------------------
         const int m = n + (n & 1);
         const int half = m >> 1;
@@ -180,6 +237,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
             for(int idx = lane; idx < n * n; idx += 64) { const int i = idx / n, j = idx - i * n; if(j < i) { double v = s_B[i * BP + j]; off += v * v; } }
             off = wave_sum_d(off);
             if(!(off > 1e-27 * tr * tr)) break;   // off-diagonal norm < 3e-14 * trace: eigenvalues converged to double precision
+            nsweeps++;
             for(int step = 0; step < m - 1; ++step) {
                 if(lane < half) {
                     int p, q;
@@ -331,7 +389,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         if(lane < nV) a.out[(long)cell_l * E + ek] = ensMean + currIncrement;   // :553
         __syncthreads();
     }
-    if(lane == 0 && a.counters) atomicAdd(&a.counters[1], (unsigned long long)ndone);
+    if(lane == 0 && a.counters) { atomicAdd(&a.counters[1], (unsigned long long)ndone); atomicAdd(&a.counters[4 + (blockIdx.x & 31)], (unsigned long long)nsweeps); }
 }
 
 namespace {
@@ -443,8 +501,14 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     int err = 0;
     GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
     f_out.finish();
+    unsigned long long hc[80];
+    if(getenv("GPP_ENSI_STATS")) GPP_HIP(hipMemcpyAsync(hc, ws.counters.p, sizeof(hc), hipMemcpyDeviceToHost, stream()));
     GPP_HIP(hipStreamSynchronize(stream()));
     GPP_HIP(hipEventElapsedTime(&g_ensi_ms, ws.e0, ws.e1));
+    if(getenv("GPP_ENSI_STATS")) {
+        unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
+        fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (double)sw / (double)hc[1] : 0.0);
+    }
     if(err & 1) runtime("optimal_interpolation_ensi: more than 32 observations per grid point requested (max_points == 0 or > 32): large-n path not built yet");
     return GPP_OK;
     GPP_CATCH
