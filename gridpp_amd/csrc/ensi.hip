@@ -34,6 +34,7 @@ struct EnsiArgs {
     const float4* oaux;       // original order: laf, obs, gYhat, sigma
     const float* gY;          // [S][nV] perturbations of the valid members (float)
     const int* validIdx;      // [nV]
+    unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
     int nV;
     int allow_extrap;
     int* err;
@@ -65,6 +66,18 @@ __global__ void k_copy(const float* __restrict__ in, long n, float* __restrict__
     if(i < n) out[i] = in[i];
 }
 
+__device__ __forceinline__ double d_rsq_nr(const double a) {   // 1/sqrt(a), a > 0, ~1 ulp
+    double r = __builtin_amdgcn_rsq(a);
+    r = r * (1.5 - 0.5 * a * r * r);
+    r = r * (1.5 - 0.5 * a * r * r);
+    return r;
+}
+__device__ __forceinline__ double d_rcp_nr(const double a) {   // 1/a, ~1 ulp
+    double r = __builtin_amdgcn_rcp(a);
+    r = r * (2.0 - a * r);
+    r = r * (2.0 - a * r);
+    return r;
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
     for(int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
@@ -72,9 +85,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 template <bool SPATIAL>
 __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
-    __shared__ unsigned long long s_keys[EN][64];        // 16 KB: keys, then origs (u32) + Y tile (f32)
-    __shared__ double s_B[EN * BP];                       // B, later M_W
-    __shared__ double s_U[EN * BP];
+    // 26 KB per wave -> 6 waves per CU: the 16 KB of scan keys are only needed until the selections are parked in HBM
+    // (a.sel, 8 KB per tile, read back one column per cell), after that B and U take their place
+    __shared__ union {
+        unsigned long long keys[EN][64];
+        struct { double B[EN * BP]; double U[EN * BP]; } m;
+    } s_un;
+    __shared__ float s_Yt[EN][64];                        // Y tile of the current cell
+    unsigned long long (*s_keys)[64] = s_un.keys;
+    double* const s_B = s_un.m.B;                         // B, later M_W
+    double* const s_U = s_un.m.U;
     __shared__ double s_sD[EN], s_r[EN], s_z[EN], s_S[EN], s_t[EN], s_dw[EN];
     __shared__ double s_rot[2 * (EN / 2)];
     __shared__ int s_pq[2 * (EN / 2)];
@@ -105,26 +125,24 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         if(lane == 0) atomicOr(a.err, 1);
         cnt = overflow ? 0 : cnt;
     }
-    // compact keys -> u32 observation lists in place (lower 8 KB); the upper 8 KB become the Y tile [EN][64] f32
-    unsigned (*origs)[64] = reinterpret_cast<unsigned (*)[64]>(&s_keys[0][0]);
-    float (*Yt)[64] = reinterpret_cast<float (*)[64]>(&s_keys[EN / 2][0]);
+    // park the selections (observation indices) of the 64 cells in HBM: sel[tile][slot][lane]
+    unsigned* const sel = a.sel + (size_t)tile * EN * 64;
+    float (*Yt)[64] = s_Yt;
+    unsigned long long hsig = 0;   // order-independent signature of this lane's selection
     for(int s = 0; s < a.s.K; ++s) {
-        const unsigned long long kk = s_keys[s][lane];
-        __builtin_amdgcn_wave_barrier();
-        origs[s][lane] = ~(unsigned)(kk & 0xffffffffull);
+        const unsigned o = ~(unsigned)(s_keys[s][lane] & 0xffffffffull);
+        sel[s * 64 + lane] = o;
+        unsigned long long x = (unsigned long long)o + 0x9e3779b97f4a7c15ull;
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+        if(s < cnt) hsig += x;
     }
+    __threadfence();
     __syncthreads();
 
     const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
     const double sqc = sqrt(c);
     // Cells that selected the same observations are visited back to back: their B matrices differ only by the diagonal
     // scaling with rho, so the eigenvectors of one cell are an excellent starting basis for the next (warm start below).
-    unsigned long long hsig = 0;   // order-independent signature of this lane's selection
-    for(int s = 0; s < a.s.K; ++s) {
-        unsigned long long x = (unsigned long long)origs[s][lane] + 0x9e3779b97f4a7c15ull;
-        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-        if(s < cnt) hsig += x;
-    }
     unsigned long long todo = __ballot(cnt > 0);
     int ndone = 0, nsweeps = 0;
     unsigned long long cur_h = 0; int cur_n = -1;
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         const float cx = readlane_f(gx, l), cy = readlane_f(gy, l), cz = readlane_f(gz, l), ce = readlane_f(ge, l), cl = readlane_f(gl, l);
         // ---- per-observation quantities (lane i < n) ----------------------------------------------------------
         // rows in ascending observation index: a canonical order, so that equal selections give equal row orders
-        unsigned orig_i = (lane < n) ? origs[lane][l] : 0xffffffffu;
+        unsigned orig_i = (lane < n) ? __hip_atomic_load(&sel[lane * 64 + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
         {
             int rank = 0;
             for(int j = 0; j < n; ++j) rank += ((unsigned)__builtin_amdgcn_readlane((int)orig_i, j) < orig_i) ? 1 : 0;
@@ -248,9 +266,14 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
                     if(q < n) {
                         const double apq = s_B[p * BP + q];
                         if(apq != 0.0) {
-                            const double theta = (s_B[q * BP + q] - s_B[p * BP + p]) / (2.0 * apq);
-                            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                            cs = 1.0 / sqrt(t * t + 1.0); sn = t * cs;
+                            // rotation angle through v_rcp_f64 / v_rsq_f64 + Newton steps instead of the library division and
+                            // square roots (a third of the instructions; a rotation only has to be orthogonal, and
+                            // cs^2 + sn^2 = 1 holds to the accuracy of cs, the iteration corrects everything else)
+                            const double theta = (s_B[q * BP + q] - s_B[p * BP + p]) * 0.5 * d_rcp_nr(apq);
+                            const double h2 = theta * theta + 1.0;
+                            const double t = (theta >= 0 ? 1.0 : -1.0) * d_rcp_nr(fabs(theta) + h2 * d_rsq_nr(h2));
+                            cs = d_rsq_nr(t * t + 1.0); sn = t * cs;
+                            if(!(fabs(theta) < 1e150)) { cs = 1.0; sn = 0.0; }   // apq negligible against the diagonal gap (theta^2 would overflow)
                         }
                     }
                     else q = p;   // dummy partner: identity
@@ -397,6 +420,7 @@ struct EnsiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> gYhat, gY;
     DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
+    DevBuf<unsigned> sel;
     DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -491,6 +515,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.s.K = (max_points > 0 && max_points <= EN) ? max_points : EN;
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
     a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;
+    a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
     GPP_HIP(hipEventRecord(ws.e0, stream()));
