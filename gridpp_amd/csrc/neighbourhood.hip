@@ -112,7 +112,7 @@ __device__ float row_quantile(const float* row, int n, float q) {   // util.cpp:
 }
 
 #define MEMBER_EC 160   // rows up to this many members are staged through LDS
-#define TB 8            // thresholds per register batch
+#define TB 12           // thresholds per register batch (multiple of 4)
 
 // Mean / Sum / Count of one LDS row with 16-byte reads issued ahead of the (sequential, reference-order) float adds
 __device__ __forceinline__ float row_mean_sum_count_v4(const float* row, int E, int statistic) {
@@ -133,6 +133,25 @@ __device__ __forceinline__ float row_mean_sum_count_v4(const float* row, int E, 
     return (statistic == GPP_MEAN) ? total / (float)count : total;
 }
 
+// sum_k += (v <= th_k) for four thresholds.  Four compares into four SGPR pairs, then four add-with-carry: two
+// instructions per (member, threshold) and no wait states between a compare and its consumer (the compiler's own
+// sequence spends a third of the issue slots on s_nop between v_cmp and the instruction that reads the mask).
+// NaN compares false, like `v <= th`.
+__device__ __forceinline__ void count_le4(const float v, const float t0, const float t1, const float t2, const float t3,
+                                          int& s0, int& s1, int& s2, int& s3) {
+    unsigned long long m0, m1, m2, m3;
+    asm volatile("v_cmp_ge_f32_e64 %4, %9, %8\n\t"
+                 "v_cmp_ge_f32_e64 %5, %10, %8\n\t"
+                 "v_cmp_ge_f32_e64 %6, %11, %8\n\t"
+                 "v_cmp_ge_f32_e64 %7, %12, %8\n\t"
+                 "v_addc_co_u32_e64 %0, %4, %0, 0, %4\n\t"
+                 "v_addc_co_u32_e64 %1, %5, %1, 0, %5\n\t"
+                 "v_addc_co_u32_e64 %2, %6, %2, 0, %6\n\t"
+                 "v_addc_co_u32_e64 %3, %7, %3, 0, %7"
+                 : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                 : "v"(v), "s"(t0), "s"(t1), "s"(t2), "s"(t3));
+}
+
 // per-lane work on one row (members of one cell); forceinlined separately for LDS rows and global rows so that the
 // LDS path keeps address space 3 (a pointer that may be either becomes a slow flat access)
 template <int MODE>
@@ -148,7 +167,7 @@ __device__ __forceinline__ void member_row_work(const float* row, const int E, c
         for(int t0 = 0; t0 < T; t0 += TB) {
             float th[TB]; int sum[TB];
 #pragma unroll
-            for(int k = 0; k < TB; k++) { th[k] = (t0 + k < T) ? thr[t0 + k] : 0.0f; sum[k] = 0; }
+            for(int k = 0; k < TB; k++) { th[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((t0 + k < T) ? thr[t0 + k] : 0.0f))); sum[k] = 0; }
             int cnt = 0;
             if(vec_ok) {   // 16-byte LDS reads, 4 members per read, issued ahead of the compares
                 const float4* r4 = reinterpret_cast<const float4*>(row);
@@ -163,7 +182,7 @@ __device__ __forceinline__ void member_row_work(const float* row, const int E, c
                         const float v = ok ? vv[j] : NAN;   // NaN compares false against every threshold
                         cnt += ok ? 1 : 0;
 #pragma unroll
-                        for(int k = 0; k < TB; k++) sum[k] += (v <= th[k]) ? 1 : 0;
+                        for(int k = 0; k < TB; k += 4) count_le4(v, th[k], th[k + 1], th[k + 2], th[k + 3], sum[k], sum[k + 1], sum[k + 2], sum[k + 3]);
                     }
                 }
             }
