@@ -19,6 +19,7 @@
 // correctly rounded sqrt/div, rho through a double-precision exp), double for the solve.
 #include "oi_common.h"
 #include "oi_union.h"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <memory>
 
@@ -28,8 +29,94 @@ using namespace gpp;
 
 void gpp_free_obs_index(gpp_obs_index* p) { delete p; }
 
+// ---- the same index built on the device (large point sets: a 4000 x 4000 grid as the source of `nearest`) ----------
+__global__ void k_ix_bins(const float* __restrict__ a, const float* __restrict__ b, int n, float amin, float bmin, float inv_s, int nbx, int nby,
+                          int* __restrict__ bin, int* __restrict__ iota) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    int bx = (int)floorf((a[i] - amin) * inv_s), by = (int)floorf((b[i] - bmin) * inv_s);
+    bx = max(0, min(nbx - 1, bx)); by = max(0, min(nby - 1, by));
+    bin[i] = by * nbx + bx;
+    iota[i] = i;
+}
+__global__ void k_ix_starts(const int* __restrict__ sbin, int n, int nbins, int* __restrict__ start) {   // start[b] = first sorted position with bin >= b
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(b > nbins) return;
+    int lo = 0, hi = n;
+    while(lo < hi) { const int mid = (lo + hi) >> 1; if(sbin[mid] < b) lo = mid + 1; else hi = mid; }
+    start[b] = lo;
+}
+__global__ void k_ix_gather(const int* __restrict__ order, int n, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                            const float* __restrict__ elev, const float* __restrict__ laf, float4* __restrict__ sgeo, float2* __restrict__ smeta,
+                            int* __restrict__ pos, float4* __restrict__ ogeo, float* __restrict__ olaf) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= n) return;
+    const int o = order[p];
+    sgeo[p] = make_float4(x[o], y[o], z[o], elev[o]);
+    smeta[p] = make_float2(laf[o], __int_as_float(o));
+    pos[o] = p;
+    ogeo[p] = make_float4(x[p], y[p], z[p], elev[p]);   // (original order: p doubles as the original index here)
+    olaf[p] = laf[p];
+}
+static gpp_obs_index* build_obs_index_device(gpp_points* pts) {
+    std::unique_ptr<gpp_obs_index> ix(new gpp_obs_index);
+    const int S = pts->n;
+    ix->S = S;
+    pts->to_device();
+    const float* dax[3] = {pts->d_x.p, pts->d_y.p, pts->d_z.p};
+    // extents of the three axes
+    DevBuf<float> d_mm;
+    DevBuf<char> tmp;
+    d_mm.get(6);
+    size_t tb = 0;
+    GPP_HIP(hipcub::DeviceReduce::Min((void*)nullptr, tb, dax[0], d_mm.p, S, stream()));
+    tmp.get(tb);
+    for(int d = 0; d < 3; d++) {
+        GPP_HIP(hipcub::DeviceReduce::Min((void*)tmp.p, tb, dax[d], d_mm.p + 2 * d, S, stream()));
+        GPP_HIP(hipcub::DeviceReduce::Max((void*)tmp.p, tb, dax[d], d_mm.p + 2 * d + 1, S, stream()));
+    }
+    float mm[6];
+    GPP_HIP(hipMemcpyAsync(mm, d_mm.p, sizeof(mm), hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    float lo[3] = {mm[0], mm[2], mm[4]}, hi[3] = {mm[1], mm[3], mm[5]};
+    int order3[3] = {0, 1, 2};
+    std::sort(order3, order3 + 3, [&](int p, int q) { return (hi[p] - lo[p]) > (hi[q] - lo[q]); });
+    const int a = std::min(order3[0], order3[1]), b = std::max(order3[0], order3[1]);
+    ix->axis_a = a; ix->axis_b = b;
+    const double ea = std::max((double)hi[a] - lo[a], 1e-3), eb = std::max((double)hi[b] - lo[b], 1e-3);
+    double s = std::sqrt(4.0 * ea * eb / std::max(S, 1));   // ~4 points per bin
+    s = std::max(s, std::max(ea, eb) / 2048.0);
+    const int nbx = std::max(1, std::min(2048, (int)std::ceil(ea / s))), nby = std::max(1, std::min(2048, (int)std::ceil(eb / s)));
+    ix->amin = lo[a]; ix->bmin = lo[b]; ix->inv_s = (float)(1.0 / s);
+    ix->nbx = nbx; ix->nby = nby;
+    const int nbins = nbx * nby;
+    // stable sort of the point indices by bin (index order inside a bin, like the host build)
+    DevBuf<int> bin, sbin, iota, order;
+    bin.get(S); sbin.get(S); iota.get(S); order.get(S);
+    hipLaunchKernelGGL(k_ix_bins, dim3((S + 255) / 256), dim3(256), 0, stream(), dax[a], dax[b], S, ix->amin, ix->bmin, ix->inv_s, nbx, nby, bin.p, iota.p);
+    GPP_HIP(hipGetLastError());
+    int bits = 1;
+    while((1ll << bits) < nbins) bits++;
+    size_t sb = 0;
+    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)nullptr, sb, bin.p, sbin.p, iota.p, order.p, S, 0, bits, stream()));
+    DevBuf<char> stmp;
+    stmp.get(sb);
+    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)stmp.p, sb, bin.p, sbin.p, iota.p, order.p, S, 0, bits, stream()));
+    ix->d_bin_start.get(nbins + 1);
+    hipLaunchKernelGGL(k_ix_starts, dim3((nbins + 1 + 255) / 256), dim3(256), 0, stream(), sbin.p, S, nbins, ix->d_bin_start.p);
+    ix->d_sgeo.get(S); ix->d_smeta.get(S); ix->d_pos.get(S); ix->d_ogeo.get(S); ix->d_olaf.get(S);
+    hipLaunchKernelGGL(k_ix_gather, dim3((S + 255) / 256), dim3(256), 0, stream(), order.p, S, pts->d_x.p, pts->d_y.p, pts->d_z.p, pts->d_elev.p, pts->d_laf.p,
+                       ix->d_sgeo.p, ix->d_smeta.p, ix->d_pos.p, ix->d_ogeo.p, ix->d_olaf.p);
+    GPP_HIP(hipGetLastError());
+    GPP_HIP(hipStreamSynchronize(stream()));
+    pts->obs_index = ix.release();
+    return pts->obs_index;
+}
+
 gpp_obs_index* gpp_build_obs_index(gpp_points* pts) {
     if(pts->obs_index) return pts->obs_index;
+    if(pts->n >= (1 << 17) && !getenv("GPP_HOST_INDEX")) return build_obs_index_device(pts);
+    pts->ensure_host_xyz();
     std::unique_ptr<gpp_obs_index> ix(new gpp_obs_index);
     int S = pts->n;
     ix->S = S;
@@ -524,7 +611,7 @@ DevStructure gpp_resolve_structure(const gpp_structure* s) {
 // field index (nearest neighbour in the field's grid, src/api/structure.cpp:190) of every point of `pts`; NULL = identity
 static const int* field_indices(const gpp_field* f, gpp_points* pts, DevBuf<int>& buf) {
     if(f->grid == pts) return nullptr;
-    if(f->grid->n == pts->n && f->grid->type == pts->type && f->grid->x == pts->x && f->grid->y == pts->y && f->grid->z == pts->z) return nullptr;
+    if(f->grid->n == pts->n && f->grid->type == pts->type && f->grid->lats == pts->lats && f->grid->lons == pts->lons) return nullptr;
     pts->to_device();
     buf.get(pts->n);
     gpp_nearest_device(f->grid, pts->d_x.p, pts->d_y.p, pts->d_z.p, pts->n, 1, buf.p);

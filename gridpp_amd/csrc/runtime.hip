@@ -130,12 +130,96 @@ extern "C" int gpp_convert_coordinates(const float* lats, const float* lons, int
     GPP_CATCH
 }
 
+// ---- the same conversion on the device, for large point sets --------------------------------------------------
+// x/y/z must equal the host libm values bit for bit.  Both libm's and the device library's sin / cos are accurate to a
+// couple of ulp(double); the float32 rounding of two doubles that close differs only if a float32 rounding boundary
+// lies between them.  So the kernel computes in double, rounds, and lists every point one of whose coordinates lies
+// within 64 ulp(double) of such a boundary (about 3 in 10^8); the host recomputes those few with libm and patches them.
+#pragma clang fp contract(off)
+__device__ __forceinline__ bool d_near_float_boundary(const double v) {
+    const float f = (float)v;
+    if(!(fabs(v) < 3.0e38)) return true;
+    const double fd = (double)f;
+    const float fn = (v >= fd) ? nextafterf(f, INFINITY) : nextafterf(f, -INFINITY);   // the neighbour on v's side
+    const double mid = 0.5 * (fd + (double)fn);
+    return fabs(v - mid) <= fabs(v) * 1.5e-14 + 1e-300;
+}
+__global__ void k_convert(const float* __restrict__ lats, const float* __restrict__ lons, int n, int type,
+                          float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
+                          int* __restrict__ flagged, int cap, int* __restrict__ counters) {   // counters[0] = #flagged, [1] = invalid input
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    const float lat = lats[i], lon = lons[i];
+    const bool vlat = !isnan(lat) && !isinf(lat), vlon = !isnan(lon) && !isinf(lon);
+    const bool ok = (type == GPP_CARTESIAN) ? vlat : (vlat && (double)lat >= -90.001 && (double)lat <= 90.001);
+    if(!ok || !vlon) { counters[1] = 1; return; }
+    if(type == GPP_CARTESIAN) { x[i] = lon; y[i] = lat; z[i] = 0; return; }
+    const double lonr = M_PI / 180 * (double)lon, latr = M_PI / 180 * (double)lat;
+    const double cl = cos(latr), sl = sin(latr), co = cos(lonr), so = sin(lonr);
+    const double xd = cl * co * 6.378137e6, yd = cl * so * 6.378137e6, zd = sl * 6.378137e6;
+    x[i] = (float)xd; y[i] = (float)yd; z[i] = (float)zd;
+    if(d_near_float_boundary(xd) || d_near_float_boundary(yd) || d_near_float_boundary(zd)) {
+        const int k = atomicAdd(&counters[0], 1);
+        if(k < cap) flagged[k] = i;
+    }
+}
+__global__ void k_patch(const int* __restrict__ idx, const float* __restrict__ v, int m, float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= m) return;
+    const int i = idx[k];
+    x[i] = v[3 * k]; y[i] = v[3 * k + 1]; z[i] = v[3 * k + 2];
+}
+// returns false when the device result cannot be trusted (too many boundary cases): the caller converts on the host
+static bool convert_all_device(gpp_points* p) {
+    const int n = p->n;
+    DevBuf<float> d_lat, d_lon;
+    DevBuf<int> d_flag, d_cnt;
+    const int cap = 1 << 16;
+    d_lat.upload(p->lats.data(), n); d_lon.upload(p->lons.data(), n);
+    p->d_x.get(n); p->d_y.get(n); p->d_z.get(n);
+    d_flag.get(cap); d_cnt.get(2);
+    GPP_HIP(hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(int), stream()));
+    hipLaunchKernelGGL(k_convert, dim3((n + 255) / 256), dim3(256), 0, stream(), d_lat.p, d_lon.p, n, p->type, p->d_x.p, p->d_y.p, p->d_z.p, d_flag.p, cap, d_cnt.p);
+    GPP_HIP(hipGetLastError());
+    int cnt[2] = {0, 0};
+    GPP_HIP(hipMemcpyAsync(cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    if(cnt[1]) invalid("Invalid coords");   // util.cpp:596-600
+    if(cnt[0] > cap) return false;
+    if(cnt[0] > 0) {
+        std::vector<int> idx(cnt[0]);
+        GPP_HIP(hipMemcpy(idx.data(), d_flag.p, sizeof(int) * cnt[0], hipMemcpyDeviceToHost));
+        std::vector<float> v(3 * (size_t)cnt[0]);
+        for(int k = 0; k < cnt[0]; k++) {
+            float lat = p->lats[idx[k]], lon = p->lons[idx[k]];
+            convert_range(&lat, &lon, 0, 1, p->type, &v[3 * k], &v[3 * k + 1], &v[3 * k + 2]);
+        }
+        DevBuf<float> d_v;
+        DevBuf<int> d_i;
+        d_v.upload(v.data(), v.size()); d_i.upload(idx.data(), idx.size());
+        hipLaunchKernelGGL(k_patch, dim3((cnt[0] + 255) / 256), dim3(256), 0, stream(), d_i.p, d_v.p, cnt[0], p->d_x.p, p->d_y.p, p->d_z.p);
+        GPP_HIP(hipGetLastError());
+        GPP_HIP(hipStreamSynchronize(stream()));
+    }
+    return true;
+}
+
 // ---- point sets ---------------------------------------------------------------
+void gpp_points::ensure_host_xyz() {
+    if(host_xyz) return;
+    x.resize(n); y.resize(n); z.resize(n);
+    GPP_HIP(hipMemcpy(x.data(), d_x.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    GPP_HIP(hipMemcpy(y.data(), d_y.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    GPP_HIP(hipMemcpy(z.data(), d_z.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    host_xyz = true;
+}
 void gpp_points::to_device() {
     if(on_device) return;
-    d_x.upload(x.data(), n);
-    d_y.upload(y.data(), n);
-    d_z.upload(z.data(), n);
+    if(host_xyz) {   // (a set converted on the device has its x / y / z there already)
+        d_x.upload(x.data(), n);
+        d_y.upload(y.data(), n);
+        d_z.upload(z.data(), n);
+    }
     d_elev.upload(elevs.data(), n);
     d_laf.upload(lafs.data(), n);
     GPP_HIP(hipStreamSynchronize(gpp::stream()));
@@ -169,8 +253,19 @@ static gpp_points* make_points(const float* lats, const float* lons, const float
         return true;
     };
     p->elev_uniform = uniform(p->elevs); p->laf_uniform = uniform(p->lafs);
-    p->x.resize(n); p->y.resize(n); p->z.resize(n);
-    convert_all(p->lats.data(), p->lons.data(), n, type, p->x.data(), p->y.data(), p->z.data());
+    // large sets: conversion on the device (the host copies of x / y / z are made only if a host-side function needs them)
+    bool done = false;
+    if(n >= (1 << 16) && !getenv("GPP_HOST_CONVERT")) {
+        if(type != GPP_GEODETIC && type != GPP_CARTESIAN) invalid("Unknown coordinate type");
+        ensure_device();
+        p->host_xyz = false;
+        done = convert_all_device(p.get());
+        if(!done) p->host_xyz = true;
+    }
+    if(!done) {
+        p->x.resize(n); p->y.resize(n); p->z.resize(n);
+        convert_all(p->lats.data(), p->lons.data(), n, type, p->x.data(), p->y.data(), p->z.data());
+    }
     return p.release();
 }
 
@@ -210,6 +305,7 @@ extern "C" int gpp_points_get(const gpp_points* p, int field, float* out) {
     GPP_TRY
     if(!p) invalid("points is NULL");
     const std::vector<float>* v = nullptr;
+    if(field >= 4) const_cast<gpp_points*>(p)->ensure_host_xyz();
     switch(field) {
         case 0: v = &p->lats; break;
         case 1: v = &p->lons; break;
@@ -235,6 +331,7 @@ extern "C" int gpp_points_get_neighbours(gpp_points* p, float lat, float lon, fl
                                          int* indices, float* distances, int cap, int* count) {
     GPP_TRY
     if(!p || !count) invalid("NULL argument");
+    p->ensure_host_xyz();
     float qx, qy, qz;
     convert_all(&lat, &lon, 1, p->type, &qx, &qy, &qz);
     float lox = qx - radius, hix = qx + radius, loy = qy - radius, hiy = qy + radius, loz = qz - radius, hiz = qz + radius;
@@ -263,6 +360,7 @@ extern "C" int gpp_points_get_closest_neighbours(gpp_points* p, float lat, float
     if(!p || !count) invalid("NULL argument");
     *count = 0;
     if(num <= 0 || p->n == 0) return GPP_OK;
+    p->ensure_host_xyz();
     float qx, qy, qz;
     convert_all(&lat, &lon, 1, p->type, &qx, &qy, &qz);
     std::vector<std::pair<float, int>> d;
