@@ -28,7 +28,7 @@ struct EnsiArgs {
     const float *gx, *gy, *gz, *gelev, *glaf;
     const float* bg;          // [C][E]
     float* out;               // [C][E]
-    int C, E, ny, nx, tiles_x, ntiles, tiled2d;
+    int C, E, ny, nx, tiles_x, ntiles, tiled2d, wshift;
     ScanArgs s;
     const float4* ogeo;       // original order: x,y,z,elev
     const float4* oaux;       // original order: laf, obs, gYhat, sigma
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
     int cell = -1;
     if(a.tiled2d) {
         int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        int y = ty * 8 + (lane >> 3), x = tx * 8 + (lane & 7);
+        int y = ty * (64 >> a.wshift) + (lane >> a.wshift), x = (tx << a.wshift) + (lane & ((1 << a.wshift) - 1));
         if(y < a.ny && x < a.nx) cell = y * a.nx + x;
     }
     else {
@@ -500,7 +500,12 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.bg = f_bg.d; a.out = f_out.d;
     a.C = C; a.E = E; a.ny = bgrid->ny; a.nx = bgrid->nx;
     a.tiled2d = (bgrid->nx > 0 && (long)bgrid->ny * bgrid->nx == C) ? 1 : 0;
-    if(a.tiled2d) { a.tiles_x = (a.nx + 7) / 8; a.ntiles = a.tiles_x * ((a.ny + 7) / 8); }
+    a.wshift = 3;
+    if(a.tiled2d) {
+        a.wshift = gpp_tile_wshift(bgrid);
+        const int tw = 1 << a.wshift, th = 64 >> a.wshift;
+        a.tiles_x = (a.nx + tw - 1) / tw; a.ntiles = a.tiles_x * ((a.ny + th - 1) / th);
+    }
     else { a.tiles_x = 0; a.ntiles = (C + 63) / 64; }
     a.s.pgeo = ws.pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
     a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;

@@ -174,6 +174,25 @@ gpp_obs_index* gpp_build_obs_index(gpp_points* pts) {
     return pts->obs_index;
 }
 
+int gpp_tile_wshift(gpp_points* g) {
+    if(getenv("GPP_TILE_WSHIFT")) return std::max(0, std::min(6, atoi(getenv("GPP_TILE_WSHIFT"))));
+    if(g->ny < 2 || g->nx < 2) return g->nx >= 64 ? 6 : 3;
+    // metric size of a cell from the three corner points (0,0), (0,1), (1,0), in the library's own coordinates
+    const float la[3] = {g->lats[0], g->lats[1], g->lats[g->nx]}, lo[3] = {g->lons[0], g->lons[1], g->lons[g->nx]};
+    float x[3], y[3], z[3];
+    if(gpp_convert_coordinates(la, lo, 3, g->type, x, y, z) != GPP_OK) return 3;
+    auto dist = [&](int i) { return std::sqrt((double)(x[i] - x[0]) * (x[i] - x[0]) + (double)(y[i] - y[0]) * (y[i] - y[0]) + (double)(z[i] - z[0]) * (z[i] - z[0])); };
+    const double dx = std::max(dist(1), 1e-9), dy = std::max(dist(2), 1e-9);
+    int best = 3; double bext = 1e300;
+    for(int w = 0; w <= 6; w++) {
+        if((1 << w) > 2 * g->nx && w > 0) break;           // no point in tiles much wider than the grid
+        if((64 >> w) > 2 * g->ny && w < 6) continue;
+        const double ext = std::max((1 << w) * dx, (64 >> w) * dy);
+        if(ext < bext * 0.999) { bext = ext; best = w; }
+    }
+    return best;
+}
+
 __global__ void k_structure_corr(DevStructure st, float4 p1, float l1, float4 p2, float l2, int background, float* out) {
     out[0] = d_corr(st, p1.x, p1.y, p1.z, p1.w, l1, p2.x, p2.y, p2.z, p2.w, l2, background != 0);
 }
@@ -193,27 +212,31 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // all tiles (one per wave), or -- behind k_oi_union -- a fixed-size grid striding over the list of what that kernel
     // declined (the list length is read on the device: no host round trip between the kernels).  A list entry >= 0 is
-    // tile * 16 + 4-cell item; an entry < 0 is ~tile, a whole tile.
+    // tile * 32 + code (code 0..15: a 4-cell item, 16..19: a 16-cell item); an entry < 0 is ~tile, a whole tile.
     const int nrun = a.in_list ? *a.in_count : a.nrun;
     for(int trun = blockIdx.x * 4 + wid; trun < nrun; trun += gridDim.x * 4) {
-    int tile = trun, sub = -1;
+    int tile = trun, sub = -1, shift = 0;
     if(a.in_list) {
         const int entry = a.in_list[trun];
         if(entry < 0) tile = ~entry;
-        else { tile = entry >> 4; sub = entry & 15; }
+        else {
+            tile = entry >> 5;
+            const int code = entry & 31;
+            if(code < 16) { sub = code; shift = 2; } else { sub = code - 16; shift = 4; }
+        }
     }
 
     int cell = -1;
     if(a.tiled2d) {
         int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        int y = ty * 8 + (lane >> 3), x = tx * 8 + (lane & 7);
+        int y = ty * (64 >> a.wshift) + (lane >> a.wshift), x = (tx << a.wshift) + (lane & ((1 << a.wshift) - 1));
         if(y < a.ny && x < a.nx) cell = y * a.nx + x;
     }
     else {
         int c = tile * 64 + lane;
         if(c < a.C) cell = c;
     }
-    if(sub >= 0 && (lane >> 2) != sub) cell = -1;
+    if(sub >= 0 && (lane >> shift) != sub) cell = -1;
     float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN, bg = NAN, bvar = 1.0f;
     if(cell >= 0) {
         gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell];
@@ -771,7 +794,12 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     a.bg = f_bg.d; a.bvar = f_bvar.d; a.out = f_out.d; a.out_var = f_var.d;
     a.C = C; a.ny = bgrid->ny; a.nx = bgrid->nx;
     a.tiled2d = (bgrid->nx > 0 && (long)bgrid->ny * bgrid->nx == C) ? 1 : 0;
-    if(a.tiled2d) { a.tiles_x = (a.nx + 7) / 8; a.ntiles = a.tiles_x * ((a.ny + 7) / 8); }
+    a.wshift = 3;
+    if(a.tiled2d) {
+        a.wshift = gpp_tile_wshift(bgrid);
+        const int tw = 1 << a.wshift, th = 64 >> a.wshift;
+        a.tiles_x = (a.nx + tw - 1) / tw; a.ntiles = a.tiles_x * ((a.ny + th - 1) / th);
+    }
     else { a.tiles_x = 0; a.ntiles = (C + 63) / 64; }
     a.s.pgeo = ws.pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
@@ -840,7 +868,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         ran_union = false;
         if(use_union && !use_lu) {
             // worst case per list: every tile declined and split into 4 (level 1) resp. 16 (level 2) items
-            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get((size_t)a.ntiles + 64); ws.fb_list3.get((size_t)a.ntiles + 64); ws.fb_count.get(3);
+            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get(2 * (size_t)a.ntiles + 64); ws.fb_list3.get(4 * (size_t)a.ntiles + 64); ws.fb_count.get(3);
             GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, 3 * sizeof(int), stream()));
             const dim3 block(256);
             auto launch_union = [&](const dim3 grid, const bool list) {
@@ -864,6 +892,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 launch_union(dim3(n1), true);
                 // pass 3: the declined 16-cell items as 4 items of 4 cells (at most 4 n1 of them)
                 a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 2;
+                a.parent_count = ws.fb_count.p;
                 launch_union(dim3(4 * (size_t)n1 > 0x7fffffffull ? 0x7fffffff : 4 * n1), true);
                 // pass 4: what is still left, one factorisation per distinct selection (grid-stride over the list)
                 a.in_list = ws.fb_list3.p; a.in_count = ws.fb_count.p + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;

@@ -29,6 +29,9 @@ struct gpp_field {   // spatially varying structure parameters resident in HBM (
     std::vector<float> h, v, w, R;
     gpp::DevBuf<float> d_h, d_v, d_w, d_R;
 };
+// log2 of the width (in grid columns) of the 64-cell tile of a 2-D grid: the most square tile in metres (8 x 8 cells for
+// an isotropic grid, 2 x 32 or 32 x 2 for strongly anisotropic ones) -- the cells of a tile should select the same observations
+int gpp_tile_wshift(gpp_points* grid);   // oi.hip
 struct DevStructure;
 DevStructure gpp_resolve_structure(const gpp_structure* s);   // oi.hip: validation + localization distance
 void gpp_bind_field(DevStructure& d, const gpp_structure* s, gpp_points* bgrid, gpp_points* points, gpp::DevBuf<int>& cbuf, gpp::DevBuf<int>& obuf);

@@ -22,6 +22,7 @@ struct OiArgs {
     const float *gx, *gy, *gz, *gelev, *glaf, *bg, *bvar;
     float *out, *out_var;
     int C, ny, nx, tiles_x, ntiles, tiled2d;
+    int wshift;              // log2 of the tile width in columns (tile = (64 >> wshift) rows x (1 << wshift) columns)
     ScanArgs s;
     const float4* ogeo;      // original order
     const float4* oaux;      // original order: laf, obs, pbg, ratio
@@ -40,6 +41,7 @@ struct OiArgs {
     int* out_count;
     int nrun;                // tiles to run when in_list is NULL
     int level;               // k_oi_union<., true>: 1 or 2 (see there)
+    const int* parent_count; // level 2: length of the level-1 input list (how many tiles were split)
     int debug;               // GPP_OI_DEBUG: bit0 = skip the solve (timing experiments only)
 };
 
@@ -99,11 +101,11 @@ __device__ __forceinline__ double rsqrt_nr(const double a) {
 }
 
 // One wave = one work item.  LIST = false (first pass): the item is a tile.  LIST = true: the items are the 4 children
-// of every entry of in_list -- a.level 1: the 16-cell quarters of a declined tile (2 rows of the 8x8 tile / 16 consecutive
-// points), a.level 2: the 4-cell quarters of a declined 16-cell item.  Smaller items have smaller unions, so almost
+// of every entry of in_list -- a.level 1: the 16-cell quarters of a declined tile (16 consecutive lanes),
+// a.level 2: the 4-cell quarters of a declined 16-cell item.  Smaller items have smaller unions, so almost
 // everything ends on this kernel; what it declines at level 2 goes to k_oi (one factorisation per distinct selection).
-// List entries: tile (produced by the first pass), tile * 16 + item index (levels 1 and 2), ~tile = whole tile
-// forwarded unsplit because the list was too long for the split to pay.
+// List entries: tile (produced by the first pass); tile * 32 + code with code 16..19 = 16-cell item, 0..15 = 4-cell item;
+// ~tile = whole tile forwarded unsplit because splitting would not pay (see `forward` below).
 template <bool PLAIN, bool LIST>
 __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
     __shared__ UnionLds s_u[4];
@@ -112,18 +114,21 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
     int shift = 0;
     if(LIST) {
         const int nlist = *a.in_count;
-        const bool forwarded = nlist > 0 && a.in_list[0] < 0;   // the previous pass forwarded whole tiles: so does this one
-        if(forwarded || (a.level == 1 && nlist > a.ntiles / 16)) {
+        // Splitting pays while most items succeed.  Level 1: more than half of the tiles declined -> forward them whole.
+        // Level 2: more than half of the 16-cell items declined (or whole tiles arrived) -> forward what arrived, unsplit.
+        const bool whole = nlist > 0 && a.in_list[0] < 0;
+        const bool forward = whole || (a.level == 1 ? nlist > a.ntiles / 2 : nlist > 2 * *a.parent_count);
+        if(forward) {
             for(int i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) {
                 const int e = a.in_list[i];
-                a.out_list[atomicAdd(a.out_count, 1)] = e < 0 ? e : ~e;
+                a.out_list[atomicAdd(a.out_count, 1)] = (a.level == 1) ? ~e : e;
             }
             return;
         }
         if(tile >= 4 * nlist) return;
         const int child = tile & 3, e = a.in_list[tile >> 2];
         if(a.level == 1) { tile = e; sub = child; shift = 4; }
-        else { tile = e >> 4; sub = (e & 15) * 4 + child; shift = 2; }
+        else { tile = e >> 5; sub = ((e & 31) - 16) * 4 + child; shift = 2; }
     }
     else if(tile >= a.ntiles) return;
     tile = __builtin_amdgcn_readfirstlane(tile); sub = __builtin_amdgcn_readfirstlane(sub);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
     int cell = -1;
     if(a.tiled2d) {
         int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        int y = ty * 8 + (lane >> 3), x = tx * 8 + (lane & 7);
+        int y = ty * (64 >> a.wshift) + (lane >> a.wshift), x = (tx << a.wshift) + (lane & ((1 << a.wshift) - 1));
         if(y < a.ny && x < a.nx) cell = y * a.nx + x;
     }
     else {
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
         }
     }
     if(fb) {
-        if(lane == 0) a.out_list[atomicAdd(a.out_count, 1)] = LIST ? tile * 16 + sub : tile;
+        if(lane == 0) a.out_list[atomicAdd(a.out_count, 1)] = !LIST ? tile : (tile * 32 + (a.level == 1 ? 16 + sub : sub));
         return;
     }
     UPROF(5);   // classification

@@ -105,3 +105,30 @@ def test_union_and_per_selection_kernels_agree_on_the_headline_geometry():
         del os.environ["GPP_OI_NO_UNION"]
     err = np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), 1e-3)
     assert err.max() < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(12, 900), (900, 12), (300, 40)])
+def test_anisotropic_grids_pick_a_matching_tile_shape(shape):
+    """Cells far from square (the 64-cell tile becomes 1x64 ... 64x1): same values as the oracle whatever the tile shape."""
+    import os
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    Y, X = shape
+    rng = np.random.default_rng(Y * 1000 + X)
+    lats, lons = np.meshgrid(np.linspace(60, 60.5, Y), np.linspace(10, 11, X), indexing="ij")
+    S = 700
+    plat, plon = 60 + 0.5 * rng.random(S), 10 + rng.random(S)
+    bg = rng.normal(0, 1, (Y, X)).astype(np.float32)
+    obs, pbg = rng.normal(0, 1, S).astype(np.float32), rng.normal(0, 1, S).astype(np.float32)
+    ratios = rng.uniform(0.1, 1, S).astype(np.float32)
+    grid, points, st = gridpp.Grid(lats, lons), gridpp.Points(plat, plon), gridpp.BarnesStructure(6000)
+    ref = O.oi(O.Pts(lats.ravel(), lons.ravel()), bg.ravel(), O.Pts(plat, plon), obs, ratios, pbg, O.Barnes(6000), 25).reshape(Y, X)
+    out = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 25)
+    _check(out, ref)
+    for w in ("0", "3", "6"):     # forced tile shapes give the same values
+        os.environ["GPP_TILE_WSHIFT"] = w
+        try:
+            out_w = gridpp.optimal_interpolation(gridpp.Grid(lats, lons), bg, points, obs, ratios, pbg, st, 25)
+        finally:
+            del os.environ["GPP_TILE_WSHIFT"]
+        _check(out_w, ref)
