@@ -596,7 +596,7 @@ def oi_last_stats():
     s = _capi.gpp_oi_stats()
     check(lib().gpp_oi_last_stats(C.byref(s)))
     return dict(cells=s.cells, cells_updated=s.cells_updated, solves=s.solves, fallback_tiles=s.fallback_tiles, kernel_ms=s.kernel_ms,
-                union_kernel_ms=s.union_kernel_ms, fallback_subtiles=s.fallback_subtiles)
+                union_kernel_ms=s.union_kernel_ms, fallback_subtiles=s.fallback_subtiles, big_cells=s.big_cells)
 
 
 # ---- nearest (src/api/nearest.cpp:124-144) ----------------------------------------------------------

@@ -21,7 +21,7 @@ class gpp_structure(C.Structure):
 
 class gpp_oi_stats(C.Structure):
     _fields_ = [("cells", C.c_longlong), ("cells_updated", C.c_longlong), ("solves", C.c_longlong),
-                ("fallback_tiles", C.c_longlong), ("kernel_ms", C.c_float), ("union_kernel_ms", C.c_float), ("fallback_subtiles", C.c_longlong)]
+                ("fallback_tiles", C.c_longlong), ("kernel_ms", C.c_float), ("union_kernel_ms", C.c_float), ("fallback_subtiles", C.c_longlong), ("big_cells", C.c_longlong)]
 
 
 _lib = None

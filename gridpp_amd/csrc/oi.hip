@@ -254,8 +254,9 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
         DevStructure cst = a.s.st;   // this lane's structure: uniform, or the parameters at its grid point
         if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
         cnt = scan_tile<N, false, PLAIN>(a.s, cst, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
-        if(__ballot(overflow) != 0ull) {
-            if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);
+        if(__ballot(overflow) != 0ull) {   // more usable observations than the register tile holds: left to k_oi_big
+            if(a.big_list) { if(overflow) a.big_list[atomicAdd(a.big_count, 1)] = cell; }
+            else if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);
             cnt = overflow ? 0 : cnt;
         }
 
@@ -574,13 +575,166 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------
+// k_oi_big: grid points with more usable observations than the 62-row register tile of k_oi holds (max_points == 0 with
+// many observations inside the localization radius, or max_points > 62).  One workgroup per listed cell: radius query
+// over the bins (all usable observations, oi.cpp:229-260), bitonic sort of the keys in LDS (rho descending, then lower
+// index: the order of oi.cpp:262-273), (P+R | d | g) in HBM scratch, right-looking Cholesky with the two right-hand
+// sides riding along as extra rows.  Slow next to the tile kernels (the reference is O(n^3) per grid point here too), but
+// it removes the cliff: any max_points up to BIG_N observations per grid point, symmetric structure functions.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_oi_big(OiArgs a) {
+    __shared__ unsigned long long s_key[BIG_CAND];   // 64 KB; after the sort: the per-observation tables below
+    __shared__ int s_n;
+    __shared__ double s_red[2][256];
+    __shared__ float s_mm[2][256];
+    const int tid = threadIdx.x;
+    const ScanArgs& sa = a.s;
+    const DevStructure& st = sa.st;
+    const int nlist = *a.big_count;
+    unsigned long long* const gkeys = a.big_keys + (size_t)blockIdx.x * BIG_CAND;
+    double* const A = a.big_mat + (size_t)blockIdx.x * (BIG_N + 2) * BIG_N;
+    for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int cell = a.big_list[li];
+        const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
+        const float bg = a.bg[cell], bvar = a.bvar ? a.bvar[cell] : 1.0f;
+        if(tid == 0) s_n = 0;
+        __syncthreads();
+        // ---- radius query: every bin the box [p - R, p + R] touches on the two binned axes ------------------------------------
+        const float R = st.R;
+        const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz), pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
+        const int bx0 = min(max((int)floorf((pa - R - sa.amin) * sa.inv_s) - 1, 0), sa.nbx - 1), bx1 = min(max((int)floorf((pa + R - sa.amin) * sa.inv_s) + 1, 0), sa.nbx - 1);
+        const int by0 = min(max((int)floorf((pb - R - sa.bmin) * sa.inv_s) - 1, 0), sa.nby - 1), by1 = min(max((int)floorf((pb + R - sa.bmin) * sa.inv_s) + 1, 0), sa.nby - 1);
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        for(int by = by0; by <= by1; ++by) {
+            const int js = sa.bin_start[by * sa.nbx + bx0], je = sa.bin_start[by * sa.nbx + bx1 + 1];
+            for(int j = js + tid; j < je; j += 256) {
+                const float4 rec = sa.pgeo[j];
+                if(!(rec.x > lox && rec.x < hix && rec.y > loy && rec.y < hiy && rec.z > loz && rec.z < hiz)) continue;   // kdtree.cpp:46,53
+                const float2 met = sa.smeta[j];
+                const float dist = d_chord(rec.x, rec.y, rec.z, gx, gy, gz);
+                if(!(dist <= R)) continue;                                                                             // kdtree.cpp:255
+                const float rho = d_corr(st, gx, gy, gz, ge, gl, rec.x, rec.y, rec.z, rec.w, met.x, true);
+                if(!(rho > 0.0f)) continue;                                                                            // oi.cpp:253
+                const int k = atomicAdd(&s_n, 1);
+                if(k < BIG_CAND) s_key[k] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~__float_as_int(met.y));
+            }
+        }
+        __syncthreads();
+        const int ncand = s_n;
+        int n = (a.s.max_points > 0) ? min(ncand, a.s.max_points) : ncand;
+        if(ncand > BIG_CAND || n > BIG_N) {   // beyond what this kernel holds: fail loudly (host raises)
+            if(tid == 0) atomicOr(a.err, ERR_OVERFLOW);
+            __syncthreads();
+            continue;
+        }
+        // ---- bitonic sort, descending: rho descending, ties -> lower observation index (oi.cpp:262-273) ------------------------
+        int np2 = 1;
+        while(np2 < ncand) np2 <<= 1;
+        for(int i = ncand + tid; i < np2; i += 256) s_key[i] = 0ull;
+        __syncthreads();
+        for(int k = 2; k <= np2; k <<= 1) {
+            for(int j = k >> 1; j > 0; j >>= 1) {
+                for(int i = tid; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if(ixj > i) {
+                        const unsigned long long x = s_key[i], y = s_key[ixj];
+                        const bool desc = (i & k) == 0;
+                        if(desc ? (x < y) : (x > y)) { s_key[i] = y; s_key[ixj] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- the selected observations: keys out to HBM, per-observation tables into the LDS the keys occupied ---------------
+        for(int i = tid; i < n; i += 256) gkeys[i] = s_key[i];
+        __syncthreads();
+        float4* const ogeo = reinterpret_cast<float4*>(s_key);                       // x, y, z, elev      [BIG_N]
+        float* const olaf = reinterpret_cast<float*>(ogeo + BIG_N);                   // laf                [BIG_N]
+        float* const odp = olaf + BIG_N;                                              // obs - background   [BIG_N] (float, for the clamp)
+        float maxInc = -INFINITY, minInc = INFINITY;
+        for(int i = tid; i < n; i += 256) {
+            const unsigned long long key = gkeys[i];
+            const unsigned orig = ~(unsigned)(key & 0xffffffffull);
+            const float4 g4 = a.ogeo[orig], x4 = a.oaux[orig];                        // oaux: laf, obs, pbg, ratio
+            ogeo[i] = g4; olaf[i] = x4.x;
+            const double d = (double)x4.y - (double)x4.z;
+            odp[i] = (float)d;
+            maxInc = fmaxf(maxInc, (float)d); minInc = fminf(minInc, (float)d);
+            A[(size_t)n * n + i] = d;                                                 // row n: lObs - lY (oi.cpp:293)
+            A[(size_t)(n + 1) * n + i] = (double)__uint_as_float((unsigned)(key >> 32));   // row n + 1: lG = rho (oi.cpp:296)
+            A[(size_t)i * n + i] = (double)x4.w;                                      // lR on the diagonal, P added below
+        }
+        __syncthreads();
+        // ---- lower triangle of P (oi.cpp:304-312) ------------------------------------------------------------------------------
+        const long ntri = (long)n * (n + 1) / 2;
+        for(long e = tid; e < ntri; e += 256) {
+            int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+            if((long)i * (i + 1) / 2 > e) i--;
+            if((long)(i + 1) * (i + 2) / 2 <= e) i++;
+            const int j = (int)(e - (long)i * (i + 1) / 2);
+            const float4 pi = ogeo[i], pj = ogeo[j];
+            const double c = (double)d_corr(st, pi.x, pi.y, pi.z, pi.w, olaf[i], pj.x, pj.y, pj.z, pj.w, olaf[j], false);
+            if(i == j) A[(size_t)i * n + i] += c; else A[(size_t)i * n + j] = c;
+        }
+        __syncthreads();
+        // ---- right-looking Cholesky, rows n and n + 1 ride along and end as L^-1 d and L^-1 g ---------------------------------
+        double* const col = reinterpret_cast<double*>(odp + BIG_N);                   // column j of the factor [BIG_N + 2]
+        bool bad = false;
+        const int ti = tid >> 4, tk = tid & 15;
+        for(int j = 0; j < n; ++j) {
+            const double ajj = A[(size_t)j * n + j];
+            if(!(ajj > 0.0)) bad = true;
+            const double rs = 1.0 / sqrt(ajj);
+            for(int i = j + tid; i < n + 2; i += 256) { const double v = A[(size_t)i * n + j] * rs; A[(size_t)i * n + j] = v; col[i] = v; }
+            __syncthreads();
+            for(int i = j + 1 + ti; i < n + 2; i += 16) {
+                const double lij = col[i];
+                const int kend = min(i, n - 1);
+                for(int k = j + 1 + tk; k <= kend; k += 16) A[(size_t)i * n + k] -= lij * col[k];
+            }
+            __syncthreads();
+        }
+        // ---- increment = (L^-1 g) . (L^-1 d), 1 - K G^T = 1 - |L^-1 g|^2 (oi.cpp:315-316,336) --------------------------------
+        double inc = 0.0, a00 = 0.0;
+        for(int k = tid; k < n; k += 256) { const double zg = A[(size_t)(n + 1) * n + k]; inc += zg * A[(size_t)n * n + k]; a00 += zg * zg; }
+        s_red[0][tid] = inc; s_red[1][tid] = a00; s_mm[0][tid] = maxInc; s_mm[1][tid] = minInc;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) {
+            if(tid < off) {
+                s_red[0][tid] += s_red[0][tid + off]; s_red[1][tid] += s_red[1][tid + off];
+                s_mm[0][tid] = fmaxf(s_mm[0][tid], s_mm[0][tid + off]); s_mm[1][tid] = fminf(s_mm[1][tid], s_mm[1][tid + off]);
+            }
+            __syncthreads();
+        }
+        if(tid == 0) {
+            if(bad) atomicOr(a.err, ERR_SINGULAR);
+            if(n > 0) {
+                float increment = (float)s_red[0][0];   // oi.cpp:317
+                const float mx = s_mm[0][0], mn = s_mm[1][0];
+                if(!a.allow_extrap) {                   // oi.cpp:318-334
+                    if(mx > 0 && increment > mx) increment = mx;
+                    else if(mx < 0 && increment > 0) increment = mx;
+                    else if(mn < 0 && increment < mn) increment = mn;
+                    else if(mn > 0 && increment < 0) increment = mn;
+                }
+                a.out[cell] = bg + increment;                                                // oi.cpp:335
+                if(a.out_var) a.out_var[cell] = (float)((double)bvar * (1.0 - s_red[1][0]));   // oi.cpp:337
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // host entry point
 // -------------------------------------------------------------------------------------------
 namespace {
 struct OiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> ones;
-    DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_list2, fb_list3, fb_count;
+    DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_list2, fb_list3, fb_count, big_list, big_count;
+    DevBuf<unsigned long long> big_keys;
+    DevBuf<double> big_mat;
     DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr;
 };
@@ -862,6 +1016,13 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const bool memo_hit = memo.points == (const void*)points && memo.h == a.s.st.h && memo.v == a.s.st.v && memo.w == a.s.st.w && memo.max_points == max_points;
     const bool memo_says_no = memo_hit && memo.declined > 0.5f;   // more than half of the tiles went to k_oi last time: skip the first pass
     const bool use_union = !use_lu && N == 32 && want_union && !memo_says_no && !getenv("GPP_OI_NO_UNION");
+    // cells with more usable observations than the 62-row tile holds are listed for k_oi_big (symmetric systems only)
+    const bool big_ok = N == 62 && !use_lu && !spatial;
+    if(big_ok) {
+        ws.big_list.get((size_t)C); ws.big_count.get(1);
+        GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, sizeof(int), stream()));
+        a.big_list = ws.big_list.p; a.big_count = ws.big_count.p;
+    }
     bool ran_union = false;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
@@ -911,8 +1072,23 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             memo.points = points; memo.h = a.s.st.h; memo.v = a.s.st.v; memo.w = a.s.st.w; memo.max_points = max_points;
             memo.declined = (float)nfb[0] / (float)a.ntiles;
         }
+        if(big_ok && !use_lu) {
+            int nbig = 0;
+            GPP_HIP(hipMemcpy(&nbig, ws.big_count.p, sizeof(int), hipMemcpyDeviceToHost));
+            if(nbig > 0) {
+                const int nwg = std::min(nbig, 256);
+                a.big_keys = ws.big_keys.get((size_t)nwg * BIG_CAND);
+                a.big_mat = ws.big_mat.get((size_t)nwg * (BIG_N + 2) * BIG_N);
+                hipLaunchKernelGGL(k_oi_big, dim3(nwg), dim3(256), 0, stream(), a);
+                GPP_HIP(hipGetLastError());
+                GPP_HIP(hipEventRecord(ws.e1, stream()));
+                fetch();
+                g_stats.big_cells = nbig;
+            }
+        }
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
+            a.big_list = nullptr; a.big_count = nullptr;   // (the LU path has no large-n kernel: it fails loudly there)
             g_stats.fallback_tiles = a.ntiles;
             GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
             GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * (80 + 2 * GPP_NSLOT), stream()));
@@ -941,7 +1117,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
 #endif
     if(getenv("GPP_SCAN_STATS")) { fprintf(stderr, "[gpp] wave-level insertions per tile histogram:"); for(int i = 0; i < 70; i++) fprintf(stderr, " %d:%llu", i, counters[4 + i]); fprintf(stderr, "\n"); }
     if(err & ERR_SINGULAR) runtime("optimal_interpolation: local (P+R) matrix is singular");
-    if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more than 62 usable observations per grid point requested (max_points == 0 or > 62): not supported on the GPU path yet");
+    if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more usable observations per grid point than the GPU path holds (512 with a symmetric structure function, 62 with a non-symmetric or spatially varying one; max_points == 0 or too large): reduce max_points");
     return GPP_OK;
     GPP_CATCH
 }

@@ -43,9 +43,16 @@ struct OiArgs {
     int level;               // k_oi_union<., true>: 1 or 2 (see there)
     const int* parent_count; // level 2: length of the level-1 input list (how many tiles were split)
     int debug;               // GPP_OI_DEBUG: bit0 = skip the solve (timing experiments only)
+    // k_oi -> k_oi_big: cells with more usable observations than the 62-row register tile holds
+    int* big_list;           // cell indices
+    int* big_count;
+    unsigned long long* big_keys;   // per workgroup of k_oi_big: BIG_CAND candidate keys (sorted there)
+    double* big_mat;         // per workgroup: (BIG_N + 2) x BIG_N matrix
 };
 
 #define GPP_NSLOT 512
+#define BIG_CAND 8192   // candidates of one cell k_oi_big can sort
+#define BIG_N 512       // observations of one cell k_oi_big can factorise
 #define ERR_OVERFLOW 1
 #define ERR_SINGULAR 2
 

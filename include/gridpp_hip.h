@@ -209,6 +209,7 @@ typedef struct gpp_oi_stats {
     float kernel_ms;          /* hipEvent time of the OI kernel(s) on the library stream */
     float union_kernel_ms;    /* of which k_oi_union, first pass (one factorisation per tile); 0 when that kernel was not used */
     long long fallback_subtiles; /* work items (4 cells, or whole tiles) k_oi_union's list passes left to k_oi */
+    long long big_cells;      /* grid points with more than 62 usable observations (done by k_oi_big) */
 } gpp_oi_stats;
 int gpp_oi_last_stats(gpp_oi_stats* stats);
 

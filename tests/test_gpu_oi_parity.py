@@ -212,12 +212,26 @@ def test_more_than_32_points(max_points):
     check(out, ref)
 
 
+@pytest.mark.parametrize("max_points,S", [(0, 200), (100, 300), (0, 450), (63, 150)])
+def test_more_than_62_points_large_n_kernel(max_points, S):
+    """More usable observations per grid point than the 62-row register tile holds (max_points == 0 with every observation
+    in range, or max_points > 62): k_oi_big, one workgroup per grid point."""
+    import gridpp_amd as gridpp
+    c = make_case(80 + S, 9, 11, S)
+    out, ref = run_both(c, 40000, 0, 0, max_points)   # R = 146 km: every observation is in range of every cell
+    check(out, ref)
+    assert gridpp.oi_last_stats()["big_cells"] == 99
+    out, ref, var, rvar = run_both(c, 40000, 0, 0, max_points, allow_extrap=False, full=True)
+    check(out, ref)
+    check(var, rvar)
+
+
 def test_too_many_points_fails_loudly():
     import gridpp_amd as gridpp
-    c = make_case(80, 8, 8, 200)
+    c = make_case(80, 4, 4, 700)
     grid = gridpp.Grid(c["lats"], c["lons"])
     points = gridpp.Points(c["plat"], c["plon"])
-    with pytest.raises(RuntimeError, match="more than 62"):
+    with pytest.raises(RuntimeError, match="more usable observations"):
         gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], gridpp.BarnesStructure(40000), 0)
 
 
