@@ -281,30 +281,49 @@ __global__ void k_member_quantile(const float* __restrict__ in, long C, int E, f
 // separable box statistics (planes: blockIdx.z selects a [Y][X] plane)
 // -------------------------------------------------------------------------------------------
 // row pass: for each cell the sum (double) and count (int) of the valid values in [x-hw, x+hw]
-__global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ in, int Y, int X, int hw, double* __restrict__ rs, int* __restrict__ rc) {
+__global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ in, int Y, int X, int hw, double* __restrict__ rs, int* __restrict__ rc,
+                                                  int* __restrict__ plane_has_invalid) {
     extern __shared__ float lds[];   // 256 + 2*hwc floats
     const long plane = (long)blockIdx.z * Y * X;
     const int y = blockIdx.y;
     const int x0 = blockIdx.x * 256;
     const int hwc = min(hw, X);   // a window wider than the row is the whole row
     const float* row = in + plane + (long)y * X;
+    int bad = 0;
     for(int i = threadIdx.x; i < 256 + 2 * hwc; i += 256) {
         int x = x0 - hwc + i;
-        lds[i] = (x >= 0 && x < X) ? row[x] : NAN;
+        const bool inrow = x >= 0 && x < X;
+        const float v = inrow ? row[x] : 0.0f;
+        bad |= (inrow && !nv(v)) ? 1 : 0;
+        lds[i] = inrow ? v : NAN;
     }
-    __syncthreads();
+    const int any_bad = __syncthreads_or(bad);   // (also the barrier after the tile load)
     int x = x0 + threadIdx.x;
-    if(x >= X) return;
     double s = 0; int c = 0;
-    for(int k = 0; k <= 2 * hwc; k++) { float v = lds[threadIdx.x + k]; if(nv(v)) { s += (double)v; c++; } }
+    if(any_bad) {   // some value of this tile is missing: validity per tap
+        if(threadIdx.x == 0) atomicOr(&plane_has_invalid[blockIdx.z], 1);
+        if(x < X) for(int k = 0; k <= 2 * hwc; k++) { float v = lds[threadIdx.x + k]; if(nv(v)) { s += (double)v; c++; } }
+    }
+    else {          // all valid (the common case): two instructions per tap, the count is the clipped window width
+        for(int i = threadIdx.x; i < 256 + 2 * hwc; i += 256) { const int xx = x0 - hwc + i; if(!(xx >= 0 && xx < X)) lds[i] = 0.0f; }
+        __syncthreads();
+        if(x < X) {
+#pragma unroll 8
+            for(int k = 0; k <= 2 * hwc; k++) s += (double)lds[threadIdx.x + k];
+            c = min(x + hwc, X - 1) - max(x - hwc, 0) + 1;
+        }
+    }
+    if(x >= X) return;
     rs[plane + (long)y * X + x] = s;
     rc[plane + (long)y * X + x] = c;
 }
 // column pass + finish (neighbourhood.cpp:132-142): Mean / Sum / Count.  Each thread owns one column of a strip of
 // COL_STRIP rows and slides the window down it (2 reads per cell instead of 2*hw+1).
-#define COL_STRIP 32
-__global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs, const int* __restrict__ rc, int Y, int X, int hw, int statistic, float* __restrict__ out, int qf_reps) {
+#define COL_STRIP 64
+__global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs, const int* __restrict__ rc, int Y, int X, int hw, int statistic, float* __restrict__ out, int qf_reps,
+                                                  const int* __restrict__ plane_has_invalid) {
     const long plane = (long)blockIdx.z * Y * X;
+    const bool counted = plane_has_invalid[blockIdx.z] != 0;   // no missing value in the plane: counts are window sizes, rc is not read
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y0 = blockIdx.y * COL_STRIP;
     if(x >= X || y0 >= Y) return;
@@ -313,13 +332,16 @@ __global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs,
     const int* cc = rc + plane + x;
     double s = 0; int c = 0;
     int lo = max(0, y0 - hw), hi = (int)min((long)Y - 1, (long)y0 + hw);   // current window [lo, hi]
-    for(int yy = lo; yy <= hi; yy++) { s += cs[(long)yy * X]; c += cc[(long)yy * X]; }
+    const int hwc = min(hw, X);
+    const int cx = min(x + hwc, X - 1) - max(x - hwc, 0) + 1;              // row count of every row when nothing is missing
+    for(int yy = lo; yy <= hi; yy++) { s += cs[(long)yy * X]; if(counted) c += cc[(long)yy * X]; }
+    if(!counted) c = cx * (hi - lo + 1);
     for(int y = y0; y < y1; y++) {
         if(y > y0) {
             const long add = (long)y + hw;
             const int sub = y - hw - 1;
-            if(add <= (long)Y - 1) { s += cs[add * X]; c += cc[add * X]; }
-            if(sub >= 0) { s -= cs[(long)sub * X]; c -= cc[(long)sub * X]; }
+            if(add <= (long)Y - 1) { s += cs[add * X]; c += counted ? cc[add * X] : cx; }
+            if(sub >= 0) { s -= cs[(long)sub * X]; c -= counted ? cc[(long)sub * X] : cx; }
         }
         float o = NAN;
         if(statistic == GPP_COUNT) o = (float)c;
@@ -500,7 +522,7 @@ namespace {
 struct NbWorkspace {
     DevBuf<float> flat, tmp, tmp2, planes, thr, qf;
     DevBuf<double> rs;
-    DevBuf<int> rc;
+    DevBuf<int> rc, plane_flags;
 };
 thread_local NbWorkspace g_nb;
 
@@ -533,9 +555,11 @@ void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statisti
         lds_set = 160 * 1024;
         GPP_HIP(hipFuncSetAttribute((const void*)k_box_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_set));
     }
-    hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, Y, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc);
+    int* flags = g_nb.plane_flags.get(nplanes);
+    GPP_HIP(hipMemsetAsync(flags, 0, sizeof(int) * nplanes, stream()));
+    hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, Y, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc, flags);
     GPP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_box_cols, dim3((X + 255) / 256, (Y + COL_STRIP - 1) / COL_STRIP, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out, qf_reps);
+    hipLaunchKernelGGL(k_box_cols, dim3((X + 255) / 256, (Y + COL_STRIP - 1) / COL_STRIP, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out, qf_reps, flags);
     GPP_HIP(hipGetLastError());
 }
 void brute(const float* d_in, int Y, int X, int E, int hw, int statistic, float q, float* d_out) {
