@@ -5,16 +5,15 @@
 //   185-230) -> filter -> top-max_points by rho (oi.cpp:251-273) -> K = G (P+R)^-1 in double
 //   (oi.cpp:289-316) -> increment, optional clamp (oi.cpp:317-335), analysis variance (:336-337).
 //
-// Mapping (wave64, one tile of 64 grid cells per wavefront, 4 tiles per workgroup):
-//   * the observation set is bin-sorted once per Points object on two projected axes
-//     (gpp_obs_index); a tile walks only the bins its bounding box +R overlaps, with the
-//     observation record read through wave-uniform (scalar) loads;
-//   * every lane owns one cell and keeps its best max_points candidates as 64-bit keys
-//     (rho bits << 32 | ~obs index) in LDS, column-per-lane so no bank conflicts;
-//   * the dense solve is wave-cooperative: lane i holds row i of (P+R) in registers, lanes
-//     N and N+1 carry the right-hand sides (obs-background and G) as extra rows of an
-//     augmented Cholesky factorisation, column broadcasts are v_readlane -> SGPR.  A lane
-//     group that shares one observation set shares the factorisation.
+// Mapping (wave64, one tile of 64 grid cells per wavefront, 4 tiles per workgroup; DESIGN.md 4.1):
+//   * the observation set is bin-sorted once per Points object on two projected axes (gpp_obs_index); a tile walks only
+//     the bins that can still matter, records are fetched 64 at a time and broadcast with v_readlane;
+//   * k_oi_union (oi_union.h): ONE shared factorisation per tile -- the cells of a tile select almost the same
+//     observations -- plus a per-lane finish; tried first for every symmetric system with max_points <= 32;
+//   * k_oi (this file): every lane keeps its best max_points candidates as 64-bit keys (rho bits << 32 | ~obs index)
+//     in LDS; lanes with the same selection share one augmented Cholesky (or pivoted LU) on rows-in-lanes; also the
+//     kernel for what k_oi_union declines, for 33..62 observations, non-symmetric and spatially varying structures;
+//   * k_oi_big (this file): one workgroup per grid point with more than 62 usable observations.
 // Arithmetic follows the reference: float32 coordinates/distances/rho (no FMA contraction,
 // correctly rounded sqrt/div, rho through a double-precision exp), double for the solve.
 #include "oi_common.h"

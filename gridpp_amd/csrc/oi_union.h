@@ -1,4 +1,4 @@
-// k_oi_union: optimal interpolation with ONE factorisation per 8x8 tile of grid cells.
+// k_oi_union: optimal interpolation with ONE factorisation per tile of 64 grid cells.
 //
 // The 64 cells of a tile select almost the same observations (src/api/oi.cpp:229-273): on the headline workload the
 // union U of the 64 selections has ~33 members of which ~28 (the core C) are selected by every cell.  With the core
@@ -12,7 +12,8 @@
 // 1 - K G^T = 1 - |L^-1 g|^2 as in k_oi (oi.cpp:315-316,336).
 //
 // A tile that does not fit (more than 40 live candidates during the scan, union > 40, more than 12 extras or more than
-// 6 per cell) is appended to a fallback list and done by k_oi (one factorisation per distinct selection).
+// 6 per cell) is appended to a work list: it is retried as four 16-cell items, those as 4-cell items, and what is still
+// left is done by k_oi (one factorisation per distinct selection).
 #pragma once
 #include "oi_common.h"
 
