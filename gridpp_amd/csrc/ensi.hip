@@ -35,6 +35,7 @@ struct EnsiArgs {
     const float* gY;          // [S][nV] perturbations of the valid members (float)
     const int* validIdx;      // [nV]
     unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
+    int debug;                // GPP_ENSI_DEBUG (timing experiments only): 1 no Jacobi, 2 no member update, 4 no B build, 8 no M_W
     int nV;
     int allow_extrap;
     int* err;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
             const int i = idx / n, j = idx - i * n;
             double acc = 0.0;
             if(j <= i) {
-                for(int k = 0; k < nV; ++k) acc = __builtin_fma((double)Yt[i][k], (double)Yt[j][k], acc);
+                if(!(a.debug & 4)) for(int k = 0; k < nV; ++k) acc = __builtin_fma((double)Yt[i][k], (double)Yt[j][k], acc);
                 acc *= s_sD[i] * s_sD[j];
                 s_B[i * BP + j] = acc; s_B[j * BP + i] = acc;
             }
@@ -250,11 +251,14 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
             itk[it] = (idx < half * n) ? k : -1;
             itt[it] = idx - k * n;
         }
-        for(int sweep = 0; sweep < 30 && n > 1; ++sweep) {
+        for(int sweep = 0; sweep < 30 && n > 1 && !(a.debug & 1); ++sweep) {
             double off = 0.0;
             for(int idx = lane; idx < n * n; idx += 64) { const int i = idx / n, j = idx - i * n; if(j < i) { double v = s_B[i * BP + j]; off += v * v; } }
             off = wave_sum_d(off);
-            if(!(off > 1e-27 * tr * tr)) break;   // off-diagonal norm < 3e-14 * trace: eigenvalues converged to double precision
+            // off-diagonal norm < 1e-11 * trace: Jacobi converges quadratically, so the eigenvalues are good to ~1e-22 and the
+            // eigenvectors to ~1e-11 relative -- five orders below what a float32 output can show; one more sweep would only
+            // polish digits nobody reads (it was a third of the work of a warm-started cell)
+            if(!(off > 1e-22 * tr * tr)) break;
             nsweeps++;
             for(int step = 0; step < m - 1; ++step) {
                 if(lane < half) {
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         for(int idx = lane; idx < n * n; idx += 64) {
             const int i = idx / n, j = idx - i * n;
             double acc = 0.0;
-            for(int k = 0; k < n; ++k) acc = __builtin_fma(s_U[i * BP + k] * s_dw[k], s_U[j * BP + k], acc);
+            if(!(a.debug & 8)) for(int k = 0; k < n; ++k) acc = __builtin_fma(s_U[i * BP + k] * s_dw[k], s_U[j * BP + k], acc);
             s_B[i * BP + j] = acc;
         }
         __syncthreads();
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         for(int i = 0; i < EN; ++i) q[i] = (i < n) ? q[i] * s_sD[i] : 0.0;
         // total_e = sum_k X_k W(k,e), float accumulation in k order (oi_ensi.cpp:505-511)
         float acc = 0.0f;
-        for(int k = 0; k < nV; ++k) {
+        for(int k = 0; k < nV && !(a.debug & 2); ++k) {
             double wke = (k == lane) ? 1.0 : 0.0;
 #pragma unroll
             for(int i = 0; i < EN; ++i) wke = __builtin_fma((double)Yt[i][k], q[i], wke);
@@ -521,6 +525,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
     a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
+    a.debug = getenv("GPP_ENSI_DEBUG") ? atoi(getenv("GPP_ENSI_DEBUG")) : 0;
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
     GPP_HIP(hipEventRecord(ws.e0, stream()));
