@@ -35,6 +35,7 @@ struct EnsiArgs {
     const float* gY;          // [S][nV] perturbations of the valid members (float)
     const int* validIdx;      // [nV]
     unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
+    double* gram;             // [ntiles][EN*EN] scratch: Y Y^T of the current run of equal selections
     int debug;                // GPP_ENSI_DEBUG (timing experiments only): 1 no Jacobi, 2 no member update, 4 no B build, 8 no M_W
     int nV;
     int allow_extrap;
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
     }
     // park the selections (observation indices) of the 64 cells in HBM: sel[tile][slot][lane]
     unsigned* const sel = a.sel + (size_t)tile * EN * 64;
+    double* const gram = a.gram + (size_t)tile * EN * EN;
     float (*Yt)[64] = s_Yt;
     unsigned long long hsig = 0;   // order-independent signature of this lane's selection
     for(int s = 0; s < a.s.K; ++s) {
@@ -198,12 +200,19 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
             const int i = idx / n, j = idx - i * n;
             double acc = 0.0;
             if(j <= i) {
-                if(!(a.debug & 4)) for(int k = 0; k < nV; ++k) acc = __builtin_fma((double)Yt[i][k], (double)Yt[j][k], acc);
+                // the Gram matrix Y Y^T depends on the selection only: computed by the first cell of a run of equal
+                // selections, parked in HBM, re-read by the others (B = (sD sD^T) o (Y Y^T) differs per cell through sD)
+                if(warm) acc = __hip_atomic_load(&gram[i * n + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else {
+                    if(!(a.debug & 4)) for(int k = 0; k < nV; ++k) acc = __builtin_fma((double)Yt[i][k], (double)Yt[j][k], acc);
+                    gram[i * n + j] = acc;
+                }
                 acc *= s_sD[i] * s_sD[j];
                 s_B[i * BP + j] = acc; s_B[j * BP + i] = acc;
             }
             if(!warm) s_U[i * BP + j] = (i == j) ? 1.0 : 0.0;
         }
+        if(!warm) __threadfence();   // the Gram matrix must be visible to the other lanes when the next cell reads it
         __syncthreads();
         if(warm) {
             // B <- U^T B U in place (U from the previous cell): nearly diagonal already, one or two sweeps finish it.
@@ -425,6 +434,7 @@ struct EnsiWorkspace {
     DevBuf<float> gYhat, gY;
     DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
     DevBuf<unsigned> sel;
+    DevBuf<double> gram;
     DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -525,6 +535,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
     a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
+    a.gram = ws.gram.get((size_t)a.ntiles * EN * EN);
     a.debug = getenv("GPP_ENSI_DEBUG") ? atoi(getenv("GPP_ENSI_DEBUG")) : 0;
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
