@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
         bool bad = false;
         constexpr int MEMB = 63 - N;   // lanes N+1..63 carry one member cell each
         // one group = one distinct observation set: leader lane l (n observations), member cells `members` (nm of them)
-        auto solve_group = [&](const int l, const int n, const unsigned long long members, const int nm) {
+        // `extra`: further member cells of the group beyond the G rows that fit beside the matrix (62-row tile: one) -- they
+        // reuse the factor through a forward substitution on rows-in-lanes instead of a factorisation of their own
+        auto solve_group = [&](const int l, const int n, const unsigned long long members, const int nm, const unsigned long long extra) {
             nsolve++;
             // lane i < n takes the i-th selected observation of the leader; lane N+1+m takes member cell m
             const unsigned orig_i = (lane < n) ? origs[lane][l] : 0u;
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             }
             else {
                 double row[N];
+                double myrs = 0.0;   // 1 / L_jj of this lane's own row (for the extra members)
                 const bool used = lane < n || lane == N || is_g;
     #pragma unroll
                 for(int p = 0; p < N; ++p) {
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                         rs = rs * (1.5 - 0.5 * ajj * rs * rs);
                         const double cj = row[j] * rs;
                         row[j] = cj;
+                        if(lane == j) myrs = rs;
     #pragma unroll
                         for(int p = j + 1; p < N; ++p) {
                             const double lpj = readlane_d(cj, p);
@@ -442,6 +446,34 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                     }
                     s_res[wid][0][src] = cbg + increment;                      // oi.cpp:335
                     s_res[wid][1][src] = (float)((double)cbv * (1.0 - a00));   // oi.cpp:337
+                }
+                // the other cells of the group: z = L^-1 g by a column-oriented forward substitution, lane i holds g_i
+                for(unsigned long long mm = extra; mm != 0ull; mm &= mm - 1ull) {
+                    const int ml = __builtin_ctzll(mm);
+                    const float cx = readlane_f(gx, ml), cy = readlane_f(gy, ml), cz = readlane_f(gz, ml), ce = readlane_f(ge, ml), cl = readlane_f(gl, ml);
+                    double gi = (lane < n) ? (double)d_corr_t<PLAIN>(pst, cx, cy, cz, ce, cl, px, py, pz, pe, pl, true) : 0.0;   // lG (oi.cpp:250,296)
+                    double inc2 = 0.0, a002 = 0.0;
+    #pragma unroll
+                    for(int j = 0; j < N; ++j) {
+                        if(j < n) {
+                            const double zj = readlane_d(gi * myrs, j);
+                            gi = __builtin_fma(-row[j], zj, gi);
+                            inc2 = __builtin_fma(zj, readlane_d(row[j], N), inc2);
+                            a002 = __builtin_fma(zj, zj, a002);
+                        }
+                    }
+                    float increment = (float)inc2;
+                    if(!a.allow_extrap) {
+                        if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                        else if(maxInc < 0 && increment > 0) increment = maxInc;
+                        else if(minInc < 0 && increment < minInc) increment = minInc;
+                        else if(minInc > 0 && increment < 0) increment = minInc;
+                    }
+                    const float bgm = readlane_f(bg, ml), bvm = readlane_f(bvar, ml);
+                    if(lane == 0) {
+                        s_res[wid][0][ml] = bgm + increment;
+                        s_res[wid][1][ml] = (float)((double)bvm * (1.0 - a002));
+                    }
                 }
                     }
         };
@@ -533,16 +565,20 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             const unsigned long long l1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h1 >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h1, l);
             const unsigned long long l2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h2s >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h2s, l);
             unsigned long long members = __ballot(cnt == n && h1 == l1 && h2s == l2) & todo;
-            // at most MEMB members per pass
+            // at most MEMB members ride along as G rows; with the 62-row tile (MEMB = 1) the other cells of the group reuse the
+            // factor through forward substitutions (Cholesky path), otherwise they form the next pass
             int nm = __popcll(members);
+            unsigned long long extra = 0ull;
             if(nm > MEMB) {
                 const int cut = nth_set_bit(members, MEMB);
-                members &= (1ull << cut) - 1ull;
+                const unsigned long long first = members & ((1ull << cut) - 1ull);
+                if(!LU && N == 62) extra = members & ~first;
+                members = first;
                 nm = MEMB;
             }
-            todo &= ~members;
+            todo &= ~(members | extra);
             if(PAIRS && nm == 1 && n <= 30) singles |= 1ull << l;
-            else solve_group(l, n, members, nm);
+            else solve_group(l, n, members, nm, extra);
         }
         if constexpr(PAIRS) {
             while(singles) {
@@ -553,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                     singles &= singles - 1;
                     solve_pair(la, lb);
                 }
-                else solve_group(la, __builtin_amdgcn_readlane(cnt, la), 1ull << la, 1);
+                else solve_group(la, __builtin_amdgcn_readlane(cnt, la), 1ull << la, 1, 0ull);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -296,3 +296,16 @@ def test_spatially_varying_structure(kind, same_grid):
     check(np.asarray(out), ref.reshape(Y, X))
     check(np.asarray(var), rvar.reshape(Y, X))
     assert np.abs(np.asarray(out) - c["bg"]).max() > 0.05
+
+
+@pytest.mark.parametrize("allow", [True, False])
+def test_62_row_tile_groups_share_one_factorisation(allow):
+    """max_points in 33..62 with every grid point selecting the same observations: one factorisation per tile, the other
+    63 cells reuse it through forward substitutions (k_oi<62>)."""
+    import gridpp_amd as gridpp
+    c = make_case(91, 40, 40, 45)
+    out, ref, var, rvar = run_both(c, 40000, 0, 0, 60, allow_extrap=allow, full=True)   # all 45 observations are in range everywhere
+    check(out, ref)
+    check(var, rvar)
+    s = gridpp.oi_last_stats()
+    assert s["solves"] <= 2 * 25          # 25 tiles, one (rarely two) selections each
