@@ -1082,14 +1082,22 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             GPP_HIP(hipMemcpyAsync(&n1, ws.fb_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
             GPP_HIP(hipStreamSynchronize(stream()));
             if(n1 > 0) {
-                // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); a list too long for the split to pay is
-                // forwarded whole by the kernel
-                a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list2.p; a.out_count = ws.fb_count.p + 1; a.level = 1;
-                launch_union(dim3(n1), true);
-                // pass 3: the declined 16-cell items as 4 items of 4 cells (at most 4 n1 of them)
-                a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 2;
-                a.parent_count = ws.fb_count.p;
-                launch_union(dim3(4 * (size_t)n1 > 0x7fffffffull ? 0x7fffffff : 4 * n1), true);
+                if(16 * n1 <= 3072) {   // (as many work items as the chip holds waves of this kernel)
+                    // a short list: every declined tile straight to its sixteen 4-cell items (one pass; the latency of a pass,
+                    // one lone work item, is what a short list costs)
+                    a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 3;
+                    launch_union(dim3(4 * n1), true);
+                }
+                else {
+                    // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); a list too long for the split to pay is
+                    // forwarded whole by the kernel
+                    a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list2.p; a.out_count = ws.fb_count.p + 1; a.level = 1;
+                    launch_union(dim3(n1), true);
+                    // pass 3: the declined 16-cell items as 4 items of 4 cells (at most 4 n1 of them)
+                    a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 2;
+                    a.parent_count = ws.fb_count.p;
+                    launch_union(dim3(4 * (size_t)n1 > 0x7fffffffull ? 0x7fffffff : 4 * n1), true);
+                }
                 // pass 4: what is still left, one factorisation per distinct selection (grid-stride over the list)
                 a.in_list = ws.fb_list3.p; a.in_count = ws.fb_count.p + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
                 launch_k_oi(false);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
         // Splitting pays while most items succeed.  Level 1: more than half of the tiles declined -> forward them whole.
         // Level 2: more than half of the 16-cell items declined (or whole tiles arrived) -> forward what arrived, unsplit.
         const bool whole = nlist > 0 && a.in_list[0] < 0;
-        const bool forward = whole || (a.level == 1 ? nlist > a.ntiles / 2 : nlist > 2 * *a.parent_count);
+        const bool forward = a.level != 3 && (whole || (a.level == 1 ? nlist > a.ntiles / 2 : nlist > 2 * *a.parent_count));
         if(forward) {
             for(int i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) {
                 const int e = a.in_list[i];
@@ -133,10 +133,16 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
             }
             return;
         }
-        if(tile >= 4 * nlist) return;
-        const int child = tile & 3, e = a.in_list[tile >> 2];
-        if(a.level == 1) { tile = e; sub = child; shift = 4; }
-        else { tile = e >> 5; sub = ((e & 31) - 16) * 4 + child; shift = 2; }
+        if(a.level == 3) {   // a short list of declined tiles goes straight to its sixteen 4-cell items: one pass instead of two
+            if(tile >= 16 * nlist) return;
+            sub = tile & 15; tile = a.in_list[tile >> 4]; shift = 2;
+        }
+        else {
+            if(tile >= 4 * nlist) return;
+            const int child = tile & 3, e = a.in_list[tile >> 2];
+            if(a.level == 1) { tile = e; sub = child; shift = 4; }
+            else { tile = e >> 5; sub = ((e & 31) - 16) * 4 + child; shift = 2; }
+        }
     }
     else if(tile >= a.ntiles) return;
     tile = __builtin_amdgcn_readfirstlane(tile); sub = __builtin_amdgcn_readfirstlane(sub);
