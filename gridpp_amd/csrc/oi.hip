@@ -767,10 +767,13 @@ namespace {
 struct OiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> ones;
-    DevBuf<int> err, cell_idx, obs_idx, fb_list, fb_list2, fb_list3, fb_count, big_list, big_count;
+    // status block of a call, one memset and one read-back: ints [0] err, [1..3] work-list lengths, [4] large-n cell count;
+    // statistics counters from byte 64 on
+    DevBuf<unsigned long long> status;
+    unsigned long long* h_status = nullptr;   // pinned host mirror
+    DevBuf<int> cell_idx, obs_idx, fb_list, fb_list2, fb_list3, big_list;
     DevBuf<unsigned long long> big_keys;
     DevBuf<double> big_mat;
-    DevBuf<unsigned long long> counters;
     hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr;
 };
 thread_local OiWorkspace g_ws;
@@ -968,9 +971,13 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
 
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); GPP_HIP(hipEventCreate(&ws.eu)); }
     ws.pgeo.get(S); ws.oaux.get(S);
-    ws.err.get(1); ws.counters.get(80 + 2 * GPP_NSLOT);
-    GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
-    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * (80 + 2 * GPP_NSLOT), stream()));
+    constexpr size_t SB = 8 + 80 + 2 * GPP_NSLOT;   // status block, in 8-byte words
+    ws.status.get(SB);
+    if(!ws.h_status) GPP_HIP(hipHostMalloc((void**)&ws.h_status, SB * sizeof(unsigned long long), hipHostMallocDefault));
+    int* const d_ints = reinterpret_cast<int*>(ws.status.p);
+    int* const d_err = d_ints, *const d_fb_count = d_ints + 1, *const d_big_count = d_ints + 4;
+    unsigned long long* const d_counters = ws.status.p + 8;
+    GPP_HIP(hipMemsetAsync(ws.status.p, 0, SB * sizeof(unsigned long long), stream()));
     hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
                        f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p);
     GPP_HIP(hipGetLastError());
@@ -1005,9 +1012,9 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
       // visits rings 0.15x wide
       const double r_k = std::sqrt(kk / (3.14159265358979 * std::max(occ, 1e-3))) / ix->inv_s;
       a.s.ring_r0 = (float)(1.5 * r_k); a.s.ring_dr = (float)(0.15 * r_k); }
-    a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
+    a.s.scan_stats = getenv("GPP_SCAN_STATS") ? d_counters + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
-    a.err = ws.err.p; a.counters = ws.counters.p;
+    a.err = d_err; a.counters = d_counters;
     a.debug = getenv("GPP_OI_DEBUG") ? atoi(getenv("GPP_OI_DEBUG")) : 0;
 
     GPP_HIP(hipEventRecord(ws.e0, stream()));
@@ -1037,10 +1044,12 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         }
         GPP_HIP(hipGetLastError());
     };
-    auto fetch = [&]() {
-        GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
-        GPP_HIP(hipMemcpyAsync(counters, ws.counters.p, sizeof(counters), hipMemcpyDeviceToHost, stream()));
+    const int* const h_ints = reinterpret_cast<const int*>(ws.h_status);
+    auto fetch = [&]() {   // the whole status block in one copy
+        GPP_HIP(hipMemcpyAsync(ws.h_status, ws.status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipStreamSynchronize(stream()));
+        err = h_ints[0];
+        memcpy(counters, ws.h_status + 8, sizeof(counters));
     };
     // one factorisation per tile (k_oi_union) when the system is symmetric and max_points fits the 32-column tile;
     // the tiles it declines, and every other configuration, run on k_oi (one factorisation per distinct selection)
@@ -1054,9 +1063,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     // cells with more usable observations than the 62-row tile holds are listed for k_oi_big (symmetric systems only)
     const bool big_ok = N == 62 && !use_lu && !spatial;
     if(big_ok) {
-        ws.big_list.get((size_t)C); ws.big_count.get(1);
-        GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, sizeof(int), stream()));
-        a.big_list = ws.big_list.p; a.big_count = ws.big_count.p;
+        ws.big_list.get((size_t)C);
+        a.big_list = ws.big_list.p; a.big_count = d_big_count;
     }
     bool ran_union = false;
     for(int attempt = 0; attempt < 2; ++attempt) {
@@ -1064,8 +1072,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         ran_union = false;
         if(use_union && !use_lu) {
             // worst case per list: every tile declined and split into 4 (level 1) resp. 16 (level 2) items
-            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get(2 * (size_t)a.ntiles + 64); ws.fb_list3.get(4 * (size_t)a.ntiles + 64); ws.fb_count.get(3);
-            GPP_HIP(hipMemsetAsync(ws.fb_count.p, 0, 3 * sizeof(int), stream()));
+            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get(2 * (size_t)a.ntiles + 64); ws.fb_list3.get(4 * (size_t)a.ntiles + 64);
             const dim3 block(256);
             auto launch_union = [&](const dim3 grid, const bool list) {
                 if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<true, false>), grid, block, 0, stream(), a); }
@@ -1073,42 +1080,42 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 GPP_HIP(hipGetLastError());
             };
             // pass 1: every tile
-            a.out_list = ws.fb_list.p; a.out_count = ws.fb_count.p;
+            a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
             launch_union(dim3((a.ntiles + 3) / 4), false);
             GPP_HIP(hipEventRecord(ws.eu, stream()));
             // How many tiles did it decline?  One small host round trip here is cheaper than launching the list passes with
             // grids sized for the worst case (tens of thousands of empty workgroups), and usually there is nothing left to do.
             int n1 = 0;
-            GPP_HIP(hipMemcpyAsync(&n1, ws.fb_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+            GPP_HIP(hipMemcpyAsync(ws.h_status, ws.status.p, 16, hipMemcpyDeviceToHost, stream()));
             GPP_HIP(hipStreamSynchronize(stream()));
+            n1 = h_ints[1];
             if(n1 > 0) {
                 if(16 * n1 <= 3072) {   // (as many work items as the chip holds waves of this kernel)
                     // a short list: every declined tile straight to its sixteen 4-cell items (one pass; the latency of a pass,
                     // one lone work item, is what a short list costs)
-                    a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 3;
+                    a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
                     launch_union(dim3(4 * n1), true);
                 }
                 else {
                     // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); a list too long for the split to pay is
                     // forwarded whole by the kernel
-                    a.in_list = ws.fb_list.p; a.in_count = ws.fb_count.p; a.out_list = ws.fb_list2.p; a.out_count = ws.fb_count.p + 1; a.level = 1;
+                    a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
                     launch_union(dim3(n1), true);
                     // pass 3: the declined 16-cell items as 4 items of 4 cells (at most 4 n1 of them)
-                    a.in_list = ws.fb_list2.p; a.in_count = ws.fb_count.p + 1; a.out_list = ws.fb_list3.p; a.out_count = ws.fb_count.p + 2; a.level = 2;
-                    a.parent_count = ws.fb_count.p;
+                    a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
+                    a.parent_count = d_fb_count;
                     launch_union(dim3(4 * (size_t)n1 > 0x7fffffffull ? 0x7fffffff : 4 * n1), true);
                 }
                 // pass 4: what is still left, one factorisation per distinct selection (grid-stride over the list)
-                a.in_list = ws.fb_list3.p; a.in_count = ws.fb_count.p + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
                 launch_k_oi(false);
             }
             ran_union = true;
         }
         else launch_k_oi(use_lu);
         GPP_HIP(hipEventRecord(ws.e1, stream()));
-        int nfb[3] = {0, 0, 0};
-        if(ran_union) GPP_HIP(hipMemcpyAsync(nfb, ws.fb_count.p, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
         fetch();
+        const int nfb[3] = {ran_union ? h_ints[1] : 0, ran_union ? h_ints[2] : 0, ran_union ? h_ints[3] : 0};
         g_stats.fallback_tiles = nfb[0];
         g_stats.fallback_subtiles = nfb[2];
         if(ran_union) {
@@ -1116,8 +1123,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             memo.declined = (float)nfb[0] / (float)a.ntiles;
         }
         if(big_ok && !use_lu) {
-            int nbig = 0;
-            GPP_HIP(hipMemcpy(&nbig, ws.big_count.p, sizeof(int), hipMemcpyDeviceToHost));
+            const int nbig = h_ints[4];
             if(nbig > 0) {
                 const int nwg = std::min(nbig, 256);
                 a.big_keys = ws.big_keys.get((size_t)nwg * BIG_CAND);
@@ -1133,14 +1139,15 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             use_lu = true;
             a.big_list = nullptr; a.big_count = nullptr;   // (the LU path has no large-n kernel: it fails loudly there)
             g_stats.fallback_tiles = a.ntiles;
-            GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
-            GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * (80 + 2 * GPP_NSLOT), stream()));
+            GPP_HIP(hipMemsetAsync(ws.status.p, 0, SB * sizeof(unsigned long long), stream()));
             continue;
         }
         break;
     }
-    f_out.finish(); f_var.finish();
-    GPP_HIP(hipStreamSynchronize(stream()));
+    if(f_out.host || f_var.host) {   // (device outputs: the stream is already idle after the status read-back)
+        f_out.finish(); f_var.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));
+    }
     float ms = 0;
     GPP_HIP(hipEventElapsedTime(&ms, ws.e0, ws.e1));
     g_stats.kernel_ms = ms;
