@@ -116,13 +116,27 @@ def main():
     points = gridpp.Points(plat, plon)             # bin-sorted observation index resident in HBM
     structure = gridpp.BarnesStructure(args.h)
     d_bg = torch.from_numpy(bg).to(dev)
-    # rank 0 owns the observation values of each step; the others receive them over RCCL
-    d_vals = torch.from_numpy(np.stack([obs, ratios, pbg])).to(dev) if rank == 0 else torch.empty((3, S), dtype=torch.float32, device=dev)
+    # rank 0 owns the observation values of each step; the others receive them over RCCL.  Double-buffered: the broadcast
+    # of the NEXT step's values is in flight on RCCL's stream while this step's kernels run on the library stream.
+    host_vals = np.stack([obs, ratios, pbg])
+    d_vals = [torch.from_numpy(host_vals).to(dev) if rank == 0 else torch.empty((3, S), dtype=torch.float32, device=dev) for _ in range(2)]
+    pending = [None, None]
+    state = {"k": 0}
+
+    def post(slot):
+        if dist is not None:
+            pending[slot] = dist.broadcast(d_vals[slot], src=0, async_op=True)
 
     def step():
+        k = state["k"]; state["k"] = k + 1
+        cur, nxt = k & 1, (k + 1) & 1
         if dist is not None:
-            dist.broadcast(d_vals, src=0)
-        return gridpp.optimal_interpolation(grid, d_bg, points, d_vals[0], d_vals[1], d_vals[2], structure, args.max_points)
+            if pending[cur] is None:
+                post(cur)
+            pending[cur].wait(); pending[cur] = None      # this step's values have arrived
+            post(nxt)                                     # next step's values travel while this step computes
+        v = d_vals[cur]
+        return gridpp.optimal_interpolation(grid, d_bg, points, v[0], v[1], v[2], structure, args.max_points)
 
     def fence():
         torch.cuda.synchronize()
@@ -139,6 +153,10 @@ def main():
         out = step()
         st_ = gridpp.oi_last_stats()
         kernel_ms.append(st_["kernel_ms"]); union_ms.append(st_["union_kernel_ms"])
+    if dist is not None:                                  # the one broadcast posted ahead of the last step
+        for w in pending:
+            if w is not None:
+                w.wait()
     fence()
     dt = time.perf_counter() - t0
     stats = gridpp.oi_last_stats()
@@ -174,7 +192,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (rho, distances) + f64 (local solve)", "data": "synthetic",
             "config": {"workload": workload,
-                       "parallelism": "row-tiles x%d, obs broadcast over RCCL" % world if world > 1 else "1 GPU",
+                       "parallelism": "row-tiles x%d, obs broadcast over RCCL (double-buffered, overlapped with the kernels)" % world if world > 1 else "1 GPU",
                        "inputs": "resident in HBM (device pointers through the C-ABI)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
