@@ -92,6 +92,7 @@ def main():
 
     import torch
     import gridpp_amd as gridpp
+    from gridpp_amd import dist as gdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,22 +121,10 @@ def main():
     # of the NEXT step's values is in flight on RCCL's stream while this step's kernels run on the library stream.
     host_vals = np.stack([obs, ratios, pbg])
     d_vals = [torch.from_numpy(host_vals).to(dev) if rank == 0 else torch.empty((3, S), dtype=torch.float32, device=dev) for _ in range(2)]
-    pending = [None, None]
-    state = {"k": 0}
-
-    def post(slot):
-        if dist is not None:
-            pending[slot] = dist.broadcast(d_vals[slot], src=0, async_op=True)
+    stream = gdist.ObservationStream(d_vals, rank)
 
     def step():
-        k = state["k"]; state["k"] = k + 1
-        cur, nxt = k & 1, (k + 1) & 1
-        if dist is not None:
-            if pending[cur] is None:
-                post(cur)
-            pending[cur].wait(); pending[cur] = None      # this step's values have arrived
-            post(nxt)                                     # next step's values travel while this step computes
-        v = d_vals[cur]
+        v = stream.next()
         return gridpp.optimal_interpolation(grid, d_bg, points, v[0], v[1], v[2], structure, args.max_points)
 
     def fence():
@@ -153,10 +142,7 @@ def main():
         out = step()
         st_ = gridpp.oi_last_stats()
         kernel_ms.append(st_["kernel_ms"]); union_ms.append(st_["union_kernel_ms"])
-    if dist is not None:                                  # the one broadcast posted ahead of the last step
-        for w in pending:
-            if w is not None:
-                w.wait()
+    stream.drain()                                        # the one broadcast posted ahead of the last step
     fence()
     dt = time.perf_counter() - t0
     stats = gridpp.oi_last_stats()

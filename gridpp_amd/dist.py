@@ -27,6 +27,51 @@ def broadcast_observations(values, src=0, group=None):
     return values
 
 
+class ObservationStream:
+    """Per-step observation blocks from rank 0, double-buffered: while step k computes from slot k&1, the broadcast of
+    step k+1's block into the other slot is already in flight (RCCL's own stream on a GPU box; gloo's worker thread in
+    the CPU tests), so the exchange is off the critical path of the kernels.
+
+    slots: two equally shaped torch tensors on every rank.  fill(slot, step) is called on rank 0 only, right before
+    the block of `step` is posted, and writes that step's values into slots[slot] (None = the slots already hold them).
+    next() returns the tensor holding the values of the next step, valid until the following next()."""
+
+    def __init__(self, slots, rank, fill=None, src=0, group=None):
+        import torch.distributed as dist
+        self.slots, self.rank, self.fill, self.src, self.group = slots, rank, fill, src, group
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.dist = dist
+        self.pending = [None, None]
+        self.k = 0
+
+    def _post(self, slot, step):
+        if self.rank == self.src and self.fill is not None:
+            self.fill(slot, step)
+        if self.on:
+            self.pending[slot] = self.dist.broadcast(self.slots[slot], src=self.src, group=self.group, async_op=True)
+
+    def next(self):
+        k = self.k
+        self.k = k + 1
+        cur, nxt = k & 1, (k + 1) & 1
+        if self.on:
+            if self.pending[cur] is None:
+                self._post(cur, k)
+            self.pending[cur].wait()                      # this step's values have arrived
+            self.pending[cur] = None
+            self._post(nxt, k + 1)                        # the next step's values travel while this step computes
+        elif self.fill is not None:
+            self.fill(cur, k)
+        return self.slots[cur]
+
+    def drain(self):
+        """Waits for the one block posted ahead of the last step (call before the final barrier)."""
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
+
+
 def tiled_optimal_interpolation(lats, lons, background, plats, plons, values, structure_args, max_points,
                                 rank, world, compute, allow_extrapolation=True):
     """Runs this rank's row tile of an optimal_interpolation call.

@@ -88,3 +88,47 @@ def test_neighbourhood_halo_tiles_equal_single_call(world, hw):
             row0, row1, tile = gdist.tiled_neighbourhood(f, hw, stat, r, world, O.neighbourhood)
             out[row0:row1] = tile
         np.testing.assert_array_equal(out, ref)
+
+
+def _stream_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, steps = 17, 7
+    slots = [torch.full((3, S), float("nan")) for _ in range(2)]
+
+    def fill(slot, step):                       # rank 0 produces a new block per step
+        slots[slot].copy_(torch.arange(3 * S, dtype=torch.float32).reshape(3, S) + 1000.0 * step)
+
+    stream = gdist.ObservationStream(slots, rank, fill)
+    seen = []
+    for k in range(steps):
+        v = stream.next()
+        seen.append(v.clone().numpy())          # "compute" of step k reads the block while k+1 is in flight
+    stream.drain()
+    assert stream.pending == [None, None]
+    np.save(os.path.join(outdir, "seen%d.npy" % rank), np.stack(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_double_buffered_observation_stream_two_ranks(tmp_path):
+    """Every rank sees step k's block in step k, although block k+1 is posted before step k is consumed."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_stream_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = np.stack([np.arange(51, dtype=np.float32).reshape(3, 17) + 1000.0 * k for k in range(7)])
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / ("seen%d.npy" % r)), want)
+
+
+def test_observation_stream_single_process():
+    import torch
+    slots = [torch.zeros(2), torch.zeros(2)]
+    stream = gdist.ObservationStream(slots, 0, lambda slot, step: slots[slot].fill_(step))
+    assert [float(stream.next()[0]) for _ in range(4)] == [0.0, 1.0, 2.0, 3.0]
+    stream.drain()
