@@ -371,6 +371,12 @@ class Grid(_PointSet):
     def get_num_neighbours(self, lat, lon, radius, include_match=True):
         return len(self._neighbours(lat, lon, radius, include_match))
 
+    def get_box(self, lat, lon):   # grid.cpp:149-229 -> [inside, Y1, X1, Y2, X2] (swig/gridpp.i:73-76 OUTPUT ints)
+        qlat, qlon = np.array([lat], np.float32), np.array([lon], np.float32)
+        inside, box = np.zeros(1, np.int32), np.zeros(4, np.int32)
+        check(lib().gpp_grid_get_box(self._h, _ptr(qlat), _ptr(qlon), 1, _ptr(inside), _ptr(box)))
+        return [bool(inside[0])] + [int(b) for b in box]
+
     def to_points(self):   # grid.cpp:131-145
         return Points(self._field(0), self._field(1), self._field(2), self._field(3), self._type)
 
@@ -615,6 +621,44 @@ def nearest(igrid, opoints, values):
         return out
     check(lib().gpp_nearest(igrid._h, opoints._h, _ptr(values), _ptr(out), _mem(values)))
     return out
+
+
+# ---- bilinear (include/gridpp.h:902-930, src/api/bilinear.cpp:26-135) ---------------------------------
+def bilinear(igrid, opoints, values):
+    """values (Y, X) -> output shaped like opoints; values (T, Y, X) -> (T,) + that shape."""
+    if not isinstance(igrid, Grid):
+        raise TypeError("bilinear: the input must be a Grid")
+    if _is_dev(values):
+        import torch
+        values = values.contiguous().to(torch.float32)
+    else:
+        values = np.ascontiguousarray(np.asarray(values), dtype=np.float32)
+    shp = _shape(values)
+    if len(shp) not in (2, 3):
+        raise RuntimeError("bilinear: values must be 2-D or 3-D")
+    # src/api/util.cpp:427-432: no rows (2-D) / no time levels or no rows (3-D) passes the size check
+    empty = shp[0] == 0 or (len(shp) == 3 and shp[1] == 0)
+    if not empty and tuple(shp[-2:]) != tuple(igrid.size()):
+        raise ValueError("Grid size is not the same as values")
+    oshape = tuple(opoints.size()) if isinstance(opoints, Grid) else (opoints.size(),)
+    nt = shp[0] if len(shp) == 3 else 1
+    lead = (nt,) if len(shp) == 3 else ()
+    out = _empty_like_field(lead + oshape, values)
+    if int(np.prod(lead + oshape)) == 0:
+        return out
+    if igrid._n and empty:
+        raise ValueError("Grid size is not the same as values")   # nothing to read from (the reference would index past the end)
+    mem = _mem(values)
+    _sync_if_dev(mem)
+    check(lib().gpp_bilinear(igrid._h, opoints._h, _ptr(values), nt, _ptr(out), mem))
+    return out
+
+
+def point_in_rectangle(A, B, C_, D, m):   # src/api/util.cpp:571-582
+    corners = (C.c_float * 8)(A.lat, A.lon, B.lat, B.lon, C_.lat, C_.lon, D.lat, D.lon)
+    inside = C.c_int(0)
+    check(lib().gpp_point_in_rectangle(corners, float(m.lat), float(m.lon), C.byref(inside)))
+    return bool(inside.value)
 
 
 # ---- neighbourhood filters (include/gridpp.h:588-716, src/api/neighbourhood.cpp) ---------------------

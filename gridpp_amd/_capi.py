@@ -45,6 +45,9 @@ SIGNATURES = {
     "gpp_points_get_closest_neighbours": [vp, C.c_float, C.c_float, C.c_int, C.c_int, vp, ip],
     "gpp_points_nearest_neighbour": [vp, vp, vp, C.c_int, C.c_int, vp],
     "gpp_nearest": [vp, vp, vp, vp, C.c_int],
+    "gpp_bilinear": [vp, vp, vp, C.c_int, vp, C.c_int],
+    "gpp_grid_get_box": [vp, vp, vp, C.c_int, vp, vp],
+    "gpp_point_in_rectangle": [vp, C.c_float, C.c_float, ip],
     "gpp_structure_min_rho": [C.c_int, C.c_float, C.c_float, fp],
     "gpp_structure_localization_distance": [C.POINTER(gpp_structure), C.c_float, C.c_float, fp],
     "gpp_structure_corr": [C.POINTER(gpp_structure), fp, fp, C.c_int, fp],

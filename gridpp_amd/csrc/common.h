@@ -108,6 +108,9 @@ struct gpp_points {
     std::vector<float> lats, lons, elevs, lafs, x, y, z;   // host copies (float32, as the reference stores them)
     gpp::DevBuf<float> d_x, d_y, d_z, d_elev, d_laf;       // HBM-resident SoA
     bool on_device = false;
+    gpp::DevBuf<float> d_lat, d_lon;                       // lat / lon in HBM, uploaded on first use (bilinear.hip)
+    bool latlon_on_device = false;
+    void latlon_to_device();
     bool host_xyz = true;            // x, y, z are present on the host (large sets are converted on the device and
     void ensure_host_xyz();          // downloaded only when a host-side function asks for them)
     bool elev_uniform = true, laf_uniform = true;   // every point has the same elevation / laf (or none has one)

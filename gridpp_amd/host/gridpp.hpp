@@ -10,6 +10,7 @@
 //   optimal_interpolation(_full)(_ensi)        :162-294
 //   neighbourhood*, get_neighbourhood_thresholds :588-716
 //   nearest(Grid|Points, Points, vec2|vec)     :895
+//   bilinear(Grid, Grid|Points, vec2|vec3)     :902-930
 //   calc_statistic / calc_quantile             :1454-1482
 // Nested vectors are flattened once, handed to the C-ABI as host buffers (GPP_MEM_HOST) and un-flattened,
 // exactly where the reference flattens them itself (src/api/oi.cpp:69-86).  Errors: GPP_EINVAL ->
@@ -137,6 +138,12 @@ class Grid {
         int i = -1;
         detail::check(gpp_points_nearest_neighbour(mH->p, &lat, &lon, 1, include_match, &i));
         return ivec{i / mX, i % mX};
+    }
+    bool get_box(float lat, float lon, int& Y1_out, int& X1_out, int& Y2_out, int& X2_out) const {   // grid.cpp:149-229
+        int inside = 0, box[4] = {-1, -1, -1, -1};
+        detail::check(gpp_grid_get_box(mH->p, &lat, &lon, 1, &inside, box));
+        Y1_out = box[0]; X1_out = box[1]; Y2_out = box[2]; X2_out = box[3];
+        return inside != 0;
     }
     gpp_points* handle() const { return mH->p; }
   private:
@@ -376,6 +383,42 @@ inline vec nearest(const Points& ipoints, const Points& opoints, const vec& ival
     vec out(opoints.size(), MV);
     if(opoints.size()) detail::check(gpp_nearest(ipoints.handle(), opoints.handle(), ivalues.data(), out.data(), GPP_MEM_HOST));
     return out;
+}
+
+// ---- bilinear (include/gridpp.h:902-930; src/api/bilinear.cpp:26-135) -------------------------------------------
+namespace detail {
+// values [T][Y][X] flattened; size rule of src/api/util.cpp:427-432
+inline vec bilinear_flat(const Grid& igrid, gpp_points* to, size_t nq, const vec& v, size_t T, size_t Y, size_t X, bool empty) {
+    if(!empty && ((int)Y != igrid.size()[0] || (int)X != igrid.size()[1])) throw std::invalid_argument("Grid size is not the same as values");
+    vec out(T * nq, MV);
+    if(T * nq == 0 || igrid.size()[0] == 0 || igrid.size()[1] == 0) return out;   // bilinear.cpp:37-39
+    if(empty) throw std::invalid_argument("Grid size is not the same as values");
+    check(gpp_bilinear(igrid.handle(), to, v.data(), (int)T, out.data(), GPP_MEM_HOST));
+    return out;
+}
+}   // namespace detail
+inline vec bilinear(const Grid& igrid, const Points& opoints, const vec2& ivalues) {
+    size_t Y, X;
+    vec v = detail::flatten(ivalues, Y, X);
+    return detail::bilinear_flat(igrid, opoints.handle(), opoints.size(), v, 1, Y, X, ivalues.size() == 0);
+}
+inline vec2 bilinear(const Grid& igrid, const Points& opoints, const vec3& ivalues) {
+    size_t T, Y, X;
+    vec v = detail::flatten(ivalues, T, Y, X);
+    vec out = detail::bilinear_flat(igrid, opoints.handle(), opoints.size(), v, T, Y, X, T == 0 || Y == 0);
+    return detail::unflatten(out, T, opoints.size());
+}
+inline vec2 bilinear(const Grid& igrid, const Grid& ogrid, const vec2& ivalues) {
+    size_t Y, X;
+    vec v = detail::flatten(ivalues, Y, X);
+    size_t oy = ogrid.size()[0], ox = ogrid.size()[1];
+    return detail::unflatten(detail::bilinear_flat(igrid, ogrid.handle(), oy * ox, v, 1, Y, X, ivalues.size() == 0), oy, ox);
+}
+inline vec3 bilinear(const Grid& igrid, const Grid& ogrid, const vec3& ivalues) {
+    size_t T, Y, X;
+    vec v = detail::flatten(ivalues, T, Y, X);
+    size_t oy = ogrid.size()[0], ox = ogrid.size()[1];
+    return detail::unflatten(detail::bilinear_flat(igrid, ogrid.handle(), oy * ox, v, T, Y, X, T == 0 || Y == 0), T, oy, ox);
 }
 
 // ---- util (include/gridpp.h:1454-1482) -----------------------------------------------------------------------------

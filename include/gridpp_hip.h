@@ -103,6 +103,18 @@ int gpp_points_nearest_neighbour(gpp_points* p, const float* qlats, const float*
  * values/out follow `mem`. */
 int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* out, int mem);
 
+/* gridpp::bilinear(Grid, Points|Grid, vec2|vec3) (src/api/bilinear.cpp:26-135; per location :322-403, weights
+ * :137-320): `values` holds nt time levels of the input grid, [nt][ny][nx]; out is [nt][size of `to`].  A location
+ * outside the grid, or whose box has a missing corner, takes the nearest grid point's value; all NaN if the input
+ * grid is empty.  GPP_ERUNTIME ("Problem with bilinear interpolation...") when the weights of a box leave [0, 1]
+ * (the reference throws std::runtime_error, :309-313).  values/out follow `mem`. */
+int gpp_bilinear(gpp_points* igrid, gpp_points* to, const float* values, int nt, float* out, int mem);
+/* Grid::get_box (src/api/grid.cpp:149-229) for nq lookups (host arrays): inside[i] and boxes[4*i..] = Y1, X1, Y2, X2
+ * (-1 when no box encloses the point). */
+int gpp_grid_get_box(gpp_points* grid, const float* qlats, const float* qlons, int nq, int* inside, int* boxes);
+/* gridpp::point_in_rectangle (src/api/util.cpp:571-582): corners A, B, C, D as (lat, lon) pairs. */
+int gpp_point_in_rectangle(const float corners_latlon[8], float lat, float lon, int* inside);
+
 /* ---- structure functions (src/api/structure.cpp) -----------------------------
  * Scalar forms of BarnesStructure, CressmanStructure, SoarStructure, ToarStructure,
  * PowerlawStructure, LinearStructure (structure.cpp:143-167,287-299,317-341,467-491,

@@ -880,6 +880,158 @@ int orc_nearest(const float* gx, const float* gy, const float* gz, int nG, const
 }
 
 /* ------------------------------------------------------------------------ */
+/* bilinear(Grid, Points|Grid, vec2|vec3): src/api/bilinear.cpp:26-135        */
+/* ------------------------------------------------------------------------ */
+/* src/api/util.cpp:561-582: signed line tests of m against the edges AB, AD, BC, CD (float arithmetic); a point is
+ * inside when the four signs fit a clockwise or a counter-clockwise quadrilateral. */
+static float orc_edge_side(float plat, float plon, float qlat, float qlon, float mlat, float mlon) {
+    float vlon = qlon - plon;            /* vect2d: lon = dlon, lat = -dlat */
+    float vlat = -1 * (qlat - plat);
+    float c = -1 * (vlat * plon + vlon * plat);
+    return (vlat * mlon + vlon * mlat) + c;
+}
+int orc_point_in_rectangle(float alat, float alon, float blat, float blon, float clat, float clon,
+                           float dlat, float dlon, float mlat, float mlon) {
+    float d1 = orc_edge_side(alat, alon, blat, blon, mlat, mlon);
+    float d2 = orc_edge_side(alat, alon, dlat, dlon, mlat, mlon);
+    float d3 = orc_edge_side(blat, blon, clat, clon, mlat, mlon);
+    float d4 = orc_edge_side(clat, clon, dlat, dlon, mlat, mlon);
+    int cw = 0 >= d1 && 0 >= d4 && 0 <= d2 && 0 >= d3;
+    int ccw = 0 <= d1 && 0 <= d4 && 0 >= d2 && 0 <= d3;
+    return cw || ccw;
+}
+
+/* src/api/grid.cpp:149-229: the grid box around (lat, lon), searched in the four quadrants of the nearest grid
+ * point in the order (+1,-1), (+1,+1), (-1,-1), (-1,+1) = (ydir, xdir).  nn = flat index of the nearest point. */
+int orc_get_box(const float* glat, const float* glon, int nY, int nX, int nn, float lat, float lon,
+                int* Y1, int* X1, int* Y2, int* X2) {
+    *Y1 = *Y2 = *X1 = *X2 = -1;
+    if(nn < 0 || nX <= 1 || nY <= 1) return 0;
+    int Y = nn / nX, X = nn % nX;
+    for(int it = 0; it < 4; it++) {
+        int xdir = -1 + 2 * (it % 2);
+        int ydir = -1 + 2 * (it < 2);
+        if((Y == 0 && ydir == -1) || (Y == nY - 1 && ydir == 1) || (X == 0 && xdir == -1) || (X == nX - 1 && xdir == 1))
+            continue;
+        int a = Y * nX + X, b = (Y + ydir) * nX + X, c = (Y + ydir) * nX + X + xdir, d = Y * nX + X + xdir;
+        if(orc_point_in_rectangle(glat[a], glon[a], glat[b], glon[b], glat[c], glon[c], glat[d], glon[d], lat, lon)) {
+            *X1 = xdir == 1 ? X : X - 1;
+            *X2 = *X1 + 1;
+            *Y1 = ydir == 1 ? Y : Y - 1;
+            *Y2 = *Y1 + 1;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* src/api/bilinear.cpp:154-157 */
+static int orc_bl_in_range(float v) {
+    float tol = 0.01;
+    return v >= -tol && v < 1 + tol;
+}
+
+/* src/api/bilinear.cpp:138-153 (parallelogram: 2x2 linear system, float) */
+static void orc_bl_parallelogram(float x, float y, float X1, float X2, float X3, float Y1, float Y2, float Y3,
+                                 float* t, float* s) {
+    float A = X2 - X1, B = X3 - X1, C = Y2 - Y1, D = Y3 - Y1;
+    float det = 1 / (A * D - B * C);
+    *s = det * ((x - X1) * (D) + (y - Y1) * (-B));
+    *t = det * ((x - X1) * (-C) + (y - Y1) * (A));
+}
+
+/* src/api/bilinear.cpp:159-267 (general quadrilateral: roots of the quadratic in double; coefficient differences
+ * are formed in float first, as the reference's `double a = -x0 + x2` does) */
+static void orc_bl_general(float x, float y, float x0, float x1, float x2, float x3, float y0, float y1, float y2,
+                           float y3, float* t_out, float* s_out) {
+    double a = -x0 + x2, b = -x0 + x1, c = x0 - x1 - x2 + x3, d = x - x0;
+    double e = -y0 + y2, f = -y0 + y1, g = y0 - y1 - y2 + y3, h = y - y0;
+    double alpha = NAN, beta = NAN;
+    double Y1 = y1, Y2 = y3, Y3 = y0, Y4 = y2, X1 = x1, X2 = x3, X3 = x0, X4 = x2;
+    double X31 = X3 - X1, X21 = X2 - X1, Y42 = Y4 - Y2, Y21 = Y2 - Y1, Y31 = Y3 - Y1, Y43 = Y4 - Y3, X42 = X4 - X2,
+           X43 = X4 - X3;
+    double qa = 2 * c * e - 2 * a * g, qb = 2 * c * f - 2 * b * g;
+    double lin1 = b * e - a * f + d * g - c * h, lin2 = b * e - a * f - d * g + c * h;
+    double root = sqrt(-4 * (c * e - a * g) * (d * f - b * h) + pow(lin1, 2));
+    if(qa != 0 && qb != 0) {
+        alpha = -(lin1 + root) / qa;
+        beta = (lin2 + root) / qb;
+        if(!orc_bl_in_range(alpha)) alpha = -(lin1 - root) / qa;
+        if(!orc_bl_in_range(beta)) beta = (lin2 - root) / qb;
+    }
+    else if(qb == 0) {
+        alpha = -(lin1 + root) / qa;
+        if(!orc_bl_in_range(alpha)) alpha = -(lin1 - root) / qa;
+        float s = alpha, t;
+        if(Y3 + Y43 * s - Y1 - Y21 * s == 0) t = (x - X1 - X21 * s) / (X3 + X43 * s - X1 - X21 * s);
+        else t = (y - Y1 - Y21 * s) / (Y3 + Y43 * s - Y1 - Y21 * s);
+        beta = 1 - t;
+    }
+    else if(qa == 0) {
+        beta = (lin2 + root) / qb;   /* the reference's retry uses the same root (:245-246) */
+        float t = 1 - beta, s;
+        if(Y2 + Y42 * t - Y1 - Y31 * t == 0) s = (x - X1 - X31 * t) / (X2 + X42 * t - X1 - X31 * t);
+        else s = (y - Y1 - Y31 * t) / (Y2 + Y42 * t - Y1 - Y31 * t);
+        alpha = s;
+    }
+    *s_out = alpha;
+    *t_out = 1 - beta;
+}
+
+/* src/api/bilinear.cpp:269-320.  Returns 0, or 1 when s / t fall outside [0, 1] after the +-0.15 snap (the
+ * reference throws std::runtime_error there); s and t are returned for the message. */
+static int orc_bl_weights(float x, float y, float x0, float x1, float x2, float x3, float y0, float y1, float y2,
+                          float y3, float* s_out, float* t_out) {
+    float Y1 = y1, Y2 = y3, Y3 = y0, Y4 = y2, X1 = x1, X2 = x3, X3 = x0, X4 = x2;
+    float s = NAN, t = NAN;
+    int vertical = fabsf((X3 - X1) * (Y4 - Y2) - (X4 - X2) * (Y3 - Y1)) <= 1e-4;
+    int horizontal = fabsf((X2 - X1) * (Y4 - Y3) - (X4 - X3) * (Y2 - Y1)) <= 1e-4;
+    if(vertical && horizontal) orc_bl_parallelogram(x, y, X1, X2, X3, Y1, Y2, Y3, &t, &s);
+    else orc_bl_general(x, y, x0, x1, x2, x3, y0, y1, y2, y3, &t, &s);
+    if(t >= 1 && t <= 1.15) t = 1;
+    if(t <= 0 && t >= -0.15) t = 0;
+    if(s >= 1 && s <= 1.15) s = 1;
+    if(s <= 0 && s >= -0.15) s = 0;
+    *s_out = s; *t_out = t;
+    return !(s >= 0 && s <= 1 && t >= 0 && t <= 1);
+}
+
+/* values [nT][nY][nX], out [nT][nQ]; glat/glon the grid's float32 lat/lon, gx/gy/gz its search coordinates.
+ * Returns ORC_OK, or ORC_ESINGULAR when a box is too distorted (bad_s / bad_t receive the offending weights). */
+int orc_bilinear(const float* glat, const float* glon, const float* gx, const float* gy, const float* gz, int nY, int nX,
+                 const float* values, int nT, const float* qlat, const float* qlon, const float* qx, const float* qy,
+                 const float* qz, int nQ, float* out, float* bad_s, float* bad_t) {
+    int nG = nY * nX;
+    for(int i = 0; i < nQ; i++) {
+        if(nG == 0) { for(int k = 0; k < nT; k++) out[(size_t)k * nQ + i] = NAN; continue; }
+        int nn = orc_nearest_neighbour(gx, gy, gz, nG, qx[i], qy[i], qz[i], 1);
+        int I1, J1, I2, J2;
+        int inside = orc_get_box(glat, glon, nY, nX, nn, qlat[i], qlon[i], &I1, &J1, &I2, &J2);
+        for(int k = 0; k < nT; k++) {
+            const float* v = values + (size_t)k * nG;
+            float res = v[nn];
+            if(inside) {
+                float v0 = v[I1 * nX + J1], v1 = v[I2 * nX + J1], v2 = v[I1 * nX + J2], v3 = v[I2 * nX + J2];
+                if(orc_valid(v0) && orc_valid(v1) && orc_valid(v2) && orc_valid(v3)) {
+                    float s, t;
+                    if(orc_bl_weights(qlon[i], qlat[i], glon[I1 * nX + J1], glon[I2 * nX + J1], glon[I1 * nX + J2],
+                                      glon[I2 * nX + J2], glat[I1 * nX + J1], glat[I2 * nX + J1], glat[I1 * nX + J2],
+                                      glat[I2 * nX + J2], &s, &t)) {
+                        if(bad_s) *bad_s = s;
+                        if(bad_t) *bad_t = t;
+                        return ORC_ESINGULAR;
+                    }
+                    float P1 = v1, P2 = v3, P3 = v0, P4 = v2;
+                    res = P1 * (1 - s) * (1 - t) + P2 * s * (1 - t) + P3 * (1 - s) * t + P4 * s * t;
+                }
+            }
+            out[(size_t)k * nQ + i] = res;
+        }
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* optimal_interpolation_ensi (Points): src/api/oi_ensi.cpp:114-568           */
 /* background [nY][nE], pbackground [nS][nE], out [nY][nE]                    */
 /* ------------------------------------------------------------------------ */

@@ -258,6 +258,50 @@ def nearest(g, q, values):
     return out
 
 
+class OracleDistorted(RuntimeError):
+    """bilinear: s / t outside [0, 1] (the reference throws std::runtime_error, src/api/bilinear.cpp:309-313)"""
+
+
+def point_in_rectangle(A, B, C_, D, m):
+    """A..D, m = (lat, lon) pairs (src/api/util.cpp:571-582)"""
+    f = lib().orc_point_in_rectangle
+    f.argtypes = [C.c_float] * 10
+    return bool(f(A[0], A[1], B[0], B[1], C_[0], C_[1], D[0], D[1], m[0], m[1]))
+
+
+def get_box(g, shape, lat, lon):
+    """Grid::get_box (src/api/grid.cpp:149-229) -> [inside, Y1, X1, Y2, X2]"""
+    nY, nX = shape
+    if g.n == 0:
+        return [False, -1, -1, -1, -1]
+    nn = nearest_neighbour(g, lat, lon, True)
+    box = (C.c_int * 4)()
+    f = lib().orc_get_box
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [C.POINTER(C.c_int)] * 4
+    inside = f(g.lats.ctypes.data, g.lons.ctypes.data, nY, nX, nn, lat, lon, *[C.cast(C.byref(box, 4 * k), C.POINTER(C.c_int)) for k in range(4)])
+    return [bool(inside)] + [int(b) for b in box]
+
+
+def bilinear(g, shape, q, values):
+    """g: Pts of a (Y, X) grid, q: Pts of the output locations, values (Y, X) or (T, Y, X) -> (nq,) or (T, nq)"""
+    nY, nX = shape
+    values = _f(values)
+    three_d = values.ndim == 3
+    nT = values.shape[0] if three_d else 1
+    out = np.empty((nT, q.n), np.float32)
+    bad = np.zeros(2, np.float32)
+    v = np.ascontiguousarray(values).ravel()
+    if v.size == 0:
+        v = np.zeros(1, np.float32)
+    rc = lib().orc_bilinear(g.lats.ctypes, g.lons.ctypes, g.x.ctypes, g.y.ctypes, g.z.ctypes, C.c_int(nY), C.c_int(nX),
+                            v.ctypes, C.c_int(nT), q.lats.ctypes, q.lons.ctypes, q.x.ctypes, q.y.ctypes, q.z.ctypes,
+                            C.c_int(q.n), out.ctypes, bad[0:].ctypes, bad[1:].ctypes)
+    if rc == -2:
+        raise OracleDistorted("Problem with bilinear interpolation. s=%g and t=%g" % (bad[0], bad[1]))
+    _check(rc)
+    return out if three_d else out[0]
+
+
 def calc_statistic(a, stat):
     a = _f(a).ravel()
     return float(lib().orc_calc_statistic(a.ctypes, C.c_int(a.size), C.c_int(stat)))

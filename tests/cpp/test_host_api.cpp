@@ -54,6 +54,25 @@ int main() {
     Points p2(vec{0, 0.1f}, vec{0, 0.1f});
     vec2 o3 = optimal_interpolation_ensi(g1, bg3, p2, vec{NAN, 0}, vec{1, 1}, vec2{{0, 0, 0}, {0, 0, 0}}, BarnesStructure(500000), 10);
     CHECK(o3[0][0] == 0 && o3[0][2] == 0);
+    // bilinear (tests/test_bilinear.py:134-156, tests/test_grid.py:23-30)
+    {
+        vec2 la1 = {{0, 0}, {1, 1}}, lo1 = {{0, 1}, {0, 1}};
+        vec2 la2 = {{0, 0, 0}, {0.5f, 0.5f, 0.5f}, {1, 1, 1}}, lo2 = {{0, 0.5f, 1}, {0, 0.5f, 1}, {0, 0.5f, 1}};
+        Grid g1(la1, lo1), g2(la2, lo2);
+        vec2 v = {{0, 1}, {2, 3}};
+        vec2 b = bilinear(g1, g2, v);
+        CHECK(b[0][1] == 0.5f && b[1][1] == 1.5f && b[2][2] == 3 && b[1][0] == 1);
+        vec3 b3 = bilinear(g1, g2, vec3{v, v, v});
+        CHECK(b3.size() == 3 && b3[2][1][2] == 2);
+        vec bp = bilinear(g1, Points(vec{0.5f}, vec{0.25f}), v);
+        CHECK(bp.size() == 1 && bp[0] == 1.25f);
+        Grid g3(vec2{{0, 0, 0}, {1, 1, 1}}, vec2{{0, 1, 2}, {0.25f, 1.25f, 2.25f}});
+        int Y1, X1, Y2, X2;
+        CHECK(g3.get_box(0.4f, 1.25f, Y1, X1, Y2, X2) && Y1 == 0 && X1 == 1 && Y2 == 1 && X2 == 2);
+        threw = false;
+        try { bilinear(g1, g2, vec2{{0, 1, 2}}); } catch(const std::invalid_argument&) { threw = true; }
+        CHECK(threw);
+    }
     std::printf("gridpp.hpp host API: all checks passed (version %s)\n", version().c_str());
     return 0;
 }

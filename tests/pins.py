@@ -452,4 +452,106 @@ def pin_oi_cross_validation(g, G):
     assert abs(float(np.asarray(g.nearest(grid, points, analysis))[k]) - float(np.asarray(analysis_cv)[k])) < 1e-6
 
 
+def pin_bilinear(g, G):
+    import pytest
+    e = G["bilinear_simple"]
+    lons, lats = np.meshgrid(e["grid_lons"], e["grid_lats"])
+    grid = g.Grid(lats, lons)
+    values = np.reshape(np.arange(9), lons.shape).astype(np.float32)
+    points = g.Points(e["point_lats"], e["point_lons"])
+    np.testing.assert_array_equal(g.bilinear(grid, points, values), e["expected"])
+    # incompatible sizes (tests/test_bilinear.py:29-40,158-163)
+    grid24 = g.Grid([[0, 0, 0, 0], [1, 1, 1, 1]], [[0, 1, 2, 3], [0, 1, 2, 3]])
+    for N in (1, 3, 5):
+        with pytest.raises(Exception):
+            g.bilinear(grid24, grid24, np.zeros([N, N], np.float32))
+        with pytest.raises(Exception):
+            g.bilinear(grid24, g.Points([0, 1], [0, 1]), np.zeros([N, N], np.float32))
+    lons2, lats2 = np.meshgrid([0, 1], [0, 1])
+    with pytest.raises(Exception):
+        g.bilinear(g.Grid(lats2, lons2), g.Grid(lats2, lons2), np.zeros([3, 1, 1], np.float32))
+    # empty outputs / inputs (tests/test_bilinear.py:165-187)
+    assert np.size(g.bilinear(grid, g.Points([], []), values)) == 0
+    out = g.bilinear(g.Grid([[]], [[]]), g.Points([0, 5, 10], [0, 5, 10]), np.zeros([0, 0], np.float32))
+    assert np.all(np.isnan(np.asarray(out))) and np.size(out) == 3
+    assert np.size(g.bilinear(grid, g.Grid([[]], [[]]), values)) == 0
+
+
+def pin_bilinear_shapes(g, G):
+    e = G["bilinear_rotation"]
+    values = np.array(e["values"], np.float32)
+    lons0, lats0 = np.array(e["lons0"], float), np.array(e["lats0"], float)
+    for rotation in e["rotations_deg"]:
+        angle = rotation * 2 * e["pi"] / 360
+        lon_p = e["point_lon0"] * np.cos(angle) - e["point_lat0"] * np.sin(angle)
+        lat_p = e["point_lon0"] * np.sin(angle) + e["point_lat0"] * np.cos(angle)
+        lons = lons0 * np.cos(angle) - lats0 * np.sin(angle)
+        lats = lons0 * np.sin(angle) + lats0 * np.cos(angle)
+        out = g.bilinear(g.Grid(lats, lons), g.Points([lat_p], [lon_p]), values)[0]
+        assert abs(float(out) - e["expected"]) < 0.5 * 10 ** -e["places"], (rotation, out)
+    e = G["bilinear_parallelogram"]
+    values = np.array(e["values"], np.float32)
+    origin = g.Points([0], [0])
+    for skew in e["skews"]:
+        grid = g.Grid([[-1, -1], [1, 1]], [[-1 + skew, 1 + skew], [-1 - skew, 1 - skew]])
+        assert g.bilinear(grid, origin, values)[0] == e["expected"]
+        grid = g.Grid([[-1 + skew, -1 - skew], [1 + skew, 1 - skew]], [[-1, 1], [-1, 1]])
+        assert g.bilinear(grid, origin, values)[0] == e["expected"]
+    e = G["bilinear_non_parallelogram"]
+    out = g.bilinear(g.Grid(e["lats"], e["lons"]), g.Points([e["point"][0]], [e["point"][1]]), np.array(e["values"], np.float32))[0]
+    assert abs(float(out) - e["expected"]) < 0.5 * 10 ** -e["places"]
+    e = G["bilinear_vertical_parallel"]          # must not fail
+    for c in e["cases"]:
+        lons = c["lons"] if "lons" in c else np.transpose(c["lons_T"])
+        lats = c["lats"] if "lats" in c else np.transpose(c["lats_T"])
+        out = g.bilinear(g.Grid(lats, lons), g.Points([e["point"][0]], [e["point"][1]]), np.array(e["values"], np.float32))
+        assert np.size(out) == 1
+    e = G["bilinear_weird"]
+    x = np.reshape(e["x"], [2, 2]).transpose()
+    y = np.reshape(e["y"], [2, 2]).transpose()
+    x0, y0 = e["px"] - x[0][0], e["py"] - y[0][0]
+    x, y = x - x[0][0], y - y[0][0]
+    values = np.reshape(np.arange(4), [2, 2]).transpose().astype(np.float32)
+    for _ in range(2):
+        x, y, values = x.transpose(), y.transpose(), values.transpose()
+        q = g.bilinear(g.Grid(y, x), g.Points([y0], [x0]), values)
+        assert abs(float(q[0]) - e["expected"]) < 0.5 * 10 ** -e["places"], q
+
+
+def pin_bilinear_missing_and_grids(g, G):
+    e = G["bilinear_missing"]
+    values = np.array([[np.nan if v is None else v for v in row] for row in e["values"]], np.float32)
+    out = g.bilinear(g.Grid(e["lats"], e["lons"]), g.Points(e["point_lats"], e["point_lons"]), values)
+    np.testing.assert_array_equal(out, e["expected"])
+    e = G["bilinear_grid_to_grid"]
+    values = np.reshape(np.arange(4), [2, 2]).astype(np.float32)
+    lons1, lats1 = np.meshgrid(e["in_axis"], e["in_axis"])
+    lons2, lats2 = np.meshgrid(e["out_axis"], e["out_axis"])
+    grid1, grid2 = g.Grid(lats1, lons1), g.Grid(lats2, lons2)
+    np.testing.assert_array_equal(g.bilinear(grid1, grid2, values), e["expected"])
+    out = np.asarray(g.bilinear(grid1, grid2, np.repeat(values[None], e["T"], axis=0)))
+    assert out.shape == (e["T"], 3, 3)
+    for t in range(e["T"]):
+        np.testing.assert_array_equal(out[t], e["expected"])
+
+
+def pin_grid_get_box(g, G):
+    e = G["grid_get_box"]
+    grid = g.Grid(e["lats"], e["lons"])
+    for c in e["cases"]:
+        np.testing.assert_array_equal(grid.get_box(*c["q"]), c["expected"])
+    o = e["one_row"]
+    assert not g.Grid(o["lats"], o["lons"]).get_box(*o["q"])[0]
+    assert not g.Grid().get_box(*o["q"])[0]
+
+
+def pin_point_in_rectangle(g, G):
+    for c in G["point_in_rectangle"]["cases"]:
+        A, B, C, D = (g.Point(*c[k]) for k in "ABCD")
+        for m in c["inside"]:
+            assert g.point_in_rectangle(A, B, C, D, g.Point(*m)), (c, m)
+        for m in c["outside"]:
+            assert not g.point_in_rectangle(A, B, C, D, g.Point(*m)), (c, m)
+
+
 ALL_PINS = [v for k, v in sorted(globals().items()) if k.startswith("pin_")]

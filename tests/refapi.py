@@ -60,6 +60,9 @@ class Grid:
     def size(self):
         return list(self.shape)
 
+    def get_box(self, lat, lon):
+        return O.get_box(self.p, tuple(self.shape) if self.p.n else (0, 0), lat, lon)
+
     def get_coordinate_type(self):
         return self.type
 
@@ -182,6 +185,30 @@ def optimal_interpolation_ensi(bg, background, points, pobs, psigmas, pbackgroun
 
 def nearest(grid, points, values):
     return O.nearest(_pts(grid), _pts(points), values)
+
+
+def bilinear(igrid, opoints, values):
+    values = np.asarray(values, np.float32)
+    ishape = tuple(igrid.size()) if igrid.p.n else (0, 0)      # src/api/grid.cpp:122-130
+    # src/api/util.cpp:427-432: no rows (2-D) / no times or no rows (3-D) is compatible with anything
+    empty = values.ndim in (2, 3) and (values.shape[0] == 0 or (values.ndim == 3 and values.shape[1] == 0))
+    if values.ndim not in (2, 3) or (not empty and tuple(values.shape[-2:]) != ishape):
+        raise ValueError("Grid size is not the same as values")
+    oshape = tuple(opoints.size()) if isinstance(opoints, Grid) else (opoints.size(),)
+    lead = (values.shape[0],) if values.ndim == 3 else ()
+    if int(np.prod(oshape)) == 0:
+        return np.zeros(lead + oshape, np.float32)
+    if igrid.p.n == 0:                                           # src/api/bilinear.cpp:37-39
+        return np.full(lead + oshape, np.nan, np.float32)
+    try:
+        out = O.bilinear(_pts(igrid), ishape, _pts(opoints), values)
+    except O.OracleDistorted as e:
+        raise RuntimeError(str(e))
+    return out.reshape(lead + oshape)
+
+
+def point_in_rectangle(A, B, C, D, m):
+    return O.point_in_rectangle((A.lat, A.lon), (B.lat, B.lon), (C.lat, C.lon), (D.lat, D.lon), (m.lat, m.lon))
 
 
 def _wrap(fn):
