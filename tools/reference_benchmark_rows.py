@@ -40,6 +40,9 @@ I500 = np.zeros((500, 500))
 rows.append(("neighbourhood_quantile 500^2 hw=7", 1.70, lambda: gridpp.neighbourhood_quantile(I500, 0.5, 7)))
 G1000 = grid(1000)
 rows.append(("nearest 1000^2 grid -> grid", 1.52, lambda: gridpp.nearest(G1000, G1000, I1000)))
+rows.append(("bilinear 1000^2 grid -> grid", 1.68, lambda: gridpp.bilinear(G1000, G1000, I1000)))
+I50 = np.zeros((50, 1000, 1000))
+rows.append(("bilinear 1000^2 x 50 levels", 4.42, lambda: gridpp.bilinear(G1000, G1000, I50)))
 G100, P1000 = grid(100), points(1000)
 rows.append(("optimal_interpolation 100^2, 1000 obs, max_points 20", 0.80,
              lambda: gridpp.optimal_interpolation(G100, np.zeros((100, 100)), P1000, np.zeros(1000), np.ones(1000), np.ones(1000), structure, 20)))
