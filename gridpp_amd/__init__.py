@@ -607,19 +607,37 @@ def oi_last_stats():
 
 # ---- nearest (src/api/nearest.cpp:124-144) ----------------------------------------------------------
 def nearest(igrid, opoints, values):
+    """All eight overloads of src/api/nearest.cpp: Grid|Points -> Grid|Points, with or without a leading time dimension."""
     nd = 2 if isinstance(igrid, Grid) else 1
-    values = _vec(values, nd, "values")
-    shape = tuple(igrid.size()) if nd == 2 else (igrid.size(),)
-    if _shape(values) != shape:
-        raise ValueError("Grid size is not the same as values")
-    if isinstance(opoints, Grid):
-        oshape = tuple(opoints.size())
+    if _is_dev(values):
+        import torch
+        values = values.contiguous().to(torch.float32)
     else:
-        oshape = (opoints.size(),)
-    out = _empty_like_field(oshape, values)
-    if int(np.prod(oshape)) == 0:
+        values = np.ascontiguousarray(np.asarray(values), dtype=np.float32)
+        if values.size == 0 and values.ndim < nd:
+            values = values.reshape((0,) * nd)
+    shp = _shape(values)
+    if len(shp) not in (nd, nd + 1):
+        raise RuntimeError("values must have %d or %d dimensions" % (nd, nd + 1))
+    levels = len(shp) == nd + 1
+    ishape = tuple(igrid.size()) if nd == 2 else (igrid.size(),)
+    if nd == 2:    # src/api/util.cpp:427-432
+        empty = shp[0] == 0 or (levels and shp[1] == 0)
+    else:          # util.cpp:433-438: a vec2 with no time levels passes, a vec must match
+        empty = levels and shp[0] == 0
+    if not empty and tuple(shp[-nd:]) != ishape:
+        raise ValueError("Grid size is not the same as values" if nd == 2 else "Points size is not the same as values")
+    oshape = tuple(opoints.size()) if isinstance(opoints, Grid) else (opoints.size(),)
+    nt = shp[0] if levels else 1
+    lead = (nt,) if levels else ()
+    out = _empty_like_field(lead + oshape, values)
+    if int(np.prod(lead + oshape)) == 0:
         return out
-    check(lib().gpp_nearest(igrid._h, opoints._h, _ptr(values), _ptr(out), _mem(values)))
+    if igrid._n and empty:
+        raise ValueError("Grid size is not the same as values")
+    mem = _mem(values)
+    _sync_if_dev(mem)
+    check(lib().gpp_nearest_levels(igrid._h, opoints._h, _ptr(values), nt, _ptr(out), mem))
     return out
 
 

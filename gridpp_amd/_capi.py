@@ -45,6 +45,7 @@ SIGNATURES = {
     "gpp_points_get_closest_neighbours": [vp, C.c_float, C.c_float, C.c_int, C.c_int, vp, ip],
     "gpp_points_nearest_neighbour": [vp, vp, vp, C.c_int, C.c_int, vp],
     "gpp_nearest": [vp, vp, vp, vp, C.c_int],
+    "gpp_nearest_levels": [vp, vp, vp, C.c_int, vp, C.c_int],
     "gpp_bilinear": [vp, vp, vp, C.c_int, vp, C.c_int],
     "gpp_grid_get_box": [vp, vp, vp, C.c_int, vp, vp],
     "gpp_point_in_rectangle": [vp, C.c_float, C.c_float, ip],

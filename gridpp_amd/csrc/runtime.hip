@@ -502,25 +502,44 @@ __global__ void k_fill(float* out, int n, float v) {
     if(i < n) out[i] = v;
 }
 
-extern "C" int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* out, int mem) {
+// values [nt][n_from] -> out [nt][nq]: the index is looked up once per location, the levels are gathered with unit-stride
+// writes (nearest.cpp:47-66 makes the same split "because we do not want time to be the inner loop")
+__global__ void k_gather_levels(const float* __restrict__ values, const int* __restrict__ idx, int nq, size_t nfrom, int nt,
+                                float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= nq) return;
+    const int j = idx[i];
+    for(int t = 0; t < nt; ++t) out[(size_t)t * nq + i] = j >= 0 ? values[(size_t)t * nfrom + j] : NAN;
+}
+__global__ void k_fill_long(float* out, size_t n, float v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = v;
+}
+
+extern "C" int gpp_nearest_levels(gpp_points* from, gpp_points* to, const float* values, int nt, float* out, int mem) {
     GPP_TRY
     if(!from || !to) invalid("points is NULL");
     if(from->type != to->type) invalid("Coordinate types must be the same");
+    if(nt < 0) invalid("negative number of time levels");
     int nq = to->n;
-    if(nq == 0) return GPP_OK;
+    if(nq == 0 || nt == 0) return GPP_OK;
+    const size_t nout = (size_t)nt * nq;
     OutField o;
-    o.bind(out, nq, mem);
+    o.bind(out, nout, mem);
     if(from->n == 0) {   // nearest.cpp:132-134
-        hipLaunchKernelGGL(k_fill, dim3((nq + 255) / 256), dim3(256), 0, stream(), o.d, nq, NAN);
+        hipLaunchKernelGGL(k_fill_long, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, stream(), o.d, nout, NAN);
+        GPP_HIP(hipGetLastError());
     }
     else {
+        if(!values) invalid("values is NULL");
         InField v;
-        v.bind(values, from->n, mem);
+        v.bind(values, (size_t)nt * from->n, mem);
         to->to_device();
         DevBuf<int> idx;
         idx.get(nq);
         gpp_nearest_device(from, to->d_x.p, to->d_y.p, to->d_z.p, nq, 1, idx.p);
-        hipLaunchKernelGGL(k_gather, dim3((nq + 255) / 256), dim3(256), 0, stream(), v.d, idx.p, nq, o.d);
+        if(nt == 1) hipLaunchKernelGGL(k_gather, dim3((nq + 255) / 256), dim3(256), 0, stream(), v.d, idx.p, nq, o.d);
+        else hipLaunchKernelGGL(k_gather_levels, dim3((nq + 255) / 256), dim3(256), 0, stream(), v.d, idx.p, nq, (size_t)from->n, nt, o.d);
         GPP_HIP(hipGetLastError());
         o.finish();
         GPP_HIP(hipStreamSynchronize(stream()));   // staged buffers die with this scope
@@ -530,4 +549,8 @@ extern "C" int gpp_nearest(gpp_points* from, gpp_points* to, const float* values
     GPP_HIP(hipStreamSynchronize(stream()));
     return GPP_OK;
     GPP_CATCH
+}
+
+extern "C" int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* out, int mem) {
+    return gpp_nearest_levels(from, to, values, 1, out, mem);
 }

@@ -9,7 +9,7 @@
 //   BarnesStructure (scalar form)              :2160-2185
 //   optimal_interpolation(_full)(_ensi)        :162-294
 //   neighbourhood*, get_neighbourhood_thresholds :588-716
-//   nearest(Grid|Points, Points, vec2|vec)     :895
+//   nearest (all eight overloads)              :860-900
 //   bilinear(Grid, Grid|Points, vec2|vec3)     :902-930
 //   calc_statistic / calc_quantile             :1454-1482
 // Nested vectors are flattened once, handed to the C-ABI as host buffers (GPP_MEM_HOST) and un-flattened,
@@ -370,19 +370,63 @@ inline vec get_neighbourhood_thresholds(const vec2& input, int num_thresholds) {
 inline vec get_neighbourhood_thresholds(const vec3& input, int num_thresholds) { size_t Y, X, E; return detail::thresholds(detail::flatten(input, Y, X, E), num_thresholds); }
 
 // ---- nearest (include/gridpp.h:895; src/api/nearest.cpp:124-144) ------------------------------------------------
+namespace detail {
+// values [T][n] flattened -> [T][nq]; `sized` = the size check of the overload passed (src/api/util.cpp:427-438)
+inline vec nearest_flat(gpp_points* from, size_t nfrom, gpp_points* to, size_t nq, const vec& v, size_t T, bool sized, const char* what) {
+    if(!sized) throw std::invalid_argument(what);
+    vec out(T * nq, MV);
+    if(T * nq == 0 || nfrom == 0) return out;
+    if(v.size() != T * nfrom) throw std::invalid_argument(what);
+    check(gpp_nearest_levels(from, to, v.data(), (int)T, out.data(), GPP_MEM_HOST));
+    return out;
+}
+inline size_t cells(const Grid& g) { return (size_t)g.size()[0] * g.size()[1]; }
+inline bool fits(const Grid& g, size_t Y, size_t X) { return (int)Y == g.size()[0] && (int)X == g.size()[1]; }
+const char* const GRID_MISMATCH = "Grid size is not the same as values";
+const char* const POINTS_MISMATCH = "Points size is not the same as values";
+}   // namespace detail
+// the eight overloads of src/api/nearest.cpp:7-222
 inline vec nearest(const Grid& igrid, const Points& opoints, const vec2& ivalues) {
     size_t Y, X;
     vec v = detail::flatten(ivalues, Y, X);
-    if((int)Y != igrid.size()[0] || (int)X != igrid.size()[1]) throw std::invalid_argument("Grid size is not the same as values");
-    vec out(opoints.size(), MV);
-    if(opoints.size()) detail::check(gpp_nearest(igrid.handle(), opoints.handle(), v.data(), out.data(), GPP_MEM_HOST));
-    return out;
+    return detail::nearest_flat(igrid.handle(), detail::cells(igrid), opoints.handle(), opoints.size(), v, 1, Y == 0 || detail::fits(igrid, Y, X), detail::GRID_MISMATCH);
+}
+inline vec2 nearest(const Grid& igrid, const Points& opoints, const vec3& ivalues) {
+    size_t T, Y, X;
+    vec v = detail::flatten(ivalues, T, Y, X);
+    return detail::unflatten(detail::nearest_flat(igrid.handle(), detail::cells(igrid), opoints.handle(), opoints.size(), v, T,
+                                                  T == 0 || Y == 0 || detail::fits(igrid, Y, X), detail::GRID_MISMATCH), T, opoints.size());
+}
+inline vec2 nearest(const Grid& igrid, const Grid& ogrid, const vec2& ivalues) {
+    size_t Y, X;
+    vec v = detail::flatten(ivalues, Y, X);
+    return detail::unflatten(detail::nearest_flat(igrid.handle(), detail::cells(igrid), ogrid.handle(), detail::cells(ogrid), v, 1,
+                                                  Y == 0 || detail::fits(igrid, Y, X), detail::GRID_MISMATCH), ogrid.size()[0], ogrid.size()[1]);
+}
+inline vec3 nearest(const Grid& igrid, const Grid& ogrid, const vec3& ivalues) {
+    size_t T, Y, X;
+    vec v = detail::flatten(ivalues, T, Y, X);
+    return detail::unflatten(detail::nearest_flat(igrid.handle(), detail::cells(igrid), ogrid.handle(), detail::cells(ogrid), v, T,
+                                                  T == 0 || Y == 0 || detail::fits(igrid, Y, X), detail::GRID_MISMATCH), T, ogrid.size()[0], ogrid.size()[1]);
 }
 inline vec nearest(const Points& ipoints, const Points& opoints, const vec& ivalues) {
-    if((int)ivalues.size() != ipoints.size()) throw std::invalid_argument("Points size is not the same as values");
-    vec out(opoints.size(), MV);
-    if(opoints.size()) detail::check(gpp_nearest(ipoints.handle(), opoints.handle(), ivalues.data(), out.data(), GPP_MEM_HOST));
-    return out;
+    return detail::nearest_flat(ipoints.handle(), ipoints.size(), opoints.handle(), opoints.size(), ivalues, 1, (int)ivalues.size() == ipoints.size(), detail::POINTS_MISMATCH);
+}
+inline vec2 nearest(const Points& ipoints, const Points& opoints, const vec2& ivalues) {
+    size_t T, N;
+    vec v = detail::flatten(ivalues, T, N);
+    return detail::unflatten(detail::nearest_flat(ipoints.handle(), ipoints.size(), opoints.handle(), opoints.size(), v, T,
+                                                  T == 0 || (int)N == ipoints.size(), detail::POINTS_MISMATCH), T, opoints.size());
+}
+inline vec2 nearest(const Points& ipoints, const Grid& ogrid, const vec& ivalues) {
+    return detail::unflatten(detail::nearest_flat(ipoints.handle(), ipoints.size(), ogrid.handle(), detail::cells(ogrid), ivalues, 1,
+                                                  (int)ivalues.size() == ipoints.size(), detail::POINTS_MISMATCH), ogrid.size()[0], ogrid.size()[1]);
+}
+inline vec3 nearest(const Points& ipoints, const Grid& ogrid, const vec2& ivalues) {
+    size_t T, N;
+    vec v = detail::flatten(ivalues, T, N);
+    return detail::unflatten(detail::nearest_flat(ipoints.handle(), ipoints.size(), ogrid.handle(), detail::cells(ogrid), v, T,
+                                                  T == 0 || (int)N == ipoints.size(), detail::POINTS_MISMATCH), T, ogrid.size()[0], ogrid.size()[1]);
 }
 
 // ---- bilinear (include/gridpp.h:902-930; src/api/bilinear.cpp:26-135) -------------------------------------------

@@ -102,6 +102,9 @@ int gpp_points_nearest_neighbour(gpp_points* p, const float* qlats, const float*
  * out[i] = values[nearest index of query i]; NaN if the source set is empty.
  * values/out follow `mem`. */
 int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* out, int mem);
+/* The overloads with a leading time dimension (src/api/nearest.cpp:32-71,95-122,145-175,198-222):
+ * values [nt][size of from] -> out [nt][size of to]. */
+int gpp_nearest_levels(gpp_points* from, gpp_points* to, const float* values, int nt, float* out, int mem);
 
 /* gridpp::bilinear(Grid, Points|Grid, vec2|vec3) (src/api/bilinear.cpp:26-135; per location :322-403, weights
  * :137-320): `values` holds nt time levels of the input grid, [nt][ny][nx]; out is [nt][size of `to`].  A location

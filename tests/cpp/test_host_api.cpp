@@ -54,6 +54,23 @@ int main() {
     Points p2(vec{0, 0.1f}, vec{0, 0.1f});
     vec2 o3 = optimal_interpolation_ensi(g1, bg3, p2, vec{NAN, 0}, vec{1, 1}, vec2{{0, 0, 0}, {0, 0, 0}}, BarnesStructure(500000), 10);
     CHECK(o3[0][0] == 0 && o3[0][2] == 0);
+    // nearest with time levels and the grid / points combinations (tests/test_nearest.py:58-104)
+    {
+        vec2 la1 = {{30, 30, 30}, {40, 40, 40}, {50, 50, 50}}, lo1 = {{0, 10, 20}, {0, 10, 20}, {0, 10, 20}};
+        vec2 la2 = {{30, 30}, {50, 50}}, lo2 = {{0, 20}, {0, 20}};
+        Grid g1(la1, lo1), g2(la2, lo2);
+        vec2 v = {{0, 1, 2}, {3, 4, 5}, {6, 7, 8}};
+        vec2 n2 = nearest(g1, g2, v);
+        CHECK(n2[0][0] == 0 && n2[0][1] == 2 && n2[1][0] == 6 && n2[1][1] == 8);
+        vec3 n3 = nearest(g1, g2, vec3{v, v});
+        CHECK(n3.size() == 2 && n3[1][1][1] == 8);
+        Points ip(vec{0, 5, 10}, vec{0, 5, 10}), op(vec{-1, 6}, vec{-1, 6});
+        vec2 pp = nearest(ip, op, vec2{{0, 1, 2}, {9, 6, 1}});
+        CHECK(pp[0][0] == 0 && pp[0][1] == 1 && pp[1][0] == 9 && pp[1][1] == 6);
+        CHECK(nearest(ip, g2, vec{0, 1, 2}).size() == 2);
+        CHECK(nearest(ip, g2, vec2{{0, 1, 2}}).size() == 1);
+        CHECK(nearest(g1, op, vec3{v, v})[1].size() == 2);
+    }
     // bilinear (tests/test_bilinear.py:134-156, tests/test_grid.py:23-30)
     {
         vec2 la1 = {{0, 0}, {1, 1}}, lo1 = {{0, 1}, {0, 1}};

@@ -452,6 +452,36 @@ def pin_oi_cross_validation(g, G):
     assert abs(float(np.asarray(g.nearest(grid, points, analysis))[k]) - float(np.asarray(analysis_cv)[k])) < 1e-6
 
 
+def pin_nearest_overloads(g, G):
+    e = G["nearest_overloads"]
+    c = e["grid_to_grid"]
+    lons1, lats1 = np.meshgrid(c["in_lons"], c["in_lats"])
+    lons2, lats2 = np.meshgrid(c["out_lons"], c["out_lats"])
+    grid1, grid2 = g.Grid(lats1, lons1), g.Grid(lats2, lons2)
+    np.testing.assert_array_equal(g.nearest(grid1, grid2, np.reshape(range(9), lons1.shape)), c["expected"])
+    np.testing.assert_array_equal(g.nearest(grid1, grid2, np.reshape(range(18), (2,) + lons1.shape)), c["expected_3d"])
+    c = e["grid_to_points_3d"]
+    lons, lats = np.meshgrid(c["axis"], c["axis"])
+    out = g.nearest(g.Grid(lats, lons), g.Points(c["point_lats"], c["point_lons"]), np.reshape(range(18), (2,) + lons.shape))
+    np.testing.assert_array_equal(out, c["expected"])
+    c = e["points_to_points"]
+    ip, op = g.Points(c["in"], c["in"]), g.Points(c["out"], c["out"])
+    np.testing.assert_array_equal(g.nearest(ip, op, c["values"]), c["expected"])
+    np.testing.assert_array_equal(g.nearest(ip, op, c["values_2d"]), c["expected_2d"])
+    np.testing.assert_array_equal(g.nearest(ip, op, [c["values"]]), [c["expected"]])
+    # points -> grid (src/api/nearest.cpp:73-122)
+    out = g.nearest(ip, grid2, c["values"])
+    assert np.shape(out) == (2, 2)
+    out = g.nearest(ip, grid2, c["values_2d"])
+    assert np.shape(out) == (2, 2, 2)
+    # empty inputs / outputs (tests/test_nearest.py:114-146)
+    out = g.nearest(g.Points([], []), g.Points([0, 5, 10], [0, 5, 10]), np.zeros([0]))
+    assert np.size(out) == 3 and np.all(np.isnan(np.asarray(out)))
+    assert np.size(g.nearest(ip, g.Points([], []), np.zeros([3]))) == 0
+    out = g.nearest(g.Grid([[]], [[]]), g.Points([0, 5, 10], [0, 5, 10]), np.zeros([0, 0]))
+    assert np.size(out) == 3 and np.all(np.isnan(np.asarray(out)))
+
+
 def pin_bilinear(g, G):
     import pytest
     e = G["bilinear_simple"]

@@ -184,7 +184,15 @@ def optimal_interpolation_ensi(bg, background, points, pobs, psigmas, pbackgroun
 
 
 def nearest(grid, points, values):
-    return O.nearest(_pts(grid), _pts(points), values)
+    values = np.asarray(values, np.float32)
+    nd = 2 if isinstance(grid, Grid) else 1
+    oshape = tuple(points.size()) if isinstance(points, Grid) else (points.size(),)
+    if values.size == 0 or int(np.prod(oshape)) == 0:
+        lead = (values.shape[0],) if values.ndim == nd + 1 else ()
+        return np.full(lead + oshape, np.nan, np.float32)
+    if values.ndim == nd + 1:
+        return np.stack([O.nearest(_pts(grid), _pts(points), v).reshape(oshape) for v in values])
+    return O.nearest(_pts(grid), _pts(points), values).reshape(oshape)
 
 
 def bilinear(igrid, opoints, values):
