@@ -641,6 +641,60 @@ def nearest(igrid, opoints, values):
     return out
 
 
+# ---- count / gridding (include/gridpp.h:938-1010, src/api/count.cpp, src/api/gridding.cpp) -------------
+def _out_shape(o):
+    return tuple(o.size()) if isinstance(o, Grid) else (o.size(),)
+
+
+def count(ipoints, opoints, radius):
+    """Number of points of `ipoints` (Grid or Points) within `radius` of every location of `opoints` (count.cpp:6-66)."""
+    out = np.empty(_out_shape(opoints), np.float32)
+    if out.size:
+        check(lib().gpp_count(ipoints._h, opoints._h, float(radius), _ptr(out), _capi.MEM_HOST))
+    return out
+
+
+def _point_values(ipoints, values):
+    if _is_dev(values):
+        import torch
+        values = values.contiguous().to(torch.float32)
+        if values.dim() != 1:
+            raise RuntimeError("values must have 1 dimension")
+    else:
+        values = _vec(values, 1, "values")
+    if _shape(values)[0] != ipoints.size():
+        raise ValueError("Points size is not the same as values")
+    return values
+
+
+def gridding(grid, points, values, radius, min_num, statistic):
+    """gridding.cpp:6-63; `grid` may be a Grid or a Points (output shaped accordingly)."""
+    values = _point_values(points, values)
+    if not is_valid(radius) or radius < 0:
+        raise ValueError("radius must be >= 0")
+    if min_num < 0:
+        raise ValueError("min_num must be >= 0")
+    out = _empty_like_field(_out_shape(grid), values)
+    if int(np.prod(_out_shape(grid))):
+        mem = _mem(values)
+        _sync_if_dev(mem)
+        check(lib().gpp_gridding(grid._h, points._h, _ptr(values), float(radius), int(min_num), int(statistic), _ptr(out), mem))
+    return out
+
+
+def gridding_nearest(grid, points, values, min_num, statistic):
+    """gridding.cpp:65-131"""
+    values = _point_values(points, values)
+    if min_num < 0:
+        raise ValueError("min_num must be >= 0")
+    out = _empty_like_field(_out_shape(grid), values)
+    if int(np.prod(_out_shape(grid))) or points.size():
+        mem = _mem(values)
+        _sync_if_dev(mem)
+        check(lib().gpp_gridding_nearest(grid._h, points._h, _ptr(values), int(min_num), int(statistic), _ptr(out), mem))
+    return out
+
+
 # ---- bilinear (include/gridpp.h:902-930, src/api/bilinear.cpp:26-135) ---------------------------------
 def bilinear(igrid, opoints, values):
     """values (Y, X) -> output shaped like opoints; values (T, Y, X) -> (T,) + that shape."""

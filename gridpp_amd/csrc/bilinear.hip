@@ -186,6 +186,7 @@ void gpp_points::latlon_to_device() {
 
 extern "C" int gpp_bilinear(gpp_points* igrid, gpp_points* to, const float* values, int nt, float* out, int mem) {
     GPP_TRY
+    ensure_device();
     if(!igrid || !to) invalid("grid / points is NULL");
     if(nt < 0) invalid("negative number of time levels");
     const int nq = to->n;
@@ -232,6 +233,7 @@ extern "C" int gpp_bilinear(gpp_points* igrid, gpp_points* to, const float* valu
 
 extern "C" int gpp_grid_get_box(gpp_points* grid, const float* qlats, const float* qlons, int nq, int* inside, int* boxes) {
     GPP_TRY
+    ensure_device();
     if(!grid) invalid("grid is NULL");
     if(nq < 0) invalid("nq < 0");
     if(nq == 0) return GPP_OK;
@@ -261,8 +263,8 @@ extern "C" int gpp_grid_get_box(gpp_points* grid, const float* qlats, const floa
 
 extern "C" int gpp_point_in_rectangle(const float corners_latlon[8], float lat, float lon, int* inside) {
     GPP_TRY
-    if(!corners_latlon || !inside) invalid("NULL argument");
     ensure_device();
+    if(!corners_latlon || !inside) invalid("NULL argument");
     float h[10];
     memcpy(h, corners_latlon, 8 * sizeof(float));
     h[8] = lat; h[9] = lon;

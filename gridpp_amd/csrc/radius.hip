@@ -1,0 +1,423 @@
+// Radius-query consumers on the device: count (src/api/count.cpp:6-66), gridding / gridding_nearest
+// (src/api/gridding.cpp:6-131) and the batched form of KDTree::get_neighbours(_with_distance) / get_num_neighbours
+// (src/api/kdtree.cpp:39-64,241-260).
+//
+// All of them walk the point set's bin index (gpp_obs_index, the same one the OI kernels and the nearest-neighbour search
+// use): one thread per output location visits the bins that overlap the axis-aligned box +-radius in the two indexed
+// axes and applies the reference's test to every point in them -- strictly inside the box, then chord length <= radius
+// in float32.  Variable-length results go through a CSR layout: a counting pass, a device-wide exclusive scan (hipCUB),
+// a filling pass.  Statistics of a location's values are the sequential float loops of util.cpp:19-178 (row_stats.h).
+#include "common.h"
+#include "oi_common.h"
+#include "row_stats.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+
+using namespace gpp;
+
+namespace {
+
+struct IxView {
+    const float4* sgeo;
+    const float2* smeta;
+    const int* bin_start;
+    int axis_a, axis_b, nbx, nby;
+    float amin, bmin, inv_s;
+};
+IxView view_of(gpp_obs_index* ix) {
+    return IxView{ix->d_sgeo.p, ix->d_smeta.p, ix->d_bin_start.p, ix->axis_a, ix->axis_b, ix->nbx, ix->nby, ix->amin, ix->bmin, ix->inv_s};
+}
+
+__device__ __forceinline__ int bin_of(float v, float lo, float inv_s, int nb) {
+    const float f = floorf((v - lo) * inv_s);
+    return (int)fminf(fmaxf(f, 0.0f), (float)(nb - 1));
+}
+
+// f(sorted position, original index, distance) for every point the reference's get_neighbours would return
+template <class F>
+__device__ __forceinline__ void visit_radius(const IxView& ix, float x, float y, float z, float radius, bool include_match, F f) {
+    if(!(radius > 0)) return;   // an empty or NaN box holds nothing strictly inside
+    const float lox = x - radius, hix = x + radius, loy = y - radius, hiy = y + radius, loz = z - radius, hiz = z + radius;
+    const float alo = ix.axis_a == 0 ? lox : (ix.axis_a == 1 ? loy : loz), ahi = ix.axis_a == 0 ? hix : (ix.axis_a == 1 ? hiy : hiz);
+    const float blo = ix.axis_b == 1 ? loy : (ix.axis_b == 2 ? loz : lox), bhi = ix.axis_b == 1 ? hiy : (ix.axis_b == 2 ? hiz : hix);
+    const int bx0 = bin_of(alo, ix.amin, ix.inv_s, ix.nbx), bx1 = bin_of(ahi, ix.amin, ix.inv_s, ix.nbx);
+    const int by0 = bin_of(blo, ix.bmin, ix.inv_s, ix.nby), by1 = bin_of(bhi, ix.bmin, ix.inv_s, ix.nby);
+    for(int row = by0; row <= by1; ++row) {
+        const int js = ix.bin_start[row * ix.nbx + bx0], je = ix.bin_start[row * ix.nbx + bx1 + 1];
+        for(int j = js; j < je; ++j) {
+            const float4 g = ix.sgeo[j];
+            if(!(g.x > lox && g.x < hix && g.y > loy && g.y < hiy && g.z > loz && g.z < hiz)) continue;   // kdtree.cpp:46,53
+            const float dx = g.x - x, dy = g.y - y, dz = g.z - z;
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);                                          // kdtree.cpp:189-194
+            if(!(include_match ? d <= radius : (d <= radius && d > 0))) continue;                        // kdtree.cpp:247-260
+            f(j, __float_as_int(ix.smeta[j].y), d);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_radius_count(IxView ix, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                      const float* __restrict__ qz, int nq, float radius, int include_match,
+                                                      int* __restrict__ cnt, float* __restrict__ cnt_f) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if(q >= nq) return;
+    int c = 0;
+    visit_radius(ix, qx[q], qy[q], qz[q], radius, include_match != 0, [&](int, int, float) { ++c; });
+    if(cnt) cnt[q] = c;
+    if(cnt_f) cnt_f[q] = (float)c;
+}
+
+// CSR fill: idx / dist / val (each optional) at [offset[q], offset[q] + count)
+__global__ __launch_bounds__(256) void k_radius_fill(IxView ix, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                     const float* __restrict__ qz, int q0, int nq, float radius, int include_match,
+                                                     const long long* __restrict__ offset, long long base, int* __restrict__ idx,
+                                                     float* __restrict__ dist, const float* __restrict__ values, float* __restrict__ val) {
+    const int q = q0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if(q >= q0 + nq) return;
+    long long w = offset[q] - base;
+    visit_radius(ix, qx[q], qy[q], qz[q], radius, include_match != 0, [&](int, int orig, float d) {
+        if(idx) idx[w] = orig;
+        if(dist) dist[w] = d;
+        if(val) val[w] = values[orig];
+        ++w;
+    });
+}
+
+__device__ __forceinline__ float segment_statistic(const float* row, int n, int statistic) {
+    if(statistic == GPP_MEDIAN) return row_quantile(row, n, 0.5f);   // util.cpp:96-105 (calc_quantile 0 / 0.5 / 1)
+    return row_statistic(row, n, statistic);
+}
+
+// gridding.cpp:23-31 / :52-59 (require_some = false) and :92-97 / :122-126 (require_some = true)
+__global__ __launch_bounds__(256) void k_segment_statistic(const float* __restrict__ val, const long long* __restrict__ offset, long long base,
+                                                           const int* __restrict__ cnt, int q0, int nq, int min_num, int statistic,
+                                                           int require_some, float* __restrict__ out) {
+    const int q = q0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if(q >= q0 + nq) return;
+    const int c = cnt[q];
+    float r = NAN;
+    if((!require_some || c > 0) && (min_num <= 0 || c >= min_num)) r = segment_statistic(val + (offset[q] - base), c, statistic);
+    out[q] = r;
+}
+
+__global__ void k_widen(const int* __restrict__ in, int n, long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = in[i];
+}
+__global__ void k_iota(int* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = i;
+}
+__global__ void k_histogram(const int* __restrict__ target, int n, int* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n && target[i] >= 0) atomicAdd(&cnt[target[i]], 1);
+}
+__global__ void k_gather_sorted(const float* __restrict__ values, const int* __restrict__ order, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = values[order[i]];
+}
+__global__ void k_fill_value(float* out, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = v;
+}
+
+const long long CSR_CAP = 1ll << 28;   // entries per filling pass (1 GiB of float values)
+
+// exclusive scan of the per-location counts into 64-bit offsets [nq + 1]; returns the total
+long long scan_counts(const int* cnt, int nq, DevBuf<long long>& wide, DevBuf<long long>& offset) {
+    wide.get((size_t)nq + 1);
+    offset.get((size_t)nq + 1);
+    GPP_HIP(hipMemsetAsync(wide.p + nq, 0, sizeof(long long), stream()));
+    hipLaunchKernelGGL(k_widen, dim3((nq + 255) / 256), dim3(256), 0, stream(), cnt, nq, wide.p);
+    size_t sb = 0;
+    GPP_HIP(hipcub::DeviceScan::ExclusiveSum((void*)nullptr, sb, wide.p, offset.p, nq + 1, stream()));
+    DevBuf<char> tmp;
+    tmp.get(sb);
+    GPP_HIP(hipcub::DeviceScan::ExclusiveSum((void*)tmp.p, sb, wide.p, offset.p, nq + 1, stream()));
+    long long total = 0;
+    GPP_HIP(hipMemcpyAsync(&total, offset.p + nq, sizeof(long long), hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return total;
+}
+
+// Query chunks [q0, q1) whose CSR segments fit CSR_CAP entries (the offsets come to the host only when one pass is not enough)
+std::vector<std::pair<int, int>> chunks_of(const DevBuf<long long>& offset, int nq, long long total) {
+    std::vector<std::pair<int, int>> ch;
+    if(total <= CSR_CAP) { ch.emplace_back(0, nq); return ch; }
+    std::vector<long long> h((size_t)nq + 1);
+    GPP_HIP(hipMemcpy(h.data(), offset.p, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+    int q0 = 0;
+    while(q0 < nq) {
+        int q1 = (int)(std::upper_bound(h.begin() + q0, h.end(), h[q0] + CSR_CAP) - h.begin()) - 1;
+        if(q1 <= q0) q1 = q0 + 1;   // a single location with more than CSR_CAP neighbours still gets its own pass
+        ch.emplace_back(q0, q1);
+        q0 = q1;
+    }
+    return ch;
+}
+
+void check_same_type(gpp_points* a, gpp_points* b) {
+    if(!a || !b) invalid("points is NULL");
+}
+
+}   // namespace
+
+// count(input set, output locations, radius): out[i] = number of input points within radius of location i
+extern "C" int gpp_count(gpp_points* from, gpp_points* to, float radius, float* out, int mem) {
+    GPP_TRY
+    ensure_device();
+    check_same_type(from, to);
+    const int nq = to->n;
+    if(nq == 0) return GPP_OK;
+    OutField o;
+    o.bind(out, nq, mem);
+    if(from->n == 0) hipLaunchKernelGGL(k_fill_value, dim3((nq + 255) / 256), dim3(256), 0, stream(), o.d, (size_t)nq, 0.0f);
+    else {
+        to->to_device();
+        gpp_obs_index* ix = gpp_build_obs_index(from);
+        hipLaunchKernelGGL(k_radius_count, dim3((nq + 255) / 256), dim3(256), 0, stream(), view_of(ix), to->d_x.p, to->d_y.p, to->d_z.p, nq,
+                           radius, 1, (int*)nullptr, o.d);
+    }
+    GPP_HIP(hipGetLastError());
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+extern "C" int gpp_gridding(gpp_points* to, gpp_points* from, const float* values, float radius, int min_num, int statistic,
+                            float* out, int mem) {
+    GPP_TRY
+    ensure_device();
+    check_same_type(from, to);
+    if(!is_valid(radius) || radius < 0) invalid("radius must be >= 0");   // gridding.cpp:9-12
+    if(min_num < 0) invalid("min_num must be >= 0");
+    const int nq = to->n;
+    if(nq == 0) return GPP_OK;
+    OutField o;
+    o.bind(out, nq, mem);
+    DevBuf<int> cnt;
+    cnt.get(nq);
+    DevBuf<long long> wide, offset;
+    DevBuf<float> val;
+    if(from->n == 0) {   // every neighbour list is empty: calc_statistic of nothing (0 for Count, NaN otherwise), NaN if min_num > 0
+        const float v = (min_num <= 0 && statistic == GPP_COUNT) ? 0.0f : NAN;
+        hipLaunchKernelGGL(k_fill_value, dim3((nq + 255) / 256), dim3(256), 0, stream(), o.d, (size_t)nq, v);
+        GPP_HIP(hipGetLastError());
+    }
+    else {
+        if(!values) invalid("values is NULL");
+        InField v;
+        v.bind(values, from->n, mem);
+        to->to_device();
+        gpp_obs_index* ix = gpp_build_obs_index(from);
+        const IxView iv = view_of(ix);
+        hipLaunchKernelGGL(k_radius_count, dim3((nq + 255) / 256), dim3(256), 0, stream(), iv, to->d_x.p, to->d_y.p, to->d_z.p, nq, radius, 1,
+                           cnt.p, (float*)nullptr);
+        GPP_HIP(hipGetLastError());
+        const long long total = scan_counts(cnt.p, nq, wide, offset);
+        for(auto ch : chunks_of(offset, nq, total)) {
+            const int q0 = ch.first, n = ch.second - ch.first;
+            long long base = 0, end = 0;
+            if(total > CSR_CAP) {
+                GPP_HIP(hipMemcpy(&base, offset.p + q0, sizeof(long long), hipMemcpyDeviceToHost));
+                GPP_HIP(hipMemcpy(&end, offset.p + ch.second, sizeof(long long), hipMemcpyDeviceToHost));
+            }
+            else end = total;
+            val.get((size_t)std::max<long long>(end - base, 1));
+            hipLaunchKernelGGL(k_radius_fill, dim3((n + 255) / 256), dim3(256), 0, stream(), iv, to->d_x.p, to->d_y.p, to->d_z.p, q0, n, radius, 1,
+                               offset.p, base, (int*)nullptr, (float*)nullptr, v.d, val.p);
+            hipLaunchKernelGGL(k_segment_statistic, dim3((n + 255) / 256), dim3(256), 0, stream(), val.p, offset.p, base, cnt.p, q0, n, min_num,
+                               statistic, 0, o.d);
+            GPP_HIP(hipGetLastError());
+        }
+        o.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));
+        return GPP_OK;
+    }
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+extern "C" int gpp_gridding_nearest(gpp_points* to, gpp_points* from, const float* values, int min_num, int statistic, float* out, int mem) {
+    GPP_TRY
+    ensure_device();
+    check_same_type(from, to);
+    if(min_num < 0) invalid("min_num must be >= 0");   // gridding.cpp:68-69
+    const int no = to->n, S = from->n;
+    if(no == 0) {
+        if(S > 0) runtime("gridding_nearest: no output location to assign the points to");   // the reference indexes an empty vector here
+        return GPP_OK;
+    }
+    OutField o;
+    o.bind(out, no, mem);
+    if(S == 0) {
+        hipLaunchKernelGGL(k_fill_value, dim3((no + 255) / 256), dim3(256), 0, stream(), o.d, (size_t)no, NAN);
+        GPP_HIP(hipGetLastError());
+        o.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));
+        return GPP_OK;
+    }
+    if(!values) invalid("values is NULL");
+    InField v;
+    v.bind(values, S, mem);
+    from->to_device();
+    DevBuf<int> target, starget, order, iota, cnt;
+    target.get(S); starget.get(S); order.get(S); iota.get(S); cnt.get(no);
+    gpp_nearest_device(to, from->d_x.p, from->d_y.p, from->d_z.p, S, 1, target.p);   // gridding.cpp:85-90
+    hipLaunchKernelGGL(k_iota, dim3((S + 255) / 256), dim3(256), 0, stream(), iota.p, S);
+    // stable sort by target keeps the input order inside every location (the reference push_backs in input order)
+    int bits = 1;
+    while((1ll << bits) < no) bits++;
+    size_t sb = 0;
+    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)nullptr, sb, target.p, starget.p, iota.p, order.p, S, 0, bits, stream()));
+    DevBuf<char> tmp;
+    tmp.get(sb);
+    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)tmp.p, sb, target.p, starget.p, iota.p, order.p, S, 0, bits, stream()));
+    GPP_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int) * no, stream()));
+    hipLaunchKernelGGL(k_histogram, dim3((S + 255) / 256), dim3(256), 0, stream(), target.p, S, cnt.p);
+    DevBuf<long long> wide, offset;
+    scan_counts(cnt.p, no, wide, offset);
+    DevBuf<float> val;
+    val.get(S);
+    hipLaunchKernelGGL(k_gather_sorted, dim3((S + 255) / 256), dim3(256), 0, stream(), v.d, order.p, S, val.p);
+    hipLaunchKernelGGL(k_segment_statistic, dim3((no + 255) / 256), dim3(256), 0, stream(), val.p, offset.p, 0ll, cnt.p, 0, no, min_num, statistic,
+                       1, o.d);
+    GPP_HIP(hipGetLastError());
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+
+// Batched KDTree::get_neighbours(_with_distance): counts[nq] always; when indices / distances are given they receive the
+// CSR payload (offsets[nq + 1], capacity `cap` entries) -- a call with cap too small returns the counts only and
+// *total, so the caller can size the buffers and call again.  Indices of a location are in ascending order.
+extern "C" int gpp_points_get_neighbours_batch(gpp_points* p, const float* qlats, const float* qlons, int nq, float radius, int include_match,
+                                               int* counts, long long* offsets, int* indices, float* distances, long long cap, long long* total) {
+    GPP_TRY
+    ensure_device();
+    if(!p || !counts || !total) invalid("NULL argument");
+    if(nq < 0) invalid("nq < 0");
+    *total = 0;
+    if(nq == 0) return GPP_OK;
+    if(p->n == 0) {
+        for(int i = 0; i < nq; i++) counts[i] = 0;
+        if(offsets) for(int i = 0; i <= nq; i++) offsets[i] = 0;
+        return GPP_OK;
+    }
+    std::vector<float> qx(nq), qy(nq), qz(nq);
+    if(gpp_convert_coordinates(qlats, qlons, nq, p->type, qx.data(), qy.data(), qz.data()) != GPP_OK) return GPP_EINVAL;
+    DevBuf<float> dx, dy, dz;
+    dx.upload(qx.data(), nq); dy.upload(qy.data(), nq); dz.upload(qz.data(), nq);
+    p->to_device();
+    gpp_obs_index* ix = gpp_build_obs_index(p);
+    const IxView iv = view_of(ix);
+    DevBuf<int> cnt;
+    cnt.get(nq);
+    hipLaunchKernelGGL(k_radius_count, dim3((nq + 255) / 256), dim3(256), 0, stream(), iv, dx.p, dy.p, dz.p, nq, radius, include_match, cnt.p,
+                       (float*)nullptr);
+    GPP_HIP(hipGetLastError());
+    DevBuf<long long> wide, offset;
+    const long long tot = scan_counts(cnt.p, nq, wide, offset);
+    *total = tot;
+    GPP_HIP(hipMemcpyAsync(counts, cnt.p, sizeof(int) * nq, hipMemcpyDeviceToHost, stream()));
+    if(offsets) GPP_HIP(hipMemcpyAsync(offsets, offset.p, sizeof(long long) * ((size_t)nq + 1), hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    if((!indices && !distances) || tot == 0 || tot > cap) return GPP_OK;
+    DevBuf<int> didx;
+    DevBuf<float> ddist;
+    didx.get((size_t)tot);
+    ddist.get((size_t)tot);
+    hipLaunchKernelGGL(k_radius_fill, dim3((nq + 255) / 256), dim3(256), 0, stream(), iv, dx.p, dy.p, dz.p, 0, nq, radius, include_match, offset.p,
+                       0ll, didx.p, ddist.p, (const float*)nullptr, (float*)nullptr);
+    GPP_HIP(hipGetLastError());
+    std::vector<int> hi((size_t)tot);
+    std::vector<float> hd((size_t)tot);
+    GPP_HIP(hipMemcpyAsync(hi.data(), didx.p, sizeof(int) * (size_t)tot, hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipMemcpyAsync(hd.data(), ddist.p, sizeof(float) * (size_t)tot, hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    // present every location's list in ascending index order (the walk delivers bin order; the reference's own order is the
+    // R-tree's, which is unspecified)
+    std::vector<long long> ho((size_t)nq + 1);
+    GPP_HIP(hipMemcpy(ho.data(), offset.p, sizeof(long long) * ho.size(), hipMemcpyDeviceToHost));
+    std::vector<std::pair<int, float>> seg;
+    for(int q = 0; q < nq; q++) {
+        const long long a = ho[q], b = ho[q + 1];
+        seg.clear();
+        for(long long k = a; k < b; k++) seg.emplace_back(hi[k], hd[k]);
+        std::sort(seg.begin(), seg.end());
+        for(long long k = a; k < b; k++) {
+            if(indices) indices[k] = seg[k - a].first;
+            if(distances) distances[k] = seg[k - a].second;
+        }
+    }
+    return GPP_OK;
+    GPP_CATCH
+}
+
+// KDTree::get_neighbours / get_neighbours_with_distance (kdtree.cpp:39-60) for one location: the batch of one
+extern "C" int gpp_points_get_neighbours(gpp_points* p, float lat, float lon, float radius, int include_match,
+                                         int* indices, float* distances, int cap, int* count) {
+    GPP_TRY
+    ensure_device();
+    if(!p || !count) invalid("NULL argument");
+    long long total = 0;
+    int c = 0;
+    const int rc = gpp_points_get_neighbours_batch(p, &lat, &lon, 1, radius, include_match, &c, nullptr, indices, distances, cap, &total);
+    *count = c;
+    return rc;
+    GPP_CATCH
+}
+
+namespace {
+// float32 squared chord in the reference's operation order as a sortable key (non-negative floats order like their bits)
+__global__ void k_dist2_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, float qx, float qy,
+                             float qz, int include_match, unsigned* __restrict__ key, int* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    const float px = x[i], py = y[i], pz = z[i];
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    float s2 = dx * dx + dy * dy;
+    s2 = s2 + dz * dz;
+    const bool skip = !include_match && px == qx && py == qy && pz == qz;   // kdtree.cpp:265-270
+    key[i] = skip ? 0xffffffffu : __float_as_uint(s2);
+    idx[i] = i;
+}
+}   // namespace
+
+// KDTree::get_closest_neighbours (kdtree.cpp:82-103) for one location: the `num` nearest points by float32 squared chord
+// distance, nearest first, ties -> lower index (the R-tree's order is unspecified): keys on the device, stable radix sort.
+extern "C" int gpp_points_get_closest_neighbours(gpp_points* p, float lat, float lon, int num, int include_match, int* indices, int* count) {
+    GPP_TRY
+    if(!p || !count) invalid("NULL argument");
+    *count = 0;
+    if(num <= 0 || p->n == 0) return GPP_OK;
+    ensure_device();
+    float qx, qy, qz;
+    if(gpp_convert_coordinates(&lat, &lon, 1, p->type, &qx, &qy, &qz) != GPP_OK) return GPP_EINVAL;
+    p->to_device();
+    const int n = p->n;
+    DevBuf<unsigned> key, skey;
+    DevBuf<int> idx, sidx;
+    key.get(n); skey.get(n); idx.get(n); sidx.get(n);
+    hipLaunchKernelGGL(k_dist2_keys, dim3((n + 255) / 256), dim3(256), 0, stream(), p->d_x.p, p->d_y.p, p->d_z.p, n, qx, qy, qz, include_match, key.p, idx.p);
+    GPP_HIP(hipGetLastError());
+    size_t sb = 0;
+    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)nullptr, sb, key.p, skey.p, idx.p, sidx.p, n, 0, 32, stream()));
+    DevBuf<char> tmp;
+    tmp.get(sb);
+    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)tmp.p, sb, key.p, skey.p, idx.p, sidx.p, n, 0, 32, stream()));
+    const int k = std::min(num, n);
+    std::vector<unsigned> hk(k);
+    std::vector<int> hi(k);
+    GPP_HIP(hipMemcpyAsync(hk.data(), skey.p, sizeof(unsigned) * k, hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipMemcpyAsync(hi.data(), sidx.p, sizeof(int) * k, hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    int c = 0;
+    for(int i = 0; i < k && hk[i] != 0xffffffffu; i++) indices[c++] = hi[i];
+    *count = c;
+    return GPP_OK;
+    GPP_CATCH
+}

@@ -324,62 +324,7 @@ extern "C" int gpp_points_get(const gpp_points* p, int field, float* out) {
 // ---- radius query for a single location (host; API completeness, not the hot path) ----
 // Exact restatement of kdtree.cpp:39-60 + within_radius :247-260 on the float32 x/y/z.
 #pragma clang fp contract(off)
-static inline float chord(float x0, float y0, float z0, float x1, float y1, float z1) {
-    return sqrtf((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1) + (z0 - z1) * (z0 - z1));
-}
-extern "C" int gpp_points_get_neighbours(gpp_points* p, float lat, float lon, float radius, int include_match,
-                                         int* indices, float* distances, int cap, int* count) {
-    GPP_TRY
-    if(!p || !count) invalid("NULL argument");
-    p->ensure_host_xyz();
-    float qx, qy, qz;
-    convert_all(&lat, &lon, 1, p->type, &qx, &qy, &qz);
-    float lox = qx - radius, hix = qx + radius, loy = qy - radius, hiy = qy + radius, loz = qz - radius, hiz = qz + radius;
-    int c = 0;
-    for(int i = 0; i < p->n; i++) {
-        float px = p->x[i], py = p->y[i], pz = p->z[i];
-        if(!(px > lox && px < hix && py > loy && py < hiy && pz > loz && pz < hiz)) continue;
-        float d = chord(px, py, pz, qx, qy, qz);
-        bool in = include_match ? (d <= radius) : (d <= radius && d > 0);
-        if(!in) continue;
-        if(c < cap) {
-            if(indices) indices[c] = i;
-            if(distances) distances[c] = d;
-        }
-        c++;
-    }
-    *count = c;
-    return GPP_OK;
-    GPP_CATCH
-}
-
-// KDTree::get_closest_neighbours (kdtree.cpp:82-103) for a single location (host; API completeness): the `num` nearest
-// points by float32 squared chord distance, nearest first, ties -> lower index (the R-tree's order is unspecified).
-extern "C" int gpp_points_get_closest_neighbours(gpp_points* p, float lat, float lon, int num, int include_match, int* indices, int* count) {
-    GPP_TRY
-    if(!p || !count) invalid("NULL argument");
-    *count = 0;
-    if(num <= 0 || p->n == 0) return GPP_OK;
-    p->ensure_host_xyz();
-    float qx, qy, qz;
-    convert_all(&lat, &lon, 1, p->type, &qx, &qy, &qz);
-    std::vector<std::pair<float, int>> d;
-    d.reserve(p->n);
-    for(int i = 0; i < p->n; i++) {
-        const float px = p->x[i], py = p->y[i], pz = p->z[i];
-        if(!include_match && px == qx && py == qy && pz == qz) continue;   // kdtree.cpp:265-270
-        const float dx = px - qx, dy = py - qy, dz = pz - qz;
-        float s2 = dx * dx + dy * dy;
-        s2 = s2 + dz * dz;
-        d.emplace_back(s2, i);
-    }
-    const int k = std::min<int>(num, (int)d.size());
-    std::partial_sort(d.begin(), d.begin() + k, d.end());
-    for(int i = 0; i < k; i++) indices[i] = d[i].second;
-    *count = k;
-    return GPP_OK;
-    GPP_CATCH
-}
+// (KDTree::get_neighbours / get_closest_neighbours for single locations: radius.hip)
 
 // ---- nearest neighbour (device, brute force over the point set; one wave per query) ----
 // Metric = float32 squared chord distance in the reference's operation order (Boost

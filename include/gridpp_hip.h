@@ -89,8 +89,8 @@ int gpp_convert_coordinates(const float* lats, const float* lons, int n, int coo
  * (lat, lon).  Writes at most `cap` indices; *count is the full count. */
 int gpp_points_get_neighbours(gpp_points* p, float lat, float lon, float radius, int include_match,
                               int* indices, float* distances /* may be NULL */, int cap, int* count);
-/* KDTree::get_closest_neighbours (src/api/kdtree.cpp:82-103): the `num` nearest points, nearest first;
- * indices must hold `num` ints, *count is the number found. */
+/* KDTree::get_closest_neighbours (src/api/kdtree.cpp:82-103): the `num` nearest points, nearest first (ties: lower
+ * index); indices must hold `num` ints, *count is the number found. */
 int gpp_points_get_closest_neighbours(gpp_points* p, float lat, float lon, int num, int include_match,
                                       int* indices, int* count);
 /* KDTree::get_nearest_neighbour / Points::get_nearest_neighbour
@@ -105,6 +105,25 @@ int gpp_nearest(gpp_points* from, gpp_points* to, const float* values, float* ou
 /* The overloads with a leading time dimension (src/api/nearest.cpp:32-71,95-122,145-175,198-222):
  * values [nt][size of from] -> out [nt][size of to]. */
 int gpp_nearest_levels(gpp_points* from, gpp_points* to, const float* values, int nt, float* out, int mem);
+
+/* Batched KDTree::get_neighbours / get_neighbours_with_distance / get_num_neighbours (src/api/kdtree.cpp:39-64) for nq
+ * lookups (host arrays): counts[nq] always; offsets[nq+1] if given; indices / distances (CSR, ascending index inside a
+ * location) if given and *total <= cap -- otherwise only the counts and *total are produced, so that the caller can size
+ * the buffers and call again. */
+int gpp_points_get_neighbours_batch(gpp_points* p, const float* qlats, const float* qlons, int nq, float radius,
+                                    int include_match, int* counts, long long* offsets, int* indices, float* distances,
+                                    long long cap, long long* total);
+/* gridpp::count (src/api/count.cpp:6-66, all four overloads): out[i] = number of points of `from` within `radius` of
+ * location i of `to`.  out follows `mem`. */
+int gpp_count(gpp_points* from, gpp_points* to, float radius, float* out, int mem);
+/* gridpp::gridding (src/api/gridding.cpp:6-63): statistic of the values of the points of `from` within `radius` of every
+ * location of `to`; NaN where fewer than min_num (> 0) points are found.  GPP_EINVAL for radius < 0 / NaN, min_num < 0.
+ * values / out follow `mem`. */
+int gpp_gridding(gpp_points* to, gpp_points* from, const float* values, float radius, int min_num, int statistic,
+                 float* out, int mem);
+/* gridpp::gridding_nearest (src/api/gridding.cpp:65-131): every point of `from` is assigned to its nearest location of
+ * `to`; statistic of what each location received (in input order), NaN for none / fewer than min_num. */
+int gpp_gridding_nearest(gpp_points* to, gpp_points* from, const float* values, int min_num, int statistic, float* out, int mem);
 
 /* gridpp::bilinear(Grid, Points|Grid, vec2|vec3) (src/api/bilinear.cpp:26-135; per location :322-403, weights
  * :137-320): `values` holds nt time levels of the input grid, [nt][ny][nx]; out is [nt][size of `to`].  A location

@@ -880,6 +880,53 @@ int orc_nearest(const float* gx, const float* gy, const float* gz, int nG, const
 }
 
 /* ------------------------------------------------------------------------ */
+/* count / gridding / gridding_nearest: src/api/count.cpp:6-66,              */
+/* src/api/gridding.cpp:6-131                                               */
+/* ------------------------------------------------------------------------ */
+/* count: number of points of the input set within `radius` of every output location (get_num_neighbours with
+ * include_match = true, src/api/kdtree.cpp:61-64) */
+int orc_count(const float* px, const float* py, const float* pz, int n, const float* qx, const float* qy, const float* qz,
+              int nq, float radius, float* out) {
+    for(int i = 0; i < nq; i++) {
+        int c = 0;
+        for(int j = 0; j < n; j++) c += orc_in_radius(qx[i], qy[i], qz[i], px[j], py[j], pz[j], radius, 1);
+        out[i] = c;
+    }
+    return ORC_OK;
+}
+/* gridding.cpp:6-63: statistic of the values of the input points within `radius` of every output location, MV when
+ * fewer than min_num (if min_num > 0).  Neighbours are taken in index order (the R-tree's order is unspecified). */
+int orc_gridding(const float* px, const float* py, const float* pz, const float* values, int n, const float* qx,
+                 const float* qy, const float* qz, int nq, float radius, int min_num, int statistic, float* out) {
+    if(!orc_valid(radius) || radius < 0 || min_num < 0) return ORC_EINVAL;
+    float* curr = (float*)malloc(sizeof(float) * (n > 0 ? n : 1));
+    for(int i = 0; i < nq; i++) {
+        int c = 0;
+        for(int j = 0; j < n; j++)
+            if(orc_in_radius(qx[i], qy[i], qz[i], px[j], py[j], pz[j], radius, 1)) curr[c++] = values[j];
+        out[i] = (min_num <= 0 || c >= min_num) ? orc_calc_statistic(curr, c, statistic) : NAN;
+    }
+    free(curr);
+    return ORC_OK;
+}
+/* gridding.cpp:65-131: every input point goes to its nearest output location; statistic of what each location received
+ * (in input order), MV for locations that received nothing or fewer than min_num. */
+int orc_gridding_nearest(const float* ox, const float* oy, const float* oz, int no, const float* px, const float* py,
+                         const float* pz, const float* values, int n, int min_num, int statistic, float* out) {
+    if(min_num < 0) return ORC_EINVAL;
+    int* target = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    float* curr = (float*)malloc(sizeof(float) * (n > 0 ? n : 1));
+    for(int s = 0; s < n; s++) target[s] = orc_nearest_neighbour(ox, oy, oz, no, px[s], py[s], pz[s], 1);
+    for(int i = 0; i < no; i++) {
+        int c = 0;
+        for(int s = 0; s < n; s++) if(target[s] == i) curr[c++] = values[s];
+        out[i] = (c > 0 && (min_num <= 0 || c >= min_num)) ? orc_calc_statistic(curr, c, statistic) : NAN;
+    }
+    free(target); free(curr);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* bilinear(Grid, Points|Grid, vec2|vec3): src/api/bilinear.cpp:26-135        */
 /* ------------------------------------------------------------------------ */
 /* src/api/util.cpp:561-582: signed line tests of m against the edges AB, AD, BC, CD (float arithmetic); a point is

@@ -258,6 +258,38 @@ def nearest(g, q, values):
     return out
 
 
+def count(p, q, radius):
+    """count(input set p, output locations q, radius) (src/api/count.cpp)"""
+    out = np.empty(q.n, np.float32)
+    lib().orc_count(p.x.ctypes, p.y.ctypes, p.z.ctypes, C.c_int(p.n), q.x.ctypes, q.y.ctypes, q.z.ctypes, C.c_int(q.n),
+                    C.c_float(radius), out.ctypes)
+    return out
+
+
+def gridding(q, p, values, radius, min_num, statistic):
+    """gridding(output locations q, input points p, values, ...) (src/api/gridding.cpp:6-63)"""
+    values = _f(values).ravel()
+    if values.size != p.n:
+        raise OracleError("Points size is not the same as values")
+    out = np.empty(q.n, np.float32)
+    v = values if values.size else np.zeros(1, np.float32)
+    _check(lib().orc_gridding(p.x.ctypes, p.y.ctypes, p.z.ctypes, v.ctypes, C.c_int(p.n), q.x.ctypes, q.y.ctypes, q.z.ctypes,
+                              C.c_int(q.n), C.c_float(radius), C.c_int(min_num), C.c_int(statistic), out.ctypes))
+    return out
+
+
+def gridding_nearest(q, p, values, min_num, statistic):
+    """gridding_nearest(output locations q, input points p, values, ...) (src/api/gridding.cpp:65-131)"""
+    values = _f(values).ravel()
+    if values.size != p.n:
+        raise OracleError("Points size is not the same as values")
+    out = np.empty(q.n, np.float32)
+    v = values if values.size else np.zeros(1, np.float32)
+    _check(lib().orc_gridding_nearest(q.x.ctypes, q.y.ctypes, q.z.ctypes, C.c_int(q.n), p.x.ctypes, p.y.ctypes, p.z.ctypes,
+                                      v.ctypes, C.c_int(p.n), C.c_int(min_num), C.c_int(statistic), out.ctypes))
+    return out
+
+
 class OracleDistorted(RuntimeError):
     """bilinear: s / t outside [0, 1] (the reference throws std::runtime_error, src/api/bilinear.cpp:309-313)"""
 

@@ -482,6 +482,80 @@ def pin_nearest_overloads(g, G):
     assert np.size(out) == 3 and np.all(np.isnan(np.asarray(out)))
 
 
+def _nan(rows):
+    return np.array([[np.nan if v is None else v for v in r] for r in rows], np.float32)
+
+
+def pin_gridding(g, G):
+    import pytest
+    e = G["gridding"]
+    y, x = np.meshgrid(e["grid_y_axis"], e["grid_x_axis"])
+    grid = g.Grid(y, x, 0 * y, 0 * y, g.Cartesian)
+    grid_as_points = grid.to_points()
+    pts = g.Points(e["points"], e["points"], [0, 0, 0], [0, 0, 0], g.Cartesian)
+    values, radius = e["values"], e["radius"]
+    for target in (grid, grid_as_points):
+        shape = tuple(target.size()) if isinstance(target.size(), (list, tuple)) else (target.size(),)
+        for min_num, expected in e["min_num"].items():
+            out = np.asarray(g.gridding(target, pts, values, radius, int(min_num), g.Sum))
+            assert out.shape == shape
+            np.testing.assert_array_almost_equal(out.ravel(), _nan(expected).ravel())
+        for name, expected in e["statistic"].items():
+            out = np.asarray(g.gridding(target, pts, values, radius, 0, getattr(g, name)))
+            np.testing.assert_array_almost_equal(out.ravel(), _nan(expected).ravel())
+        for r, expected in e["radius_cases"].items():
+            out = np.asarray(g.gridding(target, pts, values, float(r), 0, g.Sum))
+            np.testing.assert_array_almost_equal(out.ravel(), _nan(expected).ravel())
+        with pytest.raises(ValueError):
+            g.gridding(target, pts, [0], radius, 0, g.Sum)
+        for bad in (-1, np.nan):
+            with pytest.raises(ValueError):
+                g.gridding(target, pts, values, bad, 0, g.Sum)
+        with pytest.raises(ValueError):
+            g.gridding(target, pts, values, radius, -1, g.Sum)
+        # empty input points: NaN, Count 0 (tests/test_gridding.py:79-94)
+        empty = g.Points([], [], [], [], g.Cartesian)
+        for stat in (g.Sum, g.Mean):
+            out = np.asarray(g.gridding(target, empty, [], radius, 0, stat))
+            assert out.shape == shape and np.all(np.isnan(out))
+        np.testing.assert_array_equal(np.asarray(g.gridding(target, empty, [], radius, 0, g.Count)).ravel(), np.zeros(6))
+    # empty outputs (tests/test_gridding.py:96-106)
+    for stat in (g.Sum, g.Mean, g.Count):
+        assert np.size(g.gridding(g.Grid([[]], [[]], [[]], [[]], g.Cartesian), pts, values, radius, 0, stat)) == 0
+        assert np.size(g.gridding(g.Points([], [], [], [], g.Cartesian), pts, values, radius, 0, stat)) == 0
+
+
+def pin_count(g, G):
+    e = G["count"]
+    for name, factor in e["factor"].items():
+        ct = getattr(g, name)
+        lons, lats = np.meshgrid(e["grid_lons"], e["grid_lats"])
+        grid = g.Grid(lats * factor, lons * factor, lons * 0, lons * 0, ct)
+        plats, plons = np.array(e["point_lats"]) * factor, np.array(e["point_lons"]) * factor
+        points = g.Points(plats, plons, plons * 0, plons * 0, ct)
+        radius = e["radius"]
+        single_grid = g.Grid([[0]], [[0]], [[0]], [[0]], ct)
+        single_point = g.Points([0], [0], [0], [0], ct)
+        empty_grid = g.Grid([[]], [[]], [[]], [[]], ct)
+        empty_points = g.Points([], [], [], [], ct)
+        np.testing.assert_array_equal(g.count(points, grid, radius), e["point_to_grid"])
+        assert np.size(g.count(points, empty_grid, radius)) == 0
+        np.testing.assert_array_equal(g.count(empty_points, grid, radius), np.zeros((3, 2)))
+        np.testing.assert_array_equal(g.count(grid, grid, radius), e["grid_to_grid"])
+        np.testing.assert_array_equal(g.count(grid, single_grid, radius), e["grid_to_single_grid"])
+        np.testing.assert_array_equal(g.count(single_grid, grid, radius), e["single_grid_to_grid"])
+        np.testing.assert_array_equal(g.count(empty_grid, grid, radius), np.zeros((3, 2)))
+        assert np.size(g.count(grid, empty_grid, radius)) == 0
+        np.testing.assert_array_equal(g.count(grid, points, radius), e["grid_to_point"])
+        np.testing.assert_array_equal(g.count(single_grid, points, radius), e["single_grid_to_point"])
+        np.testing.assert_array_equal(g.count(grid, single_point, radius), e["grid_to_single_point"])
+        np.testing.assert_array_equal(g.count(empty_grid, points, radius), [0, 0, 0])
+        assert np.size(g.count(grid, empty_points, radius)) == 0
+        np.testing.assert_array_equal(g.count(points, points, radius), e["point_to_point"])
+        assert np.size(g.count(points, empty_points, radius)) == 0
+        np.testing.assert_array_equal(g.count(empty_points, points, radius), [0, 0, 0])
+
+
 def pin_bilinear(g, G):
     import pytest
     e = G["bilinear_simple"]

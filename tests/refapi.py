@@ -60,6 +60,9 @@ class Grid:
     def size(self):
         return list(self.shape)
 
+    def to_points(self):
+        return Points(self.p.lats, self.p.lons, self.p.elevs, self.p.lafs, self.type)
+
     def get_box(self, lat, lon):
         return O.get_box(self.p, tuple(self.shape) if self.p.n else (0, 0), lat, lon)
 
@@ -193,6 +196,36 @@ def nearest(grid, points, values):
     if values.ndim == nd + 1:
         return np.stack([O.nearest(_pts(grid), _pts(points), v).reshape(oshape) for v in values])
     return O.nearest(_pts(grid), _pts(points), values).reshape(oshape)
+
+
+def _oshape(o):
+    return tuple(o.size()) if isinstance(o, Grid) else (o.size(),)
+
+
+def count(ipoints, opoints, radius):
+    return O.count(_pts(ipoints), _pts(opoints), radius).reshape(_oshape(opoints) if _pts(opoints).n else ((0, 0) if isinstance(opoints, Grid) else (0,)))
+
+
+def gridding(ogrid, ipoints, values, radius, min_num, statistic):
+    if not np.isfinite(radius) or radius < 0:
+        raise ValueError("radius must be >= 0")
+    if min_num < 0:
+        raise ValueError("min_num must be >= 0")
+    try:
+        out = O.gridding(_pts(ogrid), _pts(ipoints), values, radius, min_num, statistic)
+    except O.OracleError as e:
+        raise ValueError(str(e))
+    return out.reshape(_oshape(ogrid) if _pts(ogrid).n else ((0, 0) if isinstance(ogrid, Grid) else (0,)))
+
+
+def gridding_nearest(ogrid, ipoints, values, min_num, statistic):
+    if min_num < 0:
+        raise ValueError("min_num must be >= 0")
+    try:
+        out = O.gridding_nearest(_pts(ogrid), _pts(ipoints), values, min_num, statistic)
+    except O.OracleError as e:
+        raise ValueError(str(e))
+    return out.reshape(_oshape(ogrid) if _pts(ogrid).n else ((0, 0) if isinstance(ogrid, Grid) else (0,)))
 
 
 def bilinear(igrid, opoints, values):

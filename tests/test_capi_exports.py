@@ -41,9 +41,6 @@ def test_host_only_entry_points_work_without_gpu(lib):
     np.testing.assert_allclose(x, [6.378137e6, 0], atol=1)
     np.testing.assert_allclose(z, [0, 6.378137e6], atol=1)
     p = gridpp.Points([0, 1000, 2000], [0, 0, 0], [0, 0, 0], [0, 0, 0], gridpp.Cartesian)
-    np.testing.assert_array_equal(p.get_neighbours(0, 0, 1001), [0, 1])
-    np.testing.assert_array_equal(p.get_closest_neighbours(900, 0, 2), [1, 0])     # tests/test_points.py style k-NN
-    np.testing.assert_array_equal(p.get_closest_neighbours(900, 0, 5), [1, 0, 2])
     np.testing.assert_array_equal(gridpp.Points().get_closest_neighbours(0, 0, 5), [])
     with pytest.raises(ValueError):
         gridpp.Points([91], [0])
@@ -58,6 +55,12 @@ def test_compute_fails_loudly_without_gpu(lib):
         pytest.skip("a GPU is visible")
     with pytest.raises(RuntimeError, match="no HIP device"):
         gridpp.neighbourhood(np.ones((4, 4)), 1, gridpp.Mean)
+    p3 = gridpp.Points([0, 1000, 2000], [0, 0, 0], [0, 0, 0], [0, 0, 0], gridpp.Cartesian)
+    for query in (lambda: p3.get_neighbours(0, 0, 1001), lambda: p3.get_closest_neighbours(900, 0, 2),
+                  lambda: gridpp.count(p3, p3, 1001), lambda: gridpp.gridding(p3, p3, [1, 2, 3], 1001, 0, gridpp.Mean),
+                  lambda: gridpp.bilinear(gridpp.Grid([[0, 0], [1, 1]], [[0, 1], [0, 1]]), gridpp.Points([0.5], [0.5]), np.zeros((2, 2)))):
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            query()
     pts = gridpp.Points([0], [0])
     with pytest.raises(RuntimeError, match="no HIP device"):
         gridpp.optimal_interpolation(pts, [0], pts, [1], [1], [0], gridpp.BarnesStructure(1000), 5)
