@@ -99,6 +99,51 @@ __global__ __launch_bounds__(256) void k_segment_statistic(const float* __restri
     out[q] = r;
 }
 
+// gridding for the statistics that stream (everything but Median): one pass, the accumulators of util.cpp:22-76 fed in
+// the walk's order -- the same order the CSR path stores, so both paths give the same bits.
+__global__ __launch_bounds__(256) void k_radius_statistic(IxView ix, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                          const float* __restrict__ qz, int nq, float radius,
+                                                          const float* __restrict__ values, int min_num, int statistic,
+                                                          float* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if(q >= nq) return;
+    int c = 0, count = 0;
+    float total = 0, total2 = 0, K = NAN, m = NAN;
+    const bool spread = statistic == GPP_STD || statistic == GPP_VARIANCE, lo = statistic == GPP_MIN, hi = statistic == GPP_MAX;
+    visit_radius(ix, qx[q], qy[q], qz[q], radius, true, [&](int, int orig, float) {
+        ++c;
+        const float v = values[orig];
+        if(!nv(v)) return;
+        if(spread) {
+            if(!nv(K)) K = v;
+            const float d = v - K;
+            total += d; total2 += d * d;
+        }
+        else if(lo || hi) {
+            if(!nv(m)) m = v;
+            else if(lo ? v < m : v > m) m = v;
+        }
+        else total += v;
+        ++count;
+    });
+    float r = NAN;
+    if(min_num <= 0 || c >= min_num) {
+        if(statistic == GPP_COUNT) r = (float)count;
+        else if(lo || hi) r = m;
+        else if(count > 0) {
+            if(spread) {
+                const float mean = total / (float)count, mean2 = total2 / (float)count;
+                float var = mean2 - mean * mean;
+                if(var < 0) var = 0;
+                r = statistic == GPP_STD ? sqrtf(var) : var;
+            }
+            else if(statistic == GPP_MEAN) r = total / (float)count;
+            else if(statistic == GPP_SUM) r = total;
+        }
+    }
+    out[q] = r;
+}
+
 __global__ void k_widen(const int* __restrict__ in, int n, long long* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) out[i] = in[i];
@@ -211,6 +256,16 @@ extern "C" int gpp_gridding(gpp_points* to, gpp_points* from, const float* value
         to->to_device();
         gpp_obs_index* ix = gpp_build_obs_index(from);
         const IxView iv = view_of(ix);
+        const bool streams = statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT || statistic == GPP_STD ||
+                             statistic == GPP_VARIANCE || statistic == GPP_MIN || statistic == GPP_MAX;
+        if(streams && !getenv("GPP_GRIDDING_CSR")) {
+            hipLaunchKernelGGL(k_radius_statistic, dim3((nq + 255) / 256), dim3(256), 0, stream(), iv, to->d_x.p, to->d_y.p, to->d_z.p, nq, radius,
+                               v.d, min_num, statistic, o.d);
+            GPP_HIP(hipGetLastError());
+            o.finish();
+            GPP_HIP(hipStreamSynchronize(stream()));
+            return GPP_OK;
+        }
         hipLaunchKernelGGL(k_radius_count, dim3((nq + 255) / 256), dim3(256), 0, stream(), iv, to->d_x.p, to->d_y.p, to->d_z.p, nq, radius, 1,
                            cnt.p, (float*)nullptr);
         GPP_HIP(hipGetLastError());

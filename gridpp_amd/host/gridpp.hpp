@@ -11,6 +11,7 @@
 //   neighbourhood*, get_neighbourhood_thresholds :588-716
 //   nearest (all eight overloads)              :860-900
 //   bilinear(Grid, Grid|Points, vec2|vec3)     :902-930
+//   count, gridding, gridding_nearest          :938-1010
 //   calc_statistic / calc_quantile             :1454-1482
 // Nested vectors are flattened once, handed to the C-ABI as host buffers (GPP_MEM_HOST) and un-flattened,
 // exactly where the reference flattens them itself (src/api/oi.cpp:69-86).  Errors: GPP_EINVAL ->
@@ -427,6 +428,51 @@ inline vec3 nearest(const Points& ipoints, const Grid& ogrid, const vec2& ivalue
     vec v = detail::flatten(ivalues, T, N);
     return detail::unflatten(detail::nearest_flat(ipoints.handle(), ipoints.size(), ogrid.handle(), detail::cells(ogrid), v, T,
                                                   T == 0 || (int)N == ipoints.size(), detail::POINTS_MISMATCH), T, ogrid.size()[0], ogrid.size()[1]);
+}
+
+// ---- count / gridding (include/gridpp.h:938-1010; src/api/count.cpp:6-66, src/api/gridding.cpp:6-131) -------------
+inline vec count(const Points& ipoints, const Points& opoints, float radius) {
+    vec out(opoints.size(), 0);
+    if(opoints.size()) detail::check(gpp_count(ipoints.handle(), opoints.handle(), radius, out.data(), GPP_MEM_HOST));
+    return out;
+}
+inline vec count(const Grid& igrid, const Points& opoints, float radius) {
+    vec out(opoints.size(), 0);
+    if(opoints.size()) detail::check(gpp_count(igrid.handle(), opoints.handle(), radius, out.data(), GPP_MEM_HOST));
+    return out;
+}
+inline vec2 count(const Points& ipoints, const Grid& ogrid, float radius) {
+    vec out(detail::cells(ogrid), 0);
+    if(out.size()) detail::check(gpp_count(ipoints.handle(), ogrid.handle(), radius, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, ogrid.size()[0], ogrid.size()[1]);
+}
+inline vec2 count(const Grid& igrid, const Grid& ogrid, float radius) {
+    vec out(detail::cells(ogrid), 0);
+    if(out.size()) detail::check(gpp_count(igrid.handle(), ogrid.handle(), radius, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, ogrid.size()[0], ogrid.size()[1]);
+}
+namespace detail {
+inline vec gridding_flat(gpp_points* to, size_t nout, const Points& points, const vec& values, float radius, int min_num, Statistic statistic, bool nearest) {
+    if((int)values.size() != points.size()) throw std::invalid_argument("Points size is not the same as values");
+    if(!nearest && (std::isnan(radius) || std::isinf(radius) || radius < 0)) throw std::invalid_argument("radius must be >= 0");
+    if(min_num < 0) throw std::invalid_argument("min_num must be >= 0");
+    vec out(nout, MV);
+    if(nearest) { if(nout || points.size()) check(gpp_gridding_nearest(to, points.handle(), values.data(), min_num, (int)statistic, out.data(), GPP_MEM_HOST)); }
+    else if(nout) check(gpp_gridding(to, points.handle(), values.data(), radius, min_num, (int)statistic, out.data(), GPP_MEM_HOST));
+    return out;
+}
+}   // namespace detail
+inline vec2 gridding(const Grid& grid, const Points& points, const vec& values, float radius, int min_num, Statistic statistic) {
+    return detail::unflatten(detail::gridding_flat(grid.handle(), detail::cells(grid), points, values, radius, min_num, statistic, false), grid.size()[0], grid.size()[1]);
+}
+inline vec gridding(const Points& opoints, const Points& ipoints, const vec& values, float radius, int min_num, Statistic statistic) {
+    return detail::gridding_flat(opoints.handle(), opoints.size(), ipoints, values, radius, min_num, statistic, false);
+}
+inline vec2 gridding_nearest(const Grid& grid, const Points& points, const vec& values, int min_num, Statistic statistic) {
+    return detail::unflatten(detail::gridding_flat(grid.handle(), detail::cells(grid), points, values, 0, min_num, statistic, true), grid.size()[0], grid.size()[1]);
+}
+inline vec gridding_nearest(const Points& opoints, const Points& ipoints, const vec& values, int min_num, Statistic statistic) {
+    return detail::gridding_flat(opoints.handle(), opoints.size(), ipoints, values, 0, min_num, statistic, true);
 }
 
 // ---- bilinear (include/gridpp.h:902-930; src/api/bilinear.cpp:26-135) -------------------------------------------

@@ -71,6 +71,23 @@ int main() {
         CHECK(nearest(ip, g2, vec2{{0, 1, 2}}).size() == 1);
         CHECK(nearest(g1, op, vec3{v, v})[1].size() == 2);
     }
+    // count / gridding (tests/test_count.py:28-40, tests/test_gridding.py:25-50)
+    {
+        vec2 gy = {{0, 1}, {0, 1}, {0, 1}}, gx = {{0, 0}, {0.5f, 0.5f}, {1, 1}}, z2 = {{0, 0}, {0, 0}, {0, 0}};
+        Grid gg(gy, gx, z2, z2, Cartesian);
+        Points gp(vec{-0.2f, 0.5f, 1}, vec{-0.2f, 0.5f, 1}, vec{0, 0, 0}, vec{0, 0, 0}, Cartesian);
+        vec2 gs = gridding(gg, gp, vec{1, 2, 3}, 0.6f, 0, Sum);
+        CHECK(gs[0][0] == 1 && std::isnan(gs[0][1]) && gs[1][0] == 2 && gs[1][1] == 5 && gs[2][1] == 3);
+        vec2 gc = gridding(gg, gp, vec{1, 2, 3}, 0.6f, 0, Count);
+        CHECK(gc[0][1] == 0 && gc[1][1] == 2);
+        vec2 cn = count(gp, gg, 0.6f);
+        CHECK(cn[1][1] == 2 && cn[0][1] == 0);
+        vec2 gn = gridding_nearest(gg, gp, vec{1, 2, 3}, 1, Sum);
+        CHECK(gn.size() == 3 && gn[0].size() == 2);
+        threw = false;
+        try { gridding(gg, gp, vec{1}, 0.6f, 0, Sum); } catch(const std::invalid_argument&) { threw = true; }
+        CHECK(threw);
+    }
     // bilinear (tests/test_bilinear.py:134-156, tests/test_grid.py:23-30)
     {
         vec2 la1 = {{0, 0}, {1, 1}}, lo1 = {{0, 1}, {0, 1}};

@@ -43,6 +43,10 @@ rows.append(("nearest 1000^2 grid -> grid", 1.52, lambda: gridpp.nearest(G1000, 
 rows.append(("bilinear 1000^2 grid -> grid", 1.68, lambda: gridpp.bilinear(G1000, G1000, I1000)))
 I50 = np.zeros((50, 1000, 1000))
 rows.append(("bilinear 1000^2 x 50 levels", 4.42, lambda: gridpp.bilinear(G1000, G1000, I50)))
+G200, P100000 = grid(200), points(100000)
+V100000 = np.zeros(100000)
+rows.append(("gridding 200^2, 100000 points, radius 5000, Mean", 0.61, lambda: gridpp.gridding(G200, P100000, V100000, 5000, 1, gridpp.Mean)))
+rows.append(("gridding_nearest 200^2, 100000 points, Mean", 0.11, lambda: gridpp.gridding_nearest(G200, P100000, V100000, 1, gridpp.Mean)))
 G100, P1000 = grid(100), points(1000)
 rows.append(("optimal_interpolation 100^2, 1000 obs, max_points 20", 0.80,
              lambda: gridpp.optimal_interpolation(G100, np.zeros((100, 100)), P1000, np.zeros(1000), np.ones(1000), np.ones(1000), structure, 20)))
