@@ -927,6 +927,184 @@ int orc_gridding_nearest(const float* ox, const float* oy, const float* oz, int 
 }
 
 /* ------------------------------------------------------------------------ */
+/* fill / fill_missing (src/api/fill.cpp:6-134), doping_square / doping_circle */
+/* (src/api/doping.cpp:5-93), neighbourhood_search                             */
+/* (src/api/neighbourhood_search.cpp:7-113), calc_gradient                     */
+/* (src/api/calc_gradient.cpp:7-126)                                           */
+/* ------------------------------------------------------------------------ */
+/* fill.cpp:6-41: grid cells within radii[i] of point i get `value` (outside = 0), or keep the input while all the
+ * others get `value` (outside = 1).  gx.. = the grid's search coordinates, px.. the points'. */
+int orc_fill(const float* gx, const float* gy, const float* gz, int nG, const float* input, const float* px,
+             const float* py, const float* pz, const float* radii, int nP, float value, int outside, float* out) {
+    for(int i = 0; i < nP; i++) if(radii[i] < 0) return ORC_EINVAL;
+    for(int c = 0; c < nG; c++) out[c] = outside ? value : input[c];
+    for(int i = 0; i < nP; i++)
+        for(int c = 0; c < nG; c++)
+            if(orc_in_radius(px[i], py[i], pz[i], gx[c], gy[c], gz[c], radii[i], 1)) out[c] = outside ? input[c] : value;
+    return ORC_OK;
+}
+/* fill.cpp:43-134: linear interpolation across runs of missing values along rows and along columns, averaged */
+int orc_fill_missing(const float* values, int Y, int X, float* out) {
+    float* ry = (float*)malloc(sizeof(float) * Y * X);
+    float* rx = (float*)malloc(sizeof(float) * Y * X);
+    for(int i = 0; i < Y * X; i++) ry[i] = rx[i] = NAN;
+    for(int y = 0; y < Y; y++) {
+        int last = 0, next = -1;
+        for(int x = 0; x < X; x++) {
+            float curr = values[y * X + x];
+            if(!orc_valid(curr)) {
+                if(next < x) for(next = x; next < X; next++) if(orc_valid(values[y * X + next])) break;
+                if(next >= X) continue;
+                float vl = values[y * X + last], vn = values[y * X + next];
+                ry[y * X + x] = (vl) + (vn - vl) * (x - last) / (next - last);
+            }
+            else { last = x; ry[y * X + x] = curr; }
+        }
+    }
+    for(int x = 0; x < X; x++) {
+        int last = 0, next = -1;
+        for(int y = 0; y < Y; y++) {
+            float curr = values[y * X + x];
+            if(!orc_valid(curr)) {
+                if(next < y) for(next = y; next < Y; next++) if(orc_valid(values[next * X + x])) break;
+                if(next >= Y) continue;
+                float vl = values[last * X + x], vn = values[next * X + x];
+                rx[y * X + x] = (vl) + (vn - vl) * (y - last) / (next - last);
+            }
+            else { last = y; rx[y * X + x] = curr; }
+        }
+    }
+    for(int i = 0; i < Y * X; i++) {
+        int count = 0; float total = 0;
+        if(orc_valid(ry[i])) { total += ry[i]; count++; }
+        if(orc_valid(rx[i])) { total += rx[i]; count++; }
+        out[i] = count > 0 ? total / count : NAN;
+    }
+    free(ry); free(rx);
+    return ORC_OK;
+}
+/* doping.cpp:5-48: a (2 hw + 1)^2 window of grid cells around the nearest grid point of every observation takes its
+ * value (later observations overwrite earlier ones); cells whose elevation differs by more than max_elev_diff are left */
+int orc_doping_square(const float* gx, const float* gy, const float* gz, const float* gelev, int Y, int X,
+                      const float* background, const float* px, const float* py, const float* pz, const float* pelev,
+                      const float* obs, const int* halfwidth, int nP, float max_elev_diff, float* out) {
+    if(orc_valid(max_elev_diff) && max_elev_diff < 0) return ORC_EINVAL;
+    for(int i = 0; i < nP; i++) if(halfwidth[i] < 0) return ORC_EINVAL;
+    for(int c = 0; c < Y * X; c++) out[c] = background[c];
+    int check = orc_valid(max_elev_diff);
+    for(int i = 0; i < nP; i++) {
+        int nn = orc_nearest_neighbour(gx, gy, gz, Y * X, px[i], py[i], pz[i], 1);
+        int iy = nn / X, ix = nn % X;
+        for(int yy = (iy - halfwidth[i] > 0 ? iy - halfwidth[i] : 0); yy <= (iy + halfwidth[i] < Y - 1 ? iy + halfwidth[i] : Y - 1); yy++)
+            for(int xx = (ix - halfwidth[i] > 0 ? ix - halfwidth[i] : 0); xx <= (ix + halfwidth[i] < X - 1 ? ix + halfwidth[i] : X - 1); xx++) {
+                if(check && fabsf(pelev[i] - gelev[yy * X + xx]) > max_elev_diff) continue;
+                out[yy * X + xx] = obs[i];
+            }
+    }
+    return ORC_OK;
+}
+/* doping.cpp:50-93: the same with a radius per observation */
+int orc_doping_circle(const float* gx, const float* gy, const float* gz, const float* gelev, int nG,
+                      const float* background, const float* px, const float* py, const float* pz, const float* pelev,
+                      const float* obs, const float* radii, int nP, float max_elev_diff, float* out) {
+    if(orc_valid(max_elev_diff) && max_elev_diff < 0) return ORC_EINVAL;
+    for(int i = 0; i < nP; i++) if(radii[i] < 0) return ORC_EINVAL;
+    for(int c = 0; c < nG; c++) out[c] = background[c];
+    int check = orc_valid(max_elev_diff);
+    for(int i = 0; i < nP; i++)
+        for(int c = 0; c < nG; c++) {
+            if(!orc_in_radius(px[i], py[i], pz[i], gx[c], gy[c], gz[c], radii[i], 1)) continue;
+            if(check && fabsf(pelev[i] - gelev[c]) > max_elev_diff) continue;
+            out[c] = obs[i];
+        }
+    return ORC_OK;
+}
+/* neighbourhood_search.cpp:7-113; apply may be NULL (no apply array) */
+int orc_neighbourhood_search(const float* array, const float* search, int nY, int nX, int halfwidth, float tmin, float tmax,
+                             float delta, const int* apply, float* out) {
+    if(tmin > tmax || halfwidth < 0) return ORC_EINVAL;
+    for(int y = 0; y < nY; y++) for(int x = 0; x < nX; x++) {
+        const int c = y * nX + x;
+        float nearest_target = NAN;
+        int ny_ = 0, nx_ = 0, counter = 0;
+        float accum = 0;
+        if(!orc_valid(search[c])) { out[c] = array[c]; continue; }
+        if(apply && apply[c] == 0) { out[c] = array[c]; continue; }
+        for(int yy = (y - halfwidth > 0 ? y - halfwidth : 0); yy <= (y + halfwidth < nY - 1 ? y + halfwidth : nY - 1); yy++)
+            for(int xx = (x - halfwidth > 0 ? x - halfwidth : 0); xx <= (x + halfwidth < nX - 1 ? x + halfwidth : nX - 1); xx++) {
+                const int n = yy * nX + xx;
+                if(!orc_valid(search[n]) || !orc_valid(array[n])) continue;
+                if(!apply || apply[c] == 1) {
+                    if(search[n] >= tmin && search[n] <= tmax) { counter++; accum = accum + array[n]; }
+                    else if(counter > 0) continue;
+                    else if(fabsf(search[n] - search[c]) >= delta) {
+                        if(!orc_valid(nearest_target)) { nearest_target = search[n]; ny_ = yy; nx_ = xx; }
+                        else {
+                            float cur = fminf(fabsf(search[n] - tmin), fabsf(search[n] - tmax));
+                            float best = fminf(fabsf(nearest_target - tmin), fabsf(nearest_target - tmax));
+                            if(cur < best) { nearest_target = search[n]; ny_ = yy; nx_ = xx; }
+                        }
+                    }
+                }
+            }
+        if(counter > 0) out[c] = accum / counter;
+        else if(orc_valid(nearest_target)) out[c] = array[ny_ * nX + nx_];
+        else out[c] = array[c];
+    }
+    return ORC_OK;
+}
+/* calc_gradient.cpp:7-126; gradient_type 0 = MinMax, 10 = LinearRegression.  (MinMax's range test is written with an
+ * unqualified abs() in the reference; it is taken as the float absolute value here.) */
+int orc_calc_gradient(const float* base, const float* values, int nY, int nX, int gradient_type, int halfwidth, int num_min,
+                      float min_range, float default_gradient, float* out) {
+    if(halfwidth <= 0 || (orc_valid(min_range) && min_range < 0) || num_min < 0 || nY == 0) return ORC_EINVAL;
+    const int n = nY * nX;
+    for(int i = 0; i < n; i++) out[i] = default_gradient;
+    if(gradient_type == 0) {
+        for(int y = 0; y < nY; y++) for(int x = 0; x < nX; x++) {
+            float cmax = NAN, cmin = NAN;
+            int imax = 0, imin = 0, count = 0;
+            for(int yy = (y - halfwidth > 0 ? y - halfwidth : 0); yy <= (y + halfwidth < nY - 1 ? y + halfwidth : nY - 1); yy++)
+                for(int xx = (x - halfwidth > 0 ? x - halfwidth : 0); xx <= (x + halfwidth < nX - 1 ? x + halfwidth : nX - 1); xx++) {
+                    float b = base[yy * nX + xx];
+                    if(!orc_valid(b) || !orc_valid(values[yy * nX + xx])) continue;
+                    if(!orc_valid(cmax) || b > cmax) { cmax = b; imax = yy * nX + xx; }
+                    if(!orc_valid(cmin) || b < cmin) { cmin = b; imin = yy * nX + xx; }
+                    count++;
+                }
+            if(count < num_min || !orc_valid(cmax) || !orc_valid(cmin) || fabsf(cmax - cmin) <= min_range) continue;
+            out[y * nX + x] = (values[imax] - values[imin]) / (cmax - cmin);
+        }
+        return ORC_OK;
+    }
+    float *b0 = (float*)malloc(sizeof(float) * n * 10), *v0 = b0 + n, *bb = b0 + 2 * n, *bv = b0 + 3 * n, *ok = b0 + 4 * n;
+    float *mX = b0 + 5 * n, *mY = b0 + 6 * n, *mXX = b0 + 7 * n, *mXY = b0 + 8 * n, *cnt = b0 + 9 * n;
+    for(int i = 0; i < n; i++) {
+        b0[i] = v0[i] = bb[i] = bv[i] = NAN; ok[i] = 0;
+        if(orc_valid(base[i]) && orc_valid(values[i])) {
+            bb[i] = (float)pow(base[i], 2); bv[i] = base[i] * values[i]; ok[i] = 1; b0[i] = base[i]; v0[i] = values[i];
+        }
+    }
+    orc_neighbourhood(b0, nY, nX, halfwidth, ST_MEAN, mX);
+    orc_neighbourhood(v0, nY, nX, halfwidth, ST_MEAN, mY);
+    orc_neighbourhood(bb, nY, nX, halfwidth, ST_MEAN, mXX);
+    orc_neighbourhood(bv, nY, nX, halfwidth, ST_MEAN, mXY);
+    orc_neighbourhood(ok, nY, nX, halfwidth, ST_SUM, cnt);
+    for(int i = 0; i < n; i++) {
+        if(cnt[i] >= num_min && orc_valid(mXX[i]) && orc_valid(mXY[i]) && orc_valid(mX[i]) && mXX[i] - mX[i] * mX[i] != 0) {
+            int valid_range = 1;
+            if(orc_valid(min_range)) {
+                float range = sqrtf(mXX[i] - mX[i] * mX[i]);
+                if(!orc_valid(range) || range < min_range) valid_range = 0;
+            }
+            if(valid_range) out[i] = (mXY[i] - mX[i] * mY[i]) / (mXX[i] - mX[i] * mX[i]);
+        }
+    }
+    free(b0);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* bilinear(Grid, Points|Grid, vec2|vec3): src/api/bilinear.cpp:26-135        */
 /* ------------------------------------------------------------------------ */
 /* src/api/util.cpp:561-582: signed line tests of m against the edges AB, AD, BC, CD (float arithmetic); a point is

@@ -290,6 +290,62 @@ def gridding_nearest(q, p, values, min_num, statistic):
     return out
 
 
+def fill(g, input, p, radii, value, outside):
+    input = _f(input)
+    radii = _f(radii).ravel()
+    out = np.empty(input.size, np.float32)
+    r = radii if radii.size else np.zeros(1, np.float32)
+    _check(lib().orc_fill(g.x.ctypes, g.y.ctypes, g.z.ctypes, C.c_int(g.n), np.ascontiguousarray(input).ctypes, p.x.ctypes, p.y.ctypes,
+                          p.z.ctypes, r.ctypes, C.c_int(p.n), C.c_float(value), C.c_int(int(bool(outside))), out.ctypes))
+    return out.reshape(input.shape)
+
+
+def fill_missing(values):
+    values = np.ascontiguousarray(_f(values))
+    out = np.empty_like(values)
+    _check(lib().orc_fill_missing(values.ctypes, C.c_int(values.shape[0]), C.c_int(values.shape[1]), out.ctypes))
+    return out
+
+
+def doping_square(g, shape, background, p, obs, halfwidth, max_elev_diff):
+    background = np.ascontiguousarray(_f(background))
+    hw = np.ascontiguousarray(np.asarray(halfwidth, np.int32).ravel())
+    obs = _f(obs).ravel()
+    out = np.empty(background.size, np.float32)
+    _check(lib().orc_doping_square(g.x.ctypes, g.y.ctypes, g.z.ctypes, g.elevs.ctypes, C.c_int(shape[0]), C.c_int(shape[1]),
+                                   background.ctypes, p.x.ctypes, p.y.ctypes, p.z.ctypes, p.elevs.ctypes, obs.ctypes, hw.ctypes,
+                                   C.c_int(p.n), C.c_float(max_elev_diff), out.ctypes))
+    return out.reshape(background.shape)
+
+
+def doping_circle(g, background, p, obs, radii, max_elev_diff):
+    background = np.ascontiguousarray(_f(background))
+    obs, radii = _f(obs).ravel(), _f(radii).ravel()
+    out = np.empty(background.size, np.float32)
+    _check(lib().orc_doping_circle(g.x.ctypes, g.y.ctypes, g.z.ctypes, g.elevs.ctypes, C.c_int(g.n), background.ctypes, p.x.ctypes,
+                                   p.y.ctypes, p.z.ctypes, p.elevs.ctypes, obs.ctypes, radii.ctypes, C.c_int(p.n),
+                                   C.c_float(max_elev_diff), out.ctypes))
+    return out.reshape(background.shape)
+
+
+def neighbourhood_search(array, search, halfwidth, tmin, tmax, delta, apply=None):
+    array, search = np.ascontiguousarray(_f(array)), np.ascontiguousarray(_f(search))
+    out = np.empty_like(array)
+    ap = None if apply is None else np.ascontiguousarray(np.asarray(apply).astype(np.int32))
+    _check(lib().orc_neighbourhood_search(array.ctypes, search.ctypes, C.c_int(array.shape[0]), C.c_int(array.shape[1]), C.c_int(halfwidth),
+                                          C.c_float(tmin), C.c_float(tmax), C.c_float(delta), None if ap is None else ap.ctypes, out.ctypes))
+    return out
+
+
+def calc_gradient(base, values, gradient_type, halfwidth, num_min, min_range, default_gradient):
+    base, values = np.ascontiguousarray(_f(base)), np.ascontiguousarray(_f(values))
+    out = np.empty_like(base)
+    _check(lib().orc_calc_gradient(base.ctypes, values.ctypes, C.c_int(base.shape[0]), C.c_int(base.shape[1] if base.ndim == 2 else 0),
+                                   C.c_int(gradient_type), C.c_int(halfwidth), C.c_int(num_min), C.c_float(min_range),
+                                   C.c_float(default_gradient), out.ctypes))
+    return out
+
+
 class OracleDistorted(RuntimeError):
     """bilinear: s / t outside [0, 1] (the reference throws std::runtime_error, src/api/bilinear.cpp:309-313)"""
 

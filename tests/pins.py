@@ -556,6 +556,86 @@ def pin_count(g, G):
         np.testing.assert_array_equal(g.count(empty_points, points, radius), [0, 0, 0])
 
 
+def pin_fill(g, G):
+    import pytest
+    e = G["fill"]
+    lons, lats = np.meshgrid(e["axis"], e["axis"])
+    grid = g.Grid(lats * e["scale"], lons * e["scale"], np.zeros([5, 5]), np.zeros([5, 5]), g.Cartesian)
+    points = g.Points(e["point_lats"], e["point_lons"], [0, 0, 0], [0, 0, 0], g.Cartesian)
+    values = np.zeros([5, 5], np.float32)
+    np.testing.assert_array_equal(g.fill(grid, values, points, e["radii"], e["value"], False), e["inside"])
+    np.testing.assert_array_equal(g.fill(grid, values, points, e["radii"], e["value"], True), e["outside"])
+    for outside in (False, True):       # tests/test_fill.py:10-31
+        with pytest.raises(Exception):
+            g.fill(grid, values, points, [-1, -1, -1], 1, outside)
+        with pytest.raises(Exception):
+            g.fill(grid, values, points, [1], 1, outside)
+        with pytest.raises(Exception):
+            g.fill(grid, np.zeros([3, 2], np.float32), points, e["radii"], 1, outside)
+    e = G["fill_missing"]
+    for c in e["cases"]:
+        n = c["shape"][0] * c["shape"][1]
+        values0 = np.reshape(np.arange(n), c["shape"]).astype(np.float32)
+        values = values0.copy()
+        for i, j in c["nan"]:
+            values[i, j] = np.nan
+        out = np.asarray(g.fill_missing(values))
+        if c["full"]:
+            np.testing.assert_array_equal(out, values0)
+        else:                            # tests/test_fill_missing.py:41-48
+            np.testing.assert_array_equal(out[0:3, :], values0[0:3, :])
+            np.testing.assert_array_equal(out[:, 0:3], values0[:, 0:3])
+            assert np.all(np.isnan(out[3:5, 3:5]))
+
+
+def pin_doping(g, G):
+    e = G["doping_square"]
+    N = e["N"]
+    x = np.linspace(0, e["extent"], N)
+    xx, yy = np.meshgrid(x, x)
+    grid = g.Grid(xx, yy, 0 * xx, 0 * xx, g.Cartesian)
+    points = g.Points(e["point_lats"], e["point_lons"], [0, 0], [0, 0], g.Cartesian)
+    out = g.doping_square(grid, np.zeros([N, N], np.float32), points, e["obs"], e["halfwidth"], e["max_elev_diff"])
+    expected = np.zeros([N, N])
+    for sq in e["squares"]:
+        expected[sq["rows"][0]:sq["rows"][1], sq["cols"][0]:sq["cols"][1]] = sq["value"]
+    np.testing.assert_array_almost_equal(out, expected)
+
+
+def pin_neighbourhood_search(g, G):
+    e = G["neighbourhood_search"]
+    nan = lambda a: np.array([[np.nan if v is None else v for v in r] for r in a], np.float32)
+    apply = lambda base, lo, hi: ((nan(base) >= lo) & (nan(base) <= hi)).astype(np.int32)
+    a = e["args"]
+    np.testing.assert_array_equal(g.neighbourhood_search(e["values"], e["base"], a[0], a[1], a[2], a[3], apply(e["base"], 0, 0.95)), e["results"])
+    np.testing.assert_array_equal(g.neighbourhood_search(e["values"], e["base"], a[0], a[1], a[2], a[3]), e["results_no_apply"])
+    np.testing.assert_array_equal(g.neighbourhood_search(e["values2"], e["base2"], a[0], a[1], a[2], a[3], apply(e["base2"], 0, 0.85)), e["values2"])
+    np.testing.assert_array_equal(g.neighbourhood_search(nan(e["values_nan"]), nan(e["base_nan"]), a[0], a[1], a[2], a[3], apply(e["base_nan"], 0, 0.95)),
+                                  e["results_nan"])
+    s_ = e["simple"]
+    np.testing.assert_array_equal(g.neighbourhood_search(s_["array"], s_["search"], *s_["args"]), s_["expected"])
+
+
+def pin_calc_gradient(g, G):
+    import pytest
+    e = G["calc_gradient"]
+    row = lambda a: np.array([[np.nan if v is None else v for v in a]], np.float32)
+    c = e["simple"]
+    out = g.calc_gradient(row(c["base"]), row(c["values"]), g.LinearRegression, c["halfwidth"], c["min_num"], c["min_range"], c["default"])
+    np.testing.assert_array_almost_equal(out, [c["expected"]])
+    c2 = e["small"]
+    np.testing.assert_array_almost_equal(g.calc_gradient(row(c2["base"]), row(c2["values"]), g.LinearRegression, c2["halfwidth"], 0, 0, -11), [c2["expected"]])
+    c3 = e["num_min"]
+    np.testing.assert_array_almost_equal(g.calc_gradient(row(c3["base"]), row(c3["values"]), g.LinearRegression, c3["halfwidth"], c3["min_num"], 0, -11),
+                                         [c3["expected"]])
+    z = np.zeros([3, 2], np.float32)      # tests/test_calc_gradient.py:40-56
+    with pytest.raises(ValueError):
+        g.calc_gradient(z, np.zeros([2, 3], np.float32), g.LinearRegression, 5, 0, 0, -11)
+    for hw, mn, mr in ((-1, 0, 0), (5, -1, 0), (5, 0, -1)):
+        with pytest.raises(ValueError):
+            g.calc_gradient(z, z, g.LinearRegression, hw, mn, mr, -11)
+
+
 def pin_bilinear(g, G):
     import pytest
     e = G["bilinear_simple"]

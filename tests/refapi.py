@@ -228,6 +228,76 @@ def gridding_nearest(ogrid, ipoints, values, min_num, statistic):
     return out.reshape(_oshape(ogrid) if _pts(ogrid).n else ((0, 0) if isinstance(ogrid, Grid) else (0,)))
 
 
+MinMax, LinearRegression = 0, 10
+
+
+def _grid_values(igrid, values, what="values"):
+    values = np.asarray(values, np.float32)
+    if values.ndim != 2 or (values.shape[0] and tuple(values.shape) != (tuple(igrid.size()) if igrid.p.n else (0, 0))):
+        raise ValueError("Grid size is not the same as " + what)
+    return values
+
+
+def fill(igrid, input, points, radii, value, outside):
+    input = _grid_values(igrid, input)
+    if np.size(radii) != points.size():
+        raise ValueError("Points size is not the same as radii size")
+    try:
+        return O.fill(_pts(igrid), input, _pts(points), radii, value, outside)
+    except O.OracleError as e:
+        raise ValueError(str(e))
+
+
+def fill_missing(values):
+    return O.fill_missing(values)
+
+
+def doping_square(igrid, background, points, observations, halfwidth, max_elev_diff=np.nan):
+    background = _grid_values(igrid, background, "observations")
+    if np.size(observations) != points.size() or np.size(halfwidth) != points.size():
+        raise ValueError("Points size mismatch")
+    try:
+        return O.doping_square(_pts(igrid), tuple(igrid.size()), background, _pts(points), observations, halfwidth, max_elev_diff)
+    except O.OracleError as e:
+        raise ValueError(str(e))
+
+
+def doping_circle(igrid, background, points, observations, radii, max_elev_diff=np.nan):
+    background = _grid_values(igrid, background, "observations")
+    if np.size(observations) != points.size() or np.size(radii) != points.size():
+        raise ValueError("Points size mismatch")
+    try:
+        return O.doping_circle(_pts(igrid), background, _pts(points), observations, radii, max_elev_diff)
+    except O.OracleError as e:
+        raise ValueError(str(e))
+
+
+def neighbourhood_search(array, search_array, halfwidth, search_target_min, search_target_max, search_delta, apply_array=None):
+    array, search_array = np.asarray(array, np.float32), np.asarray(search_array, np.float32)
+    if array.shape != search_array.shape:
+        raise ValueError("search_array must be the same size as array")
+    if apply_array is not None and np.size(apply_array) > 1 and np.shape(apply_array) != array.shape:
+        raise ValueError("apply_array must either be empty or same size as array")
+    if apply_array is not None and np.size(apply_array) == 0:
+        apply_array = None
+    try:
+        return O.neighbourhood_search(array, search_array, halfwidth, search_target_min, search_target_max, search_delta, apply_array)
+    except O.OracleError as e:
+        raise ValueError(str(e))
+
+
+def calc_gradient(base, values, gradient_type, halfwidth, num_min=2, min_range=np.nan, default_gradient=0):
+    base, values = np.asarray(base, np.float32), np.asarray(values, np.float32)
+    if base.size == 0:
+        raise ValueError("base input has no size")
+    if base.shape != values.shape:
+        raise ValueError("base is not the same size as values")
+    try:
+        return O.calc_gradient(base, values, gradient_type, halfwidth, num_min, min_range, default_gradient)
+    except O.OracleError as e:
+        raise ValueError(str(e))
+
+
 def bilinear(igrid, opoints, values):
     values = np.asarray(values, np.float32)
     ishape = tuple(igrid.size()) if igrid.p.n else (0, 0)      # src/api/grid.cpp:122-130
