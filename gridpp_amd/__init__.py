@@ -695,6 +695,121 @@ def gridding_nearest(grid, points, values, min_num, statistic):
     return out
 
 
+# ---- fill / doping / neighbourhood_search / calc_gradient -----------------------------------------------
+MinMax, LinearRegression = 0, 10   # include/gridpp.h:126-129
+
+
+def _grid_field(igrid, values, what="values"):
+    values = _vec(values, 2, what)
+    shp = _shape(values)
+    if shp[0] != 0 and tuple(shp) != tuple(igrid.size()):       # src/api/util.cpp:427-429
+        raise ValueError("Grid size is not the same as " + what)
+    return values
+
+
+def fill(igrid, input, points, radii, value, outside):
+    """src/api/fill.cpp:6-41"""
+    input = _grid_field(igrid, input)
+    radii = np.ascontiguousarray(np.asarray(radii, np.float32).ravel())
+    if radii.size != points.size():
+        raise ValueError("Points size is not the same as radii size")
+    out = _empty_like_field(_shape(input), input)
+    if int(np.prod(_shape(input))):
+        mem = _mem(input)
+        _sync_if_dev(mem)
+        check(lib().gpp_fill(igrid._h, _ptr(input), points._h, _ptr(radii), float(value), int(bool(outside)), _ptr(out), mem))
+    return out
+
+
+def fill_missing(values):
+    """src/api/fill.cpp:43-134"""
+    values = _vec(values, 2, "values")
+    out = _empty_like_field(_shape(values), values)
+    ny, nx = _shape(values)
+    if ny * nx:
+        mem = _mem(values)
+        _sync_if_dev(mem)
+        check(lib().gpp_fill_missing(_ptr(values), ny, nx, _ptr(out), mem))
+    return out
+
+
+def _doping(igrid, background, points, observations, halfwidth, radii, max_elev_diff):
+    background = _grid_field(igrid, background, "observations")
+    observations = _vec(observations, 1, "observations")
+    if _shape(observations)[0] != points.size():
+        raise ValueError("Points size is not the same as observations size")
+    per = halfwidth if halfwidth is not None else radii
+    if per.size != points.size():
+        raise ValueError("Points size is not the same as %s size" % ("halfwidth" if halfwidth is not None else "radii"))
+    out = _empty_like_field(_shape(background), background)
+    if int(np.prod(_shape(background))):
+        mem = _mem(background, observations)
+        _sync_if_dev(mem)
+        check(lib().gpp_doping(igrid._h, _ptr(background), points._h, _ptr(observations), _ptr(halfwidth), _ptr(radii), float(max_elev_diff),
+                               _ptr(out), mem))
+    return out
+
+
+def doping_square(igrid, background, points, observations, halfwidth, max_elev_diff=MV):
+    """src/api/doping.cpp:5-48"""
+    return _doping(igrid, background, points, observations, np.ascontiguousarray(np.asarray(halfwidth, np.int32).ravel()), None, max_elev_diff)
+
+
+def doping_circle(igrid, background, points, observations, radii, max_elev_diff=MV):
+    """src/api/doping.cpp:50-93"""
+    return _doping(igrid, background, points, observations, None, np.ascontiguousarray(np.asarray(radii, np.float32).ravel()), max_elev_diff)
+
+
+def neighbourhood_search(array, search_array, halfwidth, search_target_min, search_target_max, search_delta, apply_array=None):
+    """src/api/neighbourhood_search.cpp:7-113"""
+    array, search_array = _vec(array, 2, "array"), _vec(search_array, 2, "search_array")
+    if _shape(array) != _shape(search_array):
+        raise ValueError("search_array must either be the same size as array")
+    if search_target_min > search_target_max:
+        raise ValueError("Search_target_min must be smaller than search_target_max")
+    if halfwidth < 0:
+        raise ValueError("halfwidth must be positive")
+    ap = None
+    if apply_array is not None and np.size(apply_array) > 0:
+        if _is_dev(apply_array):
+            import torch
+            ap = apply_array.contiguous().to(torch.int32)
+        else:
+            ap = np.ascontiguousarray(np.asarray(apply_array).astype(np.int32))
+        if np.size(apply_array) > 1 and tuple(ap.shape) != _shape(array):
+            raise ValueError("apply_array must either be empty or same size as array")
+    out = _empty_like_field(_shape(array), array)
+    ny, nx = _shape(array)
+    if ny * nx:
+        mem = _mem(array, search_array, ap)
+        _sync_if_dev(mem)
+        check(lib().gpp_neighbourhood_search(_ptr(array), _ptr(search_array), ny, nx, int(halfwidth), float(search_target_min),
+                                             float(search_target_max), float(search_delta), _ptr(ap), _ptr(out), mem))
+    return out
+
+
+def calc_gradient(base, values, gradient_type, halfwidth, num_min=2, min_range=MV, default_gradient=0):
+    """src/api/calc_gradient.cpp:7-126"""
+    base, values = _vec(base, 2, "base"), _vec(values, 2, "values")
+    if halfwidth <= 0:
+        raise ValueError("Halwidth cannot be <= 0; must be positive integer")
+    if is_valid(min_range) and min_range < 0:
+        raise ValueError("min_range must be >= 0")
+    if num_min < 0:
+        raise ValueError("num_min must be >= 0")
+    if _shape(base)[0] == 0:
+        raise ValueError("base input has no size")
+    if _shape(base) != _shape(values):
+        raise ValueError("base is not the same size as values")
+    out = _empty_like_field(_shape(base), base)
+    ny, nx = _shape(base)
+    mem = _mem(base, values)
+    _sync_if_dev(mem)
+    check(lib().gpp_calc_gradient(_ptr(base), _ptr(values), ny, nx, int(gradient_type), int(halfwidth), int(num_min), float(min_range),
+                                  float(default_gradient), _ptr(out), mem))
+    return out
+
+
 # ---- bilinear (include/gridpp.h:902-930, src/api/bilinear.cpp:26-135) ---------------------------------
 def bilinear(igrid, opoints, values):
     """values (Y, X) -> output shaped like opoints; values (T, Y, X) -> (T,) + that shape."""

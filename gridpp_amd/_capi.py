@@ -47,6 +47,11 @@ SIGNATURES = {
     "gpp_nearest": [vp, vp, vp, vp, C.c_int],
     "gpp_nearest_levels": [vp, vp, vp, C.c_int, vp, C.c_int],
     "gpp_bilinear": [vp, vp, vp, C.c_int, vp, C.c_int],
+    "gpp_fill": [vp, vp, vp, vp, C.c_float, C.c_int, vp, C.c_int],
+    "gpp_fill_missing": [vp, C.c_int, C.c_int, vp, C.c_int],
+    "gpp_doping": [vp, vp, vp, vp, vp, vp, C.c_float, vp, C.c_int],
+    "gpp_neighbourhood_search": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, C.c_int],
+    "gpp_calc_gradient": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_int],
     "gpp_points_get_neighbours_batch": [vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, C.c_longlong, C.POINTER(C.c_longlong)],
     "gpp_count": [vp, vp, C.c_float, vp, C.c_int],
     "gpp_gridding": [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int],

@@ -125,6 +125,29 @@ int gpp_gridding(gpp_points* to, gpp_points* from, const float* values, float ra
  * `to`; statistic of what each location received (in input order), NaN for none / fewer than min_num. */
 int gpp_gridding_nearest(gpp_points* to, gpp_points* from, const float* values, int min_num, int statistic, float* out, int mem);
 
+/* gridpp::fill (src/api/fill.cpp:6-41): cells of `igrid` within radii[i] of point i get `value` (outside = 0), or keep
+ * `input` while every other cell gets `value` (outside = 1).  radii: host array, one per point.  input/out follow `mem`. */
+int gpp_fill(gpp_points* igrid, const float* input, gpp_points* points, const float* radii, float value, int outside,
+             float* out, int mem);
+/* gridpp::fill_missing (src/api/fill.cpp:43-134): linear interpolation across runs of missing values along rows and
+ * along columns, averaged. */
+int gpp_fill_missing(const float* values, int ny, int nx, float* out, int mem);
+/* gridpp::doping_square (halfwidth != NULL) / doping_circle (radii != NULL) (src/api/doping.cpp:5-93): grid cells in the
+ * index window around the nearest grid point of observation i / within radii[i] of it take observations[i]; later
+ * observations win; cells whose elevation differs from the observation's by more than max_elev_diff (if valid) are left.
+ * halfwidth / radii: host arrays.  background / observations / out follow `mem`. */
+int gpp_doping(gpp_points* igrid, const float* background, gpp_points* points, const float* observations,
+               const int* halfwidth, const float* radii, float max_elev_diff, float* out, int mem);
+/* gridpp::neighbourhood_search (src/api/neighbourhood_search.cpp:7-113); apply_array may be NULL (follows `mem`). */
+int gpp_neighbourhood_search(const float* array, const float* search_array, int ny, int nx, int halfwidth,
+                             float search_target_min, float search_target_max, float search_delta,
+                             const int* apply_array, float* out, int mem);
+/* gridpp::calc_gradient (src/api/calc_gradient.cpp:7-126); gradient types as include/gridpp.h:126-129. */
+#define GPP_GRADIENT_MINMAX 0
+#define GPP_GRADIENT_LINEAR_REGRESSION 10
+int gpp_calc_gradient(const float* base, const float* values, int ny, int nx, int gradient_type, int halfwidth, int num_min,
+                      float min_range, float default_gradient, float* out, int mem);
+
 /* gridpp::bilinear(Grid, Points|Grid, vec2|vec3) (src/api/bilinear.cpp:26-135; per location :322-403, weights
  * :137-320): `values` holds nt time levels of the input grid, [nt][ny][nx]; out is [nt][size of `to`].  A location
  * outside the grid, or whose box has a missing corner, takes the nearest grid point's value; all NaN if the input
