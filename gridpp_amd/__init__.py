@@ -654,6 +654,16 @@ def count(ipoints, opoints, radius):
     return out
 
 
+def distance(ipoints, opoints, num):
+    """Largest distance from every location of `opoints` to its `num` nearest points of `ipoints` (distance.cpp:6-120)."""
+    if ipoints.get_coordinate_type() != opoints.get_coordinate_type():
+        raise ValueError("Incompatible coordinate types")
+    out = np.empty(_out_shape(opoints), np.float32)
+    if out.size:
+        check(lib().gpp_distance(ipoints._h, opoints._h, int(num), 0 if isinstance(opoints, Grid) else 1, _ptr(out), _capi.MEM_HOST))
+    return out
+
+
 def _point_values(ipoints, values):
     if _is_dev(values):
         import torch

@@ -476,3 +476,107 @@ extern "C" int gpp_points_get_closest_neighbours(gpp_points* p, float lat, float
     return GPP_OK;
     GPP_CATCH
 }
+
+// ---- distance (src/api/distance.cpp:6-120) -----------------------------------------------------------------------
+namespace {
+// KDTree::calc_distance (kdtree.cpp:107-133): planar distance, or the great-circle arc from double trigonometry on
+// float32-rounded radians (deg2rad returns float, :195-197)
+__device__ float d_calc_distance(float lat1, float lon1, float lat2, float lon2, int type) {
+    if(type == GPP_CARTESIAN) {
+        const float dx = lon1 - lon2, dy = lat1 - lat2;
+        return sqrtf(dx * dx + dy * dy);
+    }
+    if(lat1 == lat2 && lon1 == lon2) return 0;
+    const double lat1r = (float)(lat1 * M_PI / 180), lat2r = (float)(lat2 * M_PI / 180);
+    const double lon1r = (float)(lon1 * M_PI / 180), lon2r = (float)(lon2 * M_PI / 180);
+    const double ratio = cos(lat1r) * cos(lon1r) * cos(lat2r) * cos(lon2r) + cos(lat1r) * sin(lon1r) * cos(lat2r) * sin(lon2r) + sin(lat1r) * sin(lat2r);
+    return (float)(acos(ratio) * 6.378137e6);
+}
+
+// The `num` nearest points of every location (float32 squared chord, ties -> lower index) by a ring search over the bin index
+// with a sorted list of the best `num` candidates kept in HBM scratch, then the largest calc_distance among them.
+__global__ __launch_bounds__(256) void k_knn_max_distance(IxView ix, const float* __restrict__ plat, const float* __restrict__ plon, int n,
+                                                          const float* __restrict__ qx, const float* __restrict__ qy, const float* __restrict__ qz,
+                                                          const float* __restrict__ qlat, const float* __restrict__ qlon, int nq, int num, int type,
+                                                          int query_first, float* __restrict__ skey, int* __restrict__ sidx, float* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if(q >= nq) return;
+    const int k = min(num, n);
+    float* key = skey + (size_t)q * k;
+    int* idx = sidx + (size_t)q * k;
+    const float x = qx[q], y = qy[q], z = qz[q];
+    const float qa = ix.axis_a == 0 ? x : (ix.axis_a == 1 ? y : z), qb = ix.axis_b == 1 ? y : (ix.axis_b == 2 ? z : x);
+    const int cbx = bin_of(qa, ix.amin, ix.inv_s, ix.nbx), cby = bin_of(qb, ix.bmin, ix.inv_s, ix.nby);
+    const float sbin = 1.0f / ix.inv_s;
+    int have = 0;
+    auto visit = [&](int row, int xa, int xb) {
+        if(row < 0 || row >= ix.nby) return;
+        xa = max(xa, 0); xb = min(xb, ix.nbx - 1);
+        if(xa > xb) return;
+        const int js = ix.bin_start[row * ix.nbx + xa], je = ix.bin_start[row * ix.nbx + xb + 1];
+        for(int j = js; j < je; ++j) {
+            const float4 g = ix.sgeo[j];
+            const float dx = g.x - x, dy = g.y - y, dz = g.z - z;
+            float s2 = dx * dx + dy * dy;
+            s2 = s2 + dz * dz;
+            const int o = __float_as_int(ix.smeta[j].y);
+            if(have == k && !(s2 < key[k - 1] || (s2 == key[k - 1] && o < idx[k - 1]))) continue;
+            int p = have < k ? have : k - 1;          // insertion into the sorted list
+            while(p > 0 && (s2 < key[p - 1] || (s2 == key[p - 1] && o < idx[p - 1]))) { key[p] = key[p - 1]; idx[p] = idx[p - 1]; --p; }
+            key[p] = s2; idx[p] = o;
+            if(have < k) ++have;
+        }
+    };
+    const int rmax = max(max(cbx, ix.nbx - 1 - cbx), max(cby, ix.nby - 1 - cby));
+    for(int r = 0; r <= rmax && k > 0; ++r) {
+        if(r >= 2 && have == k) { const float lb = (float)(r - 1) * sbin * 0.999f; if(key[k - 1] < lb * lb) break; }
+        if(r == 0) visit(cby, cbx, cbx);
+        else {
+            visit(cby - r, cbx - r, cbx + r);
+            visit(cby + r, cbx - r, cbx + r);
+            for(int row = cby - r + 1; row <= cby + r - 1; ++row) { visit(row, cbx - r, cbx - r); visit(row, cbx + r, cbx + r); }
+        }
+    }
+    float max_dist = 0;
+    for(int i = 0; i < have; ++i) {
+        const int o = idx[i];
+        const float d = query_first ? d_calc_distance(qlat[q], qlon[q], plat[o], plon[o], type) : d_calc_distance(plat[o], plon[o], qlat[q], qlon[q], type);
+        if(d > max_dist) max_dist = d;
+    }
+    out[q] = max_dist;
+}
+}   // namespace
+
+extern "C" int gpp_distance(gpp_points* from, gpp_points* to, int num, int query_first, float* out, int mem) {
+    GPP_TRY
+    if(!from || !to) invalid("points is NULL");
+    if(from->type != to->type) invalid("Incompatible coordinate types");   // distance.cpp:7-8
+    const int nq = to->n;
+    if(nq == 0) return GPP_OK;
+    ensure_device();
+    OutField o;
+    o.bind(out, nq, mem);
+    const int k = std::max(0, std::min(num, from->n));
+    if(k == 0) hipLaunchKernelGGL(k_fill_value, dim3((nq + 255) / 256), dim3(256), 0, stream(), o.d, (size_t)nq, 0.0f);
+    else {
+        to->to_device(); to->latlon_to_device();
+        from->latlon_to_device();
+        gpp_obs_index* ix = gpp_build_obs_index(from);
+        DevBuf<float> skey;
+        DevBuf<int> sidx;
+        // scratch of k entries per location, in slabs of at most 2^28 entries
+        const int slab = (int)std::max<long long>(1, std::min<long long>(nq, (1ll << 28) / k));
+        skey.get((size_t)slab * k); sidx.get((size_t)slab * k);
+        for(int q0 = 0; q0 < nq; q0 += slab) {
+            const int m = std::min(slab, nq - q0);
+            hipLaunchKernelGGL(k_knn_max_distance, dim3((m + 255) / 256), dim3(256), 0, stream(), view_of(ix), from->d_lat.p, from->d_lon.p, from->n,
+                               to->d_x.p + q0, to->d_y.p + q0, to->d_z.p + q0, to->d_lat.p + q0, to->d_lon.p + q0, m, num, from->type, query_first,
+                               skey.p, sidx.p, o.d + q0);
+        }
+    }
+    GPP_HIP(hipGetLastError());
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}

@@ -12,6 +12,7 @@
 //   nearest (all eight overloads)              :860-900
 //   bilinear(Grid, Grid|Points, vec2|vec3)     :902-930
 //   count, gridding, gridding_nearest          :938-1010
+//   fill, fill_missing, doping_square/circle, neighbourhood_search, calc_gradient
 //   calc_statistic / calc_quantile             :1454-1482
 // Nested vectors are flattened once, handed to the C-ABI as host buffers (GPP_MEM_HOST) and un-flattened,
 // exactly where the reference flattens them itself (src/api/oi.cpp:69-86).  Errors: GPP_EINVAL ->
@@ -473,6 +474,70 @@ inline vec2 gridding_nearest(const Grid& grid, const Points& points, const vec& 
 }
 inline vec gridding_nearest(const Points& opoints, const Points& ipoints, const vec& values, int min_num, Statistic statistic) {
     return detail::gridding_flat(opoints.handle(), opoints.size(), ipoints, values, 0, min_num, statistic, true);
+}
+
+// ---- fill / doping / neighbourhood_search / calc_gradient (src/api/fill.cpp, doping.cpp, neighbourhood_search.cpp,
+//      calc_gradient.cpp) ---------------------------------------------------------------------------------------------
+enum GradientType { MinMax = 0, LinearRegression = 10 };   // include/gridpp.h:126-129
+inline vec2 fill(const Grid& igrid, const vec2& input, const Points& points, const vec& radii, float value, bool outside) {
+    size_t Y, X;
+    vec v = detail::flatten(input, Y, X);
+    if(Y != 0 && !detail::fits(igrid, Y, X)) throw std::invalid_argument("Grid size is not the same as values");
+    if((int)radii.size() != points.size()) throw std::invalid_argument("Points size is not the same as radii size");
+    vec out(v.size(), MV);
+    if(v.size()) detail::check(gpp_fill(igrid.handle(), v.data(), points.handle(), radii.data(), value, outside, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, Y, X);
+}
+inline vec2 fill_missing(const vec2& values) {
+    size_t Y, X;
+    vec v = detail::flatten(values, Y, X);
+    vec out(v.size(), MV);
+    if(v.size()) detail::check(gpp_fill_missing(v.data(), (int)Y, (int)X, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, Y, X);
+}
+namespace detail {
+inline vec2 doping(const Grid& igrid, const vec2& background, const Points& points, const vec& observations, const int* halfwidth, const float* radii,
+                   size_t nper, float max_elev_diff) {
+    size_t Y, X;
+    vec v = flatten(background, Y, X);
+    if(Y != 0 && !fits(igrid, Y, X)) throw std::invalid_argument("Grid size is not the same as observations");
+    if((int)observations.size() != points.size()) throw std::invalid_argument("Points size is not the same as observations size");
+    if((int)nper != points.size()) throw std::invalid_argument(halfwidth ? "Points size is not the same as halfwidth size" : "Points size is not the same as radii size");
+    vec out(v.size(), MV);
+    if(v.size()) check(gpp_doping(igrid.handle(), v.data(), points.handle(), observations.data(), halfwidth, radii, max_elev_diff, out.data(), GPP_MEM_HOST));
+    return unflatten(out, Y, X);
+}
+}   // namespace detail
+inline vec2 doping_square(const Grid& igrid, const vec2& background, const Points& points, const vec& observations, const ivec& halfwidth, float max_elev_diff = MV) {
+    return detail::doping(igrid, background, points, observations, halfwidth.data(), nullptr, halfwidth.size(), max_elev_diff);
+}
+inline vec2 doping_circle(const Grid& igrid, const vec2& background, const Points& points, const vec& observations, const vec& radii, float max_elev_diff = MV) {
+    return detail::doping(igrid, background, points, observations, nullptr, radii.data(), radii.size(), max_elev_diff);
+}
+inline vec2 neighbourhood_search(const vec2& array, const vec2& search_array, int halfwidth, float search_target_min, float search_target_max,
+                                 float search_delta, const ivec2& apply_array = ivec2()) {
+    size_t Y, X, Ys, Xs;
+    vec a = detail::flatten(array, Y, X), s = detail::flatten(search_array, Ys, Xs);
+    if(Y != Ys || X != Xs) throw std::invalid_argument("search_array must either be the same size as array");
+    ivec ap;
+    if(apply_array.size() > 0) {
+        if(apply_array.size() > 1 && (apply_array.size() != Y || apply_array[0].size() != X)) throw std::invalid_argument("apply_array must either be empty or same size as array");
+        for(const auto& r : apply_array) ap.insert(ap.end(), r.begin(), r.end());
+    }
+    vec out(a.size(), MV);
+    if(a.size()) detail::check(gpp_neighbourhood_search(a.data(), s.data(), (int)Y, (int)X, halfwidth, search_target_min, search_target_max, search_delta,
+                                                        ap.size() == a.size() ? ap.data() : nullptr, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, Y, X);
+}
+inline vec2 calc_gradient(const vec2& base, const vec2& values, GradientType gradient_type, int halfwidth, int min_num = 2, float min_range = MV,
+                          float default_gradient = 0) {
+    size_t Y, X, Yv, Xv;
+    vec b = detail::flatten(base, Y, X), v = detail::flatten(values, Yv, Xv);
+    if(Y == 0) throw std::invalid_argument("base input has no size");
+    if(Y != Yv || X != Xv) throw std::invalid_argument("base is not the same size as values");
+    vec out(b.size(), MV);
+    detail::check(gpp_calc_gradient(b.data(), v.data(), (int)Y, (int)X, (int)gradient_type, halfwidth, min_num, min_range, default_gradient, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, Y, X);
 }
 
 // ---- bilinear (include/gridpp.h:902-930; src/api/bilinear.cpp:26-135) -------------------------------------------

@@ -116,6 +116,11 @@ int gpp_points_get_neighbours_batch(gpp_points* p, const float* qlats, const flo
 /* gridpp::count (src/api/count.cpp:6-66, all four overloads): out[i] = number of points of `from` within `radius` of
  * location i of `to`.  out follows `mem`. */
 int gpp_count(gpp_points* from, gpp_points* to, float radius, float* out, int mem);
+/* gridpp::distance (src/api/distance.cpp:6-120, all four overloads): out[i] = the largest KDTree::calc_distance
+ * (src/api/kdtree.cpp:107-133) between location i of `to` and its `num` nearest points of `from`.  query_first = 1 for
+ * the overloads whose output is a Points (they call calc_distance(location, neighbour)), 0 for those whose output is a
+ * Grid (calc_distance(neighbour, location)).  GPP_EINVAL if the coordinate types differ. */
+int gpp_distance(gpp_points* from, gpp_points* to, int num, int query_first, float* out, int mem);
 /* gridpp::gridding (src/api/gridding.cpp:6-63): statistic of the values of the points of `from` within `radius` of every
  * location of `to`; NaN where fewer than min_num (> 0) points are found.  GPP_EINVAL for radius < 0 / NaN, min_num < 0.
  * values / out follow `mem`. */

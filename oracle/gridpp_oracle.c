@@ -927,6 +927,38 @@ int orc_gridding_nearest(const float* ox, const float* oy, const float* oz, int 
 }
 
 /* ------------------------------------------------------------------------ */
+/* distance: src/api/distance.cpp:6-120                                      */
+/* ------------------------------------------------------------------------ */
+/* out[i] = the largest calc_distance (kdtree.cpp:107-133) from output location i to its `num` nearest input points
+ * (nearest by float32 squared chord, ties -> lower index).  query_first: argument order of calc_distance -- the
+ * Grid->Points and Points->Points overloads pass (location, neighbour), the two ->Grid overloads (neighbour, location). */
+int orc_distance(const float* px, const float* py, const float* pz, const float* plat, const float* plon, int n,
+                 const float* qx, const float* qy, const float* qz, const float* qlat, const float* qlon, int nq, int num, int type,
+                 int query_first, float* out) {
+    float* key = (float*)malloc(sizeof(float) * (n > 0 ? n : 1));
+    char* taken = (char*)malloc(n > 0 ? n : 1);
+    for(int i = 0; i < nq; i++) {
+        for(int j = 0; j < n; j++) {
+            float dx = px[j] - qx[i], dy = py[j] - qy[i], dz = pz[j] - qz[i];
+            key[j] = dx * dx + dy * dy + dz * dz;
+            taken[j] = 0;
+        }
+        float max_dist = 0;
+        for(int k = 0; k < num && k < n; k++) {
+            int best = -1;
+            for(int j = 0; j < n; j++) if(!taken[j] && (best < 0 || key[j] < key[best])) best = j;
+            taken[best] = 1;
+            float d = query_first ? orc_calc_distance(qlat[i], qlon[i], plat[best], plon[best], type)
+                                  : orc_calc_distance(plat[best], plon[best], qlat[i], qlon[i], type);
+            if(d > max_dist) max_dist = d;
+        }
+        out[i] = max_dist;
+    }
+    free(key); free(taken);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* fill / fill_missing (src/api/fill.cpp:6-134), doping_square / doping_circle */
 /* (src/api/doping.cpp:5-93), neighbourhood_search                             */
 /* (src/api/neighbourhood_search.cpp:7-113), calc_gradient                     */

@@ -346,6 +346,14 @@ def calc_gradient(base, values, gradient_type, halfwidth, num_min, min_range, de
     return out
 
 
+def distance(p, q, num, query_first):
+    """distance(input set p, output locations q, num) (src/api/distance.cpp)"""
+    out = np.empty(q.n, np.float32)
+    lib().orc_distance(p.x.ctypes, p.y.ctypes, p.z.ctypes, p.lats.ctypes, p.lons.ctypes, C.c_int(p.n), q.x.ctypes, q.y.ctypes, q.z.ctypes,
+                       q.lats.ctypes, q.lons.ctypes, C.c_int(q.n), C.c_int(num), C.c_int(p.ctype), C.c_int(int(query_first)), out.ctypes)
+    return out
+
+
 class OracleDistorted(RuntimeError):
     """bilinear: s / t outside [0, 1] (the reference throws std::runtime_error, src/api/bilinear.cpp:309-313)"""
 

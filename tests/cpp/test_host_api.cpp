@@ -88,6 +88,16 @@ int main() {
         try { gridding(gg, gp, vec{1}, 0.6f, 0, Sum); } catch(const std::invalid_argument&) { threw = true; }
         CHECK(threw);
     }
+    // fill / neighbourhood_search / calc_gradient (tests/test_fill_missing.py:8-17, tests/test_neighbourhood_search.py:52-54,
+    // tests/test_calc_gradient.py:17-26)
+    {
+        vec2 ns = neighbourhood_search(vec2{{0, 1, 2}}, vec2{{0.5f, 0.5f, 1}}, 1, 0.7f, 1, 0.1f);
+        CHECK(ns[0][0] == 0 && ns[0][1] == 2 && ns[0][2] == 2);
+        vec2 gr = calc_gradient(vec2{{0, 1, 2}}, vec2{{0, 1, 2}}, LinearRegression, 5, 0, 0, -11);
+        CHECK(std::fabs(gr[0][0] - 1) < 1e-6 && std::fabs(gr[0][2] - 1) < 1e-6);
+        vec2 fm = fill_missing(vec2{{0, 1, 2}, {3, NAN, 5}, {6, 7, 8}});
+        CHECK(fm[1][1] == 4);
+    }
     // bilinear (tests/test_bilinear.py:134-156, tests/test_grid.py:23-30)
     {
         vec2 la1 = {{0, 0}, {1, 1}}, lo1 = {{0, 1}, {0, 1}};

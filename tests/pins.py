@@ -636,6 +636,23 @@ def pin_calc_gradient(g, G):
             g.calc_gradient(z, z, g.LinearRegression, hw, mn, mr, -11)
 
 
+def pin_distance(g, G):
+    e = G["distance"]["cartesian"]
+    lons, lats = np.meshgrid(e["grid_lons"], e["grid_lats"])
+    grid = g.Grid(lats, lons, 0 * lats, 0 * lats, g.Cartesian)
+    points = g.Points(e["point_lats"], e["point_lons"], [0, 0], [0, 0], g.Cartesian)
+    for num, expected in e["point_to_grid"].items():
+        np.testing.assert_array_almost_equal(g.distance(points, grid, int(num)), expected, e["places"])
+    for num, expected in e["grid_to_point"].items():
+        np.testing.assert_array_almost_equal(g.distance(grid, points, int(num)), expected, e["places"])
+    e = G["distance"]["geodetic"]
+    lons, lats = np.meshgrid(e["grid_lons"], e["grid_lats"])
+    grid = g.Grid(lats, lons)
+    points = g.Points(e["point_lats"], e["point_lons"])
+    for num, expected in e["grid_to_point"].items():
+        np.testing.assert_array_almost_equal(g.distance(grid, points, int(num)), expected, e["places"])
+
+
 def pin_bilinear(g, G):
     import pytest
     e = G["bilinear_simple"]

@@ -298,6 +298,13 @@ def calc_gradient(base, values, gradient_type, halfwidth, num_min=2, min_range=n
         raise ValueError(str(e))
 
 
+def distance(ipoints, opoints, num):
+    if ipoints.get_coordinate_type() != opoints.get_coordinate_type():
+        raise ValueError("Incompatible coordinate types")
+    shape = _oshape(opoints) if _pts(opoints).n else ((0, 0) if isinstance(opoints, Grid) else (0,))
+    return O.distance(_pts(ipoints), _pts(opoints), num, not isinstance(opoints, Grid)).reshape(shape)
+
+
 def bilinear(igrid, opoints, values):
     values = np.asarray(values, np.float32)
     ishape = tuple(igrid.size()) if igrid.p.n else (0, 0)      # src/api/grid.cpp:122-130

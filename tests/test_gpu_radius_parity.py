@@ -148,3 +148,35 @@ def test_reference_benchmark_shape_gridding():
     np.testing.assert_allclose(out[k, k], k / 199.0, atol=2e-3)
     near = np.asarray(gridpp.gridding_nearest(grid, pts, values, 1, gridpp.Count))
     assert np.nansum(near) == n
+
+
+@pytest.mark.parametrize("geodetic", [True, False])
+def test_distance_matches_oracle(geodetic):
+    """distance.cpp: the k nearest set is exact (same float32 metric and tie rule); the great-circle arc is double trigonometry
+    on float32-rounded radians, where device and host libm may differ in the last bits of cos / sin / acos: 1e-5 relative or
+    5 cm, whichever is larger (the planar form is exact)."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    ct = 0 if geodetic else 1
+    ilat, ilon, olat, olon = _sets(6000, 900, geodetic, 77)
+    ip, op = gridpp.Points(ilat, ilon, type=ct), gridpp.Points(olat, olon, type=ct)
+    oi_, oo = O.Pts(ilat, ilon, ctype=ct), O.Pts(olat, olon, ctype=ct)
+    lats, lons = np.meshgrid(np.linspace(olat.min(), olat.max(), 20), np.linspace(olon.min(), olon.max(), 25), indexing="ij")
+    ogrid, oog = gridpp.Grid(lats, lons, type=ct), O.Pts(lats.ravel(), lons.ravel(), ctype=ct)
+    for num in (1, 3, 10, 200, 7000):
+        out = gridpp.distance(ip, op, num)
+        ref = O.distance(oi_, oo, num, True)
+        if geodetic:
+            np.testing.assert_allclose(out, ref, rtol=1e-5, atol=0.05)
+        else:
+            np.testing.assert_array_equal(out, ref)
+        outg = gridpp.distance(ip, ogrid, num)
+        refg = O.distance(oi_, oog, num, False).reshape(20, 25)
+        assert outg.shape == (20, 25)
+        if geodetic:
+            np.testing.assert_allclose(outg, refg, rtol=1e-5, atol=0.05)
+        else:
+            np.testing.assert_array_equal(outg, refg)
+    assert (gridpp.distance(ip, op, 1)[:20] == 0).all()          # exact matches
+    with pytest.raises(ValueError):
+        gridpp.distance(ip, gridpp.Points(olat, olon, type=1 - ct), 1)
