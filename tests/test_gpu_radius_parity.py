@@ -158,12 +158,12 @@ def test_distance_matches_oracle(geodetic):
     import gridpp_amd as gridpp
     from oracle import oracle as O
     ct = 0 if geodetic else 1
-    ilat, ilon, olat, olon = _sets(6000, 900, geodetic, 77)
+    ilat, ilon, olat, olon = _sets(2500, 400, geodetic, 77)
     ip, op = gridpp.Points(ilat, ilon, type=ct), gridpp.Points(olat, olon, type=ct)
     oi_, oo = O.Pts(ilat, ilon, ctype=ct), O.Pts(olat, olon, ctype=ct)
     lats, lons = np.meshgrid(np.linspace(olat.min(), olat.max(), 20), np.linspace(olon.min(), olon.max(), 25), indexing="ij")
     ogrid, oog = gridpp.Grid(lats, lons, type=ct), O.Pts(lats.ravel(), lons.ravel(), ctype=ct)
-    for num in (1, 3, 10, 200, 7000):
+    for num in (1, 3, 10, 200, 3000):            # the last one asks for more points than there are
         out = gridpp.distance(ip, op, num)
         ref = O.distance(oi_, oo, num, True)
         if geodetic:
