@@ -165,7 +165,13 @@ __global__ void k_fill_value(float* out, size_t n, float v) {
     if(i < n) out[i] = v;
 }
 
-const long long CSR_CAP = 1ll << 28;   // entries per filling pass (1 GiB of float values)
+// entries per filling pass (2^28 = 1 GiB of float values; GPP_CSR_CAP overrides it so that the tests can reach the chunked path)
+long long csr_cap() {
+    const char* e = getenv("GPP_CSR_CAP");
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? v : (1ll << 28);
+}
+#define CSR_CAP csr_cap()
 
 // exclusive scan of the per-location counts into 64-bit offsets [nq + 1]; returns the total
 long long scan_counts(const int* cnt, int nq, DevBuf<long long>& wide, DevBuf<long long>& offset) {

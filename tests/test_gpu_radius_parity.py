@@ -180,3 +180,22 @@ def test_distance_matches_oracle(geodetic):
     assert (gridpp.distance(ip, op, 1)[:20] == 0).all()          # exact matches
     with pytest.raises(ValueError):
         gridpp.distance(ip, gridpp.Points(olat, olon, type=1 - ct), 1)
+
+
+def test_gridding_median_in_chunks(monkeypatch):
+    """The CSR path splits the locations into passes when the neighbour lists exceed the scratch cap; with a tiny cap the
+    passes must reproduce the single-pass result (a location with more neighbours than the cap gets a pass of its own)."""
+    import gridpp_amd as gridpp
+    rng = np.random.default_rng(31)
+    n = 3000
+    plat, plon = 59 + rng.random(n), 10 + 2 * rng.random(n)
+    values = rng.normal(0, 2, n).astype(np.float32)
+    lats, lons = np.meshgrid(np.linspace(59, 60, 23), np.linspace(10, 12, 31), indexing="ij")
+    grid, pts = gridpp.Grid(lats, lons), gridpp.Points(plat, plon)
+    one = np.asarray(gridpp.gridding(grid, pts, values, 12000.0, 2, gridpp.Median))
+    cnt = gridpp.count(pts, grid, 12000.0)
+    for cap in (int(cnt.max()) // 2, 1000, 20000):
+        monkeypatch.setenv("GPP_CSR_CAP", str(cap))
+        np.testing.assert_array_equal(np.asarray(gridpp.gridding(grid, pts, values, 12000.0, 2, gridpp.Median)), one)
+    monkeypatch.delenv("GPP_CSR_CAP")
+    assert cnt.sum() > 20000
