@@ -144,6 +144,81 @@ __global__ __launch_bounds__(256) void k_radius_statistic(IxView ix, const float
     out[q] = r;
 }
 
+// The same pass with one wavefront per location: the 64 lanes test 64 consecutive points of a bin row at once (coalesced
+// float4 loads), the hits are then fed to the accumulators one by one in point order through v_readlane, so the result has
+// the same bits as the one-thread walk while the loads no longer form a serial latency chain.
+__global__ __launch_bounds__(256) void k_radius_statistic_wave(IxView ix, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                               const float* __restrict__ qz, int nq, float radius,
+                                                               const float* __restrict__ values, int min_num, int statistic,
+                                                               float* __restrict__ out) {
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if(q >= nq) return;
+    const float x = qx[q], y = qy[q], z = qz[q];
+    int c = 0, count = 0;
+    float total = 0, total2 = 0, K = NAN, m = NAN;
+    const bool spread = statistic == GPP_STD || statistic == GPP_VARIANCE, lo = statistic == GPP_MIN, hi = statistic == GPP_MAX;
+    if(radius > 0) {
+        const float lox = x - radius, hix = x + radius, loy = y - radius, hiy = y + radius, loz = z - radius, hiz = z + radius;
+        const float alo = ix.axis_a == 0 ? lox : (ix.axis_a == 1 ? loy : loz), ahi = ix.axis_a == 0 ? hix : (ix.axis_a == 1 ? hiy : hiz);
+        const float blo = ix.axis_b == 1 ? loy : (ix.axis_b == 2 ? loz : lox), bhi = ix.axis_b == 1 ? hiy : (ix.axis_b == 2 ? hiz : hix);
+        const int bx0 = bin_of(alo, ix.amin, ix.inv_s, ix.nbx), bx1 = bin_of(ahi, ix.amin, ix.inv_s, ix.nbx);
+        const int by0 = bin_of(blo, ix.bmin, ix.inv_s, ix.nby), by1 = bin_of(bhi, ix.bmin, ix.inv_s, ix.nby);
+        for(int row = by0; row <= by1; ++row) {
+            const int js = ix.bin_start[row * ix.nbx + bx0], je = ix.bin_start[row * ix.nbx + bx1 + 1];
+            for(int base = js; base < je; base += 64) {
+                const int j = base + lane;
+                bool in = false;
+                float v = 0;
+                if(j < je) {
+                    const float4 g = ix.sgeo[j];
+                    if(g.x > lox && g.x < hix && g.y > loy && g.y < hiy && g.z > loz && g.z < hiz) {
+                        const float dx = g.x - x, dy = g.y - y, dz = g.z - z;
+                        in = sqrtf(dx * dx + dy * dy + dz * dz) <= radius;
+                    }
+                    if(in) v = values[__float_as_int(ix.smeta[j].y)];
+                }
+                unsigned long long mask = __ballot(in);
+                c += __popcll(mask);
+                while(mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const float vb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), b));
+                    if(!nv(vb)) continue;
+                    if(spread) {
+                        if(!nv(K)) K = vb;
+                        const float d = vb - K;
+                        total += d; total2 += d * d;
+                    }
+                    else if(lo || hi) {
+                        if(!nv(m)) m = vb;
+                        else if(lo ? vb < m : vb > m) m = vb;
+                    }
+                    else total += vb;
+                    ++count;
+                }
+            }
+        }
+    }
+    if(lane != 0) return;
+    float r = NAN;
+    if(min_num <= 0 || c >= min_num) {
+        if(statistic == GPP_COUNT) r = (float)count;
+        else if(lo || hi) r = m;
+        else if(count > 0) {
+            if(spread) {
+                const float mean = total / (float)count, mean2 = total2 / (float)count;
+                float var = mean2 - mean * mean;
+                if(var < 0) var = 0;
+                r = statistic == GPP_STD ? sqrtf(var) : var;
+            }
+            else if(statistic == GPP_MEAN) r = total / (float)count;
+            else if(statistic == GPP_SUM) r = total;
+        }
+    }
+    out[q] = r;
+}
+
 __global__ void k_widen(const int* __restrict__ in, int n, long long* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) out[i] = in[i];
@@ -265,8 +340,12 @@ extern "C" int gpp_gridding(gpp_points* to, gpp_points* from, const float* value
         const bool streams = statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT || statistic == GPP_STD ||
                              statistic == GPP_VARIANCE || statistic == GPP_MIN || statistic == GPP_MAX;
         if(streams && !getenv("GPP_GRIDDING_CSR")) {
-            hipLaunchKernelGGL(k_radius_statistic, dim3((nq + 255) / 256), dim3(256), 0, stream(), iv, to->d_x.p, to->d_y.p, to->d_z.p, nq, radius,
-                               v.d, min_num, statistic, o.d);
+            if(getenv("GPP_GRIDDING_THREAD"))
+                hipLaunchKernelGGL(k_radius_statistic, dim3((nq + 255) / 256), dim3(256), 0, stream(), iv, to->d_x.p, to->d_y.p, to->d_z.p, nq, radius,
+                                   v.d, min_num, statistic, o.d);
+            else
+                hipLaunchKernelGGL(k_radius_statistic_wave, dim3((nq + 3) / 4), dim3(256), 0, stream(), iv, to->d_x.p, to->d_y.p, to->d_z.p, nq, radius,
+                                   v.d, min_num, statistic, o.d);
             GPP_HIP(hipGetLastError());
             o.finish();
             GPP_HIP(hipStreamSynchronize(stream()));

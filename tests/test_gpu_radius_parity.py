@@ -72,9 +72,10 @@ def test_gridding_matches_oracle(statistic, monkeypatch):
             np.testing.assert_allclose(out, ref, rtol=RTOL, atol=1e-5)
     assert np.isfinite(out).any() and np.isnan(out).any()
     # the one-pass kernel and the CSR path (used for Median) feed the accumulators in the same order
-    monkeypatch.setenv("GPP_GRIDDING_CSR", "1")
-    np.testing.assert_array_equal(np.asarray(gridpp.gridding(grid, pts, values, 2500.0, 7, stat)), out)
-    monkeypatch.delenv("GPP_GRIDDING_CSR")
+    for path in ("GPP_GRIDDING_CSR", "GPP_GRIDDING_THREAD"):      # default = one wavefront per location
+        monkeypatch.setenv(path, "1")
+        np.testing.assert_array_equal(np.asarray(gridpp.gridding(grid, pts, values, 2500.0, 7, stat)), out)
+        monkeypatch.delenv(path)
     # Points as the output set and device-resident values
     import torch
     outp = gridpp.gridding(grid.to_points(), pts, torch.from_numpy(values).cuda(), 9000.0, 3, stat)
