@@ -47,6 +47,15 @@ G200, P100000 = grid(200), points(100000)
 V100000 = np.zeros(100000)
 rows.append(("gridding 200^2, 100000 points, radius 5000, Mean", 0.61, lambda: gridpp.gridding(G200, P100000, V100000, 5000, 1, gridpp.Mean)))
 rows.append(("gridding_nearest 200^2, 100000 points, Mean", 0.11, lambda: gridpp.gridding_nearest(G200, P100000, V100000, 1, gridpp.Mean)))
+rows.append(("nearest 1000^2 x 50 levels", 1.93, lambda: gridpp.nearest(G1000, G1000, I50)))
+Z200 = np.zeros((200, 200))
+rows.append(("fill 200^2, 100000 points, radius 5000", 1.96, lambda: gridpp.fill(G200, Z200, P100000, np.ones(100000) * 5000, 1, False)))
+rows.append(("doping_square 200^2, 100000 points, halfwidth 5", 0.12, lambda: gridpp.doping_square(G200, Z200, P100000, np.ones(100000), np.ones(100000, "int") * 5, False)))
+rows.append(("doping_circle 200^2, 100000 points, radius 5000", 2.00, lambda: gridpp.doping_circle(G200, Z200, P100000, np.ones(100000), np.ones(100000) * 5000, False)))
+R2000a, R2000b = np.random.rand(2000, 2000) * 100, np.random.rand(2000, 2000)
+rows.append(("calc_gradient 2000^2 LinearRegression hw=10", 0.45, lambda: gridpp.calc_gradient(R2000a, I2000, gridpp.LinearRegression, 10, 0, 100, 0)))
+A2000 = np.random.rand(2000, 2000) < 0.5
+rows.append(("neighbourhood_search 2000^2 7x7", 1.11, lambda: gridpp.neighbourhood_search(R2000b, R2000b, 3, 0.7, 1, 0.1, A2000)))
 G100, P1000 = grid(100), points(1000)
 rows.append(("optimal_interpolation 100^2, 1000 obs, max_points 20", 0.80,
              lambda: gridpp.optimal_interpolation(G100, np.zeros((100, 100)), P1000, np.zeros(1000), np.ones(1000), np.ones(1000), structure, 20)))
