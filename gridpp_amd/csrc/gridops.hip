@@ -236,9 +236,11 @@ extern "C" int gpp_fill(gpp_points* igrid, const float* input, gpp_points* point
     GPP_TRY
     if(!igrid || !points) invalid("grid / points is NULL");
     const int np = points->n;
+    if(np > 0 && !radii) invalid("radii is NULL");
     for(int i = 0; i < np; i++) if(radii[i] < 0) invalid("All radius sizes must be 0 or greater");   // fill.cpp:11-14 (radii: host array)
     const size_t n = (size_t)igrid->n;
     if(n == 0) return GPP_OK;
+    if(!input || !out) invalid("input / out is NULL");
     ensure_device();
     InField in; OutField o;
     in.bind(input, n, mem);
@@ -272,6 +274,7 @@ extern "C" int gpp_fill_missing(const float* values, int ny, int nx, float* out,
     if(ny < 0 || nx < 0) invalid("negative size");
     const size_t n = (size_t)ny * nx;
     if(n == 0) return GPP_OK;
+    if(!values || !out) invalid("values / out is NULL");
     ensure_device();
     InField in; OutField o;
     in.bind(values, n, mem);
@@ -302,6 +305,7 @@ extern "C" int gpp_doping(gpp_points* igrid, const float* background, gpp_points
     }
     const size_t n = (size_t)igrid->n;
     if(n == 0) return GPP_OK;
+    if(!background || !out || (np > 0 && !observations)) invalid("background / observations / out is NULL");
     ensure_device();
     InField bg, obs; OutField o;
     bg.bind(background, n, mem);
@@ -345,6 +349,7 @@ extern "C" int gpp_neighbourhood_search(const float* array, const float* search_
     if(ny < 0 || nx < 0) invalid("negative size");
     const size_t n = (size_t)ny * nx;
     if(n == 0) return GPP_OK;
+    if(!array || !search_array || !out) invalid("array / search_array / out is NULL");
     ensure_device();
     InField a, s; OutField o;
     a.bind(array, n, mem);
@@ -375,6 +380,7 @@ extern "C" int gpp_calc_gradient(const float* base, const float* values, int ny,
     if(gradient_type != GPP_GRADIENT_MINMAX && gradient_type != GPP_GRADIENT_LINEAR_REGRESSION) invalid("unknown gradient type");
     const size_t n = (size_t)ny * nx;
     if(n == 0) return GPP_OK;
+    if(!base || !values || !out) invalid("base / values / out is NULL");
     ensure_device();
     InField b, v; OutField o;
     b.bind(base, n, mem);

@@ -294,6 +294,7 @@ extern "C" int gpp_count(gpp_points* from, gpp_points* to, float radius, float* 
     check_same_type(from, to);
     const int nq = to->n;
     if(nq == 0) return GPP_OK;
+    if(!out) invalid("out is NULL");
     OutField o;
     o.bind(out, nq, mem);
     if(from->n == 0) hipLaunchKernelGGL(k_fill_value, dim3((nq + 255) / 256), dim3(256), 0, stream(), o.d, (size_t)nq, 0.0f);
