@@ -61,31 +61,39 @@ __global__ void k_set_int(int* p, size_t n, int v) {
     if(i < n) p[i] = v;
 }
 
+// winner = max(winner, i).  Many points reach the same cell (the reference benchmark puts 100 000 of them on one diagonal), and
+// same-address atomics serialise in the L2; the winner only grows, so a plain look first -- a stale value is a smaller one, it
+// can only cause a redundant atomic, never a wrong skip -- lets all but the first few contenders of a cell leave it alone.
+__device__ __forceinline__ void raise_winner(int* w, int i) {
+    if(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) atomicMax(w, i);
+}
 // winner[cell] = highest point index whose circle reaches the cell (and, for doping, passes the elevation test)
 __global__ __launch_bounds__(256) void k_circle_winners(GridIx ix, const float* __restrict__ px, const float* __restrict__ py,
                                                         const float* __restrict__ pz, const float* __restrict__ pelev,
                                                         const float* __restrict__ radii, int np, int check_elev, float max_elev_diff,
                                                         int* __restrict__ winner) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= np) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= np) return;
+    const int i = np - 1 - t;   // high indices first: once a cell holds a high winner the lower ones only read it (see raise_winner)
     const float e = check_elev ? pelev[i] : 0.0f;
     cells_in_radius(ix, px[i], py[i], pz[i], radii[i], [&](int cell, float gelev) {
         if(check_elev && fabsf(e - gelev) > max_elev_diff) return;   // doping.cpp:83-87 (a NaN difference does not skip)
-        atomicMax(&winner[cell], i);
+        raise_winner(&winner[cell], i);
     });
 }
 // doping.cpp:32-45: index window around the nearest grid point of every observation
 __global__ __launch_bounds__(256) void k_square_winners(const int* __restrict__ nn, const float* __restrict__ pelev,
                                                         const int* __restrict__ halfwidth, int np, const float* __restrict__ gelev, int Y, int X,
                                                         int check_elev, float max_elev_diff, int* __restrict__ winner) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= np) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= np) return;
+    const int i = np - 1 - t;
     const int iy = nn[i] / X, ix = nn[i] - iy * X, hw = halfwidth[i];
     const float e = check_elev ? pelev[i] : 0.0f;
     for(int yy = max(0, iy - hw); yy <= min(Y - 1, iy + hw); ++yy)
         for(int xx = max(0, ix - hw); xx <= min(X - 1, ix + hw); ++xx) {
             if(check_elev && fabsf(e - gelev[yy * X + xx]) > max_elev_diff) continue;
-            atomicMax(&winner[yy * X + xx], i);
+            raise_winner(&winner[yy * X + xx], i);
         }
 }
 // mode 0: doping (winner's observation, else background); 1: fill inside (value where reached); 2: fill outside (input where reached)
