@@ -130,3 +130,33 @@ def test_calc_gradient_matches_oracle(gradient_type):
             np.testing.assert_allclose(out, ref, rtol=2e-3, atol=1e-6)
             assert np.median(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-9)) < 1e-5
     assert (out != dflt).mean() > 0.5
+
+
+def test_fill_and_doping_properties_at_size():
+    """Sizes the oracle cannot reach (2000 x 2000 grid, 50 000 points): inside / outside fills are complements, a doping
+    with one value and no elevation test is the inside fill, and counts agree with `count`."""
+    import gridpp_amd as gridpp
+    N, P = 2000, 50000
+    lats, lons = np.meshgrid(np.linspace(58, 60, N), np.linspace(8, 12, N), indexing="ij")
+    grid = gridpp.Grid(lats, lons)
+    rng = np.random.default_rng(5)
+    pts = gridpp.Points(58 + 2 * rng.random(P), 8 + 4 * rng.random(P))
+    radii = rng.uniform(100, 1500, P).astype(np.float32)
+    field = rng.normal(0, 1, (N, N)).astype(np.float32)          # never equal to the fill value
+    inside = np.asarray(gridpp.fill(grid, field, pts, radii, 99.0, False))
+    outside = np.asarray(gridpp.fill(grid, field, pts, radii, 99.0, True))
+    hit = inside == 99.0
+    assert 0.05 < hit.mean() < 0.95
+    np.testing.assert_array_equal(outside == 99.0, ~hit)
+    np.testing.assert_array_equal(inside[~hit], field[~hit])
+    np.testing.assert_array_equal(outside[hit], field[hit])
+    doped = np.asarray(gridpp.doping_circle(grid, field, pts, np.full(P, 99.0, np.float32), radii))
+    np.testing.assert_array_equal(doped, inside)
+    # equal radii: a cell is hit exactly when `count` finds a point within that radius
+    same = np.full(P, 800.0, np.float32)
+    hit800 = np.asarray(gridpp.fill(grid, field, pts, same, 99.0, False)) == 99.0
+    np.testing.assert_array_equal(hit800, gridpp.count(pts, grid, 800.0) > 0)
+    # the winner of overlapping circles is the highest index: doping with obs = index
+    obs = np.arange(P, dtype=np.float32)
+    who = np.asarray(gridpp.doping_circle(grid, np.full((N, N), -1, np.float32), pts, obs, same))
+    assert (who >= 0).sum() == hit800.sum() and who.max() == P - 1
