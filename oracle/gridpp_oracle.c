@@ -1109,7 +1109,7 @@ int orc_calc_gradient(const float* base, const float* values, int nY, int nX, in
         }
         return ORC_OK;
     }
-    float *b0 = (float*)malloc(sizeof(float) * n * 10), *v0 = b0 + n, *bb = b0 + 2 * n, *bv = b0 + 3 * n, *ok = b0 + 4 * n;
+    float *b0 = (float*)calloc((size_t)n * 10, sizeof(float)), *v0 = b0 + n, *bb = b0 + 2 * n, *bv = b0 + 3 * n, *ok = b0 + 4 * n;
     float *mX = b0 + 5 * n, *mY = b0 + 6 * n, *mXX = b0 + 7 * n, *mXY = b0 + 8 * n, *cnt = b0 + 9 * n;
     for(int i = 0; i < n; i++) {
         b0[i] = v0[i] = bb[i] = bv[i] = NAN; ok[i] = 0;
