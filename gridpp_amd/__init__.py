@@ -130,7 +130,10 @@ class Point:
 
 
 def convert_coordinates(lats, lons, type=Geodetic):
-    """src/api/util.cpp:583-615"""
+    """src/api/util.cpp:583-615; the scalar overload (:617-633) returns (ok, x, y, z)"""
+    if np.isscalar(lats) and np.isscalar(lons):
+        x, y, z = convert_coordinates([lats], [lons], type)
+        return True, float(x[0]), float(y[0]), float(z[0])
     lats, lons = _vec(lats, 1, "lats"), _vec(lons, 1, "lons")
     if lats.size != lons.size:
         raise ValueError("lats and lons must have the same size")
@@ -237,6 +240,18 @@ class Points(_PointSet):
     def get_point(self, index):   # src/api/points.cpp:128-130
         f = [self._field(k)[index] for k in range(7)]
         return Point(f[0], f[1], f[2], f[3], self._type, f[4], f[5], f[6])
+
+    def get_in_domain_indices(self, grid):   # src/api/points.cpp:77-92: the points some grid box encloses (Grid::get_box)
+        if self._n == 0 or grid._n == 0:
+            return np.zeros(0, np.int32)
+        lats, lons = np.ascontiguousarray(self.get_lats(), np.float32), np.ascontiguousarray(self.get_lons(), np.float32)
+        inside, boxes = np.zeros(self._n, np.int32), np.zeros(4 * self._n, np.int32)
+        check(lib().gpp_grid_get_box(grid._h, _ptr(lats), _ptr(lons), self._n, _ptr(inside), _ptr(boxes)))
+        return np.nonzero(inside)[0].astype(np.int32)
+
+    def get_in_domain(self, grid):           # points.cpp:93-109 (the new set is built with the default coordinate type)
+        idx = self.get_in_domain_indices(grid)
+        return Points(self.get_lats()[idx], self.get_lons()[idx], self.get_elevs()[idx], self.get_lafs()[idx])
 
     def subset(self, indices):
         indices = np.asarray(indices, np.int64)
@@ -371,6 +386,16 @@ class Grid(_PointSet):
     def get_num_neighbours(self, lat, lon, radius, include_match=True):
         return len(self._neighbours(lat, lon, radius, include_match))
 
+    def get_neighbours_with_distance(self, lat, lon, radius, include_match=True):   # grid.cpp:62-66
+        idx, dist = self._neighbours(lat, lon, radius, include_match, True)
+        ij = np.stack([idx // self._nx, idx % self._nx], axis=1).astype(np.int32) if idx.size else np.zeros((0, 2), np.int32)
+        return ij, dist
+
+    def get_point(self, y_index, x_index):   # grid.cpp:230-233
+        i = int(y_index) * self._nx + int(x_index)
+        f = [self._field(k)[i] for k in range(7)]
+        return Point(f[0], f[1], f[2], f[3], self._type, f[4], f[5], f[6])
+
     def get_box(self, lat, lon):   # grid.cpp:149-229 -> [inside, Y1, X1, Y2, X2] (swig/gridpp.i:73-76 OUTPUT ints)
         qlat, qlon = np.array([lat], np.float32), np.array([lon], np.float32)
         inside, box = np.zeros(1, np.int32), np.zeros(4, np.int32)
@@ -379,6 +404,14 @@ class Grid(_PointSet):
 
     def to_points(self):   # grid.cpp:131-145
         return Points(self._field(0), self._field(1), self._field(2), self._field(3), self._type)
+
+
+# SWIG's flat names of the static KDTree methods (the reference's tests use them: tests/test_kdtree.py:56-58,111-112)
+KDTree_calc_distance = KDTree.calc_distance
+KDTree_calc_distance_fast = KDTree.calc_distance_fast
+KDTree_calc_straight_distance = KDTree.calc_straight_distance
+KDTree_deg2rad = KDTree.deg2rad
+KDTree_rad2deg = KDTree.rad2deg
 
 
 # ---- structure functions (include/gridpp.h:2069-2343, src/api/structure.cpp) -----------------------

@@ -653,6 +653,37 @@ def pin_distance(g, G):
         np.testing.assert_array_almost_equal(g.distance(grid, points, int(num)), expected, e["places"])
 
 
+def pin_containers_next(g, G):
+    e = G["containers_next"]
+    c = e["in_domain"]
+    lons, lats = np.meshgrid(c["axis"], c["axis"])
+    grid = g.Grid(lats, lons)
+    points = g.Points(c["lats"], c["lons"])
+    np.testing.assert_array_equal(points.get_in_domain_indices(grid), c["inside"])
+    sub = points.get_in_domain(grid)
+    np.testing.assert_array_equal(np.sort(sub.get_lats()), np.sort(np.array(c["lats"], np.float32)[c["inside"]]))
+    np.testing.assert_array_equal(np.sort(sub.get_lons()), np.sort(np.array(c["lons"], np.float32)[c["inside"]]))
+    assert len(g.Points([], []).get_in_domain_indices(grid)) == 0
+    assert len(g.Points([0], [0]).get_in_domain_indices(g.Grid())) == 0
+    c = e["grid_with_distance"]
+    cg = g.Grid(c["lats"], c["lons"], np.zeros([3, 2]), np.zeros([3, 2]), g.Cartesian)
+    indices, distances = cg.get_neighbours_with_distance(*c["q"])
+    assert len(indices) == 4
+    np.testing.assert_array_almost_equal(np.sort(distances), c["distances"], 4)
+    c = e["grid_get_point"]
+    p = g.Grid(c["lats"], c["lons"], c["elevs"], c["lafs"]).get_point(*c["yx"])
+    for k, v in c["expected"].items():
+        assert getattr(p, k) == v
+    ok, x, y, z = g.convert_coordinates(c["expected"]["lat"], c["expected"]["lon"], g.Geodetic)
+    assert (p.x, p.y, p.z) == (x, y, z)
+    c = e["distance_limit"]
+    p0, p1 = g.Point(c["args"][0], c["args"][1]), g.Point(c["args"][2], c["args"][3])
+    assert abs(g.KDTree_calc_distance(*c["args"]) - c["expected"]) < 5e-8      # assertAlmostEqual: 7 places
+    assert abs(g.KDTree_calc_straight_distance(p0.x, p0.y, p0.z, p1.x, p1.y, p1.z) - c["expected"]) < 5e-8
+    for rad, deg in e["rad2deg"]:
+        assert abs(g.KDTree_rad2deg(rad) - deg) < 1e-4
+
+
 def pin_bilinear(g, G):
     import pytest
     e = G["bilinear_simple"]

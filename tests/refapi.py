@@ -42,6 +42,21 @@ class Points:
     def get_nearest_neighbour(self, lat, lon, include_match=True):
         return O.nearest_neighbour(self.p, lat, lon, include_match)
 
+    def get_lats(self):
+        return self.p.lats
+
+    def get_lons(self):
+        return self.p.lons
+
+    def get_in_domain_indices(self, grid):       # src/api/points.cpp:77-92
+        if self.p.n == 0 or grid.p.n == 0:
+            return np.zeros(0, np.int32)
+        return np.array([s for s in range(self.p.n) if grid.get_box(float(self.p.lats[s]), float(self.p.lons[s]))[0]], np.int32)
+
+    def get_in_domain(self, grid):               # points.cpp:93-109
+        i = self.get_in_domain_indices(grid)
+        return Points(self.p.lats[i], self.p.lons[i], self.p.elevs[i], self.p.lafs[i])
+
 
 KDTree = Points
 
@@ -62,6 +77,18 @@ class Grid:
 
     def to_points(self):
         return Points(self.p.lats, self.p.lons, self.p.elevs, self.p.lafs, self.type)
+
+    def get_point(self, y, x):                   # src/api/grid.cpp:230-233
+        i = y * self.shape[1] + x
+        q = Point(self.p.lats[i], self.p.lons[i], self.p.elevs[i], self.p.lafs[i], self.type)
+        q.x, q.y, q.z = float(self.p.x[i]), float(self.p.y[i]), float(self.p.z[i])
+        return q
+
+    def get_neighbours_with_distance(self, lat, lon, radius, include_match=True):   # grid.cpp:62-66
+        idx = O.get_neighbours(self.p, lat, lon, radius, include_match)
+        qx, qy, qz = O.convert_coordinates([lat], [lon], self.type)
+        d = np.array([O.lib().orc_calc_straight_distance(self.p.x[i], self.p.y[i], self.p.z[i], qx[0], qy[0], qz[0]) for i in idx], np.float32)
+        return np.stack([idx // self.shape[1], idx % self.shape[1]], axis=1) if len(idx) else np.zeros((0, 2), np.int32), d
 
     def get_box(self, lat, lon):
         return O.get_box(self.p, tuple(self.shape) if self.p.n else (0, 0), lat, lon)
@@ -387,3 +414,22 @@ calc_even_quantiles = O.calc_even_quantiles
 
 def is_valid(v):
     return bool(O.lib().orc_is_valid(O.C.c_float(v)))
+
+
+def convert_coordinates(lats, lons, type=Geodetic):
+    if np.isscalar(lats):
+        x, y, z = O.convert_coordinates([lats], [lons], type)
+        return True, float(x[0]), float(y[0]), float(z[0])
+    return O.convert_coordinates(lats, lons, type)
+
+
+def KDTree_calc_distance(lat1, lon1, lat2, lon2, type=Geodetic):
+    return float(O.lib().orc_calc_distance(lat1, lon1, lat2, lon2, type))
+
+
+def KDTree_calc_straight_distance(x0, y0, z0, x1, y1, z1):
+    return float(O.lib().orc_calc_straight_distance(x0, y0, z0, x1, y1, z1))
+
+
+def KDTree_rad2deg(rad):
+    return float(np.float32(np.float64(np.float32(rad)) * 180 / np.pi))      # src/api/kdtree.cpp:198-200

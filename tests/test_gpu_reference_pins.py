@@ -13,7 +13,7 @@ IMPLEMENTED = [
     "pin_oi_extrapolation", "pin_oi_no_obs", "pin_radius_queries", "pin_invalid_coords", "pin_nearest",
     "pin_neighbourhood", "pin_neighbourhood_invalid", "pin_neighbourhood_3d_and_overflow", "pin_neighbourhood_quantile",
     "pin_neighbourhood_quantile_fast", "pin_thresholds", "pin_util", "pin_ensi", "pin_structures", "pin_oi_cross_validation",
-    "pin_nearest_overloads", "pin_gridding", "pin_count", "pin_distance", "pin_fill", "pin_doping", "pin_neighbourhood_search", "pin_calc_gradient", "pin_bilinear", "pin_bilinear_shapes", "pin_bilinear_missing_and_grids", "pin_point_in_rectangle", "pin_grid_get_box",
+    "pin_nearest_overloads", "pin_containers_next", "pin_gridding", "pin_count", "pin_distance", "pin_fill", "pin_doping", "pin_neighbourhood_search", "pin_calc_gradient", "pin_bilinear", "pin_bilinear_shapes", "pin_bilinear_missing_and_grids", "pin_point_in_rectangle", "pin_grid_get_box",
 ]
 
 
