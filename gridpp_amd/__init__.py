@@ -13,6 +13,8 @@ library) or torch CUDA tensors (device path: the kernels read/write the tensors'
 HBM directly and a torch tensor is returned).
 """
 import ctypes as C
+import os
+import weakref
 
 import numpy as np
 
@@ -97,11 +99,52 @@ def _shape(a):
     return tuple(a.shape)
 
 
+class _PinnedPool:
+    """Result arrays of 1 MiB and more live in page-locked host memory (gpp_host_alloc): the device-to-host copy is then one
+    DMA transfer.  Buffers return to a free list when their numpy array dies (up to 2 GiB are kept for reuse)."""
+    MIN_BYTES, KEEP_BYTES = 1 << 20, 2 << 30
+
+    def __init__(self):
+        self.free, self.kept = {}, 0
+
+    def take(self, nbytes):
+        lst = self.free.get(nbytes)
+        if lst:
+            self.kept -= nbytes
+            return lst.pop()
+        ptr = C.c_void_p()
+        if lib().gpp_host_alloc(nbytes, C.byref(ptr)) != _capi.GPP_OK or not ptr.value:
+            return None
+        return ptr.value
+
+    def give(self, ptr, nbytes):
+        if self.kept + nbytes <= self.KEEP_BYTES:
+            self.free.setdefault(nbytes, []).append(ptr)
+            self.kept += nbytes
+        else:
+            lib().gpp_host_free(C.c_void_p(ptr))
+
+
+_pinned = _PinnedPool()
+
+
+def _host_empty(shape):
+    n = int(np.prod(shape))
+    if 4 * n < _PinnedPool.MIN_BYTES or os.environ.get("GPP_PAGEABLE_RESULTS"):
+        return np.empty(shape, dtype=np.float32)
+    ptr = _pinned.take(4 * n)
+    if ptr is None:
+        return np.empty(shape, dtype=np.float32)
+    buf = (C.c_float * n).from_address(ptr)
+    weakref.finalize(buf, _pinned.give, ptr, 4 * n)
+    return np.frombuffer(buf, dtype=np.float32).reshape(shape)     # the array keeps `buf` alive
+
+
 def _empty_like_field(shape, like):
     if _is_dev(like):
         import torch
         return torch.empty(shape, dtype=torch.float32, device=like.device)
-    return np.empty(shape, dtype=np.float32)
+    return _host_empty(shape)
 
 
 def _mem(*arrays):

@@ -35,6 +35,8 @@ SIGNATURES = {
     "gpp_set_device": [C.c_int],
     "gpp_get_stream": [C.POINTER(vp)],
     "gpp_synchronize": [],
+    "gpp_host_alloc": [C.c_size_t, C.POINTER(vp)],
+    "gpp_host_free": [vp],
     "gpp_points_create": [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)],
     "gpp_grid_create": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "gpp_points_destroy": [vp],

@@ -76,6 +76,24 @@ extern "C" int gpp_get_stream(void** s) {
     return GPP_OK;
     GPP_CATCH
 }
+// Page-locked host memory for result arrays: a device-to-host copy into it is one DMA transfer at link speed, while a copy
+// into freshly allocated pageable memory is bounded by its first-touch page faults (measured: 64 MB in 7 ms, i.e. 9 GB/s).
+extern "C" int gpp_host_alloc(size_t bytes, void** out) {
+    GPP_TRY
+    if(!out) invalid("NULL argument");
+    ensure_device();
+    *out = nullptr;
+    GPP_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_host_free(void* p) {
+    GPP_TRY
+    if(p) GPP_HIP(hipHostFree(p));
+    return GPP_OK;
+    GPP_CATCH
+}
+
 extern "C" int gpp_synchronize(void) {
     GPP_TRY
     GPP_HIP(hipStreamSynchronize(stream()));

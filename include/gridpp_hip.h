@@ -62,6 +62,11 @@ int gpp_device_count(int* count);
 int gpp_set_device(int device);           /* one process per GPU: call once with LOCAL_RANK */
 int gpp_get_stream(void** hip_stream);    /* the hipStream_t all kernels are launched on */
 int gpp_synchronize(void);
+/* Page-locked host buffers for results (optional): a caller that hands such a buffer as `out` of a GPP_MEM_HOST call gets
+ * the device-to-host copy as one DMA transfer instead of a staged copy into pageable memory.  The python mirror returns its
+ * large results in such buffers (the reference returns freshly allocated numpy arrays, swig/vector.i:172-180). */
+int gpp_host_alloc(size_t bytes, void** out);
+int gpp_host_free(void* p);
 
 /* ---- point sets: gridpp::Points / gridpp::Grid / gridpp::KDTree ----------
  * replaces gridpp::Points::Points (src/api/points.cpp:9-31),
