@@ -101,6 +101,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     dist = None
+    # GPP_BENCH_SHARE_GPU=1 + GPP_BENCH_BACKEND=gloo: every rank on GPU 0, exchange over gloo -- only to exercise the N > 1 rank
+    # logic on a one-GPU box (RCCL refuses two ranks on one device); never the measured configuration
+    share = os.environ.get("GPP_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     gridpp.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -108,7 +113,11 @@ def main():
     if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("GPP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     ny, nx, S, seed = args.ny, args.nx, args.obs, 1002
     row0, row1 = ny * rank // world, ny * (rank + 1) // world      # contiguous row tile of this rank
