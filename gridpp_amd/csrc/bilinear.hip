@@ -178,6 +178,7 @@ __global__ void k_in_rectangle(const float* p, int* out) {
 
 void gpp_points::latlon_to_device() {
     if(latlon_on_device) return;
+    ensure_host_fields();
     d_lat.upload(lats.data(), n);
     d_lon.upload(lons.data(), n);
     GPP_HIP(hipStreamSynchronize(stream()));

@@ -113,6 +113,13 @@ struct gpp_points {
     void latlon_to_device();
     bool host_xyz = true;            // x, y, z are present on the host (large sets are converted on the device and
     void ensure_host_xyz();          // downloaded only when a host-side function asks for them)
+    // large sets keep lats / lons / elevs / lafs in HBM only (d_lat, d_lon, d_elev, d_laf): the four host vectors are filled by
+    // ensure_host_fields() the first time a host-side function asks for them (a 4000 x 4000 grid would otherwise spend most of
+    // its construction time page-faulting 256 MB of copies nobody reads)
+    bool host_fields = true;
+    void ensure_host_fields();
+    float lat_at(int i);             // single elements without materialising the vectors
+    float lon_at(int i);
     bool elev_uniform = true, laf_uniform = true;   // every point has the same elevation / laf (or none has one)
     // memo of the last OI call with this point set as the background: did k_oi_union pay? (same observations handle and
     // structure scales -> same geometry -> same answer; the observation VALUES do not matter)

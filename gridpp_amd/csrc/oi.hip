@@ -116,6 +116,7 @@ gpp_obs_index* gpp_build_obs_index(gpp_points* pts) {
     if(pts->obs_index) return pts->obs_index;
     if(pts->n >= (1 << 17) && !getenv("GPP_HOST_INDEX")) return build_obs_index_device(pts);
     pts->ensure_host_xyz();
+    pts->ensure_host_fields();
     std::unique_ptr<gpp_obs_index> ix(new gpp_obs_index);
     int S = pts->n;
     ix->S = S;
@@ -177,7 +178,7 @@ int gpp_tile_wshift(gpp_points* g) {
     if(getenv("GPP_TILE_WSHIFT")) return std::max(0, std::min(6, atoi(getenv("GPP_TILE_WSHIFT"))));
     if(g->ny < 2 || g->nx < 2) return g->nx >= 64 ? 6 : 3;
     // metric size of a cell from the three corner points (0,0), (0,1), (1,0), in the library's own coordinates
-    const float la[3] = {g->lats[0], g->lats[1], g->lats[g->nx]}, lo[3] = {g->lons[0], g->lons[1], g->lons[g->nx]};
+    const float la[3] = {g->lat_at(0), g->lat_at(1), g->lat_at(g->nx)}, lo[3] = {g->lon_at(0), g->lon_at(1), g->lon_at(g->nx)};
     float x[3], y[3], z[3];
     if(gpp_convert_coordinates(la, lo, 3, g->type, x, y, z) != GPP_OK) return 3;
     auto dist = [&](int i) { return std::sqrt((double)(x[i] - x[0]) * (x[i] - x[0]) + (double)(y[i] - y[0]) * (y[i] - y[0]) + (double)(z[i] - z[0]) * (z[i] - z[0])); };
@@ -826,7 +827,10 @@ DevStructure gpp_resolve_structure(const gpp_structure* s) {
 // field index (nearest neighbour in the field's grid, src/api/structure.cpp:190) of every point of `pts`; NULL = identity
 static const int* field_indices(const gpp_field* f, gpp_points* pts, DevBuf<int>& buf) {
     if(f->grid == pts) return nullptr;
-    if(f->grid->n == pts->n && f->grid->type == pts->type && f->grid->lats == pts->lats && f->grid->lons == pts->lons) return nullptr;
+    if(f->grid->n == pts->n && f->grid->type == pts->type) {
+        f->grid->ensure_host_fields(); pts->ensure_host_fields();
+        if(f->grid->lats == pts->lats && f->grid->lons == pts->lons) return nullptr;
+    }
     pts->to_device();
     buf.get(pts->n);
     gpp_nearest_device(f->grid, pts->d_x.p, pts->d_y.p, pts->d_z.p, pts->n, 1, buf.p);

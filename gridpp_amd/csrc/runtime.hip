@@ -188,16 +188,17 @@ __global__ void k_patch(const int* __restrict__ idx, const float* __restrict__ v
     x[i] = v[3 * k]; y[i] = v[3 * k + 1]; z[i] = v[3 * k + 2];
 }
 // returns false when the device result cannot be trusted (too many boundary cases): the caller converts on the host
-static bool convert_all_device(gpp_points* p) {
+// lats / lons: the caller's arrays (they become the persistent d_lat / d_lon of the set)
+static bool convert_all_device(gpp_points* p, const float* lats, const float* lons) {
     const int n = p->n;
-    DevBuf<float> d_lat, d_lon;
     DevBuf<int> d_flag, d_cnt;
     const int cap = 1 << 16;
-    d_lat.upload(p->lats.data(), n); d_lon.upload(p->lons.data(), n);
+    p->d_lat.upload(lats, n); p->d_lon.upload(lons, n);
+    p->latlon_on_device = true;
     p->d_x.get(n); p->d_y.get(n); p->d_z.get(n);
     d_flag.get(cap); d_cnt.get(2);
     GPP_HIP(hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(int), stream()));
-    hipLaunchKernelGGL(k_convert, dim3((n + 255) / 256), dim3(256), 0, stream(), d_lat.p, d_lon.p, n, p->type, p->d_x.p, p->d_y.p, p->d_z.p, d_flag.p, cap, d_cnt.p);
+    hipLaunchKernelGGL(k_convert, dim3((n + 255) / 256), dim3(256), 0, stream(), p->d_lat.p, p->d_lon.p, n, p->type, p->d_x.p, p->d_y.p, p->d_z.p, d_flag.p, cap, d_cnt.p);
     GPP_HIP(hipGetLastError());
     int cnt[2] = {0, 0};
     GPP_HIP(hipMemcpyAsync(cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost, stream()));
@@ -209,7 +210,7 @@ static bool convert_all_device(gpp_points* p) {
         GPP_HIP(hipMemcpy(idx.data(), d_flag.p, sizeof(int) * cnt[0], hipMemcpyDeviceToHost));
         std::vector<float> v(3 * (size_t)cnt[0]);
         for(int k = 0; k < cnt[0]; k++) {
-            float lat = p->lats[idx[k]], lon = p->lons[idx[k]];
+            float lat = lats[idx[k]], lon = lons[idx[k]];
             convert_range(&lat, &lon, 0, 1, p->type, &v[3 * k], &v[3 * k + 1], &v[3 * k + 2]);
         }
         DevBuf<float> d_v;
@@ -238,10 +239,33 @@ void gpp_points::to_device() {
         d_y.upload(y.data(), n);
         d_z.upload(z.data(), n);
     }
-    d_elev.upload(elevs.data(), n);
-    d_laf.upload(lafs.data(), n);
+    if(host_fields) {   // (otherwise make_points put them there)
+        d_elev.upload(elevs.data(), n);
+        d_laf.upload(lafs.data(), n);
+    }
     GPP_HIP(hipStreamSynchronize(gpp::stream()));
     on_device = true;
+}
+void gpp_points::ensure_host_fields() {
+    if(host_fields) return;
+    lats.resize(n); lons.resize(n); elevs.resize(n); lafs.resize(n);
+    GPP_HIP(hipMemcpy(lats.data(), d_lat.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    GPP_HIP(hipMemcpy(lons.data(), d_lon.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    GPP_HIP(hipMemcpy(elevs.data(), d_elev.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    GPP_HIP(hipMemcpy(lafs.data(), d_laf.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    host_fields = true;
+}
+float gpp_points::lat_at(int i) {
+    if(host_fields) return lats[i];
+    float v;
+    GPP_HIP(hipMemcpy(&v, d_lat.p + i, sizeof(float), hipMemcpyDeviceToHost));
+    return v;
+}
+float gpp_points::lon_at(int i) {
+    if(host_fields) return lons[i];
+    float v;
+    GPP_HIP(hipMemcpy(&v, d_lon.p + i, sizeof(float), hipMemcpyDeviceToHost));
+    return v;
 }
 void gpp_free_obs_index(gpp_obs_index*);
 struct gpp_nn_index { int unused; };
@@ -251,39 +275,54 @@ gpp_points::~gpp_points() {
     if(nn_index) gpp_free_nn_index(nn_index);
 }
 
+__global__ void k_fill_f(float* out, int n, float v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = v;
+}
 static gpp_points* make_points(const float* lats, const float* lons, const float* elevs, const float* lafs, int n, int ny, int nx, int type) {
     if(n < 0) invalid("negative size");
     if(n > 0 && (!lats || !lons)) invalid("lats/lons are NULL");
     std::unique_ptr<gpp_points> p(new gpp_points);
     p->n = n; p->ny = ny; p->nx = nx; p->type = type;
-    p->lats.assign(lats, lats + n);
-    p->lons.assign(lons, lons + n);
-    if(elevs) p->elevs.assign(elevs, elevs + n); else p->elevs.assign(n, NAN);   // points.cpp:23-30, grid.cpp:41-54
-    if(lafs) p->lafs.assign(lafs, lafs + n); else p->lafs.assign(n, NAN);
     // do the vertical / land-area-fraction factors of a structure function vary over this point set at all?
-    auto uniform = [](const std::vector<float>& v) {   // all invalid, or all valid and equal
-        if(v.empty()) return true;
+    auto uniform = [](const float* v, int m) {   // absent (all NaN: points.cpp:23-30, grid.cpp:41-54), all invalid, or all valid and equal
+        if(!v || m == 0) return true;
         const bool inv0 = std::isnan(v[0]) || std::isinf(v[0]);
-        for(float e : v) {
+        for(int i = 0; i < m; i++) {
+            const float e = v[i];
             const bool inv = std::isnan(e) || std::isinf(e);
             if(inv != inv0 || (!inv && e != v[0])) return false;
         }
         return true;
     };
-    p->elev_uniform = uniform(p->elevs); p->laf_uniform = uniform(p->lafs);
-    // large sets: conversion on the device (the host copies of x / y / z are made only if a host-side function needs them)
+    p->elev_uniform = uniform(elevs, n); p->laf_uniform = uniform(lafs, n);
+    // large sets: conversion on the device straight from the caller's arrays; neither x / y / z nor the four fields get a host
+    // copy unless a host-side function asks for one
     bool done = false;
     if(n >= (1 << 16) && !getenv("GPP_HOST_CONVERT")) {
         if(type != GPP_GEODETIC && type != GPP_CARTESIAN) invalid("Unknown coordinate type");
         ensure_device();
         p->host_xyz = false;
-        done = convert_all_device(p.get());
-        if(!done) p->host_xyz = true;
+        done = convert_all_device(p.get(), lats, lons);
+        if(!done) { p->host_xyz = true; p->latlon_on_device = false; }
     }
-    if(!done) {
-        p->x.resize(n); p->y.resize(n); p->z.resize(n);
-        convert_all(p->lats.data(), p->lons.data(), n, type, p->x.data(), p->y.data(), p->z.data());
+    if(done) {
+        p->host_fields = false;
+        if(elevs) p->d_elev.upload(elevs, n);
+        else { p->d_elev.get(n); hipLaunchKernelGGL(k_fill_f, dim3((n + 255) / 256), dim3(256), 0, stream(), p->d_elev.p, n, NAN); }
+        if(lafs) p->d_laf.upload(lafs, n);
+        else { p->d_laf.get(n); hipLaunchKernelGGL(k_fill_f, dim3((n + 255) / 256), dim3(256), 0, stream(), p->d_laf.p, n, NAN); }
+        GPP_HIP(hipGetLastError());
+        GPP_HIP(hipStreamSynchronize(stream()));   // the caller's arrays may go away after this call
+        p->on_device = true;
+        return p.release();
     }
+    p->lats.assign(lats, lats + n);
+    p->lons.assign(lons, lons + n);
+    if(elevs) p->elevs.assign(elevs, elevs + n); else p->elevs.assign(n, NAN);
+    if(lafs) p->lafs.assign(lafs, lafs + n); else p->lafs.assign(n, NAN);
+    p->x.resize(n); p->y.resize(n); p->z.resize(n);
+    convert_all(p->lats.data(), p->lons.data(), n, type, p->x.data(), p->y.data(), p->z.data());
     return p.release();
 }
 
@@ -324,6 +363,7 @@ extern "C" int gpp_points_get(const gpp_points* p, int field, float* out) {
     if(!p) invalid("points is NULL");
     const std::vector<float>* v = nullptr;
     if(field >= 4) const_cast<gpp_points*>(p)->ensure_host_xyz();
+    else const_cast<gpp_points*>(p)->ensure_host_fields();
     switch(field) {
         case 0: v = &p->lats; break;
         case 1: v = &p->lons; break;
