@@ -186,6 +186,21 @@ def convert_coordinates(lats, lons, type=Geodetic):
     return x, y, z
 
 
+def _is_big_f64(*arrays):
+    """float64 numpy coordinate arrays of a large set: handed to the C-ABI as they are and cast to float32 on the device
+    (numpy's astype on 16 M doubles takes longer than building the whole Grid)"""
+    return all(isinstance(a, np.ndarray) and a.dtype == np.float64 for a in arrays) and arrays[0].size >= (1 << 16)
+
+
+def _vec64(a, ndim, name):
+    arr = np.ascontiguousarray(np.asarray(a), dtype=np.float64)
+    if arr.ndim != ndim:
+        if arr.size == 0 and arr.ndim <= ndim:
+            return arr.reshape((0,) * ndim)
+        raise RuntimeError("%s must have %d dimensions, got %d" % (name, ndim, arr.ndim))
+    return arr
+
+
 class _PointSet:
     """Owns a gpp_points handle (x/y/z resident in HBM)."""
     _h = None
@@ -236,8 +251,10 @@ class Points(_PointSet):
     """include/gridpp.h:1876-1968, src/api/points.cpp"""
 
     def __init__(self, lats=(), lons=(), elevs=(), lafs=(), type=Geodetic):
-        lats, lons = _vec(lats, 1, "lats"), _vec(lons, 1, "lons")
-        elevs, lafs = _vec(elevs, 1, "elevs"), _vec(lafs, 1, "lafs")
+        f64 = _is_big_f64(lats, lons)
+        vec = _vec64 if f64 else _vec
+        lats, lons = vec(lats, 1, "lats"), vec(lons, 1, "lons")
+        elevs, lafs = vec(elevs, 1, "elevs"), vec(lafs, 1, "lafs")
         n = lats.size
         if lons.size != n:
             raise ValueError("Cannot create points with unequal lat and lon sizes")
@@ -246,8 +263,9 @@ class Points(_PointSet):
         if lafs.size not in (0, n):
             raise ValueError("'lafs' must either be size 0 or the same size at lats/lons")
         h = C.c_void_p()
-        check(lib().gpp_points_create(_ptr(lats), _ptr(lons), _ptr(elevs) if elevs.size == n and n else None,
-                                      _ptr(lafs) if lafs.size == n and n else None, n, type, C.byref(h)))
+        create = lib().gpp_points_create_f64 if f64 else lib().gpp_points_create
+        check(create(_ptr(lats), _ptr(lons), _ptr(elevs) if elevs.size == n and n else None,
+                     _ptr(lafs) if lafs.size == n and n else None, n, type, C.byref(h)))
         self._h, self._n, self._type = h, n, type
 
     def size(self):
@@ -381,8 +399,10 @@ class Grid(_PointSet):
     """include/gridpp.h:1971-2060, src/api/grid.cpp"""
 
     def __init__(self, lats=((),), lons=((),), elevs=((),), lafs=((),), type=Geodetic):
-        lats, lons = _vec(lats, 2, "lats"), _vec(lons, 2, "lons")
-        elevs, lafs = _vec(elevs, 2, "elevs"), _vec(lafs, 2, "lafs")
+        f64 = _is_big_f64(lats, lons)
+        vec = _vec64 if f64 else _vec
+        lats, lons = vec(lats, 2, "lats"), vec(lons, 2, "lons")
+        elevs, lafs = vec(elevs, 2, "elevs"), vec(lafs, 2, "lafs")
         if lats.shape != lons.shape:
             raise ValueError("lats and lons must have the same shape")
         ny, nx = lats.shape
@@ -391,7 +411,8 @@ class Grid(_PointSet):
         e = elevs if elevs.shape == lats.shape and elevs.size else None   # grid.cpp:41-54
         l = lafs if lafs.shape == lats.shape and lafs.size else None
         h = C.c_void_p()
-        check(lib().gpp_grid_create(_ptr(lats), _ptr(lons), _ptr(e), _ptr(l), ny, nx, type, C.byref(h)))
+        create = lib().gpp_grid_create_f64 if f64 else lib().gpp_grid_create
+        check(create(_ptr(lats), _ptr(lons), _ptr(e), _ptr(l), ny, nx, type, C.byref(h)))
         self._h, self._n, self._ny, self._nx, self._type = h, ny * nx, ny, nx, type
 
     def size(self):

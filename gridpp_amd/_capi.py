@@ -39,6 +39,8 @@ SIGNATURES = {
     "gpp_host_free": [vp],
     "gpp_points_create": [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)],
     "gpp_grid_create": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+    "gpp_points_create_f64": [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)],
+    "gpp_grid_create_f64": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "gpp_points_destroy": [vp],
     "gpp_points_size": [vp, ip, ip, ip, ip],
     "gpp_points_get": [vp, C.c_int, vp],

@@ -188,12 +188,27 @@ __global__ void k_patch(const int* __restrict__ idx, const float* __restrict__ v
     x[i] = v[3 * k]; y[i] = v[3 * k + 1]; z[i] = v[3 * k + 2];
 }
 // returns false when the device result cannot be trusted (too many boundary cases): the caller converts on the host
+__global__ void k_cast_f64(const double* __restrict__ in, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = (float)in[i];   // the rounding numpy's astype(float32) / PyArray_CastToType does (swig/vector.i:42-55)
+}
+// host array (float or double) -> float buffer in HBM
+static void upload_as_float(DevBuf<float>& dst, const float* src, int n) { dst.upload(src, n); }
+static void upload_as_float(DevBuf<float>& dst, const double* src, int n) {
+    DevBuf<double> tmp;
+    tmp.upload(src, n);
+    dst.get(n);
+    hipLaunchKernelGGL(k_cast_f64, dim3((n + 255) / 256), dim3(256), 0, stream(), tmp.p, n, dst.p);
+    GPP_HIP(hipGetLastError());
+    GPP_HIP(hipStreamSynchronize(stream()));   // tmp dies here
+}
 // lats / lons: the caller's arrays (they become the persistent d_lat / d_lon of the set)
-static bool convert_all_device(gpp_points* p, const float* lats, const float* lons) {
+template <class T>
+static bool convert_all_device(gpp_points* p, const T* lats, const T* lons) {
     const int n = p->n;
     DevBuf<int> d_flag, d_cnt;
     const int cap = 1 << 16;
-    p->d_lat.upload(lats, n); p->d_lon.upload(lons, n);
+    upload_as_float(p->d_lat, lats, n); upload_as_float(p->d_lon, lons, n);
     p->latlon_on_device = true;
     p->d_x.get(n); p->d_y.get(n); p->d_z.get(n);
     d_flag.get(cap); d_cnt.get(2);
@@ -210,7 +225,7 @@ static bool convert_all_device(gpp_points* p, const float* lats, const float* lo
         GPP_HIP(hipMemcpy(idx.data(), d_flag.p, sizeof(int) * cnt[0], hipMemcpyDeviceToHost));
         std::vector<float> v(3 * (size_t)cnt[0]);
         for(int k = 0; k < cnt[0]; k++) {
-            float lat = lats[idx[k]], lon = lons[idx[k]];
+            float lat = (float)lats[idx[k]], lon = (float)lons[idx[k]];
             convert_range(&lat, &lon, 0, 1, p->type, &v[3 * k], &v[3 * k + 1], &v[3 * k + 2]);
         }
         DevBuf<float> d_v;
@@ -279,19 +294,21 @@ __global__ void k_fill_f(float* out, int n, float v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) out[i] = v;
 }
-static gpp_points* make_points(const float* lats, const float* lons, const float* elevs, const float* lafs, int n, int ny, int nx, int type) {
+template <class T>
+static gpp_points* make_points(const T* lats, const T* lons, const T* elevs, const T* lafs, int n, int ny, int nx, int type) {
     if(n < 0) invalid("negative size");
     if(n > 0 && (!lats || !lons)) invalid("lats/lons are NULL");
     std::unique_ptr<gpp_points> p(new gpp_points);
     p->n = n; p->ny = ny; p->nx = nx; p->type = type;
     // do the vertical / land-area-fraction factors of a structure function vary over this point set at all?
-    auto uniform = [](const float* v, int m) {   // absent (all NaN: points.cpp:23-30, grid.cpp:41-54), all invalid, or all valid and equal
+    auto uniform = [](const T* v, int m) {   // absent (all NaN: points.cpp:23-30, grid.cpp:41-54), all invalid, or all valid and equal
         if(!v || m == 0) return true;
-        const bool inv0 = std::isnan(v[0]) || std::isinf(v[0]);
+        const float first = (float)v[0];
+        const bool inv0 = std::isnan(first) || std::isinf(first);
         for(int i = 0; i < m; i++) {
-            const float e = v[i];
+            const float e = (float)v[i];
             const bool inv = std::isnan(e) || std::isinf(e);
-            if(inv != inv0 || (!inv && e != v[0])) return false;
+            if(inv != inv0 || (!inv && e != first)) return false;
         }
         return true;
     };
@@ -308,16 +325,16 @@ static gpp_points* make_points(const float* lats, const float* lons, const float
     }
     if(done) {
         p->host_fields = false;
-        if(elevs) p->d_elev.upload(elevs, n);
+        if(elevs) upload_as_float(p->d_elev, elevs, n);
         else { p->d_elev.get(n); hipLaunchKernelGGL(k_fill_f, dim3((n + 255) / 256), dim3(256), 0, stream(), p->d_elev.p, n, NAN); }
-        if(lafs) p->d_laf.upload(lafs, n);
+        if(lafs) upload_as_float(p->d_laf, lafs, n);
         else { p->d_laf.get(n); hipLaunchKernelGGL(k_fill_f, dim3((n + 255) / 256), dim3(256), 0, stream(), p->d_laf.p, n, NAN); }
         GPP_HIP(hipGetLastError());
         GPP_HIP(hipStreamSynchronize(stream()));   // the caller's arrays may go away after this call
         p->on_device = true;
         return p.release();
     }
-    p->lats.assign(lats, lats + n);
+    p->lats.assign(lats, lats + n);      // (element-wise conversion to float for double sources)
     p->lons.assign(lons, lons + n);
     if(elevs) p->elevs.assign(elevs, elevs + n); else p->elevs.assign(n, NAN);
     if(lafs) p->lafs.assign(lafs, lafs + n); else p->lafs.assign(n, NAN);
@@ -334,6 +351,24 @@ extern "C" int gpp_points_create(const float* lats, const float* lons, const flo
     GPP_CATCH
 }
 extern "C" int gpp_grid_create(const float* lats, const float* lons, const float* elevs, const float* lafs, int ny, int nx, int type, gpp_points** out) {
+    GPP_TRY
+    if(!out) invalid("out is NULL");
+    if(ny < 0 || nx < 0) invalid("negative grid size");
+    if((long)ny * nx > 0x7fffffffL) invalid("grid too large");
+    *out = make_points(lats, lons, elevs, lafs, ny * nx, ny, nx, type);
+    return GPP_OK;
+    GPP_CATCH
+}
+// The same from float64 arrays (what numpy hands over by default): large sets are cast to float32 on the device, which costs one
+// upload instead of numpy's single-threaded astype on 8-byte elements
+extern "C" int gpp_points_create_f64(const double* lats, const double* lons, const double* elevs, const double* lafs, int n, int type, gpp_points** out) {
+    GPP_TRY
+    if(!out) invalid("out is NULL");
+    *out = make_points(lats, lons, elevs, lafs, n, 0, 0, type);
+    return GPP_OK;
+    GPP_CATCH
+}
+extern "C" int gpp_grid_create_f64(const double* lats, const double* lons, const double* elevs, const double* lafs, int ny, int nx, int type, gpp_points** out) {
     GPP_TRY
     if(!out) invalid("out is NULL");
     if(ny < 0 || nx < 0) invalid("negative grid size");

@@ -80,6 +80,12 @@ int gpp_points_create(const float* lats, const float* lons, const float* elevs, 
                       int n, int coordinate_type, gpp_points** out);
 int gpp_grid_create(const float* lats, const float* lons, const float* elevs, const float* lafs,
                     int ny, int nx, int coordinate_type, gpp_points** out);
+/* The same from float64 arrays (numpy's default dtype; the reference's typemap casts them to float32 on the host,
+ * swig/vector.i:42-55): the cast happens on the device for large sets. */
+int gpp_points_create_f64(const double* lats, const double* lons, const double* elevs, const double* lafs,
+                          int n, int coordinate_type, gpp_points** out);
+int gpp_grid_create_f64(const double* lats, const double* lons, const double* elevs, const double* lafs,
+                        int ny, int nx, int coordinate_type, gpp_points** out);
 int gpp_points_destroy(gpp_points* p);
 int gpp_points_size(const gpp_points* p, int* n, int* ny, int* nx, int* coordinate_type);
 /* field: 0 lat, 1 lon, 2 elev, 3 laf, 4 x, 5 y, 6 z; copies n floats to host `out` */

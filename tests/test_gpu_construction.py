@@ -55,3 +55,28 @@ def test_device_built_index_gives_the_same_nearest_neighbours():
     from oracle import oracle as O
     idx = O.nearest_indices(O.Pts(lats.ravel(), lons.ravel()), O.Pts(q.get_lats()[:300], q.get_lons()[:300]))
     np.testing.assert_array_equal(a[:300], values.ravel()[idx])
+
+
+def test_float64_inputs_are_cast_on_the_device_like_astype():
+    """Grid / Points from float64 arrays (numpy's default) take the f64 entry points above 65 536 points: the device cast must
+    give the float32 values numpy's astype gives, and from there the same coordinates as the float32 path."""
+    import gridpp_amd as gridpp
+    rng = np.random.default_rng(41)
+    Y, X = 300, 400
+    lats = 50 + 10 * rng.random((Y, X))
+    lons = -20 + 60 * rng.random((Y, X))
+    elevs = 2000 * rng.random((Y, X))
+    a = gridpp.Grid(lats, lons, elevs)                                   # float64 -> f64 entry point
+    b = gridpp.Grid(lats.astype(np.float32), lons.astype(np.float32), elevs.astype(np.float32))
+    for k in range(7):
+        np.testing.assert_array_equal(a._field(k), b._field(k))
+    np.testing.assert_array_equal(a.get_lafs(), b.get_lafs())            # absent: NaN on both
+    n = 100000
+    plat, plon = 50 + 10 * rng.random(n), -20 + 60 * rng.random(n)
+    pa, pb = gridpp.Points(plat, plon), gridpp.Points(plat.astype(np.float32), plon.astype(np.float32))
+    for k in (0, 1, 4, 5, 6):
+        np.testing.assert_array_equal(pa._field(k), pb._field(k))
+    q = (55.0, 3.0)
+    assert pa.get_nearest_neighbour(*q) == pb.get_nearest_neighbour(*q)
+    with pytest.raises(ValueError):
+        gridpp.Points(np.full(n, 95.0), plon)                            # invalid latitude is still reported
