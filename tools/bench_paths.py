@@ -100,7 +100,10 @@ def host_case():
     """The same calls from numpy buffers (GPP_MEM_HOST): what a user of the reference's API sees, PCIe both ways included."""
     ny = nx = 4000
     lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, 10000, 1002, 0, ny)
-    t0 = time.perf_counter(); grid = gridpp.Grid(lats, lons); t_grid = time.perf_counter() - t0
+    gridpp.Grid(lats[:300, :300], lons[:300, :300])          # first use of the device pays the runtime's start-up
+    lats64, lons64 = lats.astype(np.float64), lons.astype(np.float64)
+    t_grid = timeit(lambda: gridpp.Grid(lats64, lons64), reps=2, warm=0)
+    grid = gridpp.Grid(lats, lons)
     lats32, lons32 = lats.astype(np.float32), lons.astype(np.float32)
     t_grid32 = timeit(lambda: gridpp.Grid(lats32, lons32), reps=2, warm=0)
     points = gridpp.Points(plat, plon)
