@@ -72,14 +72,21 @@ def _is_dev(a):
     return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
 
 
-def _vec(a, ndim, name="array"):
-    """Any dtype -> C-contiguous float32; wrong ndim raises like the typemap (swig/vector.i:39-41)."""
+def _wants_f64(*fields):
+    """The large field arrays of a call are float64 numpy arrays: hand every input over as float64 (GPP_HOST_F64, cast on the
+    device) instead of paying numpy's astype on them."""
+    big = [a for a in fields if isinstance(a, np.ndarray) and a.size >= (1 << 20)]
+    return bool(big) and all(a.dtype == np.float64 for a in big)
+
+
+def _vec(a, ndim, name="array", dtype=np.float32):
+    """Any dtype -> C-contiguous float32 (float64 in a GPP_HOST_F64 call); wrong ndim raises like the typemap (swig/vector.i:39-41)."""
     if _is_dev(a):
         import torch
         if a.dim() != ndim:
             raise RuntimeError("%s must have %d dimensions" % (name, ndim))
         return a.contiguous().to(torch.float32)
-    arr = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    arr = np.ascontiguousarray(np.asarray(a), dtype=dtype)
     if arr.ndim != ndim:
         if arr.size == 0 and arr.ndim <= ndim:   # e.g. [] or [[]]
             return arr.reshape((0,) * ndim)
@@ -651,27 +658,31 @@ def _oi_common(bg, background, bvariance, points, pobs, obs_variance, pbackgroun
     if bg.get_coordinate_type() != points.get_coordinate_type():
         raise ValueError("Both background and observations points must be of same coordinate type (lat/lon or x/y)")
     nd = 2 if isinstance(bg, Grid) else 1
-    background = _vec(background, nd, "background")
+    f64 = _wants_f64(background, bvariance)
+    dt = np.float64 if f64 else np.float32
+    background = _vec(background, nd, "background", dt)
     shape = tuple(bg.size()) if nd == 2 else (bg.size(),)
     if _shape(background) != shape:
         raise ValueError("input field %s is not the same size as the grid %s" % (_shape(background), shape))
     if bvariance is not None:
-        bvariance = _vec(bvariance, nd, "bvariance")
+        bvariance = _vec(bvariance, nd, "bvariance", dt)
         if _shape(bvariance) != shape:
             raise ValueError("Input bvariance is not the same size as the grid")
     S = points.size()
-    pobs, obs_variance, pbackground = _vec(pobs, 1, "obs"), _vec(obs_variance, 1, "variance"), _vec(pbackground, 1, "background_at_points")
+    pobs, obs_variance, pbackground = _vec(pobs, 1, "obs", dt), _vec(obs_variance, 1, "variance", dt), _vec(pbackground, 1, "background_at_points", dt)
     for name, a in (("Observations", pobs), ("Ratios", obs_variance), ("Background", pbackground)):
         if _shape(a)[0] != S:
             raise ValueError("%s (%d) and points (%d) size mismatch" % (name, _shape(a)[0], S))
     if bvariance_at_points is not None:
-        bvariance_at_points = _vec(bvariance_at_points, 1, "bvariance_at_points")
+        bvariance_at_points = _vec(bvariance_at_points, 1, "bvariance_at_points", dt)
         if _shape(bvariance_at_points)[0] != S:
             raise ValueError("Background variance and points size mismatch")
     mem = _mem(background, bvariance, pobs, obs_variance, pbackground, bvariance_at_points)
     if mem == _capi.MEM_DEVICE:
         import torch
         torch.cuda.current_stream().synchronize()   # producers of the inputs ran on torch's stream
+    elif f64:
+        mem |= _capi.HOST_F64
     out = _empty_like_field(shape, background)
     var = _empty_like_field(shape, background) if want_variance else None
     check(lib().gpp_optimal_interpolation_full(bg._h, _ptr(background), _ptr(bvariance), points._h, _ptr(pobs),
@@ -710,7 +721,7 @@ def nearest(igrid, opoints, values):
         import torch
         values = values.contiguous().to(torch.float32)
     else:
-        values = np.ascontiguousarray(np.asarray(values), dtype=np.float32)
+        values = np.ascontiguousarray(np.asarray(values), dtype=np.float64 if _wants_f64(values) else np.float32)
         if values.size == 0 and values.ndim < nd:
             values = values.reshape((0,) * nd)
     shp = _shape(values)
@@ -734,6 +745,8 @@ def nearest(igrid, opoints, values):
         raise ValueError("Grid size is not the same as values")
     mem = _mem(values)
     _sync_if_dev(mem)
+    if not _is_dev(values) and values.dtype == np.float64:
+        mem |= _capi.HOST_F64
     check(lib().gpp_nearest_levels(igrid._h, opoints._h, _ptr(values), nt, _ptr(out), mem))
     return out
 
@@ -926,7 +939,7 @@ def bilinear(igrid, opoints, values):
         import torch
         values = values.contiguous().to(torch.float32)
     else:
-        values = np.ascontiguousarray(np.asarray(values), dtype=np.float32)
+        values = np.ascontiguousarray(np.asarray(values), dtype=np.float64 if _wants_f64(values) else np.float32)
     shp = _shape(values)
     if len(shp) not in (2, 3):
         raise RuntimeError("bilinear: values must be 2-D or 3-D")
@@ -944,6 +957,8 @@ def bilinear(igrid, opoints, values):
         raise ValueError("Grid size is not the same as values")   # nothing to read from (the reference would index past the end)
     mem = _mem(values)
     _sync_if_dev(mem)
+    if not _is_dev(values) and values.dtype == np.float64:
+        mem |= _capi.HOST_F64
     check(lib().gpp_bilinear(igrid._h, opoints._h, _ptr(values), nt, _ptr(out), mem))
     return out
 
@@ -956,13 +971,14 @@ def point_in_rectangle(A, B, C_, D, m):   # src/api/util.cpp:571-582
 
 
 # ---- neighbourhood filters (include/gridpp.h:588-716, src/api/neighbourhood.cpp) ---------------------
-def _field23(a, name="input"):
-    """2-D or 3-D field -> (array, ny, nx, ne, is3d); [[]] -> empty."""
+def _field23(a, name="input", keep_f64=False):
+    """2-D or 3-D field -> (array, ny, nx, ne, is3d); [[]] -> empty.  keep_f64: a large float64 array stays float64 (the caller
+    passes GPP_HOST_F64)."""
     if _is_dev(a):
         nd = a.dim()
         arr = _vec(a, nd, name)
     else:
-        arr = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+        arr = np.ascontiguousarray(np.asarray(a), dtype=np.float64 if keep_f64 and _wants_f64(a) else np.float32)
         nd = arr.ndim
     if nd not in (2, 3):
         if getattr(arr, "size", 1) == 0:
@@ -982,7 +998,7 @@ def _sync_if_dev(mem):
 
 def neighbourhood(input, halfwidth, statistic):
     """gridpp::neighbourhood for 2-D and 3-D (Y, X, E) input (src/api/neighbourhood.cpp:12-242)."""
-    arr, ny, nx, ne, is3d = _field23(input)
+    arr, ny, nx, ne, is3d = _field23(input, keep_f64=True)
     if halfwidth < 0:
         raise ValueError("Half width must be > 0")
     if statistic == Quantile:
@@ -991,6 +1007,8 @@ def neighbourhood(input, halfwidth, statistic):
         return np.zeros((0, 0), np.float32)
     mem = _mem(arr)
     _sync_if_dev(mem)
+    if not _is_dev(arr) and arr.dtype == np.float64:
+        mem |= _capi.HOST_F64
     out = _empty_like_field((ny, nx), arr)
     check(lib().gpp_neighbourhood(_ptr(arr), ny, nx, ne, is3d, int(halfwidth), int(statistic), _ptr(out), mem))
     return out

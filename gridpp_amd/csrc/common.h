@@ -67,12 +67,25 @@ struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
 
 // A field argument of the C-ABI resolved to a device pointer: either the caller's
 // HBM pointer (GPP_MEM_DEVICE) or a staged copy (GPP_MEM_HOST).
+static __global__ void k_stage_f64(const double* __restrict__ in, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = (float)in[i];   // the rounding of the reference's PyArray_CastToType (swig/vector.i:42-55)
+}
 struct InField {
     DevBuf<float> staged;
     const float* d = nullptr;
     void bind(const float* src, size_t n, int mem) {
         if(!src) { d = nullptr; return; }
         if(mem & GPP_MEM_DEVICE) d = src;
+        else if(mem & GPP_HOST_F64) {   // the host array holds doubles: one upload + a cast on the device
+            DevBuf<double> wide;
+            wide.upload(reinterpret_cast<const double*>(src), n);
+            staged.get(n);
+            if(n) hipLaunchKernelGGL(k_stage_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), wide.p, n, staged.p);
+            GPP_HIP(hipGetLastError());
+            GPP_HIP(hipStreamSynchronize(stream()));   // `wide` is released here
+            d = staged.p;
+        }
         else { staged.upload(src, n); d = staged.p; }
     }
 };

@@ -80,3 +80,29 @@ def test_float64_inputs_are_cast_on_the_device_like_astype():
     assert pa.get_nearest_neighbour(*q) == pb.get_nearest_neighbour(*q)
     with pytest.raises(ValueError):
         gridpp.Points(np.full(n, 95.0), plon)                            # invalid latitude is still reported
+
+
+def test_float64_field_inputs_equal_the_float32_path():
+    """GPP_HOST_F64: large float64 numpy fields are cast on the device; results must equal those of the same call on
+    astype(float32) inputs bit for bit (OI, neighbourhood 2-D / 3-D, nearest, bilinear)."""
+    import gridpp_amd as gridpp
+    rng = np.random.default_rng(43)
+    Y = X = 1100                                         # > 2^20 cells: the float64 route
+    lats, lons = np.meshgrid(np.linspace(59, 60, Y), np.linspace(10, 12, X), indexing="ij")
+    grid = gridpp.Grid(lats, lons)
+    S = 400
+    pts = gridpp.Points(59 + rng.random(S), 10 + 2 * rng.random(S))
+    bg = rng.normal(0, 1, (Y, X))                        # float64
+    obs, ratios, pbg = rng.normal(0, 1, S), rng.uniform(0.1, 1, S), rng.normal(0, 1, S)
+    st = gridpp.BarnesStructure(8000)
+    a = gridpp.optimal_interpolation(grid, bg, pts, obs, ratios, pbg, st, 10)
+    b = gridpp.optimal_interpolation(grid, bg.astype(np.float32), pts, obs.astype(np.float32), ratios.astype(np.float32),
+                                     pbg.astype(np.float32), st, 10)
+    np.testing.assert_array_equal(a, b)
+    assert np.abs(np.asarray(a) - bg).max() > 0.1
+    bg[5:9, 7:300] = np.nan
+    np.testing.assert_array_equal(gridpp.neighbourhood(bg, 3, gridpp.Mean), gridpp.neighbourhood(bg.astype(np.float32), 3, gridpp.Mean))
+    cube = rng.normal(0, 1, (300, 400, 10))
+    np.testing.assert_array_equal(gridpp.neighbourhood(cube, 2, gridpp.Max), gridpp.neighbourhood(cube.astype(np.float32), 2, gridpp.Max))
+    np.testing.assert_array_equal(gridpp.nearest(grid, pts, bg), gridpp.nearest(grid, pts, bg.astype(np.float32)))
+    np.testing.assert_array_equal(gridpp.bilinear(grid, pts, bg), gridpp.bilinear(grid, pts, bg.astype(np.float32)))
