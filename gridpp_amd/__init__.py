@@ -1043,7 +1043,7 @@ def neighbourhood_quantile(input, quantile, halfwidth):
 
 def neighbourhood_quantile_fast(input, quantile, halfwidth, thresholds):
     """All four overloads of gridpp::neighbourhood_quantile_fast (src/api/neighbourhood.cpp:296-527)."""
-    arr, ny, nx, ne, is3d = _field23(input)
+    arr, ny, nx, ne, is3d = _field23(input, keep_f64=True)
     if halfwidth < 0:
         raise ValueError("Half width must be > 0")
     if ny * nx * ne == 0:
@@ -1063,6 +1063,8 @@ def neighbourhood_quantile_fast(input, quantile, halfwidth, thresholds):
     _sync_if_dev(mem)
     nq = int(np.prod(_shape(q)))
     out = _empty_like_field((ny, nx), arr)
+    if not _is_dev(arr) and arr.dtype == np.float64:
+        mem |= _capi.HOST_F64
     check(lib().gpp_neighbourhood_quantile_fast(_ptr(arr), ny, nx, ne, is3d, _ptr(q), nq, int(halfwidth), _ptr(thr),
                                                 int(_shape(thr)[0]), _ptr(out), mem))
     return out
@@ -1155,8 +1157,10 @@ def optimal_interpolation_ensi(bgrid, background, points, pobs, psigmas, pbackgr
     if not isinstance(bgrid, (Grid, Points)) or not isinstance(points, Points):
         raise TypeError("bgrid must be a Grid or Points, points a Points")
     nd = 3 if isinstance(bgrid, Grid) else 2
-    background = _vec(background, nd, "background")
     S = points.size()
+    f64 = S > 0 and _wants_f64(background)
+    dt = np.float64 if f64 else np.float32
+    background = _vec(background, nd, "background", dt)
     if S == 0:   # src/api/oi_ensi.cpp:48-50,135-137: returns the background before any other check
         return background.clone() if _is_dev(background) else background.copy()
     if bgrid.get_coordinate_type() != points.get_coordinate_type():
@@ -1167,8 +1171,8 @@ def optimal_interpolation_ensi(bgrid, background, points, pobs, psigmas, pbackgr
     if _shape(background)[:nd - 1] != shape:
         raise ValueError("Input field is not the same size as the grid")
     E = _shape(background)[-1]
-    pobs, psigmas = _vec(pobs, 1, "obs"), _vec(psigmas, 1, "sigmas")
-    pbackground = _vec(pbackground, 2, "background_at_points")
+    pobs, psigmas = _vec(pobs, 1, "obs", dt), _vec(psigmas, 1, "sigmas", dt)
+    pbackground = _vec(pbackground, 2, "background_at_points", dt)
     if _shape(pobs)[0] != S:
         raise ValueError("Observations and points size mismatch")
     if _shape(psigmas)[0] != S:
@@ -1179,6 +1183,8 @@ def optimal_interpolation_ensi(bgrid, background, points, pobs, psigmas, pbackgr
         raise ValueError("Ensemble members in gridded background is not the same as in the point background")
     mem = _mem(background, pobs, psigmas, pbackground)
     _sync_if_dev(mem)
+    if f64 and mem == _capi.MEM_HOST:
+        mem |= _capi.HOST_F64
     out = _empty_like_field(_shape(background), background)
     check(lib().gpp_optimal_interpolation_ensi(bgrid._h, _ptr(background), int(E), points._h, _ptr(pobs), _ptr(psigmas),
                                                _ptr(pbackground), _structure(structure), int(max_points),

@@ -592,8 +592,8 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
         GPP_HIP(hipStreamSynchronize(stream()));
         return GPP_OK;
     }
-    qf.bind(quantile, nq, mem);
-    th.bind(thresholds, nt, mem);
+    qf.bind(quantile, nq, mem & ~GPP_HOST_F64);      // GPP_HOST_F64 applies to `input` only: quantile / thresholds stay float32
+    th.bind(thresholds, nt, mem & ~GPP_HOST_F64);
     float* planes = g_nb.planes.get((size_t)nt * C);
     float* stats = g_nb.tmp2.get((size_t)nt * C);
     member_pass(in.d, C, ne, 1, 0, th.d, nt, planes);                 // fractions per threshold (:453-472)

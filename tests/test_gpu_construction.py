@@ -106,3 +106,15 @@ def test_float64_field_inputs_equal_the_float32_path():
     np.testing.assert_array_equal(gridpp.neighbourhood(cube, 2, gridpp.Max), gridpp.neighbourhood(cube.astype(np.float32), 2, gridpp.Max))
     np.testing.assert_array_equal(gridpp.nearest(grid, pts, bg), gridpp.nearest(grid, pts, bg.astype(np.float32)))
     np.testing.assert_array_equal(gridpp.bilinear(grid, pts, bg), gridpp.bilinear(grid, pts, bg.astype(np.float32)))
+    thr = np.linspace(-2, 2, 7)
+    np.testing.assert_array_equal(gridpp.neighbourhood_quantile_fast(cube, 0.5, 2, thr), gridpp.neighbourhood_quantile_fast(cube.astype(np.float32), 0.5, 2, thr))
+    # EnSI: (Y, X, E) background in float64
+    Ye, Xe, E = 160, 180, 40                             # 1.15 M values
+    la, lo = np.meshgrid(np.linspace(59, 59.3, Ye), np.linspace(10, 10.5, Xe), indexing="ij")
+    g2 = gridpp.Grid(la, lo)
+    p2 = gridpp.Points(59 + 0.3 * rng.random(60), 10 + 0.5 * rng.random(60))
+    bge = rng.normal(0, 1, (Ye, Xe, E))
+    pbe, ob, sg = rng.normal(0, 1, (60, E)), rng.normal(0, 1, 60), rng.uniform(0.5, 1, 60)
+    ea = gridpp.optimal_interpolation_ensi(g2, bge, p2, ob, sg, pbe, st, 8)
+    eb = gridpp.optimal_interpolation_ensi(g2, bge.astype(np.float32), p2, ob.astype(np.float32), sg.astype(np.float32), pbe.astype(np.float32), st, 8)
+    np.testing.assert_array_equal(ea, eb)
