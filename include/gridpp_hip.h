@@ -19,6 +19,10 @@
  *    Coordinate arrays given to the *_create functions are always host arrays.
  *  - 2-D fields are row-major [Y][X]; 3-D fields are [Y][X][E] with E fastest
  *    (swig/vector.i:385-390).
+ *  - the library keeps its scratch buffers and its stream per process: calls are NOT re-entrant.  One call at a time per
+ *    process, which is what the reference's python module does anyway (its calls hold the GIL, swig/python/CMakeLists.txt:5-9);
+ *    a multi-threaded C++ host serialises its calls with a mutex.  Handles (gpp_points, gpp_field) are immutable once
+ *    created, apart from internal caches that a call fills under that same rule.
  *  - all work is enqueued on the library stream (gpp_get_stream) and the call
  *    returns after the stream is synchronised, unless GPP_MEM_DEVICE |
  *    GPP_ASYNC is given.
