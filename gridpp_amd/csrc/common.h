@@ -131,6 +131,7 @@ struct gpp_points {
     // its construction time page-faulting 256 MB of copies nobody reads)
     bool host_fields = true;
     void ensure_host_fields();
+    int tile_wshift = -1;            // gpp_tile_wshift's answer for this grid (computed once)
     float lat_at(int i);             // single elements without materialising the vectors
     float lon_at(int i);
     bool elev_uniform = true, laf_uniform = true;   // every point has the same elevation / laf (or none has one)

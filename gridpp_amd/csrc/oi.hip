@@ -177,6 +177,7 @@ gpp_obs_index* gpp_build_obs_index(gpp_points* pts) {
 int gpp_tile_wshift(gpp_points* g) {
     if(getenv("GPP_TILE_WSHIFT")) return std::max(0, std::min(6, atoi(getenv("GPP_TILE_WSHIFT"))));
     if(g->ny < 2 || g->nx < 2) return g->nx >= 64 ? 6 : 3;
+    if(g->tile_wshift >= 0) return g->tile_wshift;
     // metric size of a cell from the three corner points (0,0), (0,1), (1,0), in the library's own coordinates
     const float la[3] = {g->lat_at(0), g->lat_at(1), g->lat_at(g->nx)}, lo[3] = {g->lon_at(0), g->lon_at(1), g->lon_at(g->nx)};
     float x[3], y[3], z[3];
@@ -190,6 +191,7 @@ int gpp_tile_wshift(gpp_points* g) {
         const double ext = std::max((1 << w) * dx, (64 >> w) * dy);
         if(ext < bext * 0.999) { bext = ext; best = w; }
     }
+    g->tile_wshift = best;
     return best;
 }
 
