@@ -843,13 +843,14 @@ def fill(igrid, input, points, radii, value, outside):
 
 def fill_missing(values):
     """src/api/fill.cpp:43-134"""
-    values = _vec(values, 2, "values")
+    f64 = _wants_f64(values)
+    values = _vec(values, 2, "values", np.float64 if f64 else np.float32)
     out = _empty_like_field(_shape(values), values)
     ny, nx = _shape(values)
     if ny * nx:
         mem = _mem(values)
         _sync_if_dev(mem)
-        check(lib().gpp_fill_missing(_ptr(values), ny, nx, _ptr(out), mem))
+        check(lib().gpp_fill_missing(_ptr(values), ny, nx, _ptr(out), mem | (_capi.HOST_F64 if f64 else 0)))
     return out
 
 
@@ -882,7 +883,9 @@ def doping_circle(igrid, background, points, observations, radii, max_elev_diff=
 
 def neighbourhood_search(array, search_array, halfwidth, search_target_min, search_target_max, search_delta, apply_array=None):
     """src/api/neighbourhood_search.cpp:7-113"""
-    array, search_array = _vec(array, 2, "array"), _vec(search_array, 2, "search_array")
+    f64 = _wants_f64(array, search_array)
+    dt = np.float64 if f64 else np.float32
+    array, search_array = _vec(array, 2, "array", dt), _vec(search_array, 2, "search_array", dt)
     if _shape(array) != _shape(search_array):
         raise ValueError("search_array must either be the same size as array")
     if search_target_min > search_target_max:
@@ -904,13 +907,16 @@ def neighbourhood_search(array, search_array, halfwidth, search_target_min, sear
         mem = _mem(array, search_array, ap)
         _sync_if_dev(mem)
         check(lib().gpp_neighbourhood_search(_ptr(array), _ptr(search_array), ny, nx, int(halfwidth), float(search_target_min),
-                                             float(search_target_max), float(search_delta), _ptr(ap), _ptr(out), mem))
+                                             float(search_target_max), float(search_delta), _ptr(ap), _ptr(out),
+                                             mem | (_capi.HOST_F64 if f64 and mem == _capi.MEM_HOST else 0)))
     return out
 
 
 def calc_gradient(base, values, gradient_type, halfwidth, num_min=2, min_range=MV, default_gradient=0):
     """src/api/calc_gradient.cpp:7-126"""
-    base, values = _vec(base, 2, "base"), _vec(values, 2, "values")
+    f64 = _wants_f64(base, values)
+    dt = np.float64 if f64 else np.float32
+    base, values = _vec(base, 2, "base", dt), _vec(values, 2, "values", dt)
     if halfwidth <= 0:
         raise ValueError("Halwidth cannot be <= 0; must be positive integer")
     if is_valid(min_range) and min_range < 0:
@@ -926,7 +932,7 @@ def calc_gradient(base, values, gradient_type, halfwidth, num_min=2, min_range=M
     mem = _mem(base, values)
     _sync_if_dev(mem)
     check(lib().gpp_calc_gradient(_ptr(base), _ptr(values), ny, nx, int(gradient_type), int(halfwidth), int(num_min), float(min_range),
-                                  float(default_gradient), _ptr(out), mem))
+                                  float(default_gradient), _ptr(out), mem | (_capi.HOST_F64 if f64 and mem == _capi.MEM_HOST else 0)))
     return out
 
 

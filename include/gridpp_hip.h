@@ -46,7 +46,8 @@ extern "C" {
  * they are and cast to float32 on the device -- the rounding the reference's typemap applies on the host
  * (swig/vector.i:42-55).  Outputs stay float32.  Honoured by gpp_optimal_interpolation_full,
  * gpp_optimal_interpolation_ensi, gpp_neighbourhood, gpp_nearest(_levels), gpp_bilinear (every `const float*` argument of
- * these that follows `mem` is then a `const double*`) and by gpp_neighbourhood_quantile_fast for `input` only. */
+ * these that follows `mem` is then a `const double*`), by gpp_fill_missing, gpp_neighbourhood_search and gpp_calc_gradient
+ * (their float fields), and by gpp_neighbourhood_quantile_fast for `input` only. */
 #define GPP_HOST_F64 4
 
 /* include/gridpp.h:120-123 */

@@ -118,3 +118,14 @@ def test_float64_field_inputs_equal_the_float32_path():
     ea = gridpp.optimal_interpolation_ensi(g2, bge, p2, ob, sg, pbe, st, 8)
     eb = gridpp.optimal_interpolation_ensi(g2, bge.astype(np.float32), p2, ob.astype(np.float32), sg.astype(np.float32), pbe.astype(np.float32), st, 8)
     np.testing.assert_array_equal(ea, eb)
+    # the 2-D grid operations
+    base = rng.uniform(0, 1500, (Y, X))
+    vals = 280 - 0.0065 * base + rng.normal(0, 0.3, (Y, X))
+    vals[10:20, 30:90] = np.nan
+    for gt in (gridpp.MinMax, gridpp.LinearRegression):
+        np.testing.assert_array_equal(gridpp.calc_gradient(base, vals, gt, 3, 2, 10.0, -1.0),
+                                      gridpp.calc_gradient(base.astype(np.float32), vals.astype(np.float32), gt, 3, 2, 10.0, -1.0))
+    sr = rng.random((Y, X))
+    np.testing.assert_array_equal(gridpp.neighbourhood_search(vals, sr, 2, 0.7, 1.0, 0.1),
+                                  gridpp.neighbourhood_search(vals.astype(np.float32), sr.astype(np.float32), 2, 0.7, 1.0, 0.1))
+    np.testing.assert_array_equal(gridpp.fill_missing(vals), gridpp.fill_missing(vals.astype(np.float32)))
