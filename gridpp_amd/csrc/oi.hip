@@ -1089,38 +1089,62 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
             launch_union(dim3((a.ntiles + 3) / 4), false);
             GPP_HIP(hipEventRecord(ws.eu, stream()));
-            // How many tiles did it decline?  One small host round trip here is cheaper than launching the list passes with
-            // grids sized for the worst case (tens of thousands of empty workgroups), and usually there is nothing left to do.
-            int n1 = 0;
-            GPP_HIP(hipMemcpyAsync(ws.h_status, ws.status.p, 16, hipMemcpyDeviceToHost, stream()));
-            GPP_HIP(hipStreamSynchronize(stream()));
-            n1 = h_ints[1];
-            if(n1 > 0) {
-                if(16 * n1 <= 3072) {   // (as many work items as the chip holds waves of this kernel)
-                    // a short list: every declined tile straight to its sixteen 4-cell items (one pass; the latency of a pass,
-                    // one lone work item, is what a short list costs)
-                    a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
-                    launch_union(dim3(4 * n1), true);
-                }
-                else {
-                    // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); a list too long for the split to pay is
-                    // forwarded whole by the kernel
-                    a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
-                    launch_union(dim3(n1), true);
-                    // pass 3: the declined 16-cell items as 4 items of 4 cells (at most 4 n1 of them)
-                    a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
-                    a.parent_count = d_fb_count;
-                    launch_union(dim3(4 * (size_t)n1 > 0x7fffffffull ? 0x7fffffff : 4 * n1), true);
-                }
+            // The tiles it declined.  The usual case is a short list (or none): it is taken WITHOUT asking the host how long it
+            // is -- the short-list pass and the k_oi pass behind it are launched with fixed small grids and read the lengths
+            // on the device; a list too long for that grid is left untouched by both and handled after the one read-back of
+            // the call.  (A host round trip here cost ~25 us per call.)  When the last call with this geometry had a long
+            // list, the host asks first, as the two-level passes need its length for their grids anyway.
+            const int SHORT_ITEMS = 3072;   // as many work items as the chip holds waves of this kernel
+            auto short_passes = [&](const int nblocks) {
+                // every declined tile straight to its sixteen 4-cell items (one pass; the latency of a pass, one lone work
+                // item, is what a short list costs)
+                a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
+                launch_union(dim3(nblocks), true);
+                // what is still left, one factorisation per distinct selection (grid-stride over the list)
+                a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 128;
+                launch_k_oi(false);   // (usually nothing is left: a small grid keeps the empty launch cheap)
+            };
+            auto long_passes = [&](const int n1) {
+                // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); a list too long for the split to pay is
+                // forwarded whole by the kernel
+                a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
+                launch_union(dim3(n1), true);
+                // pass 3: the declined 16-cell items as 4 items of 4 cells (at most 4 n1 of them)
+                a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
+                a.parent_count = d_fb_count;
+                launch_union(dim3(4 * (size_t)n1 > 0x7fffffffull ? 0x7fffffff : 4 * n1), true);
                 // pass 4: what is still left, one factorisation per distinct selection (grid-stride over the list)
                 a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
                 launch_k_oi(false);
+            };
+            const bool expect_long = memo_hit && 16.0 * (double)memo.declined * (double)a.ntiles > (double)SHORT_ITEMS;
+            if(!expect_long) {
+                short_passes(SHORT_ITEMS / 4);
+                GPP_HIP(hipEventRecord(ws.e1, stream()));
+                fetch();
+                const int n1 = h_ints[1];
+                if(16 * (long)n1 > SHORT_ITEMS) {   // a long list after all: nothing has touched it yet
+                    long_passes(n1);
+                    GPP_HIP(hipEventRecord(ws.e1, stream()));
+                    fetch();
+                }
+            }
+            else {
+                GPP_HIP(hipMemcpyAsync(ws.h_status, ws.status.p, 16, hipMemcpyDeviceToHost, stream()));
+                GPP_HIP(hipStreamSynchronize(stream()));
+                const int n1 = h_ints[1];
+                if(16 * (long)n1 > SHORT_ITEMS) long_passes(n1);
+                else if(n1 > 0) short_passes(4 * n1);
+                GPP_HIP(hipEventRecord(ws.e1, stream()));
+                fetch();
             }
             ran_union = true;
         }
-        else launch_k_oi(use_lu);
-        GPP_HIP(hipEventRecord(ws.e1, stream()));
-        fetch();
+        else {
+            launch_k_oi(use_lu);
+            GPP_HIP(hipEventRecord(ws.e1, stream()));
+            fetch();
+        }
         const int nfb[3] = {ran_union ? h_ints[1] : 0, ran_union ? h_ints[2] : 0, ran_union ? h_ints[3] : 0};
         g_stats.fallback_tiles = nfb[0];
         g_stats.fallback_subtiles = nfb[2];

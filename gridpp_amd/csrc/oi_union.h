@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
             return;
         }
         if(a.level == 3) {   // a short list of declined tiles goes straight to its sixteen 4-cell items: one pass instead of two
-            if(tile >= 16 * nlist) return;
+            // (launched before the host knows the length of the list, with a grid that holds a short one: a longer list is left
+            //  alone here and taken by the two-level passes once the host has seen its length)
+            if(16 * nlist > (int)gridDim.x * 4 || tile >= 16 * nlist) return;
             sub = tile & 15; tile = a.in_list[tile >> 4]; shift = 2;
         }
         else {
