@@ -452,6 +452,31 @@ inline vec2 count(const Grid& igrid, const Grid& ogrid, float radius) {
     if(out.size()) detail::check(gpp_count(igrid.handle(), ogrid.handle(), radius, out.data(), GPP_MEM_HOST));
     return detail::unflatten(out, ogrid.size()[0], ogrid.size()[1]);
 }
+// distance (include/gridpp.h; src/api/distance.cpp:6-120): largest calc_distance to the `num` nearest points of the input set
+inline vec distance(const Grid& grid, const Points& points, int num) {
+    if(grid.get_coordinate_type() != points.get_coordinate_type()) throw std::invalid_argument("Incompatible coordinate types");
+    vec out(points.size(), 0);
+    if(points.size()) detail::check(gpp_distance(grid.handle(), points.handle(), num, 1, out.data(), GPP_MEM_HOST));
+    return out;
+}
+inline vec distance(const Points& ipoints, const Points& opoints, int num) {
+    if(ipoints.get_coordinate_type() != opoints.get_coordinate_type()) throw std::invalid_argument("Incompatible coordinate types");
+    vec out(opoints.size(), 0);
+    if(opoints.size()) detail::check(gpp_distance(ipoints.handle(), opoints.handle(), num, 1, out.data(), GPP_MEM_HOST));
+    return out;
+}
+inline vec2 distance(const Grid& igrid, const Grid& ogrid, int num) {
+    if(igrid.get_coordinate_type() != ogrid.get_coordinate_type()) throw std::invalid_argument("Incompatible coordinate types");
+    vec out(detail::cells(ogrid), 0);
+    if(out.size()) detail::check(gpp_distance(igrid.handle(), ogrid.handle(), num, 0, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, ogrid.size()[0], ogrid.size()[1]);
+}
+inline vec2 distance(const Points& points, const Grid& grid, int num) {
+    if(points.get_coordinate_type() != grid.get_coordinate_type()) throw std::invalid_argument("Incompatible coordinate types");
+    vec out(detail::cells(grid), 0);
+    if(out.size()) detail::check(gpp_distance(points.handle(), grid.handle(), num, 0, out.data(), GPP_MEM_HOST));
+    return detail::unflatten(out, grid.size()[0], grid.size()[1]);
+}
 namespace detail {
 inline vec gridding_flat(gpp_points* to, size_t nout, const Points& points, const vec& values, float radius, int min_num, Statistic statistic, bool nearest) {
     if((int)values.size() != points.size()) throw std::invalid_argument("Points size is not the same as values");

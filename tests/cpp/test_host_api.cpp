@@ -82,6 +82,8 @@ int main() {
         CHECK(gc[0][1] == 0 && gc[1][1] == 2);
         vec2 cn = count(gp, gg, 0.6f);
         CHECK(cn[1][1] == 2 && cn[0][1] == 0);
+        vec2 dd = distance(gp, gg, 1);          // tests/test_distance.py: planar distance to the nearest input point
+        CHECK(dd.size() == 3 && dd[2][1] == 0 && std::fabs(dd[1][1] - 0.5f) < 1e-6 && std::fabs(dd[0][0] - std::sqrt(0.08f)) < 1e-5);
         vec2 gn = gridding_nearest(gg, gp, vec{1, 2, 3}, 1, Sum);
         CHECK(gn.size() == 3 && gn[0].size() == 2);
         threw = false;
