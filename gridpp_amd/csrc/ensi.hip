@@ -36,6 +36,9 @@ struct EnsiArgs {
     const int* validIdx;      // [nV]
     unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
     double* gram;             // [ntiles][EN*EN] scratch: Y Y^T of the current run of equal selections
+    int* big_list;            // cells with more usable observations than the 32-row tile holds (k_ensi_big), or NULL
+    int* big_count;
+    unsigned long long* big_keys;   // per workgroup of k_ensi_big: EBIG_CAND sorted candidate keys
     int debug;                // GPP_ENSI_DEBUG (timing experiments only): 1 no Jacobi, 2 no member update, 4 no B build, 8 no M_W
     int nV;
     int allow_extrap;
@@ -158,8 +161,9 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
     DevStructure cst = a.s.st;
     if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
     int cnt = scan_tile<EN, true>(a.s, cst, active, gx, gy, gz, ge, gl, s_keys, lane, overflow, truncated);
-    if(__ballot(overflow) != 0ull) {
-        if(lane == 0) atomicOr(a.err, 1);
+    if(__ballot(overflow) != 0ull) {   // more usable observations than the 32-row tile holds: those cells go to k_ensi_big
+        if(a.big_list) { if(overflow) a.big_list[atomicAdd(a.big_count, 1)] = cell; }
+        else if(lane == 0) atomicOr(a.err, 1);
         cnt = overflow ? 0 : cnt;
     }
     // park the selections (observation indices) of the 64 cells in HBM: sel[tile][slot][lane]
@@ -459,6 +463,264 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
     if(lane == 0 && a.counters) { atomicAdd(&a.counters[1], (unsigned long long)ndone); atomicAdd(&a.counters[4 + (blockIdx.x & 31)], (unsigned long long)nsweeps); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ensi_big: grid points with more than 32 usable observations (max_points == 0 or > 32).  One 256-thread workgroup per
+// cell, the E x E formulation the reference itself uses (oi_ensi.cpp:379-553), E <= 64 valid members, up to EBIG_N selected
+// observations.  With Pinv = Y^T R^-1 Y + c I = V D V^T (one cyclic Jacobi in LDS, c = E - 1):
+//     P = V D^-1 V^T,   sqrt(c P) = V diag(sqrt(c / D)) V^T,   w = P Y^T R^-1 d,   W = sqrt(c P) + w 1^T.
+// Slower per cell than the 32-row path by two orders of magnitude -- and still far from the reference's serial loop.
+#define EBIG_CAND 8192
+#define EBIG_N 512
+#define EP 65            // pitch of the 64 x 64 matrices (doubles)
+__global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
+    __shared__ unsigned long long s_key[EBIG_CAND];   // 64 KB: candidate keys; after the sort: Y chunk, tables
+    __shared__ double s_B[64 * EP];                   // Pinv, diagonalised in place
+    __shared__ double s_V[64 * EP];                   // eigenvectors; later W
+    __shared__ double s_t[64], s_w[64], s_X[64], s_cs[32], s_sn[32];
+    __shared__ int s_p[32], s_q[32];
+    __shared__ double s_off[256];
+    __shared__ int s_n;
+    __shared__ float s_mm[2][64];
+    const int tid = threadIdx.x;
+    const ScanArgs& sa = a.s;
+    const DevStructure& st = sa.st;
+    const int nV = a.nV, E = a.E;
+    const int nlist = *a.big_count;
+    unsigned long long* const gkeys = a.big_keys + (size_t)blockIdx.x * EBIG_CAND;
+    const double c = (double)((float)(nV - 1));       // oi_ensi.cpp:383 (float product, delta = 1)
+    for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int cell = a.big_list[li];
+        const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
+        if(tid == 0) s_n = 0;
+        __syncthreads();
+        // ---- radius query + filter (valid observation, rho > 0: oi_ensi.cpp:213-237) -----------------------------------------
+        const float R = st.R;
+        const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz), pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
+        const int bx0 = min(max((int)floorf((pa - R - sa.amin) * sa.inv_s) - 1, 0), sa.nbx - 1), bx1 = min(max((int)floorf((pa + R - sa.amin) * sa.inv_s) + 1, 0), sa.nbx - 1);
+        const int by0 = min(max((int)floorf((pb - R - sa.bmin) * sa.inv_s) - 1, 0), sa.nby - 1), by1 = min(max((int)floorf((pb + R - sa.bmin) * sa.inv_s) + 1, 0), sa.nby - 1);
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        for(int by = by0; by <= by1; ++by) {
+            const int js = sa.bin_start[by * sa.nbx + bx0], je = sa.bin_start[by * sa.nbx + bx1 + 1];
+            for(int j = js + tid; j < je; j += 256) {
+                const float4 rec = sa.pgeo[j];   // x = NaN for an unusable observation: fails the box test
+                if(!(rec.x > lox && rec.x < hix && rec.y > loy && rec.y < hiy && rec.z > loz && rec.z < hiz)) continue;
+                const float2 met = sa.smeta[j];
+                if(!(d_chord(rec.x, rec.y, rec.z, gx, gy, gz) <= R)) continue;
+                const float rho = d_corr(st, gx, gy, gz, ge, gl, rec.x, rec.y, rec.z, rec.w, met.x, true);
+                if(!(rho > 0.0f)) continue;
+                const int k = atomicAdd(&s_n, 1);
+                if(k < EBIG_CAND) s_key[k] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~__float_as_int(met.y));
+            }
+        }
+        __syncthreads();
+        const int ncand = s_n;
+        const bool truncated = a.s.max_points > 0 && ncand > a.s.max_points;
+        const int n = truncated ? a.s.max_points : ncand;
+        if(ncand > EBIG_CAND || n > EBIG_N) {   // beyond what this kernel holds: fail loudly (host raises)
+            if(tid == 0) atomicOr(a.err, 1);
+            __syncthreads();
+            continue;
+        }
+        // ---- order: rho descending (ties -> lower index) when the reference sorts (more candidates than max_points), candidate
+        //      (= index) order otherwise (oi_ensi.cpp:243-269); the order only matters for the clamp's lY[e] quirk and for rounding
+        int np2 = 1;
+        while(np2 < ncand) np2 <<= 1;
+        for(int i = ncand + tid; i < np2; i += 256) s_key[i] = 0ull;
+        __syncthreads();
+        for(int k = 2; k <= np2; k <<= 1) {
+            for(int j = k >> 1; j > 0; j >>= 1) {
+                for(int i = tid; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if(ixj > i) {
+                        const unsigned long long x = s_key[i], y = s_key[ixj];
+                        // truncated: whole key (rho, ~index) descending; otherwise ~index descending = index ascending
+                        const unsigned long long kx = truncated ? x : (x & 0xffffffffull), ky = truncated ? y : (y & 0xffffffffull);
+                        const bool desc = (i & k) == 0;
+                        if(desc ? (kx < ky) : (kx > ky)) { s_key[i] = y; s_key[ixj] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for(int i = tid; i < n; i += 256) gkeys[i] = s_key[i];
+        __syncthreads();
+        // ---- Pinv = Y^T Rinv Y + c I, t = Y^T Rinv d, in chunks of 64 observations staged in LDS ------------------------------
+        float* const yc = reinterpret_cast<float*>(s_key);          // [64][64] Y chunk (member-major rows: yc[i * 64 + a])
+        double* const rinv = reinterpret_cast<double*>(yc + 64 * 64);   // [64]
+        double* const dvec = rinv + 64;                                 // [64]
+        double accP[16];
+#pragma unroll
+        for(int r = 0; r < 16; ++r) accP[r] = 0.0;
+        double acct = 0.0;
+        for(int i0 = 0; i0 < n; i0 += 64) {
+            const int m = min(64, n - i0);
+            __syncthreads();
+            for(int e = tid; e < m * 64; e += 256) {
+                const int i = e >> 6, k = e & 63;
+                const unsigned orig = ~(unsigned)(gkeys[i0 + i] & 0xffffffffull);
+                yc[i * 64 + k] = (k < nV) ? a.gY[(long)orig * nV + k] : 0.0f;
+            }
+            if(tid < m) {
+                const unsigned long long key = gkeys[i0 + tid];
+                const unsigned orig = ~(unsigned)(key & 0xffffffffull);
+                const float4 x4 = a.oaux[orig];                       // laf, obs, gYhat, sigma
+                const float s2 = x4.w * x4.w;                         // float product (oi_ensi.cpp:300)
+                rinv[tid] = (double)__uint_as_float((unsigned)(key >> 32)) / (double)s2;
+                dvec[tid] = (double)x4.y - (double)x4.z;
+            }
+            __syncthreads();
+            for(int r = 0; r < 16; ++r) {
+                const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
+                if(ai < nV && bi < nV) {
+                    double sacc = accP[r];
+                    for(int i = 0; i < m; ++i) sacc = __builtin_fma((double)yc[i * 64 + ai] * rinv[i], (double)yc[i * 64 + bi], sacc);
+                    accP[r] = sacc;
+                }
+            }
+            if(tid < nV) for(int i = 0; i < m; ++i) acct = __builtin_fma((double)yc[i * 64 + tid] * rinv[i], dvec[i], acct);
+        }
+        __syncthreads();
+        for(int r = 0; r < 16; ++r) {
+            const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
+            if(ai < nV && bi < nV) {
+                s_B[ai * EP + bi] = accP[r] + (ai == bi ? c : 0.0);
+                s_V[ai * EP + bi] = ai == bi ? 1.0 : 0.0;
+            }
+        }
+        if(tid < nV) s_t[tid] = acct;
+        __syncthreads();
+        // ---- cyclic Jacobi on the nV x nV matrix, round-robin pairs -----------------------------------------------------------
+        const int mm = nV + (nV & 1), half = mm >> 1;
+        double tr = 0.0;
+        if(tid < nV) tr = fabs(s_B[tid * EP + tid]);
+        s_off[tid] = tr;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+        tr = s_off[0];
+        __syncthreads();
+        for(int sweep = 0; sweep < 40 && nV > 1; ++sweep) {
+            double off2 = 0.0;
+            for(int e = tid; e < nV * nV; e += 256) { const int i = e / nV, j = e - i * nV; if(j < i) { const double v = s_B[i * EP + j]; off2 += v * v; } }
+            s_off[tid] = off2;
+            __syncthreads();
+            for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+            off2 = s_off[0];
+            __syncthreads();
+            if(!(off2 > 1e-24 * tr * tr)) break;
+            for(int step = 0; step < mm - 1; ++step) {
+                if(tid < half) {
+                    int p, q;
+                    if(tid == 0) { p = mm - 1; q = step; }
+                    else { p = (step + tid) % (mm - 1); q = (step - tid + (mm - 1)) % (mm - 1); }
+                    if(p > q) { const int t_ = p; p = q; q = t_; }
+                    double cs = 1.0, sn = 0.0;
+                    if(q < nV) {
+                        const double apq = s_B[p * EP + q];
+                        if(apq != 0.0) {
+                            const double theta = (s_B[q * EP + q] - s_B[p * EP + p]) / (2.0 * apq);
+                            const double t_ = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                            cs = 1.0 / sqrt(t_ * t_ + 1.0); sn = t_ * cs;
+                            if(!(fabs(theta) < 1e150)) { cs = 1.0; sn = 0.0; }
+                        }
+                    }
+                    else q = p;
+                    s_p[tid] = p; s_q[tid] = q; s_cs[tid] = cs; s_sn[tid] = sn;
+                }
+                __syncthreads();
+                // columns: B <- B J, V <- V J
+                for(int e = tid; e < half * nV; e += 256) {
+                    const int k = e / nV, r = e - k * nV, p = s_p[k], q = s_q[k];
+                    if(p != q) {
+                        const double cs = s_cs[k], sn = s_sn[k];
+                        const double bp = s_B[r * EP + p], bq = s_B[r * EP + q];
+                        s_B[r * EP + p] = cs * bp - sn * bq; s_B[r * EP + q] = sn * bp + cs * bq;
+                        const double vp = s_V[r * EP + p], vq = s_V[r * EP + q];
+                        s_V[r * EP + p] = cs * vp - sn * vq; s_V[r * EP + q] = sn * vp + cs * vq;
+                    }
+                }
+                __syncthreads();
+                // rows: B <- J^T B
+                for(int e = tid; e < half * nV; e += 256) {
+                    const int k = e / nV, cidx = e - k * nV, p = s_p[k], q = s_q[k];
+                    if(p != q) {
+                        const double cs = s_cs[k], sn = s_sn[k];
+                        const double bp = s_B[p * EP + cidx], bq = s_B[q * EP + cidx];
+                        s_B[p * EP + cidx] = cs * bp - sn * bq; s_B[q * EP + cidx] = sn * bp + cs * bq;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // eigenvalues D_k = B_kk (>= c > 0 for a finite matrix); a non-finite or non-positive one is the reference's rcond <= 0
+        // passthrough (oi_ensi.cpp:386-390): the cell keeps its background values
+        bool singular = false;
+        if(tid < nV) { const double dk = s_B[tid * EP + tid]; singular = !(dk > 0.0) || isinf(dk); }
+        s_off[tid] = singular ? 1.0 : 0.0;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+        const bool skip = s_off[0] > 0.0 || nV <= 1;
+        __syncthreads();
+        if(skip) continue;
+        // ---- w = P t = V D^-1 V^T t ; W = V diag(sqrt(c / D)) V^T + w 1^T (into s_B, the eigenvalues move to s_off) ------------
+        if(tid < nV) {
+            double u = 0.0;
+            for(int k = 0; k < nV; ++k) u = __builtin_fma(s_V[k * EP + tid], s_t[k], u);   // (V^T t)_tid
+            s_off[tid] = s_B[tid * EP + tid];
+            s_X[tid] = u / s_B[tid * EP + tid];                                            // D^-1 V^T t
+        }
+        __syncthreads();
+        if(tid < nV) {
+            double wv = 0.0;
+            for(int k = 0; k < nV; ++k) wv = __builtin_fma(s_V[tid * EP + k], s_X[k], wv);
+            s_w[tid] = wv;
+        }
+        __syncthreads();
+        for(int e = tid; e < nV * nV; e += 256) {
+            const int ai = e / nV, bi = e - ai * nV;
+            double sacc = 0.0;
+            for(int k = 0; k < nV; ++k) sacc = __builtin_fma(s_V[ai * EP + k] * sqrt(c / s_off[k]), s_V[bi * EP + k], sacc);
+            s_B[ai * EP + bi] = sacc + s_w[ai];                                            // oi_ensi.cpp:419-444
+        }
+        // ---- ensemble side (oi_ensi.cpp:447-553): thread e < nV owns member e ---------------------------------------------------
+        const int ek = (tid < nV) ? a.validIdx[tid] : 0;
+        const float value = (tid < nV) ? a.bg[(long)cell * E + ek] : 0.0f;
+        __shared__ float s_val[64];
+        if(tid < 64) s_val[tid] = value;
+        __syncthreads();
+        float total = 0; int count = 0;
+        for(int k = 0; k < nV; ++k) { const float v = s_val[k]; if(d_valid(v)) { total += v; count++; } }
+        const float ensMean = total / (float)count;
+        if(tid < nV) s_X[tid] = (double)value - (double)ensMean;
+        __syncthreads();
+        if(tid < nV) {
+            float acc = 0.0f;
+            for(int k = 0; k < nV; ++k) acc = (float)((double)acc + s_X[k] * s_B[k * EP + tid]);   // float += double product (:508-511)
+            float currIncrement = acc;
+            if(!a.allow_extrap) {   // :520-552; lY[e] is a LINEAR index into the n x nV column-major matrix
+                const int li_ = tid % n, lk_ = tid / n;
+                const unsigned oo = ~(unsigned)(gkeys[li_] & 0xffffffffull);
+                const double lYe = (double)a.gY[(long)oo * nV + lk_];
+                float maxInc = 0, minInc = 0;
+                for(int i = 0; i < n; ++i) {
+                    const unsigned oi_ = ~(unsigned)(gkeys[i] & 0xffffffffull);
+                    const float4 x4 = a.oaux[oi_];
+                    const float dv = (float)((double)x4.y - (lYe + (double)x4.z));
+                    if(i == 0 || dv > maxInc) maxInc = dv;
+                    if(i == 0 || dv < minInc) minInc = dv;
+                }
+                const double Xe = s_X[tid];
+                const float memberIncrement = (float)((double)currIncrement - Xe);
+                if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + Xe);
+                else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + Xe);
+                else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + Xe);
+                else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + Xe);
+            }
+            a.out[(long)cell * E + ek] = ensMean + currIncrement;
+        }
+        __syncthreads();
+    }
+}
+
 namespace {
 struct EnsiWorkspace {
     DevBuf<float4> pgeo, oaux;
@@ -466,7 +728,8 @@ struct EnsiWorkspace {
     DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
     DevBuf<unsigned> sel;
     DevBuf<double> gram;
-    DevBuf<unsigned long long> counters;
+    DevBuf<unsigned long long> counters, big_keys;
+    DevBuf<int> big_list, big_count;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 thread_local EnsiWorkspace g_ews;
@@ -570,10 +833,28 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.debug = getenv("GPP_ENSI_DEBUG") ? atoi(getenv("GPP_ENSI_DEBUG")) : 0;
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
+    // cells with more than 32 usable observations go to k_ensi_big (scalar structure functions; the spatially varying forms
+    // fail loudly there)
+    const bool big_ok = !a.s.st.fh && (max_points == 0 || max_points > EN) && !getenv("GPP_ENSI_NO_BIG");
+    if(big_ok) {
+        a.big_list = ws.big_list.get((size_t)C); a.big_count = ws.big_count.get(1);
+        GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, sizeof(int), stream()));
+    }
     GPP_HIP(hipEventRecord(ws.e0, stream()));
     if(a.s.st.fh) hipLaunchKernelGGL(k_ensi<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
     else hipLaunchKernelGGL(k_ensi<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
     GPP_HIP(hipGetLastError());
+    if(big_ok) {
+        int nbig = 0;
+        GPP_HIP(hipMemcpyAsync(&nbig, ws.big_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipStreamSynchronize(stream()));
+        if(nbig > 0) {
+            const int nwg = std::min(nbig, 1024);
+            a.big_keys = ws.big_keys.get((size_t)nwg * EBIG_CAND);
+            hipLaunchKernelGGL(k_ensi_big, dim3(nwg), dim3(256), 0, stream(), a);
+            GPP_HIP(hipGetLastError());
+        }
+    }
     GPP_HIP(hipEventRecord(ws.e1, stream()));
     int err = 0;
     GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
@@ -586,7 +867,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
         fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (double)sw / (double)hc[1] : 0.0);
     }
-    if(err & 1) runtime("optimal_interpolation_ensi: more than 32 observations per grid point requested (max_points == 0 or > 32): large-n path not built yet");
+    if(err & 1) runtime("optimal_interpolation_ensi: a grid point has more usable observations than the GPU path holds (512; 32 with spatially varying structure functions)");
     return GPP_OK;
     GPP_CATCH
 }

@@ -84,3 +84,22 @@ def test_ensi_elev_structure_and_points_overload():
                                             gridpp.BarnesStructure(25000), 8)
     ref = O.oi_ensi(O.Pts(blat, blon), b2, O.Pts(plat, plon), obs, sig, pbg, O.Barnes(25000), 8)
     check(np.asarray(out), ref, b2)
+
+
+@pytest.mark.parametrize("E,max_points,S,h", [(10, 0, 150, 30000), (50, 50, 200, 30000), (20, 45, 200, 25000), (64, 0, 120, 40000)])
+def test_ensi_more_than_32_observations(E, max_points, S, h):
+    """max_points == 0 or > 32: grid points with more than 32 usable observations are solved by k_ensi_big (E x E
+    formulation, one workgroup per cell); the others stay on the 32-row tile.  Both kinds occur in these cases."""
+    import gridpp_amd as gridpp
+    c = case(300 + E + max_points, 18, 16, E, S)
+    out, ref = run(c, h, max_points)
+    check(out, ref, c[2])
+    out2, ref2 = run(c, h, max_points, allow=False)
+    check(out2, ref2, c[2])
+
+
+def test_ensi_large_n_with_elevation_nan_obs_and_invalid_member():
+    c = case(777, 14, 15, 12, 180, nan_member=5, nan_obs=True)
+    out, ref = run(c, 30000, 0, allow=False, v=200, elev=True)
+    check(out, ref, c[2])
+    assert np.isnan(out[3, 4, 5])
