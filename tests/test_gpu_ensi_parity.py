@@ -87,15 +87,18 @@ def test_ensi_elev_structure_and_points_overload():
 
 
 @pytest.mark.parametrize("E,max_points,S,h", [(10, 0, 150, 30000), (50, 50, 200, 30000), (20, 45, 200, 25000), (64, 0, 120, 40000)])
-def test_ensi_more_than_32_observations(E, max_points, S, h):
+def test_ensi_more_than_32_observations(E, max_points, S, h, monkeypatch):
     """max_points == 0 or > 32: grid points with more than 32 usable observations are solved by k_ensi_big (E x E
-    formulation, one workgroup per cell); the others stay on the 32-row tile.  Both kinds occur in these cases."""
-    import gridpp_amd as gridpp
+    formulation, one workgroup per cell); the others stay on the 32-row tile."""
     c = case(300 + E + max_points, 18, 16, E, S)
     out, ref = run(c, h, max_points)
     check(out, ref, c[2])
     out2, ref2 = run(c, h, max_points, allow=False)
     check(out2, ref2, c[2])
+    # the case does need the large-n kernel: without it the call fails loudly
+    monkeypatch.setenv("GPP_ENSI_NO_BIG", "1")
+    with pytest.raises(RuntimeError, match="more usable observations"):
+        run(c, h, max_points)
 
 
 def test_ensi_large_n_with_elevation_nan_obs_and_invalid_member():
