@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
             for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
             off2 = s_off[0];
             __syncthreads();
-            if(!(off2 > 1e-24 * tr * tr)) break;
+            if(!(off2 > 1e-22 * tr * tr)) break;   // as in k_ensi: eigenvalues good to 1e-22, eigenvectors to 1e-11
             for(int step = 0; step < mm - 1; ++step) {
                 if(tid < half) {
                     int p, q;
