@@ -473,9 +473,13 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
 #define EBIG_N 512
 #define EP 65            // pitch of the 64 x 64 matrices (doubles)
 __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
-    __shared__ unsigned long long s_key[EBIG_CAND];   // 64 KB: candidate keys; after the sort: Y chunk, tables
-    __shared__ double s_B[64 * EP];                   // Pinv, diagonalised in place
-    __shared__ double s_V[64 * EP];                   // eigenvectors; later W
+    // one 65 KB area, three lives: candidate keys (sort) -> Y chunk + tables (Pinv build, Pinv itself in registers) -> B and V;
+    // two workgroups fit a CU
+    __shared__ double s_area[2 * 64 * EP];
+    unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(s_area);   // [EBIG_CAND]
+    double* const s_B = s_area;                       // Pinv, diagonalised in place; later W
+    double* const s_V = s_area + 64 * EP;             // eigenvectors
+    static_assert(sizeof(double) * 2 * 64 * EP >= sizeof(unsigned long long) * EBIG_CAND, "the key area must hold EBIG_CAND keys");
     __shared__ double s_t[64], s_w[64], s_X[64], s_cs[32], s_sn[32];
     __shared__ int s_p[32], s_q[32];
     __shared__ double s_off[256];
@@ -627,27 +631,26 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
                     s_p[tid] = p; s_q[tid] = q; s_cs[tid] = cs; s_sn[tid] = sn;
                 }
                 __syncthreads();
+                // 8 threads per pair (32 pairs at most), each owning the rows / columns r = (tid & 7) + 8 j
+                const int pk = tid >> 3;
+                const bool work = pk < half && s_p[pk] != s_q[pk];
+                const int p = work ? s_p[pk] : 0, q = work ? s_q[pk] : 0;
+                const double cs = work ? s_cs[pk] : 1.0, sn = work ? s_sn[pk] : 0.0;
                 // columns: B <- B J, V <- V J
-                for(int e = tid; e < half * nV; e += 256) {
-                    const int k = e / nV, r = e - k * nV, p = s_p[k], q = s_q[k];
-                    if(p != q) {
-                        const double cs = s_cs[k], sn = s_sn[k];
+                if(work)
+                    for(int r = tid & 7; r < nV; r += 8) {
                         const double bp = s_B[r * EP + p], bq = s_B[r * EP + q];
-                        s_B[r * EP + p] = cs * bp - sn * bq; s_B[r * EP + q] = sn * bp + cs * bq;
                         const double vp = s_V[r * EP + p], vq = s_V[r * EP + q];
+                        s_B[r * EP + p] = cs * bp - sn * bq; s_B[r * EP + q] = sn * bp + cs * bq;
                         s_V[r * EP + p] = cs * vp - sn * vq; s_V[r * EP + q] = sn * vp + cs * vq;
                     }
-                }
                 __syncthreads();
                 // rows: B <- J^T B
-                for(int e = tid; e < half * nV; e += 256) {
-                    const int k = e / nV, cidx = e - k * nV, p = s_p[k], q = s_q[k];
-                    if(p != q) {
-                        const double cs = s_cs[k], sn = s_sn[k];
+                if(work)
+                    for(int cidx = tid & 7; cidx < nV; cidx += 8) {
                         const double bp = s_B[p * EP + cidx], bq = s_B[q * EP + cidx];
                         s_B[p * EP + cidx] = cs * bp - sn * bq; s_B[q * EP + cidx] = sn * bp + cs * bq;
                     }
-                }
                 __syncthreads();
             }
         }
@@ -661,11 +664,11 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
         const bool skip = s_off[0] > 0.0 || nV <= 1;
         __syncthreads();
         if(skip) continue;
-        // ---- w = P t = V D^-1 V^T t ; W = V diag(sqrt(c / D)) V^T + w 1^T (into s_B, the eigenvalues move to s_off) ------------
+        // ---- w = P t = V D^-1 V^T t ; W = V diag(sqrt(c / D)) V^T + w 1^T (into s_B; sqrt(c / D) in s_off) ------------
         if(tid < nV) {
             double u = 0.0;
             for(int k = 0; k < nV; ++k) u = __builtin_fma(s_V[k * EP + tid], s_t[k], u);   // (V^T t)_tid
-            s_off[tid] = s_B[tid * EP + tid];
+            s_off[tid] = sqrt(c / s_B[tid * EP + tid]);                                    // sqrt(c / D)
             s_X[tid] = u / s_B[tid * EP + tid];                                            // D^-1 V^T t
         }
         __syncthreads();
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
         for(int e = tid; e < nV * nV; e += 256) {
             const int ai = e / nV, bi = e - ai * nV;
             double sacc = 0.0;
-            for(int k = 0; k < nV; ++k) sacc = __builtin_fma(s_V[ai * EP + k] * sqrt(c / s_off[k]), s_V[bi * EP + k], sacc);
+            for(int k = 0; k < nV; ++k) sacc = __builtin_fma(s_V[ai * EP + k] * s_off[k], s_V[bi * EP + k], sacc);
             s_B[ai * EP + bi] = sacc + s_w[ai];                                            // oi_ensi.cpp:419-444
         }
         // ---- ensemble side (oi_ensi.cpp:447-553): thread e < nV owns member e ---------------------------------------------------
