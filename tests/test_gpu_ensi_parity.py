@@ -106,3 +106,14 @@ def test_ensi_large_n_with_elevation_nan_obs_and_invalid_member():
     out, ref = run(c, 30000, 0, allow=False, v=200, elev=True)
     check(out, ref, c[2])
     assert np.isnan(out[3, 4, 5])
+
+
+def test_ensi_large_n_limits():
+    """480 usable observations per grid point work (several 64-observation chunks of Y); 600 fail loudly, not silently."""
+    import gridpp_amd as gridpp
+    c = case(901, 5, 6, 16, 480)
+    out, ref = run(c, 200000, 0)                     # every observation is in range of every cell
+    check(out, ref, c[2])
+    c2 = case(902, 4, 4, 8, 600)
+    with pytest.raises(RuntimeError, match="more usable observations"):
+        run(c2, 200000, 0)
