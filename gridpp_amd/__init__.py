@@ -774,6 +774,18 @@ def distance(ipoints, opoints, num):
     return out
 
 
+def staticcorr_points(points, knots, structure, max_points):
+    """(L, K) static correlations between a set of points and a set of knots (src/api/corr_points.cpp:26-131)."""
+    if max_points < 0:
+        raise ValueError("max_points must be >= 0")
+    if points.get_coordinate_type() != knots.get_coordinate_type():
+        raise ValueError("Both background grid and observations points must be of same coordinate type (lat/lon or x/y)")
+    out = _host_empty((points.size(), knots.size()))
+    if out.size:
+        check(lib().gpp_staticcorr_points(points._h, knots._h, _structure(structure), int(max_points), _ptr(out), _capi.MEM_HOST))
+    return out
+
+
 def _point_values(ipoints, values):
     if _is_dev(values):
         import torch

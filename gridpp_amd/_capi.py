@@ -58,6 +58,7 @@ SIGNATURES = {
     "gpp_calc_gradient": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_int],
     "gpp_points_get_neighbours_batch": [vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, C.c_longlong, C.POINTER(C.c_longlong)],
     "gpp_count": [vp, vp, C.c_float, vp, C.c_int],
+    "gpp_staticcorr_points": [vp, vp, C.POINTER(gpp_structure), C.c_int, vp, C.c_int],
     "gpp_distance": [vp, vp, C.c_int, C.c_int, vp, C.c_int],
     "gpp_gridding": [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int],
     "gpp_gridding_nearest": [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int],

@@ -666,3 +666,94 @@ extern "C" int gpp_distance(gpp_points* from, gpp_points* to, int num, int query
     return GPP_OK;
     GPP_CATCH
 }
+
+// ---- staticcorr_points (src/api/corr_points.cpp:26-131) -----------------------------------------------------------------
+namespace {
+// the knots a point keeps: inside its localization radius with corr_background > 0 -- counted (keys == NULL) or stored as
+// sortable keys (rho bits, ~knot index) at the point's CSR offset
+__global__ __launch_bounds__(256) void k_staticcorr_candidates(IxView ix, DevStructure st, const float* __restrict__ px, const float* __restrict__ py,
+                                                               const float* __restrict__ pz, const float* __restrict__ pe, const float* __restrict__ pl,
+                                                               int np, int* __restrict__ cnt, const long long* __restrict__ offset,
+                                                               unsigned long long* __restrict__ keys) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if(y >= np) return;
+    const float x1 = px[y], y1 = py[y], z1 = pz[y], e1 = pe[y], l1 = pl[y];
+    int c = 0;
+    long long w = keys ? offset[y] : 0;
+    visit_radius(ix, x1, y1, z1, st.R, true, [&](int j, int orig, float) {
+        const float4 g = ix.sgeo[j];
+        const float rho = d_corr(st, x1, y1, z1, e1, l1, g.x, g.y, g.z, g.w, ix.smeta[j].x, true);   // corr_background(p1, p2)
+        if(!(rho > 0.0f)) return;
+        if(keys) keys[w++] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
+        ++c;
+    });
+    if(!keys) cnt[y] = c;
+}
+// out[y][knot] = rho for the kept knots: all of them, or the max_points largest keys (rho descending, ties -> lower index)
+__global__ __launch_bounds__(256) void k_staticcorr_write(const unsigned long long* __restrict__ keys, const long long* __restrict__ offset,
+                                                          const int* __restrict__ cnt, int np, int nS, int max_points, float* __restrict__ out) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if(y >= np) return;
+    const unsigned long long* k = keys + offset[y];
+    const int n = cnt[y];
+    unsigned long long thr = 0ull;   // keep keys >= thr
+    if(max_points > 0 && n > max_points) {   // the max_points-th largest key, by bisection on the key value
+        unsigned long long lo = 0ull, hi = ~0ull;   // largest t with #(keys >= t) >= max_points
+        while(lo < hi) {
+            const unsigned long long mid = lo + ((hi - lo) >> 1) + 1ull;
+            int c = 0;
+            for(int i = 0; i < n; ++i) c += (k[i] >= mid) ? 1 : 0;
+            if(c >= max_points) lo = mid; else hi = mid - 1ull;
+        }
+        thr = lo;
+    }
+    float* row = out + (size_t)y * nS;
+    for(int i = 0; i < n; ++i) {
+        const unsigned long long key = k[i];
+        if(key >= thr) row[~(unsigned)(key & 0xffffffffull)] = __uint_as_float((unsigned)(key >> 32));
+    }
+}
+}   // namespace
+
+extern "C" int gpp_staticcorr_points(gpp_points* points, gpp_points* knots, const gpp_structure* st, int max_points, float* out, int mem) {
+    GPP_TRY
+    if(max_points < 0) invalid("max_points must be >= 0");                                  // corr_points.cpp:34-35
+    if(!points || !knots || !st) invalid("NULL argument");
+    if(points->type != knots->type)
+        invalid("Both background grid and observations points must be of same coordinate type (lat/lon or x/y)");   // :37-39
+    const int nY = points->n, nS = knots->n;
+    const size_t total = (size_t)nY * nS;
+    if(total == 0) return GPP_OK;
+    if(!out) invalid("out is NULL");
+    ensure_device();
+    DevStructure d = gpp_resolve_structure(st);
+    if(d.fh) runtime("staticcorr_points: spatially varying structure functions are not supported on the GPU path yet");
+    OutField o;
+    o.bind(out, total, mem);
+    GPP_HIP(hipMemsetAsync(o.d, 0, total * sizeof(float), stream()));                       // init_vec2(nY, nS, 0) (:44)
+    points->to_device();
+    gpp_obs_index* ix = gpp_build_obs_index(knots);
+    const IxView iv = view_of(ix);
+    DevBuf<int> cnt;
+    cnt.get(nY);
+    hipLaunchKernelGGL(k_staticcorr_candidates, dim3((nY + 255) / 256), dim3(256), 0, stream(), iv, d, points->d_x.p, points->d_y.p, points->d_z.p,
+                       points->d_elev.p, points->d_laf.p, nY, cnt.p, (const long long*)nullptr, (unsigned long long*)nullptr);
+    GPP_HIP(hipGetLastError());
+    DevBuf<long long> wide, offset;
+    const long long tot = scan_counts(cnt.p, nY, wide, offset);
+    if(tot > 0) {
+        DevBuf<unsigned long long> keys;
+        keys.get((size_t)tot);
+        hipLaunchKernelGGL(k_staticcorr_candidates, dim3((nY + 255) / 256), dim3(256), 0, stream(), iv, d, points->d_x.p, points->d_y.p, points->d_z.p,
+                           points->d_elev.p, points->d_laf.p, nY, cnt.p, offset.p, keys.p);
+        hipLaunchKernelGGL(k_staticcorr_write, dim3((nY + 255) / 256), dim3(256), 0, stream(), keys.p, offset.p, cnt.p, nY, nS, max_points, o.d);
+        GPP_HIP(hipGetLastError());
+        o.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));
+        return GPP_OK;
+    }
+    o.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}

@@ -227,6 +227,11 @@ int gpp_structure_localization_distance(const gpp_structure* s, float lat, float
  * (x, y, z, elev, laf, lat, lon) -- runs the same device code as the OI kernels */
 int gpp_structure_corr(const gpp_structure* s, const float p1[7], const float p2[7], int background, float* rho);
 
+/* gridpp::staticcorr_points (src/api/corr_points.cpp:26-131): out [size of points][size of knots] = corr_background(point,
+ * knot) for the knots a point keeps (inside its localization radius, rho > 0, the max_points largest if there are more; 0
+ * elsewhere).  Scalar structure functions.  out follows `mem`. */
+int gpp_staticcorr_points(gpp_points* points, gpp_points* knots, const gpp_structure* structure, int max_points, float* out, int mem);
+
 /* ---- optimal interpolation ------------------------------------------------
  * replaces gridpp::optimal_interpolation_full (src/api/oi.cpp:138-341, Points
  * form; the Grid form :342-412 is the same call on a grid handle) and through

@@ -927,6 +927,35 @@ int orc_gridding_nearest(const float* ox, const float* oy, const float* oz, int 
 }
 
 /* ------------------------------------------------------------------------ */
+/* staticcorr_points: src/api/corr_points.cpp:26-131                          */
+/* ------------------------------------------------------------------------ */
+/* out [nY][nS], zero except at the knots a point keeps: those inside its localization radius with
+ * corr_background > 0, the max_points largest of them if there are more (ties -> lower knot index; the reference's
+ * std::sort on rho alone leaves ties unspecified).  NO test of the reference covers this function: parity unpinned. */
+int orc_staticcorr_points(int nY, const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                          int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                          int kh, int kv, int kw, float h, float v, float w, float loc, int cv, float cv_dist,
+                          int max_points, float* out) {
+    if(max_points < 0) return ORC_EINVAL;
+    orc_struct st = {kh, kv, kw, h, v, w, loc, cv, cv_dist};
+    for(size_t i = 0; i < (size_t)nY * nS; i++) out[i] = 0;
+    orc_pair* work = (orc_pair*)malloc(sizeof(orc_pair) * (nS > 0 ? nS : 1));
+    for(int y = 0; y < nY; y++) {
+        int c = 0;
+        for(int j = 0; j < nS; j++) {
+            if(!orc_in_radius(gx[y], gy[y], gz[y], ox[j], oy[j], oz[j], loc, 1)) continue;
+            float rho = orc_corr_g(&st, gx[y], gy[y], gz[y], gelev[y], glaf[y], ox[j], oy[j], oz[j], oelev[j], olaf[j], 1);
+            if(rho > 0) { work[c].rho = rho; work[c].idx = j; c++; }
+        }
+        int keep = c;
+        if(max_points > 0 && c > max_points) { qsort(work, c, sizeof(orc_pair), orc_pair_cmp); keep = max_points; }
+        for(int i = 0; i < keep; i++) out[(size_t)y * nS + work[i].idx] = work[i].rho;
+    }
+    free(work);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* distance: src/api/distance.cpp:6-120                                      */
 /* ------------------------------------------------------------------------ */
 /* out[i] = the largest calc_distance (kdtree.cpp:107-133) from output location i to its `num` nearest input points

@@ -346,6 +346,16 @@ def calc_gradient(base, values, gradient_type, halfwidth, num_min, min_range, de
     return out
 
 
+def staticcorr_points(g, p, st, max_points):
+    """g: the points, p: the knots, st: Struct (src/api/corr_points.cpp:26-131)"""
+    out = np.empty((g.n, p.n), np.float32)
+    _check(lib().orc_staticcorr_points(C.c_int(g.n), g.x.ctypes, g.y.ctypes, g.z.ctypes, g.elevs.ctypes, g.lafs.ctypes, C.c_int(p.n),
+                                       p.x.ctypes, p.y.ctypes, p.z.ctypes, p.elevs.ctypes, p.lafs.ctypes, C.c_int(st.kh), C.c_int(st.kv),
+                                       C.c_int(st.kw), C.c_float(st.h), C.c_float(st.v), C.c_float(st.w), C.c_float(st.loc), C.c_int(st.cv),
+                                       C.c_float(st.cv_dist), C.c_int(max_points), out.ctypes))
+    return out
+
+
 def distance(p, q, num, query_first):
     """distance(input set p, output locations q, num) (src/api/distance.cpp)"""
     out = np.empty(q.n, np.float32)
