@@ -1,14 +1,14 @@
 """staticcorr_points on the device vs the oracle (orc_staticcorr_points).  The reference holds no test for this function
 (src/api/corr_points.cpp is exercised only through optimal_interpolation_ensi_multi_*, which has none either): parity
 unpinned against the reference, pinned only by the restatement.  rho values are the float32 structure-function values of
-the OI kernels, so the comparison is exact."""
+the OI kernels: exact for Barnes / Cressman, within one float32 ulp for the kernels that multiply an exp."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", ["Barnes", "Cressman", "Linear"])
+@pytest.mark.parametrize("kind", ["Barnes", "Cressman", "Soar"])
 @pytest.mark.parametrize("max_points", [0, 7, 1000])
 def test_staticcorr_matches_oracle(kind, max_points):
     import gridpp_amd as gridpp
@@ -24,7 +24,10 @@ def test_staticcorr_matches_oracle(kind, max_points):
     out = gridpp.staticcorr_points(pts, knots, st, max_points)
     ref = O.staticcorr_points(op, ok, O.Struct(kind, 20000, 300), max_points)
     assert out.shape == (L, K)
-    np.testing.assert_array_equal(out, ref)
+    if kind == "Soar":      # (1 + d/h) exp(-d/h): the device exp and the host libm differ in the last bit of a few values
+        np.testing.assert_allclose(out, ref, rtol=1e-6, atol=0)
+    else:
+        np.testing.assert_array_equal(out, ref)
     kept = (out > 0).sum(axis=1)
     assert kept.max() > 7 or max_points == 7
     if max_points == 7:
