@@ -130,6 +130,54 @@ __global__ void k_fill_missing_lines(const float* __restrict__ v, int Y, int X, 
         res[base + k * step] = r;
     }
 }
+// The same scan, one 256-thread workgroup per row held in LDS: every thread owns a contiguous segment, the last valid index
+// before a segment and the first valid index after it come from two 256-entry block scans, then the segment is walked
+// backwards (next valid index of every element) and forwards (the reference's formula).  Rows up to FM_MAXX elements.
+#define FM_MAXX 8192
+__global__ __launch_bounds__(256) void k_fill_missing_rows(const float* __restrict__ v, int Y, int X, float* __restrict__ res) {
+    __shared__ float s_v[FM_MAXX];
+    __shared__ int s_next[FM_MAXX];
+    __shared__ int s_last[256], s_first[256];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const float* row = v + (size_t)y * X;
+    for(int i = tid; i < X; i += 256) s_v[i] = row[i];
+    __syncthreads();
+    const int seg = (X + 255) / 256, i0 = tid * seg, i1 = min(i0 + seg, X);
+    int sl = -1, sf = 0x7fffffff;
+    for(int i = i0; i < i1; ++i) if(gv(s_v[i])) { sl = i; if(sf == 0x7fffffff) sf = i; }
+    s_last[tid] = sl; s_first[tid] = sf;
+    __syncthreads();
+    // exclusive prefix max of s_last, exclusive suffix min of s_first (256 entries: one short loop per thread)
+    int before = -1, after = 0x7fffffff;
+    for(int t = 0; t < tid; ++t) before = max(before, s_last[t]);
+    for(int t = tid + 1; t < 256; ++t) after = min(after, s_first[t]);
+    int nx = after;
+    for(int i = i1 - 1; i >= i0; --i) { if(gv(s_v[i])) nx = i; s_next[i] = nx; }
+    int last = before < 0 ? 0 : before;   // fill.cpp:49,86: `last` starts at 0 whether or not that element is valid
+    float* orow = res + (size_t)y * X;
+    for(int i = i0; i < i1; ++i) {
+        const float curr = s_v[i];
+        float r = NAN;
+        if(!gv(curr)) {
+            const int next = s_next[i];
+            if(next < X) {
+                const float vl = s_v[last], vn = s_v[next];
+                r = (vl) + (vn - vl) * (float)(i - last) / (float)(next - last);
+            }
+        }
+        else { last = i; r = curr; }
+        orow[i] = r;
+    }
+}
+// out[x][y] = in[y][x], 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, int Y, int X, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    for(int j = ty; j < 32; j += 8) { const int y = y0 + j, x = x0 + tx; if(y < Y && x < X) tile[j][tx] = in[(size_t)y * X + x]; }
+    __syncthreads();
+    for(int j = ty; j < 32; j += 8) { const int x = x0 + j, y = y0 + tx; if(y < Y && x < X) out[(size_t)x * Y + y] = tile[tx][j]; }
+}
 __global__ void k_fill_missing_merge(const float* __restrict__ ry, const float* __restrict__ rx, size_t n, float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n) return;
@@ -289,6 +337,20 @@ extern "C" int gpp_fill_missing(const float* values, int ny, int nx, float* out,
     o.bind(out, n, mem);
     DevBuf<float> ry, rx;
     ry.get(n); rx.get(n);
+    if(nx <= FM_MAXX && ny <= FM_MAXX && !getenv("GPP_FILL_MISSING_LINES")) {
+        // rows directly; columns as the rows of the transposed field
+        DevBuf<float> vt, rxt;
+        vt.get(n); rxt.get(n);
+        hipLaunchKernelGGL(k_fill_missing_rows, dim3(ny), dim3(256), 0, stream(), in.d, ny, nx, ry.p);
+        hipLaunchKernelGGL(k_transpose, dim3((nx + 31) / 32, (ny + 31) / 32), dim3(256), 0, stream(), in.d, ny, nx, vt.p);
+        hipLaunchKernelGGL(k_fill_missing_rows, dim3(nx), dim3(256), 0, stream(), vt.p, nx, ny, rxt.p);
+        hipLaunchKernelGGL(k_transpose, dim3((ny + 31) / 32, (nx + 31) / 32), dim3(256), 0, stream(), rxt.p, nx, ny, rx.p);
+        hipLaunchKernelGGL(k_fill_missing_merge, dim3(blocks(n)), dim3(256), 0, stream(), ry.p, rx.p, n, o.d);
+        GPP_HIP(hipGetLastError());
+        o.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));   // vt / rxt die here
+        return GPP_OK;
+    }
     hipLaunchKernelGGL(k_fill_missing_lines, dim3(blocks(ny)), dim3(256), 0, stream(), in.d, ny, nx, 0, ry.p);
     hipLaunchKernelGGL(k_fill_missing_lines, dim3(blocks(nx)), dim3(256), 0, stream(), in.d, ny, nx, 1, rx.p);
     hipLaunchKernelGGL(k_fill_missing_merge, dim3(blocks(n)), dim3(256), 0, stream(), ry.p, rx.p, n, o.d);

@@ -73,7 +73,7 @@ def test_doping_matches_oracle(cartesian, max_elev_diff):
         gridpp.doping_square(grid, bg, pts, obs, hw[:-1], max_elev_diff)
 
 
-def test_fill_missing_matches_oracle():
+def test_fill_missing_matches_oracle(monkeypatch):
     import torch
     import gridpp_amd as gridpp
     from oracle import oracle as O
@@ -87,6 +87,13 @@ def test_fill_missing_matches_oracle():
     np.testing.assert_array_equal(out, O.fill_missing(f))
     dev = gridpp.fill_missing(torch.from_numpy(f).cuda())
     np.testing.assert_array_equal(dev.cpu().numpy(), out)
+    # the one-thread-per-line kernels (fields wider than the LDS row) give the same bits
+    monkeypatch.setenv("GPP_FILL_MISSING_LINES", "1")
+    np.testing.assert_array_equal(gridpp.fill_missing(f), out)
+    monkeypatch.delenv("GPP_FILL_MISSING_LINES")
+    # odd shapes: one row, one column, all missing, a missing first element
+    for g in (f[:1, :], f[:, :1], np.full((7, 9), np.nan, np.float32), np.array([[np.nan, 1, np.nan, 3, np.nan]], np.float32)):
+        np.testing.assert_array_equal(gridpp.fill_missing(np.ascontiguousarray(g)), O.fill_missing(np.ascontiguousarray(g)))
 
 
 @pytest.mark.parametrize("with_apply", [False, True])
