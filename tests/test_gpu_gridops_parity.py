@@ -167,3 +167,29 @@ def test_fill_and_doping_properties_at_size():
     obs = np.arange(P, dtype=np.float32)
     who = np.asarray(gridpp.doping_circle(grid, np.full((N, N), -1, np.float32), pts, obs, same))
     assert (who >= 0).sum() == hit800.sum() and who.max() == P - 1
+
+
+def test_device_tensor_inputs_give_the_host_results():
+    """torch CUDA tensors in -> CUDA tensors out, same values as the numpy path (fill, doping, neighbourhood_search, calc_gradient)."""
+    import torch
+    import gridpp_amd as gridpp
+    Y, X = 40, 50
+    grid, og, lats, lons, ct = _grid(Y, X, False)
+    pts, op, rng = _points(lats, lons, 30, ct, 11)
+    field = rng.normal(0, 1, (Y, X)).astype(np.float32)
+    other = rng.random((Y, X)).astype(np.float32)
+    radii = rng.uniform(500, 6000, 30).astype(np.float32)
+    obs = rng.normal(0, 2, 30).astype(np.float32)
+    d_field, d_other, d_obs = torch.from_numpy(field).cuda(), torch.from_numpy(other).cuda(), torch.from_numpy(obs).cuda()
+    pairs = [
+        (gridpp.fill(grid, d_field, pts, radii, 3.0, False), gridpp.fill(grid, field, pts, radii, 3.0, False)),
+        (gridpp.doping_circle(grid, d_field, pts, d_obs, radii), gridpp.doping_circle(grid, field, pts, obs, radii)),
+        (gridpp.doping_square(grid, d_field, pts, d_obs, np.full(30, 2, np.int32)), gridpp.doping_square(grid, field, pts, obs, np.full(30, 2, np.int32))),
+        (gridpp.neighbourhood_search(d_field, d_other, 2, 0.7, 1.0, 0.1), gridpp.neighbourhood_search(field, other, 2, 0.7, 1.0, 0.1)),
+        (gridpp.calc_gradient(d_other, d_field, gridpp.LinearRegression, 2, 0, 0.0, -1.0), gridpp.calc_gradient(other, field, gridpp.LinearRegression, 2, 0, 0.0, -1.0)),
+        (gridpp.calc_gradient(d_other, d_field, gridpp.MinMax, 2, 0, 0.0, -1.0), gridpp.calc_gradient(other, field, gridpp.MinMax, 2, 0, 0.0, -1.0)),
+        (gridpp.nearest(grid, pts, d_field), gridpp.nearest(grid, pts, field)),
+    ]
+    for dev, host in pairs:
+        assert dev.is_cuda
+        np.testing.assert_array_equal(dev.cpu().numpy(), np.asarray(host))
