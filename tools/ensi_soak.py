@@ -1,0 +1,33 @@
+"""Randomised EnSI parity soak: both the 32-row tile path and k_ensi_big, vs the oracle (1e-5 relative)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tests.test_gpu_ensi_parity import case, run, check
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+t0, seed, bad, nbig = time.time(), 0, [], 0
+while time.time() - t0 < budget:
+    seed += 1
+    rng = np.random.default_rng(seed)
+    E = int(rng.choice([2, 5, 10, 30, 50, 64]))
+    S = int(rng.choice([20, 60, 150, 300]))
+    mp = int(rng.choice([0, 3, 10, 30, 32, 40, 60]))
+    h = float(rng.choice([15000.0, 30000.0, 60000.0]))
+    Y, X = int(rng.integers(5, 14)), int(rng.integers(5, 14))
+    c = case(5000 + seed, Y, X, E, S, nan_member=(1 if seed % 5 == 0 and E > 2 else None), nan_obs=(seed % 7 == 0))
+    allow = bool(seed % 2)
+    try:
+        out, ref = run(c, h, mp, allow=allow, v=(200 if seed % 3 == 0 else 0), elev=(seed % 3 == 0))
+    except RuntimeError as e:          # more than 512 usable observations: refused loudly, as documented
+        assert "more usable observations" in str(e), e
+        continue
+    try:
+        assert out.shape == ref.shape and (np.isnan(out) == np.isnan(ref)).all()
+        m = ~np.isnan(ref)
+        err = np.abs(out[m].astype(np.float64) - ref[m]) / np.maximum(np.abs(ref[m]), 1e-2)
+        assert err.max() < 1e-5, err.max()
+    except AssertionError as e:
+        bad.append((seed, E, S, mp, h, Y, X, allow, str(e)[:80]))
+    nbig += mp == 0 or mp > 32
+print("seeds: %d (%d with max_points beyond the tile), failures: %d" % (seed, nbig, len(bad)))
+for b in bad[:10]:
+    print(b)
