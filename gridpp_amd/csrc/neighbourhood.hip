@@ -236,6 +236,62 @@ __global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ in, 
     rs[plane + (long)y * X + x] = s;
     rc[plane + (long)y * X + x] = c;
 }
+// The same pass with four consecutive outputs per thread: the first one is the sum of its 2 hw + 1 taps, the next three slide the
+// window (add the entering tap, subtract the leaving one) -- (2 hw + 7) / 4 taps per output instead of 2 hw + 1 when nothing is
+// missing in the tile.  LDS index i lives at i + i / 4, which makes the lanes' stride odd (5 floats): no bank conflicts.
+#define ROWS4_TILE 1024
+__device__ __forceinline__ int pad4(int i) { return i + (i >> 2); }
+__global__ __launch_bounds__(256) void k_box_rows4(const float* __restrict__ in, int Y, int X, int hw, double* __restrict__ rs, int* __restrict__ rc,
+                                                   int* __restrict__ plane_has_invalid) {
+    extern __shared__ float lds[];   // pad4(ROWS4_TILE + 2*hwc) floats
+    const long plane = (long)blockIdx.z * Y * X;
+    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * ROWS4_TILE;
+    const int hwc = min(hw, X);
+    const int ntap = ROWS4_TILE + 2 * hwc;
+    const float* row = in + plane + (long)y * X;
+    int bad = 0;
+    for(int i = threadIdx.x; i < ntap; i += 256) {
+        const int x = x0 - hwc + i;
+        const bool inrow = x >= 0 && x < X;
+        const float v = inrow ? row[x] : 0.0f;
+        bad |= (inrow && !nv(v)) ? 1 : 0;
+        lds[pad4(i)] = inrow ? v : NAN;
+    }
+    const int any_bad = __syncthreads_or(bad);
+    const int base = 4 * threadIdx.x;
+    double s4[4]; int c4[4];
+    if(any_bad) {   // some value of this tile is missing: validity per tap, every output on its own
+        if(threadIdx.x == 0) atomicOr(&plane_has_invalid[blockIdx.z], 1);
+#pragma unroll
+        for(int j = 0; j < 4; ++j) {
+            double s = 0; int c = 0;
+            if(x0 + base + j < X) for(int k = 0; k <= 2 * hwc; k++) { const float v = lds[pad4(base + j + k)]; if(nv(v)) { s += (double)v; c++; } }
+            s4[j] = s; c4[j] = c;
+        }
+    }
+    else {
+        for(int i = threadIdx.x; i < ntap; i += 256) { const int xx = x0 - hwc + i; if(!(xx >= 0 && xx < X)) lds[pad4(i)] = 0.0f; }
+        __syncthreads();
+        double s = 0;
+#pragma unroll 8
+        for(int k = 0; k <= 2 * hwc; k++) s += (double)lds[pad4(base + k)];
+        s4[0] = s;
+#pragma unroll
+        for(int j = 1; j < 4; ++j) {
+            s += (double)lds[pad4(base + j + 2 * hwc)];
+            s -= (double)lds[pad4(base + j - 1)];
+            s4[j] = s;
+        }
+#pragma unroll
+        for(int j = 0; j < 4; ++j) { const int x = x0 + base + j; c4[j] = min(x + hwc, X - 1) - max(x - hwc, 0) + 1; }
+    }
+#pragma unroll
+    for(int j = 0; j < 4; ++j) {
+        const int x = x0 + base + j;
+        if(x < X) { rs[plane + (long)y * X + x] = s4[j]; rc[plane + (long)y * X + x] = c4[j]; }
+    }
+}
 // column pass + finish (neighbourhood.cpp:132-142): Mean / Sum / Count.  Each thread owns one column of a strip of
 // COL_STRIP rows and slides the window down it (2 reads per cell instead of 2*hw+1).
 #define COL_STRIP 64
@@ -476,7 +532,13 @@ void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statisti
     }
     int* flags = g_nb.plane_flags.get(nplanes);
     GPP_HIP(hipMemsetAsync(flags, 0, sizeof(int) * nplanes, stream()));
-    hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, Y, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc, flags);
+    if(hwc <= 1024 && hwc > 0 && !getenv("GPP_BOX_ROWS_DIRECT")) {
+        const int ntap = ROWS4_TILE + 2 * hwc;
+        hipLaunchKernelGGL(k_box_rows4, dim3((X + ROWS4_TILE - 1) / ROWS4_TILE, Y, nplanes), dim3(256), (size_t)(ntap + (ntap >> 2) + 4) * sizeof(float), stream(),
+                           d_in, Y, X, hw, rs, rc, flags);
+    }
+    else
+        hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, Y, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc, flags);
     GPP_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_box_cols, dim3((X + 255) / 256, (Y + COL_STRIP - 1) / COL_STRIP, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out, qf_reps, flags);
     GPP_HIP(hipGetLastError());
