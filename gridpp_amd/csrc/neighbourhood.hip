@@ -294,7 +294,9 @@ __global__ __launch_bounds__(256) void k_box_rows4(const float* __restrict__ in,
 }
 // column pass + finish (neighbourhood.cpp:132-142): Mean / Sum / Count.  Each thread owns one column of a strip of
 // COL_STRIP rows and slides the window down it (2 reads per cell instead of 2*hw+1).
-#define COL_STRIP 64
+#ifndef COL_STRIP
+#define COL_STRIP 32   // rows per thread-strip: 32 beats 64 by 4-6 % (more strips in flight; the pass is latency-bound)
+#endif
 __global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs, const int* __restrict__ rc, int Y, int X, int hw, int statistic, float* __restrict__ out, int qf_reps,
                                                   const int* __restrict__ plane_has_invalid) {
     const long plane = (long)blockIdx.z * Y * X;
