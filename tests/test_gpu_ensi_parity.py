@@ -117,3 +117,32 @@ def test_ensi_large_n_limits():
     c2 = case(902, 4, 4, 8, 600)
     with pytest.raises(RuntimeError, match="more usable observations"):
         run(c2, 200000, 0)
+
+
+# ---- vectors of an independent LAPACK restatement + the analytic 1-observation update (tests/golden/ensi_cases.npz,
+# tools/make_ensi_fixtures.py): the same vectors pin the oracle on the CPU (tests/test_oracle_golden.py)
+from tests import ensi_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ensi_golden.NAMES)
+def test_ensi_golden_vectors(name):
+    import gridpp_amd as gridpp
+    c = ensi_golden.CASES[name]
+    h, v, w, mp, allow = c["params"]
+    nb, ns = c["blat"].size, c["plat"].size
+    belev, blaf = c.get("belev", np.full(nb, np.nan, np.float32)), c.get("blaf", np.full(nb, np.nan, np.float32))
+    pelev, plaf = c.get("pelev", np.full(ns, np.nan, np.float32)), c.get("plaf", np.full(ns, np.nan, np.float32))
+    points = gridpp.Points(c["plat"], c["plon"], pelev, plaf)
+    E = c["background"].shape[1]
+    if "shape" in c and c["shape"][0] > 0:      # Grid overload
+        Y, X = int(c["shape"][0]), int(c["shape"][1])
+        grid = gridpp.Grid(c["blat"].reshape(Y, X), c["blon"].reshape(Y, X), belev.reshape(Y, X), blaf.reshape(Y, X))
+        out = gridpp.optimal_interpolation_ensi(grid, c["background"].reshape(Y, X, E), points, c["pobs"], c["psigmas"],
+                                                c["pbackground"], gridpp.BarnesStructure(h, v, w), int(mp), bool(allow))
+    else:                                        # Points overload
+        bpoints = gridpp.Points(c["blat"], c["blon"], belev, blaf)
+        out = gridpp.optimal_interpolation_ensi(bpoints, c["background"], points, c["pobs"], c["psigmas"], c["pbackground"],
+                                                gridpp.BarnesStructure(h, v, w), int(mp), bool(allow))
+    out = np.asarray(out)
+    assert out.dtype == np.float32
+    ensi_golden.check(out.reshape(nb, E), c)

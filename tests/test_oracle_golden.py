@@ -8,3 +8,22 @@ from tests import pins, refapi
 @pytest.mark.parametrize("pin", pins.ALL_PINS, ids=lambda f: f.__name__)
 def test_oracle_pin(pin, golden):
     pin(refapi, golden)
+
+
+# ---- EnSI: the reference's tests hold no numeric value (tests/test_optimal_interpolation_ens.py:9-35), so the oracle's EnSI
+# part (own LU inverse + cyclic Jacobi) is pinned by vectors from an independent LAPACK restatement and a closed form
+from tests import ensi_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ensi_golden.NAMES)
+def test_oracle_ensi_golden(name):
+    import numpy as np
+    from oracle import oracle as O
+    c = ensi_golden.CASES[name]
+    h, v, w, mp, allow = c["params"]
+    nan_b = np.full(c["blat"].size, np.nan, np.float32)
+    nan_p = np.full(c["plat"].size, np.nan, np.float32)
+    g = O.Pts(c["blat"], c["blon"], c.get("belev", nan_b), c.get("blaf", nan_b))
+    p = O.Pts(c["plat"], c["plon"], c.get("pelev", nan_p), c.get("plaf", nan_p))
+    out = O.oi_ensi(g, c["background"], p, c["pobs"], c["psigmas"], c["pbackground"], O.Barnes(h, v, w), int(mp), bool(allow))
+    ensi_golden.check(out, c)
