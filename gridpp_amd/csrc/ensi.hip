@@ -35,6 +35,8 @@ struct EnsiArgs {
     const float* gY;          // [S][nV] perturbations of the valid members (float)
     const int* validIdx;      // [nV]
     unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
+    unsigned* meta;           // [ntiles][64] k_ensi_scan -> k_ensi_pair: selection length | 0x100 if the reference sorted
+    unsigned long long* hsigs;   // [ntiles][64] order-independent signature of every selection
     double* gram;             // [ntiles][EN*EN] scratch: Y Y^T of the current run of equal selections
     int* big_list;            // cells with more usable observations than the 32-row tile holds (k_ensi_big), or NULL
     int* big_count;
@@ -463,6 +465,8 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
     if(lane == 0 && a.counters) { atomicAdd(&a.counters[1], (unsigned long long)ndone); atomicAdd(&a.counters[4 + (blockIdx.x & 31)], (unsigned long long)nsweeps); }
 }
 
+#include "ensi_pair.h"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_ensi_big: grid points with more than 32 usable observations (max_points == 0 or > 32).  One 256-thread workgroup per
 // cell, the E x E formulation the reference itself uses (oi_ensi.cpp:379-553), E <= 64 valid members, up to EBIG_N selected
@@ -729,7 +733,8 @@ struct EnsiWorkspace {
     DevBuf<float4> pgeo, oaux;
     DevBuf<float> gYhat, gY;
     DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
-    DevBuf<unsigned> sel;
+    DevBuf<unsigned> sel, meta;
+    DevBuf<unsigned long long> hsigs;
     DevBuf<double> gram;
     DevBuf<unsigned long long> counters, big_keys;
     DevBuf<int> big_list, big_count;
@@ -791,7 +796,10 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     std::vector<int> valid;
     for(int e = 0; e < E; e++) if(flags[e]) valid.push_back(e);
     const int nV = (int)valid.size();
-    if(nV > EMAXV) runtime("optimal_interpolation_ensi: more than 64 valid ensemble members are not supported on the GPU path yet");
+    // k_ensi_pair (default) takes any number of valid members; the older LDS-resident k_ensi (GPP_ENSI_V1=1, kept for A/B
+    // measurements) and k_ensi_big (more than 32 usable observations at a grid point) hold one member per lane
+    const bool use_pair = !getenv("GPP_ENSI_V1");
+    if(!use_pair && nV > EMAXV) runtime("optimal_interpolation_ensi: more than 64 valid ensemble members need the default kernel (unset GPP_ENSI_V1)");
     if(nV == 0) { f_out.finish(); GPP_HIP(hipStreamSynchronize(stream())); return GPP_OK; }
     ws.validIdx.upload(valid.data(), nV);
     ws.gYhat.get(S); ws.gY.get((size_t)S * nV);
@@ -844,13 +852,27 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, sizeof(int), stream()));
     }
     GPP_HIP(hipEventRecord(ws.e0, stream()));
-    if(a.s.st.fh) hipLaunchKernelGGL(k_ensi<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+    if(use_pair) {
+        a.meta = ws.meta.get((size_t)a.ntiles * 64);
+        a.hsigs = ws.hsigs.get((size_t)a.ntiles * 64);
+        if(a.s.st.fh) {
+            hipLaunchKernelGGL(k_ensi_scan<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+            hipLaunchKernelGGL(k_ensi_pair<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+        }
+        else {
+            hipLaunchKernelGGL(k_ensi_scan<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+            hipLaunchKernelGGL(k_ensi_pair<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+        }
+    }
+    else if(a.s.st.fh) hipLaunchKernelGGL(k_ensi<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
     else hipLaunchKernelGGL(k_ensi<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
     GPP_HIP(hipGetLastError());
     if(big_ok) {
         int nbig = 0;
         GPP_HIP(hipMemcpyAsync(&nbig, ws.big_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipStreamSynchronize(stream()));
+        if(nbig > 0 && nV > EMAXV)
+            runtime("optimal_interpolation_ensi: grid points with more than 32 usable observations are limited to 64 valid ensemble members on the GPU path");
         if(nbig > 0) {
             const int nwg = std::min(nbig, 1024);
             a.big_keys = ws.big_keys.get((size_t)nwg * EBIG_CAND);

@@ -1,0 +1,592 @@
+// k_ensi_pair: ensemble OI with the n x n eigenproblem held in registers (included by ensi.hip).
+//
+// Same mathematics as k_ensi (B = A A^T = U S U^T, n <= 32 selected observations; oi_ensi.cpp:379-553), different machine
+// mapping.  k_ensi kept B and U in LDS and spent most of its time waiting for LDS (every Jacobi step = two barriers, four
+// dependent LDS round trips, ~100 LDS instructions).  Here
+//   * TWO grid cells with the SAME selection are solved side by side, one per half wave: lane 32 h + i holds row i of B and
+//     row i of U of cell h in 128 VGPRs; Y, the Gram matrix Y Y^T and the staging areas are shared by the pair;
+//   * the Jacobi sweeps use the odd-even ordering with the swap folded into the rotation (phases alternate between the
+//     pairs (2k, 2k+1) and (2k+1, 2k+2); after 32 phases every pair of indices has met exactly once): the partner of a
+//     row is always the neighbouring lane (DPP quad_perm / wave shifts, no LDS), the partner of a column always the
+//     neighbouring register (static indices);  the only LDS traffic of a step is the broadcast of the 16 (c, s) pairs;
+//   * the n x n x n products (warm start U^T B U, U diag U^T, (M_W D) Y) run on the matrix cores through two 8.5 KB
+//     staging areas that are reused for Y and for the transposed member-update operands;
+//   * any number of valid ensemble members (chunks of 64 lanes); the member update keeps the reference's float
+//     accumulation over k (oi_ensi.cpp:505-511) term by term.
+#pragma once
+
+#define PP 34             // pitch (doubles) of the staged 32 x 32 matrices: 16-byte aligned rows, 2-way bank conflicts at most
+#define YP 65             // pitch (floats) of the Y tile
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+// ---- cross-lane moves of doubles on the VALU (DPP) -------------------------------------------------------------------------
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_d(const double old, const double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+// value of the partner lane (byte address paddr = 4 * partner lane) through the LDS crossbar: keeps the VALU free, and the odd
+// phase has no DPP pattern (bank_mask selects groups of four lanes, not a lane parity)
+__device__ __forceinline__ double partner_of(const double v, const int paddr) {
+    const int lo = __builtin_amdgcn_ds_bpermute(paddr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(paddr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// sum over the 32 lanes of each half wave, returned to every lane of the half
+__device__ __forceinline__ double half_sum_d(double v, const int lane) {
+    v += dpp_d<0x111, 0xf>(0.0, v);   // row_shr:1  (old = 0: lanes without a source add 0)
+    v += dpp_d<0x112, 0xf>(0.0, v);
+    v += dpp_d<0x114, 0xf>(0.0, v);
+    v += dpp_d<0x118, 0xf>(0.0, v);
+    // lane 15 of every row holds the row sum; rows 1 and 3 add the sum of the row before (row_bcast:15, rows 1 and 3 only)
+    {
+        int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xa, 0xf, false);
+        int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xa, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    }
+    const double s0 = readlane_d(v, 31), s1 = readlane_d(v, 63);
+    return lane < 32 ? s0 : s1;
+}
+
+// a value the optimiser cannot trace back to its load: keeps `select(load, load)` from becoming `load(select(address))`, which
+// would turn the register-resident rows into a dynamically indexed stack array
+__device__ __forceinline__ double opq(double x) { asm("" : "+v"(x)); return x; }
+
+// 16-way selection x[sel] by four lane-dependent bits (b0 = least significant): a tree of 15 v_cndmask pairs.  The leaves are
+// made opaque first, all of them unconditionally (an asm inside a conditional arm would turn the tree into branches).
+__device__ __forceinline__ double mux16(const bool b0, const bool b1, const bool b2, const bool b3, double x0, double x1, double x2, double x3,
+                                        double x4, double x5, double x6, double x7, double x8, double x9, double x10, double x11, double x12,
+                                        double x13, double x14, double x15) {
+    x0 = opq(x0); x1 = opq(x1); x2 = opq(x2); x3 = opq(x3); x4 = opq(x4); x5 = opq(x5); x6 = opq(x6); x7 = opq(x7);
+    x8 = opq(x8); x9 = opq(x9); x10 = opq(x10); x11 = opq(x11); x12 = opq(x12); x13 = opq(x13); x14 = opq(x14); x15 = opq(x15);
+    const double y0 = b0 ? x1 : x0, y1 = b0 ? x3 : x2, y2 = b0 ? x5 : x4, y3 = b0 ? x7 : x6, y4 = b0 ? x9 : x8, y5 = b0 ? x11 : x10,
+                 y6 = b0 ? x13 : x12, y7 = b0 ? x15 : x14;
+    const double z0 = b1 ? y1 : y0, z1 = b1 ? y3 : y2, z2 = b1 ? y5 : y4, z3 = b1 ? y7 : y6;
+    const double w0 = b2 ? z1 : z0, w1 = b2 ? z3 : z2;
+    return b3 ? w1 : w0;
+}
+#define MUX16(...) mux16(m1, m2, m3, m4, __VA_ARGS__)      /* x[(i >> 1) & 15] */
+#define MUXD(...) mux16(e0, e1, e2, e3, __VA_ARGS__)       /* x[i & 15] */
+
+__device__ __forceinline__ double d_rcp_n1(const double a) { double r = __builtin_amdgcn_rcp(a); return r * (2.0 - a * r); }
+__device__ __forceinline__ double d_rsq_n1(const double a) { double r = __builtin_amdgcn_rsq(a); return r * (1.5 - 0.5 * a * r * r); }
+
+// Jacobi rotation that annihilates apq (dp, dq: the two diagonal entries).  The angle only has to be accurate enough for
+// the quadratic convergence (one Newton step on the reciprocals); cs^2 + sn^2 = 1 holds to the accuracy of cs (two steps).
+__device__ __forceinline__ void jacobi_rotation(const double apq, const double dp, const double dq, double& cs, double& sn, double& tap) {
+    const double theta = (dq - dp) * 0.5 * d_rcp_n1(apq);
+    const double h2 = theta * theta + 1.0;
+    const double t = (theta >= 0 ? 1.0 : -1.0) * d_rcp_n1(fabs(theta) + h2 * d_rsq_n1(h2));
+    const double c_ = d_rsq_nr(t * t + 1.0);
+    const bool ok = fabs(theta) < 1e150;      // false for apq == 0 (theta inf / NaN) and for a negligible apq
+    cs = ok ? c_ : 1.0;
+    sn = ok ? t * c_ : 0.0;
+    tap = ok ? t * apq : 0.0;
+}
+
+// full 32 x 32 x 32 product on the matrix cores, operands through accessors (no bounds: the staged matrices are zero padded)
+template <class FA, class FB>
+__device__ __forceinline__ Acc32 mfma_32_full(const int lane, FA a_at, FB b_at) {
+    Acc32 c;
+    c.t[0][0] = c.t[0][1] = c.t[1][0] = c.t[1][1] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for(int kk = 0; kk < 32; kk += 4) {
+        const int k = kk + kq;
+        const double a0 = a_at(r, k), a1 = a_at(r + 16, k), b0 = b_at(k, r), b1 = b_at(k, r + 16);
+        c.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c.t[0][0], 0, 0, 0);
+        c.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c.t[0][1], 0, 0, 0);
+        c.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c.t[1][0], 0, 0, 0);
+        c.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c.t[1][1], 0, 0, 0);
+    }
+    return c;
+}
+__device__ __forceinline__ void acc32_store_full(const Acc32& c, const int lane, double* M) {
+#pragma unroll
+    for(int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for(int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for(int r = 0; r < 4; ++r) M[(16 * ti + (lane >> 4) + 4 * r) * PP + 16 * tj + (lane & 15)] = c.t[ti][tj][r];
+}
+
+// one phase of the odd-even Jacobi ordering on the register-resident rows (b: B, u: U, dg: diagonal of B)
+template <bool ODD>
+__device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], double& dg, const int i, const int h,
+                                             const bool m1, const bool m2, const bool m3, const bool m4, double* s_cs) {
+    // the off-diagonal entry of this lane's pair: leaders (even rows in the even phase, odd rows in the odd phase) hold it in
+    // register i + 1
+    const double apq = ODD ? MUX16(b[2], b[4], b[6], b[8], b[10], b[12], b[14], b[16], b[18], b[20], b[22], b[24], b[26], b[28], b[30], 0.0)
+                           : MUX16(b[1], b[3], b[5], b[7], b[9], b[11], b[13], b[15], b[17], b[19], b[21], b[23], b[25], b[27], b[29], b[31]);
+    const bool idle = ODD && (i == 0 || i == 31);
+    const bool leader = ODD ? ((i & 1) != 0 && !idle) : ((i & 1) == 0);
+    const int paddr = (ODD ? (idle ? (32 * h + i) : ((i & 1) ? 32 * h + i + 1 : 32 * h + i - 1)) : ((32 * h + i) ^ 1)) << 2;
+    const double dpart = partner_of(dg, paddr);
+    double cs, sn, tap;
+    jacobi_rotation(apq, dg, dpart, cs, sn, tap);
+    // the partner lane takes the leader's rotation
+    const double cs_p = partner_of(cs, paddr);
+    const double sn_p = partner_of(sn, paddr);
+    const double tap_p = partner_of(tap, paddr);
+    cs = leader ? cs : cs_p; sn = leader ? sn : sn_p; tap = leader ? tap : tap_p;
+    if(idle) { cs = 1.0; sn = 0.0; tap = 0.0; }
+    if(leader) { double2 v; v.x = cs; v.y = sn; *reinterpret_cast<double2*>(&s_cs[(h * 16 + (i >> 1)) * 2]) = v; }
+    // rotation + swap: position p receives the rotated row / column q and vice versa, so the pairs of the next phase are neighbours again
+    //   row p' = c row p - s row q,  row q' = s row p + c row q;  lane p keeps q' = s own + c partner, lane q keeps p' = c partner - s own
+    const double alpha = idle ? 1.0 : (leader ? sn : -sn);
+    const double beta = idle ? 0.0 : cs;
+    dg = idle ? dg : dpart + (leader ? tap : -tap);      // a_pp' = a_pp - t a_pq, a_qq' = a_qq + t a_pq, swapped
+    // groups of 8 registers / 4 pairs with scheduling barriers in between: the scheduler would otherwise hoist all 32 partner
+    // values and all 16 (c, s) pairs to the front and push the two matrices out of the register file
+#pragma unroll
+    for(int j0 = 0; j0 < 32; j0 += 8) {
+#pragma unroll
+        for(int j = j0; j < j0 + 8; ++j) {
+            const double pj = partner_of(b[j], paddr);
+            b[j] = __builtin_fma(alpha, b[j], beta * pj);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // (c, s) of all pairs visible
+    // columns: (x, y) = columns (p, q):  p' = c x - s y,  q' = s x + c y, stored swapped
+#pragma unroll
+    for(int k0 = 0; k0 < 16; k0 += 4) {
+#pragma unroll
+        for(int k = k0; k < k0 + 4; ++k) {
+            if(ODD && k == 15) continue;
+            const double2 cs2 = *reinterpret_cast<const double2*>(&s_cs[(h * 16 + k) * 2]);
+            const int p = ODD ? 2 * k + 1 : 2 * k, q = p + 1;
+            const double x = b[p], y = b[q];
+            b[p] = __builtin_fma(cs2.y, x, cs2.x * y);
+            b[q] = __builtin_fma(cs2.x, x, -(cs2.y * y));
+            const double ux = u[p], uy = u[q];
+            u[p] = __builtin_fma(cs2.y, ux, cs2.x * uy);
+            u[q] = __builtin_fma(cs2.x, ux, -(cs2.y * uy));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // before the next phase overwrites s_cs
+}
+
+
+// cell of lane `l` of tile `tile` (the same mapping in both kernels)
+__device__ __forceinline__ int ensi_cell_of(const EnsiArgs& a, const int tile, const int l) {
+    if(a.tiled2d) {
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int y = ty * (64 >> a.wshift) + (l >> a.wshift), x = (tx << a.wshift) + (l & ((1 << a.wshift) - 1));
+        return (y < a.ny && x < a.nx) ? y * a.nx + x : -1;
+    }
+    const int c = tile * 64 + l;
+    return c < a.C ? c : -1;
+}
+
+// ---- pass 1: candidate scan of a tile; the selections are parked in HBM in ascending observation index (a canonical order:
+//      equal selections give equal lists) together with their length, the "reference sorted" flag and an order-independent
+//      signature:  sel[tile][position][lane], meta[tile][lane], hsigs[tile][lane]
+template <bool SPATIAL>
+__global__ __launch_bounds__(64) void k_ensi_scan(EnsiArgs a) {
+    __shared__ unsigned long long s_keys[EN][64];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int cell = ensi_cell_of(a, tile, lane);
+    float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN;
+    if(cell >= 0) { gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell]; }
+    const bool active = cell >= 0;   // no background validity test here (oi_ensi.cpp:207-213)
+    if(__ballot(active) == 0ull) return;
+    bool overflow, truncated;
+    DevStructure cst = a.s.st;
+    if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
+    int cnt = scan_tile<EN, true>(a.s, cst, active, gx, gy, gz, ge, gl, s_keys, lane, overflow, truncated);
+    if(__ballot(overflow) != 0ull) {   // more usable observations than the 32-row tile holds: those cells go to k_ensi_big
+        if(a.big_list) { if(overflow) a.big_list[atomicAdd(a.big_count, 1)] = cell; }
+        else if(lane == 0) atomicOr(a.err, 1);
+        cnt = overflow ? 0 : cnt;
+    }
+    unsigned* const sel = a.sel + (size_t)tile * EN * 64;
+    unsigned long long hsig = 0;
+    unsigned idx[EN];
+#pragma unroll
+    for(int s = 0; s < EN; ++s) idx[s] = (s < cnt) ? ~(unsigned)(s_keys[s][lane] & 0xffffffffull) : 0xffffffffu;
+#pragma unroll 1
+    for(int s = 0; s < a.s.K; ++s) {
+        const unsigned mine = (s < cnt) ? ~(unsigned)(s_keys[s][lane] & 0xffffffffull) : 0xffffffffu;
+        int rank = 0;
+#pragma unroll
+        for(int t = 0; t < EN; ++t) rank += (idx[t] < mine) ? 1 : 0;
+        if(s < cnt) {
+            sel[rank * 64 + lane] = mine;
+            unsigned long long x = (unsigned long long)mine + 0x9e3779b97f4a7c15ull;
+            x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+            hsig += x;
+        }
+    }
+    a.meta[(size_t)tile * 64 + lane] = (unsigned)cnt | (truncated ? 0x100u : 0u);
+    a.hsigs[(size_t)tile * 64 + lane] = hsig;
+}
+
+// ---- pass 2: the solves -------------------------------------------------------------------------------------------------------
+template <bool SPATIAL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ensi_pair(EnsiArgs a) {
+    // 17 KB: staging areas A / B of the products; B doubles as Y tile and as the transposed operands of the member update
+    __shared__ __attribute__((aligned(16))) double s_ab[2 * 32 * PP];
+    __shared__ __attribute__((aligned(16))) double s_sD[2][32], s_r[2][32], s_z[2][32];
+    __shared__ __attribute__((aligned(16))) double s_cs[64];      // (c, s) of the Jacobi pairs [h][16][2]; later dw[32], t[32]
+    __shared__ int s_i[128];                                      // perm[32] | obs[32] | yhat[32] (floats) | selection[32]
+    double* const sA = s_ab;
+    double* const sB = s_ab + 32 * PP;
+    float* const sBf = reinterpret_cast<float*>(sB);             // Y tile [32][YP] floats (8320 B <= 8704 B)
+    double* const s_dw = s_cs;
+    double* const s_t = s_cs + 32;
+    int* const s_perm = s_i;
+    float* const s_ob = reinterpret_cast<float*>(s_i + 32);
+    float* const s_yh = reinterpret_cast<float*>(s_i + 64);
+    unsigned* const s_sel = reinterpret_cast<unsigned*>(s_i + 96);
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int h = lane >> 5, i = lane & 31;
+    const bool m1 = (i & 2) != 0, m2 = (i & 4) != 0, m3 = (i & 8) != 0, m4 = (i & 16) != 0;
+    const int nV = a.nV, E = a.E;
+    if(nV <= 1) return;   // Pinv is the zero matrix: rcond <= 0 -> raw values everywhere (oi_ensi.cpp:386-390)
+    const unsigned meta = a.meta[(size_t)tile * 64 + lane];
+    const int cnt = ensi_cell_of(a, tile, lane) >= 0 ? (int)(meta & 0xffu) : 0;
+    const unsigned long long hsig = a.hsigs[(size_t)tile * 64 + lane];
+    const unsigned long long trunc_mask = __ballot((meta & 0x100u) != 0u);
+    const unsigned* const sel = a.sel + (size_t)tile * EN * 64;
+    double* const gram = a.gram + (size_t)tile * EN * EN;
+
+    const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
+    const double sqc = sqrt(c);
+    double b[32], u[32];
+#pragma unroll
+    for(int j = 0; j < 32; ++j) { b[j] = 0.0; u[j] = (j == i) ? 1.0 : 0.0; }
+    unsigned prev_orig = 0xffffffffu; int prev_n = -1;
+    unsigned long long todo = __ballot(cnt > 0);
+    int ndone = 0, nsweeps = 0;
+    while(todo) {
+        // ---- next group: the cells whose selection equals that of the lowest cell still to do ------------------------------------
+        const int l0 = __builtin_ctzll(todo);
+        const int n = __builtin_amdgcn_readlane(cnt, l0);
+        const unsigned long long cur_h = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hsig >> 32), l0) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane((int)hsig, l0);
+        const unsigned long long grp = __ballot(cnt == n && hsig == cur_h) & todo;
+        const int npairs = (__builtin_popcountll(grp) + 1) >> 1;
+        const int rk = __builtin_popcountll(grp & ((1ull << lane) - 1ull));   // this lane's rank inside the group
+        unsigned long long done = 0ull;
+        // half 0 walks the first half of the group, half 1 the second half: consecutive cells of a half are neighbours,
+        // so the eigenvectors of one cell are an excellent starting basis for the next (warm start below)
+#pragma unroll 1
+        for(int jp = 0; jp < npairs; ++jp) {
+            const int la = __builtin_ctzll(__ballot(((grp >> lane) & 1ull) && rk == jp));
+            const unsigned long long mb = __ballot(((grp >> lane) & 1ull) && rk == jp + npairs);
+            int lb = mb ? __builtin_ctzll(mb) : la;
+            // ---- selection (ascending observation index); both cells must have the very same list -------------------------------
+            const unsigned orig_i = (i < n) ? sel[i * 64 + la] : 0xffffffffu;
+            if(lb != la) {
+                const unsigned ob = (i < n) ? sel[i * 64 + lb] : 0xffffffffu;
+                if(__ballot(orig_i != ob) != 0ull) lb = la;   // equal signature, different lists (never seen): that cell waits for its own group
+            }
+            const bool dup = lb == la;     // half 1 repeats cell la, its result is not stored
+            done |= (1ull << la) | (1ull << lb);
+            const bool same = n == prev_n && __ballot(orig_i != prev_orig) == 0ull;   // u still holds the eigenvectors of this selection
+            prev_n = n; prev_orig = orig_i;
+            const int cell_c = ensi_cell_of(a, tile, h ? lb : la);
+            const float cx = a.gx[cell_c], cy = a.gy[cell_c], cz = a.gz[cell_c], ce = a.gelev[cell_c], cl = a.glaf[cell_c];
+            ndone += dup ? 1 : 2;
+            // ---- per-observation quantities (lane i < n of each half) ----------------------------------------------------------------
+            float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 1);
+            if(i < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
+            DevStructure lst = a.s.st;
+            if(SPATIAL) d_structure_at(lst, lst.cell_idx ? lst.cell_idx[cell_c] : cell_c);
+            const float rho = d_corr(lst, cx, cy, cz, ce, cl, o0.x, o0.y, o0.z, o0.w, o1.x, true);   // :227
+            const float sig2 = o1.w * o1.w;                                    // float product (:300)
+            const double D = (double)rho / (double)sig2;                       // Rinv(i,i)
+            const double sD = (i < n) ? sqrt(D) : 0.0;
+            const double dobs = (double)o1.y - (double)o1.z;                   // lObs - lYhat (:437)
+            __syncthreads();
+            s_sD[h][i] = sD; s_r[h][i] = (i < n) ? sD * dobs : 0.0;
+            if(h == 0) s_sel[i] = orig_i;
+            __syncthreads();
+            // ---- new selection: Gram matrix Y Y^T on the matrix cores (all members, chunks of 64), parked in HBM -----------------------
+            if(!same) {
+                Acc32 g;
+                g.t[0][0] = g.t[0][1] = g.t[1][0] = g.t[1][1] = (v4d){0.0, 0.0, 0.0, 0.0};
+                for(int m0 = 0; m0 < nV; m0 += 64) {
+                    __syncthreads();
+#pragma unroll 4
+                    for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = (r < n && m0 + lane < nV) ? a.gY[(long)s_sel[r] * nV + m0 + lane] : 0.0f;
+                    __syncthreads();
+                    const int r = lane & 15, kq = lane >> 4;
+                    const int kend = min(64, nV - m0);
+                    for(int kk = 0; kk < kend; kk += 4) {
+                        const double a0 = (double)sBf[r * YP + kk + kq], a1 = (double)sBf[(r + 16) * YP + kk + kq];
+                        g.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, g.t[0][0], 0, 0, 0);
+                        g.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, g.t[0][1], 0, 0, 0);
+                        g.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, g.t[1][0], 0, 0, 0);
+                        g.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g.t[1][1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for(int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for(int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for(int r = 0; r < 4; ++r) gram[(16 * ti + (lane >> 4) + 4 * r) * EN + 16 * tj + (lane & 15)] = g.t[ti][tj][r];
+                __threadfence();
+                __syncthreads();
+#pragma unroll
+                for(int j = 0; j < 32; ++j) u[j] = (j == i) ? 1.0 : 0.0;
+            }
+            // ---- B = (sD sD^T) o (Y Y^T): row i of each half ------------------------------------------------------------------------------
+#pragma unroll
+            for(int j = 0; j < 32; ++j) {
+                const double gij = __hip_atomic_load(&gram[i * EN + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b[j] = gij * (sD * s_sD[h][j]);
+            }
+            // ---- warm start: B <- U^T B U with the eigenvectors of the previous cell of this half (nearly diagonal already) ------------
+            if(same) {
+#pragma unroll 1
+                for(int hh = 0; hh < 2; ++hh) {
+                    __syncthreads();
+                    if(h == hh) {
+#pragma unroll
+                        for(int j = 0; j < 32; j += 2) {
+                            double2 v; v.x = b[j]; v.y = b[j + 1]; *reinterpret_cast<double2*>(&sA[i * PP + j]) = v;
+                            double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w;
+                        }
+                    }
+                    __syncthreads();
+                    const Acc32 t = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
+                    __syncthreads();
+                    acc32_store_full(t, lane, sA);
+                    __syncthreads();
+                    const Acc32 bb = mfma_32_full(lane, [&](int r, int k) { return sB[k * PP + r]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
+                    __syncthreads();
+                    acc32_store_full(bb, lane, sA);
+                    __syncthreads();
+                    if(h == hh) {   // symmetrised (the two one-sided products round differently)
+#pragma unroll
+                        for(int j = 0; j < 32; ++j) b[j] = 0.5 * (sA[i * PP + j] + sA[j * PP + i]);
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- Jacobi sweeps, both cells in lockstep --------------------------------------------------------------------------------------
+            const bool e0 = (i & 1) != 0, e1 = (i & 2) != 0, e2 = (i & 4) != 0, e3 = (i & 8) != 0;
+            auto diag_of_rows = [&]() {
+                const double dhi = MUXD(b[16], b[17], b[18], b[19], b[20], b[21], b[22], b[23], b[24], b[25], b[26], b[27], b[28], b[29], b[30], b[31]);
+                const double dlo = MUXD(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11], b[12], b[13], b[14], b[15]);
+                return m4 ? dhi : dlo;
+            };
+            double dg = diag_of_rows();
+#pragma unroll 1
+            for(int sweep = 0; sweep < 30 && n > 1 && !(a.debug & 1); ++sweep) {
+                double off = 0.0;   // (not sum(b^2) - dg^2: the off-diagonal part is 20 orders below the diagonal when converged)
+#pragma unroll
+                for(int j = 0; j < 32; ++j) { const double v = (j == i) ? 0.0 : b[j]; off = __builtin_fma(v, v, off); }
+                off = half_sum_d(off, lane);
+                const double tr = half_sum_d(fabs(dg), lane);
+                // off-diagonal norm < 1e-11 * trace: Jacobi converges quadratically, so the eigenvalues are good to ~1e-22 and the
+                // eigenvectors to ~1e-11 relative -- five orders below what a float32 output can show
+                const bool open = off > 1e-22 * tr * tr;
+                if(__ballot(open && !(dup && h == 1)) == 0ull) break;
+                nsweeps++;
+#pragma unroll 1
+                for(int st = 0; st < 16; ++st) {
+                    jacobi_phase<false>(b, u, dg, i, h, m1, m2, m3, m4, s_cs);
+                    jacobi_phase<true>(b, u, dg, i, h, m1, m2, m3, m4, s_cs);
+                }
+                // the diagonal from the rows again (the running update drifts in the last bits)
+                dg = diag_of_rows();
+            }
+            // ---- spectral functions (lane i of half h: eigenvalue i of cell h) -------------------------------------------------------------
+            const double S = dg < 0.0 ? 0.0 : dg;
+            const double rt = sqrt(c + S);
+            const double dwv = -1.0 / (rt * (rt + sqc));      // W_sym = I + A^T U diag(dw) U^T A
+            const double inv = 1.0 / (c + S);
+#pragma unroll 1
+            for(int hh = 0; hh < (dup ? 1 : 2); ++hh) {
+                const int lcell = hh ? lb : la;
+                const int cell_l = ensi_cell_of(a, tile, lcell);
+                __syncthreads();
+                if(h == hh) {
+#pragma unroll
+                    for(int j = 0; j < 32; j += 2) { double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w; }
+                    s_dw[i] = dwv;
+                }
+                __syncthreads();
+                // z = U diag(1 / (c + S)) U^T r
+                if(h == hh) {
+                    double ur = 0.0;
+#pragma unroll 8
+                    for(int r = 0; r < 32; ++r) ur = __builtin_fma(sB[r * PP + i], s_r[hh][r], ur);
+                    s_t[i] = ur * inv;
+                }
+                __syncthreads();
+                if(h == hh) {
+                    double zz = 0.0;
+#pragma unroll
+                    for(int j = 0; j < 32; ++j) zz = __builtin_fma(u[j], s_t[j], zz);
+                    s_z[hh][i] = zz;
+                }
+                // M_W = U diag(dw) U^T, scaled: M'(i, j) = sD_i M_W(i, j) sD_j   -> area A (stays there for the whole member update)
+                {
+                    const Acc32 mw = mfma_32_full(lane, [&](int r, int k) { return sB[r * PP + k] * s_dw[k]; }, [&](int k, int cc) { return sB[cc * PP + k]; });
+                    __syncthreads();
+#pragma unroll
+                    for(int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for(int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                            for(int r = 0; r < 4; ++r) {
+                                const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
+                                sA[row * PP + col] = (a.debug & 8) ? 0.0 : mw.t[ti][tj][r] * (s_sD[hh][row] * s_sD[hh][col]);
+                            }
+                }
+                __syncthreads();
+                // anti-extrapolation tables (oi_ensi.cpp:520-552): lY[e] is a LINEAR index into the n x nV column-major matrix, so it
+                // depends on the ORDER of the selected observations: rho descending when the reference sorted (more usable
+                // observations than max_points), candidate (= index) order otherwise
+                if(!a.allow_extrap) {
+                    const bool tr_l = (trunc_mask >> lcell) & 1ull;
+                    unsigned long long* const s_k64 = reinterpret_cast<unsigned long long*>(s_t);   // 32 keys (s_t is free again)
+                    if(h == hh) s_k64[i] = (i < n) ? (((tr_l ? (unsigned long long)__float_as_uint(rho) << 32 : 0ull)) | (unsigned)(~orig_i)) : 0ull;
+                    __syncthreads();
+                    if(h == hh && i < n) {
+                        const unsigned long long mine = s_k64[i];
+                        int rank = 0;
+                        for(int j = 0; j < n; ++j) rank += (s_k64[j] > mine) ? 1 : 0;
+                        s_perm[rank] = (int)orig_i;
+                        s_ob[i] = o1.y; s_yh[i] = o1.z;
+                    }
+                    __syncthreads();
+                }
+                // ---- ensemble side: all 64 lanes, lane = member (chunks of 64) -----------------------------------------------------------------
+                // ensemble mean: sequential float sum over the valid members in member order (oi_ensi.cpp:447-461)
+                float total = 0.0f;
+                for(int m0 = 0; m0 < nV; m0 += 64) {
+                    const float v = (m0 + lane < nV) ? a.bg[(long)cell_l * E + a.validIdx[m0 + lane]] : 0.0f;
+                    const int kend = min(64, nV - m0);
+                    for(int k = 0; k < kend; ++k) total += readlane_f(v, k);
+                }
+                const float ensMean = total / (float)nV;
+#pragma unroll 1
+                for(int e0_ = 0; e0_ < nV; e0_ += 64) {
+                    const int e = e0_ + lane;
+                    // Y tile of this member chunk -> area B (floats)
+                    __syncthreads();
+#pragma unroll 4
+                    for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = (r < n && e < nV) ? a.gY[(long)s_sel[r] * nV + e] : 0.0f;
+                    __syncthreads();
+                    // Q = M' Y  (32 x 64) on the matrix cores
+                    v4d qa[2][4];
+#pragma unroll
+                    for(int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for(int tj = 0; tj < 4; ++tj) qa[ti][tj] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    {
+                        const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+                        for(int ks = 0; ks < 8; ++ks) {
+                            double bop[4];
+#pragma unroll
+                            for(int tj = 0; tj < 4; ++tj) bop[tj] = (double)sBf[(4 * ks + kq) * YP + 16 * tj + r];
+                            const double am0 = sA[r * PP + 4 * ks + kq], am1 = sA[(r + 16) * PP + 4 * ks + kq];
+#pragma unroll
+                            for(int tj = 0; tj < 4; ++tj) {
+                                qa[0][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(am0, bop[tj], qa[0][tj], 0, 0, 0);
+                                qa[1][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(am1, bop[tj], qa[1][tj], 0, 0, 0);
+                            }
+                        }
+                    }
+                    // transposed through area B, 32 members at a time: Qt[member][row]
+                    double q[32];
+#pragma unroll
+                    for(int half = 0; half < 2; ++half) {
+                        __syncthreads();
+#pragma unroll
+                        for(int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                            for(int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                                for(int r = 0; r < 4; ++r) sB[(16 * tj + (lane & 15)) * PP + 16 * ti + (lane >> 4) + 4 * r] = qa[ti][2 * half + tj][r];
+                        __syncthreads();
+#pragma unroll
+                        for(int j = 0; j < 32; j += 2) {   // (selects, not a conditional store: the array must stay in registers)
+                            const double2 v = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
+                            q[j] = (half == 0 || h == 1) ? v.x : q[j]; q[j + 1] = (half == 0 || h == 1) ? v.y : q[j + 1];
+                        }
+                    }
+                    const float value = (e < nV) ? a.bg[(long)cell_l * E + a.validIdx[e]] : 0.0f;
+                    const double X = (double)value - (double)ensMean;
+                    // total_e = sum_k X_k W(k,e), W(k,e) = [k == e] + sum_i Y(i,k) q_e(i) + w_k, float accumulation in k order (:505-511)
+                    float acc = 0.0f;
+#pragma unroll 1
+                    for(int k0 = 0; k0 < nV; k0 += 32) {
+                        const int kk = k0 + i;    // lanes i and 32 + i share column kk: rows [16 h, 16 h + 16)
+                        __syncthreads();
+                        {   // column kk of Y as doubles, X_kk and w_kk = sum_r sD_r Y(r,kk) z_r  -> row i of the table in area B
+                            double wk = 0.0;
+#pragma unroll
+                            for(int rr = 0; rr < 16; rr += 2) {
+                                const int r = 16 * h + rr;
+                                double2 v;
+                                v.x = (r < n && kk < nV) ? (double)a.gY[(long)s_sel[r] * nV + kk] : 0.0;
+                                v.y = (r + 1 < n && kk < nV) ? (double)a.gY[(long)s_sel[r + 1] * nV + kk] : 0.0;
+                                wk = __builtin_fma(s_sD[hh][r] * v.x, s_z[hh][r], wk);
+                                wk = __builtin_fma(s_sD[hh][r + 1] * v.y, s_z[hh][r + 1], wk);
+                                *reinterpret_cast<double2*>(&sB[i * PP + r]) = v;
+                            }
+                            const double wo = __shfl_xor(wk, 32);
+                            if(h == 0) {
+                                const float vk = (kk < nV) ? a.bg[(long)cell_l * E + a.validIdx[kk]] : 0.0f;
+                                double2 xw; xw.x = (double)vk - (double)ensMean; xw.y = wk + wo;
+                                *reinterpret_cast<double2*>(&sB[i * PP + 32]) = xw;
+                            }
+                        }
+                        __syncthreads();
+                        const int kend = min(32, nV - k0);
+#pragma unroll 1
+                        for(int k = 0; k < kend && !(a.debug & 2); ++k) {
+                            const double* row = &sB[k * PP];
+                            double wke = (k0 + k == e) ? 1.0 : 0.0;
+#pragma unroll
+                            for(int r0 = 0; r0 < 32; r0 += 8) {
+#pragma unroll
+                                for(int r = r0; r < r0 + 8; r += 2) {
+                                    const double2 y2 = *reinterpret_cast<const double2*>(&row[r]);
+                                    wke = __builtin_fma(y2.x, q[r], wke);
+                                    wke = __builtin_fma(y2.y, q[r + 1], wke);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            const double2 xw = *reinterpret_cast<const double2*>(&row[32]);
+                            wke += xw.y;
+                            acc = (float)((double)acc + xw.x * wke);
+                        }
+                    }
+                    float currIncrement = acc;
+                    if(!a.allow_extrap && e < nV) {
+                        const int li = e % n, lk = e / n;
+                        const double lYe = (double)a.gY[(long)(unsigned)s_perm[li] * nV + lk];
+                        float maxInc = -INFINITY, minInc = INFINITY;
+                        for(int r = 0; r < n; ++r) {
+                            const float dv = (float)((double)s_ob[r] - (lYe + (double)s_yh[r]));
+                            maxInc = fmaxf(maxInc, dv); minInc = fminf(minInc, dv);
+                        }
+                        const float memberIncrement = (float)((double)currIncrement - X);
+                        if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + X);
+                        else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + X);
+                        else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + X);
+                        else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + X);
+                    }
+                    if(e < nV) a.out[(long)cell_l * E + a.validIdx[e]] = ensMean + currIncrement;   // :553
+                }
+                __syncthreads();
+            }
+        }
+        todo &= ~done;
+    }
+    if(lane == 0 && a.counters) { atomicAdd(&a.counters[1], (unsigned long long)ndone); atomicAdd(&a.counters[4 + (blockIdx.x & 31)], (unsigned long long)nsweeps); }
+}
