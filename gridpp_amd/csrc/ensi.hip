@@ -35,6 +35,7 @@ struct EnsiArgs {
     const float* gY;          // [S][nV] perturbations of the valid members (float)
     const int* validIdx;      // [nV]
     unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
+    double *upark, *mpark;    // [ntiles][64][32] k_ensi_pair: parked eigenvector rows / middle-matrix rows of the current pair of cells
     unsigned* meta;           // [ntiles][64] k_ensi_scan -> k_ensi_pair: selection length | 0x100 if the reference sorted
     unsigned long long* hsigs;   // [ntiles][64] order-independent signature of every selection
     double* gram;             // [ntiles][EN*EN] scratch: Y Y^T of the current run of equal selections
@@ -735,7 +736,7 @@ struct EnsiWorkspace {
     DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
     DevBuf<unsigned> sel, meta;
     DevBuf<unsigned long long> hsigs;
-    DevBuf<double> gram;
+    DevBuf<double> gram, upark, mpark;
     DevBuf<unsigned long long> counters, big_keys;
     DevBuf<int> big_list, big_count;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -854,6 +855,8 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     GPP_HIP(hipEventRecord(ws.e0, stream()));
     if(use_pair) {
         a.meta = ws.meta.get((size_t)a.ntiles * 64);
+        a.upark = ws.upark.get((size_t)a.ntiles * 64 * 32);
+        a.mpark = ws.mpark.get((size_t)a.ntiles * 64 * 32);
         a.hsigs = ws.hsigs.get((size_t)a.ntiles * 64);
         if(a.s.st.fh) {
             hipLaunchKernelGGL(k_ensi_scan<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);

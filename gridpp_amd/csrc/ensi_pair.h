@@ -138,32 +138,40 @@ __device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], d
     const double alpha = idle ? 1.0 : (leader ? sn : -sn);
     const double beta = idle ? 0.0 : cs;
     dg = idle ? dg : dpart + (leader ? tap : -tap);      // a_pp' = a_pp - t a_pq, a_qq' = a_qq + t a_pq, swapped
-    // groups of 8 registers / 4 pairs with scheduling barriers in between: the scheduler would otherwise hoist all 32 partner
-    // values and all 16 (c, s) pairs to the front and push the two matrices out of the register file
+    // The partner values travel through the LDS crossbar (~100 cycles): all 32 requests of a half of the row are issued before
+    // the first one is consumed, and the second half is in flight while the first is rotated.  The scheduling barriers pin
+    // that order (left alone, the scheduler issues one request, waits for it, rotates, issues the next).
+    double pa[16], pb[16];
 #pragma unroll
-    for(int j0 = 0; j0 < 32; j0 += 8) {
+    for(int j = 0; j < 16; ++j) pa[j] = partner_of(b[j], paddr);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for(int j = j0; j < j0 + 8; ++j) {
-            const double pj = partner_of(b[j], paddr);
-            b[j] = __builtin_fma(alpha, b[j], beta * pj);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    for(int j = 0; j < 16; ++j) pb[j] = partner_of(b[16 + j], paddr);
+#pragma unroll
+    for(int j = 0; j < 16; ++j) b[j] = __builtin_fma(alpha, b[j], beta * pa[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for(int j = 0; j < 16; ++j) b[16 + j] = __builtin_fma(alpha, b[16 + j], beta * pb[j]);
     __syncthreads();   // (c, s) of all pairs visible
-    // columns: (x, y) = columns (p, q):  p' = c x - s y,  q' = s x + c y, stored swapped
+    // columns: (x, y) = columns (p, q):  p' = c x - s y,  q' = s x + c y, stored swapped; the (c, s) pairs of eight column pairs
+    // are fetched at a time
 #pragma unroll
-    for(int k0 = 0; k0 < 16; k0 += 4) {
+    for(int k0 = 0; k0 < 16; k0 += 8) {
+        double2 cs2[8];
 #pragma unroll
-        for(int k = k0; k < k0 + 4; ++k) {
+        for(int k = 0; k < 8; ++k) cs2[k] = *reinterpret_cast<const double2*>(&s_cs[(h * 16 + k0 + k) * 2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for(int kk = 0; kk < 8; ++kk) {
+            const int k = k0 + kk;
             if(ODD && k == 15) continue;
-            const double2 cs2 = *reinterpret_cast<const double2*>(&s_cs[(h * 16 + k) * 2]);
             const int p = ODD ? 2 * k + 1 : 2 * k, q = p + 1;
             const double x = b[p], y = b[q];
-            b[p] = __builtin_fma(cs2.y, x, cs2.x * y);
-            b[q] = __builtin_fma(cs2.x, x, -(cs2.y * y));
+            b[p] = __builtin_fma(cs2[kk].y, x, cs2[kk].x * y);
+            b[q] = __builtin_fma(cs2[kk].x, x, -(cs2[kk].y * y));
             const double ux = u[p], uy = u[q];
-            u[p] = __builtin_fma(cs2.y, ux, cs2.x * uy);
-            u[q] = __builtin_fma(cs2.x, ux, -(cs2.y * uy));
+            u[p] = __builtin_fma(cs2[kk].y, ux, cs2[kk].x * uy);
+            u[q] = __builtin_fma(cs2[kk].x, ux, -(cs2[kk].y * uy));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -232,12 +240,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // 17 KB: staging areas A / B of the products; B doubles as Y tile and as the transposed operands of the member update
     __shared__ __attribute__((aligned(16))) double s_ab[2 * 32 * PP];
     __shared__ __attribute__((aligned(16))) double s_sD[2][32], s_r[2][32], s_z[2][32];
-    __shared__ __attribute__((aligned(16))) double s_cs[64];      // (c, s) of the Jacobi pairs [h][16][2]; later dw[32], t[32]
+    __shared__ __attribute__((aligned(16))) double s_cs[64];      // (c, s) of the Jacobi pairs [h][16][2]; later t[32]
+    __shared__ __attribute__((aligned(16))) double s_dwa[2][2][32];   // [cell][dw | a = sqrt(c + S)][eigenvalue]
     __shared__ int s_i[128];                                      // perm[32] | obs[32] | yhat[32] (floats) | selection[32]
     double* const sA = s_ab;
     double* const sB = s_ab + 32 * PP;
     float* const sBf = reinterpret_cast<float*>(sB);             // Y tile [32][YP] floats (8320 B <= 8704 B)
-    double* const s_dw = s_cs;
     double* const s_t = s_cs + 32;
     int* const s_perm = s_i;
     float* const s_ob = reinterpret_cast<float*>(s_i + 32);
@@ -258,9 +266,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
     const double sqc = sqrt(c);
-    double b[32], u[32];
-#pragma unroll
-    for(int j = 0; j < 32; ++j) { b[j] = 0.0; u[j] = (j == i) ? 1.0 : 0.0; }
+    // Between two pairs the eigenvectors of each half's last cell (the warm start) and, between the spectral step and the
+    // ensemble side, the middle matrices wait in HBM (2 x 16 KB per tile, L2 resident): held in registers they would cost
+    // the ensemble side its register budget.
+    double* const upark = a.upark + ((size_t)tile * 64 + lane) * 32;
+    double* const mpark = a.mpark + ((size_t)tile * 64 + lane) * 32;
     unsigned prev_orig = 0xffffffffu; int prev_n = -1;
     unsigned long long todo = __ballot(cnt > 0);
     int ndone = 0, nsweeps = 0;
@@ -335,6 +345,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         for(int r = 0; r < 4; ++r) gram[(16 * ti + (lane >> 4) + 4 * r) * EN + 16 * tj + (lane & 15)] = g.t[ti][tj][r];
                 __threadfence();
                 __syncthreads();
+            }
+            double b[32], u[32];
+            if(same) {
+#pragma unroll
+                for(int j = 0; j < 32; ++j) u[j] = __hip_atomic_load(&upark[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else {
 #pragma unroll
                 for(int j = 0; j < 32; ++j) u[j] = (j == i) ? 1.0 : 0.0;
             }
@@ -387,9 +404,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for(int j = 0; j < 32; ++j) { const double v = (j == i) ? 0.0 : b[j]; off = __builtin_fma(v, v, off); }
                 off = half_sum_d(off, lane);
                 const double tr = half_sum_d(fabs(dg), lane);
-                // off-diagonal norm < 1e-11 * trace: Jacobi converges quadratically, so the eigenvalues are good to ~1e-22 and the
-                // eigenvectors to ~1e-11 relative -- five orders below what a float32 output can show
-                const bool open = off > 1e-22 * tr * tr;
+                // The sweeps stop at an off-diagonal norm of 1e-6 * trace: what is left of the off-diagonal part E enters the matrix
+                // functions below through their first-order (Daleckii-Krein) term, f(L + E) = f(L) + f[L_i, L_j] o E + O(|E|^2) with
+                // bounded divided differences (no small eigenvalue gaps in any denominator), so the result is good to ~1e-12 -- and
+                // the last sweep of a plain Jacobi iteration, which only polishes 1e-8 down to 1e-16, is not run at all
+                const bool open = off > 1e-12 * tr * tr;
                 if(__ballot(open && !(dup && h == 1)) == 0ull) break;
                 nsweeps++;
 #pragma unroll 1
@@ -405,18 +424,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const double rt = sqrt(c + S);
             const double dwv = -1.0 / (rt * (rt + sqc));      // W_sym = I + A^T U diag(dw) U^T A
             const double inv = 1.0 / (c + S);
+            __syncthreads();
+            s_dwa[h][0][i] = dwv; s_dwa[h][1][i] = rt;
+            // eigenvectors -> park (warm start of the next pair, operand of the products below)
+#pragma unroll
+            for(int j = 0; j < 32; j += 2) { double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&upark[j]) = w; }
+            __syncthreads();
+            // middle matrix of W_sym: diag(dw) + G1 o E,  G1(i, j) = (g_i - g_j) / (S_i - S_j) = (1 + sqrt(c) / (a_i + a_j)) dw_i dw_j  (a = sqrt(c + S));
+            // G1 multiplies entries 1e-6 of the trace and smaller, a float reciprocal is plenty  -> park
+#pragma unroll
+            for(int j = 0; j < 32; j += 2) {
+                double2 v;
+                const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_dwa[h][1][j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_dwa[h][1][j + 1]));
+                v.x = (j == i) ? dwv : (1.0 + sqc * (double)r0) * (dwv * s_dwa[h][0][j]) * b[j];
+                v.y = (j + 1 == i) ? dwv : (1.0 + sqc * (double)r1) * (dwv * s_dwa[h][0][j + 1]) * b[j + 1];
+                *reinterpret_cast<double2*>(&mpark[j]) = v;
+            }
+            // z = U [diag(1 / (c + S)) + H1 o E] U^T r,  H1(i, j) = -1 / ((c + S_i)(c + S_j)), one cell after the other through area B
 #pragma unroll 1
-            for(int hh = 0; hh < (dup ? 1 : 2); ++hh) {
-                const int lcell = hh ? lb : la;
-                const int cell_l = ensi_cell_of(a, tile, lcell);
+            for(int hh = 0; hh < 2; ++hh) {
                 __syncthreads();
                 if(h == hh) {
 #pragma unroll
                     for(int j = 0; j < 32; j += 2) { double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w; }
-                    s_dw[i] = dwv;
                 }
                 __syncthreads();
-                // z = U diag(1 / (c + S)) U^T r
                 if(h == hh) {
                     double ur = 0.0;
 #pragma unroll 8
@@ -424,15 +456,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     s_t[i] = ur * inv;
                 }
                 __syncthreads();
+                double t2 = 0.0;
+                if(h == hh) {
+                    double corr = 0.0;
+#pragma unroll
+                    for(int j = 0; j < 32; ++j) corr = __builtin_fma((j == i) ? 0.0 : b[j], s_t[j], corr);
+                    t2 = s_t[i] - inv * corr;
+                }
+                __syncthreads();
+                if(h == hh) s_t[i] = t2;
+                __syncthreads();
                 if(h == hh) {
                     double zz = 0.0;
 #pragma unroll
                     for(int j = 0; j < 32; ++j) zz = __builtin_fma(u[j], s_t[j], zz);
                     s_z[hh][i] = zz;
                 }
-                // M_W = U diag(dw) U^T, scaled: M'(i, j) = sD_i M_W(i, j) sD_j   -> area A (stays there for the whole member update)
+            }
+            __threadfence();
+            __syncthreads();
+            // ---- per cell: M_W, then the ensemble side ----------------------------------------------------------------------------------------
+#pragma unroll 1
+            for(int hh = 0; hh < (dup ? 1 : 2); ++hh) {
+                const int lcell = hh ? lb : la;
+                const int cell_l = ensi_cell_of(a, tile, lcell);
+                __syncthreads();
+                {   // eigenvectors and middle matrix of this cell: park -> areas B and A (lane l fetches half a row of each)
+                    const double* const up = a.upark + ((size_t)tile * 64 + 32 * hh + i) * 32 + 16 * h;
+                    const double* const mp = a.mpark + ((size_t)tile * 64 + 32 * hh + i) * 32 + 16 * h;
+#pragma unroll
+                    for(int j = 0; j < 16; ++j) {
+                        sB[i * PP + 16 * h + j] = __hip_atomic_load(&up[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sA[i * PP + 16 * h + j] = __hip_atomic_load(&mp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                __syncthreads();
+                // M_W = U Mmid U^T, scaled: M'(i, j) = sD_i M_W(i, j) sD_j   -> area A (stays there for the whole member update)
                 {
-                    const Acc32 mw = mfma_32_full(lane, [&](int r, int k) { return sB[r * PP + k] * s_dw[k]; }, [&](int k, int cc) { return sB[cc * PP + k]; });
+                    const Acc32 tm = mfma_32_full(lane, [&](int r, int k) { return sB[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
+                    __syncthreads();
+                    acc32_store_full(tm, lane, sA);
+                    __syncthreads();
+                    const Acc32 mw = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[cc * PP + k]; });
                     __syncthreads();
 #pragma unroll
                     for(int ti = 0; ti < 2; ++ti)
