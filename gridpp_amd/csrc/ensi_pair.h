@@ -15,6 +15,13 @@
 //     accumulation over k (oi_ensi.cpp:505-511) term by term.
 #pragma once
 
+// -DGPP_ENSI_PROFILE: cycles per phase of k_ensi_pair (s_memtime, summed over the waves) in counters[40 + phase]
+#ifdef GPP_ENSI_PROFILE
+#define EPROF(k) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; }
+#else
+#define EPROF(k)
+#endif
+
 #define PP 34             // pitch (doubles) of the staged 32 x 32 matrices: 16-byte aligned rows, 2-way bank conflicts at most
 #define YP 65             // pitch (floats) of the Y tile
 
@@ -123,14 +130,12 @@ __device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], d
     const bool idle = ODD && (i == 0 || i == 31);
     const bool leader = ODD ? ((i & 1) != 0 && !idle) : ((i & 1) == 0);
     const int paddr = (ODD ? (idle ? (32 * h + i) : ((i & 1) ? 32 * h + i + 1 : 32 * h + i - 1)) : ((32 * h + i) ^ 1)) << 2;
+    // both lanes of a pair compute the same rotation from the same three numbers (the partner receives the leader's off-diagonal
+    // entry together with its diagonal entry: one exchange instead of two)
     const double dpart = partner_of(dg, paddr);
+    const double apart = partner_of(apq, paddr);
     double cs, sn, tap;
-    jacobi_rotation(apq, dg, dpart, cs, sn, tap);
-    // the partner lane takes the leader's rotation
-    const double cs_p = partner_of(cs, paddr);
-    const double sn_p = partner_of(sn, paddr);
-    const double tap_p = partner_of(tap, paddr);
-    cs = leader ? cs : cs_p; sn = leader ? sn : sn_p; tap = leader ? tap : tap_p;
+    jacobi_rotation(leader ? apq : apart, leader ? dg : dpart, leader ? dpart : dg, cs, sn, tap);
     if(idle) { cs = 1.0; sn = 0.0; tap = 0.0; }
     if(leader) { double2 v; v.x = cs; v.y = sn; *reinterpret_cast<double2*>(&s_cs[(h * 16 + (i >> 1)) * 2]) = v; }
     // rotation + swap: position p receives the rotated row / column q and vice versa, so the pairs of the next phase are neighbours again
@@ -141,7 +146,9 @@ __device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], d
     // The partner values travel through the LDS crossbar (~100 cycles): all 32 requests of a half of the row are issued before
     // the first one is consumed, and the second half is in flight while the first is rotated.  The scheduling barriers pin
     // that order (left alone, the scheduler issues one request, waits for it, rotates, issues the next).
+    __syncthreads();   // (c, s) of all pairs visible (one wave: this waits for the LDS write, nothing else)
     double pa[16], pb[16];
+    double2 ca[8], cb[8];
 #pragma unroll
     for(int j = 0; j < 16; ++j) pa[j] = partner_of(b[j], paddr);
     __builtin_amdgcn_sched_barrier(0);
@@ -151,29 +158,25 @@ __device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], d
     for(int j = 0; j < 16; ++j) b[j] = __builtin_fma(alpha, b[j], beta * pa[j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+    for(int k = 0; k < 8; ++k) ca[k] = *reinterpret_cast<const double2*>(&s_cs[(h * 16 + k) * 2]);
+#pragma unroll
     for(int j = 0; j < 16; ++j) b[16 + j] = __builtin_fma(alpha, b[16 + j], beta * pb[j]);
-    __syncthreads();   // (c, s) of all pairs visible
-    // columns: (x, y) = columns (p, q):  p' = c x - s y,  q' = s x + c y, stored swapped; the (c, s) pairs of eight column pairs
-    // are fetched at a time
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for(int k0 = 0; k0 < 16; k0 += 8) {
-        double2 cs2[8];
+    for(int k = 0; k < 8; ++k) cb[k] = *reinterpret_cast<const double2*>(&s_cs[(h * 16 + 8 + k) * 2]);
+    // columns: (x, y) = columns (p, q):  p' = c x - s y,  q' = s x + c y, stored swapped
 #pragma unroll
-        for(int k = 0; k < 8; ++k) cs2[k] = *reinterpret_cast<const double2*>(&s_cs[(h * 16 + k0 + k) * 2]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for(int kk = 0; kk < 8; ++kk) {
-            const int k = k0 + kk;
-            if(ODD && k == 15) continue;
-            const int p = ODD ? 2 * k + 1 : 2 * k, q = p + 1;
-            const double x = b[p], y = b[q];
-            b[p] = __builtin_fma(cs2[kk].y, x, cs2[kk].x * y);
-            b[q] = __builtin_fma(cs2[kk].x, x, -(cs2[kk].y * y));
-            const double ux = u[p], uy = u[q];
-            u[p] = __builtin_fma(cs2[kk].y, ux, cs2[kk].x * uy);
-            u[q] = __builtin_fma(cs2[kk].x, ux, -(cs2[kk].y * uy));
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for(int k = 0; k < 16; ++k) {
+        if(k == 8) __builtin_amdgcn_sched_barrier(0);
+        if(ODD && k == 15) continue;
+        const double2 cs2 = k < 8 ? ca[k & 7] : cb[k & 7];
+        const int p = ODD ? 2 * k + 1 : 2 * k, q = p + 1;
+        const double x = b[p], y = b[q];
+        b[p] = __builtin_fma(cs2.y, x, cs2.x * y);
+        b[q] = __builtin_fma(cs2.x, x, -(cs2.y * y));
+        const double ux = u[p], uy = u[q];
+        u[p] = __builtin_fma(cs2.y, ux, cs2.x * uy);
+        u[q] = __builtin_fma(cs2.x, ux, -(cs2.y * uy));
     }
     __syncthreads();   // before the next phase overwrites s_cs
 }
@@ -271,6 +274,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // the ensemble side its register budget.
     double* const upark = a.upark + ((size_t)tile * 64 + lane) * 32;
     double* const mpark = a.mpark + ((size_t)tile * 64 + lane) * 32;
+#ifdef GPP_ENSI_PROFILE
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     unsigned prev_orig = 0xffffffffu; int prev_n = -1;
     unsigned long long todo = __ballot(cnt > 0);
     int ndone = 0, nsweeps = 0;
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             s_sD[h][i] = sD; s_r[h][i] = (i < n) ? sD * dobs : 0.0;
             if(h == 0) s_sel[i] = orig_i;
             __syncthreads();
+            EPROF(0)   // pair setup: selection, rho
             // ---- new selection: Gram matrix Y Y^T on the matrix cores (all members, chunks of 64), parked in HBM -----------------------
             if(!same) {
                 Acc32 g;
@@ -349,18 +357,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             double b[32], u[32];
             if(same) {
 #pragma unroll
-                for(int j = 0; j < 32; ++j) u[j] = __hip_atomic_load(&upark[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for(int j = 0; j < 32; j += 2) { const double2 w = *reinterpret_cast<const double2*>(&upark[j]); u[j] = w.x; u[j + 1] = w.y; }
             }
             else {
 #pragma unroll
                 for(int j = 0; j < 32; ++j) u[j] = (j == i) ? 1.0 : 0.0;
             }
             // ---- B = (sD sD^T) o (Y Y^T): row i of each half ------------------------------------------------------------------------------
+            // (plain loads: the Gram matrix, like the parked rows below, was written by lanes of this workgroup before a barrier)
 #pragma unroll
-            for(int j = 0; j < 32; ++j) {
-                const double gij = __hip_atomic_load(&gram[i * EN + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b[j] = gij * (sD * s_sD[h][j]);
+            for(int j = 0; j < 32; j += 2) {
+                const double2 g2 = *reinterpret_cast<const double2*>(&gram[i * EN + j]);
+                b[j] = g2.x * (sD * s_sD[h][j]); b[j + 1] = g2.y * (sD * s_sD[h][j + 1]);
             }
+            EPROF(1)   // Gram (new selections), B build
             // ---- warm start: B <- U^T B U with the eigenvectors of the previous cell of this half (nearly diagonal already) ------------
             if(same) {
 #pragma unroll 1
@@ -389,6 +399,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 __syncthreads();
             }
+            EPROF(2)   // warm-start transform
             // ---- Jacobi sweeps, both cells in lockstep --------------------------------------------------------------------------------------
             const bool e0 = (i & 1) != 0, e1 = (i & 2) != 0, e2 = (i & 4) != 0, e3 = (i & 8) != 0;
             auto diag_of_rows = [&]() {
@@ -419,6 +430,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 // the diagonal from the rows again (the running update drifts in the last bits)
                 dg = diag_of_rows();
             }
+            EPROF(3)   // Jacobi
             // ---- spectral functions (lane i of half h: eigenvalue i of cell h) -------------------------------------------------------------
             const double S = dg < 0.0 ? 0.0 : dg;
             const double rt = sqrt(c + S);
@@ -475,6 +487,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             __threadfence();
             __syncthreads();
+            EPROF(4)   // park, middle matrix, z
             // ---- per cell: M_W, then the ensemble side ----------------------------------------------------------------------------------------
 #pragma unroll 1
             for(int hh = 0; hh < (dup ? 1 : 2); ++hh) {
@@ -485,9 +498,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     const double* const up = a.upark + ((size_t)tile * 64 + 32 * hh + i) * 32 + 16 * h;
                     const double* const mp = a.mpark + ((size_t)tile * 64 + 32 * hh + i) * 32 + 16 * h;
 #pragma unroll
-                    for(int j = 0; j < 16; ++j) {
-                        sB[i * PP + 16 * h + j] = __hip_atomic_load(&up[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sA[i * PP + 16 * h + j] = __hip_atomic_load(&mp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for(int j = 0; j < 16; j += 2) {
+                        *reinterpret_cast<double2*>(&sB[i * PP + 16 * h + j]) = *reinterpret_cast<const double2*>(&up[j]);
+                        *reinterpret_cast<double2*>(&sA[i * PP + 16 * h + j]) = *reinterpret_cast<const double2*>(&mp[j]);
                     }
                 }
                 __syncthreads();
@@ -510,6 +523,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             }
                 }
                 __syncthreads();
+                EPROF(5)   // fetch from the park, M_W
                 // anti-extrapolation tables (oi_ensi.cpp:520-552): lY[e] is a LINEAR index into the n x nV column-major matrix, so it
                 // depends on the ORDER of the selected observations: rho descending when the reference sorted (more usable
                 // observations than max_points), candidate (= index) order otherwise
@@ -539,6 +553,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll 1
                 for(int e0_ = 0; e0_ < nV; e0_ += 64) {
                     const int e = e0_ + lane;
+                    EPROF(6)   // tables, ensemble mean
                     // Y tile of this member chunk -> area B (floats)
                     __syncthreads();
 #pragma unroll 4
@@ -565,6 +580,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             }
                         }
                     }
+                    EPROF(7)   // Y tile, Q = M' Y
                     // transposed through area B, 32 members at a time: Qt[member][row]
                     double q[32];
 #pragma unroll
@@ -585,6 +601,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     }
                     const float value = (e < nV) ? a.bg[(long)cell_l * E + a.validIdx[e]] : 0.0f;
                     const double X = (double)value - (double)ensMean;
+                    EPROF(8)   // transposition of Q
                     // total_e = sum_k X_k W(k,e), W(k,e) = [k == e] + sum_i Y(i,k) q_e(i) + w_k, float accumulation in k order (:505-511)
                     float acc = 0.0f;
 #pragma unroll 1
@@ -611,26 +628,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             }
                         }
                         __syncthreads();
-                        const int kend = min(32, nV - k0);
-#pragma unroll 1
-                        for(int k = 0; k < kend && !(a.debug & 2); ++k) {
-                            const double* row = &sB[k * PP];
+                        const int kend = (a.debug & 2) ? 0 : min(32, nV - k0);
+                        // rows of the table two at a time, the next pair in flight while this one is used (one wave per SIMD:
+                        // nobody else hides the LDS latency)
+                        double2 ra[17], rb[17];
+                        auto load_row = [&](double2 (&dst)[17], const int k) {
+#pragma unroll
+                            for(int r = 0; r < 17; ++r) dst[r] = *reinterpret_cast<const double2*>(&sB[k * PP + 2 * r]);
+                        };
+                        auto use_row = [&](const double2 (&row)[17], const int k) {
                             double wke = (k0 + k == e) ? 1.0 : 0.0;
 #pragma unroll
-                            for(int r0 = 0; r0 < 32; r0 += 8) {
-#pragma unroll
-                                for(int r = r0; r < r0 + 8; r += 2) {
-                                    const double2 y2 = *reinterpret_cast<const double2*>(&row[r]);
-                                    wke = __builtin_fma(y2.x, q[r], wke);
-                                    wke = __builtin_fma(y2.y, q[r + 1], wke);
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
+                            for(int r = 0; r < 16; ++r) {
+                                wke = __builtin_fma(row[r].x, q[2 * r], wke);
+                                wke = __builtin_fma(row[r].y, q[2 * r + 1], wke);
                             }
-                            const double2 xw = *reinterpret_cast<const double2*>(&row[32]);
-                            wke += xw.y;
-                            acc = (float)((double)acc + xw.x * wke);
+                            wke += row[16].y;
+                            acc = (float)((double)acc + row[16].x * wke);
+                        };
+                        load_row(ra, 0);
+#pragma unroll 1
+                        for(int k = 0; k < kend; k += 2) {
+                            load_row(rb, min(k + 1, 31));
+                            __builtin_amdgcn_sched_barrier(0);
+                            use_row(ra, k);
+                            __builtin_amdgcn_sched_barrier(0);
+                            load_row(ra, min(k + 2, 31));
+                            __builtin_amdgcn_sched_barrier(0);
+                            if(k + 1 < kend) use_row(rb, k + 1);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    EPROF(9)   // member update (k loop with its tables)
                     float currIncrement = acc;
                     if(!a.allow_extrap && e < nV) {
                         const int li = e % n, lk = e / n;
@@ -653,5 +682,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
         todo &= ~done;
     }
+#ifdef GPP_ENSI_PROFILE
+    if(lane == 0 && a.counters) for(int k = 0; k < 12; ++k) atomicAdd(&a.counters[40 + k], prof[k]);
+#endif
     if(lane == 0 && a.counters) { atomicAdd(&a.counters[1], (unsigned long long)ndone); atomicAdd(&a.counters[4 + (blockIdx.x & 31)], (unsigned long long)nsweeps); }
 }
