@@ -10,7 +10,16 @@ values are broadcast from rank 0 over RCCL, and there is no other data-path coll
 Inputs are synthetic (seed 1002) and resident in HBM (torch CUDA tensors handed to the
 C-ABI as device pointers) when the timed region starts.
 
-Prints ONE JSON line on rank 0.
+The ONE JSON line of rank 0 carries, besides the contract keys:
+  roofline          HBM view of the dominant kernel (algorithmic 24 B/cell over its HIP-event duration)
+  roofline_compute  the bound that actually binds OI: VALU issue (wave-instructions per launch from the committed
+                    rocprofv3 PMC pass over the live kernel time, against 1024 SIMDs x one instruction per 4 cycles)
+  host_inclusive    the same call from numpy buffers (PCIe both ways; never `value`)
+  other_configs     the other BASELINE.json configs with the same per-step fields (N = 1 only)
+  cpu_baseline      the oracle's OpenMP / cell-list build of the same loop on this box's host cores (1 thread and all threads)
+
+`--case ensi` / `--case nbh` run config 5 / config 4 instead of OI with the same contract (row tiles; EnSI broadcasts the
+observation block, the neighbourhood filter exchanges halo rows between neighbouring ranks with RCCL send / recv).
 """
 import argparse
 import json
@@ -22,58 +31,56 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from tools.bench_cases import make_workload, HBM_PEAK, FP64_PEAK  # noqa: E402
 
 BYTES_PER_CELL = 24   # read lat,lon,elev,laf,background (5x4 B) + write analysis (4 B)
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-
-
-def make_workload(ny, nx, S, seed, row0, row1):
-    """[0,1] deg^2 geodetic grid, uniform obs, obs = pbg + N(0,1), ratios U(0.1,1)."""
-    rng = np.random.default_rng(seed)
-    lat1 = np.linspace(0, 1, ny, dtype=np.float64)[row0:row1]
-    lon1 = np.linspace(0, 1, nx, dtype=np.float64)
-    lats, lons = np.meshgrid(lat1, lon1, indexing="ij")
-    plat, plon = rng.random(S), rng.random(S)
-    pbg = rng.normal(0, 1, S).astype(np.float32)
-    obs = (pbg + rng.normal(0, 1, S)).astype(np.float32)
-    ratios = rng.uniform(0.1, 1, S).astype(np.float32)
-    # smooth deterministic background field (any fixed smooth function)
-    bg = (np.sin(6 * lats) * np.cos(4 * lons) * 3).astype(np.float32)
-    return lats, lons, bg, plat, plon, obs, ratios, pbg
+HBM_PEAK_GBS = HBM_PEAK / 1e9
+SIMDS, CLOCK_HZ = 1024, 2.4e9   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; one VALU wave-instruction per 4 cycles per SIMD
 
 
 def cpu_baseline(ny, nx, S, seed, h, max_points, target_s=12.0):
-    """The CPU oracle (a port of the reference algorithm, oracle/gridpp_oracle.c) timed on this box's host
-    cores on a bounded sample of the same workload: every k-th row, all host threads."""
-    from concurrent.futures import ThreadPoolExecutor
+    """The CPU oracle's OpenMP build of the reference loop (oracle/gridpp_oracle.c: orc_oi_full_omp -- cell-list radius query,
+    dynamic schedule over the grid points; bit-identical to the serial oracle, tests/test_oracle_baseline.py) timed on this
+    box's host cores on a bounded sample of the same workload: every k-th grid row."""
     from oracle import oracle as O
     lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, S, seed, 0, ny)
-    threads = max(1, min(os.cpu_count() or 1, 128))
+    threads = max(1, min(os.cpu_count() or 1, O.omp_max_threads()))
     op = O.Pts(plat, plon)
     st = O.Barnes(h)
-    # calibrate on a few cells, then size the sample for ~target_s of wall time
-    row = ny // 2
-    og = O.Pts(lats[row], lons[row])
-    t0 = time.perf_counter()
-    ncal = min(nx, 64)
-    O.oi(og, bg[row], op, obs, ratios, pbg, st, max_points, True, 0, ncal)
-    per_cell = (time.perf_counter() - t0) / ncal
-    cells_target = int(target_s / per_cell * threads * 0.1)
-    nrows = max(threads, min(ny, cells_target // nx))
-    rows = np.linspace(0, ny - 1, nrows).astype(int)
-    sets = [(O.Pts(lats[r], lons[r]), bg[r]) for r in rows]
 
-    def work(item):
-        g, b = item
-        return O.oi(g, b, op, obs, ratios, pbg, st, max_points)
+    def run(nrows, thr):
+        rows = np.unique(np.linspace(0, ny - 1, nrows).astype(int))
+        g = O.Pts(lats[rows].ravel(), lons[rows].ravel())
+        b = bg[rows].ravel()
+        t0 = time.perf_counter()
+        O.oi_baseline(g, b, op, obs, ratios, pbg, st, max_points, threads=thr)
+        return rows.size * nx, time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(work, sets))
-    dt = time.perf_counter() - t0
-    cells = nrows * nx
-    return {"value": cells / dt, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": "%d of %d grid rows (%d cells) of the same workload, %.1f s wall" % (nrows, ny, cells, dt)}
+    # one thread: a few rows; sized from a one-row calibration
+    c0, t0 = run(1, 1)
+    per_cell = t0 / c0
+    n1 = max(1, min(ny, int(0.25 * target_s / per_cell / nx)))
+    c1, t1 = run(n1, 1)
+    one = c1 / t1
+    nall = max(threads // 8 + 1, min(ny, int(0.75 * target_s * one * threads * 0.7 / nx)))
+    ca, ta = run(nall, threads)
+    return {"value": ca / ta, "unit": "cells/s", "cores": threads, "kind": "port",
+            "one_thread_value": one,
+            "sample": "%d of %d grid rows (%d cells) of the same workload on %d threads in %.1f s; 1 thread: %d rows in %.1f s"
+                      % (ca // nx, ny, ca, threads, ta, c1 // nx, t1),
+            "algorithm": "cell-list radius query + per-point double inverse, OpenMP dynamic schedule (oracle/gridpp_oracle.c:orc_oi_full_omp)"}
+
+
+def pmc_profile(workload, world):
+    """Counters of the dominant kernel per launch from the committed rocprofv3 PMC passes of this exact workload (profiles/)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            t = json.load(f)["k_oi_union"]
+        if t["workload"] == workload and t["n_gpus"] == world:
+            return t
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def main():
@@ -81,12 +88,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--ny", type=int, default=4000)
-    ap.add_argument("--nx", type=int, default=4000)
-    ap.add_argument("--obs", type=int, default=10000)
+    ap.add_argument("--case", choices=["oi", "ensi", "nbh"], default="oi")
+    ap.add_argument("--ny", type=int, default=0)
+    ap.add_argument("--nx", type=int, default=0)
+    ap.add_argument("--obs", type=int, default=0)
     ap.add_argument("--max-points", type=int, default=30)
     ap.add_argument("--h", type=float, default=10000.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -110,31 +119,14 @@ def main():
     gridpp.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run, also for N = 1
+    backend = os.environ.get("GPP_BENCH_BACKEND", "nccl")
     if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GPP_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    ny, nx, S, seed = args.ny, args.nx, args.obs, 1002
-    row0, row1 = ny * rank // world, ny * (rank + 1) // world      # contiguous row tile of this rank
-    lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, S, seed, row0, row1)
-    grid = gridpp.Grid(lats, lons)                 # x/y/z resident in HBM
-    points = gridpp.Points(plat, plon)             # bin-sorted observation index resident in HBM
-    structure = gridpp.BarnesStructure(args.h)
-    d_bg = torch.from_numpy(bg).to(dev)
-    # rank 0 owns the observation values of each step; the others receive them over RCCL.  Double-buffered: the broadcast
-    # of the NEXT step's values is in flight on RCCL's stream while this step's kernels run on the library stream.
-    host_vals = np.stack([obs, ratios, pbg])
-    d_vals = [torch.from_numpy(host_vals).to(dev) if rank == 0 else torch.empty((3, S), dtype=torch.float32, device=dev) for _ in range(2)]
-    stream = gdist.ObservationStream(d_vals, rank)
-
-    def step():
-        v = stream.next()
-        return gridpp.optimal_interpolation(grid, d_bg, points, v[0], v[1], v[2], structure, args.max_points)
 
     def fence():
         torch.cuda.synchronize()
@@ -142,61 +134,175 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    case = args.case
+    seed = 1002
+    extra = {}
+    if case == "oi":
+        ny, nx, S = args.ny or 4000, args.nx or 4000, args.obs or 10000
+        row0, row1 = gdist.row_tile(ny, rank, world)      # contiguous row tile of this rank
+        lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, S, seed, row0, row1)
+        grid = gridpp.Grid(lats, lons)                 # x/y/z resident in HBM
+        points = gridpp.Points(plat, plon)             # bin-sorted observation index resident in HBM
+        structure = gridpp.BarnesStructure(args.h)
+        d_bg = torch.from_numpy(bg).to(dev)
+        # rank 0 owns the observation values of each step; the others receive them over RCCL.  Double-buffered: the broadcast
+        # of the NEXT step's values is in flight on RCCL's stream while this step's kernels run on the library stream.
+        host_vals = np.stack([obs, ratios, pbg])
+        d_vals = [torch.from_numpy(host_vals).to(dev) if rank == 0 else torch.empty((3, S), dtype=torch.float32, device=dev) for _ in range(2)]
+        stream = gdist.ObservationStream(d_vals, rank)
+        kernel_ms, union_ms = [], []
+
+        def step():
+            v = stream.next()
+            out = gridpp.optimal_interpolation(grid, d_bg, points, v[0], v[1], v[2], structure, args.max_points)
+            st_ = gridpp.oi_last_stats()
+            kernel_ms.append(st_["kernel_ms"]); union_ms.append(st_["union_kernel_ms"])
+            return out
+        cells_total, cells_rank = ny * nx, (row1 - row0) * nx
+        workload = "optimal_interpolation %dx%d grid, %d obs, BarnesStructure(%g), max_points=%d" % (ny, nx, S, args.h, args.max_points)
+        metric = "grid cells/sec for optimal_interpolation, 4000x4000 grid, 10k obs"
+        dtype = "f32 (rho, distances) + f64 (local solve)"
+    elif case == "ensi":
+        from tools.bench_cases import ensi_inputs
+        ny, nx, S, E = args.ny or 2500, args.nx or 2500, args.obs or 5000, 50
+        row0, row1 = gdist.row_tile(ny, rank, world)
+        lats, lons, bg, plat, plon, pbg, obs, sig = ensi_inputs(ny, nx, E, S, row0, row1)
+        grid = gridpp.Grid(lats, lons)
+        points = gridpp.Points(plat, plon)
+        structure = gridpp.BarnesStructure(args.h)
+        # per-step observation block from rank 0: [obs | sigma | background at the points (S x E)] in one tensor, one broadcast
+        block = torch.cat([obs.reshape(S, 1), sig.reshape(S, 1), pbg], dim=1).contiguous()
+        slots = [block.clone() if rank == 0 else torch.empty_like(block) for _ in range(2)]
+        stream = gdist.ObservationStream(slots, rank)
+        kernel_ms, union_ms = [], []
+
+        def step():
+            v = stream.next()
+            out = gridpp.optimal_interpolation_ensi(grid, bg, points, v[:, 0].contiguous(), v[:, 1].contiguous(), v[:, 2:].contiguous(),
+                                                    structure, args.max_points)
+            kernel_ms.append(gridpp.ensi_last_kernel_ms()); union_ms.append(kernel_ms[-1])
+            return out
+        cells_total, cells_rank = ny * nx, (row1 - row0) * nx
+        workload = "optimal_interpolation_ensi %dx%d grid x %d members, %d obs, BarnesStructure(%g), max_points=%d" % (ny, nx, E, S, args.h, args.max_points)
+        metric = "grid cells/sec for optimal_interpolation_ensi, 2500x2500 grid, 50 members, 5k obs"
+        dtype = "f32 (rho, distances, member update accumulation) + f64 (local eigenproblem)"
+        extra["bytes_per_cell"] = 8 * E + 16
+    else:
+        from tools.bench_cases import c4_cube
+        ny, nx, E, hw = args.ny or 4000, args.nx or 4000, 100, 15
+        row0, row1 = gdist.row_tile(ny, rank, world)
+        # every rank generates its own rows of the cube (the data are synthetic); halo rows come from the neighbours each step
+        g = torch.Generator(device="cuda").manual_seed(1003 + rank)
+        tile = torch.rand((row1 - row0, nx, E), generator=g, device=dev) * 10
+        halo = gdist.HaloExchange(tile, hw, rank, world) if world > 1 else None
+        stream = None
+        kernel_ms, union_ms = [], []
+
+        def step():
+            if halo is None:
+                return gridpp.neighbourhood(tile, hw, gridpp.Mean)
+            padded, top = halo.exchange()                       # ncclSend / ncclRecv of hw rows per boundary
+            out = gridpp.neighbourhood(padded, hw, gridpp.Mean)
+            return out[top:top + (row1 - row0)]
+        cells_total, cells_rank = ny * nx, (row1 - row0) * nx
+        workload = "neighbourhood Mean %dx%dx%d, halfwidth %d" % (ny, nx, E, hw)
+        metric = "grid cells/sec for neighbourhood(Mean), 4000x4000 grid x 100 members, halfwidth 15"
+        dtype = "f32 (member means) + f64 (box sums)"
+        extra["bytes_per_cell"] = 4 * E + 4
+
     for _ in range(args.warmup):
         step()
-    kernel_ms, union_ms = [], []
+    kernel_ms.clear(); union_ms.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-        st_ = gridpp.oi_last_stats()
-        kernel_ms.append(st_["kernel_ms"]); union_ms.append(st_["union_kernel_ms"])
-    stream.drain()                                        # the one broadcast posted ahead of the last step
+    if stream is not None:
+        stream.drain()                                        # the one broadcast posted ahead of the last step
     fence()
     dt = time.perf_counter() - t0
-    stats = gridpp.oi_last_stats()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert bool(torch.isfinite(out).all())
+    assert bool(torch.isfinite(torch.as_tensor(out)).all())
 
     if rank == 0:
-        cells_total = ny * nx
         ms_per_step = dt / args.steps * 1e3
         value = cells_total * args.steps / dt
-        all_ms = float(np.mean(kernel_ms))            # every kernel of the call (hipEvents on the library stream)
-        k_ms = float(np.mean(union_ms))               # the dominant one: k_oi_union, first pass (all tiles)
-        k_name = "k_oi_union<true, false>"
-        if k_ms <= 0:                                  # that kernel was not used (GPP_OI_NO_UNION): k_oi did everything
-            k_ms, k_name = all_ms, "k_oi<32, false, true, false>"
-        cells_rank = (row1 - row0) * nx
-        achieved = cells_rank * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
-        workload = "optimal_interpolation %dx%d grid, %d obs, BarnesStructure(%g), max_points=%d" % (ny, nx, S, args.h, args.max_points)
-        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload
-        try:
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                t = json.load(f)["k_oi_union"]
-            if t["workload"] == workload and t["n_gpus"] == world:
-                traffic = t["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
+        par = {"oi": "row-tiles x%d, obs broadcast over RCCL (double-buffered, overlapped with the kernels)",
+               "ensi": "row-tiles x%d, observation block (obs, sigma, S x E background) broadcast over RCCL (double-buffered)",
+               "nbh": "row-tiles x%d, halfwidth-row halos exchanged between neighbouring ranks with RCCL send / recv every step"}[case] % world
         res = {
-            "metric": "grid cells/sec for optimal_interpolation, 4000x4000 grid, 10k obs",
-            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (rho, distances) + f64 (local solve)", "data": "synthetic",
-            "config": {"workload": workload,
-                       "parallelism": "row-tiles x%d, obs broadcast over RCCL (double-buffered, overlapped with the kernels)" % world if world > 1 else "1 GPU",
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "parallelism": par if world > 1 else "1 GPU",
                        "inputs": "resident in HBM (device pointers through the C-ABI)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "note": "OI is instruction-issue-bound by construction (observations stay on-chip); algorithmic bytes = 24 B/cell; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/)"},
-            "kernel": {"name": k_name, "avg_ms": k_ms, "all_oi_kernels_ms": all_ms, "cells_per_launch": cells_rank,
-                       "factorisations_per_launch": stats["solves"], "cells_updated": stats["cells_updated"],
-                       "tiles_declined_by_first_pass": stats["fallback_tiles"], "subtiles_left_to_k_oi": stats["fallback_subtiles"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if case == "oi":
+            stats = gridpp.oi_last_stats()
+            all_ms = float(np.mean(kernel_ms))            # every kernel of the call (hipEvents on the library stream)
+            k_ms = float(np.mean(union_ms))               # the dominant one: k_oi_union, first pass (all tiles)
+            k_name = "k_oi_union<true, false>"
+            if k_ms <= 0:                                  # that kernel was not used (GPP_OI_NO_UNION): k_oi did everything
+                k_ms, k_name = all_ms, "k_oi<32, false, true, false>"
+            achieved = cells_rank * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
+            prof = pmc_profile(workload, world)
+            res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": prof["traffic_bytes"] if prof else None,
+                               "note": "OI is instruction-issue-bound by construction (observations stay on-chip): see roofline_compute; algorithmic bytes = 24 B/cell; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/)"}
+            if prof and "SQ_INSTS_VALU" in prof:
+                peak = SIMDS * CLOCK_HZ / 4.0
+                ach = prof["SQ_INSTS_VALU"] / (k_ms * 1e-3)
+                res["roofline_compute"] = {"bound": "valu_issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+                                           "frac": ach / peak, "valu_wave_instructions_per_launch": prof["SQ_INSTS_VALU"],
+                                           "salu_wave_instructions_per_launch": prof.get("SQ_INSTS_SALU"),
+                                           "lds_wave_instructions_per_launch": prof.get("SQ_INSTS_LDS"),
+                                           "instructions_per_cell": (prof["SQ_INSTS_VALU"] + prof.get("SQ_INSTS_SALU", 0) + prof.get("SQ_INSTS_LDS", 0)) * 64.0 / cells_rank / 64.0,
+                                           "note": "VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, profiles/) over the live kernel time, against 1024 SIMDs issuing one per 4 cycles at 2.4 GHz"}
+            res["kernel"] = {"name": k_name, "avg_ms": k_ms, "all_oi_kernels_ms": all_ms, "cells_per_launch": cells_rank,
+                             "factorisations_per_launch": stats["solves"], "cells_updated": stats["cells_updated"],
+                             "tiles_declined_by_first_pass": stats["fallback_tiles"], "subtiles_left_to_k_oi": stats["fallback_subtiles"]}
+        else:
+            bpc = extra["bytes_per_cell"]
+            k_ms = float(np.mean(kernel_ms)) if kernel_ms else ms_per_step
+            achieved = cells_rank * bpc / (k_ms * 1e-3) / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": None, "note": "algorithmic bytes = %d B/cell" % bpc}
+            res["kernel"] = {"avg_ms": k_ms, "cells_per_launch": cells_rank}
+            if case == "ensi":
+                E, n = 50, args.max_points
+                flops = cells_rank * (2.0 * n * E * E + 10.0 * E ** 3 + 2.0 * E * E * n)
+                res["roofline_compute"] = {"bound": "fp64", "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
+                                           "frac": flops / (k_ms * 1e-3) / FP64_PEAK,
+                                           "note": "flops by SURVEY.md 8(d)'s count of the reference's E x E formulation (2nE^2 + 10E^3 + 2E^2n per cell); the kernel solves an n x n problem instead"}
+        if world == 1 and case == "oi":
+            # the same call from numpy buffers (GPP_MEM_HOST): PCIe both ways included -- reported, never `value`
+            hl, hlo, hbg, hplat, hplon, hobs, hrat, hpbg = make_workload(ny, nx, S, seed, 0, ny)
+            hs = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                gridpp.optimal_interpolation(grid, hbg, points, hobs, hrat, hpbg, structure, args.max_points)
+                hs.append(time.perf_counter() - t1)
+            res["host_inclusive"] = {"ms_per_step": min(hs) * 1e3, "value": cells_total / min(hs), "unit": "cells/s",
+                                     "note": "numpy float32 buffers in, numpy out: 64 MB over PCIe each way inside the call"}
+        if world == 1 and not args.no_other_configs and case == "oi":
+            from tools import bench_cases as bc
+            oc = []
+            try:
+                oc.append(bc.oi_case("C1 OI 200x200, 10 obs, mp=10", 200, 200, 10, 10, 1000))
+                oc.append(bc.oi_case("C2 OI 1000x1000, 1k obs, mp=20", 1000, 1000, 1000, 20, 1001))
+                oc.append(bc.oi_case("C3 OI 4000x4000, 10k obs, mp=30, smooth terrain elev+laf (v=200,w=0.5)", 4000, 4000, 10000, 30, 1002, elev=True))
+                oc.append(bc.oi_case("C3 OI 4000x4000, 10k obs, mp=30, white-noise elev+laf (v=200,w=0.5)", 4000, 4000, 10000, 30, 1002, elev="noise", reps=2))
+                oc.extend(bc.nb_cases(4000, 4000, 100, 15, two_d=False))
+                torch.cuda.empty_cache()
+                oc.append(bc.ensi_case(2500, 2500, 50, 5000, 30))
+            except Exception as e:   # a failing secondary case must not take the headline line with it
+                oc.append({"case": "error", "message": repr(e)[:300]})
+            res["other_configs"] = oc
+        if world == 1 and not args.no_cpu_baseline and case == "oi":
             res["cpu_baseline"] = cpu_baseline(ny, nx, S, seed, args.h, args.max_points, args.cpu_seconds)
             res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)

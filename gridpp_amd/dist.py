@@ -118,3 +118,53 @@ def tiled_neighbourhood(field, halfwidth, statistic, rank, world, compute):
     lo, hi, row0, row1 = halo_rows(np.shape(field)[0], rank, world, halfwidth)
     sub = compute(field[lo:hi], halfwidth, statistic)
     return row0, row1, sub[row0 - lo:row0 - lo + (row1 - row0)]
+
+
+class HaloExchange:
+    """Device-side halo of a row-tiled field for the neighbourhood filters: every step each rank sends its first
+    and last `halfwidth` rows to the neighbouring ranks and receives theirs -- point-to-point over xGMI (torch.distributed
+    batch_isend_irecv = ncclSend / ncclRecv on the nccl = RCCL backend; gloo in the CPU tests), 2 x halfwidth x X x E x 4 bytes
+    per interior boundary and no collective.  The padded tile lives in one preallocated buffer: [top halo | tile | bottom halo],
+    the tile rows are a view of it, so "exchange" moves only the halo rows.
+
+    tile: (rows, X[, E]) tensor of this rank's rows; exchange() -> (padded, top) with padded[top:top + rows] == tile."""
+
+    def __init__(self, tile, halfwidth, rank, world, group=None):
+        import torch
+        self.rank, self.world, self.hw, self.group = rank, world, int(halfwidth), group
+        rows = tile.shape[0]
+        if world > 1 and rows < self.hw:
+            raise ValueError("a row tile must hold at least `halfwidth` rows")
+        self.top = self.hw if rank > 0 else 0
+        self.bot = self.hw if rank < world - 1 else 0
+        self.buf = torch.empty((self.top + rows + self.bot,) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
+        self.tile = self.buf[self.top:self.top + rows]
+        self.tile.copy_(tile)
+
+    def exchange(self):
+        import torch.distributed as dist
+        hw = self.hw
+        rows = self.tile.shape[0]
+        ops = []
+        if self.top:     # neighbour above: my first hw rows go up, its last hw rows come down
+            ops.append(dist.P2POp(dist.isend, self.tile[:hw].contiguous(), self.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, self.buf[:hw], self.rank - 1, self.group))
+        if self.bot:
+            ops.append(dist.P2POp(dist.isend, self.tile[rows - hw:].contiguous(), self.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, self.buf[self.top + rows:], self.rank + 1, self.group))
+        if ops and self.buf.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no device point-to-point: only the one-GPU logic test (bench.py with GPP_BENCH_BACKEND=gloo) comes here
+            cpu_ops, back = [], []
+            for o in ops:
+                t = o.tensor.cpu()
+                cpu_ops.append(dist.P2POp(o.op, t, o.peer, self.group))
+                if o.op is dist.irecv:
+                    back.append((o.tensor, t))
+            for w in dist.batch_isend_irecv(cpu_ops):
+                w.wait()
+            for dst, src in back:
+                dst.copy_(src)
+        elif ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return self.buf, self.top

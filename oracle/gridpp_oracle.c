@@ -29,6 +29,9 @@
  * unbuildable in this image (needs Boost, Armadillo, LAPACK, SWIG).
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
@@ -315,15 +318,25 @@ static int orc_pair_cmp(const void* a, const void* b) {
     if(p->rho < q->rho) return 1;
     return (p->idx > q->idx) - (p->idx < q->idx); /* oracle-defined tie-break */
 }
+static int orc_pair_idx_cmp(const void* a, const void* b) {
+    const orc_pair* p = (const orc_pair*)a; const orc_pair* q = (const orc_pair*)b;
+    return (p->idx > q->idx) - (p->idx < q->idx);
+}
 /* Returns number selected; sel[] = observation indices, srho[] = rho (float). */
-static int orc_select(float gx, float gy, float gz, float ge, float gl,
+/* cand == NULL: linear scan over all observations (the reference's R-tree returns the same set; its order is unspecified
+   and only matters for exact rho ties).  cand != NULL: the same test on a pre-filtered list in ascending index order (the
+   cell list of the CPU baseline below, any order) -- a superset of the observations in range; the kept set is put back into
+   index order where the reference keeps candidate order, so the result is identical. */
+static int orc_select_from(const int* cand, int ncand, float gx, float gy, float gz, float ge, float gl,
                       int nS, const float* ox, const float* oy, const float* oz,
                       const float* oe, const float* ol,
                       const float* pobs, const float* pbg /* may be NULL: EnSI */,
                       float h, float v, float w, float loc, int max_points,
                       orc_pair* work, int* sel, float* srho) {
     int n = 0;
-    for(int s = 0; s < nS; s++) {
+    const int nloop = cand ? ncand : nS;
+    for(int k = 0; k < nloop; k++) {
+        const int s = cand ? cand[k] : k;
         if(!orc_in_radius(gx, gy, gz, ox[s], oy[s], oz[s], loc, 1)) continue;      /* oi.cpp:233 */
         float rho = orc_barnes_corr(gx, gy, gz, ge, gl, ox[s], oy[s], oz[s], oe[s], ol[s], h, v, w, loc); /* :250 */
         if(!orc_valid(pobs[s])) continue;                                            /* :252 */
@@ -334,10 +347,68 @@ static int orc_select(float gx, float gy, float gz, float ge, float gl,
         qsort(work, n, sizeof(orc_pair), orc_pair_cmp);
         n = max_points;
     }
+    else if(cand) qsort(work, n, sizeof(orc_pair), orc_pair_idx_cmp);   /* kept in candidate order: that of the linear scan */
     for(int i = 0; i < n; i++) { sel[i] = work[i].idx; srho[i] = work[i].rho; }
     return n;
 }
+static int orc_select(float gx, float gy, float gz, float ge, float gl,
+                      int nS, const float* ox, const float* oy, const float* oz,
+                      const float* oe, const float* ol,
+                      const float* pobs, const float* pbg,
+                      float h, float v, float w, float loc, int max_points,
+                      orc_pair* work, int* sel, float* srho) {
+    return orc_select_from(NULL, 0, gx, gy, gz, ge, gl, nS, ox, oy, oz, oe, ol, pobs, pbg, h, v, w, loc, max_points, work, sel, srho);
+}
 
+/* the local analysis of one grid point from its selected observations (oi.cpp:289-337) */
+static int orc_oi_solve_cell(int y, int lS, const int* sel, const float* srho,
+                         const float* background, const float* bvariance,
+                         const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                         const float* pobs, const float* pratios, const float* pbackground,
+                         float h, float v, float w, float loc, int allow_extrapolation, float* out, float* out_var,
+                         double** scratch, size_t* scratch_cap) {
+    /* caller-owned work space (one per thread), grown on demand: A [lS x lS], d [lS], G [lS] */
+    const size_t need = (size_t)lS * lS + 2 * (size_t)lS;
+    if(*scratch_cap < need) { free(*scratch); *scratch = (double*)malloc(sizeof(double) * need); *scratch_cap = need; }
+    double* A = *scratch;
+    double* d = A + (size_t)lS * lS;
+    double* G = d + lS;
+    for(int i = 0; i < lS; i++) {                                               /* :297-314 */
+        int si = sel[i];
+        d[i] = (double)pobs[si] - (double)pbackground[si];                      /* lObs - lY in double */
+        G[i] = (double)srho[i];
+        for(int j = 0; j < lS; j++) {
+            int sj = sel[j];
+            float c = orc_barnes_corr(ox[si], oy[si], oz[si], oelev[si], olaf[si],
+                                      ox[sj], oy[sj], oz[sj], oelev[sj], olaf[sj], h, v, w, loc);
+            A[i * lS + j] = (double)c;
+        }
+        A[i * lS + i] += (double)pratios[si];                                   /* lP + lR */
+    }
+    if(orc_inv(A, lS) != ORC_OK) return ORC_ESINGULAR; /* :315 */
+    double dx = 0, a00 = 0; float maxInc = 0, minInc = 0;
+    for(int j = 0; j < lS; j++) {
+        double gsr = 0;
+        for(int i = 0; i < lS; i++) gsr += G[i] * A[i * lS + j];                /* lGSR = lG * inv */
+        dx += gsr * d[j];                                                       /* :316 */
+        a00 += gsr * G[j];                                                      /* :336 */
+    }
+    for(int j = 0; j < lS; j++) {                                               /* :319-320 */
+        float dj = (float)d[j];
+        if(j == 0 || dj > maxInc) maxInc = dj;
+        if(j == 0 || dj < minInc) minInc = dj;
+    }
+    float increment = (float)dx;                                                /* :317 */
+    if(!allow_extrapolation) {                                                  /* :318-334 */
+        if(maxInc > 0 && increment > maxInc) increment = maxInc;
+        else if(maxInc < 0 && increment > 0) increment = maxInc;
+        else if(minInc < 0 && increment < minInc) increment = minInc;
+        else if(minInc > 0 && increment < 0) increment = minInc;
+    }
+    out[y] = background[y] + increment;                                         /* :335 */
+    out_var[y] = (float)((double)bvariance[y] * (1 - a00));                     /* :337 */
+    return ORC_OK;
+}
 /* ------------------------------------------------------------------------ */
 /* optimal_interpolation_full (Points): src/api/oi.cpp:138-341                */
 /* Arrays are flat; obs x/y/z from orc_convert_coordinates.                   */
@@ -362,52 +433,18 @@ int orc_oi_full_range(int y0, int y1,
     orc_pair* work = (orc_pair*)malloc(sizeof(orc_pair) * nS);
     int* sel = (int*)malloc(sizeof(int) * nS);
     float* srho = (float*)malloc(sizeof(float) * nS);
+    double* scratch = NULL; size_t scratch_cap = 0;
     int rc = ORC_OK;
     for(int y = y0; y < y1; y++) {
         if(!orc_valid(background[y])) continue;                                     /* :223 */
         int lS = orc_select(gx[y], gy[y], gz[y], gelev[y], glaf[y], nS, ox, oy, oz, oelev, olaf,
                             pobs, pbackground, h, v, w, loc, max_points, work, sel, srho);
         if(lS == 0) continue;                                                       /* :234,284 */
-        double* A = (double*)malloc(sizeof(double) * lS * lS);
-        double* d = (double*)malloc(sizeof(double) * lS);
-        double* G = (double*)malloc(sizeof(double) * lS);
-        for(int i = 0; i < lS; i++) {                                               /* :297-314 */
-            int si = sel[i];
-            d[i] = (double)pobs[si] - (double)pbackground[si];                      /* lObs - lY in double */
-            G[i] = (double)srho[i];
-            for(int j = 0; j < lS; j++) {
-                int sj = sel[j];
-                float c = orc_barnes_corr(ox[si], oy[si], oz[si], oelev[si], olaf[si],
-                                          ox[sj], oy[sj], oz[sj], oelev[sj], olaf[sj], h, v, w, loc);
-                A[i * lS + j] = (double)c;
-            }
-            A[i * lS + i] += (double)pratios[si];                                   /* lP + lR */
-        }
-        if(orc_inv(A, lS) != ORC_OK) { rc = ORC_ESINGULAR; free(A); free(d); free(G); break; } /* :315 */
-        double dx = 0, a00 = 0; float maxInc = 0, minInc = 0;
-        for(int j = 0; j < lS; j++) {
-            double gsr = 0;
-            for(int i = 0; i < lS; i++) gsr += G[i] * A[i * lS + j];                /* lGSR = lG * inv */
-            dx += gsr * d[j];                                                       /* :316 */
-            a00 += gsr * G[j];                                                      /* :336 */
-        }
-        for(int j = 0; j < lS; j++) {                                               /* :319-320 */
-            float dj = (float)d[j];
-            if(j == 0 || dj > maxInc) maxInc = dj;
-            if(j == 0 || dj < minInc) minInc = dj;
-        }
-        float increment = (float)dx;                                                /* :317 */
-        if(!allow_extrapolation) {                                                  /* :318-334 */
-            if(maxInc > 0 && increment > maxInc) increment = maxInc;
-            else if(maxInc < 0 && increment > 0) increment = maxInc;
-            else if(minInc < 0 && increment < minInc) increment = minInc;
-            else if(minInc > 0 && increment < 0) increment = minInc;
-        }
-        out[y] = background[y] + increment;                                         /* :335 */
-        out_var[y] = (float)((double)bvariance[y] * (1 - a00));                     /* :337 */
-        free(A); free(d); free(G);
+        rc = orc_oi_solve_cell(y, lS, sel, srho, background, bvariance, ox, oy, oz, oelev, olaf, pobs, pratios, pbackground,
+                               h, v, w, loc, allow_extrapolation, out, out_var, &scratch, &scratch_cap);
+        if(rc != ORC_OK) break;
     }
-    free(pratios); free(work); free(sel); free(srho);
+    free(pratios); free(work); free(sel); free(srho); free(scratch);
     return rc;
 }
 int orc_oi_full(int nY,
@@ -421,6 +458,109 @@ int orc_oi_full(int nY,
     return orc_oi_full_range(0, nY, gx, gy, gz, gelev, glaf, background, bvariance, nS, ox, oy, oz, oelev, olaf,
                              pobs, obs_variance, pbackground, bvariance_at_points, h, v, w, min_rho,
                              max_points, allow_extrapolation, out, out_var);
+}
+/* ------------------------------------------------------------------------ */
+/* CPU baseline of bench.py: the same loop as orc_oi_full_range with (a) the  */
+/* radius query answered from a cell list instead of a linear scan -- the     */
+/* algorithm class of the reference's R-tree query (kdtree.cpp:39-60): only   */
+/* the observations of the bins that overlap the query box are tested, and    */
+/* the kept ones are put back into index order, so every number computed     */
+/* from them is identical to the linear scan (tests/test_oracle_baseline.py) --   */
+/* and (b) the grid points spread over OpenMP threads with a dynamic schedule */
+/* (the reference: `#pragma omp parallel for`, oi.cpp:221).                    */
+/* nthreads <= 0: OMP default.  use_cell_list = 0: linear scan.               */
+/* ------------------------------------------------------------------------ */
+int orc_oi_full_omp(int nthreads, int use_cell_list, int y0, int y1,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* background, const float* bvariance,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* obs_variance, const float* pbackground, const float* bvariance_at_points,
+                float h, float v, float w, float min_rho,
+                int max_points, int allow_extrapolation,
+                float* out, float* out_var) {
+    if(max_points < 0) return ORC_EINVAL;
+    for(int y = y0; y < y1; y++) { out[y] = background[y]; out_var[y] = bvariance[y]; }
+    if(nS == 0) return ORC_OK;
+    float* pratios = (float*)malloc(sizeof(float) * nS);
+    for(int s = 0; s < nS; s++) pratios[s] = obs_variance[s] / bvariance_at_points[s];
+    const float loc = orc_barnes_localization_distance(h, min_rho);
+    /* cell list on the two axes with the widest extent; bin edge = half the query radius */
+    int ax = 0, ay = 1, nbx = 1, nby = 1;
+    float amin = 0, bmin = 0, inv = 0;
+    int* bin_start = NULL; int* bin_items = NULL;
+    if(use_cell_list) {
+        const float* c[3] = {ox, oy, oz};
+        float lo[3], hi[3];
+        for(int k = 0; k < 3; k++) { lo[k] = hi[k] = c[k][0]; for(int s = 1; s < nS; s++) { if(c[k][s] < lo[k]) lo[k] = c[k][s]; if(c[k][s] > hi[k]) hi[k] = c[k][s]; } }
+        int order[3] = {0, 1, 2};
+        for(int a = 0; a < 3; a++) for(int b = a + 1; b < 3; b++) if(hi[order[b]] - lo[order[b]] > hi[order[a]] - lo[order[a]]) { int t = order[a]; order[a] = order[b]; order[b] = t; }
+        ax = order[0]; ay = order[1];
+        const float edge = loc > 0 ? loc * 0.5f : 1.0f;
+        inv = 1.0f / edge; amin = lo[ax]; bmin = lo[ay];
+        nbx = (int)((hi[ax] - lo[ax]) * inv) + 1; nby = (int)((hi[ay] - lo[ay]) * inv) + 1;
+        if((long)nbx * nby > 4000000L) { nbx = nby = 1; inv = 0; }
+        bin_start = (int*)calloc((size_t)nbx * nby + 1, sizeof(int));
+        bin_items = (int*)malloc(sizeof(int) * nS);
+        int* bin_of = (int*)malloc(sizeof(int) * nS);
+        for(int s = 0; s < nS; s++) {
+            int bx = (int)((c[ax][s] - amin) * inv), by = (int)((c[ay][s] - bmin) * inv);
+            if(bx < 0) bx = 0; if(bx >= nbx) bx = nbx - 1; if(by < 0) by = 0; if(by >= nby) by = nby - 1;
+            bin_of[s] = by * nbx + bx; bin_start[bin_of[s] + 1]++;
+        }
+        for(int k = 0; k < nbx * nby; k++) bin_start[k + 1] += bin_start[k];
+        int* fill = (int*)malloc(sizeof(int) * (size_t)nbx * nby);
+        for(int k = 0; k < nbx * nby; k++) fill[k] = bin_start[k];
+        for(int s = 0; s < nS; s++) bin_items[fill[bin_of[s]]++] = s;      /* ascending index inside a bin */
+        free(fill); free(bin_of);
+    }
+    int rc = ORC_OK;
+#ifdef _OPENMP
+    if(nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        orc_pair* work = (orc_pair*)malloc(sizeof(orc_pair) * nS);
+        int* sel = (int*)malloc(sizeof(int) * nS);
+        float* srho = (float*)malloc(sizeof(float) * nS);
+        int* cand = (int*)malloc(sizeof(int) * nS);
+        double* scratch = NULL; size_t scratch_cap = 0;
+#pragma omp for schedule(dynamic, 64)
+        for(int y = y0; y < y1; y++) {
+            if(rc != ORC_OK) continue;
+            if(!orc_valid(background[y])) continue;
+            int lS;
+            if(use_cell_list) {
+                const float g[3] = {gx[y], gy[y], gz[y]};
+                int bx0 = (int)floorf((g[ax] - loc - amin) * inv), bx1 = (int)floorf((g[ax] + loc - amin) * inv);
+                int by0 = (int)floorf((g[ay] - loc - bmin) * inv), by1 = (int)floorf((g[ay] + loc - bmin) * inv);
+                if(bx0 < 0) bx0 = 0; if(by0 < 0) by0 = 0; if(bx1 >= nbx) bx1 = nbx - 1; if(by1 >= nby) by1 = nby - 1;
+                int nc = 0;
+                for(int by = by0; by <= by1; by++)
+                    for(int k = bin_start[by * nbx + bx0]; k < bin_start[by * nbx + bx1 + 1]; k++) cand[nc++] = bin_items[k];
+                lS = orc_select_from(cand, nc, gx[y], gy[y], gz[y], gelev[y], glaf[y], nS, ox, oy, oz, oelev, olaf,
+                                     pobs, pbackground, h, v, w, loc, max_points, work, sel, srho);
+            }
+            else lS = orc_select(gx[y], gy[y], gz[y], gelev[y], glaf[y], nS, ox, oy, oz, oelev, olaf,
+                                 pobs, pbackground, h, v, w, loc, max_points, work, sel, srho);
+            if(lS == 0) continue;
+            int r = orc_oi_solve_cell(y, lS, sel, srho, background, bvariance, ox, oy, oz, oelev, olaf, pobs, pratios, pbackground,
+                                      h, v, w, loc, allow_extrapolation, out, out_var, &scratch, &scratch_cap);
+            if(r != ORC_OK) {
+#pragma omp critical
+                rc = r;
+            }
+        }
+        free(work); free(sel); free(srho); free(cand); free(scratch);
+    }
+    free(pratios); free(bin_start); free(bin_items);
+    return rc;
+}
+int orc_omp_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 /* ------------------------------------------------------------------------ */
 /* optimal_interpolation_full with a generic scalar structure (same loop as   */

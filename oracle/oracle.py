@@ -190,6 +190,27 @@ def oi_full(g, background, bvariance, p, obs, obs_variance, pbackground, bvarian
     return out[y0:y1], var[y0:y1]
 
 
+def oi_baseline(g, background, p, obs, ratios, pbackground, st, max_points, threads=0, cell_list=True, allow_extrapolation=True):
+    """The CPU baseline of bench.py: the loop of oi() with a cell-list radius query and OpenMP over the grid points
+    (orc_oi_full_omp); bit-identical to oi() by construction, asserted in tests/test_oracle_baseline.py."""
+    background = _f(background).ravel()
+    obs, ratios, pbackground = _f(obs), _f(ratios), _f(pbackground)
+    ones_g, ones_p = np.ones(g.n, np.float32), np.ones(p.n, np.float32)
+    out = np.empty(g.n, np.float32)
+    var = np.empty(g.n, np.float32)
+    rc = lib().orc_oi_full_omp(C.c_int(threads), C.c_int(1 if cell_list else 0), C.c_int(0), C.c_int(g.n), g.x.ctypes, g.y.ctypes,
+                               g.z.ctypes, g.elevs.ctypes, g.lafs.ctypes, background.ctypes, ones_g.ctypes, C.c_int(p.n), p.x.ctypes,
+                               p.y.ctypes, p.z.ctypes, p.elevs.ctypes, p.lafs.ctypes, obs.ctypes, ratios.ctypes, pbackground.ctypes,
+                               ones_p.ctypes, C.c_float(st.h), C.c_float(st.v), C.c_float(st.w), C.c_float(st.min_rho),
+                               C.c_int(max_points), C.c_int(1 if allow_extrapolation else 0), out.ctypes, var.ctypes)
+    _check(rc)
+    return out
+
+
+def omp_max_threads():
+    return int(lib().orc_omp_max_threads())
+
+
 def oi(g, background, p, obs, ratios, pbackground, st, max_points, allow_extrapolation=True, y0=0, y1=None):
     """optimal_interpolation(Points...) = _full with unit variances (src/api/oi.cpp:123-135)."""
     ones_g = np.ones(g.n, np.float32)

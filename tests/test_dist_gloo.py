@@ -132,3 +132,41 @@ def test_observation_stream_single_process():
     stream = gdist.ObservationStream(slots, 0, lambda slot, step: slots[slot].fill_(step))
     assert [float(stream.next()[0]) for _ in range(4)] == [0.0, 1.0, 2.0, 3.0]
     stream.drain()
+
+
+def _halo_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11)
+    full = rng.uniform(0, 10, (40, 13, 3)).astype(np.float32)      # every rank can regenerate the full field: only its rows are used
+    hw = 4
+    row0, row1 = gdist.row_tile(full.shape[0], rank, world)
+    halo = gdist.HaloExchange(torch.from_numpy(full[row0:row1].copy()), hw, rank, world)
+    for step in range(2):                                         # the second exchange must leave the tile rows untouched
+        padded, top = halo.exchange()
+    lo, hi, _, _ = gdist.halo_rows(full.shape[0], rank, world, hw)
+    np.testing.assert_array_equal(padded.numpy(), full[lo:hi])    # tile + the neighbours' rows = the rows a single process would see
+    out = O.neighbourhood(padded.numpy(), hw, O.Mean)[top:top + (row1 - row0)]
+    np.save(os.path.join(outdir, "nb%d.npy" % rank), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_side_halo_exchange(tmp_path, world):
+    """HaloExchange (send / recv of `halfwidth` rows between neighbouring ranks) + the filter on the padded tile = the single call."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_halo_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(11)
+    full = rng.uniform(0, 10, (40, 13, 3)).astype(np.float32)
+    ref = O.neighbourhood(full, 4, O.Mean)
+    got = np.concatenate([np.load(tmp_path / ("nb%d.npy" % r)) for r in range(world)])
+    np.testing.assert_array_equal(got, ref)

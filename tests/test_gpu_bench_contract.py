@@ -30,7 +30,14 @@ def test_single_gpu_line():
     assert KEYS <= set(r) and "cpu_baseline" in r
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["value"] > 1e8
     assert set(r["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
-    assert set(r["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert set(r["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "one_thread_value"}
+    assert r["roofline_compute"]["bound"] == "valu_issue" and 0 < r["roofline_compute"]["frac"] < 1
+    assert r["host_inclusive"]["ms_per_step"] > r["ms_per_step"]
+    cases = " | ".join(c["case"] for c in r["other_configs"])
+    for key in ("C1 OI", "C2 OI", "C4 neighbourhood Mean", "C4 quantile_fast", "C5 EnSI"):
+        assert key in cases, cases
+    for c in r["other_configs"]:
+        assert c["ms"] > 0 and c["Mcells/s"] > 0 and 0 < c["frac_hbm"] < 1, c
     assert abs(r["value"] - 16e6 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
 
 
@@ -46,3 +53,18 @@ def test_two_rank_logic_on_one_gpu():
     r = _json_line(out.stdout)
     assert KEYS <= set(r) and r["n_gpus"] == 2 and r["scaling"] == "strong" and r["value"] > 0
     assert r["kernel"]["cells_per_launch"] == 8_000_000          # rank 0's row tile: half of the 4000 x 4000 grid
+
+
+@pytest.mark.parametrize("case,extra", [("ensi", ["--ny", "256", "--nx", "256", "--obs", "500"]), ("nbh", ["--ny", "512", "--nx", "256"])])
+def test_other_cases_two_rank_logic(case, extra):
+    """--case ensi / nbh: row tiles, block broadcast resp. halo exchange, on two ranks sharing GPU 0 over gloo (logic only)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GPP_BENCH_SHARE_GPU="1", GPP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--case", case] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _json_line(out.stdout)
+    assert KEYS <= set(r) and r["n_gpus"] == 2 and r["value"] > 0 and r["roofline"]["achieved"] > 0

@@ -1,0 +1,139 @@
+"""Synthetic workloads of BASELINE.json's configs (shapes, distributions, seeds) and one timed case per config.
+Shared by bench.py (the `other_configs` object of the bench line) and tools/bench_paths.py (one JSON line per case).
+Every case returns a dict with the same per-step fields: ms, kernel_ms (HIP events where the library reports them), Mcells/s,
+algorithmic GB/s and its fraction of the 8 TB/s HBM peak."""
+import time
+
+import numpy as np
+
+HBM_PEAK = 8.0e12      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK = 78.6e12    # vector fp64 (the matrix fp64 peak of MI355X is the same figure)
+
+
+def make_workload(ny, nx, S, seed, row0, row1):
+    """[0,1] deg^2 geodetic grid, uniform obs, obs = pbg + N(0,1), ratios U(0.1,1)."""
+    rng = np.random.default_rng(seed)
+    lat1 = np.linspace(0, 1, ny, dtype=np.float64)[row0:row1]
+    lon1 = np.linspace(0, 1, nx, dtype=np.float64)
+    lats, lons = np.meshgrid(lat1, lon1, indexing="ij")
+    plat, plon = rng.random(S), rng.random(S)
+    pbg = rng.normal(0, 1, S).astype(np.float32)
+    obs = (pbg + rng.normal(0, 1, S)).astype(np.float32)
+    ratios = rng.uniform(0.1, 1, S).astype(np.float32)
+    # smooth deterministic background field (any fixed smooth function)
+    bg = (np.sin(6 * lats) * np.cos(4 * lons) * 3).astype(np.float32)
+    return lats, lons, bg, plat, plon, obs, ratios, pbg
+
+
+def timeit(fn, reps=3, warm=1):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return min(ts)
+
+
+def terrain(lat, lon):
+    """smooth synthetic topography (m) and land area fraction: a few hundred metres of relief over tens of km"""
+    z = 500 + 300 * np.sin(lat * 9.0) * np.cos(lon * 7.0) + 150 * np.sin(lat * 31.0 + 1.0) * np.sin(lon * 23.0) + 50 * np.cos(lat * 90.0) * np.cos(lon * 70.0)
+    laf = np.clip(0.5 + 0.6 * np.sin(lat * 5.0 + lon * 3.0), 0, 1)
+    return z, laf
+
+
+def oi_case(name, ny, nx, S, mp, seed, elev=False, reps=3):
+    import torch
+    import gridpp_amd as gridpp
+    lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, S, seed, 0, ny)
+    rng = np.random.default_rng(seed + 7)
+    ge = gl = pe = pl = ()
+    v = w = 0
+    if elev == "noise":     # white-noise elevation / laf per cell: no two cells of a tile select the same observations
+        ge, gl = rng.uniform(0, 1000, (ny, nx)), rng.uniform(0, 1, (ny, nx))
+        pe, pl = rng.uniform(0, 1000, S), rng.uniform(0, 1, S)
+        v, w = 200, 0.5
+    elif elev:              # smooth terrain
+        ge, gl = terrain(np.deg2rad(lats) * 40, np.deg2rad(lons) * 40)
+        pe, pl = terrain(np.deg2rad(plat) * 40, np.deg2rad(plon) * 40)
+        pe = pe + rng.normal(0, 30, S)   # stations are not exactly on the model terrain
+        v, w = 200, 0.5
+    grid = gridpp.Grid(lats, lons, ge, gl)
+    points = gridpp.Points(plat, plon, pe, pl)
+    st = gridpp.BarnesStructure(10000, v, w)
+    d = [torch.from_numpy(a).cuda() for a in (bg, obs, ratios, pbg)]
+    t = timeit(lambda: gridpp.optimal_interpolation(grid, d[0], points, d[1], d[2], d[3], st, mp), reps=reps)
+    s = gridpp.oi_last_stats()
+    gbs = ny * nx * 24 / (s["kernel_ms"] * 1e-3) / 1e9
+    return {"case": name, "cells": ny * nx, "ms": t * 1e3, "kernel_ms": s["kernel_ms"], "Mcells/s": ny * nx / t / 1e6,
+            "solves": s["solves"], "declined_tiles": s["fallback_tiles"], "items_left_to_k_oi": s["fallback_subtiles"],
+            "GB/s_algorithmic": gbs, "frac_hbm": gbs * 1e9 / HBM_PEAK, "bytes_per_cell": 24}
+
+
+def c4_cube(ny, nx, E):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(1003)
+    return torch.rand((ny, nx, E), generator=g, device="cuda") * 10
+
+
+def nb_cases(ny, nx, E, hw, cube=None, qs=(0.5,), two_d=True):
+    import torch
+    import gridpp_amd as gridpp
+    if cube is None:
+        cube = c4_cube(ny, nx, E)
+    out = []
+    bytes_alg = ny * nx * (4 * E + 4)
+    t = timeit(lambda: gridpp.neighbourhood(cube, hw, gridpp.Mean))
+    out.append({"case": "C4 neighbourhood Mean %dx%dx%d hw=%d" % (ny, nx, E, hw), "cells": ny * nx, "ms": t * 1e3, "Mcells/s": ny * nx / t / 1e6,
+                "GB/s_algorithmic": bytes_alg / t / 1e9, "frac_hbm": bytes_alg / t / HBM_PEAK, "bytes_per_cell": 4 * E + 4})
+    thr = torch.linspace(0, 10, 11, device="cuda")
+    for q in qs:
+        t = timeit(lambda: gridpp.neighbourhood_quantile_fast(cube, q, hw, thr))
+        out.append({"case": "C4 quantile_fast q=%g T=11 %dx%dx%d hw=%d" % (q, ny, nx, E, hw), "cells": ny * nx, "ms": t * 1e3,
+                    "Mcells/s": ny * nx / t / 1e6, "GB/s_algorithmic": bytes_alg / t / 1e9, "frac_hbm": bytes_alg / t / HBM_PEAK,
+                    "bytes_per_cell": 4 * E + 4})
+    if two_d:
+        f2 = cube[:, :, 0].contiguous()
+        for stat, nm in ((gridpp.Mean, "Mean"), (gridpp.Max, "Max")):
+            t = timeit(lambda: gridpp.neighbourhood(f2, 7, stat))
+            out.append({"case": "neighbourhood 2-D %s %dx%d hw=7" % (nm, ny, nx), "cells": ny * nx, "ms": t * 1e3, "Mcells/s": ny * nx / t / 1e6,
+                        "GB/s_algorithmic": ny * nx * 8 / t / 1e9, "frac_hbm": ny * nx * 8 / t / HBM_PEAK, "bytes_per_cell": 8})
+    return out
+
+
+def ensi_inputs(ny, nx, E, S, row0=0, row1=None):
+    """smooth field + N(0,1) per member, sigma = 1, h = 10 km."""
+    import torch
+    row1 = ny if row1 is None else row1
+    rng = np.random.default_rng(1004)
+    lat1 = np.linspace(0, 1, ny)[row0:row1]
+    lats, lons = np.meshgrid(lat1, np.linspace(0, 1, nx), indexing="ij")
+    base = torch.from_numpy((np.sin(6 * lats) * np.cos(4 * lons) * 3).astype(np.float32)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(1004 + row0)
+    bg = base[:, :, None] + torch.randn((row1 - row0, nx, E), generator=g, device="cuda")
+    plat, plon = rng.random(S), rng.random(S)
+    pbg = torch.from_numpy(rng.normal(0, 1, (S, E)).astype(np.float32)).cuda()
+    obs = torch.from_numpy(rng.normal(0, 1, S).astype(np.float32)).cuda()
+    sig = torch.ones(S, device="cuda")
+    return lats, lons, bg, plat, plon, pbg, obs, sig
+
+
+def ensi_case(ny, nx, E, S, mp, reps=2):
+    import gridpp_amd as gridpp
+    lats, lons, bg, plat, plon, pbg, obs, sig = ensi_inputs(ny, nx, E, S)
+    grid = gridpp.Grid(lats, lons)
+    points = gridpp.Points(plat, plon)
+    st = gridpp.BarnesStructure(10000)
+    t = timeit(lambda: gridpp.optimal_interpolation_ensi(grid, bg, points, obs, sig, pbg, st, mp), reps=reps, warm=1)
+    # flops per cell by SURVEY.md 8(d)'s count for the reference's E x E formulation: 2nE^2 + ~10E^3 + 2E^2n
+    n = mp
+    flops = ny * nx * (2.0 * n * E * E + 10.0 * E ** 3 + 2.0 * E * E * n)
+    kms = gridpp.ensi_last_kernel_ms()
+    return {"case": "C5 EnSI %dx%dx%d, %d obs, max_points=%d" % (ny, nx, E, S, mp), "cells": ny * nx, "ms": t * 1e3, "kernel_ms": kms,
+            "Mcells/s": ny * nx / t / 1e6, "GB/s_algorithmic": ny * nx * (8 * E + 16) / t / 1e9, "frac_hbm": ny * nx * (8 * E + 16) / t / HBM_PEAK,
+            "bytes_per_cell": 8 * E + 16, "fp64_TFLOPs_reference_count": flops / (kms * 1e-3) / 1e12,
+            "frac_fp64_peak_reference_count": flops / (kms * 1e-3) / FP64_PEAK}

@@ -11,89 +11,22 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gridpp_amd as gridpp  # noqa: E402
-from bench import make_workload  # noqa: E402
 
 
-def timeit(fn, reps=3, warm=1):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        fn()
-        torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-    return min(ts)
+from tools.bench_cases import make_workload, timeit, oi_case as _oi_case, nb_cases, ensi_case as _ensi_case  # noqa: E402
 
 
-def terrain(lat, lon):
-    """smooth synthetic topography (m) and land area fraction: a few hundred metres of relief over tens of km"""
-    z = 500 + 300 * np.sin(lat * 9.0) * np.cos(lon * 7.0) + 150 * np.sin(lat * 31.0 + 1.0) * np.sin(lon * 23.0) + 50 * np.cos(lat * 90.0) * np.cos(lon * 70.0)
-    laf = np.clip(0.5 + 0.6 * np.sin(lat * 5.0 + lon * 3.0), 0, 1)
-    return z, laf
-
-
-def oi_case(name, ny, nx, S, mp, seed, elev=False):
-    lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, S, seed, 0, ny)
-    rng = np.random.default_rng(seed + 7)
-    ge = gl = pe = pl = ()
-    v = w = 0
-    if elev == "noise":     # white-noise elevation / laf per cell: no two cells of a tile select the same observations
-        ge, gl = rng.uniform(0, 1000, (ny, nx)), rng.uniform(0, 1, (ny, nx))
-        pe, pl = rng.uniform(0, 1000, S), rng.uniform(0, 1, S)
-        v, w = 200, 0.5
-    elif elev:              # smooth terrain
-        ge, gl = terrain(np.deg2rad(lats) * 40, np.deg2rad(lons) * 40)
-        pe, pl = terrain(np.deg2rad(plat) * 40, np.deg2rad(plon) * 40)
-        pe = pe + rng.normal(0, 30, S)   # stations are not exactly on the model terrain
-        v, w = 200, 0.5
-    grid = gridpp.Grid(lats, lons, ge, gl)
-    points = gridpp.Points(plat, plon, pe, pl)
-    st = gridpp.BarnesStructure(10000, v, w)
-    d = [torch.from_numpy(a).cuda() for a in (bg, obs, ratios, pbg)]
-    t = timeit(lambda: gridpp.optimal_interpolation(grid, d[0], points, d[1], d[2], d[3], st, mp))
-    s = gridpp.oi_last_stats()
-    print(json.dumps({"case": name, "cells": ny * nx, "ms": t * 1e3, "kernel_ms": s["kernel_ms"], "Mcells/s": ny * nx / t / 1e6,
-                      "solves": s["solves"], "declined_tiles": s["fallback_tiles"], "items_left_to_k_oi": s["fallback_subtiles"], "GB/s_algorithmic": ny * nx * 24 / (s["kernel_ms"] * 1e-3) / 1e9}), flush=True)
+def oi_case(*a, **k):
+    print(json.dumps(_oi_case(*a, **k)), flush=True)
 
 
 def nb_case(ny, nx, E, hw):
-    g = torch.Generator(device="cuda").manual_seed(1003)
-    cube = torch.rand((ny, nx, E), generator=g, device="cuda") * 10
-    bytes_alg = ny * nx * (4 * E + 4)
-    t = timeit(lambda: gridpp.neighbourhood(cube, hw, gridpp.Mean))
-    print(json.dumps({"case": "C4 neighbourhood Mean %dx%dx%d hw=%d" % (ny, nx, E, hw), "ms": t * 1e3, "Mcells/s": ny * nx / t / 1e6,
-                      "GB/s_algorithmic": bytes_alg / t / 1e9, "frac_hbm_8TBs": bytes_alg / t / 8e12}), flush=True)
-    thr = torch.linspace(0, 10, 11, device="cuda")
-    for q in (0.5, 0.9):
-        t = timeit(lambda: gridpp.neighbourhood_quantile_fast(cube, q, hw, thr))
-        print(json.dumps({"case": "C4 quantile_fast q=%g T=11 %dx%dx%d hw=%d" % (q, ny, nx, E, hw), "ms": t * 1e3,
-                          "Mcells/s": ny * nx / t / 1e6, "GB/s_algorithmic": bytes_alg / t / 1e9, "frac_hbm_8TBs": bytes_alg / t / 8e12}), flush=True)
-    f2 = cube[:, :, 0].contiguous()
-    for stat, nm in ((gridpp.Mean, "Mean"), (gridpp.Max, "Max")):
-        t = timeit(lambda: gridpp.neighbourhood(f2, 7, stat))
-        print(json.dumps({"case": "neighbourhood 2-D %s %dx%d hw=7" % (nm, ny, nx), "ms": t * 1e3, "Mcells/s": ny * nx / t / 1e6,
-                          "GB/s_algorithmic": ny * nx * 8 / t / 1e9}), flush=True)
+    for r in nb_cases(ny, nx, E, hw, qs=(0.5, 0.9)):
+        print(json.dumps(r), flush=True)
 
 
-def ensi_case(ny, nx, E, S, mp):
-    rng = np.random.default_rng(1004)
-    lats, lons = np.meshgrid(np.linspace(0, 1, ny), np.linspace(0, 1, nx), indexing="ij")
-    base = torch.from_numpy((np.sin(6 * lats) * np.cos(4 * lons) * 3).astype(np.float32)).cuda()
-    g = torch.Generator(device="cuda").manual_seed(1004)
-    bg = base[:, :, None] + torch.randn((ny, nx, E), generator=g, device="cuda")
-    plat, plon = rng.random(S), rng.random(S)
-    pbg = torch.from_numpy(rng.normal(0, 1, (S, E)).astype(np.float32)).cuda()
-    obs = torch.from_numpy(rng.normal(0, 1, S).astype(np.float32)).cuda()
-    sig = torch.ones(S, device="cuda")
-    grid = gridpp.Grid(lats, lons)
-    points = gridpp.Points(plat, plon)
-    st = gridpp.BarnesStructure(10000)
-    t = timeit(lambda: gridpp.optimal_interpolation_ensi(grid, bg, points, obs, sig, pbg, st, mp), reps=2, warm=1)
-    print(json.dumps({"case": "C5 EnSI %dx%dx%d, %d obs, max_points=%d" % (ny, nx, E, S, mp), "ms": t * 1e3,
-                      "kernel_ms": gridpp.ensi_last_kernel_ms(), "Mcells/s": ny * nx / t / 1e6,
-                      "GB/s_algorithmic": ny * nx * (8 * E + 16) / t / 1e9}), flush=True)
+def ensi_case(*a, **k):
+    print(json.dumps(_ensi_case(*a, **k)), flush=True)
 
 
 def host_case():
