@@ -56,13 +56,15 @@ def cpu_baseline(ny, nx, S, seed, h, max_points, target_s=12.0):
         O.oi_baseline(g, b, op, obs, ratios, pbg, st, max_points, threads=thr)
         return rows.size * nx, time.perf_counter() - t0
 
-    # one thread: a few rows; sized from a one-row calibration
+    # one thread: a few rows, sized from a one-row calibration; all threads: sized from a short all-thread calibration (the
+    # scaling over the threads of a shared box is not known in advance)
     c0, t0 = run(1, 1)
     per_cell = t0 / c0
     n1 = max(1, min(ny, int(0.25 * target_s / per_cell / nx)))
     c1, t1 = run(n1, 1)
     one = c1 / t1
-    nall = max(threads // 8 + 1, min(ny, int(0.75 * target_s * one * threads * 0.7 / nx)))
+    cc, tc = run(max(2, threads // 8), threads)
+    nall = max(2, min(ny, int(0.6 * target_s * (cc / tc) / nx)))
     ca, ta = run(nall, threads)
     return {"value": ca / ta, "unit": "cells/s", "cores": threads, "kind": "port",
             "one_thread_value": one,

@@ -116,9 +116,18 @@ __device__ __forceinline__ void member_row_work(const float* row, const int E, c
                 }
             }
             count = cnt;
+            if(MODE == 2) {   // raw counts, one byte each (E <= 255): plane t = #(valid members <= thr[t]), plane T = #valid members
+                unsigned char* out8 = reinterpret_cast<unsigned char*>(out);
 #pragma unroll
-            for(int k = 0; k < TB; k++)
-                if(t0 + k < T) out[(long)(t0 + k) * C + cell] = count > 0 ? (float)sum[k] / (float)count : NAN;
+                for(int k = 0; k < TB; k++)
+                    if(t0 + k < T) out8[(long)(t0 + k) * C + cell] = (unsigned char)sum[k];
+                if(t0 + TB >= T) out8[(long)T * C + cell] = (unsigned char)count;
+            }
+            else {
+#pragma unroll
+                for(int k = 0; k < TB; k++)
+                    if(t0 + k < T) out[(long)(t0 + k) * C + cell] = count > 0 ? (float)sum[k] / (float)count : NAN;
+            }
         }
     }
 }
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (idx < nf4 ? idx : nf4 - 1)), (lds_void_t*)(dst + k * 64), 16, 0, 0);
             }
         };
-        if(MODE == 1) {
+        if(MODE != 0) {
             // threshold counting is VALU-bound (2*T*E compare/adds per cell): a single buffer doubles the resident waves
             for(long tile = blockIdx.x; tile < nfull; tile += gridDim.x) {
                 __syncthreads();                                    // previous tile fully consumed
@@ -493,6 +502,255 @@ __global__ void k_qf_interp(const float* __restrict__ ya, long C, int T, const f
 }
 
 // -------------------------------------------------------------------------------------------
+// quantile_fast, 3-D input, fused box pass (neighbourhood.cpp:453-522): the T threshold planes never exist as float / double
+// arrays in HBM.  The member pass leaves T + 1 BYTES per cell (#members <= thr[t], #valid members); one workgroup per
+// 64 x 32 tile of output cells then, plane by plane, rebuilds temp = count / valid (float, :465-470) for the tile and its
+// halo in LDS, forms the box sums separably with sliding windows -- rows into a double tile, columns into registers -- and
+// keeps the clamped means of its cells (yarray, :494-506) in registers until the interpolation (util.cpp:377-414) writes the
+// one output value.  The window sums are EXACT: every temp is a float32 in [0, 1] with at least 2^-31 resolution and a
+// window holds at most (2 hw + 1)^2 of them, so all partial sums fit a double without rounding, in any order -- the
+// reference's summed-area table differs from them only by its own double rounding.
+// HBM traffic: (T + 1) bytes per cell written, about twice that read (halo, mostly L2 hits) instead of 28 T bytes per cell.
+// -------------------------------------------------------------------------------------------
+#define QF_TX 64      // tile width (cells)
+#define QF_TY 32      // tile height
+#define QF_SEGX 16    // outputs per thread in the row pass
+#define QF_SEGY 8     // outputs per thread in the column pass
+#define QF_TMAX 16    // most thresholds held in registers per cell (template TM: 8, 12 or 16)
+#define QF_RP (QF_TX + 1)   // pitch (doubles) of the row-sum tile: consecutive rows fall into different banks
+#define QF_RMAX 64    // most rows of a tile with its halo (halfwidth <= 16): each thread keeps its 32 bytes of a plane in 8 registers
+template <int TM>
+__global__ __launch_bounds__(256, 2) void k_qf_fused(const unsigned char* __restrict__ cnt8, int Y, int X, int reps, int hw, int T,
+                                                  const float* __restrict__ thr, const float* __restrict__ q, int qfield, float* __restrict__ out, int dbg) {
+    extern __shared__ double qf_lds[];
+    const long C = (long)Y * X;
+    const int rows = QF_TY + 2 * hw, cols = QF_TX + 2 * hw;
+    const int pitch = cols | 1;                                     // odd pitch: a column of the float tile hits 64 different banks
+    double* const rsum = qf_lds;                                    // [rows][QF_RP] row sums
+    float* const tmp = reinterpret_cast<float*>(rsum + rows * QF_RP);   // [rows][pitch] temp = count / valid (0 outside the domain / no valid member)
+    unsigned char* const val = reinterpret_cast<unsigned char*>(tmp + rows * pitch);   // [rows][cols] #valid members (0 outside the domain)
+    __shared__ int s_invalid;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * QF_TX, y0 = blockIdx.y * QF_TY;
+    if(tid == 0) s_invalid = 0;
+    __syncthreads();
+    // thread -> (four neighbouring columns of the tile + halo, every eighth row): one (unaligned) dword load fetches four cells
+    const int lc = (tid & 31) * 4, lrg = tid >> 5;
+    const int lx = x0 - hw + lc;
+    const bool quad_in = lx >= 0 && lx + 3 < X && lc + 3 < cols;    // the whole quad inside the domain and the tile
+    auto load4 = [&](const unsigned char* plane, const int y) -> unsigned {   // bytes of columns lx .. lx + 3 of row y (0 outside)
+        if(y < 0 || y >= Y || (dbg & 1)) return 0u;
+        const unsigned char* p = plane + (long)y * X + lx;
+        if(quad_in) return *reinterpret_cast<const unsigned*>(p);
+        unsigned w = 0;
+#pragma unroll
+        for(int b4 = 0; b4 < 4; b4++) if(lc + b4 < cols && lx + b4 >= 0 && lx + b4 < X) w |= (unsigned)p[b4] << (8 * b4);
+        return w;
+    };
+    // #valid members of the tile + halo
+    const unsigned char* vplane = cnt8 + (long)T * C;
+    int inv = 0;
+    unsigned vb[QF_RMAX / 8], pre[QF_RMAX / 8];   // this thread's quads of the #valid plane and of the current / next threshold plane
+#pragma unroll
+    for(int ii = 0; ii < QF_RMAX / 8; ii++) {
+        const int r = 8 * ii + lrg, y = y0 - hw + r;
+        unsigned w = 0;
+        if(r < rows) {
+            w = load4(vplane, y);
+#pragma unroll
+            for(int b4 = 0; b4 < 4; b4++) {
+                const int x = lx + b4;
+                if(lc + b4 < cols) {
+                    const unsigned v = (w >> (8 * b4)) & 0xffu;
+                    if(v == 0 && y >= 0 && y < Y && x >= 0 && x < X) inv = 1;
+                    val[r * cols + lc + b4] = (unsigned char)v;
+                }
+            }
+        }
+        vb[ii] = w;
+    }
+    if(inv) s_invalid = 1;
+    __syncthreads();
+    const bool counted = s_invalid != 0;   // some cell of the tile or its halo has no valid member: window counts are summed, not computed
+    // this thread's cells in the column pass: column cx, rows [cy0, cy0 + QF_SEGY)
+    const int cx = tid & (QF_TX - 1), cy0 = (tid / QF_TX) * QF_SEGY;
+    const int gx = x0 + cx;
+    float ya[QF_SEGY][TM];
+    int wc[QF_SEGY];
+    double sums[QF_SEGY];
+    // box sums of the float tile `tmp` for this thread's QF_SEGY cells -> sums[]
+    auto box_pass = [&]() {
+        // rows: thread (row r, segment s): QF_SEGX outputs with a sliding window over tmp
+        for(int it = tid; it < rows * (QF_TX / QF_SEGX) && !(dbg & 2); it += 256) {
+            const int r = it % rows, sg = it / rows;
+            const float* tr = tmp + r * pitch + sg * QF_SEGX;       // window of output j: tr[j .. j + 2 hw]
+            // (the sums are exact, so any order will do: four accumulators, reads issued eight at a time)
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = 0;
+            for(; k + 8 <= 2 * hw + 1; k += 8) {
+                const float a0 = tr[k], a1 = tr[k + 1], a2 = tr[k + 2], a3 = tr[k + 3], a4 = tr[k + 4], a5 = tr[k + 5], a6 = tr[k + 6], a7 = tr[k + 7];
+                s0 += (double)a0; s1 += (double)a1; s2 += (double)a2; s3 += (double)a3;
+                s0 += (double)a4; s1 += (double)a5; s2 += (double)a6; s3 += (double)a7;
+            }
+            for(; k <= 2 * hw; k++) s0 += (double)tr[k];
+            double sm = (s0 + s1) + (s2 + s3);
+            rsum[r * QF_RP + sg * QF_SEGX] = sm;
+            float in_[QF_SEGX - 1], out_[QF_SEGX - 1];
+#pragma unroll
+            for(int j = 1; j < QF_SEGX; j++) { in_[j - 1] = tr[j + 2 * hw]; out_[j - 1] = tr[j - 1]; }
+#pragma unroll
+            for(int j = 1; j < QF_SEGX; j++) {
+                sm += (double)in_[j - 1];
+                sm -= (double)out_[j - 1];
+                rsum[r * QF_RP + sg * QF_SEGX + j] = sm;
+            }
+        }
+        __syncthreads();
+        // columns: thread (column cx, segment): QF_SEGY outputs, window of output row j: rsum rows [cy0 + j, cy0 + j + 2 hw]
+        const double* cr = rsum + cy0 * QF_RP + cx;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+        int k = 0;
+        for(; k + 8 <= 2 * hw + 1 && !(dbg & 4); k += 8) {
+            const double a0 = cr[k * QF_RP], a1 = cr[(k + 1) * QF_RP], a2 = cr[(k + 2) * QF_RP], a3 = cr[(k + 3) * QF_RP];
+            const double a4 = cr[(k + 4) * QF_RP], a5 = cr[(k + 5) * QF_RP], a6 = cr[(k + 6) * QF_RP], a7 = cr[(k + 7) * QF_RP];
+            c0 += a0; c1 += a1; c2 += a2; c3 += a3; c0 += a4; c1 += a5; c2 += a6; c3 += a7;
+        }
+        for(; k <= 2 * hw; k++) c0 += cr[k * QF_RP];
+        double sm = (c0 + c1) + (c2 + c3);
+        sums[0] = sm;
+        double cin[QF_SEGY - 1], cout[QF_SEGY - 1];
+#pragma unroll
+        for(int j = 1; j < QF_SEGY; j++) { cin[j - 1] = cr[(j + 2 * hw) * QF_RP]; cout[j - 1] = cr[(j - 1) * QF_RP]; }
+#pragma unroll
+        for(int j = 1; j < QF_SEGY; j++) {
+            sm += cin[j - 1];
+            sm -= cout[j - 1];
+            sums[j] = sm;
+        }
+        __syncthreads();
+    };
+    // window counts
+    if(counted) {
+        for(int k = tid; k < rows * cols; k += 256) { const int r = k / cols, c = k - r * cols; tmp[r * pitch + c] = val[k] ? 1.0f : 0.0f; }
+        __syncthreads();
+        box_pass();
+#pragma unroll
+        for(int j = 0; j < QF_SEGY; j++) wc[j] = (int)sums[j];
+    }
+    else {
+        const int nx_w = min(gx + hw, X - 1) - max(gx - hw, 0) + 1;
+#pragma unroll
+        for(int j = 0; j < QF_SEGY; j++) { const int gy = y0 + cy0 + j; wc[j] = nx_w * (min(gy + hw, Y - 1) - max(gy - hw, 0) + 1); }
+    }
+#pragma unroll
+    for(int j = 0; j < QF_SEGY; j++)
+#pragma unroll
+        for(int tt = 0; tt < TM; tt++) ya[j][tt] = 0.0f;
+    // the next plane is fetched while the current one is summed
+    auto fetch = [&](const unsigned char* plane) {
+#pragma unroll
+        for(int ii = 0; ii < QF_RMAX / 8; ii++) { const int r = 8 * ii + lrg; pre[ii] = (r < rows) ? load4(plane, y0 - hw + r) : 0u; }
+    };
+    fetch(cnt8);
+    float* const tab = reinterpret_cast<float*>(val + rows * cols + 16 - ((rows * cols) & 3));   // k / reps for k = 0 .. 255 (the usual case: every member valid)
+    for(int k = tid; k < 256; k += 256) tab[k] = (float)k / (float)reps;
+    __syncthreads();
+#pragma unroll 1
+    for(int t = 0; t < T; t++) {
+#pragma unroll
+        for(int ii = 0; ii < QF_RMAX / 8; ii++) {
+            const int r = 8 * ii + lrg;
+            if(r < rows) {
+#pragma unroll
+                for(int b4 = 0; b4 < 4; b4++) {
+                    if(lc + b4 < cols) {
+                        const int v = (int)((vb[ii] >> (8 * b4)) & 0xffu);
+                        const int cb = (int)((pre[ii] >> (8 * b4)) & 0xffu);
+                        // :465-470 (no valid member: NaN there, skipped by the mean)
+                        tmp[r * pitch + lc + b4] = (v == reps) ? tab[cb] : (v ? (float)cb / (float)v : 0.0f);
+                    }
+                }
+            }
+        }
+        if(t + 1 < T) fetch(cnt8 + (long)(t + 1) * C);
+        __syncthreads();
+        box_pass();
+        // mean (:473), E-fold float sum / E (:494-499: `sum += value` E times, two cells per packed add), clamp (:500-506)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f o2[QF_SEGY / 2], acc[QF_SEGY / 2];
+#pragma unroll
+        for(int jj = 0; jj < QF_SEGY / 2; jj++) {
+            o2[jj].x = wc[2 * jj] > 0 ? (float)(sums[2 * jj] / (double)wc[2 * jj]) : NAN;
+            o2[jj].y = wc[2 * jj + 1] > 0 ? (float)(sums[2 * jj + 1] / (double)wc[2 * jj + 1]) : NAN;
+            acc[jj] = (v2f){0.0f, 0.0f};
+        }
+        if(reps > 1) {   // ONE loop over the members with all the cells' chains in it (a loop per cell would be a bare dependency chain)
+            const int nrep = (dbg & 8) ? 1 : reps;
+            for(int e = 0; e < nrep; e++) {
+#pragma unroll
+                for(int jj = 0; jj < QF_SEGY / 2; jj++) acc[jj] += o2[jj];
+            }
+        }
+#pragma unroll
+        for(int jj = 0; jj < QF_SEGY / 2; jj++) {
+            v2f yv = o2[jj];
+            if(reps > 1) { yv.x = acc[jj].x / (float)reps; yv.y = acc[jj].y / (float)reps; }
+            const float oa = !nv(o2[jj].x) ? NAN : (yv.x > 1 ? 1.0f : (yv.x < 0 ? 0.0f : yv.x));
+            const float ob = !nv(o2[jj].y) ? NAN : (yv.y > 1 ? 1.0f : (yv.y < 0 ? 0.0f : yv.y));
+#pragma unroll
+            for(int tt = 0; tt < TM; tt++) {   // (selects: the array stays in registers)
+                ya[2 * jj][tt] = (tt == t) ? oa : ya[2 * jj][tt];
+                ya[2 * jj + 1][tt] = (tt == t) ? ob : ya[2 * jj + 1][tt];
+            }
+        }
+    }
+    // interpolation per cell (the code of k_qf_interp on the register copy of yarray)
+#pragma unroll
+    for(int j = 0; j < QF_SEGY; j++) {
+        const int gy = y0 + cy0 + j;
+        if(gx >= X || gy >= Y) continue;
+        const long c = (long)gy * X + gx;
+        const float x = qfield ? q[c] : q[0];
+        // (opaque copies: `select(load, load)` must not become `load(select(address))`, which would put the array on the stack)
+        float yr[TM];
+#pragma unroll
+        for(int tt = 0; tt < TM; tt++) { float v = ya[j][tt]; asm("" : "+v"(v)); yr[tt] = v; }
+        auto yat = [&](int idx) { float v = yr[0];
+#pragma unroll
+            for(int tt = 1; tt < TM; tt++) v = (tt == idx) ? yr[tt] : v;
+            return v; };
+        bool missing = false;
+#pragma unroll
+        for(int tt = 0; tt < TM; tt++) if(tt < T && !nv(yr[tt])) missing = true;
+        float o = NAN;
+        if(!missing) {
+            const float y0a = yr[0], yLa = yat(T - 1);
+            if(x == 1 && y0a == 1) o = thr[0];
+            else if(x == 0 && yLa == 0) o = thr[T - 1];
+            else if(!nv(x)) o = NAN;
+            else if(x > yLa) o = thr[T - 1];
+            else if(x < y0a) o = thr[0];
+            else {
+                int i0 = -1, i1 = -1;
+                for(int i = 0; i < T; i++) { float cv = yat(i); if(cv < x) i0 = i; else if(cv == x) { i0 = i; break; } else break; }
+                for(int i = T - 1; i >= 0; i--) { float cv = yat(i); if(cv > x) i1 = i; else if(cv == x) { i1 = i; break; } else break; }
+                if(i0 < 0) i0 = 0;
+                if(i1 < 0) i1 = T - 1;
+                const float xa = yat(i0), xb = yat(i1), ta = thr[i0], tb = thr[i1];
+                if(xa == xb) {
+                    if(i0 == 0 && i1 == T - 1) o = (ta + tb) / 2;
+                    else if(i0 == 0) o = tb;
+                    else if(i1 == T - 1) o = ta;
+                    else o = (ta + tb) / 2;
+                }
+                else o = ta + (tb - ta) * (x - xa) / (xb - xa);
+            }
+        }
+        out[c] = o;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------
 namespace {
@@ -508,7 +766,7 @@ void member_pass_launch(const float* d_in, long C, int E, int statistic, const f
     const long tiles = (C + 63) / 64;
     const int nchunk = (16 * E + 63) / 64;
     const bool dma = E <= MEMBER_EC && (reinterpret_cast<size_t>(d_in) & 15) == 0;
-    const size_t lds = dma ? (size_t)(MODE == 1 ? 1 : 2) * nchunk * 1024 : 16;   // (double) buffer of whole 1 KiB chunks
+    const size_t lds = dma ? (size_t)(MODE != 0 ? 1 : 2) * nchunk * 1024 : 16;   // (double) buffer of whole 1 KiB chunks
     static bool attr = false;
     if(!attr) { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((16 * MEMBER_EC + 63) / 64) * 1024)); attr = true; }
     const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds, 1)));
@@ -518,6 +776,7 @@ void member_pass_launch(const float* d_in, long C, int E, int statistic, const f
 }
 void member_pass(const float* d_in, long C, int E, int mode, int statistic, const float* d_thr, int T, float* d_out) {
     if(mode == 0) member_pass_launch<0>(d_in, C, E, statistic, d_thr, T, d_out);
+    else if(mode == 2) member_pass_launch<2>(d_in, C, E, statistic, d_thr, T, d_out);
     else member_pass_launch<1>(d_in, C, E, statistic, d_thr, T, d_out);
 }
 // Mean / Sum / Count of `nplanes` [Y][X] planes
@@ -658,6 +917,32 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
     }
     qf.bind(quantile, nq, mem & ~GPP_HOST_F64);      // GPP_HOST_F64 applies to `input` only: quantile / thresholds stay float32
     th.bind(thresholds, nt, mem & ~GPP_HOST_F64);
+    {   // 3-D input with at most 255 members and 16 thresholds: byte counts + the fused box pass (k_qf_fused)
+        const int rows = QF_TY + 2 * halfwidth, cols = QF_TX + 2 * halfwidth;
+        const size_t lds = (size_t)rows * QF_RP * sizeof(double) + (size_t)rows * (cols | 1) * sizeof(float) + (size_t)rows * cols + 16 + 256 * sizeof(float);
+        if(is3d && ne <= 255 && nt <= QF_TMAX && lds <= 100 * 1024 && rows <= QF_RMAX && cols <= 128 && !getenv("GPP_QF_NO_FUSED")) {
+            unsigned char* cnt8 = reinterpret_cast<unsigned char*>(g_nb.planes.get(((size_t)(nt + 1) * C + 3) / 4));
+            member_pass(in.d, C, ne, 2, 0, th.d, nt, reinterpret_cast<float*>(cnt8));
+            static size_t lds_set = 0;
+            if(lds > lds_set) {
+                GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+                GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+                GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+                lds_set = 100 * 1024;
+            }
+            const dim3 grid((nx + QF_TX - 1) / QF_TX, (ny + QF_TY - 1) / QF_TY);
+            const unsigned char* c8 = cnt8;
+            const int qfl = nq == 1 ? 0 : 1;
+            const int dbg = getenv("GPP_QF_DEBUG") ? atoi(getenv("GPP_QF_DEBUG")) : 0;   // timing experiments only
+            if(nt <= 8) hipLaunchKernelGGL(k_qf_fused<8>, grid, dim3(256), lds, stream(), c8, ny, nx, ne, halfwidth, nt, th.d, qf.d, qfl, o.d, dbg);
+            else if(nt <= 12) hipLaunchKernelGGL(k_qf_fused<12>, grid, dim3(256), lds, stream(), c8, ny, nx, ne, halfwidth, nt, th.d, qf.d, qfl, o.d, dbg);
+            else hipLaunchKernelGGL(k_qf_fused<16>, grid, dim3(256), lds, stream(), c8, ny, nx, ne, halfwidth, nt, th.d, qf.d, qfl, o.d, dbg);
+            GPP_HIP(hipGetLastError());
+            o.finish();
+            GPP_HIP(hipStreamSynchronize(stream()));
+            return GPP_OK;
+        }
+    }
     float* planes = g_nb.planes.get((size_t)nt * C);
     float* stats = g_nb.tmp2.get((size_t)nt * C);
     member_pass(in.d, C, ne, 1, 0, th.d, nt, planes);                 // fractions per threshold (:453-472)
