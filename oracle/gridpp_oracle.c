@@ -1589,3 +1589,214 @@ int orc_oi_ensi(int nY, int nE,
     return orc_oi_ensi_range(0, nY, nY, nE, gx, gy, gz, gelev, glaf, background, nS, ox, oy, oz, oelev, olaf,
                              pobs, psigmas, pbackground, h, v, w, min_rho, max_points, allow_extrapolation, out);
 }
+
+/* ------------------------------------------------------------------------ */
+/* optimal_interpolation_ensi_multi_{ebe, ebesc, utem} (Points overloads):    */
+/* src/api/oi_ensi_multi.cpp:329-628, :630-860, :862-1311.                     */
+/* variant 1 = ebe, 2 = ebesc, 3 = utem.  background / background_corr         */
+/* [nY][nE]; pbackground / pbackground_corr [nS][nE]; pobs [nS][nE] (ebe,      */
+/* ebesc) or [nS] (utem); bratios [nY]; pratios [nS]; out [nY][nE].            */
+/* The reference indexes `lInnov(i, ei)` with the ORIGINAL member index into a */
+/* matrix with nValidEns columns (:563-567, :770-773): with an invalid member  */
+/* in front of a valid one that is out of bounds (Armadillo throws) ->         */
+/* ORC_ESINGULAR here (RuntimeError in the mirrors).                           */
+/* ------------------------------------------------------------------------ */
+#define ORC_MIN_STD 0.0013f
+int orc_oi_ensi_multi(int variant, int nY, int nE,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* bratios, const float* background, const float* background_corr,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* pratios, const float* pbackground, const float* pbackground_corr,
+                float h, float v, float w, float min_rho,
+                int max_points, int allow_extrapolation, float* out) {
+    if(max_points < 0) return ORC_EINVAL;
+    for(size_t i = 0; i < (size_t)nY * nE; i++) out[i] = background[i];
+    if(nS == 0) return ORC_OK;
+    const int corr = variant != 2;
+    int* validEns = (int*)malloc(sizeof(int) * (nE + 1));
+    int nV = 0;
+    for(int e = 0; e < nE; e++) {                                         /* :395-418 / :691-712 / :930-950 */
+        int bad = 0;
+        for(int y = 0; y < nY && !bad; y++) {
+            if(!orc_valid(background[(size_t)y * nE + e])) bad = 1;
+            if(corr && !orc_valid(background_corr[(size_t)y * nE + e])) bad = 1;
+        }
+        for(int i = 0; i < nS && !bad; i++) {
+            if(!orc_valid(pbackground[(size_t)i * nE + e])) bad = 1;
+            if(corr && !orc_valid(pbackground_corr[(size_t)i * nE + e])) bad = 1;
+        }
+        if(!bad) validEns[nV++] = e;
+    }
+    if(nV == 0) { free(validEns); return ORC_OK; }
+    int oob = (variant != 3) && validEns[nV - 1] != nV - 1;
+    /* per-observation ensemble quantities */
+    float* gZ = (float*)calloc((size_t)nS * nV, sizeof(float));          /* ebe: gZ_R (:421-444); utem: gY_corr (:985-1002) */
+    float* gY = (float*)calloc((size_t)nS * nV, sizeof(float));          /* utem: gY (:976-984) */
+    float* gYhat = (float*)calloc(nS, sizeof(float));
+    float* row = (float*)malloc(sizeof(float) * nV);
+    float* obs0 = (float*)malloc(sizeof(float) * nS);                    /* the value whose validity selects an observation */
+    const float const_fact = 1 / sqrt(nV - 1);                           /* :968 (float) */
+    for(int i = 0; i < nS; i++) {
+        obs0[i] = variant == 3 ? pobs[i] : pobs[(size_t)i * nE];
+        if(variant == 3) {
+            for(int e = 0; e < nV; e++) row[e] = pbackground[(size_t)i * nE + validEns[e]];
+            float mean = orc_calc_statistic(row, nV, ST_MEAN);
+            for(int e = 0; e < nV; e++) gY[(size_t)i * nV + e] = orc_valid(mean) ? row[e] - mean : 0;
+            gYhat[i] = mean;
+        }
+        if(corr) {
+            for(int e = 0; e < nV; e++) row[e] = pbackground_corr[(size_t)i * nE + validEns[e]];
+            float mean = orc_calc_statistic(row, nV, ST_MEAN), std = orc_calc_statistic(row, nV, ST_STD);
+            if(orc_valid(mean) && orc_valid(std) && std > ORC_MIN_STD) {
+                for(int e = 0; e < nV; e++) {
+                    if(variant == 1) gZ[(size_t)i * nV + e] = 1 / sqrt(nV - 1) * (row[e] - mean) / std;     /* double expression -> float */
+                    else gZ[(size_t)i * nV + e] = const_fact * (row[e] - mean) / std;                         /* float expression */
+                }
+            }
+        }
+    }
+    float loc = orc_barnes_localization_distance(h, min_rho);
+    orc_pair* work = (orc_pair*)malloc(sizeof(orc_pair) * nS);
+    int* sel = (int*)malloc(sizeof(int) * nS);
+    float* srho = (float*)malloc(sizeof(float) * nS);
+    int rc = ORC_OK;
+    for(int y = 0; y < nY && rc == ORC_OK; y++) {
+        float ratio = bratios[y];
+        int lS = orc_select(gx[y], gy[y], gz[y], gelev[y], glaf[y], nS, ox, oy, oz, oelev, olaf,
+                            obs0, NULL, h, v, w, loc, max_points, work, sel, srho);
+        if(lS == 0) continue;
+        if(oob) { rc = ORC_ESINGULAR; break; }
+        if(variant != 3) {
+            double* A = (double*)malloc(sizeof(double) * lS * lS);
+            double* rl = (double*)malloc(sizeof(double) * lS);
+            double* K = (double*)malloc(sizeof(double) * lS);
+            double* xL = (double*)calloc(nV, sizeof(double));
+            if(variant == 1) {                                                 /* :531-541 */
+                for(int e = 0; e < nV; e++) row[e] = background_corr[(size_t)y * nE + validEns[e]];
+                float mean = orc_calc_statistic(row, nV, ST_MEAN), std = orc_calc_statistic(row, nV, ST_STD);
+                if(orc_valid(mean) && orc_valid(std) && std > ORC_MIN_STD)
+                    for(int e = 0; e < nV; e++) xL[e] = 1 / sqrt(nV - 1) * (row[e] - mean) / std;
+            }
+            for(int i = 0; i < lS; i++) {
+                int si = sel[i];
+                double rz = 1.0;
+                if(variant == 1) { rz = 0; for(int e = 0; e < nV; e++) rz += xL[e] * (double)gZ[(size_t)si * nV + e]; }
+                rl[i] = (double)srho[i] * rz;                                  /* :581 / lCorr1D */
+                for(int j = 0; j < lS; j++) {
+                    int sj = sel[j];
+                    float c = orc_barnes_corr(ox[si], oy[si], oz[si], oelev[si], olaf[si], ox[sj], oy[sj], oz[sj], oelev[sj], olaf[sj], h, v, w, loc);
+                    double zz = 1.0;
+                    if(variant == 1) { zz = 0; for(int e = 0; e < nV; e++) zz += (double)gZ[(size_t)si * nV + e] * (double)gZ[(size_t)sj * nV + e]; }
+                    A[i * lS + j] = (double)c * zz;                            /* :584 */
+                }
+                A[i * lS + i] += (double)pratios[si];                          /* + lR_dd */
+            }
+            if(orc_inv(A, lS) != ORC_OK) { rc = ORC_ESINGULAR; free(A); free(rl); free(K); free(xL); break; }
+            for(int j = 0; j < lS; j++) { double s = 0; for(int i = 0; i < lS; i++) s += rl[i] * A[i * lS + j]; K[j] = s; }   /* :586 */
+            for(int e = 0; e < nV; e++) {
+                double s = 0; float maxInc = 0, minInc = 0;
+                for(int i = 0; i < lS; i++) {
+                    float inn = pobs[(size_t)sel[i] * nE + validEns[e]] - pbackground[(size_t)sel[i] * nE + validEns[e]];   /* :565 */
+                    s += K[i] * (double)inn;
+                    if(i == 0 || inn > maxInc) maxInc = inn;
+                    if(i == 0 || inn < minInc) minInc = inn;
+                }
+                double dx = ratio * s;                                         /* :588 */
+                if(!allow_extrapolation) {                                     /* :593-615 */
+                    float increment = dx;
+                    if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                    else if(maxInc < 0 && increment > 0) increment = 0;
+                    else if(minInc < 0 && increment < minInc) increment = minInc;
+                    else if(minInc > 0 && increment < 0) increment = 0;
+                    dx = increment;
+                }
+                out[(size_t)y * nE + validEns[e]] = background[(size_t)y * nE + validEns[e]] + dx;   /* :620 */
+            }
+            free(A); free(rl); free(K); free(xL);
+        }
+        else {
+            double* lY = (double*)malloc(sizeof(double) * lS * nV);           /* column-major lS x nV */
+            double* lYc = (double*)malloc(sizeof(double) * lS * nV);
+            double* Rinv = (double*)malloc(sizeof(double) * lS);
+            double* dvec = (double*)malloc(sizeof(double) * lS);
+            double* Pinv = (double*)malloc(sizeof(double) * nV * nV);
+            double* P = (double*)malloc(sizeof(double) * nV * nV);
+            double* Aw = (double*)malloc(sizeof(double) * nV * nV);
+            double* eval = (double*)malloc(sizeof(double) * nV);
+            double* evec = (double*)malloc(sizeof(double) * nV * nV);
+            double* W = (double*)malloc(sizeof(double) * nV * nV);
+            double* wv = (double*)malloc(sizeof(double) * nV);
+            double* X = (double*)malloc(sizeof(double) * nV);
+            double* Xc = (double*)malloc(sizeof(double) * nV);
+            for(int i = 0; i < lS; i++) {
+                int idx = sel[i];
+                for(int e = 0; e < nV; e++) { lY[(size_t)e * lS + i] = (double)gY[(size_t)idx * nV + e]; lYc[(size_t)e * lS + i] = (double)gZ[(size_t)idx * nV + e]; }
+                Rinv[i] = (double)srho[i] / (double)pratios[idx];             /* :1078 */
+                dvec[i] = (double)pobs[idx] - (double)gYhat[idx];
+            }
+            for(int a = 0; a < nV; a++) for(int b = 0; b < nV; b++) {          /* :1082-1085 */
+                double s = 0;
+                for(int i = 0; i < lS; i++) s += lYc[(size_t)a * lS + i] * Rinv[i] * lYc[(size_t)b * lS + i];
+                Pinv[a * nV + b] = s + (a == b ? 1.0 : 0.0);
+            }
+            memcpy(P, Pinv, sizeof(double) * nV * nV);
+            if(orc_inv(P, nV) == ORC_OK) {
+                for(int i = 0; i < nV * nV; i++) Aw[i] = (nV - 1) * P[i];      /* :1098 */
+                orc_eig_sym(Aw, nV, eval, evec);
+                for(int a = 0; a < nV; a++) for(int b = 0; b < nV; b++) {
+                    double s = 0;
+                    for(int k = 0; k < nV; k++) s += evec[a * nV + k] * sqrt(eval[k]) * evec[b * nV + k];
+                    W[a * nV + b] = s;
+                }
+                for(int a = 0; a < nV; a++) {                                   /* :1131-1139 */
+                    double s = 0;
+                    for(int i = 0; i < lS; i++) {
+                        double pc = 0;
+                        for(int b = 0; b < nV; b++) pc += P[a * nV + b] * lYc[(size_t)b * lS + i] * Rinv[i];
+                        s += pc * dvec[i];
+                    }
+                    wv[a] = s;
+                }
+                float* vals = row;                                              /* :1141-1179 */
+                float* valc = (float*)malloc(sizeof(float) * nV);
+                float total = 0, totalc = 0;
+                for(int e = 0; e < nV; e++) {
+                    vals[e] = background[(size_t)y * nE + validEns[e]]; valc[e] = background_corr[(size_t)y * nE + validEns[e]];
+                    total += vals[e]; totalc += valc[e];
+                }
+                float ensMean = total / nV, ensStd = orc_calc_statistic(vals, nV, ST_STD);
+                float ensMeanC = totalc / nV, ensStdC = orc_calc_statistic(valc, nV, ST_STD);
+                for(int e = 0; e < nV; e++) {
+                    X[e] = (double)vals[e] - ensMean;
+                    float value_corr = (float)(double)valc[e];                  /* X_corr(e) holds the float in a double */
+                    Xc[e] = (ensStdC <= ORC_MIN_STD) ? 0 : const_fact * (value_corr - ensMeanC) / ensStdC;
+                }
+                for(int a = 0; a < nV; a++) for(int b = 0; b < nV; b++) W[a * nV + b] = ensStd * W[a * nV + b] + ratio * wv[a];   /* :1181-1185 */
+                for(int e = 0; e < nV; e++) {
+                    float tot = 0;
+                    for(int k = 0; k < nV; k++) tot += Xc[k] * W[k * nV + e];   /* :1229-1233 */
+                    float currIncrement = tot;
+                    if(!allow_extrapolation) {
+                        double lYe = lY[e];                                     /* LINEAR index, :1240 */
+                        float maxInc = 0, minInc = 0;
+                        for(int i = 0; i < lS; i++) {
+                            float dv = (float)((double)pobs[sel[i]] - (lYe + (double)gYhat[sel[i]]));
+                            if(i == 0 || dv > maxInc) maxInc = dv;
+                            if(i == 0 || dv < minInc) minInc = dv;
+                        }
+                        float memberIncrement = currIncrement - X[e];
+                        if(maxInc > 0 && memberIncrement > maxInc) currIncrement = maxInc + X[e];
+                        else if(maxInc < 0 && memberIncrement > 0) currIncrement = 0 + X[e];
+                        else if(minInc < 0 && memberIncrement < minInc) currIncrement = minInc + X[e];
+                        else if(minInc > 0 && memberIncrement < 0) currIncrement = 0 + X[e];
+                    }
+                    out[(size_t)y * nE + validEns[e]] = ensMean + currIncrement;
+                }
+                free(valc);
+            }
+            free(lY); free(lYc); free(Rinv); free(dvec); free(Pinv); free(P); free(Aw); free(eval); free(evec); free(W); free(wv); free(X); free(Xc);
+        }
+    }
+    free(validEns); free(gZ); free(gY); free(gYhat); free(row); free(obs0); free(work); free(sel); free(srho);
+    return rc;
+}

@@ -248,6 +248,28 @@ def oi_ensi(g, background, p, obs, sigmas, pbackground, st, max_points, allow_ex
     return out[y0:y1]
 
 
+def oi_ensi_multi(variant, g, bratios, background, background_corr, p, pobs, pratios, pbackground, pbackground_corr, st, max_points,
+                  allow_extrapolation=True):
+    """optimal_interpolation_ensi_multi_{ebe, ebesc, utem}: variant 'ebe' | 'ebesc' | 'utem' (background_corr / pbackground_corr
+    are ignored by ebesc)."""
+    vid = {"ebe": 1, "ebesc": 2, "utem": 3}[variant]
+    background = _f(background)
+    nY, nE = background.shape
+    bc = _f(background_corr).reshape(nY, nE) if background_corr is not None else background
+    pb = _f(pbackground).reshape(p.n, nE)
+    pbc = _f(pbackground_corr).reshape(p.n, nE) if pbackground_corr is not None else pb
+    pobs = _f(pobs).reshape(p.n) if vid == 3 else _f(pobs).reshape(p.n, nE)
+    bratios, pratios = _f(bratios).ravel(), _f(pratios).ravel()
+    out = np.empty((nY, nE), np.float32)
+    rc = lib().orc_oi_ensi_multi(C.c_int(vid), C.c_int(nY), C.c_int(nE), g.x.ctypes, g.y.ctypes, g.z.ctypes, g.elevs.ctypes, g.lafs.ctypes,
+                                 bratios.ctypes, background.ctypes, bc.ctypes, C.c_int(p.n), p.x.ctypes, p.y.ctypes, p.z.ctypes,
+                                 p.elevs.ctypes, p.lafs.ctypes, pobs.ctypes, pratios.ctypes, pb.ctypes, pbc.ctypes,
+                                 C.c_float(st.h), C.c_float(st.v), C.c_float(st.w), C.c_float(st.min_rho),
+                                 C.c_int(max_points), C.c_int(1 if allow_extrapolation else 0), out.ctypes)
+    _check(rc)
+    return out
+
+
 def get_neighbours(p, qlat, qlon, radius, include_match=True):
     qx, qy, qz = convert_coordinates([qlat], [qlon], p.ctype)
     out = np.empty(max(p.n, 1), np.int32)

@@ -27,3 +27,19 @@ def test_oracle_ensi_golden(name):
     p = O.Pts(c["plat"], c["plon"], c.get("pelev", nan_p), c.get("plaf", nan_p))
     out = O.oi_ensi(g, c["background"], p, c["pobs"], c["psigmas"], c["pbackground"], O.Barnes(h, v, w), int(mp), bool(allow))
     ensi_golden.check(out, c)
+
+
+# ---- ensi_multi: no test or known answer in the reference; pinned by an independent LAPACK restatement
+from tests import ensi_multi_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ensi_multi_golden.NAMES)
+def test_oracle_ensi_multi_golden(name):
+    from oracle import oracle as O
+    c = ensi_multi_golden.CASES[name]
+    h, v, w, mp, allow = c["params"]
+    g = O.Pts(c["blat"], c["blon"], c["belev"], c["blaf"])
+    p = O.Pts(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    out = O.oi_ensi_multi(str(c["variant"]), g, c["bratios"], c["background"], c["background_corr"], p, c["pobs"], c["pratios"],
+                          c["pbackground"], c["pbackground_corr"], O.Barnes(h, v, w), int(mp), bool(allow))
+    ensi_multi_golden.check(out, c)
