@@ -1210,6 +1210,80 @@ def optimal_interpolation_ensi(bgrid, background, points, pobs, psigmas, pbackgr
     return out
 
 
+def _ensi_multi(variant, name, bgrid, bratios, background, background_corr, points, pobs, pratios, pbackground, pbackground_corr,
+                structure, max_points, allow_extrapolation):
+    """Shared body of the optimal_interpolation_ensi_multi_* mirrors (validation as src/api/oi_ensi_multi.cpp:341-362)."""
+    if max_points < 0:
+        raise ValueError("max_points must be >= 0")
+    if not isinstance(bgrid, (Grid, Points)) or not isinstance(points, Points):
+        raise TypeError("bgrid must be a Grid or Points, points a Points")
+    nd = 3 if isinstance(bgrid, Grid) else 2
+    S = points.size()
+    background = _vec(background, nd, "background", np.float32)
+    if S == 0:
+        return background.clone() if _is_dev(background) else background.copy()
+    if bgrid.get_coordinate_type() != points.get_coordinate_type():
+        raise ValueError("Both background and observations points must be of same coorindate type (lat/lon or x/y)")
+    shape = tuple(bgrid.size()) if nd == 3 else (bgrid.size(),)
+    if nd == 3 and shape[0] * shape[1] == 0:
+        raise ValueError("Grid size cannot be zero")
+    if _shape(background)[:nd - 1] != shape:
+        raise ValueError("Input background field is not the same size as the grid")
+    E = _shape(background)[-1]
+    corr = variant != 2
+    if corr:
+        background_corr = _vec(background_corr, nd, "background_corr", np.float32)
+        if _shape(background_corr) != _shape(background):
+            raise ValueError("Input background_corr field is not the same size as the grid")
+        pbackground_corr = _vec(pbackground_corr, 2, "pbackground_corr", np.float32)
+        if _shape(pbackground_corr)[0] != S:
+            raise ValueError("Background_corr and points size mismatch")
+    bratios = _vec(bratios, nd - 1, "bratios", np.float32)
+    if _shape(bratios) != shape:
+        raise ValueError("Bratios and grid size mismatch")
+    pobs = _vec(pobs, 1 if variant == 3 else 2, "pobs", np.float32)
+    pratios = _vec(pratios, 1, "pratios", np.float32)
+    pbackground = _vec(pbackground, 2, "pbackground", np.float32)
+    if _shape(pobs)[0] != S:
+        raise ValueError("Observations and points exception mismatch")
+    if _shape(pratios)[0] != S:
+        raise ValueError("Pratios and points size mismatch")
+    if _shape(pbackground)[0] != S:
+        raise ValueError("Background and points size mismatch")
+    if _shape(pbackground)[1] != E or (variant != 3 and _shape(pobs)[1] != E) or (corr and _shape(pbackground_corr)[1] != E):
+        raise ValueError("Ensemble members in gridded background is not the same as in the point fields")
+    args = [bratios, background, pobs, pratios, pbackground] + ([background_corr, pbackground_corr] if corr else [])
+    mem = _mem(*args)
+    _sync_if_dev(mem)
+    out = _empty_like_field(_shape(background), background)
+    check(lib().gpp_optimal_interpolation_ensi_multi(int(variant), bgrid._h, _ptr(bratios), _ptr(background),
+                                                     _ptr(background_corr) if corr else None, int(E), points._h, _ptr(pobs), _ptr(pratios),
+                                                     _ptr(pbackground), _ptr(pbackground_corr) if corr else None, _structure(structure),
+                                                     int(max_points), int(bool(allow_extrapolation)), _ptr(out), mem))
+    return out
+
+
+def optimal_interpolation_ensi_multi_ebe(bgrid, bratios, background, background_corr, obs_points, pobs, pratios, pbackground,
+                                         pbackground_corr, structure, max_points, allow_extrapolation=True):
+    """gridpp::optimal_interpolation_ensi_multi_ebe (include/gridpp.h:311-322,373-384): ensemble-based correlations, member by member."""
+    return _ensi_multi(1, "ebe", bgrid, bratios, background, background_corr, obs_points, pobs, pratios, pbackground, pbackground_corr,
+                       structure, max_points, allow_extrapolation)
+
+
+def optimal_interpolation_ensi_multi_ebesc(bgrid, bratios, background, obs_points, pobs, pratios, pbackground, structure, max_points,
+                                           allow_extrapolation=True):
+    """gridpp::optimal_interpolation_ensi_multi_ebesc (include/gridpp.h:336-345,398-407): static correlations, member by member."""
+    return _ensi_multi(2, "ebesc", bgrid, bratios, background, None, obs_points, pobs, pratios, pbackground, None, structure, max_points,
+                       allow_extrapolation)
+
+
+def optimal_interpolation_ensi_multi_utem(bgrid, bratios, background, background_corr, obs_points, pobs, pratios, pbackground,
+                                          pbackground_corr, structure, max_points, allow_extrapolation=True):
+    """gridpp::optimal_interpolation_ensi_multi_utem (include/gridpp.h:360-371,421-432): ensemble mean first, then the analysis ensemble."""
+    return _ensi_multi(3, "utem", bgrid, bratios, background, background_corr, obs_points, pobs, pratios, pbackground, pbackground_corr,
+                       structure, max_points, allow_extrapolation)
+
+
 def ensi_last_kernel_ms():
     ms = C.c_float(0)
     check(lib().gpp_ensi_last_kernel_ms(C.byref(ms)))

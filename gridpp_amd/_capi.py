@@ -73,6 +73,7 @@ SIGNATURES = {
     "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
     "gpp_optimal_interpolation_ensi": [vp, vp, C.c_int, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],
     "gpp_ensi_last_kernel_ms": [fp],
+    "gpp_optimal_interpolation_ensi_multi": [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],
     "gpp_calc_statistic": [vp, C.c_long, C.c_int, C.c_int, vp, C.c_int],
     "gpp_calc_quantile": [vp, C.c_long, C.c_int, vp, C.c_long, vp, C.c_int],
     "gpp_calc_even_quantiles": [vp, C.c_long, C.c_int, C.c_int, vp, ip, C.c_int],

@@ -729,10 +729,12 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
     }
 }
 
+#include "ensi_multi.h"
+
 namespace {
 struct EnsiWorkspace {
     DevBuf<float4> pgeo, oaux;
-    DevBuf<float> gYhat, gY;
+    DevBuf<float> gYhat, gY, gYm, obs0;
     DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
     DevBuf<unsigned> sel, meta;
     DevBuf<unsigned long long> hsigs;
@@ -898,6 +900,111 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         if(tot) { fprintf(stderr, "[gpp] ensi phases (%% of wave cycles):"); for(int i = 0; i < 10; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[40 + i] / (double)tot); fprintf(stderr, "\n"); }
     }
     if(err & 1) runtime("optimal_interpolation_ensi: a grid point has more usable observations than the GPU path holds (512; 32 with spatially varying structure functions)");
+    return GPP_OK;
+    GPP_CATCH
+}
+
+// optimal_interpolation_ensi_multi_{ebe (1), ebesc (2), utem (3)}: src/api/oi_ensi_multi.cpp:329-1311 (Points overloads; a Grid is
+// its row-major flattening, :34-327)
+extern "C" int gpp_optimal_interpolation_ensi_multi(int variant, gpp_points* bgrid, const float* bratios, const float* background,
+                                                    const float* background_corr, int ne, gpp_points* points, const float* pobs,
+                                                    const float* pratios, const float* pbackground, const float* pbackground_corr,
+                                                    const gpp_structure* st, int max_points, int allow_extrapolation, float* out, int mem) {
+    GPP_TRY
+    if(variant < 1 || variant > 3) invalid("variant must be 1 (ebe), 2 (ebesc) or 3 (utem)");
+    if(max_points < 0) invalid("max_points must be >= 0");                                      // :341-342
+    if(!bgrid || !points) invalid("grid/points handle is NULL");
+    if(bgrid->type != points->type)
+        invalid("Both background and observations points must be of same coorindate type (lat/lon or x/y)");
+    if(!st) invalid("structure is NULL");
+    if(ne < 0) invalid("negative ensemble size");
+    if(mem & GPP_HOST_F64) invalid("GPP_HOST_F64 is not supported by optimal_interpolation_ensi_multi");
+    const bool corr = variant != 2;
+    const int C = bgrid->n, S = points->n, E = ne;
+    ensure_device();
+    g_ensi_ms = 0;
+    if(C == 0 || E == 0) return GPP_OK;
+    EnsiWorkspace& ws = g_ews;
+    InField f_bg, f_bgc, f_br, f_obs, f_pr, f_pbg, f_pbgc;
+    OutField f_out;
+    f_bg.bind(background, (size_t)C * E, mem);
+    f_out.bind(out, (size_t)C * E, mem);
+    const long nbg = (long)C * E;
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)((nbg + 255) / 256)), dim3(256), 0, stream(), f_bg.d, nbg, f_out.d);   // output = background (:375)
+    GPP_HIP(hipGetLastError());
+    if(S == 0) { f_out.finish(); GPP_HIP(hipStreamSynchronize(stream())); return GPP_OK; }        // :361-363
+    if(corr) { f_bgc.bind(background_corr, (size_t)C * E, mem); f_pbgc.bind(pbackground_corr, (size_t)S * E, mem); }
+    f_br.bind(bratios, C, mem);
+    f_obs.bind(pobs, variant == 3 ? (size_t)S : (size_t)S * E, mem);
+    f_pr.bind(pratios, S, mem);
+    f_pbg.bind(pbackground, (size_t)S * E, mem);
+    bgrid->to_device();
+    gpp_obs_index* ix = gpp_build_obs_index(points);
+    // members valid in every field (:395-418)
+    std::vector<int> flags(E, 1);
+    ws.flags.upload(flags.data(), E);
+    const long npb = (long)S * E;
+    hipLaunchKernelGGL(k_ensi_member_flags, dim3((unsigned)((nbg + 255) / 256)), dim3(256), 0, stream(), f_bg.d, nbg, E, ws.flags.p);
+    hipLaunchKernelGGL(k_ensi_member_flags, dim3((unsigned)((npb + 255) / 256)), dim3(256), 0, stream(), f_pbg.d, npb, E, ws.flags.p);
+    if(corr) {
+        hipLaunchKernelGGL(k_ensi_member_flags, dim3((unsigned)((nbg + 255) / 256)), dim3(256), 0, stream(), f_bgc.d, nbg, E, ws.flags.p);
+        hipLaunchKernelGGL(k_ensi_member_flags, dim3((unsigned)((npb + 255) / 256)), dim3(256), 0, stream(), f_pbgc.d, npb, E, ws.flags.p);
+    }
+    GPP_HIP(hipMemcpyAsync(flags.data(), ws.flags.p, sizeof(int) * E, hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    std::vector<int> valid;
+    for(int e = 0; e < E; e++) if(flags[e]) valid.push_back(e);
+    const int nV = (int)valid.size();
+    if(nV == 0) { f_out.finish(); GPP_HIP(hipStreamSynchronize(stream())); return GPP_OK; }      // :419-420
+    if(variant == 3 && nV > EMAXV) runtime("optimal_interpolation_ensi_multi_utem: more than 64 valid ensemble members are not supported on the GPU path");
+    if(variant == 1 && nV > 4096) runtime("optimal_interpolation_ensi_multi_ebe: more than 4096 valid ensemble members are not supported on the GPU path");
+    ws.validIdx.upload(valid.data(), nV);
+    ws.gYhat.get(S); ws.gY.get((size_t)S * nV); ws.gYm.get((size_t)S * nV); ws.obs0.get(S);
+    hipLaunchKernelGGL(k_multi_obs_prep, dim3((S + 127) / 128), dim3(128), 0, stream(), variant, f_pbg.d, corr ? f_pbgc.d : f_pbg.d, f_obs.d, S, E,
+                       (const int*)ws.validIdx.p, nV, ws.gY.p, ws.gYm.p, ws.gYhat.p, ws.obs0.p);
+    ws.pgeo.get(S); ws.oaux.get(S);
+    // oaux = (laf, obs[.][0] / obs, gYhat, pratio); an observation is usable when that first value is valid (:480)
+    hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
+                       (const float*)ws.obs0.p, f_pr.d, (const float*)ws.gYhat.p, (const float*)nullptr, 0, ws.pgeo.p, ws.oaux.p);
+    GPP_HIP(hipGetLastError());
+    ws.err.get(1);
+    GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
+    if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
+    MultiArgs ma = MultiArgs();
+    EnsiArgs& a = ma.e;
+    a.gx = bgrid->d_x.p; a.gy = bgrid->d_y.p; a.gz = bgrid->d_z.p; a.gelev = bgrid->d_elev.p; a.glaf = bgrid->d_laf.p;
+    a.bg = f_bg.d; a.out = f_out.d;
+    a.C = C; a.E = E;
+    a.s.pgeo = ws.pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
+    a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
+    a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
+    a.s.st = gpp_resolve_structure(st);
+    gpp_bind_field(a.s.st, st, bgrid, points, ws.cell_idx, ws.obs_idx);
+    if(a.s.st.fh) runtime("optimal_interpolation_ensi_multi: spatially varying structure functions are not supported on the GPU path");
+    a.s.max_points = max_points;
+    a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
+    a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;
+    a.allow_extrap = allow_extrapolation ? 1 : 0;
+    a.err = ws.err.p;
+    ma.gYm = ws.gYm.p; ma.bgc = corr ? f_bgc.d : f_bg.d; ma.bratios = f_br.d;
+    ma.pobs2 = f_obs.d; ma.pbg2 = f_pbg.d;
+    ma.oob = (variant != 3 && valid[nV - 1] != nV - 1) ? 1 : 0;
+    const int nwg = std::min(C, 2048);
+    a.big_keys = ws.big_keys.get((size_t)nwg * EBIG_CAND);
+    GPP_HIP(hipEventRecord(ws.e0, stream()));
+    if(variant == 1) hipLaunchKernelGGL(k_ensi_multi<1>, dim3(nwg), dim3(256), 0, stream(), ma);
+    else if(variant == 2) hipLaunchKernelGGL(k_ensi_multi<2>, dim3(nwg), dim3(256), 0, stream(), ma);
+    else hipLaunchKernelGGL(k_ensi_multi<3>, dim3(nwg), dim3(256), 0, stream(), ma);
+    GPP_HIP(hipGetLastError());
+    GPP_HIP(hipEventRecord(ws.e1, stream()));
+    int err = 0;
+    GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    f_out.finish();
+    GPP_HIP(hipStreamSynchronize(stream()));
+    GPP_HIP(hipEventElapsedTime(&g_ensi_ms, ws.e0, ws.e1));
+    if(err & 4) runtime("optimal_interpolation_ensi_multi: an ensemble member is invalid in front of a valid one: the reference indexes its innovation matrix with the original member index (oi_ensi_multi.cpp:565), which is out of bounds");
+    if(err & 2) runtime("optimal_interpolation_ensi_multi: singular matrix at a grid point (arma::inv fails in the reference)");
+    if(err & 1) runtime("optimal_interpolation_ensi_multi: a grid point has more usable observations than the GPU path holds (64 for ebe / ebesc, 512 for utem)");
     return GPP_OK;
     GPP_CATCH
 }

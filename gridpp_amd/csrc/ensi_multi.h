@@ -1,0 +1,408 @@
+// optimal_interpolation_ensi_multi_{ebe, ebesc, utem} (src/api/oi_ensi_multi.cpp:329-1311), included by ensi.hip.
+//
+// One 256-thread workgroup per grid point: radius query over the observation bins, LDS bitonic sort of the candidates (the
+// prologue of k_ensi_big), then
+//   ebe / ebesc : K = r (A + R)^-1 with A = C o (Z Z^T) (ebe: ensemble correlations Z localised by the static correlations C)
+//                 or A = C (ebesc); pivoted LU in LDS on A^T (n <= 64 selected observations), then dx_e = ratio K innov_e for
+//                 every member e (any number of members), the anti-extrapolation clamp, out = background + dx;
+//   utem        : the E x E square-root filter of optimal_interpolation_ensi with Pinv = Yc^T Rinv Yc + I, Rinv = rho / pratio,
+//                 W' = ensStd sqrt((E-1) P) + ratio w 1^T applied to the normalised perturbations of background_corr
+//                 (E <= 64 valid members, n <= 512).
+// These functions have no performance configuration in BASELINE.json; the kernel is written for correctness first.
+#pragma once
+
+struct MultiArgs {
+    EnsiArgs e;                 // gY = gZ (ebe) / gY_corr (utem); bg = background
+    const float* gYm;           // utem: mean-removed pbackground of the valid members [S][nV]
+    const float* bgc;           // background_corr [C][E] (ebe, utem)
+    const float* bratios;       // [C]
+    const float* pobs2;         // ebe / ebesc: [S][E]
+    const float* pbg2;          // ebe / ebesc: [S][E]
+    int oob;                    // an invalid member in front of a valid one: the reference indexes out of bounds
+};
+
+// calc_statistic(Mean) / (Std) of row[0..n) through an accessor (util.cpp:22-75: sequential float accumulation)
+template <class F> __device__ __forceinline__ float seq_mean_f(const int n, F at) {
+    float total = 0; int count = 0;
+    for(int i = 0; i < n; ++i) { const float v = at(i); if(d_valid(v)) { total += v; count++; } }
+    return count > 0 ? total / (float)count : NAN;
+}
+template <class F> __device__ __forceinline__ float seq_std_f(const int n, F at) {
+    float total = 0, total2 = 0, K = NAN; int count = 0;
+    for(int i = 0; i < n; ++i) { const float v = at(i); if(d_valid(v)) { if(!d_valid(K)) K = v; const float d = v - K; total += d; total2 += d * d; count++; } }
+    if(count == 0) return NAN;
+    const float mean = total / (float)count, mean2 = total2 / (float)count;
+    float var = mean2 - mean * mean;
+    if(var < 0) var = 0;
+    return sqrtf(var);
+}
+
+// per-observation ensemble quantities (oi_ensi_multi.cpp:421-444, :969-1003): one thread per observation
+__global__ void k_multi_obs_prep(const int variant, const float* __restrict__ pbg, const float* __restrict__ pbgc, const float* __restrict__ pobs, int S, int E,
+                                 const int* __restrict__ validIdx, int nV, float* __restrict__ gZ, float* __restrict__ gYm, float* __restrict__ gYhat,
+                                 float* __restrict__ obs0) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if(s >= S) return;
+    obs0[s] = variant == 3 ? pobs[s] : pobs[(long)s * E];
+    gYhat[s] = 0.0f;
+    if(variant == 3) {
+        const float* row = pbg + (long)s * E;
+        const float mean = seq_mean_f(nV, [&](int k) { return row[validIdx[k]]; });
+        for(int k = 0; k < nV; ++k) gYm[(long)s * nV + k] = d_valid(mean) ? row[validIdx[k]] - mean : 0.0f;
+        gYhat[s] = mean;
+    }
+    if(variant != 2) {
+        const float* row = pbgc + (long)s * E;
+        const float mean = seq_mean_f(nV, [&](int k) { return row[validIdx[k]]; });
+        const float sd = seq_std_f(nV, [&](int k) { return row[validIdx[k]]; });
+        const bool ok = d_valid(mean) && d_valid(sd) && sd > 0.0013f;
+        const float const_fact = (float)(1.0 / sqrt((double)(nV - 1)));
+        for(int k = 0; k < nV; ++k) {
+            float z = 0.0f;
+            if(ok) {
+                const float d = row[validIdx[k]] - mean;
+                z = variant == 1 ? (float)(1.0 / sqrt((double)(nV - 1)) * (double)d / (double)sd) : (const_fact * d) / sd;
+            }
+            gZ[(long)s * nV + k] = z;
+        }
+    }
+}
+__global__ void k_iota(int* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if(i < n) p[i] = i; }
+
+#define MULTI_N 64     // most selected observations of ebe / ebesc (LU in LDS)
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_ensi_multi(MultiArgs ma) {
+    const EnsiArgs& a = ma.e;
+    __shared__ double s_area[2 * 64 * EP];
+    unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(s_area);   // [EBIG_CAND]
+    double* const s_B = s_area;
+    double* const s_V = s_area + 64 * EP;
+    __shared__ double s_t[64], s_w[64], s_X[64], s_cs[32], s_sn[32];
+    __shared__ int s_p[32], s_q[32];
+    __shared__ double s_off[256];
+    __shared__ int s_n, s_piv;
+    const int tid = threadIdx.x;
+    const ScanArgs& sa = a.s;
+    const DevStructure& st = sa.st;
+    const int nV = a.nV, E = a.E;
+    unsigned long long* const gkeys = a.big_keys + (size_t)blockIdx.x * EBIG_CAND;
+    for(int cell = blockIdx.x; cell < a.C; cell += gridDim.x) {
+        const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
+        __syncthreads();
+        if(tid == 0) s_n = 0;
+        __syncthreads();
+        // ---- radius query + filter (valid observation, rho > 0: oi_ensi_multi.cpp:459-486) -----------------------------------------
+        const float R = st.R;
+        const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz), pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
+        const int bx0 = min(max((int)floorf((pa - R - sa.amin) * sa.inv_s) - 1, 0), sa.nbx - 1), bx1 = min(max((int)floorf((pa + R - sa.amin) * sa.inv_s) + 1, 0), sa.nbx - 1);
+        const int by0 = min(max((int)floorf((pb - R - sa.bmin) * sa.inv_s) - 1, 0), sa.nby - 1), by1 = min(max((int)floorf((pb + R - sa.bmin) * sa.inv_s) + 1, 0), sa.nby - 1);
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        for(int by = by0; by <= by1; ++by) {
+            const int js = sa.bin_start[by * sa.nbx + bx0], je = sa.bin_start[by * sa.nbx + bx1 + 1];
+            for(int j = js + tid; j < je; j += 256) {
+                const float4 rec = sa.pgeo[j];   // x = NaN for an unusable observation: fails the box test
+                if(!(rec.x > lox && rec.x < hix && rec.y > loy && rec.y < hiy && rec.z > loz && rec.z < hiz)) continue;
+                const float2 met = sa.smeta[j];
+                if(!(d_chord(rec.x, rec.y, rec.z, gx, gy, gz) <= R)) continue;
+                const float rho = d_corr(st, gx, gy, gz, ge, gl, rec.x, rec.y, rec.z, rec.w, met.x, true);
+                if(!(rho > 0.0f)) continue;
+                const int k = atomicAdd(&s_n, 1);
+                if(k < EBIG_CAND) s_key[k] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~__float_as_int(met.y));
+            }
+        }
+        __syncthreads();
+        const int ncand = s_n;
+        if(ncand == 0) continue;
+        const bool truncated = sa.max_points > 0 && ncand > sa.max_points;
+        const int n = truncated ? sa.max_points : ncand;
+        if(ncand > EBIG_CAND || n > (VARIANT == 3 ? EBIG_N : MULTI_N)) { if(tid == 0) atomicOr(a.err, 1); continue; }
+        if(ma.oob) { if(tid == 0) atomicOr(a.err, 4); continue; }
+        // ---- order: rho descending (ties -> lower index) when the reference sorts, index order otherwise -------------------------------
+        int np2 = 1;
+        while(np2 < ncand) np2 <<= 1;
+        for(int i = ncand + tid; i < np2; i += 256) s_key[i] = 0ull;
+        __syncthreads();
+        for(int k = 2; k <= np2; k <<= 1) {
+            for(int j = k >> 1; j > 0; j >>= 1) {
+                for(int i = tid; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if(ixj > i) {
+                        const unsigned long long x = s_key[i], y = s_key[ixj];
+                        const unsigned long long kx = truncated ? x : (x & 0xffffffffull), ky = truncated ? y : (y & 0xffffffffull);
+                        const bool desc = (i & k) == 0;
+                        if(desc ? (kx < ky) : (kx > ky)) { s_key[i] = y; s_key[ixj] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for(int i = tid; i < n; i += 256) gkeys[i] = s_key[i];
+        __threadfence_block();
+        __syncthreads();
+        const float ratio = ma.bratios[cell];
+        if(VARIANT != 3) {
+            // ---- K = r (A + R_dd)^-1: the transposed system in LDS, right-hand side in column n --------------------------------------------
+            double* const A = s_area;                    // [n][MULTI_N + 1]
+            const int AP = MULTI_N + 1;
+            double* const xL = s_area + MULTI_N * AP;    // ebe: normalised perturbations of background_corr at this point [nV] (nV <= 4096)
+            if(VARIANT == 1) {
+                const float* rowc = ma.bgc + (long)cell * E;
+                __shared__ float s_ms[2];
+                if(tid == 0) {
+                    s_ms[0] = seq_mean_f(nV, [&](int k) { return rowc[a.validIdx[k]]; });
+                    s_ms[1] = seq_std_f(nV, [&](int k) { return rowc[a.validIdx[k]]; });
+                }
+                __syncthreads();
+                const float mean = s_ms[0], sd = s_ms[1];
+                const bool ok = d_valid(mean) && d_valid(sd) && sd > 0.0013f;
+                for(int k = tid; k < nV; k += 256) xL[k] = ok ? 1.0 / sqrt((double)(nV - 1)) * (double)(rowc[a.validIdx[k]] - mean) / (double)sd : 0.0;   // :531-541
+                __syncthreads();
+            }
+            for(int e2 = tid; e2 < n * n; e2 += 256) {
+                const int i = e2 / n, j = e2 - i * n;
+                const unsigned oi = ~(unsigned)(gkeys[i] & 0xffffffffull), oj = ~(unsigned)(gkeys[j] & 0xffffffffull);
+                const float4 gi = a.ogeo[oi], gj = a.ogeo[oj];
+                const float4 xi = a.oaux[oi], xj = a.oaux[oj];
+                const float cc = d_corr(st, gi.x, gi.y, gi.z, gi.w, xi.x, gj.x, gj.y, gj.z, gj.w, xj.x, false);   // structure.corr(p_i, p_j), :570-577
+                double zz = 1.0;
+                if(VARIANT == 1) { zz = 0.0; for(int k = 0; k < nV; ++k) zz += (double)a.gY[(long)oi * nV + k] * (double)a.gY[(long)oj * nV + k]; }
+                A[j * AP + i] = (double)cc * zz + (i == j ? (double)xi.w : 0.0);   // transposed: row j, column i
+            }
+            for(int i = tid; i < n; i += 256) {
+                const unsigned long long key = gkeys[i];
+                const unsigned oi = ~(unsigned)(key & 0xffffffffull);
+                const float rho = __uint_as_float((unsigned)(key >> 32));
+                double rz = 1.0;
+                if(VARIANT == 1) { rz = 0.0; for(int k = 0; k < nV; ++k) rz += xL[k] * (double)a.gY[(long)oi * nV + k]; }
+                A[i * AP + n] = (double)rho * rz;                                  // :581 / lCorr1D
+            }
+            __syncthreads();
+            // pivoted LU (Gauss elimination with the right-hand side riding along)
+            bool singular = false;
+            for(int k = 0; k < n; ++k) {
+                if(tid == 0) {
+                    int p = k; double best = fabs(A[k * AP + k]);
+                    for(int r = k + 1; r < n; ++r) { const double v = fabs(A[r * AP + k]); if(v > best) { best = v; p = r; } }
+                    s_piv = (best > 0.0 && best < INFINITY) ? p : -1;
+                }
+                __syncthreads();
+                const int p = s_piv;
+                if(p < 0) { singular = true; break; }
+                if(p != k) for(int cidx = tid; cidx <= n; cidx += 256) { const double t = A[k * AP + cidx]; A[k * AP + cidx] = A[p * AP + cidx]; A[p * AP + cidx] = t; }
+                __syncthreads();
+                const double pinv = 1.0 / A[k * AP + k];
+                for(int e2 = tid; e2 < (n - k - 1) * (n - k); e2 += 256) {
+                    const int r = k + 1 + e2 / (n - k), cidx = k + 1 + e2 % (n - k);
+                    A[r * AP + cidx] -= A[r * AP + k] * pinv * A[k * AP + cidx];
+                }
+                __syncthreads();
+            }
+            if(singular) { if(tid == 0) atomicOr(a.err, 2); continue; }
+            if(tid == 0) {   // back substitution: K in column n
+                for(int r = n - 1; r >= 0; --r) {
+                    double sacc = A[r * AP + n];
+                    for(int cidx = r + 1; cidx < n; ++cidx) sacc -= A[r * AP + cidx] * A[cidx * AP + n];
+                    A[r * AP + n] = sacc / A[r * AP + r];
+                }
+            }
+            __syncthreads();
+            // dx_e = ratio * K innov_e (:588), clamp (:593-615), out = background + dx (:620)
+            for(int k = tid; k < nV; k += 256) {
+                const int ei = a.validIdx[k];
+                double sacc = 0.0; float maxInc = 0, minInc = 0;
+                for(int i = 0; i < n; ++i) {
+                    const unsigned oi = ~(unsigned)(gkeys[i] & 0xffffffffull);
+                    const float inn = ma.pobs2[(long)oi * E + ei] - ma.pbg2[(long)oi * E + ei];
+                    sacc = __builtin_fma(A[i * AP + n], (double)inn, sacc);
+                    if(i == 0 || inn > maxInc) maxInc = inn;
+                    if(i == 0 || inn < minInc) minInc = inn;
+                }
+                double dx = (double)ratio * sacc;
+                if(!a.allow_extrap) {
+                    float increment = (float)dx;
+                    if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                    else if(maxInc < 0 && increment > 0) increment = 0;
+                    else if(minInc < 0 && increment < minInc) increment = minInc;
+                    else if(minInc > 0 && increment < 0) increment = 0;
+                    dx = (double)increment;
+                }
+                a.out[(long)cell * E + ei] = (float)((double)a.bg[(long)cell * E + ei] + dx);
+            }
+            continue;
+        }
+        // ================================ utem: E x E square-root filter (:1060-1265) ==================================================
+        float* const yc = reinterpret_cast<float*>(s_key);          // [64][64] Yc chunk
+        double* const rinv = reinterpret_cast<double*>(yc + 64 * 64);
+        double* const dvec = rinv + 64;
+        double accP[16];
+#pragma unroll
+        for(int r = 0; r < 16; ++r) accP[r] = 0.0;
+        double acct = 0.0;
+        for(int i0 = 0; i0 < n; i0 += 64) {
+            const int m = min(64, n - i0);
+            __syncthreads();
+            for(int e2 = tid; e2 < m * 64; e2 += 256) {
+                const int i = e2 >> 6, k = e2 & 63;
+                const unsigned orig = ~(unsigned)(gkeys[i0 + i] & 0xffffffffull);
+                yc[i * 64 + k] = (k < nV) ? a.gY[(long)orig * nV + k] : 0.0f;
+            }
+            if(tid < m) {
+                const unsigned long long key = gkeys[i0 + tid];
+                const unsigned orig = ~(unsigned)(key & 0xffffffffull);
+                const float4 x4 = a.oaux[orig];                       // laf, obs, gYhat, pratio
+                rinv[tid] = (double)__uint_as_float((unsigned)(key >> 32)) / (double)x4.w;   // :1078
+                dvec[tid] = (double)x4.y - (double)x4.z;
+            }
+            __syncthreads();
+            for(int r = 0; r < 16; ++r) {
+                const int e2 = tid + 256 * r, ai = e2 >> 6, bi = e2 & 63;
+                if(ai < nV && bi < nV) {
+                    double sacc = accP[r];
+                    for(int i = 0; i < m; ++i) sacc = __builtin_fma((double)yc[i * 64 + ai] * rinv[i], (double)yc[i * 64 + bi], sacc);
+                    accP[r] = sacc;
+                }
+            }
+            if(tid < nV) for(int i = 0; i < m; ++i) acct = __builtin_fma((double)yc[i * 64 + tid] * rinv[i], dvec[i], acct);
+        }
+        __syncthreads();
+        for(int r = 0; r < 16; ++r) {
+            const int e2 = tid + 256 * r, ai = e2 >> 6, bi = e2 & 63;
+            if(ai < nV && bi < nV) {
+                s_B[ai * EP + bi] = accP[r] + (ai == bi ? 1.0 : 0.0);   // Pinv = C Yc + I (:1085)
+                s_V[ai * EP + bi] = ai == bi ? 1.0 : 0.0;
+            }
+        }
+        if(tid < nV) s_t[tid] = acct;
+        __syncthreads();
+        // cyclic Jacobi on the nV x nV matrix (as k_ensi_big)
+        const int mm = nV + (nV & 1), half = mm >> 1;
+        double tr = 0.0;
+        if(tid < nV) tr = fabs(s_B[tid * EP + tid]);
+        s_off[tid] = tr;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+        tr = s_off[0];
+        __syncthreads();
+        for(int sweep = 0; sweep < 40 && nV > 1; ++sweep) {
+            double off2 = 0.0;
+            for(int e2 = tid; e2 < nV * nV; e2 += 256) { const int i = e2 / nV, j = e2 - i * nV; if(j < i) { const double vv = s_B[i * EP + j]; off2 += vv * vv; } }
+            s_off[tid] = off2;
+            __syncthreads();
+            for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+            off2 = s_off[0];
+            __syncthreads();
+            if(!(off2 > 1e-22 * tr * tr)) break;
+            for(int step = 0; step < mm - 1; ++step) {
+                if(tid < half) {
+                    int p, q;
+                    if(tid == 0) { p = mm - 1; q = step; }
+                    else { p = (step + tid) % (mm - 1); q = (step - tid + (mm - 1)) % (mm - 1); }
+                    if(p > q) { const int t_ = p; p = q; q = t_; }
+                    double cs = 1.0, sn = 0.0;
+                    if(q < nV) {
+                        const double apq = s_B[p * EP + q];
+                        if(apq != 0.0) {
+                            const double theta = (s_B[q * EP + q] - s_B[p * EP + p]) / (2.0 * apq);
+                            const double t_ = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                            cs = 1.0 / sqrt(t_ * t_ + 1.0); sn = t_ * cs;
+                            if(!(fabs(theta) < 1e150)) { cs = 1.0; sn = 0.0; }
+                        }
+                    }
+                    else q = p;
+                    s_p[tid] = p; s_q[tid] = q; s_cs[tid] = cs; s_sn[tid] = sn;
+                }
+                __syncthreads();
+                const int pk = tid >> 3;
+                const bool work = pk < half && s_p[pk] != s_q[pk];
+                const int p = work ? s_p[pk] : 0, q = work ? s_q[pk] : 0;
+                const double cs = work ? s_cs[pk] : 1.0, sn = work ? s_sn[pk] : 0.0;
+                if(work)
+                    for(int r = tid & 7; r < nV; r += 8) {
+                        const double bp = s_B[r * EP + p], bq = s_B[r * EP + q];
+                        const double vp = s_V[r * EP + p], vq = s_V[r * EP + q];
+                        s_B[r * EP + p] = cs * bp - sn * bq; s_B[r * EP + q] = sn * bp + cs * bq;
+                        s_V[r * EP + p] = cs * vp - sn * vq; s_V[r * EP + q] = sn * vp + cs * vq;
+                    }
+                __syncthreads();
+                if(work)
+                    for(int cidx = tid & 7; cidx < nV; cidx += 8) {
+                        const double bp = s_B[p * EP + cidx], bq = s_B[q * EP + cidx];
+                        s_B[p * EP + cidx] = cs * bp - sn * bq; s_B[q * EP + cidx] = sn * bp + cs * bq;
+                    }
+                __syncthreads();
+            }
+        }
+        bool singular = false;
+        if(tid < nV) { const double dk = s_B[tid * EP + tid]; singular = !(dk > 0.0) || isinf(dk); }
+        s_off[tid] = singular ? 1.0 : 0.0;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+        const bool skip = s_off[0] > 0.0;
+        __syncthreads();
+        if(skip) continue;   // rcond <= 0 -> raw values (:1087-1090)
+        const double cscale = (double)(nV - 1);
+        if(tid < nV) {
+            double u = 0.0;
+            for(int k = 0; k < nV; ++k) u = __builtin_fma(s_V[k * EP + tid], s_t[k], u);
+            s_off[tid] = sqrt(cscale / s_B[tid * EP + tid]);        // eigenvalues of (nV - 1) P, square root (:1098-1121)
+            s_X[tid] = u / s_B[tid * EP + tid];
+        }
+        __syncthreads();
+        if(tid < nV) {
+            double wv = 0.0;
+            for(int k = 0; k < nV; ++k) wv = __builtin_fma(s_V[tid * EP + k], s_X[k], wv);
+            s_w[tid] = wv;                                           // w = P C (lObs - lYhat)
+        }
+        __syncthreads();
+        // ensemble statistics of this grid point (:1141-1179)
+        __shared__ float s_val[64], s_valc[64], s_st[4];
+        const int ek = (tid < nV) ? a.validIdx[tid] : 0;
+        if(tid < nV) { s_val[tid] = a.bg[(long)cell * E + ek]; s_valc[tid] = ma.bgc[(long)cell * E + ek]; }
+        __syncthreads();
+        if(tid == 0) {
+            float total = 0, totalc = 0;
+            for(int k = 0; k < nV; ++k) { total += s_val[k]; totalc += s_valc[k]; }
+            s_st[0] = total / (float)nV; s_st[2] = totalc / (float)nV;
+            s_st[1] = seq_std_f(nV, [&](int k) { return s_val[k]; });
+            s_st[3] = seq_std_f(nV, [&](int k) { return s_valc[k]; });
+        }
+        __syncthreads();
+        const float ensMean = s_st[0], ensStd = s_st[1], ensMeanC = s_st[2], ensStdC = s_st[3];
+        const float const_fact = (float)(1.0 / sqrt((double)(nV - 1)));
+        for(int e2 = tid; e2 < nV * nV; e2 += 256) {
+            const int ai = e2 / nV, bi = e2 - ai * nV;
+            double sacc = 0.0;
+            for(int k = 0; k < nV; ++k) sacc = __builtin_fma(s_V[ai * EP + k] * s_off[k], s_V[bi * EP + k], sacc);
+            s_B[ai * EP + bi] = (double)ensStd * sacc + (double)ratio * s_w[ai];    // :1181-1185
+        }
+        __syncthreads();
+        if(tid < nV) s_X[tid] = (ensStdC <= 0.0013f) ? 0.0 : (double)((const_fact * (s_valc[tid] - ensMeanC)) / ensStdC);   // X_corr
+        __syncthreads();
+        if(tid < nV) {
+            float acc = 0.0f;
+            for(int k = 0; k < nV; ++k) acc = (float)((double)acc + s_X[k] * s_B[k * EP + tid]);   // :1229-1233
+            float currIncrement = acc;
+            const double Xe = (double)s_val[tid] - (double)ensMean;
+            if(!a.allow_extrap) {   // :1238-1262; lY[e] is a LINEAR index into the n x nV column-major matrix of the mean-removed pbackground
+                const int li_ = tid % n, lk_ = tid / n;
+                const unsigned oo = ~(unsigned)(gkeys[li_] & 0xffffffffull);
+                const double lYe = (double)ma.gYm[(long)oo * nV + lk_];
+                float maxInc = 0, minInc = 0;
+                for(int i = 0; i < n; ++i) {
+                    const unsigned oi_ = ~(unsigned)(gkeys[i] & 0xffffffffull);
+                    const float4 x4 = a.oaux[oi_];
+                    const float dv = (float)((double)x4.y - (lYe + (double)x4.z));
+                    if(i == 0 || dv > maxInc) maxInc = dv;
+                    if(i == 0 || dv < minInc) minInc = dv;
+                }
+                const float memberIncrement = (float)((double)currIncrement - Xe);
+                if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + Xe);
+                else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + Xe);
+                else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + Xe);
+                else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + Xe);
+            }
+            a.out[(long)cell * E + ek] = ensMean + currIncrement;
+        }
+        __syncthreads();
+    }
+}

@@ -319,6 +319,81 @@ inline vec3 optimal_interpolation_ensi(const Grid& bgrid, const vec3& background
     return detail::unflatten(out, Y, X, E);
 }
 
+// include/gridpp.h:311-441 (optimal_interpolation_ensi_multi_ebe / _ebesc / _utem; variant 1 / 2 / 3 of the C-ABI entry point)
+namespace detail {
+inline vec2 ensi_multi_points(int variant, gpp_points* bhandle, int bsize, CoordinateType btype, const vec& bratios, const vec2& background, const vec2* background_corr,
+                              const Points& points, const vec* pobs1, const vec2* pobs2, const vec& pratios, const vec2& pbackground,
+                              const vec2* pbackground_corr, const StructureFunction& structure, int max_points, bool allow_extrapolation) {
+    if(max_points < 0) throw std::invalid_argument("max_points must be >= 0");
+    if(btype != points.get_coordinate_type())
+        throw std::invalid_argument("Both background and observations points must be of same coorindate type (lat/lon or x/y)");
+    if((int)background.size() != bsize) throw std::invalid_argument("Input background field is not the same size as the grid");
+    if(background_corr && (int)background_corr->size() != bsize) throw std::invalid_argument("Input background_corr field is not the same size as the grid");
+    if((int)bratios.size() != bsize) throw std::invalid_argument("Bratios and grid size mismatch");
+    if((int)(pobs1 ? pobs1->size() : pobs2->size()) != points.size()) throw std::invalid_argument("Observations and points exception mismatch");
+    if((int)pratios.size() != points.size()) throw std::invalid_argument("Pratios and points size mismatch");
+    if((int)pbackground.size() != points.size()) throw std::invalid_argument("Background and points size mismatch");
+    if(pbackground_corr && (int)pbackground_corr->size() != points.size()) throw std::invalid_argument("Background_corr and points size mismatch");
+    if(points.size() == 0) return background;
+    size_t N, E, S, E2;
+    vec bg = flatten(background, N, E), pbg = flatten(pbackground, S, E2), bgc, pbgc, po;
+    if(background_corr) { size_t a, b; bgc = flatten(*background_corr, a, b); pbgc = flatten(*pbackground_corr, a, b); }
+    if(pobs2) { size_t a, b; po = flatten(*pobs2, a, b); } else po = *pobs1;
+    if(E != E2) throw std::invalid_argument("Ensemble size mismatch");
+    vec out(bg.size());
+    check(gpp_optimal_interpolation_ensi_multi(variant, bhandle, bratios.data(), bg.data(), background_corr ? bgc.data() : nullptr, (int)E,
+                                               points.handle(), po.data(), pratios.data(), pbg.data(), pbackground_corr ? pbgc.data() : nullptr,
+                                               structure.c_struct(), max_points, allow_extrapolation, out.data(), GPP_MEM_HOST));
+    return unflatten(out, N, E);
+}
+}  // namespace detail
+inline vec2 optimal_interpolation_ensi_multi_ebe(const Points& bpoints, const vec& bratios, const vec2& background, const vec2& background_corr,
+                                                 const Points& obs_points, const vec2& pobs, const vec& pratios, const vec2& pbackground,
+                                                 const vec2& pbackground_corr, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    return detail::ensi_multi_points(1, bpoints.handle(), bpoints.size(), bpoints.get_coordinate_type(), bratios, background, &background_corr, obs_points, nullptr, &pobs, pratios, pbackground, &pbackground_corr,
+                                     structure, max_points, allow_extrapolation);
+}
+inline vec2 optimal_interpolation_ensi_multi_ebesc(const Points& bpoints, const vec& bratios, const vec2& background, const Points& obs_points, const vec2& pobs,
+                                                   const vec& pratios, const vec2& pbackground, const StructureFunction& structure, int max_points,
+                                                   bool allow_extrapolation = true) {
+    return detail::ensi_multi_points(2, bpoints.handle(), bpoints.size(), bpoints.get_coordinate_type(), bratios, background, nullptr, obs_points, nullptr, &pobs, pratios, pbackground, nullptr, structure, max_points,
+                                     allow_extrapolation);
+}
+inline vec2 optimal_interpolation_ensi_multi_utem(const Points& bpoints, const vec& bratios, const vec2& background, const vec2& background_corr,
+                                                  const Points& obs_points, const vec& pobs, const vec& pratios, const vec2& pbackground,
+                                                  const vec2& pbackground_corr, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    return detail::ensi_multi_points(3, bpoints.handle(), bpoints.size(), bpoints.get_coordinate_type(), bratios, background, &background_corr, obs_points, &pobs, nullptr, pratios, pbackground, &pbackground_corr,
+                                     structure, max_points, allow_extrapolation);
+}
+// Grid overloads (src/api/oi_ensi_multi.cpp:34-327): the grid's points in row-major order, fields flattened the same way
+namespace detail {
+inline vec2 flat_field(const vec3& f) { vec2 o; for(const auto& row : f) for(const auto& c : row) o.push_back(c); return o; }
+inline vec flat_field(const vec2& f) { vec o; for(const auto& row : f) for(float c : row) o.push_back(c); return o; }
+inline vec3 unflat_field(const vec2& f, size_t Y, size_t X) { vec3 o(Y, vec2(X)); for(size_t y = 0; y < Y; y++) for(size_t x = 0; x < X; x++) o[y][x] = f[y * X + x]; return o; }
+}  // namespace detail
+inline vec3 optimal_interpolation_ensi_multi_ebe(const Grid& bgrid, const vec2& bratios, const vec3& background, const vec3& background_corr,
+                                                 const Points& obs_points, const vec2& pobs, const vec& pratios, const vec2& pbackground,
+                                                 const vec2& pbackground_corr, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    const vec2 bgc = detail::flat_field(background_corr);
+    return detail::unflat_field(detail::ensi_multi_points(1, bgrid.handle(), bgrid.size()[0] * bgrid.size()[1], bgrid.get_coordinate_type(), detail::flat_field(bratios),
+                                detail::flat_field(background), &bgc, obs_points, nullptr, &pobs, pratios, pbackground, &pbackground_corr, structure, max_points,
+                                allow_extrapolation), background.size(), background.empty() ? 0 : background[0].size());
+}
+inline vec3 optimal_interpolation_ensi_multi_ebesc(const Grid& bgrid, const vec2& bratios, const vec3& background, const Points& obs_points, const vec2& pobs,
+                                                   const vec& pratios, const vec2& pbackground, const StructureFunction& structure, int max_points,
+                                                   bool allow_extrapolation = true) {
+    return detail::unflat_field(detail::ensi_multi_points(2, bgrid.handle(), bgrid.size()[0] * bgrid.size()[1], bgrid.get_coordinate_type(), detail::flat_field(bratios),
+                                detail::flat_field(background), nullptr, obs_points, nullptr, &pobs, pratios, pbackground, nullptr, structure, max_points, allow_extrapolation), background.size(), background.empty() ? 0 : background[0].size());
+}
+inline vec3 optimal_interpolation_ensi_multi_utem(const Grid& bgrid, const vec2& bratios, const vec3& background, const vec3& background_corr,
+                                                  const Points& obs_points, const vec& pobs, const vec& pratios, const vec2& pbackground,
+                                                  const vec2& pbackground_corr, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    const vec2 bgc = detail::flat_field(background_corr);
+    return detail::unflat_field(detail::ensi_multi_points(3, bgrid.handle(), bgrid.size()[0] * bgrid.size()[1], bgrid.get_coordinate_type(), detail::flat_field(bratios),
+                                detail::flat_field(background), &bgc, obs_points, &pobs, nullptr, pratios, pbackground, &pbackground_corr, structure, max_points,
+                                allow_extrapolation), background.size(), background.empty() ? 0 : background[0].size());
+}
+
 // ---- neighbourhood (include/gridpp.h:588-716) ---------------------------------------------------------------
 namespace detail {
 inline vec2 nb(const vec& f, size_t Y, size_t X, size_t E, int is3d, int halfwidth, Statistic statistic) {

@@ -257,7 +257,17 @@ int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* background, i
                                    const float* obs, const float* sigmas, const float* background_at_points,
                                    const gpp_structure* structure, int max_points, int allow_extrapolation,
                                    float* out, int mem);
-int gpp_ensi_last_kernel_ms(float* ms);   /* hipEvent time of the last EnSI kernel (diagnostics / bench) */
+int gpp_ensi_last_kernel_ms(float* ms);
+
+/* gridpp::optimal_interpolation_ensi_multi_ebe / _ebesc / _utem (include/gridpp.h:311-441, src/api/oi_ensi_multi.cpp:329-1311;
+ * Points overloads, a Grid is its row-major flattening).  variant: 1 = ebe, 2 = ebesc, 3 = utem.  bratios [bgrid-size];
+ * background / background_corr / out [bgrid-size][ne]; pobs [points-size][ne] (ebe, ebesc) or [points-size] (utem); pratios
+ * [points-size]; pbackground / pbackground_corr [points-size][ne].  background_corr / pbackground_corr are ignored by ebesc
+ * (may be NULL).  Members invalid in any of the fields are left untouched (:395-418). */
+int gpp_optimal_interpolation_ensi_multi(int variant, gpp_points* bgrid, const float* bratios, const float* background,
+                                         const float* background_corr, int ne, gpp_points* points, const float* pobs,
+                                         const float* pratios, const float* pbackground, const float* pbackground_corr,
+                                         const gpp_structure* structure, int max_points, int allow_extrapolation, float* out, int mem);   /* hipEvent time of the last EnSI kernel (diagnostics / bench) */
 
 /* ---- neighbourhood filters (src/api/neighbourhood.cpp) -------------------------
  * input is [ny][nx] (is3d == 0, ne must be 1) or [ny][nx][ne] (is3d == 1); out is

@@ -119,6 +119,31 @@ int main() {
         try { bilinear(g1, g2, vec2{{0, 1, 2}}); } catch(const std::invalid_argument&) { threw = true; }
         CHECK(threw);
     }
+    // optimal_interpolation_ensi_multi_* (include/gridpp.h:311-441): one observation on a grid point, unit ratios, no ensemble spread in
+    // the observation term -> ebesc moves every member half way (K = rho / (1 + pratio) = 1 / 2 at the observed point); the Grid and
+    // Points overloads agree
+    {
+        vec2 la = {{0, 0}, {0.01f, 0.01f}}, lo = {{0, 0.01f}, {0, 0.01f}};
+        Grid g(la, lo);
+        Points gp(vec{0, 0, 0.01f, 0.01f}, vec{0, 0.01f, 0, 0.01f});
+        Points ob(vec{0}, vec{0});
+        vec3 bg3 = {{{1, 2, 3}, {1, 2, 3}}, {{1, 2, 3}, {1, 2, 3}}};
+        vec2 bg2 = {{1, 2, 3}, {1, 2, 3}, {1, 2, 3}, {1, 2, 3}};
+        vec2 pobs = {{3, 4, 5}}, pbg = {{1, 2, 3}};
+        BarnesStructure st(10000);
+        vec3 a3 = optimal_interpolation_ensi_multi_ebesc(g, vec2{{1, 1}, {1, 1}}, bg3, ob, pobs, vec{1}, pbg, st, 5);
+        vec2 a2 = optimal_interpolation_ensi_multi_ebesc(gp, vec{1, 1, 1, 1}, bg2, ob, pobs, vec{1}, pbg, st, 5);
+        CHECK(std::fabs(a3[0][0][0] - 2) < 1e-6 && std::fabs(a3[0][0][2] - 4) < 1e-6);
+        CHECK(a3[1][1][1] == a2[3][1] && a3[0][1][0] == a2[1][0] && a3[1][1][1] > 2 && a3[1][1][1] < 3);
+        vec3 u3 = optimal_interpolation_ensi_multi_utem(g, vec2{{1, 1}, {1, 1}}, bg3, bg3, ob, vec{3}, vec{1}, pbg, pbg, st, 5);
+        CHECK(u3.size() == 2 && u3[0][0].size() == 3 && std::isfinite(u3[0][0][0]));
+        vec3 e3 = optimal_interpolation_ensi_multi_ebe(g, vec2{{1, 1}, {1, 1}}, bg3, bg3, ob, pobs, vec{1}, pbg, pbg, st, 5);
+        // perfectly correlated 3-member ensembles: Z Z^T = n / (n - 1) = 1.5 (population std, 1 / sqrt(n - 1) factor), K = 1.5 / 2.5
+        CHECK(std::fabs(e3[0][0][0] - 2.2f) < 1e-5);
+        threw = false;
+        try { optimal_interpolation_ensi_multi_ebesc(gp, vec{1, 1, 1}, bg2, ob, pobs, vec{1}, pbg, st, 5); } catch(const std::invalid_argument&) { threw = true; }
+        CHECK(threw);
+    }
     std::printf("gridpp.hpp host API: all checks passed (version %s)\n", version().c_str());
     return 0;
 }
