@@ -660,8 +660,8 @@ __global__ __launch_bounds__(256) void k_oi_big(OiArgs a) {
         __syncthreads();
         const int ncand = s_n;
         int n = (a.s.max_points > 0) ? min(ncand, a.s.max_points) : ncand;
-        if(ncand > BIG_CAND || n > BIG_N) {   // beyond what this kernel holds: fail loudly (host raises)
-            if(tid == 0) atomicOr(a.err, ERR_OVERFLOW);
+        if(ncand > BIG_CAND || n > BIG_N) {   // beyond what this kernel holds: the general kernel takes the cell
+            if(tid == 0) { if(a.huge_list) a.huge_list[atomicAdd(a.huge_count, 1)] = cell; else atomicOr(a.err, ERR_OVERFLOW); }
             __syncthreads();
             continue;
         }
@@ -763,6 +763,191 @@ __global__ __launch_bounds__(256) void k_oi_big(OiArgs a) {
     }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// k_oi_huge: the general form of the local analysis (oi.cpp:229-337) for the grid points the faster kernels cannot hold: more
+// than BIG_N selected observations, or more than 62 with a non-symmetric (Cressman / SOAR / TOAR vertical factors) or
+// spatially varying structure function.  No capacity of its own beyond the scratch the host sized for the call: the
+// candidate keys and the augmented matrix (P + R | obs - background | rho) live in HBM, the candidates are sorted by a
+// bitonic network over global memory, the system is solved by Gaussian elimination with partial pivoting (what
+// arma::inv = LAPACK does, so indefinite truncated kernels behave as in the reference), the pivot row staged in LDS.
+// One 256-thread workgroup per listed grid point; O(n^3) like the reference.
+// -------------------------------------------------------------------------------------------
+#define HUGE_ROW 4096
+template <bool SPATIAL>
+__global__ __launch_bounds__(256) void k_oi_huge(OiArgs a, const int* __restrict__ list, const int* __restrict__ count) {
+    __shared__ double s_row[HUGE_ROW];      // pivot row (the first HUGE_ROW entries are staged; longer rows are read from HBM)
+    __shared__ double s_red[2][256];
+    __shared__ float s_mm[2][256];
+    __shared__ int s_idx[256];
+    __shared__ int s_n, s_piv;
+    const int tid = threadIdx.x;
+    const ScanArgs& sa = a.s;
+    const int nlist = *count;
+    unsigned long long* const keys = a.huge_keys + (size_t)blockIdx.x * a.huge_kcap;
+    double* const M = a.huge_mat + (size_t)blockIdx.x * a.huge_ncap * (a.huge_ncap + 2);
+    for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int cell = list[li];
+        const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
+        const float bg = a.bg[cell], bvar = a.bvar ? a.bvar[cell] : 1.0f;
+        DevStructure st = sa.st;
+        if(SPATIAL) d_structure_at(st, st.cell_idx ? st.cell_idx[cell] : cell);
+        if(tid == 0) s_n = 0;
+        __syncthreads();
+        const float R = st.R;
+        const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz), pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
+        const int bx0 = min(max((int)floorf((pa - R - sa.amin) * sa.inv_s) - 1, 0), sa.nbx - 1), bx1 = min(max((int)floorf((pa + R - sa.amin) * sa.inv_s) + 1, 0), sa.nbx - 1);
+        const int by0 = min(max((int)floorf((pb - R - sa.bmin) * sa.inv_s) - 1, 0), sa.nby - 1), by1 = min(max((int)floorf((pb + R - sa.bmin) * sa.inv_s) + 1, 0), sa.nby - 1);
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        for(int by = by0; by <= by1; ++by) {
+            const int js = sa.bin_start[by * sa.nbx + bx0], je = sa.bin_start[by * sa.nbx + bx1 + 1];
+            for(int j = js + tid; j < je; j += 256) {
+                const float4 rec = sa.pgeo[j];
+                if(!(rec.x > lox && rec.x < hix && rec.y > loy && rec.y < hiy && rec.z > loz && rec.z < hiz)) continue;   // kdtree.cpp:46,53
+                const float2 met = sa.smeta[j];
+                if(!(d_chord(rec.x, rec.y, rec.z, gx, gy, gz) <= R)) continue;                                          // kdtree.cpp:255
+                const float rho = d_corr(st, gx, gy, gz, ge, gl, rec.x, rec.y, rec.z, rec.w, met.x, true);
+                if(!(rho > 0.0f)) continue;                                                                            // oi.cpp:253
+                const int k = atomicAdd(&s_n, 1);
+                if(k < a.huge_kcap) keys[k] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~__float_as_int(met.y));
+            }
+        }
+        __syncthreads();
+        const int ncand = s_n;
+        const bool truncated = a.s.max_points > 0 && ncand > a.s.max_points;
+        const int n = truncated ? a.s.max_points : ncand;
+        int np2 = 1;
+        while(np2 < ncand) np2 <<= 1;
+        if(np2 > a.huge_kcap || n > a.huge_ncap) { if(tid == 0) atomicOr(a.err, ERR_OVERFLOW); __syncthreads(); continue; }
+        if(n == 0) continue;
+        // ---- order: rho descending, ties -> lower index, when the reference sorts (oi.cpp:262-273); candidate (= index) order otherwise
+        for(int i = ncand + tid; i < np2; i += 256) keys[i] = 0ull;
+        __threadfence_block();
+        __syncthreads();
+        for(int k = 2; k <= np2; k <<= 1) {
+            for(int j = k >> 1; j > 0; j >>= 1) {
+                for(int i = tid; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if(ixj > i) {
+                        const unsigned long long x = keys[i], y = keys[ixj];
+                        const unsigned long long kx = truncated ? x : (x & 0xffffffffull), ky = truncated ? y : (y & 0xffffffffull);
+                        const bool desc = (i & k) == 0;
+                        if(desc ? (kx < ky) : (kx > ky)) { keys[i] = y; keys[ixj] = x; }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+        // ---- augmented matrix: row i = (corr(p_i, p_j) + [i == j] ratio_i | obs_i - pbg_i | rho_i), oi.cpp:289-314 ----------------------
+        const int W = n + 2;
+        float maxInc = -INFINITY, minInc = INFINITY;
+        for(long e = tid; e < (long)n * n; e += 256) {
+            const int i = (int)(e / n), j = (int)(e - (long)i * n);
+            const unsigned oi = ~(unsigned)(keys[i] & 0xffffffffull), oj = ~(unsigned)(keys[j] & 0xffffffffull);
+            const float4 gi = a.ogeo[oi], gj = a.ogeo[oj];
+            const float4 xi = a.oaux[oi], xj = a.oaux[oj];
+            DevStructure si = sa.st;
+            if(SPATIAL) d_structure_at(si, si.obs_idx[oi]);   // corr(p1, p2) takes the scales at its FIRST point (structure.cpp:188-214)
+            const double c = (double)d_corr(si, gi.x, gi.y, gi.z, gi.w, xi.x, gj.x, gj.y, gj.z, gj.w, xj.x, false);
+            M[(size_t)i * W + j] = c + (i == j ? (double)xi.w : 0.0);
+        }
+        for(int i = tid; i < n; i += 256) {
+            const unsigned long long key = keys[i];
+            const float4 x4 = a.oaux[~(unsigned)(key & 0xffffffffull)];
+            const double d = (double)x4.y - (double)x4.z;
+            M[(size_t)i * W + n] = d;
+            M[(size_t)i * W + n + 1] = (double)__uint_as_float((unsigned)(key >> 32));
+            maxInc = fmaxf(maxInc, (float)d); minInc = fminf(minInc, (float)d);
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- Gaussian elimination with partial pivoting on (A | d | g^T) -------------------------------------------------------------------
+        // inc = G A^-1 d and a00 = G A^-1 G^T need u = A^-1 d and v = A^-1 G^T: both right-hand sides ride along
+        bool singular = false;
+        for(int k = 0; k < n; ++k) {
+            double best = -1.0; int bi = -1;
+            for(int i = k + tid; i < n; i += 256) { const double v = fabs(M[(size_t)i * W + k]); if(v > best) { best = v; bi = i; } }
+            s_red[0][tid] = best; s_idx[tid] = bi;
+            __syncthreads();
+            for(int off = 128; off > 0; off >>= 1) {
+                if(tid < off && (s_red[0][tid + off] > s_red[0][tid] || (s_red[0][tid + off] == s_red[0][tid] && s_idx[tid + off] >= 0 && (s_idx[tid] < 0 || s_idx[tid + off] < s_idx[tid])))) {
+                    s_red[0][tid] = s_red[0][tid + off]; s_idx[tid] = s_idx[tid + off];
+                }
+                __syncthreads();
+            }
+            if(tid == 0) s_piv = (s_red[0][0] > 0.0 && s_red[0][0] < INFINITY) ? s_idx[0] : -1;
+            __syncthreads();
+            const int p = s_piv;
+            if(p < 0) { singular = true; break; }
+            // swap rows k and p (columns k .. n + 1), stage the pivot row
+            for(int j = k + tid; j < W; j += 256) {
+                const double vk = M[(size_t)k * W + j], vp = M[(size_t)p * W + j];
+                M[(size_t)k * W + j] = vp; M[(size_t)p * W + j] = vk;
+                if(j - k < HUGE_ROW) s_row[j - k] = vp;
+            }
+            __threadfence_block();
+            __syncthreads();
+            const double pinv = 1.0 / s_row[0];
+            const int ti = tid >> 4, tk = tid & 15;
+            for(int i = k + 1 + ti; i < n; i += 16) {
+                const double f = M[(size_t)i * W + k] * pinv;
+                if(f != 0.0)
+                    for(int j = k + 1 + tk; j < W; j += 16) {
+                        const double pr = (j - k < HUGE_ROW) ? s_row[j - k] : M[(size_t)k * W + j];
+                        M[(size_t)i * W + j] -= f * pr;
+                    }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        if(singular) { if(tid == 0) atomicOr(a.err, ERR_SINGULAR); __syncthreads(); continue; }
+        // ---- back substitution for the two right-hand sides (columns n, n + 1 become u, v) ----------------------------------------------
+        for(int r = n - 1; r >= 0; --r) {
+            double su = 0.0, sv = 0.0;
+            for(int j = r + 1 + tid; j < n; j += 256) { const double m = M[(size_t)r * W + j]; su += m * M[(size_t)j * W + n]; sv += m * M[(size_t)j * W + n + 1]; }
+            s_red[0][tid] = su; s_red[1][tid] = sv;
+            __syncthreads();
+            for(int off = 128; off > 0; off >>= 1) { if(tid < off) { s_red[0][tid] += s_red[0][tid + off]; s_red[1][tid] += s_red[1][tid + off]; } __syncthreads(); }
+            if(tid == 0) {
+                const double dinv = 1.0 / M[(size_t)r * W + r];
+                M[(size_t)r * W + n] = (M[(size_t)r * W + n] - s_red[0][0]) * dinv;
+                M[(size_t)r * W + n + 1] = (M[(size_t)r * W + n + 1] - s_red[1][0]) * dinv;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        // increment = G u, K G^T = G v (oi.cpp:315-316,336); G in the ORIGINAL row order is rho of keys[i]: the row swaps permuted
+        // equations, not unknowns, so u_i and v_i still belong to observation i
+        double inc = 0.0, a00 = 0.0;
+        for(int i = tid; i < n; i += 256) {
+            const double g = (double)__uint_as_float((unsigned)(keys[i] >> 32));
+            inc += g * M[(size_t)i * W + n]; a00 += g * M[(size_t)i * W + n + 1];
+        }
+        s_red[0][tid] = inc; s_red[1][tid] = a00; s_mm[0][tid] = maxInc; s_mm[1][tid] = minInc;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) {
+            if(tid < off) {
+                s_red[0][tid] += s_red[0][tid + off]; s_red[1][tid] += s_red[1][tid + off];
+                s_mm[0][tid] = fmaxf(s_mm[0][tid], s_mm[0][tid + off]); s_mm[1][tid] = fminf(s_mm[1][tid], s_mm[1][tid + off]);
+            }
+            __syncthreads();
+        }
+        if(tid == 0) {
+            float increment = (float)s_red[0][0];   // oi.cpp:317
+            const float mx = s_mm[0][0], mn = s_mm[1][0];
+            if(!a.allow_extrap) {                   // oi.cpp:318-334
+                if(mx > 0 && increment > mx) increment = mx;
+                else if(mx < 0 && increment > 0) increment = mx;
+                else if(mn < 0 && increment < mn) increment = mn;
+                else if(mn > 0 && increment < 0) increment = mn;
+            }
+            a.out[cell] = bg + increment;                                                // oi.cpp:335
+            if(a.out_var) a.out_var[cell] = (float)((double)bvar * (1.0 - s_red[1][0]));   // oi.cpp:337
+        }
+        __syncthreads();
+    }
+}
 // -------------------------------------------------------------------------------------------
 // host entry point
 // -------------------------------------------------------------------------------------------
@@ -775,8 +960,9 @@ struct OiWorkspace {
     DevBuf<unsigned long long> status;
     unsigned long long* h_status = nullptr;   // pinned host mirror
     DevBuf<int> cell_idx, obs_idx, fb_list, fb_list2, fb_list3, big_list;
-    DevBuf<unsigned long long> big_keys;
-    DevBuf<double> big_mat;
+    DevBuf<unsigned long long> big_keys, huge_keys;
+    DevBuf<double> big_mat, huge_mat;
+    DevBuf<int> huge_list;
     hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr;
 };
 thread_local OiWorkspace g_ws;
@@ -981,7 +1167,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     ws.status.get(SB);
     if(!ws.h_status) GPP_HIP(hipHostMalloc((void**)&ws.h_status, SB * sizeof(unsigned long long), hipHostMallocDefault));
     int* const d_ints = reinterpret_cast<int*>(ws.status.p);
-    int* const d_err = d_ints, *const d_fb_count = d_ints + 1, *const d_big_count = d_ints + 4;
+    int* const d_err = d_ints, *const d_fb_count = d_ints + 1, *const d_big_count = d_ints + 4, *const d_huge_count = d_ints + 5;
     unsigned long long* const d_counters = ws.status.p + 8;
     GPP_HIP(hipMemsetAsync(ws.status.p, 0, SB * sizeof(unsigned long long), stream()));
     hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
@@ -1066,12 +1252,30 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const bool memo_hit = memo.points == (const void*)points && memo.h == a.s.st.h && memo.v == a.s.st.v && memo.w == a.s.st.w && memo.max_points == max_points;
     const bool memo_says_no = memo_hit && memo.declined > 0.5f;   // more than half of the tiles went to k_oi last time: skip the first pass
     const bool use_union = !use_lu && N == 32 && want_union && !memo_says_no && !getenv("GPP_OI_NO_UNION");
-    // cells with more usable observations than the 62-row tile holds are listed for k_oi_big (symmetric systems only)
-    const bool big_ok = N == 62 && !use_lu && !spatial;
+    // cells with more usable observations than the 62-row tile holds are listed: symmetric systems go to k_oi_big (Cholesky, up
+    // to BIG_N observations), what that kernel cannot hold and every listed cell of a non-symmetric or spatially varying
+    // structure to k_oi_huge (pivoted elimination in HBM scratch, no capacity of its own)
+    const bool big_ok = N == 62;
     if(big_ok) {
         ws.big_list.get((size_t)C);
         a.big_list = ws.big_list.p; a.big_count = d_big_count;
     }
+    auto run_huge = [&](const int* d_list, const int* d_count, const int ncells) {
+        // scratch for the worst case of this call: every observation a candidate, max_points (or all of them) selected
+        size_t kcap = 1; while(kcap < (size_t)S) kcap <<= 1;
+        const size_t ncap = (max_points > 0) ? (size_t)std::min(max_points, S) : (size_t)S;
+        const size_t per_wg = ncap * (ncap + 2) * sizeof(double) + kcap * sizeof(unsigned long long);
+        size_t budget = (size_t)16 << 30;   // 16 GB of the 288 GB for this rarely used path
+        if(getenv("GPP_OI_HUGE_BUDGET_MB")) budget = (size_t)atol(getenv("GPP_OI_HUGE_BUDGET_MB")) << 20;
+        if(per_wg > budget) runtime("optimal_interpolation: a grid point may select more observations than the scratch budget of the general kernel holds (set max_points, or raise GPP_OI_HUGE_BUDGET_MB)");
+        const int nwg = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)ncells, 512), budget / per_wg));
+        a.huge_kcap = (int)kcap; a.huge_ncap = (int)ncap;
+        a.huge_keys = ws.huge_keys.get((size_t)nwg * kcap);
+        a.huge_mat = ws.huge_mat.get((size_t)nwg * ncap * (ncap + 2));
+        if(spatial) hipLaunchKernelGGL(k_oi_huge<true>, dim3(nwg), dim3(256), 0, stream(), a, d_list, d_count);
+        else hipLaunchKernelGGL(k_oi_huge<false>, dim3(nwg), dim3(256), 0, stream(), a, d_list, d_count);
+        GPP_HIP(hipGetLastError());
+    };
     bool ran_union = false;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
@@ -1152,14 +1356,28 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             memo.points = points; memo.h = a.s.st.h; memo.v = a.s.st.v; memo.w = a.s.st.w; memo.max_points = max_points;
             memo.declined = (float)nfb[0] / (float)a.ntiles;
         }
-        if(big_ok && !use_lu) {
+        if(big_ok) {
             const int nbig = h_ints[4];
-            if(nbig > 0) {
+            if(nbig > 0 && !use_lu && !getenv("GPP_OI_NO_BIG")) {
                 const int nwg = std::min(nbig, 256);
                 a.big_keys = ws.big_keys.get((size_t)nwg * BIG_CAND);
                 a.big_mat = ws.big_mat.get((size_t)nwg * (BIG_N + 2) * BIG_N);
+                ws.huge_list.get((size_t)nbig);
+                a.huge_list = ws.huge_list.p; a.huge_count = d_huge_count;
                 hipLaunchKernelGGL(k_oi_big, dim3(nwg), dim3(256), 0, stream(), a);
                 GPP_HIP(hipGetLastError());
+                GPP_HIP(hipEventRecord(ws.e1, stream()));
+                fetch();
+                g_stats.big_cells = nbig;
+                const int nhuge = h_ints[5];
+                if(nhuge > 0) {   // beyond BIG_N observations / BIG_CAND candidates
+                    run_huge(ws.huge_list.p, d_huge_count, nhuge);
+                    GPP_HIP(hipEventRecord(ws.e1, stream()));
+                    fetch();
+                }
+            }
+            else if(nbig > 0) {   // non-symmetric / spatially varying structure (or the retry after a non-positive pivot)
+                run_huge(ws.big_list.p, d_big_count, nbig);
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
                 g_stats.big_cells = nbig;
@@ -1167,7 +1385,6 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         }
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
-            a.big_list = nullptr; a.big_count = nullptr;   // (the LU path has no large-n kernel: it fails loudly there)
             g_stats.fallback_tiles = a.ntiles;
             GPP_HIP(hipMemsetAsync(ws.status.p, 0, SB * sizeof(unsigned long long), stream()));
             continue;
@@ -1197,7 +1414,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
 #endif
     if(getenv("GPP_SCAN_STATS")) { fprintf(stderr, "[gpp] wave-level insertions per tile histogram:"); for(int i = 0; i < 70; i++) fprintf(stderr, " %d:%llu", i, counters[4 + i]); fprintf(stderr, "\n"); }
     if(err & ERR_SINGULAR) runtime("optimal_interpolation: local (P+R) matrix is singular");
-    if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more usable observations per grid point than the GPU path holds (512 with a symmetric structure function, 62 with a non-symmetric or spatially varying one; max_points == 0 or too large): reduce max_points");
+    if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more usable observations at a grid point than the scratch of the general kernel was sized for");
     return GPP_OK;
     GPP_CATCH
 }

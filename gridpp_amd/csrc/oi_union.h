@@ -49,6 +49,12 @@ struct OiArgs {
     int* big_count;
     unsigned long long* big_keys;   // per workgroup of k_oi_big: BIG_CAND candidate keys (sorted there)
     double* big_mat;         // per workgroup: (BIG_N + 2) x BIG_N matrix
+    // k_oi_big -> k_oi_huge: cells beyond BIG_N / BIG_CAND, and every listed cell of a non-symmetric or spatially varying structure
+    int* huge_list;
+    int* huge_count;
+    unsigned long long* huge_keys;  // per workgroup: huge_kcap candidate keys
+    double* huge_mat;        // per workgroup: huge_ncap x (huge_ncap + 2) augmented matrix
+    int huge_kcap, huge_ncap;
 };
 
 #define GPP_NSLOT 512

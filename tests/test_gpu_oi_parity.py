@@ -226,13 +226,60 @@ def test_more_than_62_points_large_n_kernel(max_points, S):
     check(var, rvar)
 
 
-def test_too_many_points_fails_loudly():
-    import gridpp_amd as gridpp
+def test_more_points_than_the_large_n_kernel_holds():
+    """700 usable observations at every grid point (max_points = 0): beyond k_oi_big's 512, taken by the general kernel
+    (k_oi_huge: pivoted elimination in HBM scratch) -- the reference has no limit (oi.cpp:262-315)."""
     c = make_case(80, 4, 4, 700)
-    grid = gridpp.Grid(c["lats"], c["lons"])
-    points = gridpp.Points(c["plat"], c["plon"])
-    with pytest.raises(RuntimeError, match="more usable observations"):
-        gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], gridpp.BarnesStructure(40000), 0)
+    out, ref, var, rvar = run_both(c, 40000, 0, 0, 0, full=True)
+    check(out, ref)
+    check(var, rvar)
+    out, ref = run_both(c, 40000, 0, 0, 600, allow_extrap=False)
+    check(out, ref)
+
+
+def test_large_n_with_the_pivoted_solver(monkeypatch):
+    """More than 62 usable observations on the LU path (non-symmetric systems, retry after a non-positive pivot): the general kernel."""
+    import gridpp_amd as gridpp
+    c = make_case(83, 7, 9, 180)
+    monkeypatch.setenv("GPP_OI_FORCE_LU", "1")
+    out, ref, var, rvar = run_both(c, 40000, 0, 0, 0, full=True)
+    check(out, ref)
+    check(var, rvar)
+    assert gridpp.oi_last_stats()["big_cells"] == 63
+    out, ref = run_both(c, 40000, 0, 0, 100, allow_extrap=False)
+    check(out, ref)
+
+
+@pytest.mark.parametrize("kind", ["Barnes", "Soar"])
+def test_spatially_varying_structure_large_n(kind):
+    """A spatially varying structure with more than 62 usable observations per grid point (max_points = 0 and 80)."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    c = make_case(92, 10, 12, 140, with_elev=True)
+    Y, X = c["bg"].shape
+    rng = np.random.default_rng(6)
+    base = {"Barnes": 30000, "Soar": 9000}[kind]
+    hf = (base * rng.uniform(0.8, 1.2, (Y, X))).astype(np.float32)
+    vf = (300 * rng.uniform(0.7, 1.3, (Y, X))).astype(np.float32)
+    wf = (0.6 * rng.uniform(0.7, 1.3, (Y, X))).astype(np.float32)
+    min_rho = 0.0013
+    grid = gridpp.Grid(c["lats"], c["lons"], c["gelev"], c["glaf"])
+    points = gridpp.Points(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    st = getattr(gridpp, kind + "Structure")(grid, hf, vf, wf, min_rho)
+    ones_g, ones_p = np.ones((Y, X), np.float32), np.ones(c["obs"].size, np.float32)
+    og = O.Pts(c["lats"].ravel(), c["lons"].ravel(), c["gelev"].ravel(), c["glaf"].ravel())
+    op = O.Pts(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    ci, oi = np.arange(Y * X), O.nearest_indices(og, op)
+    Rf = np.array([O.structure_localization(kind, h, min_rho) for h in hf.ravel()], np.float32)
+    cp = [a.ravel()[ci] for a in (hf, vf, wf)] + [Rf[ci]]
+    opar = [a.ravel()[oi] for a in (hf, vf, wf)] + [Rf[oi]]
+    ost = O.Struct(kind, base)
+    for mp in (0, 80):
+        out, var = gridpp.optimal_interpolation_full(grid, c["bg"], ones_g, points, c["obs"], c["ratios"], c["pbg"], ones_p, st, mp)
+        ref, rvar = O.oi_full_generic(og, c["bg"].ravel(), ones_g.ravel(), op, c["obs"], c["ratios"], c["pbg"], ones_p, ost, mp, True, cp, opar)
+        check(np.asarray(out), ref.reshape(Y, X))
+        check(np.asarray(var), rvar.reshape(Y, X))
+        assert gridpp.oi_last_stats()["big_cells"] > 0
 
 
 # ---- spatially varying structure functions (structure.cpp:168-214) ------------------------------------------------------
