@@ -911,7 +911,8 @@ def neighbourhood_search(array, search_array, halfwidth, search_target_min, sear
             ap = apply_array.contiguous().to(torch.int32)
         else:
             ap = np.ascontiguousarray(np.asarray(apply_array).astype(np.int32))
-        if np.size(apply_array) > 1 and tuple(ap.shape) != _shape(array):
+        # (the reference indexes apply_array[y][x] for every cell whatever its size; anything but a full-size mask reads out of bounds there)
+        if tuple(ap.shape) != _shape(array):
             raise ValueError("apply_array must either be empty or same size as array")
     out = _empty_like_field(_shape(array), array)
     ny, nx = _shape(array)

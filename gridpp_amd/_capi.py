@@ -73,6 +73,14 @@ SIGNATURES = {
     "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
     "gpp_optimal_interpolation_ensi": [vp, vp, C.c_int, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],
     "gpp_ensi_last_kernel_ms": [fp],
+    "gpp_row_tile": [C.c_int, C.c_int, C.c_int, ip, ip],
+    "gpp_comm_unique_id": [C.c_char_p],
+    "gpp_comm_init": [C.c_int, C.c_int, C.c_char_p],
+    "gpp_comm_rank": [ip, ip],
+    "gpp_comm_broadcast": [vp, C.c_size_t, C.c_int],
+    "gpp_comm_broadcast_host": [vp, C.c_size_t, C.c_int],
+    "gpp_comm_halo_exchange": [vp, C.c_int, C.c_size_t, C.c_int, vp, ip],
+    "gpp_comm_destroy": [],
     "gpp_optimal_interpolation_ensi_multi": [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],
     "gpp_calc_statistic": [vp, C.c_long, C.c_int, C.c_int, vp, C.c_int],
     "gpp_calc_quantile": [vp, C.c_long, C.c_int, vp, C.c_long, vp, C.c_int],

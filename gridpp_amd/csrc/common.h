@@ -137,7 +137,9 @@ struct gpp_points {
     bool elev_uniform = true, laf_uniform = true;   // every point has the same elevation / laf (or none has one)
     // memo of the last OI call with this point set as the background: did k_oi_union pay? (same observations handle and
     // structure scales -> same geometry -> same answer; the observation VALUES do not matter)
-    struct { const void* points = nullptr; float h = 0, v = 0, w = 0; int max_points = -1; float declined = 0; } union_memo;
+    // (keyed on the observation set's serial number, not its address: a new handle may reuse the address of a destroyed one)
+    struct { unsigned long long points_id = 0; float h = 0, v = 0, w = 0; int kh = -1, kv = -1, kw = -1, cv = -1; int max_points = -1; float declined = 0; } union_memo;
+    unsigned long long serial = 0;   // unique per handle, assigned at creation
     gpp_obs_index* obs_index = nullptr;
     gpp_nn_index* nn_index = nullptr;
     void to_device();

@@ -1249,7 +1249,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     //  white-noise elevations none does and the first pass costs a few per cent before the lists hand everything to k_oi.)
     const bool want_union = getenv("GPP_OI_UNION") ? atoi(getenv("GPP_OI_UNION")) != 0 : true;
     auto& memo = bgrid->union_memo;
-    const bool memo_hit = memo.points == (const void*)points && memo.h == a.s.st.h && memo.v == a.s.st.v && memo.w == a.s.st.w && memo.max_points == max_points;
+    const bool memo_hit = memo.points_id == points->serial && memo.h == a.s.st.h && memo.v == a.s.st.v && memo.w == a.s.st.w && memo.kh == a.s.st.kh &&
+                          memo.kv == a.s.st.kv && memo.kw == a.s.st.kw && memo.cv == a.s.st.cv && memo.max_points == max_points;
     const bool memo_says_no = memo_hit && memo.declined > 0.5f;   // more than half of the tiles went to k_oi last time: skip the first pass
     const bool use_union = !use_lu && N == 32 && want_union && !memo_says_no && !getenv("GPP_OI_NO_UNION");
     // cells with more usable observations than the 62-row tile holds are listed: symmetric systems go to k_oi_big (Cholesky, up
@@ -1353,7 +1354,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         g_stats.fallback_tiles = nfb[0];
         g_stats.fallback_subtiles = nfb[2];
         if(ran_union) {
-            memo.points = points; memo.h = a.s.st.h; memo.v = a.s.st.v; memo.w = a.s.st.w; memo.max_points = max_points;
+            memo.points_id = points->serial; memo.h = a.s.st.h; memo.v = a.s.st.v; memo.w = a.s.st.w; memo.max_points = max_points;
+            memo.kh = a.s.st.kh; memo.kv = a.s.st.kv; memo.kw = a.s.st.kw; memo.cv = a.s.st.cv;
             memo.declined = (float)nfb[0] / (float)a.ntiles;
         }
         if(big_ok) {

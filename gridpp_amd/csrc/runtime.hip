@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <thread>
 #include <mutex>
+#include <atomic>
 
 namespace gpp {
 
@@ -19,6 +20,7 @@ int fail(int code, const char* fmt, ...) {
 }
 
 static hipStream_t g_stream = nullptr;
+static std::atomic<int> g_live_handles{0};   // gpp_points alive (gpp_set_device refuses to switch under them)
 static int g_device = -1;
 static std::mutex g_mutex;
 
@@ -62,6 +64,9 @@ extern "C" int gpp_set_device(int device) {
     if(device < 0 || device >= count) invalid("device index out of range");
     GPP_HIP(hipSetDevice(device));
     if(g_device != device) {
+        // every handle, workspace and the stream live on the device that was current at the first call: moving to another one
+        // afterwards would mix pointers of two devices
+        if(g_stream && g_live_handles.load() > 0) invalid("gpp_set_device: the device cannot change while point sets / fields created on the current one are alive");
         if(g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
         g_device = device;
         GPP_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
@@ -286,6 +291,7 @@ void gpp_free_obs_index(gpp_obs_index*);
 struct gpp_nn_index { int unused; };
 void gpp_free_nn_index(gpp_nn_index* p) { delete p; }
 gpp_points::~gpp_points() {
+    g_live_handles.fetch_sub(1);
     if(obs_index) gpp_free_obs_index(obs_index);
     if(nn_index) gpp_free_nn_index(nn_index);
 }
@@ -299,6 +305,7 @@ static gpp_points* make_points(const T* lats, const T* lons, const T* elevs, con
     if(n < 0) invalid("negative size");
     if(n > 0 && (!lats || !lons)) invalid("lats/lons are NULL");
     std::unique_ptr<gpp_points> p(new gpp_points);
+    { static std::atomic<unsigned long long> next_serial{1}; p->serial = next_serial.fetch_add(1); g_live_handles.fetch_add(1); }
     p->n = n; p->ny = ny; p->nx = nx; p->type = type;
     // do the vertical / land-area-fraction factors of a structure function vary over this point set at all?
     auto uniform = [](const T* v, int m) {   // absent (all NaN: points.cpp:23-30, grid.cpp:41-54), all invalid, or all valid and equal

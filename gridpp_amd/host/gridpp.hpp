@@ -394,6 +394,39 @@ inline vec3 optimal_interpolation_ensi_multi_utem(const Grid& bgrid, const vec2&
                                 allow_extrapolation), background.size(), background.empty() ? 0 : background[0].size());
 }
 
+// ---- multi-GPU: one process per GPU, contiguous row tiles, observation values broadcast from rank 0 over RCCL --------
+// No counterpart in include/gridpp.h (the reference's parallelism is OpenMP).  Usage, on every rank:
+//     gridpp::multi::init(rank, world, id);                      // id from multi::unique_id() on rank 0, distributed by the caller
+//     multi::row_tile(Y, rank, world, r0, r1);                   // build Grid(lats[r0:r1], lons[r0:r1]) and the full Points
+//     tile = multi::optimal_interpolation(tile_grid, tile_background, points, pobs, pratios, pbackground, structure, max_points);
+// pobs / pratios / pbackground need valid contents on rank 0 only (the other ranks pass vectors of the right size).
+namespace multi {
+inline void row_tile(int ny, int rank, int world, int& row0, int& row1) { detail::check(gpp_row_tile(ny, rank, world, &row0, &row1)); }
+inline std::string unique_id() { std::string id(128, '\0'); detail::check(gpp_comm_unique_id(&id[0])); return id; }
+inline void init(int rank, int world, const std::string& id) {
+    if(id.size() != 128) throw std::invalid_argument("multi::init: the id must hold 128 bytes");
+    detail::check(gpp_comm_init(rank, world, id.data()));
+}
+inline void destroy() { detail::check(gpp_comm_destroy()); }
+inline void broadcast(vec& values, int root = 0) { detail::check(gpp_comm_broadcast_host(values.data(), values.size() * sizeof(float), root)); }
+inline vec2 optimal_interpolation(const Grid& tile_grid, const vec2& tile_background, const Points& points, vec& pobs, vec& pratios, vec& pbackground,
+                                  const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
+    if((int)pobs.size() != points.size() || (int)pratios.size() != points.size() || (int)pbackground.size() != points.size())
+        throw std::invalid_argument("Observations / ratios / background and points size mismatch");
+    vec block;                                   // one broadcast for the three vectors
+    block.reserve(3 * pobs.size());
+    block.insert(block.end(), pobs.begin(), pobs.end());
+    block.insert(block.end(), pratios.begin(), pratios.end());
+    block.insert(block.end(), pbackground.begin(), pbackground.end());
+    broadcast(block, 0);
+    const size_t S = pobs.size();
+    std::copy(block.begin(), block.begin() + S, pobs.begin());
+    std::copy(block.begin() + S, block.begin() + 2 * S, pratios.begin());
+    std::copy(block.begin() + 2 * S, block.end(), pbackground.begin());
+    return gridpp::optimal_interpolation(tile_grid, tile_background, points, pobs, pratios, pbackground, structure, max_points, allow_extrapolation);
+}
+}  // namespace multi
+
 // ---- neighbourhood (include/gridpp.h:588-716) ---------------------------------------------------------------
 namespace detail {
 inline vec2 nb(const vec& f, size_t Y, size_t X, size_t E, int is3d, int halfwidth, Statistic statistic) {

@@ -30,6 +30,7 @@
 #ifndef GRIDPP_HIP_H
 #define GRIDPP_HIP_H
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -268,6 +269,20 @@ int gpp_optimal_interpolation_ensi_multi(int variant, gpp_points* bgrid, const f
                                          const float* background_corr, int ne, gpp_points* points, const float* pobs,
                                          const float* pratios, const float* pbackground, const float* pbackground_corr,
                                          const gpp_structure* structure, int max_points, int allow_extrapolation, float* out, int mem);   /* hipEvent time of the last EnSI kernel (diagnostics / bench) */
+
+/* ---- multi-GPU helpers (no counterpart in the reference, whose parallelism is OpenMP, src/api/oi.cpp:221) --------
+ * One process per GPU.  The output grid is cut into contiguous row tiles (gpp_row_tile), every rank builds its tile's Grid and
+ * the full Points, rank 0 owns the observation values of a step and broadcasts them (gpp_comm_broadcast: ncclBroadcast over
+ * xGMI on the library stream), the neighbourhood filters get their halfwidth-row halos from the neighbouring ranks
+ * (gpp_comm_halo_exchange: ncclSend / ncclRecv).  There is no other cross-tile dependence.  RCCL is loaded on first use. */
+int gpp_row_tile(int ny, int rank, int world, int* row0, int* row1);
+int gpp_comm_unique_id(char* id128);                              /* rank 0; the caller distributes the 128 bytes */
+int gpp_comm_init(int rank, int world, const char* id128);        /* collective; after gpp_set_device */
+int gpp_comm_rank(int* rank, int* world);                         /* (0, 1) without a communicator */
+int gpp_comm_broadcast(void* device_buf, size_t bytes, int root); /* in place, device memory, library stream */
+int gpp_comm_broadcast_host(void* host_buf, size_t bytes, int root); /* host memory, staged through HBM */
+int gpp_comm_halo_exchange(const float* tile, int rows, size_t row_floats, int halfwidth, float* padded, int* top_rows);
+int gpp_comm_destroy(void);
 
 /* ---- neighbourhood filters (src/api/neighbourhood.cpp) -------------------------
  * input is [ny][nx] (is3d == 0, ne must be 1) or [ny][nx][ne] (is3d == 1); out is

@@ -144,6 +144,23 @@ int main() {
         try { optimal_interpolation_ensi_multi_ebesc(gp, vec{1, 1, 1}, bg2, ob, pobs, vec{1}, pbg, st, 5); } catch(const std::invalid_argument&) { threw = true; }
         CHECK(threw);
     }
+    // multi-GPU helpers through RCCL with a world of one: the same code path as N ranks (ncclCommInitRank, ncclBroadcast on the library
+    // stream), checked here as far as one GPU allows; row tiles partition the rows
+    {
+        int r0, r1, covered = 0;
+        for(int r = 0; r < 3; r++) { multi::row_tile(10, r, 3, r0, r1); CHECK(r0 == covered); covered = r1; }
+        CHECK(covered == 10);
+        multi::init(0, 1, multi::unique_id());
+        vec2 la = {{0, 0}, {0.01f, 0.01f}}, lo = {{0, 0.01f}, {0, 0.01f}};
+        Grid g(la, lo);
+        Points ob(vec{0}, vec{0});
+        vec pobs = {1}, prat = {1}, pbg = {0};
+        BarnesStructure st(10000);
+        vec2 t = multi::optimal_interpolation(g, vec2{{0, 0}, {0, 0}}, ob, pobs, prat, pbg, st, 5);
+        vec2 u = optimal_interpolation(g, vec2{{0, 0}, {0, 0}}, ob, pobs, prat, pbg, st, 5);
+        CHECK(t[0][0] == u[0][0] && t[1][1] == u[1][1] && std::fabs(t[0][0] - 0.5f) < 1e-6);
+        multi::destroy();
+    }
     std::printf("gridpp.hpp host API: all checks passed (version %s)\n", version().c_str());
     return 0;
 }
