@@ -1289,3 +1289,86 @@ def ensi_last_kernel_ms():
     ms = C.c_float(0)
     check(lib().gpp_ensi_last_kernel_ms(C.byref(ms)))
     return ms.value
+
+
+# ---- the typemap test helpers of the reference (src/api/swig.cpp:6-100, include/gridpp.h:1680-1702): they exist so that
+# tests/test_swig.py can pin the binding layer -- element types of results, accepted input types, ndim checks, zero-size
+# dimensions.  Here they exercise the same conversion helper (_vec) every entry point of this mirror goes through.
+_SWIG_DEFAULT = -1          # swig_default_value
+
+
+def _ivec(a, ndim, name="array"):
+    arr = np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+    if arr.ndim != ndim:
+        if arr.size == 0 and arr.ndim <= ndim:
+            return arr.reshape((0,) * ndim)
+        raise RuntimeError("%s must have %d dimensions, got %d" % (name, ndim, arr.ndim))
+    return arr
+
+
+def _seq_sum(a):
+    total = np.float32(0)
+    for v in a.ravel():
+        total = np.float32(total + v)
+    return float(total)
+
+
+def test_vec_input(input):
+    return _seq_sum(_vec(input, 1, "input"))
+
+
+def test_ivec_input(input):
+    return int(_ivec(input, 1, "input").sum())
+
+
+def test_vec2_input(input):
+    return _seq_sum(_vec(input, 2, "input"))
+
+
+def test_vec3_input(input):
+    return _seq_sum(_vec(input, 3, "input"))
+
+
+def test_vec_output():
+    return np.full(3, _SWIG_DEFAULT, np.float32)
+
+
+def test_vec2_output():
+    return np.full((3, 3), _SWIG_DEFAULT, np.float32)
+
+
+def test_vec3_output():
+    return np.full((3, 3, 3), _SWIG_DEFAULT, np.float32)
+
+
+def test_ivec_output():
+    return np.full(3, _SWIG_DEFAULT, np.int32)
+
+
+def test_ivec2_output():
+    return np.full((3, 3), _SWIG_DEFAULT, np.int32)
+
+
+def test_ivec3_output():
+    return np.full((3, 3, 3), _SWIG_DEFAULT, np.int32)
+
+
+def test_vec_argout():
+    return 0.0, np.full(10, _SWIG_DEFAULT, np.float32)
+
+
+def test_vec2_argout():
+    return 0.0, np.full((10, 10), _SWIG_DEFAULT, np.float32)
+
+
+def test_array(v):
+    return _vec(v, 1, "v")
+
+
+def test_not_implemented_exception():
+    raise RuntimeError("Not implemented")     # gridpp::not_implemented_exception -> RuntimeError (swig/gridpp.i:21-40)
+
+
+for _f in (test_vec_input, test_ivec_input, test_vec2_input, test_vec3_input, test_vec_output, test_vec2_output, test_vec3_output, test_ivec_output,
+           test_ivec2_output, test_ivec3_output, test_vec_argout, test_vec2_argout, test_array, test_not_implemented_exception):
+    _f.__test__ = False       # not pytest tests

@@ -119,3 +119,29 @@ def test_config5_ensi_2500x2500x50_sample():
         err = np.abs(out[k, cols].astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
         assert err.max() < 1e-5, err.max()
     assert np.abs(out - bg).max() > 0.1
+
+
+def test_config5_ensi_full_grid_with_oracle_sample():
+    """The FULL config 5 (2500 x 2500 x 50 members, 5 000 obs, max_points 30) in one call, inputs resident in HBM, checked against
+    the oracle on 600 grid points: a regular lattice that includes the four corners and the edges, plus random points."""
+    import torch
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    from tools.bench_cases import ensi_inputs
+    ny = nx = 2500
+    E, S = 50, 5000
+    lats, lons, bg, plat, plon, pbg, obs, sig = ensi_inputs(ny, nx, E, S)
+    out = gridpp.optimal_interpolation_ensi(gridpp.Grid(lats, lons), bg, gridpp.Points(plat, plon), obs, sig, pbg, gridpp.BarnesStructure(10000), 30)
+    assert tuple(out.shape) == (ny, nx, E) and bool(torch.isfinite(out).all())
+    rng = np.random.default_rng(77)
+    yy, xx = np.meshgrid(np.linspace(0, ny - 1, 15).astype(int), np.linspace(0, nx - 1, 20).astype(int), indexing="ij")
+    ys = np.concatenate([yy.ravel(), rng.integers(0, ny, 300)])
+    xs = np.concatenate([xx.ravel(), rng.integers(0, nx, 300)])
+    iy, ix = torch.from_numpy(ys).cuda(), torch.from_numpy(xs).cuda()
+    got = out[iy, ix].cpu().numpy()
+    bgs = bg[iy, ix].cpu().numpy()
+    ref = O.oi_ensi(O.Pts(lats[ys, xs], lons[ys, xs]), bgs, O.Pts(plat, plon), obs.cpu().numpy(), sig.cpu().numpy(), pbg.cpu().numpy(),
+                    O.Barnes(10000), 30)
+    err = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
+    assert err.max() < 1e-5, err.max()
+    assert np.abs(got - bgs).max() > 0.1
