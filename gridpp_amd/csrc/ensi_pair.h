@@ -36,6 +36,10 @@ __device__ __forceinline__ double dpp_d(const double old, const double v) {
 }
 // value of the partner lane (byte address paddr = 4 * partner lane) through the LDS crossbar: keeps the VALU free, and the odd
 // phase has no DPP pattern (bank_mask selects groups of four lanes, not a lane parity)
+// even phase: the partner is the other lane of the pair (2k, 2k+1) -- a quad permute on the VALU, which has issue slots to spare,
+// instead of two more trips through the LDS crossbar, which has not (C5: 515 -> 491 ms; the odd phase done the same way --
+// both wave shifts and a select -- costs three VALU instructions per dword and loses: 509 ms)
+__device__ __forceinline__ double partner_quad(const double v) { return dpp_d<0xB1, 0xf>(v, v); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ double partner_of(const double v, const int paddr) {
     const int lo = __builtin_amdgcn_ds_bpermute(paddr, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(paddr, __double2hiint(v));
@@ -132,8 +136,8 @@ __device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], d
     const int paddr = (ODD ? (idle ? (32 * h + i) : ((i & 1) ? 32 * h + i + 1 : 32 * h + i - 1)) : ((32 * h + i) ^ 1)) << 2;
     // both lanes of a pair compute the same rotation from the same three numbers (the partner receives the leader's off-diagonal
     // entry together with its diagonal entry: one exchange instead of two)
-    const double dpart = partner_of(dg, paddr);
-    const double apart = partner_of(apq, paddr);
+    const double dpart = ODD ? partner_of(dg, paddr) : partner_quad(dg);
+    const double apart = ODD ? partner_of(apq, paddr) : partner_quad(apq);
     double cs, sn, tap;
     jacobi_rotation(leader ? apq : apart, leader ? dg : dpart, leader ? dpart : dg, cs, sn, tap);
     if(idle) { cs = 1.0; sn = 0.0; tap = 0.0; }
@@ -150,10 +154,10 @@ __device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], d
     double pa[16], pb[16];
     double2 ca[8], cb[8];
 #pragma unroll
-    for(int j = 0; j < 16; ++j) pa[j] = partner_of(b[j], paddr);
+    for(int j = 0; j < 16; ++j) pa[j] = ODD ? partner_of(b[j], paddr) : partner_quad(b[j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for(int j = 0; j < 16; ++j) pb[j] = partner_of(b[16 + j], paddr);
+    for(int j = 0; j < 16; ++j) pb[j] = ODD ? partner_of(b[16 + j], paddr) : partner_quad(b[16 + j]);
 #pragma unroll
     for(int j = 0; j < 16; ++j) b[j] = __builtin_fma(alpha, b[j], beta * pa[j]);
     __builtin_amdgcn_sched_barrier(0);
