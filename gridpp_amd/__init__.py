@@ -624,10 +624,16 @@ class MultipleStructure(StructureFunction):
         sh, sv, sw = structure_h._s, structure_v._s, structure_w._s
         kv = sv.kind_v - 1 if sv.kind_v else sv.kind
         kw = sw.kind_w - 1 if sw.kind_w else sw.kind
-        if sh.field or sv.field or sw.field:
-            raise RuntimeError("spatially varying structures inside a MultipleStructure are not on the GPU path")
-        loc = structure_h.localization_distance()
-        self._s = _capi.gpp_structure(sh.kind, sh.h, sv.v, sw.w, sh.min_rho, kv + 1, kw + 1, loc, 0.0, _ST_HAS_LOC, None)
+        if sv.kind_v or sv.kind_w or sw.kind_v or sw.kind_w or sh.kind_v or sh.kind_w:
+            raise RuntimeError("a MultipleStructure inside a MultipleStructure is not on the GPU path")
+        # spatially varying parts: the horizontal scale (and the localization distance) from structure_h's field, the vertical
+        # scale from structure_v's, the laf scale from structure_w's (each at the nearest point of ITS grid to the first point)
+        self._field_owner = [getattr(t, "_field_owner", None) for t in (structure_h, structure_v, structure_w)]
+        if sh.field:
+            loc, flags = 0.0, 0
+        else:
+            loc, flags = structure_h.localization_distance(), _ST_HAS_LOC
+        self._s = _capi.gpp_structure(sh.kind, sh.h, sv.v, sw.w, sh.min_rho, kv + 1, kw + 1, loc, 0.0, flags, sh.field, sv.field, sw.field)
 
 
 class CrossValidation(StructureFunction):

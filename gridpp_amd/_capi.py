@@ -16,7 +16,7 @@ MEM_HOST, MEM_DEVICE, ASYNC, HOST_F64 = 0, 1, 2, 4
 class gpp_structure(C.Structure):
     _fields_ = [("kind", C.c_int), ("h", C.c_float), ("v", C.c_float), ("w", C.c_float), ("min_rho", C.c_float),
                 ("kind_v", C.c_int), ("kind_w", C.c_int), ("loc", C.c_float), ("cv_dist", C.c_float), ("flags", C.c_int),
-                ("field", C.c_void_p)]
+                ("field", C.c_void_p), ("field_v", C.c_void_p), ("field_w", C.c_void_p)]
 
 
 class gpp_oi_stats(C.Structure):

@@ -1005,10 +1005,16 @@ DevStructure gpp_resolve_structure(const gpp_structure* s) {
     d.cv_dist = s->cv_dist;
     if(d.cv && (!is_valid(d.cv_dist) || d.cv_dist < 0)) invalid("Invalid 'dist' in CrossValidation structure");   // :912-913
     d.fh = d.fv = d.fw = d.fR = nullptr; d.cell_idx = d.obs_idx = nullptr;
-    if(s->field) {
+    if(s->field && !s->kind_v && !s->kind_w && !s->field_v && !s->field_w) {   // one spatially varying structure: its own fields
         const gpp_field* f = (const gpp_field*)s->field;
-        if(f->kind != s->kind || s->kind_v || s->kind_w) runtime("a spatially varying structure cannot be mixed into a MultipleStructure on the GPU path");
+        if(f->kind != s->kind) runtime("structure kind and field kind differ");
         d.fh = f->d_h.p; d.fv = f->d_v.p; d.fw = f->d_w.p; d.fR = f->d_R.p;
+    }
+    else if(s->field || s->field_v || s->field_w) {
+        // MultipleStructure with spatially varying parts: gpp_bind_field materialises per-point scales; until then the marker below
+        // tells the callers that the structure is spatial
+        static float dummy = 0;
+        d.fh = d.fv = d.fw = d.fR = &dummy;
     }
     return d;
 }
@@ -1024,8 +1030,54 @@ static const int* field_indices(const gpp_field* f, gpp_points* pts, DevBuf<int>
     gpp_nearest_device(f->grid, pts->d_x.p, pts->d_y.p, pts->d_z.p, pts->n, 1, buf.p);
     return buf.p;
 }
+// per-point scale out[i] = src[idx[i]] (idx NULL: identity) or the constant `value` (src NULL)
+__global__ void k_gather_scale(const float* __restrict__ src, const int* __restrict__ idx, float value, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) out[i] = src ? src[idx ? idx[i] : i] : value;
+}
 void gpp_bind_field(DevStructure& d, const gpp_structure* s, gpp_points* bgrid, gpp_points* points, DevBuf<int>& cbuf, DevBuf<int>& obuf) {
-    if(!s->field) return;
+    if(!s->field && !s->field_v && !s->field_w) return;
+    if(s->kind_v || s->kind_w || s->field_v || s->field_w) {
+        // MultipleStructure(sh, sv, sw) with spatially varying parts (structure.cpp:90-138): corr_h comes from sh with the elevation /
+        // laf of p1 on both sides (its vertical factors are 1), corr_v from sv at zero horizontal distance, corr_w from sw likewise:
+        // per point, h and the localization distance are sh's, v is sv's, w is sw's -- each looked up at the nearest point of ITS
+        // grid.  Materialised once per call for [background points | observations]; the kernels index it like one field.
+        static thread_local DevBuf<float> mh, mv, mw, mR;
+        static thread_local DevBuf<int> tmpi;
+        const int C = bgrid->n, S = points->n, n = C + S;
+        mh.get(n); mv.get(n); mw.get(n); mR.get(n);
+        const float Rconst = (s->flags & GPP_ST_HAS_LOC) ? s->loc : st_localization(s->kind, s->h, s->min_rho);
+        auto fill = [&](const gpp_field* f, const float* src_c, float value, float* out) {
+            // background points, then observations
+            for(int part = 0; part < 2; ++part) {
+                gpp_points* pts = part ? points : bgrid;
+                const int m = part ? S : C;
+                if(m == 0) continue;
+                const int* idx = nullptr;
+                if(f) {
+                    if(f->grid->type != pts->type) invalid("the structure function's grid and the background must have the same coordinate type");
+                    idx = field_indices(f, pts, tmpi);
+                }
+                hipLaunchKernelGGL(k_gather_scale, dim3((m + 255) / 256), dim3(256), 0, stream(), f ? src_c : (const float*)nullptr, idx, value, m, out + (part ? C : 0));
+                GPP_HIP(hipGetLastError());
+                GPP_HIP(hipStreamSynchronize(stream()));   // tmpi is reused by the next lookup
+            }
+        };
+        const gpp_field* fh = (const gpp_field*)s->field;
+        const gpp_field* fv = (const gpp_field*)s->field_v;
+        const gpp_field* fw = (const gpp_field*)s->field_w;
+        fill(fh, fh ? fh->d_h.p : nullptr, s->h, mh.p);
+        fill(fh, fh ? fh->d_R.p : nullptr, Rconst, mR.p);
+        fill(fv, fv ? fv->d_v.p : nullptr, s->v, mv.p);
+        fill(fw, fw ? fw->d_w.p : nullptr, s->w, mw.p);
+        d.fh = mh.p; d.fv = mv.p; d.fw = mw.p; d.fR = mR.p;
+        d.cell_idx = nullptr;                         // identity: entry i belongs to background point i
+        std::vector<int> id(S);
+        for(int i = 0; i < S; i++) id[i] = C + i;     // observation i lives behind the background points
+        obuf.upload(id.data(), id.size());
+        d.obs_idx = obuf.p;
+        return;
+    }
     const gpp_field* f = (const gpp_field*)s->field;
     if(f->grid->type != bgrid->type) invalid("the structure function's grid and the background must have the same coordinate type");
     d.cell_idx = field_indices(f, bgrid, cbuf);
@@ -1064,6 +1116,18 @@ extern "C" int gpp_field_destroy(gpp_field* f) {
 // scalar structure at one location of a spatially varying one (nearest neighbour of (lat, lon) in the field's grid)
 static gpp_structure structure_at(const gpp_structure* s, float lat, float lon) {
     gpp_structure t = *s;
+    if(s->field_v || s->field_w || (s->field && (s->kind_v || s->kind_w))) {   // MultipleStructure with spatially varying parts
+        auto at = [&](const gpp_field* f) {
+            int idx = -1;
+            if(gpp_points_nearest_neighbour(f->grid, &lat, &lon, 1, 1, &idx) != GPP_OK || idx < 0) runtime("structure function grid is empty");
+            return idx;
+        };
+        if(s->field) { const gpp_field* f = (const gpp_field*)s->field; const int k = at(f); t.h = f->h[k]; t.min_rho = f->min_rho; t.loc = f->R[k]; t.flags |= GPP_ST_HAS_LOC; }
+        if(s->field_v) { const gpp_field* f = (const gpp_field*)s->field_v; t.v = f->v[at(f)]; }
+        if(s->field_w) { const gpp_field* f = (const gpp_field*)s->field_w; t.w = f->w[at(f)]; }
+        t.field = t.field_v = t.field_w = nullptr;
+        return t;
+    }
     if(!s->field) return t;
     const gpp_field* f = (const gpp_field*)s->field;
     int idx = -1;

@@ -188,6 +188,7 @@ class MultipleStructure : public StructureFunction {   // src/api/structure.cpp:
         mS.loc = sh.localization_distance();
         mS.flags = GPP_ST_HAS_LOC;
         mS.cv_dist = 0;
+        mS.field = h->field; mS.field_v = v->field; mS.field_w = w->field;   // (this header offers the scalar constructors only: all NULL)
     }
 };
 class CrossValidation : public StructureFunction {     // src/api/structure.cpp:910-944

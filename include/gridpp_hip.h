@@ -212,6 +212,10 @@ typedef struct gpp_structure {
     float cv_dist;   /* CrossValidation distance if flags & GPP_ST_CV */
     int flags;
     struct gpp_field* field;   /* spatially varying form: h, v, w fields (gpp_field_create); NULL = scalar */
+    /* MultipleStructure(sh, sv, sw) with spatially varying parts (structure.cpp:90-138): `field` = sh's (its h and the localization
+     * distance), field_v = sv's (its v), field_w = sw's (its w); NULL = that factor is scalar (v / w above) */
+    struct gpp_field* field_v;
+    struct gpp_field* field_w;
 } gpp_structure;
 /* BarnesStructure(Grid, vec2 h, vec2 v, vec2 w, min_rho) and the Soar/Toar/Powerlaw/Linear equivalents
  * (structure.cpp:168-184,342-358,...): h, v, w are host arrays with one value per point of `grid`

@@ -356,3 +356,54 @@ def test_62_row_tile_groups_share_one_factorisation(allow):
     check(var, rvar)
     s = gridpp.oi_last_stats()
     assert s["solves"] <= 2 * 25          # 25 tiles, one (rarely two) selections each
+
+
+def test_spatially_varying_parts_inside_a_multiple_structure():
+    """MultipleStructure(sh, sv, sw) with spatially varying parts on three DIFFERENT grids (structure.cpp:90-138): per point the
+    horizontal scale and the localization distance are sh's, the vertical scale sv's, the laf scale sw's."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    c = make_case(95, 26, 30, 90, with_elev=True)
+    Y, X = c["bg"].shape
+    rng = np.random.default_rng(8)
+
+    def field_grid(ny, nx):
+        la, lo = np.meshgrid(np.linspace(0, 1, ny), np.linspace(0, 1, nx), indexing="ij")
+        return la, lo
+    (hla, hlo), (vla, vlo), (wla, wlo) = field_grid(7, 9), field_grid(5, 6), field_grid(11, 4)
+    hf = (9000 * rng.uniform(0.7, 1.3, hla.shape)).astype(np.float32)
+    vf = (300 * rng.uniform(0.7, 1.3, vla.shape)).astype(np.float32)
+    wf = (0.6 * rng.uniform(0.7, 1.3, wla.shape)).astype(np.float32)
+    one = lambda a: np.ones(a.shape, np.float32)
+    gh, gv, gw = gridpp.Grid(hla, hlo), gridpp.Grid(vla, vlo), gridpp.Grid(wla, wlo)
+    sh = gridpp.BarnesStructure(gh, hf, 100 * one(hf), 0.3 * one(hf), 0.0013)
+    sv = gridpp.SoarStructure(gv, 5000 * one(vf), vf, 0.3 * one(vf), 0.0013)
+    sw = gridpp.BarnesStructure(gw, 5000 * one(wf), 100 * one(wf), wf, 0.0013)
+    st = gridpp.MultipleStructure(sh, sv, sw)
+    grid = gridpp.Grid(c["lats"], c["lons"], c["gelev"], c["glaf"])
+    points = gridpp.Points(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    ones_g, ones_p = np.ones((Y, X), np.float32), np.ones(c["obs"].size, np.float32)
+    og = O.Pts(c["lats"].ravel(), c["lons"].ravel(), c["gelev"].ravel(), c["glaf"].ravel())
+    op = O.Pts(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    par = []
+    for pts in (og, op):
+        ih = O.nearest_indices(O.Pts(hla.ravel(), hlo.ravel()), pts)
+        iv = O.nearest_indices(O.Pts(vla.ravel(), vlo.ravel()), pts)
+        iw = O.nearest_indices(O.Pts(wla.ravel(), wlo.ravel()), pts)
+        Rf = np.array([O.structure_localization("Barnes", h, 0.0013) for h in hf.ravel()], np.float32)
+        par.append([hf.ravel()[ih], vf.ravel()[iv], wf.ravel()[iw], Rf[ih]])
+    ost = O.Struct.multiple(O.Struct("Barnes", 9000), O.Struct("Soar", 5000, 300), O.Struct("Barnes", 5000, 0, 0.6))
+    for mp in (10, 0):
+        out, var = gridpp.optimal_interpolation_full(grid, c["bg"], ones_g, points, c["obs"], c["ratios"], c["pbg"], ones_p, st, mp)
+        ref, rvar = O.oi_full_generic(og, c["bg"].ravel(), ones_g.ravel(), op, c["obs"], c["ratios"], c["pbg"], ones_p, ost, mp, True, par[0], par[1])
+        check(np.asarray(out), ref.reshape(Y, X))
+        check(np.asarray(var), rvar.reshape(Y, X))
+    assert np.abs(np.asarray(out) - c["bg"]).max() > 0.05
+    # the single-pair functions see the same scales
+    p1 = gridpp.Point(0.31, 0.42, 120.0, 0.4)
+    p2 = gridpp.Point(0.33, 0.45, 260.0, 0.7)
+    q1, q2 = O.Pts([0.31], [0.42], [120.0], [0.4]), O.Pts([0.33], [0.45], [260.0], [0.7])
+    k = [int(O.nearest_indices(O.Pts(a.ravel(), b.ravel()), q1)[0]) for a, b in ((hla, hlo), (vla, vlo), (wla, wlo))]
+    s1 = O.Struct.multiple(O.Struct("Barnes", float(hf.ravel()[k[0]])), O.Struct("Soar", 5000, float(vf.ravel()[k[1]])), O.Struct("Barnes", 5000, 0, float(wf.ravel()[k[2]])))
+    want = s1.corr((q1.x[0], q1.y[0], q1.z[0], 120.0, 0.4), (q2.x[0], q2.y[0], q2.z[0], 260.0, 0.7))
+    assert abs(st.corr(p1, p2) - want) < 1e-6
