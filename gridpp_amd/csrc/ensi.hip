@@ -477,6 +477,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
 #define EBIG_CAND 8192
 #define EBIG_N 512
 #define EP 65            // pitch of the 64 x 64 matrices (doubles)
+template <bool SPATIAL>
 __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
     // one 65 KB area, three lives: candidate keys (sort) -> Y chunk + tables (Pinv build, Pinv itself in registers) -> B and V;
     // two workgroups fit a CU
@@ -492,7 +493,6 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
     __shared__ float s_mm[2][64];
     const int tid = threadIdx.x;
     const ScanArgs& sa = a.s;
-    const DevStructure& st = sa.st;
     const int nV = a.nV, E = a.E;
     const int nlist = *a.big_count;
     unsigned long long* const gkeys = a.big_keys + (size_t)blockIdx.x * EBIG_CAND;
@@ -500,6 +500,8 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
     for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
         const int cell = a.big_list[li];
         const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
+        DevStructure st = sa.st;   // spatially varying forms: the scales at this grid point (corr_background(p1 = grid point, .), structure.cpp:188-214)
+        if(SPATIAL) d_structure_at(st, st.cell_idx ? st.cell_idx[cell] : cell);
         if(tid == 0) s_n = 0;
         __syncthreads();
         // ---- radius query + filter (valid observation, rho > 0: oi_ensi.cpp:213-237) -----------------------------------------
@@ -849,7 +851,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.err = ws.err.p; a.counters = ws.counters.p;
     // cells with more than 32 usable observations go to k_ensi_big (scalar structure functions; the spatially varying forms
     // fail loudly there)
-    const bool big_ok = !a.s.st.fh && (max_points == 0 || max_points > EN) && !getenv("GPP_ENSI_NO_BIG");
+    const bool big_ok = (max_points == 0 || max_points > EN) && !getenv("GPP_ENSI_NO_BIG");
     if(big_ok) {
         a.big_list = ws.big_list.get((size_t)C); a.big_count = ws.big_count.get(1);
         GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, sizeof(int), stream()));
@@ -881,7 +883,8 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         if(nbig > 0) {
             const int nwg = std::min(nbig, 1024);
             a.big_keys = ws.big_keys.get((size_t)nwg * EBIG_CAND);
-            hipLaunchKernelGGL(k_ensi_big, dim3(nwg), dim3(256), 0, stream(), a);
+            if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_big<true>, dim3(nwg), dim3(256), 0, stream(), a);
+            else hipLaunchKernelGGL(k_ensi_big<false>, dim3(nwg), dim3(256), 0, stream(), a);
             GPP_HIP(hipGetLastError());
         }
     }
@@ -899,7 +902,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         unsigned long long tot = 0; for(int i = 0; i < 12; i++) tot += hc[40 + i];
         if(tot) { fprintf(stderr, "[gpp] ensi phases (%% of wave cycles):"); for(int i = 0; i < 10; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[40 + i] / (double)tot); fprintf(stderr, "\n"); }
     }
-    if(err & 1) runtime("optimal_interpolation_ensi: a grid point has more usable observations than the GPU path holds (512; 32 with spatially varying structure functions)");
+    if(err & 1) runtime("optimal_interpolation_ensi: a grid point has more usable observations than the GPU path holds (512)");
     return GPP_OK;
     GPP_CATCH
 }

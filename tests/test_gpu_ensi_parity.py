@@ -137,8 +137,12 @@ def test_ensi_golden_vectors(name):
     if "shape" in c and c["shape"][0] > 0:      # Grid overload
         Y, X = int(c["shape"][0]), int(c["shape"][1])
         grid = gridpp.Grid(c["blat"].reshape(Y, X), c["blon"].reshape(Y, X), belev.reshape(Y, X), blaf.reshape(Y, X))
+        if "hfield" in c:   # spatially varying scales on the background grid
+            st = gridpp.BarnesStructure(grid, c["hfield"].reshape(Y, X), c["vfield"].reshape(Y, X), c["wfield"].reshape(Y, X))
+        else:
+            st = gridpp.BarnesStructure(h, v, w)
         out = gridpp.optimal_interpolation_ensi(grid, c["background"].reshape(Y, X, E), points, c["pobs"], c["psigmas"],
-                                                c["pbackground"], gridpp.BarnesStructure(h, v, w), int(mp), bool(allow))
+                                                c["pbackground"], st, int(mp), bool(allow))
     else:                                        # Points overload
         bpoints = gridpp.Points(c["blat"], c["blon"], belev, blaf)
         out = gridpp.optimal_interpolation_ensi(bpoints, c["background"], points, c["pobs"], c["psigmas"], c["pbackground"],

@@ -20,6 +20,8 @@ def test_oracle_ensi_golden(name):
     import numpy as np
     from oracle import oracle as O
     c = ensi_golden.CASES[name]
+    if "hfield" in c:
+        pytest.skip("spatially varying scales: the oracle's EnSI part takes scalar scales (the GPU test checks these vectors)")
     h, v, w, mp, allow = c["params"]
     nan_b = np.full(c["blat"].size, np.nan, np.float32)
     nan_p = np.full(c["plat"].size, np.nan, np.float32)

@@ -47,10 +47,20 @@ def barnes_rho(dist, length):
     return np.where(np.isfinite(dist), r, F(0)).astype(F)
 
 
-def localization_distance(h, min_rho=DEFAULT_MIN_RHO):
-    """structure.cpp:280-282.  The float / double reading of log and sqrt must not matter for a fixture."""
+def _loc_readings(h, min_rho):
     a = F(np.sqrt(np.float64(-2.0) * np.log(np.float64(min_rho))) * np.float64(F(h)))
     b = F(F(np.sqrt(F(F(-2) * np.log(F(min_rho))))) * F(h))
+    return a, b
+
+
+def _loc_readings_agree(h, min_rho=None):
+    a, b = _loc_readings(h, DEFAULT_MIN_RHO if min_rho is None else min_rho)
+    return a == b
+
+
+def localization_distance(h, min_rho=DEFAULT_MIN_RHO):
+    """structure.cpp:280-282.  The float / double reading of log and sqrt must not matter for a fixture."""
+    a, b = _loc_readings(h, min_rho)
     assert a == b, (a, b)
     return a
 
@@ -110,9 +120,13 @@ def ensi(blat, blon, belev, blaf, background, plat, plon, pelev, plaf, pobs, psi
     # :187-201
     validEns = [e for e in range(nEns) if np.isfinite(background[:, e]).all()]
     nV = len(validEns)
-    loc = localization_distance(h)
+    # h, v, w: scalars, or one value per background point (the spatially varying BarnesStructure(grid, h, v, w) on the background's
+    # own grid, structure.cpp:168-214: localization_distance(p1) and corr_background(p1, .) take the scales at p1)
+    hs, vs, ws = (np.broadcast_to(np.asarray(t, F), (nY,)) for t in (h, v, w))
     sorted_everywhere = True
     for y in range(nY):
+        h, v, w = float(hs[y]), float(vs[y]), float(ws[y])
+        loc = localization_distance(h)
         p1 = (bx[y], by[y], bz[y], F(belev[y]), F(blaf[y]))
         idx0 = get_neighbours(px, py, pz, bx[y], by[y], bz[y], loc)                       # :213
         if idx0.size == 0:
@@ -195,7 +209,7 @@ def one_obs_closed_form(bg_row, y_row, rho, sigma, obs, yhat):
 
 
 def make_case(seed, Y, X, E, S, h, max_points, allow, v=0.0, w=0.0, elev=False, laf=False, nan_member=None, nan_obs=False,
-              points_background=0):
+              points_background=0, spatial=False):
     rng = np.random.default_rng(seed)
     if points_background:
         blat, blon = rng.random(points_background).astype(F), rng.random(points_background).astype(F)
@@ -220,12 +234,24 @@ def make_case(seed, Y, X, E, S, h, max_points, allow, v=0.0, w=0.0, elev=False, 
     if nan_obs:
         obs[::7] = np.nan
     info = {}
-    out = ensi(blat, blon, belev, blaf, bg, plat, plon, pelev, plaf, obs, sig, pbg, h, v, w, max_points, allow, info)
+    extra = {}
+    if spatial:     # per-cell scales (+- 30 % around the nominal ones)
+        hq = (np.round(h * rng.uniform(0.7, 1.3, n) / 250.0) * 250.0).astype(F)
+        for i in range(n):      # keep only scales whose localisation distance reads the same in float and in double
+            while not _loc_readings_agree(hq[i]):
+                hq[i] += F(250.0)
+        vq = (v * rng.uniform(0.7, 1.3, n)).astype(F)
+        wq = (w * rng.uniform(0.7, 1.3, n)).astype(F)
+        extra = dict(hfield=hq, vfield=vq, wfield=wq)
+        out = ensi(blat, blon, belev, blaf, bg, plat, plon, pelev, plaf, obs, sig, pbg, hq, vq, wq, max_points, allow, info)
+    else:
+        out = ensi(blat, blon, belev, blaf, bg, plat, plon, pelev, plaf, obs, sig, pbg, h, v, w, max_points, allow, info)
     if not allow and max_points > 0:
         assert info["sorted_everywhere"], "no-extrapolation case with an unsorted grid point: its result is order dependent"
     d = dict(shape=np.array([Y, X, E] if not points_background else [0, points_background, E]), blat=blat, blon=blon, belev=belev,
              blaf=blaf, background=bg, plat=plat, plon=plon, pelev=pelev, plaf=plaf, pobs=obs, psigmas=sig, pbackground=pbg,
              params=np.array([h, v, w, max_points, 1.0 if allow else 0.0]), expected=out)
+    d.update(extra)
     return d
 
 
@@ -242,6 +268,9 @@ CASES = {
     "e80_mp20":          dict(seed=19, Y=12, X=12, E=80, S=60, h=30000, max_points=20, allow=True),
     "e6_points_background": dict(seed=20, Y=0, X=0, E=6, S=40, h=25000, max_points=8, allow=True, points_background=300),
     "e8_short_range":    dict(seed=21, Y=32, X=32, E=8, S=50, h=5000, max_points=6, allow=True),   # many cells without observations
+    # spatially varying BarnesStructure(grid, h, v, w) on the background grid (GPU tests only: the oracle's EnSI part takes scalar scales)
+    "e10_spatial_mp10":  dict(seed=22, Y=24, X=24, E=10, S=70, h=25000, max_points=10, allow=True, v=300.0, w=0.5, elev=True, laf=True, spatial=True),
+    "e12_spatial_mp0":   dict(seed=23, Y=14, X=14, E=12, S=110, h=28000, max_points=0, allow=True, v=300.0, elev=True, spatial=True),
 }
 
 
