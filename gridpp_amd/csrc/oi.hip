@@ -9,15 +9,18 @@
 //   * the observation set is bin-sorted once per Points object on two projected axes (gpp_obs_index); a tile walks only
 //     the bins that can still matter, records are fetched 64 at a time and broadcast with v_readlane;
 //   * k_oi_union (oi_union.h): ONE shared factorisation per tile -- the cells of a tile select almost the same
-//     observations -- plus a per-lane finish; tried first for every symmetric system with max_points <= 32;
+//     observations -- plus a per-lane finish; tried first for every symmetric system with max_points <= 32 (32-column
+//     form) or 33..62 (64-column form, oi_union64.hip);
 //   * k_oi (this file): every lane keeps its best max_points candidates as 64-bit keys (rho bits << 32 | ~obs index)
 //     in LDS; lanes with the same selection share one augmented Cholesky (or pivoted LU) on rows-in-lanes; also the
-//     kernel for what k_oi_union declines, for 33..62 observations, non-symmetric and spatially varying structures;
+//     kernel for what k_oi_union declines, for max_points = 0 / > 62, non-symmetric and spatially varying structures;
 //   * k_oi_big (this file): one workgroup per grid point with more than 62 usable observations.
 // Arithmetic follows the reference: float32 coordinates/distances/rho (no FMA contraction,
 // correctly rounded sqrt/div, rho through a double-precision exp), double for the solve.
 #include "oi_common.h"
 #include "oi_union.h"
+
+void gpp_launch_union64(const OiArgs& a, unsigned nblocks, bool plain, bool list, hipStream_t stream);   // oi_union64.hip
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <memory>
@@ -1316,7 +1319,9 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const bool memo_hit = memo.points_id == points->serial && memo.h == a.s.st.h && memo.v == a.s.st.v && memo.w == a.s.st.w && memo.kh == a.s.st.kh &&
                           memo.kv == a.s.st.kv && memo.kw == a.s.st.kw && memo.cv == a.s.st.cv && memo.max_points == max_points;
     const bool memo_says_no = memo_hit && memo.declined > 0.5f;   // more than half of the tiles went to k_oi last time: skip the first pass
-    const bool use_union = !use_lu && N == 32 && want_union && !memo_says_no && !getenv("GPP_OI_NO_UNION");
+    // (the 62-row form only for 33 <= max_points <= 62: with max_points = 0 a cell may hold more than any tile kernel can)
+    const bool use_union = !use_lu && (N == 32 || (max_points > 32 && max_points <= 62)) && want_union && !memo_says_no && !getenv("GPP_OI_NO_UNION");
+    const int WPB = N == 32 ? UnionCfg<32>::WPB : UnionCfg<64>::WPB;   // work items (waves) per workgroup of k_oi_union
     // cells with more usable observations than the 62-row tile holds are listed: symmetric systems go to k_oi_big (Cholesky, up
     // to BIG_N observations), what that kernel cannot hold and every listed cell of a non-symmetric or spatially varying
     // structure to k_oi_huge (pivoted elimination in HBM scratch, no capacity of its own)
@@ -1347,28 +1352,33 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         ran_union = false;
         if(use_union && !use_lu) {
             // worst case per list: every tile declined and split into 4 (level 1) resp. 16 (level 2) items
-            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get(2 * (size_t)a.ntiles + 64); ws.fb_list3.get(4 * (size_t)a.ntiles + 64);
+            const int SHORT_ITEMS = 3072;   // as many work items as the chip holds waves of this kernel
+            // (the short-list pass writes up to 16 entries per declined tile, SHORT_ITEMS at most, whatever the number of tiles)
+            ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get(2 * (size_t)a.ntiles + 64);
+            ws.fb_list3.get(std::max<size_t>(4 * (size_t)a.ntiles, (size_t)SHORT_ITEMS) + 64);
             const dim3 block(256);
-            auto launch_union = [&](const dim3 grid, const bool list) {
-                if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<true, false>), grid, block, 0, stream(), a); }
-                else { if(list) hipLaunchKernelGGL((k_oi_union<false, true>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<false, false>), grid, block, 0, stream(), a); }
+            auto launch_union = [&](const long items, const bool list) {   // one wave per work item
+                const long nb = (items + WPB - 1) / WPB;
+                const dim3 grid((unsigned)std::min<long>(nb, 0x7fffffffL));
+                if(N != 32) gpp_launch_union64(a, grid.x, plain, list, stream());
+                else if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true, 32>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<true, false, 32>), grid, block, 0, stream(), a); }
+                else { if(list) hipLaunchKernelGGL((k_oi_union<false, true, 32>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<false, false, 32>), grid, block, 0, stream(), a); }
                 GPP_HIP(hipGetLastError());
             };
             // pass 1: every tile
             a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
-            launch_union(dim3((a.ntiles + 3) / 4), false);
+            launch_union(a.ntiles, false);
             GPP_HIP(hipEventRecord(ws.eu, stream()));
             // The tiles it declined.  The usual case is a short list (or none): it is taken WITHOUT asking the host how long it
             // is -- the short-list pass and the k_oi pass behind it are launched with fixed small grids and read the lengths
             // on the device; a list too long for that grid is left untouched by both and handled after the one read-back of
             // the call.  (A host round trip here cost ~25 us per call.)  When the last call with this geometry had a long
             // list, the host asks first, as the two-level passes need its length for their grids anyway.
-            const int SHORT_ITEMS = 3072;   // as many work items as the chip holds waves of this kernel
-            auto short_passes = [&](const int nblocks) {
+            auto short_passes = [&](const int nitems) {
                 // every declined tile straight to its sixteen 4-cell items (one pass; the latency of a pass, one lone work
                 // item, is what a short list costs)
                 a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
-                launch_union(dim3(nblocks), true);
+                launch_union(nitems, true);
                 // what is still left, one factorisation per distinct selection (grid-stride over the list)
                 a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 128;
                 launch_k_oi(false);   // (usually nothing is left: a small grid keeps the empty launch cheap)
@@ -1377,18 +1387,18 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); a list too long for the split to pay is
                 // forwarded whole by the kernel
                 a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
-                launch_union(dim3(n1), true);
+                launch_union(4 * (long)n1, true);
                 // pass 3: the declined 16-cell items as 4 items of 4 cells (at most 4 n1 of them)
                 a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
                 a.parent_count = d_fb_count;
-                launch_union(dim3(4 * (size_t)n1 > 0x7fffffffull ? 0x7fffffff : 4 * n1), true);
+                launch_union(16 * (long)n1, true);
                 // pass 4: what is still left, one factorisation per distinct selection (grid-stride over the list)
                 a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
                 launch_k_oi(false);
             };
             const bool expect_long = memo_hit && 16.0 * (double)memo.declined * (double)a.ntiles > (double)SHORT_ITEMS;
             if(!expect_long) {
-                short_passes(SHORT_ITEMS / 4);
+                short_passes(SHORT_ITEMS);
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
                 const int n1 = h_ints[1];
@@ -1403,7 +1413,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 GPP_HIP(hipStreamSynchronize(stream()));
                 const int n1 = h_ints[1];
                 if(16 * (long)n1 > SHORT_ITEMS) long_passes(n1);
-                else if(n1 > 0) short_passes(4 * n1);
+                else if(n1 > 0) short_passes(16 * n1);
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
             }

@@ -86,13 +86,27 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
 #define UPROF(i) do { } while(0)
 #endif
 
-constexpr int U_WCAP = 40;     // candidate slots of a tile (live union during the scan)
-constexpr int U_MAXU = 40;     // rows of the shared factorisation: 32 register columns + 8
+// Two sizes of the kernel.  NC = 32: max_points <= 32, 32 register columns (+ 8 late columns kept in LDS), four waves per
+// workgroup.  NC = 64: max_points 33..62, 64 register columns, two waves per workgroup (46 KB of LDS) at one wave per SIMD.
+template <int NC> struct UnionCfg;
+template <> struct UnionCfg<32> {
+    static constexpr int WCAP = 40;     // candidate slots of a tile (live union during the scan)
+    static constexpr int MAXU = 40;     // rows of the shared factorisation: 32 register columns + 8
+    static constexpr int SOLVE = 1024;  // doubles of the shared-factor area
+    static constexpr int WPB = 4;       // waves (work items) per workgroup
+};
+template <> struct UnionCfg<64> {
+    static constexpr int WCAP = 64;
+    static constexpr int MAXU = 62;     // lane 63 carries obs - background
+    static constexpr int SOLVE = 2240;  // worst case c = 50, 12 extras: 2143 doubles, + the 64 of the column staging
+    static constexpr int WPB = 2;
+};
 constexpr int U_MAXE = 12;     // union minus core
 constexpr int U_MAXM = 6;      // extras of one cell
-constexpr int U_SOLVE = 1024;  // doubles of the shared-factor area
 
+template <int NC>
 struct UnionLds {
+    static constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE;
     union {
         float rho[U_WCAP][64];     // scan: rho(cell = lane, candidate slot); +inf = not (or no longer) selected by that cell
         struct {                   // solve (the cells take their rho values into registers first)
@@ -120,11 +134,12 @@ __device__ __forceinline__ double rsqrt_nr(const double a) {
 // everything ends on this kernel; what it declines at level 2 goes to k_oi (one factorisation per distinct selection).
 // List entries: tile (produced by the first pass); tile * 32 + code with code 16..19 = 16-cell item, 0..15 = 4-cell item;
 // ~tile = whole tile forwarded unsplit because splitting would not pay (see `forward` below).
-template <bool PLAIN, bool LIST>
-__global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
-    __shared__ UnionLds s_u[4];
+template <bool PLAIN, bool LIST, int NC>
+__global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
+    constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE, WPB = UnionCfg<NC>::WPB;
+    __shared__ UnionLds<NC> s_u[WPB];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int tile = blockIdx.x * 4 + wid, sub = -1;   // sub: (lane >> shift) of the lanes of this item, -1 = all
+    int tile = blockIdx.x * WPB + wid, sub = -1;   // sub: (lane >> shift) of the lanes of this item, -1 = all
     int shift = 0;
     if(LIST) {
         const int nlist = *a.in_count;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
         const bool whole = nlist > 0 && a.in_list[0] < 0;
         const bool forward = a.level != 3 && (whole || (a.level == 1 ? nlist > a.ntiles / 2 : nlist > 2 * *a.parent_count));
         if(forward) {
-            for(int i = blockIdx.x * 256 + threadIdx.x; i < nlist; i += gridDim.x * 256) {
+            for(int i = blockIdx.x * (64 * WPB) + threadIdx.x; i < nlist; i += gridDim.x * (64 * WPB)) {
                 const int e = a.in_list[i];
                 a.out_list[atomicAdd(a.out_count, 1)] = (a.level == 1) ? ~e : e;
             }
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
         if(a.level == 3) {   // a short list of declined tiles goes straight to its sixteen 4-cell items: one pass instead of two
             // (launched before the host knows the length of the list, with a grid that holds a short one: a longer list is left
             //  alone here and taken by the two-level passes once the host has seen its length)
-            if(16 * nlist > (int)gridDim.x * 4 || tile >= 16 * nlist) return;
+            if(16 * nlist > (int)gridDim.x * WPB || tile >= 16 * nlist) return;
             sub = tile & 15; tile = a.in_list[tile >> 4]; shift = 2;
         }
         else {
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
     }
     else if(tile >= a.ntiles) return;
     tile = __builtin_amdgcn_readfirstlane(tile); sub = __builtin_amdgcn_readfirstlane(sub);
-    UnionLds& L = s_u[wid];
+    UnionLds<NC>& L = s_u[wid];
 #ifdef GPP_UNION_PROFILE
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
     int cnt = 0;
     unsigned long long alloc = 0ull;   // allocated slots (wave-uniform)
     bool fb = false;                   // wave-uniform: this tile goes to k_oi
-    constexpr unsigned long long FULL = (1ull << U_WCAP) - 1ull;
+    constexpr unsigned long long FULL = U_WCAP >= 64 ? ~0ull : ((1ull << (U_WCAP & 63)) - 1ull);
     // an empty (never used / evicted / not wanted by this cell) entry is +inf; all slot loops are static so that the
     // slot LDS reads issue back to back (ds_read2st64) instead of one latency per slot
 #pragma unroll
@@ -572,18 +587,19 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
         const float dpf = (float)((double)o1.y - (double)o1.z);   // obs - background at the observation (oi.cpp:293)
         // this cell's rho for every row of the union (lG, oi.cpp:296); afterwards the rho slots are dead and the
         // shared-factor area takes their place
-        float gf[32];
+        float gf[NC];
         {
-            float gx8[U_MAXU - 32];   // rows 32.. are always extras (c <= 32): they only pass through
+            constexpr int NLATE = U_MAXU > NC ? U_MAXU - NC : 1;
+            float gx8[NLATE];   // rows NC.. are always extras (c <= NC): they only pass through
 #pragma unroll
-            for(int k = 0; k < 32; ++k) gf[k] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
+            for(int k = 0; k < NC; ++k) gf[k] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
 #pragma unroll
-            for(int k = 32; k < U_MAXU; ++k) gx8[k - 32] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
+            for(int k = NC; k < U_MAXU; ++k) gx8[k - NC] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for(int k = 0; k < 32; ++k) if(k >= c && k < u) L.f.erho[k - c][lane] = gf[k];
+            for(int k = 0; k < NC; ++k) if(k >= c && k < u) L.f.erho[k - c][lane] = gf[k];
 #pragma unroll
-            for(int k = 32; k < U_MAXU; ++k) if(k < u) L.f.erho[k - c][lane] = gx8[k - 32];
+            for(int k = NC; k < U_MAXU; ++k) if(k < u) L.f.erho[k - c][lane] = gx8[k - NC];
         }
         if(lane >= c && lane < u) L.worig[lane - c] = __float_as_int(dpf);
         UPROF(6);   // observation records of the union
@@ -604,9 +620,9 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
             }
         }
         UPROF(7);   // P build
-        double row[32];
+        double row[NC];
 #pragma unroll
-        for(int p = 0; p < 32; ++p) {
+        for(int p = 0; p < NC; ++p) {
             double v = 0.0;
             if(p < u) {
                 if(lane < u && lane >= p) {   // lower triangle only (all the factorisation reads)
@@ -622,7 +638,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
         // in LDS and are reduced after the elimination
         const int lidx = lane == 63 ? 8 : lane - 32;
 #pragma unroll
-        for(int b = 0; b < 8; ++b) {
+        for(int b = 0; b < (U_MAXU > NC ? 8 : 0); ++b) {
             const int p = 32 + b;
             if(p < u) {
                 double v = 0.0;
@@ -643,7 +659,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
         bool bad = false;
         // right-looking Cholesky over the core columns; the trailing rows/columns end as B, the Schur complement, L_C^-1 d, d'
 #pragma unroll
-        for(int j = 0; j < 32; ++j) {
+        for(int j = 0; j < NC; ++j) {
             if(j < c) {
                 const double ajj = readlane_d(row[j], j);
                 if(!(ajj > 0.0)) bad = true;
@@ -655,14 +671,14 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
                 // the rank-1 update -- half the instructions of a v_readlane pair per multiply-add
                 colL[lane] = cj;
 #pragma unroll
-                for(int p = j + 1; p < 32; ++p) row[p] = __builtin_fma(-cj, colL[p], row[p]);
+                for(int p = j + 1; p < NC; ++p) row[p] = __builtin_fma(-cj, colL[p], row[p]);
             }
         }
         UPROF(8);   // row load + elimination
         // export: L_C rows packed, B rows (stride bs), L_C^-1 d, Schur complement, d'
         const int ea = lane - c;   // extras row index of this lane
 #pragma unroll
-        for(int p = 0; p < 32; ++p) {
+        for(int p = 0; p < NC; ++p) {
             if(p < u) {
                 if(lane < c) { if(p <= lane) sv[oL + lane * (lane + 1) / 2 + p] = row[p]; }
                 else if(lane < u) {
@@ -675,7 +691,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
                 }
             }
         }
-        if(u > 32 && !(a.debug & 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
+        if(U_MAXU > NC && u > 32 && !(a.debug & 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
 #pragma unroll
             for(int b = 0; b < 8; ++b) {
                 const int p = 32 + b;
@@ -696,10 +712,10 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
 
         UPROF(9);   // export
         // ============= per cell (lane): forward substitution of G against L_C, then its own extras ==================
-        double z[32];
+        double z[NC];
         double inc = 0.0, a00 = 0.0;
 #pragma unroll
-        for(int k = 0; k < 32; ++k) {
+        for(int k = 0; k < NC; ++k) {
             double zk = 0.0;
             if(k < c && !(a.debug & 32)) {
                 const double gk = (double)gf[k];
@@ -733,7 +749,7 @@ __global__ __launch_bounds__(256, PLAIN ? 3 : 2) void k_oi_union(OiArgs a) {   /
                     const double* brow = sv + oB + ai * bs;
                     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-                    for(int j0 = 0; j0 < 32; j0 += 4) {
+                    for(int j0 = 0; j0 < NC; j0 += 4) {
                         if(j0 < c) {   // reads at most 3 elements past the row (finite data, multiplied by z = 0)
                             acc0 = __builtin_fma(brow[j0], z[j0], acc0);
                             acc1 = __builtin_fma(brow[j0 + 1], z[j0 + 1], acc1);

@@ -1,0 +1,14 @@
+// k_oi_union with 64 register columns (max_points 33..62): its own translation unit so that it compiles beside oi.hip.
+#include "oi_union.h"
+
+void gpp_launch_union64(const OiArgs& a, const unsigned nblocks, const bool plain, const bool list, hipStream_t stream) {
+    const dim3 grid(nblocks), block(64 * UnionCfg<64>::WPB);
+    if(plain) {
+        if(list) hipLaunchKernelGGL((k_oi_union<true, true, 64>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_oi_union<true, false, 64>), grid, block, 0, stream, a);
+    }
+    else {
+        if(list) hipLaunchKernelGGL((k_oi_union<false, true, 64>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_oi_union<false, false, 64>), grid, block, 0, stream, a);
+    }
+}

@@ -19,13 +19,23 @@ def _check(out, ref):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_configurations(seed):
+    _random_configuration(seed, [1, 2, 7, 20, 30, 32])
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_random_configurations_62_row_tile(seed):
+    """max_points 33..62: the 64-column form of k_oi_union (two waves per workgroup) and k_oi<62> behind its work lists."""
+    _random_configuration(seed, [33, 40, 50, 62], cressman=seed % 5 == 0)
+
+
+def _random_configuration(seed, mps, cressman=False):
     import gridpp_amd as gridpp
     from oracle import oracle as O
     rng = np.random.default_rng(4000 + seed)
     Y, X = int(rng.integers(5, 70)), int(rng.integers(5, 70))
     S = int(rng.choice([3, 12, 40, 150, 600, 2500]))
     h = float(rng.choice([3000.0, 10000.0, 40000.0]))
-    mp = int(rng.choice([1, 2, 7, 20, 30, 32]))
+    mp = int(rng.choice(mps))
     ext = 0.3 * float(rng.choice([0.2, 1.0, 3.0]))          # domain size in degrees: tile size relative to h varies
     lats, lons = np.meshgrid(np.linspace(60, 60 + ext, Y), np.linspace(10, 10 + 2 * ext, X), indexing="ij")
     kind = seed % 3
@@ -50,6 +60,14 @@ def test_random_configurations(seed):
     allow = bool(seed % 2)
     grid, points, st = gridpp.Grid(lats, lons), gridpp.Points(plat, plon), gridpp.BarnesStructure(h)
     og, op, ost = O.Pts(lats.ravel(), lons.ravel()), O.Pts(plat, plon), O.Barnes(h)
+    if cressman:    # a symmetric structure function that is not the Barnes fast path (k_oi_union<false, ...>)
+        st = gridpp.CressmanStructure(h)
+        ones_g, ones_p = np.ones(Y * X, np.float32), np.ones(S, np.float32)
+        out = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, mp, allow)
+        ref, _ = O.oi_full_generic(og, bg.ravel(), ones_g, op, obs, ratios, pbg, ones_p, O.Struct("Cressman", h), mp, allow)
+        _check(out, ref.reshape(Y, X))
+        assert gridpp.oi_last_stats()["union_kernel_ms"] > 0
+        return
     out = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, mp, allow)
     ref = O.oi(og, bg.ravel(), op, obs, ratios, pbg, ost, mp, allow).reshape(Y, X)
     _check(out, ref)
