@@ -18,6 +18,8 @@
 //   * min/max: separable running min/max ignoring non-finite values;
 //   * exact quantile / median / brute force: one wavefront per cell, k-th order statistic by
 //     bisection on the monotone uint32 image of the float values (no sort, no scratch).
+#include <mutex>
+#include <atomic>
 #include "common.h"
 #include <algorithm>
 #include <hipcub/hipcub.hpp>
@@ -210,10 +212,10 @@ __global__ void k_member_quantile(const float* __restrict__ in, long C, int E, f
 // -------------------------------------------------------------------------------------------
 // row pass: for each cell the sum (double) and count (int) of the valid values in [x-hw, x+hw]
 __global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ in, int Y, int X, int hw, double* __restrict__ rs, int* __restrict__ rc,
-                                                  int* __restrict__ plane_has_invalid) {
+                                                  int* __restrict__ plane_has_invalid, int ybase) {
     extern __shared__ float lds[];   // 256 + 2*hwc floats
     const long plane = (long)blockIdx.z * Y * X;
-    const int y = blockIdx.y;
+    const int y = ybase + blockIdx.y;   // (the host launches row chunks of at most 65535: gridDim.y is 16 bits)
     const int x0 = blockIdx.x * 256;
     const int hwc = min(hw, X);   // a window wider than the row is the whole row
     const float* row = in + plane + (long)y * X;
@@ -251,10 +253,10 @@ __global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ in, 
 #define ROWS4_TILE 1024
 __device__ __forceinline__ int pad4(int i) { return i + (i >> 2); }
 __global__ __launch_bounds__(256) void k_box_rows4(const float* __restrict__ in, int Y, int X, int hw, double* __restrict__ rs, int* __restrict__ rc,
-                                                   int* __restrict__ plane_has_invalid) {
+                                                   int* __restrict__ plane_has_invalid, int ybase) {
     extern __shared__ float lds[];   // pad4(ROWS4_TILE + 2*hwc) floats
     const long plane = (long)blockIdx.z * Y * X;
-    const int y = blockIdx.y;
+    const int y = ybase + blockIdx.y;
     const int x0 = blockIdx.x * ROWS4_TILE;
     const int hwc = min(hw, X);
     const int ntap = ROWS4_TILE + 2 * hwc;
@@ -301,6 +303,29 @@ __global__ __launch_bounds__(256) void k_box_rows4(const float* __restrict__ in,
         if(x < X) { rs[plane + (long)y * X + x] = s4[j]; rc[plane + (long)y * X + x] = c4[j]; }
     }
 }
+// Row pass for windows too wide for an LDS tile (min(hw, X) beyond ~20 000 columns): one workgroup per row, every thread owns a
+// contiguous segment of the row, sums the window of its first cell directly and slides it along the segment (valid values only).
+__global__ __launch_bounds__(256) void k_box_rows_wide(const float* __restrict__ in, int Y, int X, int hw, double* __restrict__ rs, int* __restrict__ rc,
+                                                       int* __restrict__ plane_has_invalid, int ybase) {
+    const long plane = (long)blockIdx.z * Y * X;
+    const int y = ybase + blockIdx.y;
+    const float* row = in + plane + (long)y * X;
+    const int seg = (X + 255) / 256, xa = threadIdx.x * seg, xb = min(X, xa + seg);
+    if(xa >= xb) return;
+    double s = 0; int c = 0, bad = 0;
+    const int lo = max(xa - hw, 0), hi = (int)min((long)X - 1, (long)xa + hw);
+    for(int k = lo; k <= hi; ++k) { const float v = row[k]; if(nv(v)) { s += (double)v; c++; } else bad = 1; }
+    for(int x = xa; x < xb; ++x) {
+        if(x > xa) {
+            const long in_k = (long)x + hw; const int out_k = x - hw - 1;
+            if(in_k < X) { const float v = row[in_k]; if(nv(v)) { s += (double)v; c++; } else bad = 1; }
+            if(out_k >= 0) { const float v = row[out_k]; if(nv(v)) { s -= (double)v; c--; } }
+        }
+        rs[plane + (long)y * X + x] = s;
+        rc[plane + (long)y * X + x] = c;
+    }
+    if(bad) atomicOr(&plane_has_invalid[blockIdx.z], 1);
+}
 // column pass + finish (neighbourhood.cpp:132-142): Mean / Sum / Count.  Each thread owns one column of a strip of
 // COL_STRIP rows and slides the window down it (2 reads per cell instead of 2*hw+1).
 #ifndef COL_STRIP
@@ -341,9 +366,9 @@ __global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs,
     }
 }
 // separable min / max ignoring non-finite values (dir 0: along x, dir 1: along y)
-__global__ __launch_bounds__(256) void k_minmax_pass(const float* __restrict__ in, int Y, int X, int hw, int is_max, int dir, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_minmax_pass(const float* __restrict__ in, int Y, int X, int hw, int is_max, int dir, float* __restrict__ out, int ybase) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = ybase + blockIdx.y * 4 + (threadIdx.x >> 6);
     if(x >= X || y >= Y) return;
     float m = NAN;
     if(dir == 0) {
@@ -767,8 +792,8 @@ void member_pass_launch(const float* d_in, long C, int E, int statistic, const f
     const int nchunk = (16 * E + 63) / 64;
     const bool dma = E <= MEMBER_EC && (reinterpret_cast<size_t>(d_in) & 15) == 0;
     const size_t lds = dma ? (size_t)(MODE != 0 ? 1 : 2) * nchunk * 1024 : 16;   // (double) buffer of whole 1 KiB chunks
-    static bool attr = false;
-    if(!attr) { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((16 * MEMBER_EC + 63) / 64) * 1024)); attr = true; }
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((16 * MEMBER_EC + 63) / 64) * 1024)); });
     const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds, 1)));
     const long grid = std::min<long>(tiles, (long)256 * waves_per_cu);
     hipLaunchKernelGGL((k_member_pass<MODE>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, statistic, d_thr, T, d_out, dma ? 1 : 0);
@@ -785,29 +810,32 @@ void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statisti
     double* rs = g_nb.rs.get(n);
     int* rc = g_nb.rc.get(n);
     int hwc = std::min(hw, X);
-    if((256 + 2 * (size_t)hwc) * sizeof(float) > 160 * 1024) runtime("neighbourhood: halfwidth too large for the row pass");
-    static size_t lds_set = 0;
-    if((256 + 2 * (size_t)hwc) * sizeof(float) > std::max<size_t>(lds_set, 64 * 1024)) {
-        lds_set = 160 * 1024;
-        GPP_HIP(hipFuncSetAttribute((const void*)k_box_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_set));
-    }
+    const bool wide = (256 + 2 * (size_t)hwc) * sizeof(float) > 160 * 1024 || getenv("GPP_BOX_ROWS_WIDE");   // no LDS tile holds the window
+    static std::once_flag lds_once;
+    if(!wide && (256 + 2 * (size_t)hwc) * sizeof(float) > 64 * 1024)
+        std::call_once(lds_once, [] { GPP_HIP(hipFuncSetAttribute((const void*)k_box_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     int* flags = g_nb.plane_flags.get(nplanes);
     GPP_HIP(hipMemsetAsync(flags, 0, sizeof(int) * nplanes, stream()));
-    if(hwc <= 1024 && hwc > 0 && !getenv("GPP_BOX_ROWS_DIRECT")) {
-        const int ntap = ROWS4_TILE + 2 * hwc;
-        hipLaunchKernelGGL(k_box_rows4, dim3((X + ROWS4_TILE - 1) / ROWS4_TILE, Y, nplanes), dim3(256), (size_t)(ntap + (ntap >> 2) + 4) * sizeof(float), stream(),
-                           d_in, Y, X, hw, rs, rc, flags);
+    for(int ybase = 0; ybase < Y; ybase += 65535) {   // gridDim.y is a 16-bit quantity
+        const int ny = std::min(65535, Y - ybase);
+        if(wide)
+            hipLaunchKernelGGL(k_box_rows_wide, dim3(1, ny, nplanes), dim3(256), 0, stream(), d_in, Y, X, hw, rs, rc, flags, ybase);
+        else if(hwc <= 1024 && hwc > 0 && !getenv("GPP_BOX_ROWS_DIRECT")) {
+            const int ntap = ROWS4_TILE + 2 * hwc;
+            hipLaunchKernelGGL(k_box_rows4, dim3((X + ROWS4_TILE - 1) / ROWS4_TILE, ny, nplanes), dim3(256), (size_t)(ntap + (ntap >> 2) + 4) * sizeof(float), stream(),
+                               d_in, Y, X, hw, rs, rc, flags, ybase);
+        }
+        else
+            hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, ny, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc, flags, ybase);
+        GPP_HIP(hipGetLastError());
     }
-    else
-        hipLaunchKernelGGL(k_box_rows, dim3((X + 255) / 256, Y, nplanes), dim3(256), (256 + 2 * hwc) * sizeof(float), stream(), d_in, Y, X, hw, rs, rc, flags);
-    GPP_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_box_cols, dim3((X + 255) / 256, (Y + COL_STRIP - 1) / COL_STRIP, nplanes), dim3(256), 0, stream(), rs, rc, Y, X, hw, statistic, d_out, qf_reps, flags);
     GPP_HIP(hipGetLastError());
 }
 void brute(const float* d_in, int Y, int X, int E, int hw, int statistic, float q, float* d_out) {
     long C = (long)Y * X;
-    static unsigned seed = 12345u;
-    seed = seed * 1664525u + 1013904223u;
+    static std::atomic<unsigned> seed_state{12345u};
+    const unsigned seed = seed_state.fetch_add(1013904223u) * 1664525u + 1013904223u;
     hipLaunchKernelGGL(k_brute, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, stream(), d_in, Y, X, E, hw, statistic, q, seed, d_out);
     GPP_HIP(hipGetLastError());
 }
@@ -817,10 +845,12 @@ void neighbourhood2d(const float* d_in, int Y, int X, int hw, int statistic, flo
     if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT) box_stat(d_in, Y, X, 1, hw, statistic, d_out);
     else if(statistic == GPP_MIN || statistic == GPP_MAX) {
         float* t = g_nb.tmp.get(C);
-        dim3 grid((X + 63) / 64, (Y + 3) / 4);
-        hipLaunchKernelGGL(k_minmax_pass, grid, dim3(256), 0, stream(), d_in, Y, X, hw, statistic == GPP_MAX, 1, t);
-        hipLaunchKernelGGL(k_minmax_pass, grid, dim3(256), 0, stream(), (const float*)t, Y, X, hw, statistic == GPP_MAX, 0, d_out);
-        GPP_HIP(hipGetLastError());
+        for(int dir = 1; dir >= 0; --dir)
+            for(int ybase = 0; ybase < Y; ybase += 4 * 65535) {
+                const dim3 grid((X + 63) / 64, (std::min(4 * 65535, Y - ybase) + 3) / 4);
+                hipLaunchKernelGGL(k_minmax_pass, grid, dim3(256), 0, stream(), dir ? d_in : (const float*)t, Y, X, hw, statistic == GPP_MAX, dir, dir ? t : d_out, ybase);
+                GPP_HIP(hipGetLastError());
+            }
     }
     else if(statistic == GPP_STD || statistic == GPP_VARIANCE) {
         float* mean = g_nb.tmp.get(C);
@@ -923,13 +953,12 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
         if(is3d && ne <= 255 && nt <= QF_TMAX && lds <= 100 * 1024 && rows <= QF_RMAX && cols <= 128 && !getenv("GPP_QF_NO_FUSED")) {
             unsigned char* cnt8 = reinterpret_cast<unsigned char*>(g_nb.planes.get(((size_t)(nt + 1) * C + 3) / 4));
             member_pass(in.d, C, ne, 2, 0, th.d, nt, reinterpret_cast<float*>(cnt8));
-            static size_t lds_set = 0;
-            if(lds > lds_set) {
+            static std::once_flag qf_once;
+            std::call_once(qf_once, [] {
                 GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
                 GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
                 GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-                lds_set = 100 * 1024;
-            }
+            });
             const dim3 grid((nx + QF_TX - 1) / QF_TX, (ny + QF_TY - 1) / QF_TY);
             const unsigned char* c8 = cnt8;
             const int qfl = nq == 1 ? 0 : 1;

@@ -72,6 +72,30 @@ def test_2d_statistics(api, hw):
         close(gridpp.neighbourhood(f, hw, stat), O.neighbourhood(f, hw, stat), exact=True)
 
 
+def test_more_rows_than_one_launch_dimension_holds(api):
+    """Grids with more than 65 535 rows (gridDim.y is a 16-bit quantity): the row passes run in row chunks."""
+    gridpp, O = api
+    f = field(7, 70001, 9)
+    for stat in (gridpp.Mean, gridpp.Sum):
+        close(gridpp.neighbourhood(f, 2, stat), O.neighbourhood(f, 2, stat))
+    f = field(8, 262150, 5)      # beyond 4 x 65 535 rows: the min / max passes chunk too
+    for stat in (gridpp.Count, gridpp.Min, gridpp.Max):
+        close(gridpp.neighbourhood(f, 2, stat), O.neighbourhood(f, 2, stat), exact=True)
+
+
+@pytest.mark.parametrize("hw", [3, 40, 500])
+def test_row_pass_for_windows_wider_than_an_lds_tile(api, hw, monkeypatch):
+    """The sliding row pass that takes over when min(halfwidth, X) is beyond ~20 000 columns (forced here on a small field)."""
+    gridpp, O = api
+    monkeypatch.setenv("GPP_BOX_ROWS_WIDE", "1")
+    f = field(9, 61, 333)
+    for stat in (gridpp.Mean, gridpp.Sum):
+        close(gridpp.neighbourhood(f, hw, stat), O.neighbourhood(f, hw, stat))
+    close(gridpp.neighbourhood(f, hw, gridpp.Count), O.neighbourhood(f, hw, gridpp.Count), exact=True)
+    g3 = field(10, 40, 70, 6)
+    close(gridpp.neighbourhood(g3, hw, gridpp.Mean), O.neighbourhood(g3, hw, gridpp.Mean))
+
+
 @pytest.mark.parametrize("E", [1, 5, 100, 130])
 def test_3d_statistics(api, E):
     gridpp, O = api
