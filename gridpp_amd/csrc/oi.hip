@@ -214,6 +214,7 @@ template <int N, bool LU, bool PLAIN, bool SPATIAL>
 __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
+    __shared__ double s_col[4][64];   // column staging of the half-wave solves
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // all tiles (one per wave), or -- behind k_oi_union -- a fixed-size grid striding over the list of what that kernel
     // declined (the list length is read on the device: no host round trip between the kernels).  A list entry >= 0 is
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
 
         // ---- dense solves: one augmented Cholesky per DISTINCT observation set -----------------------------------
         unsigned long long todo = __ballot(cnt > 0);
+        if(a.debug & 1) todo = 0ull;   // GPP_OI_DEBUG bit0: skip the solves (timing experiments only)
         const int nupd = __popcll(todo);
         int nsolve = 0;
         bool bad = false;
@@ -497,19 +499,38 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
             float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
             if(hl < nh) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
             const bool is_g = hl == 31;
-            float px = __shfl(gx, lh), py = __shfl(gy, lh), pz = __shfl(gz, lh), pe = __shfl(ge, lh), pl = __shfl(gl, lh);
+            const float cx = __shfl(gx, lh), cy = __shfl(gy, lh), cz = __shfl(gz, lh), ce = __shfl(ge, lh), cl = __shfl(gl, lh);
             const float cbg = __shfl(bg, lh), cbv = __shfl(bvar, lh);
-            if(hl < nh) { px = o0.x; py = o0.y; pz = o0.z; pe = o0.w; pl = o1.x; }
             float maxInc = -INFINITY, minInc = INFINITY;
-            for(int p = 0; p < nmax; ++p) {
-                const int sp = base + p;
-                const float xp = __shfl(o0.x, sp), yp = __shfl(o0.y, sp), zp = __shfl(o0.z, sp);
-                const float ep = __shfl(o0.w, sp), lp = __shfl(o1.x, sp);
-                const float c = d_corr_t<PLAIN>(a.s.st, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
-                colbuf[p][lane] = (p < nh) ? c : 0.0f;
-                const float dpf = (float)((double)__shfl(o1.y, sp) - (double)__shfl(o1.z, sp));
-                if(p < nh) { maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf); }
+            if(!a.allow_extrap) {   // extremes of obs - background over the half's selection (oi.cpp:318-334)
+                const float dpf = (float)((double)o1.y - (double)o1.z);
+                maxInc = hl < nh ? dpf : -INFINITY; minInc = hl < nh ? dpf : INFINITY;
+                for(int off = 16; off > 0; off >>= 1) { maxInc = fmaxf(maxInc, __shfl_xor(maxInc, off)); minInc = fminf(minInc, __shfl_xor(minInc, off)); }
             }
+            // lower triangle of P (oi.cpp:304-312) and the G row (oi.cpp:250) of each half, one entry per lane and pass: entry
+            // e = i (i + 1) / 2 + p (p <= i) for e < ntri, then G entry p = e - ntri; the records of both points come by ds_bpermute
+            const int ntri = nh * (nh + 1) / 2, nent = ntri + nh, nentmax = nmax * (nmax + 1) / 2 + nmax;
+            for(int e0 = 0; e0 < nentmax; e0 += 32) {
+                const int e = e0 + hl;
+                const bool gent = e >= ntri;
+                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                if(i * (i + 1) / 2 > e) i--;
+                if((i + 1) * (i + 2) / 2 <= e) i++;
+                int pc = e - i * (i + 1) / 2;
+                if(gent) { pc = min(e - ntri, 29); i = 31; }
+                const int si = base + min(i, 29), sp = base + pc;
+                float xi = __shfl(o0.x, si), yi = __shfl(o0.y, si), zi = __shfl(o0.z, si), ei = __shfl(o0.w, si), li = __shfl(o1.x, si);
+                const float xp = __shfl(o0.x, sp), yp = __shfl(o0.y, sp), zp = __shfl(o0.z, sp), ep = __shfl(o0.w, sp), lp = __shfl(o1.x, sp);
+                xi = gent ? cx : xi; yi = gent ? cy : yi; zi = gent ? cz : zi; ei = gent ? ce : ei; li = gent ? cl : li;
+                const float c = d_corr_t<PLAIN>(a.s.st, xi, yi, zi, ei, li, xp, yp, zp, ep, lp, gent);
+                if(e < nent) colbuf[pc][base + i] = c;
+            }
+            // obs and background at the observations for the obs - background row (lane 30 of the half): obs rides in column
+            // position 30 of every matrix column, the background in row 30 of the staging area
+            if(hl < nh) { colbuf[hl][base + 30] = o1.y; colbuf[30][base + hl] = o1.z; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             double row[30];
             const bool used = hl < nh || hl >= 30;
 #pragma unroll
@@ -517,13 +538,15 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                 double v = 0.0;
                 if(p < nmax) {
                     v = (double)colbuf[p][lane];
-                    if(hl == p) v += (double)o1.w;
-                    const double dp = (double)__shfl(o1.y, base + p) - (double)__shfl(o1.z, base + p);
-                    if(hl == 30) v = dp;
-                    if(!used || p >= nh) v = 0.0;
+                    if(hl == p) v += (double)o1.w;                                       // lP + lR
+                    if(hl == 30) v = v - (double)colbuf[30][base + p];                   // lObs - lY
+                    if(!used || p >= nh || (hl < p)) v = 0.0;                            // (only the lower triangle is read)
                 }
                 row[p] = v;
             }
+            __builtin_amdgcn_wave_barrier();
+            // right-looking Cholesky; column j goes to LDS once (s_col) and comes back as broadcast reads inside the half
+            double* const colL = s_col[wid];
 #pragma unroll
             for(int j = 0; j < 30; ++j) {
                 if(j < nmax) {
@@ -536,17 +559,23 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                     rs = rs * (1.5 - 0.5 * aj * rs * rs);
                     const double cj = colok ? row[j] * rs : 0.0;
                     row[j] = cj;
+                    colL[lane] = cj;
 #pragma unroll
-                    for(int p = j + 1; p < 30; ++p) {
-                        const double lpj = __shfl(cj, base + p);
-                        row[p] = __builtin_fma(-cj, lpj, row[p]);
-                    }
+                    for(int p = j + 1; p < 30; ++p) row[p] = __builtin_fma(-cj, colL[base + p], row[p]);
                 }
             }
             double inc = 0.0, a00 = 0.0;
 #pragma unroll
             for(int p = 0; p < 30; ++p) {
-                const double tp = __shfl(row[p], base + 30);
+                if(hl == 30) colL[base + p] = row[p];           // L^-1 (obs - background)
+            }
+            // (one lane writes, the others read: without the fences the compiler orders the two sides per thread -- readers first)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for(int p = 0; p < 30; ++p) {
+                const double tp = colL[base + p];
                 inc = __builtin_fma(row[p], tp, inc);
                 a00 = __builtin_fma(row[p], row[p], a00);
             }
@@ -561,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                 s_res[wid][0][lh] = cbg + increment;
                 s_res[wid][1][lh] = (float)((double)cbv * (1.0 - a00));
             }
+            __builtin_amdgcn_wave_barrier();
         };
 
         constexpr bool PAIRS = !LU && !SPATIAL && N == 32;
@@ -598,7 +628,9 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                 else solve_group(la, __builtin_amdgcn_readlane(cnt, la), 1ull << la, 1, 0ull);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (results were written by single lanes: see solve_pair)
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if(cnt > 0) { res_out = s_res[wid][0][lane]; res_var = s_res[wid][1][lane]; }
         if(__ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
         if(lane == 0 && a.counters) {
