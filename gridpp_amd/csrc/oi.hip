@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void k_oi_huge(OiArgs a, const int* __restrict
 // -------------------------------------------------------------------------------------------
 namespace {
 struct OiWorkspace {
-    DevBuf<float4> pgeo, oaux;
+    DevBuf<float4> pgeo, oaux, saux;
     DevBuf<float> ones;
     // status block of a call, one memset and one read-back: ints [0] err, [1..3] work-list lengths, [4] large-n cell count;
     // statistics counters from byte 64 on
@@ -1261,7 +1261,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     gpp_obs_index* ix = gpp_build_obs_index(points);
 
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); GPP_HIP(hipEventCreate(&ws.eu)); }
-    ws.pgeo.get(S); ws.oaux.get(S);
+    ws.pgeo.get(S); ws.oaux.get(S); ws.saux.get(S);
     constexpr size_t SB = 8 + 80 + 2 * GPP_NSLOT;   // status block, in 8-byte words
     ws.status.get(SB);
     if(!ws.h_status) GPP_HIP(hipHostMalloc((void**)&ws.h_status, SB * sizeof(unsigned long long), hipHostMallocDefault));
@@ -1270,7 +1270,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     unsigned long long* const d_counters = ws.status.p + 8;
     GPP_HIP(hipMemsetAsync(ws.status.p, 0, SB * sizeof(unsigned long long), stream()));
     hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
-                       f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p);
+                       f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p, ws.saux.p);
     GPP_HIP(hipGetLastError());
 
     // register-tile size of the solve: 32 rows (max_points <= 32, the common case) or 62 rows (everything up to 62
@@ -1289,7 +1289,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     }
     else { a.tiles_x = 0; a.ntiles = (C + 63) / 64; }
     a.s.pgeo = ws.pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
-    a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
+    a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p; a.saux = ws.saux.p;
     a.S = S; a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
     a.s.st = gpp_resolve_structure(st);

@@ -237,7 +237,8 @@ __device__ __forceinline__ int wave_scan_add(int x) {
 // Per-call observation pack: validity (oi.cpp:252), variance ratio (oi.cpp:192-195).
 static __global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const int* __restrict__ pos, const float* __restrict__ olaf,
                            const float* __restrict__ obs, const float* __restrict__ obs_var, const float* __restrict__ pbg,
-                           const float* __restrict__ bvp, int need_pbg, float4* __restrict__ pgeo, float4* __restrict__ oaux) {
+                           const float* __restrict__ bvp, int need_pbg, float4* __restrict__ pgeo, float4* __restrict__ oaux,
+                           float4* __restrict__ saux = nullptr) {   // saux: the same record at the SORTED position (optional)
     int o = blockIdx.x * blockDim.x + threadIdx.x;
     if(o >= S) return;
     float ob = obs[o], pb = pbg ? pbg[o] : 0.0f;
@@ -245,6 +246,7 @@ static __global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const 
     float ratio = obs_var[o] / bv;
     oaux[o] = make_float4(olaf[o], ob, pb, ratio);
     int p = pos[o];
+    if(saux) saux[p] = make_float4(olaf[o], ob, pb, ratio);
     float4 g = sgeo[p];
     bool ok = d_valid(ob) && (!need_pbg || d_valid(pb));
     if(!ok) g.x = NAN;   // fails the box test of the radius query -> never a candidate

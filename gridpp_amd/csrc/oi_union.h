@@ -27,6 +27,7 @@ struct OiArgs {
     ScanArgs s;
     const float4* ogeo;      // original order
     const float4* oaux;      // original order: laf, obs, pbg, ratio
+    const float4* saux;      // the same records at the sorted positions (k_oi_union: one dependent load less per tile)
     int S, allow_extrap;
     int* err;                // bit0: list overflow (needs the large-n path), bit1: singular / not SPD
     unsigned long long* counters;   // [80 + 2 k], [81 + 2 k]: cells updated, factorisations -- spread over GPP_NSLOT slots (k = block
@@ -581,8 +582,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         if(lane < u) {
             const int pos = L.wpos[myslot];
             o0 = sa.pgeo[pos];
-            const float2 met = sa.smeta[pos];
-            o1 = a.oaux[__float_as_int(met.y)];
+            o1 = a.saux[pos];
         }
         const float dpf = (float)((double)o1.y - (double)o1.z);   // obs - background at the observation (oi.cpp:293)
         // this cell's rho for every row of the union (lG, oi.cpp:296); afterwards the rho slots are dead and the
@@ -619,6 +619,12 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
                 colbuf[pcol * U_MAXU + i] = cv;
             }
         }
+        // obs - background of every row (oi.cpp:293) for the row of lane 63: through the (still free) column staging area
+        double* const colL = L.f.solve + (U_SOLVE - 64);   // free until the export (the P staging and 1/diag live below it)
+        if(lane < u) colL[lane] = (double)o1.y - (double)o1.z;                                             // lObs - lY
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         UPROF(7);   // P build
         double row[NC];
 #pragma unroll
@@ -629,8 +635,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
                     v = (double)colbuf[p * U_MAXU + lane];
                     if(lane == p) v += (double)o1.w;                                                       // lP + lR
                 }
-                const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);               // lObs - lY
-                if(lane == 63) v = dp;
+                if(lane == 63) v = colL[p];
             }
             row[p] = v;
         }
@@ -646,8 +651,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
                     v = (double)colbuf[p * U_MAXU + lane];
                     if(lane == p) v += (double)o1.w;
                 }
-                const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);
-                if(lane == 63) v = dp;
+                if(lane == 63) v = colL[p];
                 if((lane >= p && lane < u) || lane == 63) L.late[b][lidx] = v;
             }
         }
@@ -655,7 +659,6 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         // layout of the shared-factor area (doubles)
         const int oL = 0, oI = c * (c + 1) / 2, oZ = oI + c, oB = oZ + c, bs = c | 1, oS = oB + nE * bs, oD = oS + nE * nE;
         double* const sv = L.f.solve;
-        double* const colL = L.f.solve + (U_SOLVE - 64);   // free until the export (1/diag lives below index 600)
         bool bad = false;
         // right-looking Cholesky over the core columns; the trailing rows/columns end as B, the Schur complement, L_C^-1 d, d'
 #pragma unroll
@@ -677,29 +680,33 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         UPROF(8);   // row load + elimination
         // export: L_C rows packed, B rows (stride bs), L_C^-1 d, Schur complement, d'
         const int ea = lane - c;   // extras row index of this lane
+        {   // one masked store per column: every lane has a last column and two bases (columns below c / from c on); written
+            // with nested ifs this loop compiled to ~60 mostly scalar instructions and a dozen branches per column
+            int maxp = -1, baseLo = 0, baseHi = 0;
+            if(lane < c) { maxp = lane; baseLo = oL + lane * (lane + 1) / 2; baseHi = baseLo; }
+            else if(lane < u) { maxp = u - 1; baseLo = oB + ea * bs; baseHi = oS + ea * nE - c; }
+            else if(lane == 63) { maxp = u - 1; baseLo = oZ; baseHi = oD - c; }
 #pragma unroll
-        for(int p = 0; p < NC; ++p) {
-            if(p < u) {
-                if(lane < c) { if(p <= lane) sv[oL + lane * (lane + 1) / 2 + p] = row[p]; }
-                else if(lane < u) {
-                    if(p < c) sv[oB + ea * bs + p] = row[p];
-                    else sv[oS + ea * nE + (p - c)] = row[p];
-                }
-                else if(lane == 63) {
-                    if(p < c) sv[oZ + p] = row[p];
-                    else sv[oD + (p - c)] = row[p];
-                }
+            for(int p = 0; p < NC; ++p) {
+                const int bse = (p < c) ? baseLo : baseHi;
+                if(p <= maxp) sv[bse + p] = row[p];
             }
         }
         if(U_MAXU > NC && u > 32 && !(a.debug & 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
+            // (row p of B has just been exported: it comes back as LDS broadcasts, one read per two multiply-adds, instead of a
+            //  v_readlane pair per multiply-add; columns c.. of the padded row are multiplied by zeros)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for(int b = 0; b < 8; ++b) {
                 const int p = 32 + b;
                 if(p < u) {
                     const bool mine = (lane >= p && lane < u) || lane == 63;
                     double acc = mine ? L.late[b][lidx] : 0.0;
+                    const double* const bp = sv + oB + (p - c) * bs;
 #pragma unroll
-                    for(int k = 0; k < 32; ++k) if(k < c) acc = __builtin_fma(-row[k], readlane_d(row[k], p), acc);
+                    for(int k = 0; k < 32; ++k) if(k < c) acc = __builtin_fma(-row[k], bp[k], acc);
                     if(lane >= p && lane < u) sv[oS + ea * nE + (p - c)] = acc;
                     else if(lane == 63) sv[oD + (p - c)] = acc;
                 }
