@@ -24,6 +24,8 @@ using namespace gpp;
 #define EMAXV 64       // max valid ensemble members (one lane per member)
 #define BP (EN + 1)    // pitch of B / U (doubles)
 
+#define ENSI_PARK_D 1120   // doubles parked per cell: M' 1024 | sD 32 | z 32 | rho 32
+
 struct EnsiArgs {
     const float *gx, *gy, *gz, *gelev, *glaf;
     const float* bg;          // [C][E]
@@ -35,13 +37,15 @@ struct EnsiArgs {
     const float* gY;          // [S][nV] perturbations of the valid members (float)
     const int* validIdx;      // [nV]
     unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
-    double *upark, *mpark;    // [ntiles][64][32] k_ensi_pair: parked eigenvector rows / middle-matrix rows of the current pair of cells
+    double* cpark;            // [tiles of the batch][64][ENSI_PARK_D] k_ensi_pair -> k_ensi_members: M' (32 x 32), sD, z, rho of every cell
+    int tile0;                // first tile of the batch
     unsigned* meta;           // [ntiles][64] k_ensi_scan -> k_ensi_pair: selection length | 0x100 if the reference sorted
     unsigned long long* hsigs;   // [ntiles][64] order-independent signature of every selection
     double* gram;             // [ntiles][EN*EN] scratch: Y Y^T of the current run of equal selections
     int* big_list;            // cells with more usable observations than the 32-row tile holds (k_ensi_big), or NULL
     int* big_count;
     unsigned long long* big_keys;   // per workgroup of k_ensi_big: EBIG_CAND sorted candidate keys
+    double jtol2;             // k_ensi_pair: the Jacobi sweeps stop at (off-diagonal norm)^2 <= jtol2 * trace^2
     int debug;                // GPP_ENSI_DEBUG (timing experiments only): 1 no Jacobi, 2 no member update, 4 no B build, 8 no M_W
     int nV;
     int allow_extrap;
@@ -740,7 +744,7 @@ struct EnsiWorkspace {
     DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
     DevBuf<unsigned> sel, meta;
     DevBuf<unsigned long long> hsigs;
-    DevBuf<double> gram, upark, mpark;
+    DevBuf<double> gram, cpark;
     DevBuf<unsigned long long> counters, big_keys;
     DevBuf<int> big_list, big_count;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -847,6 +851,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
     a.gram = ws.gram.get((size_t)a.ntiles * EN * EN);
     a.debug = getenv("GPP_ENSI_DEBUG") ? atoi(getenv("GPP_ENSI_DEBUG")) : 0;
+    a.jtol2 = getenv("GPP_ENSI_JTOL2") ? atof(getenv("GPP_ENSI_JTOL2")) : 1e-12;
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
     // cells with more than 32 usable observations go to k_ensi_big (scalar structure functions; the spatially varying forms
@@ -859,16 +864,24 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     GPP_HIP(hipEventRecord(ws.e0, stream()));
     if(use_pair) {
         a.meta = ws.meta.get((size_t)a.ntiles * 64);
-        a.upark = ws.upark.get((size_t)a.ntiles * 64 * 32);
-        a.mpark = ws.mpark.get((size_t)a.ntiles * 64 * 32);
         a.hsigs = ws.hsigs.get((size_t)a.ntiles * 64);
-        if(a.s.st.fh) {
-            hipLaunchKernelGGL(k_ensi_scan<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
-            hipLaunchKernelGGL(k_ensi_pair<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
-        }
-        else {
-            hipLaunchKernelGGL(k_ensi_scan<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
-            hipLaunchKernelGGL(k_ensi_pair<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+        if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_scan<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+        else hipLaunchKernelGGL(k_ensi_scan<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
+        GPP_HIP(hipGetLastError());
+        // spectral side (pairs of cells, warm-started along a tile) and ensemble side (one wave per cell) in batches of tiles: what
+        // the second kernel needs of a cell (8.75 KB) waits in HBM, 24 GB of the 288 at most (GPP_ENSI_PARK_MB)
+        size_t park_bytes = (size_t)24 << 30;
+        if(getenv("GPP_ENSI_PARK_MB")) park_bytes = (size_t)atol(getenv("GPP_ENSI_PARK_MB")) << 20;
+        const size_t per_tile = (size_t)64 * ENSI_PARK_D * sizeof(double);
+        const int tcap = (int)std::max<size_t>(1, std::min<size_t>((size_t)a.ntiles, park_bytes / per_tile));
+        a.cpark = ws.cpark.get((size_t)tcap * 64 * ENSI_PARK_D);
+        for(int t0 = 0; t0 < a.ntiles; t0 += tcap) {
+            const int nt = std::min(tcap, a.ntiles - t0);
+            a.tile0 = t0;
+            if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_pair<true>, dim3(nt), dim3(64), 0, stream(), a);
+            else hipLaunchKernelGGL(k_ensi_pair<false>, dim3(nt), dim3(64), 0, stream(), a);
+            hipLaunchKernelGGL(k_ensi_members<0>, dim3((unsigned)nt * 64u), dim3(64), 0, stream(), a);
+            GPP_HIP(hipGetLastError());
         }
     }
     else if(a.s.st.fh) hipLaunchKernelGGL(k_ensi<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);

@@ -259,10 +259,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     float* const s_yh = reinterpret_cast<float*>(s_i + 64);
     unsigned* const s_sel = reinterpret_cast<unsigned*>(s_i + 96);
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int tile = a.tile0 + blockIdx.x;
     const int h = lane >> 5, i = lane & 31;
     const bool m1 = (i & 2) != 0, m2 = (i & 4) != 0, m3 = (i & 8) != 0, m4 = (i & 16) != 0;
-    const int nV = a.nV, E = a.E;
+    const int nV = a.nV;
     if(nV <= 1) return;   // Pinv is the zero matrix: rcond <= 0 -> raw values everywhere (oi_ensi.cpp:386-390)
     const unsigned meta = a.meta[(size_t)tile * 64 + lane];
     const int cnt = ensi_cell_of(a, tile, lane) >= 0 ? (int)(meta & 0xffu) : 0;
@@ -273,11 +273,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
     const double sqc = sqrt(c);
-    // Between two pairs the eigenvectors of each half's last cell (the warm start) and, between the spectral step and the
-    // ensemble side, the middle matrices wait in HBM (2 x 16 KB per tile, L2 resident): held in registers they would cost
-    // the ensemble side its register budget.
-    double* const upark = a.upark + ((size_t)tile * 64 + lane) * 32;
-    double* const mpark = a.mpark + ((size_t)tile * 64 + lane) * 32;
+    // The eigenvectors of each half's last cell stay in registers between two pairs (the warm start).  What the ensemble side
+    // (k_ensi_members, one wave per cell) needs of a cell -- M' = sD (U Mmid U^T) sD, sD, z, rho -- is parked in HBM.
+    double u[32];
+#pragma unroll
+    for(int j = 0; j < 32; ++j) u[j] = (j == i) ? 1.0 : 0.0;
 #ifdef GPP_ENSI_PROFILE
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
@@ -358,12 +358,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 __threadfence();
                 __syncthreads();
             }
-            double b[32], u[32];
-            if(same) {
-#pragma unroll
-                for(int j = 0; j < 32; j += 2) { const double2 w = *reinterpret_cast<const double2*>(&upark[j]); u[j] = w.x; u[j + 1] = w.y; }
-            }
-            else {
+            double b[32];
+            if(!same) {
 #pragma unroll
                 for(int j = 0; j < 32; ++j) u[j] = (j == i) ? 1.0 : 0.0;
             }
@@ -423,7 +419,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 // functions below through their first-order (Daleckii-Krein) term, f(L + E) = f(L) + f[L_i, L_j] o E + O(|E|^2) with
                 // bounded divided differences (no small eigenvalue gaps in any denominator), so the result is good to ~1e-12 -- and
                 // the last sweep of a plain Jacobi iteration, which only polishes 1e-8 down to 1e-16, is not run at all
-                const bool open = off > 1e-12 * tr * tr;
+                const bool open = off > a.jtol2 * tr * tr;
                 if(__ballot(open && !(dup && h == 1)) == 0ull) break;
                 nsweeps++;
 #pragma unroll 1
@@ -442,80 +438,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const double inv = 1.0 / (c + S);
             __syncthreads();
             s_dwa[h][0][i] = dwv; s_dwa[h][1][i] = rt;
-            // eigenvectors -> park (warm start of the next pair, operand of the products below)
-#pragma unroll
-            for(int j = 0; j < 32; j += 2) { double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&upark[j]) = w; }
             __syncthreads();
-            // middle matrix of W_sym: diag(dw) + G1 o E,  G1(i, j) = (g_i - g_j) / (S_i - S_j) = (1 + sqrt(c) / (a_i + a_j)) dw_i dw_j  (a = sqrt(c + S));
-            // G1 multiplies entries 1e-6 of the trace and smaller, a float reciprocal is plenty  -> park
-#pragma unroll
-            for(int j = 0; j < 32; j += 2) {
-                double2 v;
-                const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_dwa[h][1][j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_dwa[h][1][j + 1]));
-                v.x = (j == i) ? dwv : (1.0 + sqc * (double)r0) * (dwv * s_dwa[h][0][j]) * b[j];
-                v.y = (j + 1 == i) ? dwv : (1.0 + sqc * (double)r1) * (dwv * s_dwa[h][0][j + 1]) * b[j + 1];
-                *reinterpret_cast<double2*>(&mpark[j]) = v;
-            }
-            // z = U [diag(1 / (c + S)) + H1 o E] U^T r,  H1(i, j) = -1 / ((c + S_i)(c + S_j)), one cell after the other through area B
+            // ---- per cell: z and M' = sD (U Mmid U^T) sD, parked for k_ensi_members -----------------------------------------------------
 #pragma unroll 1
-            for(int hh = 0; hh < 2; ++hh) {
+            for(int hh = 0; hh < (dup ? 1 : 2); ++hh) {
+                const int lcell = hh ? lb : la;
+                double* const park = a.cpark + ((size_t)(tile - a.tile0) * 64 + lcell) * ENSI_PARK_D;
                 __syncthreads();
                 if(h == hh) {
+                    // eigenvectors -> area B; middle matrix of W_sym -> area A:  diag(dw) + G1 o E,
+                    // G1(i, j) = (g_i - g_j) / (S_i - S_j) = (1 + sqrt(c) / (a_i + a_j)) dw_i dw_j  (a = sqrt(c + S));
+                    // G1 multiplies entries 1e-6 of the trace and smaller, a float reciprocal is plenty
 #pragma unroll
-                    for(int j = 0; j < 32; j += 2) { double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w; }
+                    for(int j = 0; j < 32; j += 2) {
+                        double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w;
+                        double2 v;
+                        const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_dwa[h][1][j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_dwa[h][1][j + 1]));
+                        v.x = (j == i) ? dwv : (1.0 + sqc * (double)r0) * (dwv * s_dwa[h][0][j]) * b[j];
+                        v.y = (j + 1 == i) ? dwv : (1.0 + sqc * (double)r1) * (dwv * s_dwa[h][0][j + 1]) * b[j + 1];
+                        *reinterpret_cast<double2*>(&sA[i * PP + j]) = v;
+                    }
                 }
                 __syncthreads();
+                // z = U [diag(1 / (c + S)) + H1 o E] U^T r,  H1(i, j) = -1 / ((c + S_i)(c + S_j))
                 if(h == hh) {
-                    double ur = 0.0;
+                    double ur0 = 0.0, ur1 = 0.0;
 #pragma unroll 8
-                    for(int r = 0; r < 32; ++r) ur = __builtin_fma(sB[r * PP + i], s_r[hh][r], ur);
-                    s_t[i] = ur * inv;
+                    for(int r = 0; r < 32; r += 2) { ur0 = __builtin_fma(sB[r * PP + i], s_r[hh][r], ur0); ur1 = __builtin_fma(sB[(r + 1) * PP + i], s_r[hh][r + 1], ur1); }
+                    s_t[i] = (ur0 + ur1) * inv;
                 }
                 __syncthreads();
                 double t2 = 0.0;
                 if(h == hh) {
-                    double corr = 0.0;
+                    double corr0 = 0.0, corr1 = 0.0;
 #pragma unroll
-                    for(int j = 0; j < 32; ++j) corr = __builtin_fma((j == i) ? 0.0 : b[j], s_t[j], corr);
-                    t2 = s_t[i] - inv * corr;
+                    for(int j = 0; j < 32; j += 2) {
+                        corr0 = __builtin_fma((j == i) ? 0.0 : b[j], s_t[j], corr0);
+                        corr1 = __builtin_fma((j + 1 == i) ? 0.0 : b[j + 1], s_t[j + 1], corr1);
+                    }
+                    t2 = s_t[i] - inv * (corr0 + corr1);
                 }
                 __syncthreads();
                 if(h == hh) s_t[i] = t2;
                 __syncthreads();
                 if(h == hh) {
-                    double zz = 0.0;
+                    double zz0 = 0.0, zz1 = 0.0;
 #pragma unroll
-                    for(int j = 0; j < 32; ++j) zz = __builtin_fma(u[j], s_t[j], zz);
-                    s_z[hh][i] = zz;
+                    for(int j = 0; j < 32; j += 2) { zz0 = __builtin_fma(u[j], s_t[j], zz0); zz1 = __builtin_fma(u[j + 1], s_t[j + 1], zz1); }
+                    park[1024 + i] = sD;
+                    park[1056 + i] = zz0 + zz1;
+                    park[1088 + i] = (double)rho;
                 }
-            }
-            __threadfence();
-            __syncthreads();
-            EPROF(4)   // park, middle matrix, z
-            // ---- per cell: M_W, then the ensemble side ----------------------------------------------------------------------------------------
-#pragma unroll 1
-            for(int hh = 0; hh < (dup ? 1 : 2); ++hh) {
-                const int lcell = hh ? lb : la;
-                const int cell_l = ensi_cell_of(a, tile, lcell);
-                __syncthreads();
-                {   // eigenvectors and middle matrix of this cell: park -> areas B and A (lane l fetches half a row of each)
-                    const double* const up = a.upark + ((size_t)tile * 64 + 32 * hh + i) * 32 + 16 * h;
-                    const double* const mp = a.mpark + ((size_t)tile * 64 + 32 * hh + i) * 32 + 16 * h;
-#pragma unroll
-                    for(int j = 0; j < 16; j += 2) {
-                        *reinterpret_cast<double2*>(&sB[i * PP + 16 * h + j]) = *reinterpret_cast<const double2*>(&up[j]);
-                        *reinterpret_cast<double2*>(&sA[i * PP + 16 * h + j]) = *reinterpret_cast<const double2*>(&mp[j]);
-                    }
-                }
-                __syncthreads();
-                // M_W = U Mmid U^T, scaled: M'(i, j) = sD_i M_W(i, j) sD_j   -> area A (stays there for the whole member update)
+                EPROF(4)   // staging, z
+                // M_W = U Mmid U^T, scaled: M'(i, j) = sD_i M_W(i, j) sD_j
                 {
                     const Acc32 tm = mfma_32_full(lane, [&](int r, int k) { return sB[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
                     __syncthreads();
                     acc32_store_full(tm, lane, sA);
                     __syncthreads();
                     const Acc32 mw = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[cc * PP + k]; });
-                    __syncthreads();
 #pragma unroll
                     for(int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -523,166 +504,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                             for(int r = 0; r < 4; ++r) {
                                 const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
-                                sA[row * PP + col] = (a.debug & 8) ? 0.0 : mw.t[ti][tj][r] * (s_sD[hh][row] * s_sD[hh][col]);
+                                park[row * 32 + col] = (a.debug & 8) ? 0.0 : mw.t[ti][tj][r] * (s_sD[hh][row] * s_sD[hh][col]);
                             }
                 }
-                __syncthreads();
-                EPROF(5)   // fetch from the park, M_W
-                // anti-extrapolation tables (oi_ensi.cpp:520-552): lY[e] is a LINEAR index into the n x nV column-major matrix, so it
-                // depends on the ORDER of the selected observations: rho descending when the reference sorted (more usable
-                // observations than max_points), candidate (= index) order otherwise
-                if(!a.allow_extrap) {
-                    const bool tr_l = (trunc_mask >> lcell) & 1ull;
-                    unsigned long long* const s_k64 = reinterpret_cast<unsigned long long*>(s_t);   // 32 keys (s_t is free again)
-                    if(h == hh) s_k64[i] = (i < n) ? (((tr_l ? (unsigned long long)__float_as_uint(rho) << 32 : 0ull)) | (unsigned)(~orig_i)) : 0ull;
-                    __syncthreads();
-                    if(h == hh && i < n) {
-                        const unsigned long long mine = s_k64[i];
-                        int rank = 0;
-                        for(int j = 0; j < n; ++j) rank += (s_k64[j] > mine) ? 1 : 0;
-                        s_perm[rank] = (int)orig_i;
-                        s_ob[i] = o1.y; s_yh[i] = o1.z;
-                    }
-                    __syncthreads();
-                }
-                // ---- ensemble side: all 64 lanes, lane = member (chunks of 64) -----------------------------------------------------------------
-                // ensemble mean: sequential float sum over the valid members in member order (oi_ensi.cpp:447-461)
-                float total = 0.0f;
-                for(int m0 = 0; m0 < nV; m0 += 64) {
-                    const float v = (m0 + lane < nV) ? a.bg[(long)cell_l * E + a.validIdx[m0 + lane]] : 0.0f;
-                    const int kend = min(64, nV - m0);
-                    for(int k = 0; k < kend; ++k) total += readlane_f(v, k);
-                }
-                const float ensMean = total / (float)nV;
-#pragma unroll 1
-                for(int e0_ = 0; e0_ < nV; e0_ += 64) {
-                    const int e = e0_ + lane;
-                    EPROF(6)   // tables, ensemble mean
-                    // Y tile of this member chunk -> area B (floats)
-                    __syncthreads();
-#pragma unroll 4
-                    for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = (r < n && e < nV) ? a.gY[(long)s_sel[r] * nV + e] : 0.0f;
-                    __syncthreads();
-                    // Q = M' Y  (32 x 64) on the matrix cores
-                    v4d qa[2][4];
-#pragma unroll
-                    for(int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                        for(int tj = 0; tj < 4; ++tj) qa[ti][tj] = (v4d){0.0, 0.0, 0.0, 0.0};
-                    {
-                        const int r = lane & 15, kq = lane >> 4;
-#pragma unroll
-                        for(int ks = 0; ks < 8; ++ks) {
-                            double bop[4];
-#pragma unroll
-                            for(int tj = 0; tj < 4; ++tj) bop[tj] = (double)sBf[(4 * ks + kq) * YP + 16 * tj + r];
-                            const double am0 = sA[r * PP + 4 * ks + kq], am1 = sA[(r + 16) * PP + 4 * ks + kq];
-#pragma unroll
-                            for(int tj = 0; tj < 4; ++tj) {
-                                qa[0][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(am0, bop[tj], qa[0][tj], 0, 0, 0);
-                                qa[1][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(am1, bop[tj], qa[1][tj], 0, 0, 0);
-                            }
-                        }
-                    }
-                    EPROF(7)   // Y tile, Q = M' Y
-                    // transposed through area B, 32 members at a time: Qt[member][row]
-                    double q[32];
-#pragma unroll
-                    for(int half = 0; half < 2; ++half) {
-                        __syncthreads();
-#pragma unroll
-                        for(int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                            for(int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                                for(int r = 0; r < 4; ++r) sB[(16 * tj + (lane & 15)) * PP + 16 * ti + (lane >> 4) + 4 * r] = qa[ti][2 * half + tj][r];
-                        __syncthreads();
-#pragma unroll
-                        for(int j = 0; j < 32; j += 2) {   // (selects, not a conditional store: the array must stay in registers)
-                            const double2 v = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
-                            q[j] = (half == 0 || h == 1) ? v.x : q[j]; q[j + 1] = (half == 0 || h == 1) ? v.y : q[j + 1];
-                        }
-                    }
-                    const float value = (e < nV) ? a.bg[(long)cell_l * E + a.validIdx[e]] : 0.0f;
-                    const double X = (double)value - (double)ensMean;
-                    EPROF(8)   // transposition of Q
-                    // total_e = sum_k X_k W(k,e), W(k,e) = [k == e] + sum_i Y(i,k) q_e(i) + w_k, float accumulation in k order (:505-511)
-                    float acc = 0.0f;
-#pragma unroll 1
-                    for(int k0 = 0; k0 < nV; k0 += 32) {
-                        const int kk = k0 + i;    // lanes i and 32 + i share column kk: rows [16 h, 16 h + 16)
-                        __syncthreads();
-                        {   // column kk of Y as doubles, X_kk and w_kk = sum_r sD_r Y(r,kk) z_r  -> row i of the table in area B
-                            double wk = 0.0;
-#pragma unroll
-                            for(int rr = 0; rr < 16; rr += 2) {
-                                const int r = 16 * h + rr;
-                                double2 v;
-                                v.x = (r < n && kk < nV) ? (double)a.gY[(long)s_sel[r] * nV + kk] : 0.0;
-                                v.y = (r + 1 < n && kk < nV) ? (double)a.gY[(long)s_sel[r + 1] * nV + kk] : 0.0;
-                                wk = __builtin_fma(s_sD[hh][r] * v.x, s_z[hh][r], wk);
-                                wk = __builtin_fma(s_sD[hh][r + 1] * v.y, s_z[hh][r + 1], wk);
-                                *reinterpret_cast<double2*>(&sB[i * PP + r]) = v;
-                            }
-                            const double wo = __shfl_xor(wk, 32);
-                            if(h == 0) {
-                                const float vk = (kk < nV) ? a.bg[(long)cell_l * E + a.validIdx[kk]] : 0.0f;
-                                double2 xw; xw.x = (double)vk - (double)ensMean; xw.y = wk + wo;
-                                *reinterpret_cast<double2*>(&sB[i * PP + 32]) = xw;
-                            }
-                        }
-                        __syncthreads();
-                        const int kend = (a.debug & 2) ? 0 : min(32, nV - k0);
-                        // rows of the table two at a time, the next pair in flight while this one is used (one wave per SIMD:
-                        // nobody else hides the LDS latency)
-                        double2 ra[17], rb[17];
-                        auto load_row = [&](double2 (&dst)[17], const int k) {
-#pragma unroll
-                            for(int r = 0; r < 17; ++r) dst[r] = *reinterpret_cast<const double2*>(&sB[k * PP + 2 * r]);
-                        };
-                        auto use_row = [&](const double2 (&row)[17], const int k) {
-                            double wke = (k0 + k == e) ? 1.0 : 0.0;
-#pragma unroll
-                            for(int r = 0; r < 16; ++r) {
-                                wke = __builtin_fma(row[r].x, q[2 * r], wke);
-                                wke = __builtin_fma(row[r].y, q[2 * r + 1], wke);
-                            }
-                            wke += row[16].y;
-                            acc = (float)((double)acc + row[16].x * wke);
-                        };
-                        load_row(ra, 0);
-#pragma unroll 1
-                        for(int k = 0; k < kend; k += 2) {
-                            load_row(rb, min(k + 1, 31));
-                            __builtin_amdgcn_sched_barrier(0);
-                            use_row(ra, k);
-                            __builtin_amdgcn_sched_barrier(0);
-                            load_row(ra, min(k + 2, 31));
-                            __builtin_amdgcn_sched_barrier(0);
-                            if(k + 1 < kend) use_row(rb, k + 1);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                    EPROF(9)   // member update (k loop with its tables)
-                    float currIncrement = acc;
-                    if(!a.allow_extrap && e < nV) {
-                        const int li = e % n, lk = e / n;
-                        const double lYe = (double)a.gY[(long)(unsigned)s_perm[li] * nV + lk];
-                        float maxInc = -INFINITY, minInc = INFINITY;
-                        for(int r = 0; r < n; ++r) {
-                            const float dv = (float)((double)s_ob[r] - (lYe + (double)s_yh[r]));
-                            maxInc = fmaxf(maxInc, dv); minInc = fminf(minInc, dv);
-                        }
-                        const float memberIncrement = (float)((double)currIncrement - X);
-                        if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + X);
-                        else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + X);
-                        else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + X);
-                        else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + X);
-                    }
-                    if(e < nV) a.out[(long)cell_l * E + a.validIdx[e]] = ensMean + currIncrement;   // :553
-                }
-                __syncthreads();
+                EPROF(5)   // M_W
             }
+            __syncthreads();
         }
         todo &= ~done;
     }
@@ -690,4 +517,175 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if(lane == 0 && a.counters) for(int k = 0; k < 12; ++k) atomicAdd(&a.counters[40 + k], prof[k]);
 #endif
     if(lane == 0 && a.counters) { atomicAdd(&a.counters[1], (unsigned long long)ndone); atomicAdd(&a.counters[4 + (blockIdx.x & 31)], (unsigned long long)nsweeps); }
+}
+
+// ---- pass 3: the ensemble side, one wave per cell (lane = member, chunks of 64): no dependence between cells, so the chip runs as
+//      many of these as its registers hold -- inside k_ensi_pair this part ran at one wave per SIMD with nobody to hide its loads
+template <int UNUSED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ensi_members(EnsiArgs a) {
+    __shared__ __attribute__((aligned(16))) double s_ab[2 * 32 * PP];
+    __shared__ __attribute__((aligned(16))) double s_sD1[32], s_z1[32], s_t[32];
+    __shared__ int s_i[128];                                      // perm[32] | obs[32] | yhat[32] (floats) | selection[32]
+    double* const sA = s_ab;
+    double* const sB = s_ab + 32 * PP;
+    float* const sBf = reinterpret_cast<float*>(sB);             // Y tile [32][YP] floats
+    int* const s_perm = s_i;
+    float* const s_ob = reinterpret_cast<float*>(s_i + 32);
+    float* const s_yh = reinterpret_cast<float*>(s_i + 64);
+    unsigned* const s_sel = reinterpret_cast<unsigned*>(s_i + 96);
+    const int lane = threadIdx.x;
+    const int h = lane >> 5, i = lane & 31;
+    const int nV = a.nV, E = a.E;
+    if(nV <= 1) return;
+    const int tile = a.tile0 + (int)(blockIdx.x >> 6), lcell = (int)(blockIdx.x & 63);
+    const int cell_l = ensi_cell_of(a, tile, lcell);
+    if(cell_l < 0) return;
+    const unsigned meta = a.meta[(size_t)tile * 64 + lcell];
+    const int n = (int)(meta & 0xffu);
+    if(n == 0) return;   // no observation in range (the output already holds the background) or a cell of k_ensi_big
+    const double* const park = a.cpark + ((size_t)blockIdx.x) * ENSI_PARK_D;
+    const unsigned orig_i = (i < n) ? a.sel[(size_t)tile * EN * 64 + i * 64 + lcell] : 0xffffffffu;
+    float4 o1 = make_float4(NAN, 0, 0, 1);
+    if(i < n) o1 = a.oaux[orig_i];
+    const float rho = (float)park[1088 + i];
+    if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = park[1024 + i]; s_z1[i] = park[1056 + i]; }
+#pragma unroll
+    for(int j = 0; j < 16; j += 2) *reinterpret_cast<double2*>(&sA[i * PP + 16 * h + j]) = *reinterpret_cast<const double2*>(&park[i * 32 + 16 * h + j]);
+    __syncthreads();
+        // anti-extrapolation tables (oi_ensi.cpp:520-552): lY[e] is a LINEAR index into the n x nV column-major matrix, so it
+        // depends on the ORDER of the selected observations: rho descending when the reference sorted (more usable
+        // observations than max_points), candidate (= index) order otherwise
+        if(!a.allow_extrap) {
+            const bool tr_l = (meta & 0x100u) != 0u;
+            unsigned long long* const s_k64 = reinterpret_cast<unsigned long long*>(s_t);   // 32 keys (s_t is free again)
+            if(h == 0) s_k64[i] = (i < n) ? (((tr_l ? (unsigned long long)__float_as_uint(rho) << 32 : 0ull)) | (unsigned)(~orig_i)) : 0ull;
+            __syncthreads();
+            if(h == 0 && i < n) {
+                const unsigned long long mine = s_k64[i];
+                int rank = 0;
+                for(int j = 0; j < n; ++j) rank += (s_k64[j] > mine) ? 1 : 0;
+                s_perm[rank] = (int)orig_i;
+                s_ob[i] = o1.y; s_yh[i] = o1.z;
+            }
+            __syncthreads();
+        }
+        // ---- ensemble side: all 64 lanes, lane = member (chunks of 64) -----------------------------------------------------------------
+        // ensemble mean: sequential float sum over the valid members in member order (oi_ensi.cpp:447-461)
+        float total = 0.0f;
+        for(int m0 = 0; m0 < nV; m0 += 64) {
+            const float v = (m0 + lane < nV) ? a.bg[(long)cell_l * E + a.validIdx[m0 + lane]] : 0.0f;
+            const int kend = min(64, nV - m0);
+            for(int k = 0; k < kend; ++k) total += readlane_f(v, k);
+        }
+        const float ensMean = total / (float)nV;
+#pragma unroll 1
+        for(int e0_ = 0; e0_ < nV; e0_ += 64) {
+            const int e = e0_ + lane;
+            // Y tile of this member chunk -> area B (floats)
+            __syncthreads();
+#pragma unroll 4
+            for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = (r < n && e < nV) ? a.gY[(long)s_sel[r] * nV + e] : 0.0f;
+            __syncthreads();
+            // Q = M' Y  (32 x 64) on the matrix cores
+            v4d qa[2][4];
+#pragma unroll
+            for(int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for(int tj = 0; tj < 4; ++tj) qa[ti][tj] = (v4d){0.0, 0.0, 0.0, 0.0};
+            {
+                const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+                for(int ks = 0; ks < 8; ++ks) {
+                    double bop[4];
+#pragma unroll
+                    for(int tj = 0; tj < 4; ++tj) bop[tj] = (double)sBf[(4 * ks + kq) * YP + 16 * tj + r];
+                    const double am0 = sA[r * PP + 4 * ks + kq], am1 = sA[(r + 16) * PP + 4 * ks + kq];
+#pragma unroll
+                    for(int tj = 0; tj < 4; ++tj) {
+                        qa[0][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(am0, bop[tj], qa[0][tj], 0, 0, 0);
+                        qa[1][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(am1, bop[tj], qa[1][tj], 0, 0, 0);
+                    }
+                }
+            }
+            // transposed through area B, 32 members at a time: Qt[member][row]
+            double q[32];
+#pragma unroll
+            for(int half = 0; half < 2; ++half) {
+                __syncthreads();
+#pragma unroll
+                for(int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for(int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for(int r = 0; r < 4; ++r) sB[(16 * tj + (lane & 15)) * PP + 16 * ti + (lane >> 4) + 4 * r] = qa[ti][2 * half + tj][r];
+                __syncthreads();
+#pragma unroll
+                for(int j = 0; j < 32; j += 2) {   // (selects, not a conditional store: the array must stay in registers)
+                    const double2 v = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
+                    q[j] = (half == 0 || h == 1) ? v.x : q[j]; q[j + 1] = (half == 0 || h == 1) ? v.y : q[j + 1];
+                }
+            }
+            const float value = (e < nV) ? a.bg[(long)cell_l * E + a.validIdx[e]] : 0.0f;
+            const double X = (double)value - (double)ensMean;
+            // total_e = sum_k X_k W(k,e), W(k,e) = [k == e] + sum_i Y(i,k) q_e(i) + w_k, float accumulation in k order (:505-511)
+            float acc = 0.0f;
+#pragma unroll 1
+            for(int k0 = 0; k0 < nV; k0 += 32) {
+                const int kk = k0 + i;    // lanes i and 32 + i share column kk: rows [16 h, 16 h + 16)
+                __syncthreads();
+                {   // column kk of Y as doubles, X_kk and w_kk = sum_r sD_r Y(r,kk) z_r  -> row i of the table in area B
+                    double wk = 0.0;
+#pragma unroll
+                    for(int rr = 0; rr < 16; rr += 2) {
+                        const int r = 16 * h + rr;
+                        double2 v;
+                        v.x = (r < n && kk < nV) ? (double)a.gY[(long)s_sel[r] * nV + kk] : 0.0;
+                        v.y = (r + 1 < n && kk < nV) ? (double)a.gY[(long)s_sel[r + 1] * nV + kk] : 0.0;
+                        wk = __builtin_fma(s_sD1[r] * v.x, s_z1[r], wk);
+                        wk = __builtin_fma(s_sD1[r + 1] * v.y, s_z1[r + 1], wk);
+                        *reinterpret_cast<double2*>(&sB[i * PP + r]) = v;
+                    }
+                    const double wo = __shfl_xor(wk, 32);
+                    if(h == 0) {
+                        const float vk = (kk < nV) ? a.bg[(long)cell_l * E + a.validIdx[kk]] : 0.0f;
+                        double2 xw; xw.x = (double)vk - (double)ensMean; xw.y = wk + wo;
+                        *reinterpret_cast<double2*>(&sB[i * PP + 32]) = xw;
+                    }
+                }
+                __syncthreads();
+                const int kend = (a.debug & 2) ? 0 : min(32, nV - k0);
+                // one row of the table per step (other waves of the SIMD hide the LDS latency here)
+#pragma unroll 1
+                for(int k = 0; k < kend; ++k) {
+                    double2 row[17];
+#pragma unroll
+                    for(int r = 0; r < 17; ++r) row[r] = *reinterpret_cast<const double2*>(&sB[k * PP + 2 * r]);
+                    double wke = (k0 + k == e) ? 1.0 : 0.0, wk1 = 0.0;   // (two chains: the sum over the rows has no prescribed order)
+#pragma unroll
+                    for(int r = 0; r < 16; ++r) {
+                        wke = __builtin_fma(row[r].x, q[2 * r], wke);
+                        wk1 = __builtin_fma(row[r].y, q[2 * r + 1], wk1);
+                    }
+                    wke = (wke + wk1) + row[16].y;
+                    acc = (float)((double)acc + row[16].x * wke);
+                }
+            }
+            float currIncrement = acc;
+            if(!a.allow_extrap && e < nV) {
+                const int li = e % n, lk = e / n;
+                const double lYe = (double)a.gY[(long)(unsigned)s_perm[li] * nV + lk];
+                float maxInc = -INFINITY, minInc = INFINITY;
+                for(int r = 0; r < n; ++r) {
+                    const float dv = (float)((double)s_ob[r] - (lYe + (double)s_yh[r]));
+                    maxInc = fmaxf(maxInc, dv); minInc = fminf(minInc, dv);
+                }
+                const float memberIncrement = (float)((double)currIncrement - X);
+                if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + X);
+                else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + X);
+                else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + X);
+                else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + X);
+            }
+            if(e < nV) a.out[(long)cell_l * E + a.validIdx[e]] = ensMean + currIncrement;   // :553
+        }
+
 }

@@ -150,3 +150,21 @@ def test_ensi_golden_vectors(name):
     out = np.asarray(out)
     assert out.dtype == np.float32
     ensi_golden.check(out.reshape(nb, E), c)
+
+
+def test_ensi_in_many_batches_of_tiles(monkeypatch):
+    """The spectral kernel and the ensemble kernel run in batches of tiles (what the second needs of a cell waits in an HBM park of
+    bounded size): one tile per batch here must give the values of the single-batch run, bit for bit."""
+    import gridpp_amd as gridpp
+    c = ensi_golden.CASES["e50_mp30_noextrap"]
+    h, v, w, mp, allow = c["params"]
+    Y, X = int(c["shape"][0]), int(c["shape"][1])
+    E = c["background"].shape[1]
+    grid = gridpp.Grid(c["blat"].reshape(Y, X), c["blon"].reshape(Y, X), c["belev"].reshape(Y, X), c["blaf"].reshape(Y, X))
+    points = gridpp.Points(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    args = (grid, c["background"].reshape(Y, X, E), points, c["pobs"], c["psigmas"], c["pbackground"], gridpp.BarnesStructure(h, v, w), int(mp), bool(allow))
+    one = np.asarray(gridpp.optimal_interpolation_ensi(*args))
+    monkeypatch.setenv("GPP_ENSI_PARK_MB", "1")
+    many = np.asarray(gridpp.optimal_interpolation_ensi(*args))
+    assert np.array_equal(one, many, equal_nan=True)
+    ensi_golden.check(one, c)
