@@ -24,7 +24,7 @@ using namespace gpp;
 #define EMAXV 64       // max valid ensemble members (one lane per member)
 #define BP (EN + 1)    // pitch of B / U (doubles)
 
-#define ENSI_PARK_D 1120   // doubles parked per cell: M' 1024 | sD 32 | z 32 | rho 32
+#define ENSI_PARK_D 2144   // doubles parked per cell: U 1024 | U^T B U 1024 | sD 32 | sD (obs - yhat) 32 | rho 32
 
 struct EnsiArgs {
     const float *gx, *gy, *gz, *gelev, *glaf;
@@ -37,7 +37,7 @@ struct EnsiArgs {
     const float* gY;          // [S][nV] perturbations of the valid members (float)
     const int* validIdx;      // [nV]
     unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
-    double* cpark;            // [tiles of the batch][64][ENSI_PARK_D] k_ensi_pair -> k_ensi_members: M' (32 x 32), sD, z, rho of every cell
+    double* cpark;            // [tiles of the batch][64][ENSI_PARK_D] k_ensi_pair -> k_ensi_members: U, U^T B U, sD, r, rho of every cell
     int tile0;                // first tile of the batch
     unsigned* meta;           // [ntiles][64] k_ensi_scan -> k_ensi_pair: selection length | 0x100 if the reference sorted
     unsigned long long* hsigs;   // [ntiles][64] order-independent signature of every selection
@@ -45,7 +45,7 @@ struct EnsiArgs {
     int* big_list;            // cells with more usable observations than the 32-row tile holds (k_ensi_big), or NULL
     int* big_count;
     unsigned long long* big_keys;   // per workgroup of k_ensi_big: EBIG_CAND sorted candidate keys
-    double jtol2;             // k_ensi_pair: the Jacobi sweeps stop at (off-diagonal norm)^2 <= jtol2 * trace^2
+    double jtol2;             // k_ensi_pair: the Jacobi sweeps stop at (off-diagonal norm)^2 <= jtol2 * c^2, c = nV - 1
     int debug;                // GPP_ENSI_DEBUG (timing experiments only): 1 no Jacobi, 2 no member update, 4 no B build, 8 no M_W
     int nV;
     int allow_extrap;
@@ -851,7 +851,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
     a.gram = ws.gram.get((size_t)a.ntiles * EN * EN);
     a.debug = getenv("GPP_ENSI_DEBUG") ? atoi(getenv("GPP_ENSI_DEBUG")) : 0;
-    a.jtol2 = getenv("GPP_ENSI_JTOL2") ? atof(getenv("GPP_ENSI_JTOL2")) : 1e-12;
+    a.jtol2 = getenv("GPP_ENSI_JTOL2") ? atof(getenv("GPP_ENSI_JTOL2")) : 2e-4;
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
     // cells with more than 32 usable observations go to k_ensi_big (scalar structure functions; the spatially varying forms
@@ -869,7 +869,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         else hipLaunchKernelGGL(k_ensi_scan<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
         GPP_HIP(hipGetLastError());
         // spectral side (pairs of cells, warm-started along a tile) and ensemble side (one wave per cell) in batches of tiles: what
-        // the second kernel needs of a cell (8.75 KB) waits in HBM, 24 GB of the 288 at most (GPP_ENSI_PARK_MB)
+        // the second kernel needs of a cell (17 KB) waits in HBM, 24 GB of the 288 at most (GPP_ENSI_PARK_MB)
         size_t park_bytes = (size_t)24 << 30;
         if(getenv("GPP_ENSI_PARK_MB")) park_bytes = (size_t)atol(getenv("GPP_ENSI_PARK_MB")) << 20;
         const size_t per_tile = (size_t)64 * ENSI_PARK_D * sizeof(double);
