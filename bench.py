@@ -246,7 +246,7 @@ def main():
             stats = gridpp.oi_last_stats()
             all_ms = float(np.mean(kernel_ms))            # every kernel of the call (hipEvents on the library stream)
             k_ms = float(np.mean(union_ms))               # the dominant one: k_oi_union, first pass (all tiles)
-            k_name = "k_oi_union<true, false>"
+            k_name = "k_oi_union<true, false, 32>"
             if k_ms <= 0:                                  # that kernel was not used (GPP_OI_NO_UNION): k_oi did everything
                 k_ms, k_name = all_ms, "k_oi<32, false, true, false>"
             achieved = cells_rank * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
