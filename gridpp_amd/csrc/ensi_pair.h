@@ -479,6 +479,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const unsigned meta = a.meta[(size_t)tile * 64 + lcell];
     const int n = (int)(meta & 0xffu);
     if(n == 0) return;   // no observation in range (the output already holds the background) or a cell of k_ensi_big
+    // this cell's values of the first 64 valid members: needed late (ensemble mean, X), asked for first
+    const float v0 = (lane < nV) ? a.bg[(long)cell_l * E + a.validIdx[lane]] : 0.0f;
     const double* const park = a.cpark + ((size_t)blockIdx.x) * ENSI_PARK_D;
     const unsigned orig_i = (i < n) ? a.sel[(size_t)tile * EN * 64 + i * 64 + lcell] : 0xffffffffu;
     float4 o1 = make_float4(NAN, 0, 0, 1);
@@ -500,6 +502,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double inv = 1.0 / (c + S);
     if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = park[2048 + i]; s_r1[i] = park[2080 + i]; s_dw[i] = dwv; s_rt[i] = rt; }
     __syncthreads();
+    // column k0 + i of Y, rows [16 h, 16 h + 16), for the tables of the member update: the first chunk is asked for here, every
+    // further one while the rows of the previous chunk are being used
+    float yp[16];
+    auto load_cols = [&](const int k0) {
+        const int kk = k0 + i;
+#pragma unroll
+        for(int rr = 0; rr < 16; ++rr) { const int r = 16 * h + rr; yp[rr] = (r < n && kk < nV) ? a.gY[(long)s_sel[r] * nV + kk] : 0.0f; }
+    };
+    load_cols(0);
     // ---- g(D + E) to second order in E, without eigenvalue gaps in any denominator.  With M = c I + D + E:
     //        M^(1/2) = diag(a) + R1 + R2,   R1 = E o rinv,  R2 = -(R1 R1) o rinv,   rinv(i, j) = 1 / (a_i + a_j)      (Sylvester, twice)
     //        g(D + E) = -(M + sqrt(c) M^(1/2))^-1 = -(P + F)^-1,   P = diag(a (a + sqrt(c))) = diag(-1 / dw),   F = E + sqrt(c) (R1 + R2)
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // ensemble mean: sequential float sum over the valid members in member order (oi_ensi.cpp:447-461)
         float total = 0.0f;
         for(int m0 = 0; m0 < nV; m0 += 64) {
-            const float v = (m0 + lane < nV) ? a.bg[(long)cell_l * E + a.validIdx[m0 + lane]] : 0.0f;
+            const float v = (m0 == 0) ? v0 : ((m0 + lane < nV) ? a.bg[(long)cell_l * E + a.validIdx[m0 + lane]] : 0.0f);
             const int kend = min(64, nV - m0);
             for(int k = 0; k < kend; ++k) total += readlane_f(v, k);
         }
@@ -707,7 +718,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     q[j] = (half == 0 || h == 1) ? v.x : q[j]; q[j + 1] = (half == 0 || h == 1) ? v.y : q[j + 1];
                 }
             }
-            const float value = (e < nV) ? a.bg[(long)cell_l * E + a.validIdx[e]] : 0.0f;
+            const float value = (e0_ == 0) ? v0 : ((e < nV) ? a.bg[(long)cell_l * E + a.validIdx[e]] : 0.0f);
+            if(e0_ > 0) load_cols(0);
             const double X = (double)value - (double)ensMean;
             // total_e = sum_k X_k W(k,e), W(k,e) = [k == e] + sum_i Y(i,k) q_e(i) + w_k, float accumulation in k order (:505-511)
             float acc = 0.0f;
@@ -721,20 +733,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for(int rr = 0; rr < 16; rr += 2) {
                         const int r = 16 * h + rr;
                         double2 v;
-                        v.x = (r < n && kk < nV) ? (double)a.gY[(long)s_sel[r] * nV + kk] : 0.0;
-                        v.y = (r + 1 < n && kk < nV) ? (double)a.gY[(long)s_sel[r + 1] * nV + kk] : 0.0;
+                        v.x = (double)yp[rr]; v.y = (double)yp[rr + 1];
                         wk = __builtin_fma(s_sD1[r] * v.x, s_z1[r], wk);
                         wk = __builtin_fma(s_sD1[r + 1] * v.y, s_z1[r + 1], wk);
                         *reinterpret_cast<double2*>(&sB[i * PP + r]) = v;
                     }
                     const double wo = __shfl_xor(wk, 32);
+                    const float vk64 = __shfl(v0, kk & 63);
                     if(h == 0) {
-                        const float vk = (kk < nV) ? a.bg[(long)cell_l * E + a.validIdx[kk]] : 0.0f;
+                        const float vk = (kk < 64) ? vk64 : ((kk < nV) ? a.bg[(long)cell_l * E + a.validIdx[kk]] : 0.0f);
                         double2 xw; xw.x = (double)vk - (double)ensMean; xw.y = wk + wo;
                         *reinterpret_cast<double2*>(&sB[i * PP + 32]) = xw;
                     }
                 }
                 __syncthreads();
+                if(k0 + 32 < nV) load_cols(k0 + 32);
                 const int kend = (a.debug & 2) ? 0 : min(32, nV - k0);
                 // one row of the table per step (other waves of the SIMD hide the LDS latency here)
 #pragma unroll 1
