@@ -407,3 +407,26 @@ def test_spatially_varying_parts_inside_a_multiple_structure():
     s1 = O.Struct.multiple(O.Struct("Barnes", float(hf.ravel()[k[0]])), O.Struct("Soar", 5000, float(vf.ravel()[k[1]])), O.Struct("Barnes", 5000, 0, float(wf.ravel()[k[2]])))
     want = s1.corr((q1.x[0], q1.y[0], q1.z[0], 120.0, 0.4), (q2.x[0], q2.y[0], q2.z[0], 260.0, 0.7))
     assert abs(st.corr(p1, p2) - want) < 1e-6
+
+
+# ---- LAPACK golden vectors (tools/make_oi_fixtures.py: independent numpy + scipy restatement of src/api/oi.cpp:176-338) -----------
+from tests import oi_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", oi_golden.NAMES)
+def test_oi_golden_vectors(name):
+    import gridpp_amd as gridpp
+    c = oi_golden.CASES[name]
+    h, v, w, mp, allow = c["params"]
+    points = gridpp.Points(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    st = gridpp.BarnesStructure(h, v, w)
+    if c["shape"][0] > 0:
+        Y, X = int(c["shape"][0]), int(c["shape"][1])
+        grid = gridpp.Grid(c["blat"].reshape(Y, X), c["blon"].reshape(Y, X), c["belev"].reshape(Y, X), c["blaf"].reshape(Y, X))
+        out, var = gridpp.optimal_interpolation_full(grid, c["background"].reshape(Y, X), c["bvariance"].reshape(Y, X), points, c["pobs"],
+                                                     c["obs_variance"], c["pbackground"], c["bvariance_at_points"], st, int(mp), bool(allow))
+    else:
+        bpoints = gridpp.Points(c["blat"], c["blon"], c["belev"], c["blaf"])
+        out, var = gridpp.optimal_interpolation_full(bpoints, c["background"], c["bvariance"], points, c["pobs"], c["obs_variance"],
+                                                     c["pbackground"], c["bvariance_at_points"], st, int(mp), bool(allow))
+    oi_golden.check(out, var, c)

@@ -45,3 +45,21 @@ def test_oracle_ensi_multi_golden(name):
     out = O.oi_ensi_multi(str(c["variant"]), g, c["bratios"], c["background"], c["background_corr"], p, c["pobs"], c["pratios"],
                           c["pbackground"], c["pbackground_corr"], O.Barnes(h, v, w), int(mp), bool(allow))
     ensi_multi_golden.check(out, c)
+
+
+# ---- optimal_interpolation_full against the LAPACK golden vectors (tools/make_oi_fixtures.py) --------------------------------------
+from tests import oi_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", oi_golden.NAMES)
+def test_oi_golden_vectors(name):
+    """The oracle's OI (top-max_points cut, its own Cholesky / LU solve, clamp, variance) against an independent numpy + LAPACK
+    restatement of src/api/oi.cpp:176-338."""
+    from oracle import oracle as O
+    c = oi_golden.CASES[name]
+    h, v, w, mp, allow = c["params"]
+    og = O.Pts(c["blat"], c["blon"], c["belev"], c["blaf"])
+    op = O.Pts(c["plat"], c["plon"], c["pelev"], c["plaf"])
+    out, var = O.oi_full(og, c["background"], c["bvariance"], op, c["pobs"], c["obs_variance"], c["pbackground"], c["bvariance_at_points"],
+                         O.Barnes(h, v, w), int(mp), bool(allow))
+    oi_golden.check(out, var, c)
