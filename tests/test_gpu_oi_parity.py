@@ -419,7 +419,7 @@ def test_oi_golden_vectors(name):
     c = oi_golden.CASES[name]
     h, v, w, mp, allow = c["params"]
     points = gridpp.Points(c["plat"], c["plon"], c["pelev"], c["plaf"])
-    st = gridpp.BarnesStructure(h, v, w)
+    st = gridpp.CressmanStructure(h, v, w) if int(c["kind"]) == 1 else gridpp.BarnesStructure(h, v, w)
     if c["shape"][0] > 0:
         Y, X = int(c["shape"][0]), int(c["shape"][1])
         grid = gridpp.Grid(c["blat"].reshape(Y, X), c["blon"].reshape(Y, X), c["belev"].reshape(Y, X), c["blaf"].reshape(Y, X))

@@ -60,6 +60,10 @@ def test_oi_golden_vectors(name):
     h, v, w, mp, allow = c["params"]
     og = O.Pts(c["blat"], c["blon"], c["belev"], c["blaf"])
     op = O.Pts(c["plat"], c["plon"], c["pelev"], c["plaf"])
-    out, var = O.oi_full(og, c["background"], c["bvariance"], op, c["pobs"], c["obs_variance"], c["pbackground"], c["bvariance_at_points"],
-                         O.Barnes(h, v, w), int(mp), bool(allow))
+    if int(c["kind"]) == 1:
+        out, var = O.oi_full_generic(og, c["background"], c["bvariance"], op, c["pobs"], c["obs_variance"], c["pbackground"],
+                                     c["bvariance_at_points"], O.Struct("Cressman", h, v, w), int(mp), bool(allow))
+    else:
+        out, var = O.oi_full(og, c["background"], c["bvariance"], op, c["pobs"], c["obs_variance"], c["pbackground"], c["bvariance_at_points"],
+                             O.Barnes(h, v, w), int(mp), bool(allow))
     oi_golden.check(out, var, c)

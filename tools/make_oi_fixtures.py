@@ -24,8 +24,32 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_ensi_fixtures import F, convert_coordinates, corr_barnes, get_neighbours, localization_distance   # noqa: E402
 
 
+def cressman_rho(dist, length):
+    """structure.cpp:35-44 on float32 arrays (signed `dist` for the elevation / laf factors: only dist >= length cuts)."""
+    length = F(length)
+    if not np.isfinite(length) or length == 0:
+        return np.ones(dist.shape, F)
+    l2 = F(length * length)
+    d2 = (dist * dist).astype(F)
+    r = ((l2 - d2).astype(F) / (l2 + d2).astype(F)).astype(F)
+    r = np.where(dist >= length, F(0), r)
+    return np.where(np.isfinite(dist), r, F(0)).astype(F)
+
+
+def corr_cressman(p1, p2, h, v, w):
+    """CressmanStructure::corr, structure.cpp:297-309; p1 one point, p2 arrays.  Not symmetric in (p1, p2) when v or w are set."""
+    dx, dy, dz = (F(p1[0]) - p2[0]).astype(F), (F(p1[1]) - p2[1]).astype(F), (F(p1[2]) - p2[2]).astype(F)
+    hdist = np.sqrt(((dx * dx).astype(F) + (dy * dy).astype(F)).astype(F) + (dz * dz).astype(F)).astype(F)
+    rho = cressman_rho(hdist, h)
+    if np.isfinite(p1[3]):
+        rho = np.where(np.isfinite(p2[3]), (rho * cressman_rho((F(p1[3]) - p2[3]).astype(F), v)).astype(F), rho)
+    if np.isfinite(p1[4]):
+        rho = np.where(np.isfinite(p2[4]), (rho * cressman_rho((F(p1[4]) - p2[4]).astype(F), w)).astype(F), rho)
+    return rho.astype(F), hdist
+
+
 def oi_full(blat, blon, belev, blaf, background, bvariance, plat, plon, pelev, plaf, pobs, obs_variance, pbackground,
-            bvariance_at_points, h, v, w, max_points, allow_extrapolation):
+            bvariance_at_points, h, v, w, max_points, allow_extrapolation, kind="barnes"):
     background, bvariance = background.astype(F), bvariance.astype(F)
     pobs, obs_variance, pbackground, bvp = pobs.astype(F), obs_variance.astype(F), pbackground.astype(F), bvariance_at_points.astype(F)
     nY, nS = background.size, plat.size
@@ -36,7 +60,8 @@ def oi_full(blat, blon, belev, blaf, background, bvariance, plat, plon, pelev, p
     bx, by, bz = convert_coordinates(blat, blon)
     px, py, pz = convert_coordinates(plat, plon)
     pelev, plaf = pelev.astype(F), plaf.astype(F)
-    loc = localization_distance(h)
+    corr = corr_barnes if kind == "barnes" else corr_cressman
+    loc = localization_distance(h) if kind == "barnes" else F(h)      # structure.cpp:280-282 / StructureFunction(h) for Cressman (:286)
     for y in range(nY):
         if not np.isfinite(background[y]):                                                     # :223
             continue
@@ -44,7 +69,7 @@ def oi_full(blat, blon, belev, blaf, background, bvariance, plat, plon, pelev, p
         idx0 = get_neighbours(px, py, pz, bx[y], by[y], bz[y], loc)                            # :233
         if idx0.size == 0:
             continue
-        rhos, _ = corr_barnes(p1, (px[idx0], py[idx0], pz[idx0], pelev[idx0], plaf[idx0]), h, v, w)   # :250 (corr_background == corr for Barnes)
+        rhos, _ = corr(p1, (px[idx0], py[idx0], pz[idx0], pelev[idx0], plaf[idx0]), h, v, w)   # :250 (corr_background == corr here)
         keep = np.isfinite(pobs[idx0]) & np.isfinite(pbackground[idx0]) & (rhos > 0)           # :251-257
         cand, crho = idx0[keep], rhos[keep]
         if max_points > 0 and cand.size > max_points:                                          # :262-273: the largest rho first
@@ -60,7 +85,7 @@ def oi_full(blat, blon, belev, blaf, background, bvariance, plat, plon, pelev, p
         lP = np.empty((lS, lS))
         for i in range(lS):                                                                    # :304-312 corr(p_i, p_j), float32 -> double
             k = cand[i]
-            lP[i], _ = corr_barnes((px[k], py[k], pz[k], pelev[k], plaf[k]), (px[cand], py[cand], pz[cand], pelev[cand], plaf[cand]), h, v, w)
+            lP[i], _ = corr((px[k], py[k], pz[k], pelev[k], plaf[k]), (px[cand], py[cand], pz[cand], pelev[cand], plaf[cand]), h, v, w)
         lR = np.diag(pratios[cand].astype(np.float64))
         lGSR = lG @ sla.inv(lP + lR)                                                           # :315
         increment = F((lGSR @ (lObs - lY))[0])                                                 # :316-317
@@ -80,7 +105,8 @@ def oi_full(blat, blon, belev, blaf, background, bvariance, plat, plon, pelev, p
     return output, analysis_variance
 
 
-def make_case(seed, Y, X, S, h, max_points, allow, v=0.0, w=0.0, elev=False, laf=False, nans=False, points_background=0, cluster=False):
+def make_case(seed, Y, X, S, h, max_points, allow, v=0.0, w=0.0, elev=False, laf=False, nans=False, points_background=0, cluster=False,
+              kind="barnes"):
     rng = np.random.default_rng(seed)
     if points_background:
         blat, blon = rng.random(points_background).astype(F), rng.random(points_background).astype(F)
@@ -108,10 +134,11 @@ def make_case(seed, Y, X, S, h, max_points, allow, v=0.0, w=0.0, elev=False, laf
         obs[::9] = np.nan
         pbg[4::13] = np.nan
         bg[::17] = np.nan
-    out, var = oi_full(blat, blon, belev, blaf, bg, bvar, plat, plon, pelev, plaf, obs, ovar, pbg, bvp, h, v, w, max_points, allow)
+    out, var = oi_full(blat, blon, belev, blaf, bg, bvar, plat, plon, pelev, plaf, obs, ovar, pbg, bvp, h, v, w, max_points, allow, kind)
     return dict(shape=shape, blat=blat, blon=blon, belev=belev, blaf=blaf, background=bg, bvariance=bvar, plat=plat, plon=plon,
                 pelev=pelev, plaf=plaf, pobs=obs, obs_variance=ovar, pbackground=pbg, bvariance_at_points=bvp,
-                params=np.array([h, v, w, max_points, 1.0 if allow else 0.0]), expected=out, expected_variance=var)
+                params=np.array([h, v, w, max_points, 1.0 if allow else 0.0]), kind=np.array(0 if kind == "barnes" else 1),
+                expected=out, expected_variance=var)
 
 
 CASES = {
@@ -124,6 +151,10 @@ CASES = {
     "mp6_points_background":   dict(seed=37, Y=0, X=0, S=50, h=25000, max_points=6, allow=True, points_background=400),
     "mp45_beyond_32":          dict(seed=38, Y=14, X=14, S=160, h=30000, max_points=45, allow=True),
     "mp5_short_range":         dict(seed=39, Y=28, X=28, S=60, h=5000, max_points=5, allow=True),     # many cells without observations
+    # CressmanStructure: symmetric with h only; with v its factor acts on the SIGNED elevation difference, so (P + R) is not symmetric
+    # and only a general inverse (LAPACK's LU here, the pivoted LU of k_oi on the GPU) gives the reference's numbers
+    "cressman_mp10":           dict(seed=40, Y=24, X=24, S=90, h=60000, max_points=10, allow=True, kind="cressman"),
+    "cressman_elev_mp12_noextrap": dict(seed=41, Y=20, X=20, S=90, h=60000, max_points=12, allow=False, v=400.0, elev=True, kind="cressman"),
 }
 
 
