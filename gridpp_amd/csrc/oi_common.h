@@ -254,10 +254,29 @@ static __global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const 
 }
 
 
+// d_barnes_corr as straight-line code: the three factors are independent exp chains, and without the branches of d_barnes_rho
+// around them the compiler interleaves them (same values: d_barnes_rho_flat; a disabled factor is skipped by a uniform branch, an
+// invalid elevation / laf on either side deselects its factor).  The reciprocals are loop invariants of the calling kernels.
+__device__ __forceinline__ float d_barnes_corr_flat(float x1, float y1, float z1, float e1, float l1, float x2, float y2, float z2, float e2,
+                                                    float l2, float h, float v, float w, float R) {
+    const bool hh = d_valid(h) && h != 0.0f, hv = d_valid(v) && v != 0.0f, hw = d_valid(w) && w != 0.0f;
+    const float hdist = d_chord(x1, y1, z1, x2, y2, z2);
+    float rho = 1.0f;
+    if(hh) rho = d_barnes_rho_flat(hdist, 1.0 / (double)h);
+    if(hv) {
+        const float f = d_barnes_rho_flat(e1 - e2, 1.0 / (double)v);
+        rho = (d_valid(e1) && d_valid(e2)) ? rho * f : rho;
+    }
+    if(hw) {
+        const float f = d_barnes_rho_flat(l1 - l2, 1.0 / (double)w);
+        rho = (d_valid(l1) && d_valid(l2)) ? rho * f : rho;
+    }
+    return hdist > R ? 0.0f : rho;
+}
 template <bool PLAIN>
 __device__ __forceinline__ float d_corr_t(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
                                           float x2, float y2, float z2, float e2, float l2, const bool background) {
-    if(PLAIN) return d_barnes_corr(x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, s.h, s.v, s.w, s.R);
+    if(PLAIN) return d_barnes_corr_flat(x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, s.h, s.v, s.w, s.R);
     return d_corr(s, x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, background);
 }
 
@@ -297,6 +316,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
     truncated = false;
     const float R = st.R;
     const int K = a.K;
+    // scalar Barnes structure (PLAIN): which factors are enabled, and the reciprocals of their scales
+    const bool p_hh = d_valid(st.h) && st.h != 0.0f, p_hv = d_valid(st.v) && st.v != 0.0f, p_hw = d_valid(st.w) && st.w != 0.0f;
+    const double p_rh = p_hh ? 1.0 / (double)st.h : 0.0, p_rv = p_hv ? 1.0 / (double)st.v : 0.0, p_rw = p_hw ? 1.0 / (double)st.w : 0.0;
     const bool bounded = a.max_points > 0 && a.max_points <= N;
     const float h2 = st.h * st.h;
     const bool prune = bounded && (PLAIN || st.kh == SK_BARNES);   // rho <= rho_h(d) with the closed-form inverse of the Barnes kernel
@@ -342,9 +364,17 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
                         const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        float rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
+                        float rho;
+                        if constexpr(PLAIN) {   // straight-line code: the three exp chains interleave (same values as d_barnes_rho)
+                            rho = p_hh ? d_barnes_rho_flat(dist, p_rh) : 1.0f;
+                            if(p_hv) { const float f = d_barnes_rho_flat(ge - oe, p_rv); rho = (d_valid(ge) && d_valid(oe)) ? rho * f : rho; }
+                            if(p_hw) { const float f = d_barnes_rho_flat(gl - ol, p_rw); rho = (d_valid(gl) && d_valid(ol)) ? rho * f : rho; }
+                        }
+                        else {
+                            rho = (st.cv && dist <= st.cv_dist) ? 0.0f : d_rho(st.kh, dist, st.h);   // corr_background
+                            if(d_valid(ge) && d_valid(oe)) rho *= d_rho(st.kv, ge - oe, st.v);
+                            if(d_valid(gl) && d_valid(ol)) rho *= d_rho(st.kw, gl - ol, st.w);
+                        }
                         const bool ins_ = rho > 0.0f && (cnt < K || (((unsigned long long)__float_as_uint(rho) << 32) | 0xffffffffull) > wkey);
                         if(a.scan_stats && __ballot(ins_) != 0ull) nins++;
                         if(rho > 0.0f) {   // oi.cpp:253
@@ -386,9 +416,17 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {
                         const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
-                        float rho = (!PLAIN && st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_t<PLAIN>(st.kh, dist, st.h);   // corr_background
-                        if(d_valid(ge) && d_valid(oe)) rho *= d_rho_t<PLAIN>(st.kv, ge - oe, st.v);
-                        if(d_valid(gl) && d_valid(ol)) rho *= d_rho_t<PLAIN>(st.kw, gl - ol, st.w);
+                        float rho;
+                        if constexpr(PLAIN) {   // straight-line code: the three exp chains interleave (same values as d_barnes_rho)
+                            rho = p_hh ? d_barnes_rho_flat(dist, p_rh) : 1.0f;
+                            if(p_hv) { const float f = d_barnes_rho_flat(ge - oe, p_rv); rho = (d_valid(ge) && d_valid(oe)) ? rho * f : rho; }
+                            if(p_hw) { const float f = d_barnes_rho_flat(gl - ol, p_rw); rho = (d_valid(gl) && d_valid(ol)) ? rho * f : rho; }
+                        }
+                        else {
+                            rho = (st.cv && dist <= st.cv_dist) ? 0.0f : d_rho(st.kh, dist, st.h);   // corr_background
+                            if(d_valid(ge) && d_valid(oe)) rho *= d_rho(st.kv, ge - oe, st.v);
+                            if(d_valid(gl) && d_valid(ol)) rho *= d_rho(st.kw, gl - ol, st.w);
+                        }
                         if(rho > 0.0f) truncated = true;
                     }
                 }
