@@ -871,6 +871,10 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         // spectral side (pairs of cells, warm-started along a tile) and ensemble side (one wave per cell) in batches of tiles: what
         // the second kernel needs of a cell (17 KB) waits in HBM, 24 GB of the 288 at most (GPP_ENSI_PARK_MB)
         size_t park_bytes = (size_t)24 << 30;
+        {   // (never more than a quarter of what is free on the device right now, counting the park already held)
+            size_t free_b = 0, total_b = 0;
+            if(hipMemGetInfo(&free_b, &total_b) == hipSuccess) park_bytes = std::min(park_bytes, std::max<size_t>((free_b + ws.cpark.cap * sizeof(double)) / 4, (size_t)64 << 20));
+        }
         if(getenv("GPP_ENSI_PARK_MB")) park_bytes = (size_t)atol(getenv("GPP_ENSI_PARK_MB")) << 20;
         const size_t per_tile = (size_t)64 * ENSI_PARK_D * sizeof(double);
         const int tcap = (int)std::max<size_t>(1, std::min<size_t>((size_t)a.ntiles, park_bytes / per_tile));
