@@ -756,9 +756,24 @@ __global__ __launch_bounds__(256, 2) void k_qf_fused(const unsigned char* __rest
             else if(x > yLa) o = thr[T - 1];
             else if(x < y0a) o = thr[0];
             else {
+                // the two index scans of util.cpp:339-414 with static register indices (a running flag instead of `break`: a scan that
+                // indexes the register copy dynamically costs a select chain per step)
                 int i0 = -1, i1 = -1;
-                for(int i = 0; i < T; i++) { float cv = yat(i); if(cv < x) i0 = i; else if(cv == x) { i0 = i; break; } else break; }
-                for(int i = T - 1; i >= 0; i--) { float cv = yat(i); if(cv > x) i1 = i; else if(cv == x) { i1 = i; break; } else break; }
+                bool run0 = true, run1 = true;
+#pragma unroll
+                for(int i = 0; i < TM; i++) {
+                    const float cv = yr[i];
+                    const bool on = run0 && i < T, lt = on && cv < x, eq = on && cv == x;
+                    i0 = (lt || eq) ? i : i0;
+                    run0 = lt;
+                }
+#pragma unroll
+                for(int i = TM - 1; i >= 0; i--) {
+                    const float cv = yr[i];
+                    const bool on = run1 && i < T, gt = on && cv > x, eq = on && cv == x;
+                    i1 = (gt || eq) ? i : i1;
+                    run1 = (i < T) ? gt : run1;
+                }
                 if(i0 < 0) i0 = 0;
                 if(i1 < 0) i1 = T - 1;
                 const float xa = yat(i0), xb = yat(i1), ta = thr[i0], tb = thr[i1];
