@@ -45,8 +45,8 @@ def run(c, h, max_points, allow=True, v=0, w=0, elev=False):
 def check(out, ref, bg):
     assert out.dtype == np.float32 and out.shape == ref.shape
     assert (np.isnan(out) == np.isnan(ref)).all()
-    m = ~np.isnan(ref)
-    err = np.abs(out[m].astype(np.float64) - ref[m]) / np.maximum(np.abs(ref[m]), 1e-2)
+    from tests.ensi_golden import rel_err
+    err = rel_err(out, ref, bg)     # relative to max(|ref|, 1e-2, one float32 ulp of the cell's members)
     assert err.max() < RTOL, err.max()
     assert np.nanmax(np.abs(out - bg)) > 0.05   # the update did something
 

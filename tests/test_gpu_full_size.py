@@ -3,6 +3,7 @@ checked on (a) a sample of cells against the oracle (cells are independent, so a
 (b) size-independent properties: tile independence (the same cells computed as a Points list give the same bits),
 linearity in the innovations, pass-through where no observation is in range, window properties of the filters."""
 import numpy as np
+from tests.ensi_golden import rel_err
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -116,7 +117,7 @@ def test_config5_ensi_2500x2500x50_sample():
     cols = np.arange(0, nx, 25)
     for k in range(3):
         ref = O.oi_ensi(O.Pts(lats[k, cols], lons[k, cols]), bg[k, cols], O.Pts(plat, plon), obs, sig, pbg, O.Barnes(10000), 30)
-        err = np.abs(out[k, cols].astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
+        err = rel_err(out[k, cols], ref, bg[k, cols])     # relative to max(|ref|, 1e-2, one float32 ulp of the cell's members)
         assert err.max() < 1e-5, err.max()
     assert np.abs(out - bg).max() > 0.1
 
@@ -142,6 +143,6 @@ def test_config5_ensi_full_grid_with_oracle_sample():
     bgs = bg[iy, ix].cpu().numpy()
     ref = O.oi_ensi(O.Pts(lats[ys, xs], lons[ys, xs]), bgs, O.Pts(plat, plon), obs.cpu().numpy(), sig.cpu().numpy(), pbg.cpu().numpy(),
                     O.Barnes(10000), 30)
-    err = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-2)
+    err = rel_err(got, ref, bgs)
     assert err.max() < 1e-5, err.max()
     assert np.abs(got - bgs).max() > 0.1

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tests.test_gpu_ensi_parity import case, run, check
+from tests.ensi_golden import rel_err
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0, seed, bad, nbig = time.time(), 0, [], 0
 while time.time() - t0 < budget:
@@ -22,8 +23,7 @@ while time.time() - t0 < budget:
         continue
     try:
         assert out.shape == ref.shape and (np.isnan(out) == np.isnan(ref)).all()
-        m = ~np.isnan(ref)
-        err = np.abs(out[m].astype(np.float64) - ref[m]) / np.maximum(np.abs(ref[m]), 1e-2)
+        err = rel_err(out, ref, c[2])        # relative to max(|ref|, 1e-2, one float32 ulp of the cell's members)
         assert err.max() < 1e-5, err.max()
     except AssertionError as e:
         bad.append((seed, E, S, mp, h, Y, X, allow, str(e)[:80]))

@@ -26,8 +26,7 @@ for name, c in ensi_golden.CASES.items():
         out = gridpp.optimal_interpolation_ensi(gridpp.Points(c["blat"], c["blon"], c["belev"], c["blaf"]), c["background"], points, c["pobs"], c["psigmas"],
                                                 c["pbackground"], gridpp.BarnesStructure(h, v, w), int(mp), bool(allow))
     out = np.asarray(out); exp = c["expected"].reshape(out.shape)
-    m = ~np.isnan(exp)
-    err = (np.abs(out[m].astype(np.float64) - exp[m]) / np.maximum(np.abs(exp[m]), 1e-2)).max()
+    err = ensi_golden.rel_err(out, exp.astype(np.float64), c["background"]).max()
     worst = max(worst, err)
     print("%-32s %.2e" % (name, err))
 print("JTOL2 %s worst %.2e" % (os.environ.get("GPP_ENSI_JTOL2", "default"), worst))
