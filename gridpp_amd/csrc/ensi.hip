@@ -851,7 +851,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
     a.gram = ws.gram.get((size_t)a.ntiles * EN * EN);
     a.debug = getenv("GPP_ENSI_DEBUG") ? atoi(getenv("GPP_ENSI_DEBUG")) : 0;
-    a.jtol2 = getenv("GPP_ENSI_JTOL2") ? atof(getenv("GPP_ENSI_JTOL2")) : 2e-4;
+    a.jtol2 = getenv("GPP_ENSI_JTOL2") ? atof(getenv("GPP_ENSI_JTOL2")) : 1.5e-4;
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
     // cells with more than 32 usable observations go to k_ensi_big (scalar structure functions; the spatially varying forms
@@ -915,7 +915,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     GPP_HIP(hipEventElapsedTime(&g_ensi_ms, ws.e0, ws.e1));
     if(getenv("GPP_ENSI_STATS")) {
         unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
-        fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (double)sw / (double)hc[1] : 0.0);
+        fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (use_pair ? 0.25 : 1.0) * (double)sw / (double)hc[1] : 0.0);
         unsigned long long tot = 0; for(int i = 0; i < 12; i++) tot += hc[40 + i];
         if(tot) { fprintf(stderr, "[gpp] ensi phases (%% of wave cycles):"); for(int i = 0; i < 10; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[40 + i] / (double)tot); fprintf(stderr, "\n"); }
     }

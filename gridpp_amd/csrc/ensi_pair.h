@@ -409,22 +409,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             };
             double dg = diag_of_rows();
 #pragma unroll 1
-            for(int sweep = 0; sweep < 30 && n > 1 && !(a.debug & 1); ++sweep) {
+            for(int sweep = 0; sweep < 120 && n > 1 && !(a.debug & 1); ++sweep) {   // (in quarters of a sweep: 4 of its 16 double phases)
                 double off = 0.0;   // (not sum(b^2) - dg^2: the off-diagonal part is 20 orders below the diagonal when converged)
 #pragma unroll
                 for(int j = 0; j < 32; ++j) { const double v = (j == i) ? 0.0 : b[j]; off = __builtin_fma(v, v, off); }
                 off = half_sum_d(off, lane);
                 const double tr = half_sum_d(fabs(dg), lane);
-                // The sweeps stop at an off-diagonal norm |E| of sqrt(jtol2) * c = 0.014 c (c = nV - 1 bounds every eigenvalue of c I + B from
+                // The sweeps stop at an off-diagonal norm |E| of sqrt(jtol2) * c = 0.012 c (c = nV - 1 bounds every eigenvalue of c I + B from
                 // below): what is left of E enters the matrix functions in k_ensi_members as a perturbation series without eigenvalue
                 // gaps in any denominator (see there; measured against the LAPACK golden vectors the result stays at the float32
-                // rounding floor up to 0.014 c, tools/ensi_tol.py).  Most warm-started cells need no sweep at all that way (C5: 0.58
+                // rounding floor up to there, tools/ensi_tol.py), tested after every quarter of a sweep.  Most warm-started cells need no sweep at all that way (C5: 0.52
                 // sweeps per cell instead of 1.13 with a threshold of 1e-6 of the trace and only the first-order term)
                 const bool open = off > a.jtol2 * c * c && off > 1e-24 * tr * tr;   // (and never beyond what double precision resolves)
                 if(__ballot(open && !(dup && h == 1)) == 0ull) break;
                 nsweeps++;
 #pragma unroll 1
-                for(int st = 0; st < 16; ++st) {
+                for(int st = 0; st < 4; ++st) {   // every double phase is a complete similarity transform: the test above may come after any
                     jacobi_phase<false>(b, u, dg, i, h, m1, m2, m3, m4, s_cs);
                     jacobi_phase<true>(b, u, dg, i, h, m1, m2, m3, m4, s_cs);
                 }
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     //        g(D + E) = -(M + sqrt(c) M^(1/2))^-1 = -(P + F)^-1,   P = diag(a (a + sqrt(c))) = diag(-1 / dw),   F = E + sqrt(c) (R1 + R2)
     //                 = diag(dw) + H + (H F) diag(dw) + (H F) diag(dw) F diag(dw),   H = diag(dw) F diag(dw)                (Neumann, three terms)
     //      The first-order part is the Daleckii-Krein term (1 + sqrt(c) / (a_i + a_j)) dw_i dw_j E_ij; the second-order part lets the
-    //      sweeps of k_ensi_pair stop at |E| <= 0.014 c -- most warm-started cells need no sweep at all then -- with an error of
+    //      sweeps of k_ensi_pair stop at |E| <= 0.012 c -- most warm-started cells need no sweep at all then -- with an error of
     //      (|F| / (2 c))^4.  Three 32 x 32 products on the matrix cores per cell.
     if(h == 0) {
 #pragma unroll
