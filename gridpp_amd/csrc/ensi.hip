@@ -869,11 +869,12 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         else hipLaunchKernelGGL(k_ensi_scan<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
         GPP_HIP(hipGetLastError());
         // spectral side (pairs of cells, warm-started along a tile) and ensemble side (one wave per cell) in batches of tiles: what
-        // the second kernel needs of a cell (17 KB) waits in HBM, 24 GB of the 288 at most (GPP_ENSI_PARK_MB)
-        size_t park_bytes = (size_t)24 << 30;
-        {   // (never more than a quarter of what is free on the device right now, counting the park already held)
+        // the second kernel needs of a cell (17 KB) waits in HBM: up to 112 GB of the 288 (config 5 in one batch; every batch ends with a
+        // tail of few long tiles, 5 batches cost 3 % over one), never more than half of what is free right now (GPP_ENSI_PARK_MB)
+        size_t park_bytes = (size_t)112 << 30;
+        {
             size_t free_b = 0, total_b = 0;
-            if(hipMemGetInfo(&free_b, &total_b) == hipSuccess) park_bytes = std::min(park_bytes, std::max<size_t>((free_b + ws.cpark.cap * sizeof(double)) / 4, (size_t)64 << 20));
+            if(hipMemGetInfo(&free_b, &total_b) == hipSuccess) park_bytes = std::min(park_bytes, std::max<size_t>((free_b + ws.cpark.cap * sizeof(double)) / 2, (size_t)64 << 20));
         }
         if(getenv("GPP_ENSI_PARK_MB")) park_bytes = (size_t)atol(getenv("GPP_ENSI_PARK_MB")) << 20;
         const size_t per_tile = (size_t)64 * ENSI_PARK_D * sizeof(double);
