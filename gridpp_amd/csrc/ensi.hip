@@ -918,6 +918,8 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
         fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (use_pair ? 0.25 : 1.0) * (double)sw / (double)hc[1] : 0.0);
         unsigned long long tot = 0; for(int i = 0; i < 12; i++) tot += hc[40 + i];
+        unsigned long long tot2 = 0; for(int i = 0; i < 9; i++) tot2 += hc[60 + i];
+        if(tot2) { fprintf(stderr, "[gpp] ensi members phases (%% of wave cycles):"); for(int i = 0; i < 9; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[60 + i] / (double)tot2); fprintf(stderr, "\n"); }
         if(tot) { fprintf(stderr, "[gpp] ensi phases (%% of wave cycles):"); for(int i = 0; i < 10; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[40 + i] / (double)tot); fprintf(stderr, "\n"); }
     }
     if(err & 1) runtime("optimal_interpolation_ensi: a grid point has more usable observations than the GPU path holds (512)");

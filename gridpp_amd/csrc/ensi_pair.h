@@ -336,8 +336,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 g.t[0][0] = g.t[0][1] = g.t[1][0] = g.t[1][1] = (v4d){0.0, 0.0, 0.0, 0.0};
                 for(int m0 = 0; m0 < nV; m0 += 64) {
                     __syncthreads();
-#pragma unroll 4
-                    for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = (r < n && m0 + lane < nV) ? a.gY[(long)s_sel[r] * nV + m0 + lane] : 0.0f;
+                    {   // unconditional loads (clamped address, value deselected afterwards): all 32 in flight together
+                        float yv[EN];
+#pragma unroll
+                        for(int r = 0; r < EN; ++r) {
+                            const bool on = r < n && m0 + lane < nV;
+                            yv[r] = a.gY[on ? (long)s_sel[r] * nV + m0 + lane : 0];
+                            yv[r] = on ? yv[r] : 0.0f;
+                        }
+#pragma unroll
+                        for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = yv[r];
+                    }
                     __syncthreads();
                     const int r = lane & 15, kq = lane >> 4;
                     const int kend = min(64, nV - m0);
@@ -473,6 +482,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int h = lane >> 5, i = lane & 31;
     const int nV = a.nV, E = a.E;
     if(nV <= 1) return;
+#ifdef GPP_ENSI_PROFILE
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     const int tile = a.tile0 + (int)(blockIdx.x >> 6), lcell = (int)(blockIdx.x & 63);
     const int cell_l = ensi_cell_of(a, tile, lcell);
     if(cell_l < 0) return;
@@ -502,15 +515,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double inv = 1.0 / (c + S);
     if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = park[2048 + i]; s_r1[i] = park[2080 + i]; s_dw[i] = dwv; s_rt[i] = rt; }
     __syncthreads();
-    // column k0 + i of Y, rows [16 h, 16 h + 16), for the tables of the member update: the first chunk is asked for here, every
-    // further one while the rows of the previous chunk are being used
-    float yp[16];
-    auto load_cols = [&](const int k0) {
-        const int kk = k0 + i;
-#pragma unroll
-        for(int rr = 0; rr < 16; ++rr) { const int r = 16 * h + rr; yp[rr] = (r < n && kk < nV) ? a.gY[(long)s_sel[r] * nV + kk] : 0.0f; }
-    };
-    load_cols(0);
+    EPROF(0)   // park loads, spectral scalars
     // ---- g(D + E) to second order in E, without eigenvalue gaps in any denominator.  With M = c I + D + E:
     //        M^(1/2) = diag(a) + R1 + R2,   R1 = E o rinv,  R2 = -(R1 R1) o rinv,   rinv(i, j) = 1 / (a_i + a_j)      (Sylvester, twice)
     //        g(D + E) = -(M + sqrt(c) M^(1/2))^-1 = -(P + F)^-1,   P = diag(a (a + sqrt(c))) = diag(-1 / dw),   F = E + sqrt(c) (R1 + R2)
@@ -587,6 +592,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     }
     __syncthreads();
+    EPROF(1)   // perturbation series (three products)
     if(h == 1) {   // U -> area B
 #pragma unroll
         for(int j = 0; j < 32; j += 2) { double2 w; w.x = e[j]; w.y = e[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w; }
@@ -626,6 +632,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for(int j = 0; j < 32; j += 2) { zz0 = __builtin_fma(sB[i * PP + j], s_t[j], zz0); zz1 = __builtin_fma(sB[i * PP + j + 1], s_t[j + 1], zz1); }
         s_z1[i] = zz0 + zz1;
     }
+    EPROF(2)   // z
     // M_W = U Mmid U^T, scaled: M'(i, j) = sD_i M_W(i, j) sD_j   -> area A (stays there for the whole member update)
     {
         const Acc32 tm = mfma_32_full(lane, [&](int r, int k) { return sB[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
@@ -645,6 +652,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
     }
     __syncthreads();
+    EPROF(3)   // M_W (two products)
         // anti-extrapolation tables (oi_ensi.cpp:520-552): lY[e] is a LINEAR index into the n x nV column-major matrix, so it
         // depends on the ORDER of the selected observations: rho descending when the reference sorted (more usable
         // observations than max_points), candidate (= index) order otherwise
@@ -671,13 +679,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for(int k = 0; k < kend; ++k) total += readlane_f(v, k);
         }
         const float ensMean = total / (float)nV;
+        EPROF(4)   // tables, ensemble mean
 #pragma unroll 1
         for(int e0_ = 0; e0_ < nV; e0_ += 64) {
             const int e = e0_ + lane;
             // Y tile of this member chunk -> area B (floats)
             __syncthreads();
-#pragma unroll 4
-            for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = (r < n && e < nV) ? a.gY[(long)s_sel[r] * nV + e] : 0.0f;
+            {   // unconditional loads (clamped address, value deselected afterwards) so that all of them are in flight together
+                float yv[EN];
+#pragma unroll
+                for(int r = 0; r < EN; ++r) {
+                    const bool on = r < n && e < nV;
+                    yv[r] = a.gY[on ? (long)s_sel[r] * nV + e : 0];
+                    yv[r] = on ? yv[r] : 0.0f;
+                }
+#pragma unroll
+                for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = yv[r];
+            }
             __syncthreads();
             // Q = M' Y  (32 x 64) on the matrix cores
             v4d qa[2][4];
@@ -700,6 +718,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                 }
             }
+            EPROF(5)   // Y tile, Q
+            // columns i and 32 + i of Y, rows [16 h, 16 h + 16), for the tables of the member update: out of the Y tile while it is still
+            // there (first member chunk: the tile holds columns 0..63; otherwise they are loaded again below)
+            float ya[16], yb[16];
+#pragma unroll
+            for(int rr = 0; rr < 16; ++rr) { ya[rr] = sBf[(16 * h + rr) * YP + i]; yb[rr] = sBf[(16 * h + rr) * YP + 32 + i]; }
             // transposed through area B, 32 members at a time: Qt[member][row]
             double q[32];
 #pragma unroll
@@ -719,8 +743,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
             const float value = (e0_ == 0) ? v0 : ((e < nV) ? a.bg[(long)cell_l * E + a.validIdx[e]] : 0.0f);
-            if(e0_ > 0) load_cols(0);
             const double X = (double)value - (double)ensMean;
+            EPROF(6)   // transposition
             // total_e = sum_k X_k W(k,e), W(k,e) = [k == e] + sum_i Y(i,k) q_e(i) + w_k, float accumulation in k order (:505-511)
             float acc = 0.0f;
 #pragma unroll 1
@@ -733,7 +757,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for(int rr = 0; rr < 16; rr += 2) {
                         const int r = 16 * h + rr;
                         double2 v;
-                        v.x = (double)yp[rr]; v.y = (double)yp[rr + 1];
+                        if(e0_ == 0 && k0 < 64) {
+                            v.x = (double)(k0 == 0 ? ya[rr] : yb[rr]); v.y = (double)(k0 == 0 ? ya[rr + 1] : yb[rr + 1]);
+                        }
+                        else {
+                            v.x = (r < n && kk < nV) ? (double)a.gY[(long)s_sel[r] * nV + kk] : 0.0;
+                            v.y = (r + 1 < n && kk < nV) ? (double)a.gY[(long)s_sel[r + 1] * nV + kk] : 0.0;
+                        }
                         wk = __builtin_fma(s_sD1[r] * v.x, s_z1[r], wk);
                         wk = __builtin_fma(s_sD1[r + 1] * v.y, s_z1[r + 1], wk);
                         *reinterpret_cast<double2*>(&sB[i * PP + r]) = v;
@@ -747,7 +777,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                 }
                 __syncthreads();
-                if(k0 + 32 < nV) load_cols(k0 + 32);
                 const int kend = (a.debug & 2) ? 0 : min(32, nV - k0);
                 // one row of the table per step (other waves of the SIMD hide the LDS latency here)
 #pragma unroll 1
@@ -765,6 +794,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     acc = (float)((double)acc + row[16].x * wke);
                 }
             }
+            EPROF(7)   // member update
             float currIncrement = acc;
             if(!a.allow_extrap && e < nV) {
                 const int li = e % n, lk = e / n;
@@ -783,4 +813,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if(e < nV) a.out[(long)cell_l * E + a.validIdx[e]] = ensMean + currIncrement;   // :553
         }
 
+#ifdef GPP_ENSI_PROFILE
+    EPROF(8)   // clamp, store
+    if(lane == 0 && a.counters) for(int k = 0; k < 9; ++k) atomicAdd(&a.counters[60 + k], prof[k]);
+#endif
 }
