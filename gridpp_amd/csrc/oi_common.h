@@ -321,6 +321,8 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
     const double p_rh = p_hh ? 1.0 / (double)st.h : 0.0, p_rv = p_hv ? 1.0 / (double)st.v : 0.0, p_rw = p_hw ? 1.0 / (double)st.w : 0.0;
     const bool bounded = a.max_points > 0 && a.max_points <= N;
     const float h2 = st.h * st.h;
+    // h / v and h / w for the combined pruning test (0: factor disabled, or a ratio float32 cannot hold)
+    const float p_sv = (p_hh && p_hv && d_valid(st.h / st.v)) ? st.h / st.v : 0.0f, p_sw = (p_hh && p_hw && d_valid(st.h / st.w)) ? st.h / st.w : 0.0f;
     const bool prune = bounded && (PLAIN || st.kh == SK_BARNES);   // rho <= rho_h(d) with the closed-form inverse of the Barnes kernel
     float pa = a.axis_a == 0 ? gx : (a.axis_a == 1 ? gy : gz);
     float pb = a.axis_b == 1 ? gy : (a.axis_b == 2 ? gz : gx);
@@ -341,6 +343,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
     // d2 > thr2 can neither be within R nor beat the worst kept rho (rho <= rho_h(d), monotone in d)
     const float thr2_R = R * R * 1.000001f + 1e-30f;
     float thr2 = active ? thr2_R : -1.0f;
+    float thrq = INFINITY;   // the same threshold before the cut at R^2: what the SUM of the three exponents (x h^2) is tested against
 
     // all observations of bins [xa, xb] of bin row `row`
     auto process_row = [&](const int row, const int xa, const int xb) {
@@ -353,17 +356,49 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
             if(mine < je) { rec = a.pgeo[mine]; met = a.smeta[mine]; }
             const int nc = min(64, je - base);
             if(a.scan_stats && lane == 0) atomicAdd(&a.scan_stats[0], (unsigned long long)nc);
+            // Pass A: which candidates of the chunk can matter to THIS cell (one bit per candidate).  With elevation / laf dependent rho
+            // on rough terrain nearly every candidate passes for SOME cell of the wave; evaluated wave-wide, all 64 lanes paid three
+            // double exps per candidate for the sake of a few.  Pass B lets every lane walk its own list, in the same candidate order
+            // (the per-cell sequence of insertions, thresholds and results is unchanged; a stale bit only costs a re-test).
+            unsigned long long pm = 0ull;
             for(int c = 0; c < nc; ++c) {
                 const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
                 const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
                 float d2 = dx * dx + dy * dy;
                 d2 = d2 + dz * dz;
-                if(a.scan_stats && __ballot(d2 <= thr2) != 0ull && lane == 0) atomicAdd(&a.scan_stats[1], 1ull);
-                if(d2 <= thr2) {
+                bool pass = d2 <= thr2;
+                if constexpr(PLAIN && !WANT_TRUNC) {
+                    // full list: rho = rho_h rho_v rho_w can only beat the worst kept rho if the SUM of the three exponents stays below
+                    // that of the threshold (slack for the separately rounded factors: 1e-4 relative + 1e-4 h^2)
+                    if(prune) {
+                        const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
+                        const float te = (ge - oe) * p_sv, tl = (gl - ol) * p_sw;
+                        float q = d2;
+                        q = (p_sv != 0.0f && d_valid(ge) && d_valid(oe)) ? q + te * te : q;
+                        q = (p_sw != 0.0f && d_valid(gl) && d_valid(ol)) ? q + tl * tl : q;
+                        pass = pass && q <= thrq * 1.0001f + 1e-4f * h2;
+                    }
+                }
+                if(WANT_TRUNC) pass = pass || d2 <= thr2_R;
+                pm |= pass ? (1ull << c) : 0ull;
+            }
+            // Pass B
+            while(__ballot(pm != 0ull) != 0ull) {
+                const bool has = pm != 0ull;
+                const int c = has ? __builtin_ctzll(pm) : 0;
+                pm &= pm - 1ull;
+                // (all six fields here, under the full EXEC mask: ds_bpermute returns 0 for a source lane that is switched off)
+                const float ox = __shfl(rec.x, c), oy = __shfl(rec.y, c), oz = __shfl(rec.z, c);
+                const float oe = __shfl(rec.w, c), ol = __shfl(met.x, c);
+                const unsigned orig = (unsigned)__shfl(__float_as_int(met.y), c);
+                const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+                float d2 = dx * dx + dy * dy;
+                d2 = d2 + dz * dz;
+                if(a.scan_stats && __ballot(has && d2 <= thr2) != 0ull && lane == 0) atomicAdd(&a.scan_stats[1], 1ull);
+                if(has && d2 <= thr2) {
                     const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
-                        const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
                         float rho;
                         if constexpr(PLAIN) {   // straight-line code: the three exp chains interleave (same values as d_barnes_rho)
                             rho = p_hh ? d_barnes_rho_flat(dist, p_rh) : 1.0f;
@@ -378,7 +413,6 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                         const bool ins_ = rho > 0.0f && (cnt < K || (((unsigned long long)__float_as_uint(rho) << 32) | 0xffffffffull) > wkey);
                         if(a.scan_stats && __ballot(ins_) != 0ull) nins++;
                         if(rho > 0.0f) {   // oi.cpp:253
-                            const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
                             const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
                             if(cnt < K) {
                                 keys[cnt][lane] = key;
@@ -405,17 +439,17 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                             else overflow = true;   // more than N usable observations requested
                             if(prune && cnt == K) {
                                 const float wr = __uint_as_float((unsigned)(wkey >> 32));
-                                thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
+                                thrq = -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2;
+                                thr2 = fminf(thr2_R, thrq);
                             }
                         }
                     }
                 }
-                else if(WANT_TRUNC && !truncated && cnt == K && d2 <= thr2_R) {
+                else if(WANT_TRUNC && has && !truncated && cnt == K && d2 <= thr2_R) {
                     // pruned by the rho threshold: does it still count as a usable observation?
                     const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
                     const float dist = sqrtf(d2);
                     if(inbox && dist <= R) {
-                        const float oe = readlane_f(rec.w, c), ol = readlane_f(met.x, c);
                         float rho;
                         if constexpr(PLAIN) {   // straight-line code: the three exp chains interleave (same values as d_barnes_rho)
                             rho = p_hh ? d_barnes_rho_flat(dist, p_rh) : 1.0f;

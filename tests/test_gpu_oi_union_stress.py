@@ -28,6 +28,37 @@ def test_random_configurations_62_row_tile(seed):
     _random_configuration(seed, [33, 40, 50, 62], cressman=seed % 5 == 0)
 
 
+@pytest.mark.parametrize("seed", range(200, 212))
+def test_random_configurations_rough_terrain(seed):
+    """White-noise elevations / land fractions with elevation and laf dependent rho: every cell has its own observation set, the
+    per-selection kernel does everything (its per-lane candidate lists with the combined pruning test, its half-wave solves)."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(7000 + seed)
+    Y, X = int(rng.integers(8, 60)), int(rng.integers(8, 60))
+    S = int(rng.choice([40, 150, 600, 2000]))
+    h = float(rng.choice([5000.0, 10000.0, 30000.0]))
+    v = float(rng.choice([100.0, 300.0, 1000.0]))
+    w = float(rng.choice([0.0, 0.5]))
+    mp = int(rng.choice([3, 10, 30, 32, 50]))
+    ext = 0.3 * float(rng.choice([0.3, 1.0]))
+    lats, lons = np.meshgrid(np.linspace(60, 60 + ext, Y), np.linspace(10, 10 + 2 * ext, X), indexing="ij")
+    ge, gl = rng.uniform(0, 1000, (Y, X)).astype(np.float32), rng.uniform(0, 1, (Y, X)).astype(np.float32)
+    plat, plon = 60 + ext * rng.random(S), 10 + 2 * ext * rng.random(S)
+    pe, pl = rng.uniform(0, 1000, S).astype(np.float32), rng.uniform(0, 1, S).astype(np.float32)
+    if seed % 3 == 0:
+        pe[rng.random(S) < 0.1] = np.nan     # observations without an elevation: their vertical factor is 1
+    bg = rng.normal(0, 2, (Y, X)).astype(np.float32)
+    obs, pbg = rng.normal(0, 2, S).astype(np.float32), rng.normal(0, 2, S).astype(np.float32)
+    ratios = rng.uniform(0.05, 2, S).astype(np.float32)
+    allow = bool(seed % 2)
+    out = gridpp.optimal_interpolation(gridpp.Grid(lats, lons, ge, gl), bg, gridpp.Points(plat, plon, pe, pl), obs, ratios, pbg,
+                                       gridpp.BarnesStructure(h, v, w), mp, allow)
+    ref = O.oi(O.Pts(lats.ravel(), lons.ravel(), ge.ravel(), gl.ravel()), bg.ravel(), O.Pts(plat, plon, pe, pl), obs, ratios, pbg,
+               O.Barnes(h, v, w), mp, allow).reshape(Y, X)
+    _check(out, ref)
+
+
 def _random_configuration(seed, mps, cressman=False):
     import gridpp_amd as gridpp
     from oracle import oracle as O
