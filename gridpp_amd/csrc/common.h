@@ -52,8 +52,10 @@ struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
     DevBuf& operator=(const DevBuf&) = delete;
     T* get(size_t n) {
         if(n > cap) {
-            if(p) GPP_HIP(hipFree(p));
+            T* old = p;
             p = nullptr;
+            cap = 0;   // (a failed hipMalloc below must not leave a capacity behind a null pointer)
+            if(old) GPP_HIP(hipFree(old));
             GPP_HIP(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
             cap = n;
         }

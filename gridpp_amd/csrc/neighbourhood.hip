@@ -28,6 +28,7 @@
 using namespace gpp;
 
 #include "row_stats.h"
+#include "qf_box.h"
 
 // -------------------------------------------------------------------------------------------
 // member pass
@@ -77,7 +78,8 @@ __device__ __forceinline__ void count_le4(const float v, const float t0, const f
 // LDS path keeps address space 3 (a pointer that may be either becomes a slow flat access)
 template <int MODE>
 __device__ __forceinline__ void member_row_work(const float* row, const int E, const bool vec_ok, const int statistic,
-                                                const float* __restrict__ thr, const int T, float* __restrict__ out, const long C, const long cell) {
+                                                const float* __restrict__ thr, const int T, float* __restrict__ out, const long C, const long cell,
+                                                const QfGeom& g) {
     if(MODE == 0) {
         if(vec_ok && (statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT))
             out[cell] = row_mean_sum_count_v4(row, E, statistic);
@@ -118,12 +120,15 @@ __device__ __forceinline__ void member_row_work(const float* row, const int E, c
                 }
             }
             count = cnt;
-            if(MODE == 2) {   // raw counts, one byte each (E <= 255): plane t = #(valid members <= thr[t]), plane T = #valid members
-                unsigned char* out8 = reinterpret_cast<unsigned char*>(out);
+            if(MODE == 2) {   // raw counts, one byte each (E <= 254) in the padded planes of qf_box.h
+                unsigned char* out8 = reinterpret_cast<unsigned char*>(out) + qf_cell_offset(g, cell);
 #pragma unroll
                 for(int k = 0; k < TB; k++)
-                    if(t0 + k < T) out8[(long)(t0 + k) * C + cell] = (unsigned char)sum[k];
-                if(t0 + TB >= T) out8[(long)T * C + cell] = (unsigned char)count;
+                    if(t0 + k < T) out8[(long)(t0 + k) * g.Pp] = (unsigned char)sum[k];
+                if(t0 + TB >= T) {
+                    out8[(long)T * g.Pp] = (unsigned char)count;
+                    if(count != E) { g.rowflag[cell / g.X] = 1; g.rowflag[g.Y] = 1; }
+                }
             }
             else {
 #pragma unroll
@@ -145,7 +150,7 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 template <int MODE>
 __global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in, long C, int E, int statistic,
-                                                    const float* __restrict__ thr, int T, float* __restrict__ out, int use_dma) {
+                                                    const float* __restrict__ thr, int T, float* __restrict__ out, int use_dma, const QfGeom g) {
     extern __shared__ float4 lds4[];
     const int lane = threadIdx.x;
     const long ntiles = (C + 63) / 64;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in
                 issue(tile, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                member_row_work<MODE>(reinterpret_cast<const float*>(lds4) + lane * E, E, (E & 3) == 0, statistic, thr, T, out, C, tile * 64 + lane);
+                member_row_work<MODE>(reinterpret_cast<const float*>(lds4) + lane * E, E, (E & 3) == 0, statistic, thr, T, out, C, tile * 64 + lane, g);
             }
         }
         else {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in
                 const long nxt = tile + gridDim.x;
                 if(nxt < nfull) issue(nxt, b ^ 1);                   // next tile flies during the row walk
                 const float* row = reinterpret_cast<const float*>(lds4 + b * bufstride) + lane * E;
-                member_row_work<MODE>(row, E, (E & 3) == 0, statistic, thr, T, out, C, tile * 64 + lane);
+                member_row_work<MODE>(row, E, (E & 3) == 0, statistic, thr, T, out, C, tile * 64 + lane, g);
                 b ^= 1;
             }
         }
@@ -190,14 +195,217 @@ __global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in
         // the last, partial tile (if any): lane-private walk straight from memory, on block 0
         if(nfull < ntiles && blockIdx.x == 0) {
             const long cell = nfull * 64 + lane;
-            if(cell < C) member_row_work<MODE>(in + cell * E, E, false, statistic, thr, T, out, C, cell);
+            if(cell < C) member_row_work<MODE>(in + cell * E, E, false, statistic, thr, T, out, C, cell, g);
         }
         return;
     }
     // generic path (long rows or unaligned input): lane-private walk straight from memory
     for(long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long cell = tile * 64 + lane;
-        if(cell < C) member_row_work<MODE>(in + cell * E, E, false, statistic, thr, T, out, C, cell);
+        if(cell < C) member_row_work<MODE>(in + cell * E, E, false, statistic, thr, T, out, C, cell, g);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// quantile_fast member pass, round 3: k_qf_lut + k_qf_count<NL>  (neighbourhood.cpp:453-472)
+//
+// plane t of the result = #(valid members <= thr[t]) per cell, plane T = #valid members, one byte each (E <= 255) -- what
+// k_member_pass<2> writes with 2 * T instructions per member.  Here a member costs ~8:
+//   * rank instead of T compares.  With u[0 .. U) the distinct finite thresholds in ascending order and
+//     idx(v) = #{k : u[k] < v}:   v <= u[k]  <=>  idx(v) <= k.  idx comes from a 256-entry bucket table (LDS): the bucket of v
+//     is b(v) = sat_u8(fma(v, scale, off)) -- monotone in v whatever the rounding, so every threshold in a lower bucket is
+//     below v and every threshold in a higher bucket is not: only the (at most one) threshold INSIDE the bucket needs the
+//     exact float compare, idx = idx0[b] + (v > thr_in[b]).  k_qf_lut computes the buckets of the thresholds with the very
+//     instructions of the member pass (so table and pass cannot disagree by a rounding) and raises a flag -- the call then
+//     takes k_member_pass<2> -- when two distinct thresholds share a bucket or a threshold is not finite.
+//     Invalid members cost nothing: NaN / -inf saturate into bucket 0, whose entry (-inf, 255) turns a finite value into
+//     rank 0 (255 + 1, byte arithmetic) and leaves 255 for the others; +inf lands in bucket 255 = (FLT_MAX, U) -> U + 1.
+//     Any rank above U means "not counted".
+//   * sums of absolute differences instead of counters.  The ranks of four members are the bytes of one dword, and with
+//     f(k) = sum_m |idx_m - k| (v_sad_u8: four members per instruction)   #(idx <= k) = (f(k + 1) - f(k) + E) / 2,
+//     so all counts of a cell come from U + 2 accumulators: (U + 2) / 4 instructions per member.  #(idx <= U) = #valid.
+//   * lanes = consecutive float4 of the cube while the ranks are formed (coalesced global_load_dwordx4, no staging of the
+//     floats), lanes = cells for the sums: only the rank bytes (E bytes per cell) cross the LDS.
+// -------------------------------------------------------------------------------------------
+#define QF_NB 256
+#define QC_G 5     // float4 loads in flight per lane and group
+struct QfLut {
+    float scale, off;
+    int U;          // distinct finite thresholds
+    int flag;       // 1: this table cannot serve the thresholds (two in one bucket, bucket 0 / 255 hit, non-finite threshold)
+    int ident;      // rank[t] == t for every t (thresholds strictly ascending): planes leave in accumulator order
+    int rank[16];   // thr[t] = u[rank[t]]
+    int pad[3];
+    uint2 lut[QF_NB];   // (threshold inside the bucket or a sentinel, rank below the bucket)
+};
+__device__ __forceinline__ unsigned qf_bucket_into(const float v, const float scale, const float off, const unsigned sel, const unsigned old) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v, scale, off), sel, old);
+}
+__global__ __launch_bounds__(QF_NB) void k_qf_lut(const float* __restrict__ thr, int T, QfLut* __restrict__ L) {
+    __shared__ float u[16];
+    __shared__ int ub[16];
+    __shared__ int s_U, s_flag;
+    const int j = threadIdx.x;
+    if(j == 0) {
+        int flag = 0, U = 0;
+        for(int t = 0; t < T; t++) if(!nv(thr[t]) || fabsf(thr[t]) > 1e37f) flag = 1;
+        if(!flag) {   // distinct values, ascending (T <= 16: insertion)
+            for(int t = 0; t < T; t++) {
+                const float v = thr[t];
+                int k = 0; bool dup = false;
+                while(k < U && u[k] < v) k++;
+                if(k < U && u[k] == v) dup = true;
+                if(!dup) { for(int m = U; m > k; m--) u[m] = u[m - 1]; u[k] = v; U++; }
+            }
+            int ident = 1;
+            for(int t = 0; t < T; t++) { int k = 0; while(u[k] < thr[t]) k++; L->rank[t] = k; if(k != t) ident = 0; }
+            L->ident = ident;
+            // lowest threshold -> bucket 1.5, highest -> bucket 253.5
+            const float lo = u[0], hi = u[U - 1];
+            float scale = (hi > lo) ? 252.0f / (hi - lo) : 1.0f;
+            if(!nv(scale) || scale <= 0) scale = 1.0f;
+            const float off = (hi > lo ? 1.5f : 127.5f) - lo * scale;
+            L->scale = scale; L->off = off;
+            for(int k = 0; k < U; k++) {
+                ub[k] = (int)(qf_bucket_into(u[k], scale, off, 0, 0) & 0xffu);
+                if(ub[k] < 1 || ub[k] > 254 || (k > 0 && ub[k] == ub[k - 1])) flag = 1;
+            }
+            if(!nv(off)) flag = 1;
+        }
+        s_U = U; s_flag = flag;
+        L->U = U; L->flag = flag;
+    }
+    __syncthreads();
+    if(s_flag) return;
+    const int U = s_U;
+    int below = 0; float inside = INFINITY;   // `v > +inf` is never true: an empty bucket keeps the rank below it
+    for(int k = 0; k < U; k++) { if(ub[k] < j) below++; else if(ub[k] == j) inside = u[k]; }
+    if(j == 0) { inside = -INFINITY; below = 255; }
+    if(j == QF_NB - 1) inside = 3.402823466e38f;
+    L->lut[j] = make_uint2(__float_as_uint(inside), (unsigned)below);
+}
+
+template <int NL>
+__global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, long C, int E, const float* __restrict__ thr, int T,
+                                                 const QfLut* __restrict__ L, unsigned char* __restrict__ out8, const QfGeom g) {
+    extern __shared__ unsigned qc_lds[];
+    uint2* const lut = reinterpret_cast<uint2*>(qc_lds);          // [QF_NB]
+    unsigned* const ranks = qc_lds + 2 * QF_NB;                    // [16 E] rank bytes of a tile, four members per dword, cell-major
+    const int lane = threadIdx.x;
+    const int E4 = E >> 2;                                        // float4 per cell = dwords of rank bytes per cell = 64-lane loads per tile
+    if((unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)qc_lds != 0u) __builtin_trap();   // see quad()
+    for(int k = lane; k < QF_NB; k += 64) lut[k] = L->lut[k];
+    const float scale = L->scale, off = L->off;
+    const int ident = L->ident;
+    const long nfull = C / 64;
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    const unsigned zero = 0;
+    __syncthreads();
+    for(long tile = blockIdx.x; tile < nfull; tile += gridDim.x) {
+        const float4* src = in4 + tile * 16 * E + lane;
+        // rank bytes of four members (one float4) -> ranks[k * 64 + lane]
+        auto quad = [&](const float4 q, const int k) {
+            unsigned bk = 0;
+            bk = qf_bucket_into(q.x, scale, off, 0, bk);
+            bk = qf_bucket_into(q.y, scale, off, 1, bk);
+            bk = qf_bucket_into(q.z, scale, off, 2, bk);
+            bk = qf_bucket_into(q.w, scale, off, 3, bk);
+            unsigned a0, a1, a2, a3;   // byte offsets of the four table entries (one instruction each: byte select + shift)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a0) : "v"(3u), "v"(bk));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a1) : "v"(3u), "v"(bk));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a2) : "v"(3u), "v"(bk));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a3) : "v"(3u), "v"(bk));
+            // (the table sits at LDS address 0 -- checked at kernel entry -- so the byte offsets ARE the addresses: no base add)
+            typedef unsigned qc_u2 __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(3))) qc_u2* lds_u2;
+#if defined(QC_ABL) && (QC_ABL & 1)   // timing experiment: no table gathers
+            const qc_u2 e0 = {a0, a1}, e1 = {a1, a2}, e2 = {a2, a3}, e3 = {a3, a0};
+#else
+            const qc_u2 e0 = *(lds_u2)(size_t)a0, e1 = *(lds_u2)(size_t)a1, e2 = *(lds_u2)(size_t)a2, e3 = *(lds_u2)(size_t)a3;
+#endif
+            unsigned pk;   // byte m = rank of member m = rank below its bucket + (value > threshold inside the bucket)
+            asm volatile("v_cmp_gt_f32_e32 vcc, %1, %2\n\t"
+                         "v_addc_co_u32_sdwa %0, vcc, %3, %4, vcc dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+                         : "=v"(pk) : "v"(q.x), "v"(e0.x), "v"(e0.y), "v"(zero) : "vcc");
+            asm volatile("v_cmp_gt_f32_e32 vcc, %1, %2\n\t"
+                         "v_addc_co_u32_sdwa %0, vcc, %3, %4, vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                         : "+v"(pk) : "v"(q.y), "v"(e1.x), "v"(e1.y), "v"(zero) : "vcc");
+            asm volatile("v_cmp_gt_f32_e32 vcc, %1, %2\n\t"
+                         "v_addc_co_u32_sdwa %0, vcc, %3, %4, vcc dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                         : "+v"(pk) : "v"(q.z), "v"(e2.x), "v"(e2.y), "v"(zero) : "vcc");
+            asm volatile("v_cmp_gt_f32_e32 vcc, %1, %2\n\t"
+                         "v_addc_co_u32_sdwa %0, vcc, %3, %4, vcc dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                         : "+v"(pk) : "v"(q.w), "v"(e3.x), "v"(e3.y), "v"(zero) : "vcc");
+            ranks[k * 64 + lane] = pk;
+        };
+        // whole groups of QC_G loads in flight: the next group is asked for before the current one is ranked
+        const int ng = E4 / QC_G;
+        float4 cur[QC_G], nxt[QC_G];
+        if(ng > 0) {
+#pragma unroll
+            for(int i = 0; i < QC_G; i++) cur[i] = src[i * 64];
+        }
+        for(int g = 0; g < ng; g++) {
+            if(g + 1 < ng) {
+#pragma unroll
+                for(int i = 0; i < QC_G; i++) nxt[i] = src[((g + 1) * QC_G + i) * 64];
+            }
+#pragma unroll
+            for(int i = 0; i < QC_G; i++) quad(cur[i], g * QC_G + i);
+#pragma unroll
+            for(int i = 0; i < QC_G; i++) cur[i] = nxt[i];
+        }
+        for(int k = ng * QC_G; k < E4; k++) quad(src[k * 64], k);
+        __syncthreads();
+        unsigned f[NL];
+#pragma unroll
+        for(int l = 0; l < NL; l++) f[l] = 0;
+        const unsigned* row = ranks + lane * E4;
+#if defined(QC_ABL) && (QC_ABL & 2)   // timing experiment: a fifth of the sums
+        const int E4c = E4 / 5;
+#else
+        const int E4c = E4;
+#endif
+#pragma unroll 5
+        for(int k = 0; k < E4c; k++) {
+            const unsigned w = row[k];
+#pragma unroll
+            for(int l = 0; l < NL; l++) f[l] = __builtin_amdgcn_sad_u8(w, 0x01010101u * (unsigned)l, f[l]);
+        }
+        const long cell = tile * 64 + lane;
+        unsigned cum[NL - 1];
+#pragma unroll
+        for(int l = 0; l < NL - 1; l++) cum[l] = (f[l + 1] - f[l] + (unsigned)E) >> 1;   // #(rank <= l); l = U: #valid members
+        // (row, column) of the cell in the padded planes: one scalar division per tile, the lanes step on from there
+        int y = (int)((tile * 64) / g.X), x = (int)(tile * 64 - (long)y * g.X) + lane;
+        while(x >= g.X) { x -= g.X; y++; }
+        unsigned char* o8 = out8 + (long)(y + QF_PADY) * g.Xp + x + QF_PADX;
+        if(cum[NL - 2] != (unsigned)E) { g.rowflag[y] = 1; g.rowflag[g.Y] = 1; }
+        if(ident) {   // U == T == NL - 2
+#if defined(QC_ABL) && (QC_ABL & 4)   // timing experiment: one plane stored
+            unsigned acc = 0;
+#pragma unroll
+            for(int l = 0; l < NL - 1; l++) acc += cum[l];
+            o8[0] = (unsigned char)acc;
+#else
+#pragma unroll
+            for(int l = 0; l < NL - 1; l++) o8[(long)l * g.Pp] = (unsigned char)cum[l];
+#endif
+        }
+        else {   // thresholds not in ascending order: the counts change places through the (consumed) rank area
+            __syncthreads();
+            unsigned* const xch = ranks;
+#pragma unroll
+            for(int l = 0; l < NL - 1; l++) xch[l * 64 + lane] = cum[l];
+            for(int t = 0; t < T; t++) o8[(long)t * g.Pp] = (unsigned char)xch[L->rank[t] * 64 + lane];
+            o8[(long)T * g.Pp] = (unsigned char)cum[NL - 2];
+        }
+        __syncthreads();   // the rank bytes are consumed
+    }
+    // the last, partial tile (if any): lane-private walk straight from memory, on block 0
+    if(nfull * 64 < C && blockIdx.x == 0) {
+        const long cell = nfull * 64 + lane;
+        if(cell < C) member_row_work<2>(in + cell * E, E, false, 0, thr, T, reinterpret_cast<float*>(out8), C, cell, g);
     }
 }
 
@@ -527,270 +735,6 @@ __global__ void k_qf_interp(const float* __restrict__ ya, long C, int T, const f
 }
 
 // -------------------------------------------------------------------------------------------
-// quantile_fast, 3-D input, fused box pass (neighbourhood.cpp:453-522): the T threshold planes never exist as float / double
-// arrays in HBM.  The member pass leaves T + 1 BYTES per cell (#members <= thr[t], #valid members); one workgroup per
-// 64 x 32 tile of output cells then, plane by plane, rebuilds temp = count / valid (float, :465-470) for the tile and its
-// halo in LDS, forms the box sums separably with sliding windows -- rows into a double tile, columns into registers -- and
-// keeps the clamped means of its cells (yarray, :494-506) in registers until the interpolation (util.cpp:377-414) writes the
-// one output value.  The window sums are EXACT: every temp is a float32 in [0, 1] with at least 2^-31 resolution and a
-// window holds at most (2 hw + 1)^2 of them, so all partial sums fit a double without rounding, in any order -- the
-// reference's summed-area table differs from them only by its own double rounding.
-// HBM traffic: (T + 1) bytes per cell written, about twice that read (halo, mostly L2 hits) instead of 28 T bytes per cell.
-// -------------------------------------------------------------------------------------------
-#define QF_TX 64      // tile width (cells)
-#define QF_TY 32      // tile height
-#define QF_SEGX 16    // outputs per thread in the row pass
-#define QF_SEGY 8     // outputs per thread in the column pass
-#define QF_TMAX 16    // most thresholds held in registers per cell (template TM: 8, 12 or 16)
-#define QF_RP (QF_TX + 1)   // pitch (doubles) of the row-sum tile: consecutive rows fall into different banks
-#define QF_RMAX 64    // most rows of a tile with its halo (halfwidth <= 16): each thread keeps its 32 bytes of a plane in 8 registers
-template <int TM>
-__global__ __launch_bounds__(256, 2) void k_qf_fused(const unsigned char* __restrict__ cnt8, int Y, int X, int reps, int hw, int T,
-                                                  const float* __restrict__ thr, const float* __restrict__ q, int qfield, float* __restrict__ out, int dbg) {
-    extern __shared__ double qf_lds[];
-    const long C = (long)Y * X;
-    const int rows = QF_TY + 2 * hw, cols = QF_TX + 2 * hw;
-    const int pitch = cols | 1;                                     // odd pitch: a column of the float tile hits 64 different banks
-    double* const rsum = qf_lds;                                    // [rows][QF_RP] row sums
-    float* const tmp = reinterpret_cast<float*>(rsum + rows * QF_RP);   // [rows][pitch] temp = count / valid (0 outside the domain / no valid member)
-    unsigned char* const val = reinterpret_cast<unsigned char*>(tmp + rows * pitch);   // [rows][cols] #valid members (0 outside the domain)
-    __shared__ int s_invalid;
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * QF_TX, y0 = blockIdx.y * QF_TY;
-    if(tid == 0) s_invalid = 0;
-    __syncthreads();
-    // thread -> (four neighbouring columns of the tile + halo, every eighth row): one (unaligned) dword load fetches four cells
-    const int lc = (tid & 31) * 4, lrg = tid >> 5;
-    const int lx = x0 - hw + lc;
-    const bool quad_in = lx >= 0 && lx + 3 < X && lc + 3 < cols;    // the whole quad inside the domain and the tile
-    auto load4 = [&](const unsigned char* plane, const int y) -> unsigned {   // bytes of columns lx .. lx + 3 of row y (0 outside)
-        if(y < 0 || y >= Y || (dbg & 1)) return 0u;
-        const unsigned char* p = plane + (long)y * X + lx;
-        if(quad_in) return *reinterpret_cast<const unsigned*>(p);
-        unsigned w = 0;
-#pragma unroll
-        for(int b4 = 0; b4 < 4; b4++) if(lc + b4 < cols && lx + b4 >= 0 && lx + b4 < X) w |= (unsigned)p[b4] << (8 * b4);
-        return w;
-    };
-    // #valid members of the tile + halo
-    const unsigned char* vplane = cnt8 + (long)T * C;
-    int inv = 0;
-    unsigned vb[QF_RMAX / 8], pre[QF_RMAX / 8];   // this thread's quads of the #valid plane and of the current / next threshold plane
-#pragma unroll
-    for(int ii = 0; ii < QF_RMAX / 8; ii++) {
-        const int r = 8 * ii + lrg, y = y0 - hw + r;
-        unsigned w = 0;
-        if(r < rows) {
-            w = load4(vplane, y);
-#pragma unroll
-            for(int b4 = 0; b4 < 4; b4++) {
-                const int x = lx + b4;
-                if(lc + b4 < cols) {
-                    const unsigned v = (w >> (8 * b4)) & 0xffu;
-                    if(v == 0 && y >= 0 && y < Y && x >= 0 && x < X) inv = 1;
-                    val[r * cols + lc + b4] = (unsigned char)v;
-                }
-            }
-        }
-        vb[ii] = w;
-    }
-    if(inv) s_invalid = 1;
-    __syncthreads();
-    const bool counted = s_invalid != 0;   // some cell of the tile or its halo has no valid member: window counts are summed, not computed
-    // this thread's cells in the column pass: column cx, rows [cy0, cy0 + QF_SEGY)
-    const int cx = tid & (QF_TX - 1), cy0 = (tid / QF_TX) * QF_SEGY;
-    const int gx = x0 + cx;
-    float ya[QF_SEGY][TM];
-    int wc[QF_SEGY];
-    double sums[QF_SEGY];
-    // box sums of the float tile `tmp` for this thread's QF_SEGY cells -> sums[]
-    auto box_pass = [&]() {
-        // rows: thread (row r, segment s): QF_SEGX outputs with a sliding window over tmp
-        for(int it = tid; it < rows * (QF_TX / QF_SEGX) && !(dbg & 2); it += 256) {
-            const int r = it % rows, sg = it / rows;
-            const float* tr = tmp + r * pitch + sg * QF_SEGX;       // window of output j: tr[j .. j + 2 hw]
-            // (the sums are exact, so any order will do: four accumulators, reads issued eight at a time)
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int k = 0;
-            for(; k + 8 <= 2 * hw + 1; k += 8) {
-                const float a0 = tr[k], a1 = tr[k + 1], a2 = tr[k + 2], a3 = tr[k + 3], a4 = tr[k + 4], a5 = tr[k + 5], a6 = tr[k + 6], a7 = tr[k + 7];
-                s0 += (double)a0; s1 += (double)a1; s2 += (double)a2; s3 += (double)a3;
-                s0 += (double)a4; s1 += (double)a5; s2 += (double)a6; s3 += (double)a7;
-            }
-            for(; k <= 2 * hw; k++) s0 += (double)tr[k];
-            double sm = (s0 + s1) + (s2 + s3);
-            rsum[r * QF_RP + sg * QF_SEGX] = sm;
-            float in_[QF_SEGX - 1], out_[QF_SEGX - 1];
-#pragma unroll
-            for(int j = 1; j < QF_SEGX; j++) { in_[j - 1] = tr[j + 2 * hw]; out_[j - 1] = tr[j - 1]; }
-#pragma unroll
-            for(int j = 1; j < QF_SEGX; j++) {
-                sm += (double)in_[j - 1];
-                sm -= (double)out_[j - 1];
-                rsum[r * QF_RP + sg * QF_SEGX + j] = sm;
-            }
-        }
-        __syncthreads();
-        // columns: thread (column cx, segment): QF_SEGY outputs, window of output row j: rsum rows [cy0 + j, cy0 + j + 2 hw]
-        const double* cr = rsum + cy0 * QF_RP + cx;
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-        int k = 0;
-        for(; k + 8 <= 2 * hw + 1 && !(dbg & 4); k += 8) {
-            const double a0 = cr[k * QF_RP], a1 = cr[(k + 1) * QF_RP], a2 = cr[(k + 2) * QF_RP], a3 = cr[(k + 3) * QF_RP];
-            const double a4 = cr[(k + 4) * QF_RP], a5 = cr[(k + 5) * QF_RP], a6 = cr[(k + 6) * QF_RP], a7 = cr[(k + 7) * QF_RP];
-            c0 += a0; c1 += a1; c2 += a2; c3 += a3; c0 += a4; c1 += a5; c2 += a6; c3 += a7;
-        }
-        for(; k <= 2 * hw; k++) c0 += cr[k * QF_RP];
-        double sm = (c0 + c1) + (c2 + c3);
-        sums[0] = sm;
-        double cin[QF_SEGY - 1], cout[QF_SEGY - 1];
-#pragma unroll
-        for(int j = 1; j < QF_SEGY; j++) { cin[j - 1] = cr[(j + 2 * hw) * QF_RP]; cout[j - 1] = cr[(j - 1) * QF_RP]; }
-#pragma unroll
-        for(int j = 1; j < QF_SEGY; j++) {
-            sm += cin[j - 1];
-            sm -= cout[j - 1];
-            sums[j] = sm;
-        }
-        __syncthreads();
-    };
-    // window counts
-    if(counted) {
-        for(int k = tid; k < rows * cols; k += 256) { const int r = k / cols, c = k - r * cols; tmp[r * pitch + c] = val[k] ? 1.0f : 0.0f; }
-        __syncthreads();
-        box_pass();
-#pragma unroll
-        for(int j = 0; j < QF_SEGY; j++) wc[j] = (int)sums[j];
-    }
-    else {
-        const int nx_w = min(gx + hw, X - 1) - max(gx - hw, 0) + 1;
-#pragma unroll
-        for(int j = 0; j < QF_SEGY; j++) { const int gy = y0 + cy0 + j; wc[j] = nx_w * (min(gy + hw, Y - 1) - max(gy - hw, 0) + 1); }
-    }
-#pragma unroll
-    for(int j = 0; j < QF_SEGY; j++)
-#pragma unroll
-        for(int tt = 0; tt < TM; tt++) ya[j][tt] = 0.0f;
-    // the next plane is fetched while the current one is summed
-    auto fetch = [&](const unsigned char* plane) {
-#pragma unroll
-        for(int ii = 0; ii < QF_RMAX / 8; ii++) { const int r = 8 * ii + lrg; pre[ii] = (r < rows) ? load4(plane, y0 - hw + r) : 0u; }
-    };
-    fetch(cnt8);
-    float* const tab = reinterpret_cast<float*>(val + rows * cols + 16 - ((rows * cols) & 3));   // k / reps for k = 0 .. 255 (the usual case: every member valid)
-    for(int k = tid; k < 256; k += 256) tab[k] = (float)k / (float)reps;
-    __syncthreads();
-#pragma unroll 1
-    for(int t = 0; t < T; t++) {
-#pragma unroll
-        for(int ii = 0; ii < QF_RMAX / 8; ii++) {
-            const int r = 8 * ii + lrg;
-            if(r < rows) {
-#pragma unroll
-                for(int b4 = 0; b4 < 4; b4++) {
-                    if(lc + b4 < cols) {
-                        const int v = (int)((vb[ii] >> (8 * b4)) & 0xffu);
-                        const int cb = (int)((pre[ii] >> (8 * b4)) & 0xffu);
-                        // :465-470 (no valid member: NaN there, skipped by the mean)
-                        tmp[r * pitch + lc + b4] = (v == reps) ? tab[cb] : (v ? (float)cb / (float)v : 0.0f);
-                    }
-                }
-            }
-        }
-        if(t + 1 < T) fetch(cnt8 + (long)(t + 1) * C);
-        __syncthreads();
-        box_pass();
-        // mean (:473), E-fold float sum / E (:494-499: `sum += value` E times, two cells per packed add), clamp (:500-506)
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        v2f o2[QF_SEGY / 2], acc[QF_SEGY / 2];
-#pragma unroll
-        for(int jj = 0; jj < QF_SEGY / 2; jj++) {
-            o2[jj].x = wc[2 * jj] > 0 ? (float)(sums[2 * jj] / (double)wc[2 * jj]) : NAN;
-            o2[jj].y = wc[2 * jj + 1] > 0 ? (float)(sums[2 * jj + 1] / (double)wc[2 * jj + 1]) : NAN;
-            acc[jj] = (v2f){0.0f, 0.0f};
-        }
-        if(reps > 1) {   // ONE loop over the members with all the cells' chains in it (a loop per cell would be a bare dependency chain)
-            const int nrep = (dbg & 8) ? 1 : reps;
-            for(int e = 0; e < nrep; e++) {
-#pragma unroll
-                for(int jj = 0; jj < QF_SEGY / 2; jj++) acc[jj] += o2[jj];
-            }
-        }
-#pragma unroll
-        for(int jj = 0; jj < QF_SEGY / 2; jj++) {
-            v2f yv = o2[jj];
-            if(reps > 1) { yv.x = acc[jj].x / (float)reps; yv.y = acc[jj].y / (float)reps; }
-            const float oa = !nv(o2[jj].x) ? NAN : (yv.x > 1 ? 1.0f : (yv.x < 0 ? 0.0f : yv.x));
-            const float ob = !nv(o2[jj].y) ? NAN : (yv.y > 1 ? 1.0f : (yv.y < 0 ? 0.0f : yv.y));
-#pragma unroll
-            for(int tt = 0; tt < TM; tt++) {   // (selects: the array stays in registers)
-                ya[2 * jj][tt] = (tt == t) ? oa : ya[2 * jj][tt];
-                ya[2 * jj + 1][tt] = (tt == t) ? ob : ya[2 * jj + 1][tt];
-            }
-        }
-    }
-    // interpolation per cell (the code of k_qf_interp on the register copy of yarray)
-#pragma unroll
-    for(int j = 0; j < QF_SEGY; j++) {
-        const int gy = y0 + cy0 + j;
-        if(gx >= X || gy >= Y) continue;
-        const long c = (long)gy * X + gx;
-        const float x = qfield ? q[c] : q[0];
-        // (opaque copies: `select(load, load)` must not become `load(select(address))`, which would put the array on the stack)
-        float yr[TM];
-#pragma unroll
-        for(int tt = 0; tt < TM; tt++) { float v = ya[j][tt]; asm("" : "+v"(v)); yr[tt] = v; }
-        auto yat = [&](int idx) { float v = yr[0];
-#pragma unroll
-            for(int tt = 1; tt < TM; tt++) v = (tt == idx) ? yr[tt] : v;
-            return v; };
-        bool missing = false;
-#pragma unroll
-        for(int tt = 0; tt < TM; tt++) if(tt < T && !nv(yr[tt])) missing = true;
-        float o = NAN;
-        if(!missing) {
-            const float y0a = yr[0], yLa = yat(T - 1);
-            if(x == 1 && y0a == 1) o = thr[0];
-            else if(x == 0 && yLa == 0) o = thr[T - 1];
-            else if(!nv(x)) o = NAN;
-            else if(x > yLa) o = thr[T - 1];
-            else if(x < y0a) o = thr[0];
-            else {
-                // the two index scans of util.cpp:339-414 with static register indices (a running flag instead of `break`: a scan that
-                // indexes the register copy dynamically costs a select chain per step)
-                int i0 = -1, i1 = -1;
-                bool run0 = true, run1 = true;
-#pragma unroll
-                for(int i = 0; i < TM; i++) {
-                    const float cv = yr[i];
-                    const bool on = run0 && i < T, lt = on && cv < x, eq = on && cv == x;
-                    i0 = (lt || eq) ? i : i0;
-                    run0 = lt;
-                }
-#pragma unroll
-                for(int i = TM - 1; i >= 0; i--) {
-                    const float cv = yr[i];
-                    const bool on = run1 && i < T, gt = on && cv > x, eq = on && cv == x;
-                    i1 = (gt || eq) ? i : i1;
-                    run1 = (i < T) ? gt : run1;
-                }
-                if(i0 < 0) i0 = 0;
-                if(i1 < 0) i1 = T - 1;
-                const float xa = yat(i0), xb = yat(i1), ta = thr[i0], tb = thr[i1];
-                if(xa == xb) {
-                    if(i0 == 0 && i1 == T - 1) o = (ta + tb) / 2;
-                    else if(i0 == 0) o = tb;
-                    else if(i1 == T - 1) o = ta;
-                    else o = (ta + tb) / 2;
-                }
-                else o = ta + (tb - ta) * (x - xa) / (xb - xa);
-            }
-        }
-        out[c] = o;
-    }
-}
-
-// -------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------
 namespace {
@@ -798,11 +742,13 @@ struct NbWorkspace {
     DevBuf<float> flat, tmp, tmp2, planes, thr, qf;
     DevBuf<double> rs;
     DevBuf<int> rc, plane_flags;
+    const void* pad_ptr = nullptr;   // the padding of the quantile_fast count planes is in place for this buffer and shape
+    int pad_y = 0, pad_x = 0, pad_t = 0, pad_e = 0;
 };
 thread_local NbWorkspace g_nb;
 
 template <int MODE>
-void member_pass_launch(const float* d_in, long C, int E, int statistic, const float* d_thr, int T, float* d_out) {
+void member_pass_launch(const float* d_in, long C, int E, int statistic, const float* d_thr, int T, float* d_out, const QfGeom& g) {
     const long tiles = (C + 63) / 64;
     const int nchunk = (16 * E + 63) / 64;
     const bool dma = E <= MEMBER_EC && (reinterpret_cast<size_t>(d_in) & 15) == 0;
@@ -811,13 +757,31 @@ void member_pass_launch(const float* d_in, long C, int E, int statistic, const f
     std::call_once(attr_once, [] { GPP_HIP(hipFuncSetAttribute((const void*)k_member_pass<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ((16 * MEMBER_EC + 63) / 64) * 1024)); });
     const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds, 1)));
     const long grid = std::min<long>(tiles, (long)256 * waves_per_cu);
-    hipLaunchKernelGGL((k_member_pass<MODE>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, statistic, d_thr, T, d_out, dma ? 1 : 0);
+    hipLaunchKernelGGL((k_member_pass<MODE>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, statistic, d_thr, T, d_out, dma ? 1 : 0, g);
     GPP_HIP(hipGetLastError());
 }
-void member_pass(const float* d_in, long C, int E, int mode, int statistic, const float* d_thr, int T, float* d_out) {
-    if(mode == 0) member_pass_launch<0>(d_in, C, E, statistic, d_thr, T, d_out);
-    else if(mode == 2) member_pass_launch<2>(d_in, C, E, statistic, d_thr, T, d_out);
-    else member_pass_launch<1>(d_in, C, E, statistic, d_thr, T, d_out);
+void member_pass(const float* d_in, long C, int E, int mode, int statistic, const float* d_thr, int T, float* d_out, const QfGeom& g = QfGeom()) {
+    if(mode == 0) member_pass_launch<0>(d_in, C, E, statistic, d_thr, T, d_out, g);
+    else if(mode == 2) member_pass_launch<2>(d_in, C, E, statistic, d_thr, T, d_out, g);
+    else member_pass_launch<1>(d_in, C, E, statistic, d_thr, T, d_out, g);
+}
+// byte counts of quantile_fast by ranks (k_qf_count<U + 2>)
+template <int NL>
+void qf_count_launch_nl(const float* d_in, long C, int E, const float* d_thr, int T, const QfLut* lut, unsigned char* cnt8, const QfGeom& g) {
+    const size_t lds = (size_t)(2 * QF_NB + std::max(16 * E, NL * 64)) * sizeof(unsigned);
+    const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(24, (160 * 1024) / lds));
+    const long grid = std::max<long>(1, std::min<long>(C / 64, (long)256 * waves_per_cu));
+    hipLaunchKernelGGL((k_qf_count<NL>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, d_thr, T, lut, cnt8, g);
+    GPP_HIP(hipGetLastError());
+}
+void qf_count_launch(const float* d_in, long C, int E, const float* d_thr, int T, const QfLut* lut, int U, unsigned char* cnt8, const QfGeom& g) {
+    switch(U + 2) {
+#define QF_NL_CASE(n) case n: qf_count_launch_nl<n>(d_in, C, E, d_thr, T, lut, cnt8, g); break;
+        QF_NL_CASE(3) QF_NL_CASE(4) QF_NL_CASE(5) QF_NL_CASE(6) QF_NL_CASE(7) QF_NL_CASE(8) QF_NL_CASE(9) QF_NL_CASE(10)
+        QF_NL_CASE(11) QF_NL_CASE(12) QF_NL_CASE(13) QF_NL_CASE(14) QF_NL_CASE(15) QF_NL_CASE(16) QF_NL_CASE(17) QF_NL_CASE(18)
+#undef QF_NL_CASE
+        default: runtime("Internal error. quantile_fast: number of distinct thresholds");
+    }
 }
 // Mean / Sum / Count of `nplanes` [Y][X] planes
 void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statistic, float* d_out, int qf_reps = 0) {
@@ -948,10 +912,23 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
     OutField o;
     in.bind(input, (size_t)C * ne, mem);
     o.bind(out, C, mem);
+    // 3-D input with at most 254 members, 16 thresholds and a halfwidth of 16: byte counts in padded planes + the box pass of
+    // qf_box.hip.  The counts come from the rank / sum-of-absolute-differences pass (k_qf_count) when the rows are whole float4s
+    const bool fused = nt > 0 && is3d && ne <= 254 && nt <= 16 && halfwidth <= QF_MAXHW && C < (1L << 31) && !getenv("GPP_QF_NO_FUSED");
+    bool ranked = fused && (ne & 3) == 0 && (reinterpret_cast<size_t>(in.d) & 15) == 0 && !getenv("GPP_QF_NO_RANKS");
+    if(nt > 0) th.bind(thresholds, nt, mem & ~GPP_HOST_F64);   // GPP_HOST_F64 applies to `input` only: quantile / thresholds stay float32
+    QfLut* lut = nullptr;
+    int lut_head[5] = {0, 0, 0, 1, 0};   // scale, off, U, flag, ident
+    if(ranked) {
+        lut = reinterpret_cast<QfLut*>(g_nb.qf.get((sizeof(QfLut) + 3) / 4));
+        hipLaunchKernelGGL(k_qf_lut, dim3(1), dim3(QF_NB), 0, stream(), th.d, nt, lut);
+        GPP_HIP(hipGetLastError());
+        GPP_HIP(hipMemcpyAsync(lut_head, lut, sizeof(lut_head), hipMemcpyDeviceToHost, stream()));
+    }
     // quantile validation (:315-321) needs the values on the host
     std::vector<float> hq(nq);
     if(mem & GPP_MEM_DEVICE) { GPP_HIP(hipMemcpyAsync(hq.data(), quantile, sizeof(float) * nq, hipMemcpyDeviceToHost, stream())); GPP_HIP(hipStreamSynchronize(stream())); }
-    else memcpy(hq.data(), quantile, sizeof(float) * nq);
+    else { memcpy(hq.data(), quantile, sizeof(float) * nq); if(ranked) GPP_HIP(hipStreamSynchronize(stream())); }
     for(int i = 0; i < nq; i++)
         if(is_valid(hq[i]) && (hq[i] < 0 || hq[i] > 1)) invalid("All quantiles must be >= 0 and <= 1");
     if(nt == 0) {   // :330-331: all missing
@@ -960,33 +937,28 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
         GPP_HIP(hipStreamSynchronize(stream()));
         return GPP_OK;
     }
-    qf.bind(quantile, nq, mem & ~GPP_HOST_F64);      // GPP_HOST_F64 applies to `input` only: quantile / thresholds stay float32
-    th.bind(thresholds, nt, mem & ~GPP_HOST_F64);
-    {   // 3-D input with at most 255 members and 16 thresholds: byte counts + the fused box pass (k_qf_fused)
-        const int rows = QF_TY + 2 * halfwidth, cols = QF_TX + 2 * halfwidth;
-        const size_t lds = (size_t)rows * QF_RP * sizeof(double) + (size_t)rows * (cols | 1) * sizeof(float) + (size_t)rows * cols + 16 + 256 * sizeof(float);
-        if(is3d && ne <= 255 && nt <= QF_TMAX && lds <= 100 * 1024 && rows <= QF_RMAX && cols <= 128 && !getenv("GPP_QF_NO_FUSED")) {
-            unsigned char* cnt8 = reinterpret_cast<unsigned char*>(g_nb.planes.get(((size_t)(nt + 1) * C + 3) / 4));
-            member_pass(in.d, C, ne, 2, 0, th.d, nt, reinterpret_cast<float*>(cnt8));
-            static std::once_flag qf_once;
-            std::call_once(qf_once, [] {
-                GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-                GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-                GPP_HIP(hipFuncSetAttribute((const void*)k_qf_fused<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-            });
-            const dim3 grid((nx + QF_TX - 1) / QF_TX, (ny + QF_TY - 1) / QF_TY);
-            const unsigned char* c8 = cnt8;
-            const int qfl = nq == 1 ? 0 : 1;
-            const int dbg = getenv("GPP_QF_DEBUG") ? atoi(getenv("GPP_QF_DEBUG")) : 0;   // timing experiments only
-            if(nt <= 8) hipLaunchKernelGGL(k_qf_fused<8>, grid, dim3(256), lds, stream(), c8, ny, nx, ne, halfwidth, nt, th.d, qf.d, qfl, o.d, dbg);
-            else if(nt <= 12) hipLaunchKernelGGL(k_qf_fused<12>, grid, dim3(256), lds, stream(), c8, ny, nx, ne, halfwidth, nt, th.d, qf.d, qfl, o.d, dbg);
-            else hipLaunchKernelGGL(k_qf_fused<16>, grid, dim3(256), lds, stream(), c8, ny, nx, ne, halfwidth, nt, th.d, qf.d, qfl, o.d, dbg);
-            GPP_HIP(hipGetLastError());
-            o.finish();
-            GPP_HIP(hipStreamSynchronize(stream()));
-            return GPP_OK;
+    qf.bind(quantile, nq, mem & ~GPP_HOST_F64);
+    if(ranked && lut_head[3]) ranked = false;   // two thresholds in one bucket / a non-finite threshold: the compare-per-threshold pass
+    if(fused) {
+        QfGeom g = qf_geom(ny, nx);
+        unsigned char* cnt8 = reinterpret_cast<unsigned char*>(g_nb.planes.get(((size_t)(nt + 1) * g.Pp + 3) / 4));
+        if(g_nb.pad_ptr != cnt8 || g_nb.pad_y != ny || g_nb.pad_x != nx || g_nb.pad_t != nt || g_nb.pad_e != ne) {
+            // the padding is written when the planes are laid out (the passes below only ever write the cells of the field)
+            g_nb.pad_ptr = nullptr;
+            GPP_HIP(hipMemsetAsync(cnt8, 255, (size_t)nt * g.Pp, stream()));
+            GPP_HIP(hipMemsetAsync(cnt8 + (size_t)nt * g.Pp, ne, (size_t)g.Pp, stream()));
+            g_nb.pad_ptr = cnt8; g_nb.pad_y = ny; g_nb.pad_x = nx; g_nb.pad_t = nt; g_nb.pad_e = ne;
         }
+        g.rowflag = g_nb.plane_flags.get(ny + 1);
+        GPP_HIP(hipMemsetAsync(g.rowflag, 0, sizeof(int) * (ny + 1), stream()));
+        if(ranked) qf_count_launch(in.d, C, ne, th.d, nt, lut, lut_head[2], cnt8, g);
+        else member_pass(in.d, C, ne, 2, 0, th.d, nt, reinterpret_cast<float*>(cnt8), g);
+        qf_box_launch(cnt8, g, ne, halfwidth, nt, th.d, qf.d, nq == 1 ? 0 : 1, o.d);
+        o.finish();
+        GPP_HIP(hipStreamSynchronize(stream()));
+        return GPP_OK;
     }
+    g_nb.pad_ptr = nullptr;   // (the unfused path below uses the same buffer)
     float* planes = g_nb.planes.get((size_t)nt * C);
     float* stats = g_nb.tmp2.get((size_t)nt * C);
     member_pass(in.d, C, ne, 1, 0, th.d, nt, planes);                 // fractions per threshold (:453-472)

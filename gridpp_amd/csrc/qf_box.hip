@@ -1,0 +1,237 @@
+// neighbourhood_quantile_fast, 3-D input: the box pass over the count planes (gfx950).
+//
+// Replaces src/api/neighbourhood.cpp:473-522 (per threshold: stats = neighbourhood(temp, halfwidth, Mean); per cell: the
+// E-fold float sum of the clamped means, then interpolate()) and util.cpp:339-414, on the byte planes of qf_box.h.
+//
+// k_qf_box<HW>: one workgroup marches down a strip of 256 output columns.  Thread (p, s) owns threshold plane p and the
+// 16 columns of segment s and keeps, in registers, the exact window sums V[16] of its cells (doubles: every temp is a
+// float32 in [0, 1] with a resolution of 2^-31 at worst and a window holds at most 33^2 of them, so no partial sum is
+// ever rounded -- the reference's summed-area table differs from them by its own rounding only).  One step = one output
+// row: V += H(row y + HW) - H(row y - HW - 1), where H is the horizontal window sum of a row.  Both rows come as 48 bytes
+// (three 16-byte loads, always aligned and always in bounds thanks to the padding), every byte is turned into
+// temp = count / E through a 256-entry table of doubles in LDS (ds_read_b64; 255 = padding -> 0.0), and the 16 window
+// sums of the difference row cost ONE pass over its 16 + 2 HW values: with a pivot inside all 16 windows, the running
+// suffix sums below the pivot and the running prefix sums above it are exactly the two parts of every window.
+// No LDS tile, no barrier and no other thread is involved until the 16 clamped means (yarray) of the step are ready;
+// they meet the other planes' in LDS, where thread c interpolates column c of the strip (util.cpp:377-414).
+// Rows in which some cell has fewer than E valid members (rowflag) form count / valid per cell and count the valid
+// cells of every window; everywhere else the window counts are known from the geometry alone.
+#include "qf_box.h"
+
+#pragma clang fp contract(off)
+using namespace gpp;
+
+namespace {
+#define QB_SEG 16       // output columns per thread
+#define QB_SW 256       // output columns per workgroup (16 segments)
+#define QB_SH 64        // output rows per workgroup (plus 2 HW + 1 rows of run-in)
+
+__device__ __forceinline__ bool qb_nv(float v) { return !isnan(v) && !isinf(v); }
+
+// 8 * byte I of the dword array w (I is a constant after unrolling): one instruction, the byte offset of a table entry
+__device__ __forceinline__ unsigned qb_byte_x8(const unsigned (&w)[12], const int i) {
+    unsigned a;
+    const unsigned d = w[i >> 2];
+    switch(i & 3) {
+        case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(3u), "v"(d)); break;
+        case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(3u), "v"(d)); break;
+        case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(3u), "v"(d)); break;
+        default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(3u), "v"(d)); break;
+    }
+    return a;
+}
+__device__ __forceinline__ unsigned qb_byte(const unsigned (&w)[12], const int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; }
+// the table of doubles sits at LDS address 0 (checked at kernel entry): the byte offset is the address
+__device__ __forceinline__ double qb_tab(const unsigned a) { return *(const __attribute__((address_space(3))) double*)(size_t)a; }
+
+// the 16 window sums of one row of 16 + 2 HW values val(i), i = byte index in the 48-byte row (column x0 - 16 + i):
+// acc(j, sum of val over [16 - HW + j, 16 + HW + j]).  Blocks of BS <= 2 HW + 1 outputs share a pivot.
+template <int HW, class Val, class Acc>
+__device__ __forceinline__ void qb_windows(Val val, Acc acc) {
+    constexpr int W = 2 * HW + 1;
+    constexpr int BS = W >= 16 ? 16 : (W >= 8 ? 8 : (W >= 4 ? 4 : (W >= 2 ? 2 : 1)));
+    constexpr int a = 16 - HW, b = 16 + HW;
+#pragma unroll
+    for(int j0 = 0; j0 < QB_SEG; j0 += BS) {
+        const int m = a + j0 + BS - 1;   // first value of the block's last window: inside every window of the block
+        auto S = val(m);
+        acc(m - a, S);
+#pragma unroll
+        for(int i = m - 1; i >= a + j0; i--) { S += val(i); acc(i - a, S); }
+        if(b + j0 + BS - 1 > m) {
+            auto R = val(m + 1);
+            if(m + 1 >= b + j0) acc(m + 1 - b, R);
+#pragma unroll
+            for(int i = m + 2; i <= b + j0 + BS - 1; i++) { R += val(i); if(i >= b + j0) acc(i - b, R); }
+        }
+    }
+}
+
+__device__ float qb_interp(const float* __restrict__ ya, const int stride, const int T, const float* __restrict__ thr, const float x) {
+    bool missing = false;
+    for(int t = 0; t < T; t++) if(!qb_nv(ya[t * stride])) missing = true;
+    if(missing) return NAN;
+    const float y0a = ya[0], yLa = ya[(T - 1) * stride];
+    if(x == 1 && y0a == 1) return thr[0];                     // neighbourhood.cpp:508-513
+    if(x == 0 && yLa == 0) return thr[T - 1];
+    if(!qb_nv(x)) return NAN;                                  // interpolate(): util.cpp:378-379
+    if(x > yLa) return thr[T - 1];                             // util.cpp:386-389
+    if(x < y0a) return thr[0];
+    int i0 = -1, i1 = -1;                                      // get_lower_index / get_upper_index (util.cpp:339-376)
+    for(int i = 0; i < T; i++) { const float cv = ya[i * stride]; if(cv < x) i0 = i; else if(cv == x) { i0 = i; break; } else break; }
+    for(int i = T - 1; i >= 0; i--) { const float cv = ya[i * stride]; if(cv > x) i1 = i; else if(cv == x) { i1 = i; break; } else break; }
+    if(i0 < 0) i0 = 0;
+    if(i1 < 0) i1 = T - 1;
+    const float x0 = ya[i0 * stride], x1 = ya[i1 * stride], t0 = thr[i0], t1 = thr[i1];
+    if(x0 == x1) {
+        if(i0 == 0 && i1 == T - 1) return (t0 + t1) / 2;
+        if(i0 == 0) return t1;
+        if(i1 == T - 1) return t0;
+        return (t0 + t1) / 2;
+    }
+    return t0 + (t1 - t0) * (x - x0) / (x1 - x0);
+}
+
+// GENERAL = false: every cell of the field has E valid members (g.rowflag[Y] == 0, else the kernel returns at once);
+// GENERAL = true: the other case (returns at once when no row is flagged).  Both are launched, one of them works.
+template <int HW, bool GENERAL>
+__global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict__ cnt8, const QfGeom g, const int reps, const int T,
+                                                const float* __restrict__ thr, const float* __restrict__ q, const int qfield, float* __restrict__ out) {
+    extern __shared__ double qb_lds[];
+    double* const tab = qb_lds;                                             // [256] count -> (double)(float)(count / E); 255 -> 0
+    float* const sthr = reinterpret_cast<float*>(tab + 256);                // [16]
+    float* const ya = sthr + 16;                                            // [2][T][QB_SW] clamped means of the current / previous step
+    if((unsigned)(size_t)(__attribute__((address_space(3))) double*)qb_lds != 0u) __builtin_trap();   // see qb_tab()
+    if((g.rowflag[g.Y] != 0) != GENERAL) return;
+    const int tid = threadIdx.x;
+    const int p = tid >> 4, s = tid & 15;
+    const int X = g.X, Y = g.Y;
+    const int xs = blockIdx.x * QB_SW;                                      // first column of the strip
+    const int x0 = xs + s * QB_SEG;                                         // first column of this thread's segment
+    const int ybeg = blockIdx.y * QB_SH, yend = min(Y, ybeg + QB_SH);
+    const bool active = p < T && x0 < X;
+    for(int k = tid; k < 256; k += blockDim.x) tab[k] = (k <= reps) ? (double)((float)k / (float)reps) : 0.0;
+    if(tid < 16) sthr[tid] = tid < T ? thr[tid] : 0.0f;
+    __syncthreads();
+    // byte i of a loaded row = padded column x0 + i = field column x0 - 16 + i (QF_PADX == 16)
+    const unsigned char* const plane = cnt8 + (long)(active ? p : 0) * g.Pp + (active ? x0 : 0);
+    const unsigned char* const vplane = cnt8 + (long)T * g.Pp + (active ? x0 : 0);
+    auto load_row = [&](const unsigned char* base, const int y, unsigned (&w)[12]) __attribute__((always_inline)) {   // y = field row, or < -QF_PADY..: row 0 of the plane is padding
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4* rp = reinterpret_cast<const u4*>(base + (long)(y + QF_PADY) * g.Xp);
+#pragma unroll
+        for(int k = 0; k < 3; k++) { const u4 v = rp[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+    };
+    double V[QB_SEG];
+    int Vc[QB_SEG];
+#pragma unroll
+    for(int j = 0; j < QB_SEG; j++) { V[j] = 0.0; Vc[j] = 0; }
+    // the number of field columns in the window of column x (rows whose every cell has E valid members count their cells this way)
+    auto nxw = [&](const int j) __attribute__((always_inline)) { const int x = x0 + j; return min(x + HW, X - 1) - max(x - HW, 0) + 1; };
+    // one row of a flagged kind: count / valid per cell (neighbourhood.cpp:465-470), and the valid cells counted
+    auto flagged_row = [&](const int y, const int sign) __attribute__((always_inline)) {
+        unsigned b[12], v[12];
+        load_row(plane, y, b);
+        load_row(vplane, y, v);
+        const double sg = (double)sign;
+        qb_windows<HW>([&](const int i) {
+                           const unsigned cb = qb_byte(b, i), cv = qb_byte(v, i);
+                           const bool ok = (unsigned)(x0 - 16 + i) < (unsigned)X && cv > 0;
+                           return ok ? (double)((float)cb / (float)cv) : 0.0; },
+                       [&](const int j, const double S) { V[j] += sg * S; });
+        qb_windows<HW>([&](const int i) { return ((unsigned)(x0 - 16 + i) < (unsigned)X && qb_byte(v, i) > 0) ? 1 : 0; },
+                       [&](const int j, const int S) { Vc[j] += sign * S; });
+    };
+    auto plain_row = [&](const int y, const int sign) __attribute__((always_inline)) {   // every cell of the row has E valid members (or the row is outside the field: padding)
+        unsigned b[12];
+        load_row(plane, y, b);
+        const double sg = (double)sign;
+        qb_windows<HW>([&](const int i) { return qb_tab(qb_byte_x8(b, i)); }, [&](const int j, const double S) { V[j] += sg * S; });
+        if(y >= 0 && y < Y) {
+#pragma unroll
+            for(int j = 0; j < QB_SEG; j++) Vc[j] += sign * nxw(j);
+        }
+    };
+    // step: the window of rows moves from [y - HW - 1, y + HW - 1] to [y - HW, y + HW]
+    auto step = [&](const int yin, const int yout) __attribute__((always_inline)) {
+        const bool in_field = yin >= 0 && yin < Y, out_field = yout >= 0 && yout < Y;
+        bool fin = false, fout = false;
+        if constexpr (GENERAL) { fin = in_field && g.rowflag[yin] != 0; fout = out_field && g.rowflag[yout] != 0; }
+        if(!fin && !fout) {
+            unsigned bi[12], bo[12];
+            load_row(plane, yin, bi);
+            load_row(plane, out_field ? yout : -QF_PADY, bo);
+            qb_windows<HW>([&](const int i) { return qb_tab(qb_byte_x8(bi, i)) - qb_tab(qb_byte_x8(bo, i)); }, [&](const int j, const double S) { V[j] += S; });
+            if constexpr (GENERAL) {
+                if(in_field != out_field) {
+                    const int sign = in_field ? 1 : -1;
+#pragma unroll
+                    for(int j = 0; j < QB_SEG; j++) Vc[j] += sign * nxw(j);
+                }
+            }
+        }
+        else if constexpr (GENERAL) {
+            if(fin) flagged_row(yin, 1); else plain_row(yin, 1);
+            if(out_field) { if(fout) flagged_row(yout, -1); else plain_row(yout, -1); }
+        }
+    };
+    const float freps = (float)reps;
+    // run-in (y < ybeg): rows ybeg - HW .. ybeg + HW - 1 enter and nothing leaves; from ybeg on every step completes a row of output
+    for(int y = ybeg - 2 * HW; y < yend; y++) {
+        if(active) step(y + HW, y > ybeg ? y - HW - 1 : -QF_PADY - 1000000);
+        if(y < ybeg) continue;
+        float* const yab = ya + ((y - ybeg) & 1) * T * QB_SW;
+        if(active) {
+            // mean (:473), E-fold float sum / E (:494-499: `sum += value` E times), clamp (:500-506)
+            float o[QB_SEG], acc[QB_SEG];
+#pragma unroll
+            for(int j = 0; j < QB_SEG; j++) {
+                // (no flagged row: the window holds all the field cells it covers)
+                const int wc = GENERAL ? Vc[j] : nxw(j) * (min(y + HW, Y - 1) - max(y - HW, 0) + 1);
+                o[j] = wc > 0 ? (float)(V[j] / (double)wc) : NAN;
+                acc[j] = 0.0f;
+            }
+            if(reps > 1) {
+                for(int e = 0; e < reps; e++) {
+#pragma unroll
+                    for(int j = 0; j < QB_SEG; j++) acc[j] += o[j];
+                }
+            }
+#pragma unroll
+            for(int j = 0; j < QB_SEG; j++) {
+                float yv = reps > 1 ? acc[j] / freps : o[j];
+                yv = yv > 1 ? 1.0f : (yv < 0 ? 0.0f : yv);
+                yab[p * QB_SW + s * QB_SEG + j] = qb_nv(o[j]) ? yv : NAN;
+            }
+        }
+        __syncthreads();
+        for(int c = tid; c < QB_SW; c += blockDim.x) {
+            const int x = xs + c;
+            if(x < X) {
+                const long cell = (long)y * X + x;
+                out[cell] = qb_interp(yab + c, QB_SW, T, sthr, qfield ? q[cell] : q[0]);
+            }
+        }
+    }
+}
+
+template <int HW>
+void launch_hw(const unsigned char* cnt8, const QfGeom& g, int reps, int T, const float* d_thr, const float* d_q, int qfield, float* d_out) {
+    const int threads = 64 * ((T * 16 + 63) / 64);
+    const size_t lds = 256 * sizeof(double) + 16 * sizeof(float) + (size_t)2 * T * QB_SW * sizeof(float);
+    const dim3 grid((g.X + QB_SW - 1) / QB_SW, (g.Y + QB_SH - 1) / QB_SH);
+    hipLaunchKernelGGL((k_qf_box<HW, false>), grid, dim3(threads), lds, stream(), cnt8, g, reps, T, d_thr, d_q, qfield, d_out);
+    hipLaunchKernelGGL((k_qf_box<HW, true>), grid, dim3(threads), lds, stream(), cnt8, g, reps, T, d_thr, d_q, qfield, d_out);
+    GPP_HIP(hipGetLastError());
+}
+}   // namespace
+
+void qf_box_launch(const unsigned char* cnt8, const QfGeom& g, int reps, int hw, int T, const float* d_thr, const float* d_q, int qfield, float* d_out) {
+    switch(hw) {
+#define QB_CASE(n) case n: launch_hw<n>(cnt8, g, reps, T, d_thr, d_q, qfield, d_out); break;
+        QB_CASE(0) QB_CASE(1) QB_CASE(2) QB_CASE(3) QB_CASE(4) QB_CASE(5) QB_CASE(6) QB_CASE(7) QB_CASE(8)
+        QB_CASE(9) QB_CASE(10) QB_CASE(11) QB_CASE(12) QB_CASE(13) QB_CASE(14) QB_CASE(15) QB_CASE(16)
+#undef QB_CASE
+        default: runtime("Internal error. quantile_fast: halfwidth of the fused box pass");
+    }
+}
