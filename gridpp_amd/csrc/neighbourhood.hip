@@ -228,7 +228,9 @@ __global__ __launch_bounds__(64) void k_member_pass(const float* __restrict__ in
 //     floats), lanes = cells for the sums: only the rank bytes (E bytes per cell) cross the LDS.
 // -------------------------------------------------------------------------------------------
 #define QF_NB 256
+#ifndef QC_G
 #define QC_G 5     // float4 loads in flight per lane and group
+#endif
 struct QfLut {
     float scale, off;
     int U;          // distinct finite thresholds
@@ -301,7 +303,23 @@ __global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, l
     const float4* in4 = reinterpret_cast<const float4*>(in);
     const unsigned zero = 0;
     __syncthreads();
-    for(long tile = blockIdx.x; tile < nfull; tile += gridDim.x) {
+    const int ng = E4 / QC_G;
+    float4 cur[QC_G], nxt[QC_G];
+    // A workgroup takes super-tiles of four consecutive tiles (256 cells): the counts of a super-tile leave through an LDS
+    // buffer as one dword store per lane and plane (256 contiguous bytes per instruction instead of four times 64)
+    unsigned char* const obuf = reinterpret_cast<unsigned char*>(ranks + 16 * E);   // [T + 1][256]
+    const long nsuper = (nfull + 3) / 4;
+    if(ng > 0 && (long)blockIdx.x < nsuper) {
+        const float4* src0 = in4 + (long)blockIdx.x * 4 * 16 * E + lane;
+#pragma unroll
+        for(int i = 0; i < QC_G; i++) cur[i] = src0[i * 64];
+    }
+    for(long st = blockIdx.x; st < nsuper; st += gridDim.x) {
+      const int nsub = (int)min(4L, nfull - st * 4);
+      const bool buffered = nsub == 4 && (g.X & 3) == 0;
+      for(int sub = 0; sub < nsub; sub++) {
+        const long tile = st * 4 + sub;
+        const long next_tile = sub + 1 < nsub ? tile + 1 : (st + gridDim.x < nsuper ? (st + gridDim.x) * 4 : -1);
         const float4* src = in4 + tile * 16 * E + lane;
         // rank bytes of four members (one float4) -> ranks[k * 64 + lane]
         auto quad = [&](const float4 q, const int k) {
@@ -338,20 +356,20 @@ __global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, l
                          : "+v"(pk) : "v"(q.w), "v"(e3.x), "v"(e3.y), "v"(zero) : "vcc");
             ranks[k * 64 + lane] = pk;
         };
-        // whole groups of QC_G loads in flight: the next group is asked for before the current one is ranked
-        const int ng = E4 / QC_G;
-        float4 cur[QC_G], nxt[QC_G];
-        if(ng > 0) {
+        // whole groups of QC_G loads in flight: the next group is asked for before the current one is ranked, and the first
+        // group of the NEXT tile before the sums of this one (`cur` holds it: loaded before the loop for the first tile)
+        for(int g0 = 0; g0 < ng; g0++) {
+            if(g0 + 1 < ng) {
 #pragma unroll
-            for(int i = 0; i < QC_G; i++) cur[i] = src[i * 64];
-        }
-        for(int g = 0; g < ng; g++) {
-            if(g + 1 < ng) {
+                for(int i = 0; i < QC_G; i++) nxt[i] = src[((g0 + 1) * QC_G + i) * 64];
+            }
+            else if(next_tile >= 0) {
+                const float4* nsrc = in4 + next_tile * 16 * E + lane;
 #pragma unroll
-                for(int i = 0; i < QC_G; i++) nxt[i] = src[((g + 1) * QC_G + i) * 64];
+                for(int i = 0; i < QC_G; i++) nxt[i] = nsrc[i * 64];
             }
 #pragma unroll
-            for(int i = 0; i < QC_G; i++) quad(cur[i], g * QC_G + i);
+            for(int i = 0; i < QC_G; i++) quad(cur[i], g0 * QC_G + i);
 #pragma unroll
             for(int i = 0; i < QC_G; i++) cur[i] = nxt[i];
         }
@@ -381,26 +399,39 @@ __global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, l
         while(x >= g.X) { x -= g.X; y++; }
         unsigned char* o8 = out8 + (long)(y + QF_PADY) * g.Xp + x + QF_PADX;
         if(cum[NL - 2] != (unsigned)E) { g.rowflag[y] = 1; g.rowflag[g.Y] = 1; }
-        if(ident) {   // U == T == NL - 2
-#if defined(QC_ABL) && (QC_ABL & 4)   // timing experiment: one plane stored
-            unsigned acc = 0;
+        if(!ident) {   // thresholds not in ascending order: the counts change places through the (consumed) rank area
+            __syncthreads();
 #pragma unroll
-            for(int l = 0; l < NL - 1; l++) acc += cum[l];
-            o8[0] = (unsigned char)acc;
-#else
+            for(int l = 0; l < NL - 1; l++) ranks[l * 64 + lane] = cum[l];
+        }
+        if(buffered) {
+            if(ident) {   // U == T == NL - 2
+#pragma unroll
+                for(int l = 0; l < NL - 1; l++) obuf[l * 256 + sub * 64 + lane] = (unsigned char)cum[l];
+            }
+            else {
+                for(int t = 0; t < T; t++) obuf[t * 256 + sub * 64 + lane] = (unsigned char)ranks[L->rank[t] * 64 + lane];
+                obuf[T * 256 + sub * 64 + lane] = (unsigned char)cum[NL - 2];
+            }
+        }
+        else if(ident) {
 #pragma unroll
             for(int l = 0; l < NL - 1; l++) o8[(long)l * g.Pp] = (unsigned char)cum[l];
-#endif
         }
-        else {   // thresholds not in ascending order: the counts change places through the (consumed) rank area
-            __syncthreads();
-            unsigned* const xch = ranks;
-#pragma unroll
-            for(int l = 0; l < NL - 1; l++) xch[l * 64 + lane] = cum[l];
-            for(int t = 0; t < T; t++) o8[(long)t * g.Pp] = (unsigned char)xch[L->rank[t] * 64 + lane];
+        else {
+            for(int t = 0; t < T; t++) o8[(long)t * g.Pp] = (unsigned char)ranks[L->rank[t] * 64 + lane];
             o8[(long)T * g.Pp] = (unsigned char)cum[NL - 2];
         }
         __syncthreads();   // the rank bytes are consumed
+      }
+      if(buffered) {   // lane l: cells 4 l .. 4 l + 3 of the super-tile (one row: X is a multiple of 4), every plane
+          int y = (int)((st * 256) / g.X), x = (int)(st * 256 - (long)y * g.X) + 4 * lane;
+          while(x >= g.X) { x -= g.X; y++; }
+          unsigned char* o8 = out8 + (long)(y + QF_PADY) * g.Xp + x + QF_PADX;
+          const unsigned* ob4 = reinterpret_cast<const unsigned*>(obuf);
+          for(int t = 0; t <= T; t++) *reinterpret_cast<unsigned*>(o8 + (long)t * g.Pp) = ob4[t * 64 + lane];
+          __syncthreads();
+      }
     }
     // the last, partial tile (if any): lane-private walk straight from memory, on block 0
     if(nfull * 64 < C && blockIdx.x == 0) {
@@ -768,9 +799,9 @@ void member_pass(const float* d_in, long C, int E, int mode, int statistic, cons
 // byte counts of quantile_fast by ranks (k_qf_count<U + 2>)
 template <int NL>
 void qf_count_launch_nl(const float* d_in, long C, int E, const float* d_thr, int T, const QfLut* lut, unsigned char* cnt8, const QfGeom& g) {
-    const size_t lds = (size_t)(2 * QF_NB + std::max(16 * E, NL * 64)) * sizeof(unsigned);
+    const size_t lds = (size_t)(2 * QF_NB + std::max(16 * E, NL * 64)) * sizeof(unsigned) + (size_t)(T + 1) * 256;
     const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(24, (160 * 1024) / lds));
-    const long grid = std::max<long>(1, std::min<long>(C / 64, (long)256 * waves_per_cu));
+    const long grid = std::max<long>(1, std::min<long>((C / 64 + 3) / 4, (long)256 * waves_per_cu));
     hipLaunchKernelGGL((k_qf_count<NL>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, d_thr, T, lut, cnt8, g);
     GPP_HIP(hipGetLastError());
 }

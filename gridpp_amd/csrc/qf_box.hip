@@ -17,19 +17,22 @@
 // Rows in which some cell has fewer than E valid members (rowflag) form count / valid per cell and count the valid
 // cells of every window; everywhere else the window counts are known from the geometry alone.
 #include "qf_box.h"
+#include <algorithm>
+#include <numeric>
 
 #pragma clang fp contract(off)
 using namespace gpp;
 
 namespace {
-#define QB_SEG 16       // output columns per thread
-#define QB_SW 256       // output columns per workgroup (16 segments)
+#define QB_SEG 8        // output columns per thread
+#define QB_NDW ((QB_SEG + 32) / 4)   // dwords of a row a thread reads: its columns and 16 on either side
+#define QB_SW 256       // output columns per workgroup (32 segments)
 #define QB_SH 64        // output rows per workgroup (plus 2 HW + 1 rows of run-in)
 
 __device__ __forceinline__ bool qb_nv(float v) { return !isnan(v) && !isinf(v); }
 
 // 8 * byte I of the dword array w (I is a constant after unrolling): one instruction, the byte offset of a table entry
-__device__ __forceinline__ unsigned qb_byte_x8(const unsigned (&w)[12], const int i) {
+__device__ __forceinline__ unsigned qb_byte_x8(const unsigned (&w)[QB_NDW], const int i) {
     unsigned a;
     const unsigned d = w[i >> 2];
     switch(i & 3) {
@@ -40,7 +43,7 @@ __device__ __forceinline__ unsigned qb_byte_x8(const unsigned (&w)[12], const in
     }
     return a;
 }
-__device__ __forceinline__ unsigned qb_byte(const unsigned (&w)[12], const int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; }
+__device__ __forceinline__ unsigned qb_byte(const unsigned (&w)[QB_NDW], const int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; }
 // the table of doubles sits at LDS address 0 (checked at kernel entry): the byte offset is the address
 __device__ __forceinline__ double qb_tab(const unsigned a) { return *(const __attribute__((address_space(3))) double*)(size_t)a; }
 
@@ -49,7 +52,7 @@ __device__ __forceinline__ double qb_tab(const unsigned a) { return *(const __at
 template <int HW, class Val, class Acc>
 __device__ __forceinline__ void qb_windows(Val val, Acc acc) {
     constexpr int W = 2 * HW + 1;
-    constexpr int BS = W >= 16 ? 16 : (W >= 8 ? 8 : (W >= 4 ? 4 : (W >= 2 ? 2 : 1)));
+    constexpr int BS = W >= QB_SEG ? QB_SEG : (W >= 4 ? 4 : (W >= 2 ? 2 : 1));
     constexpr int a = 16 - HW, b = 16 + HW;
 #pragma unroll
     for(int j0 = 0; j0 < QB_SEG; j0 += BS) {
@@ -95,8 +98,8 @@ __device__ float qb_interp(const float* __restrict__ ya, const int stride, const
 // GENERAL = false: every cell of the field has E valid members (g.rowflag[Y] == 0, else the kernel returns at once);
 // GENERAL = true: the other case (returns at once when no row is flagged).  Both are launched, one of them works.
 template <int HW, bool GENERAL>
-__global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict__ cnt8, const QfGeom g, const int reps, const int T,
-                                                const float* __restrict__ thr, const float* __restrict__ q, const int qfield, float* __restrict__ out) {
+__global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict__ cnt8, const QfGeom g, const int reps, const int T,
+                                                const float* __restrict__ thr, const float* __restrict__ q, const int qfield, float* __restrict__ out, const int SH) {
     extern __shared__ double qb_lds[];
     double* const tab = qb_lds;                                             // [256] count -> (double)(float)(count / E); 255 -> 0
     float* const sthr = reinterpret_cast<float*>(tab + 256);                // [16]
@@ -104,11 +107,11 @@ __global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict_
     if((unsigned)(size_t)(__attribute__((address_space(3))) double*)qb_lds != 0u) __builtin_trap();   // see qb_tab()
     if((g.rowflag[g.Y] != 0) != GENERAL) return;
     const int tid = threadIdx.x;
-    const int p = tid >> 4, s = tid & 15;
+    const int p = tid / (QB_SW / QB_SEG), s = tid % (QB_SW / QB_SEG);
     const int X = g.X, Y = g.Y;
     const int xs = blockIdx.x * QB_SW;                                      // first column of the strip
     const int x0 = xs + s * QB_SEG;                                         // first column of this thread's segment
-    const int ybeg = blockIdx.y * QB_SH, yend = min(Y, ybeg + QB_SH);
+    const int ybeg = blockIdx.y * SH, yend = min(Y, ybeg + SH);
     const bool active = p < T && x0 < X;
     for(int k = tid; k < 256; k += blockDim.x) tab[k] = (k <= reps) ? (double)((float)k / (float)reps) : 0.0;
     if(tid < 16) sthr[tid] = tid < T ? thr[tid] : 0.0f;
@@ -116,11 +119,11 @@ __global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict_
     // byte i of a loaded row = padded column x0 + i = field column x0 - 16 + i (QF_PADX == 16)
     const unsigned char* const plane = cnt8 + (long)(active ? p : 0) * g.Pp + (active ? x0 : 0);
     const unsigned char* const vplane = cnt8 + (long)T * g.Pp + (active ? x0 : 0);
-    auto load_row = [&](const unsigned char* base, const int y, unsigned (&w)[12]) __attribute__((always_inline)) {   // y = field row, or < -QF_PADY..: row 0 of the plane is padding
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        const u4* rp = reinterpret_cast<const u4*>(base + (long)(y + QF_PADY) * g.Xp);
+    auto load_row = [&](const unsigned char* base, const int y, unsigned (&w)[QB_NDW]) __attribute__((always_inline)) {   // y = field row, or < -QF_PADY..: row 0 of the plane is padding
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));   // (a segment starts on a multiple of 8 columns)
+        const u2* rp = reinterpret_cast<const u2*>(base + (long)(y + QF_PADY) * g.Xp);
 #pragma unroll
-        for(int k = 0; k < 3; k++) { const u4 v = rp[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+        for(int k = 0; k < QB_NDW / 2; k++) { const u2 v = rp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
     };
     double V[QB_SEG];
     int Vc[QB_SEG];
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict_
     auto nxw = [&](const int j) __attribute__((always_inline)) { const int x = x0 + j; return min(x + HW, X - 1) - max(x - HW, 0) + 1; };
     // one row of a flagged kind: count / valid per cell (neighbourhood.cpp:465-470), and the valid cells counted
     auto flagged_row = [&](const int y, const int sign) __attribute__((always_inline)) {
-        unsigned b[12], v[12];
+        unsigned b[QB_NDW], v[QB_NDW];
         load_row(plane, y, b);
         load_row(vplane, y, v);
         const double sg = (double)sign;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict_
                        [&](const int j, const int S) { Vc[j] += sign * S; });
     };
     auto plain_row = [&](const int y, const int sign) __attribute__((always_inline)) {   // every cell of the row has E valid members (or the row is outside the field: padding)
-        unsigned b[12];
+        unsigned b[QB_NDW];
         load_row(plane, y, b);
         const double sg = (double)sign;
         qb_windows<HW>([&](const int i) { return qb_tab(qb_byte_x8(b, i)); }, [&](const int j, const double S) { V[j] += sg * S; });
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict_
         bool fin = false, fout = false;
         if constexpr (GENERAL) { fin = in_field && g.rowflag[yin] != 0; fout = out_field && g.rowflag[yout] != 0; }
         if(!fin && !fout) {
-            unsigned bi[12], bo[12];
+            unsigned bi[QB_NDW], bo[QB_NDW];
             load_row(plane, yin, bi);
             load_row(plane, out_field ? yout : -QF_PADY, bo);
             qb_windows<HW>([&](const int i) { return qb_tab(qb_byte_x8(bi, i)) - qb_tab(qb_byte_x8(bo, i)); }, [&](const int j, const double S) { V[j] += S; });
@@ -175,23 +178,44 @@ __global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict_
             if(out_field) { if(fout) flagged_row(yout, -1); else plain_row(yout, -1); }
         }
     };
-    const float freps = (float)reps;
+    const double rreps = 1.0 / (double)reps;
+    const bool xfull = x0 - HW >= 0 && x0 + QB_SEG - 1 + HW <= X - 1;   // every window of the segment lies inside the field's columns
     // run-in (y < ybeg): rows ybeg - HW .. ybeg + HW - 1 enter and nothing leaves; from ybeg on every step completes a row of output
     for(int y = ybeg - 2 * HW; y < yend; y++) {
-        if(active) step(y + HW, y > ybeg ? y - HW - 1 : -QF_PADY - 1000000);
+        if(active) {
+            step(y + HW, y > ybeg ? y - HW - 1 : -QF_PADY - 1000000);
+        }
         if(y < ybeg) continue;
         float* const yab = ya + ((y - ybeg) & 1) * T * QB_SW;
         if(active) {
             // mean (:473), E-fold float sum / E (:494-499: `sum += value` E times), clamp (:500-506)
             float o[QB_SEG], acc[QB_SEG];
+            const int nyw = min(y + HW, Y - 1) - max(y - HW, 0) + 1;
+            if(!GENERAL && xfull) {
+                // every window of the segment holds (2 HW + 1) * nyw cells: ONE division per step, then per cell
+                // q = V * r, corrected by the exact residual (q' = q + (V - q wc) r).  V / wc is a multiple of 2^-33 / wc away from
+                // every float32 rounding boundary or exactly on it, and q' is within an ulp(double) of it and exact when V / wc is
+                // representable: (float)q' is the float the double division rounds to.
+                const double wcd = (double)((2 * HW + 1) * nyw), r = 1.0 / wcd;
 #pragma unroll
-            for(int j = 0; j < QB_SEG; j++) {
-                // (no flagged row: the window holds all the field cells it covers)
-                const int wc = GENERAL ? Vc[j] : nxw(j) * (min(y + HW, Y - 1) - max(y - HW, 0) + 1);
-                o[j] = wc > 0 ? (float)(V[j] / (double)wc) : NAN;
-                acc[j] = 0.0f;
+                for(int j = 0; j < QB_SEG; j++) {
+                    const double q0 = V[j] * r;
+                    o[j] = (float)__builtin_fma(__builtin_fma(-q0, wcd, V[j]), r, q0);
+                    acc[j] = 0.0f;
+                }
+            }
+            else {
+#pragma unroll
+                for(int j = 0; j < QB_SEG; j++) {
+                    // (no flagged row: the window holds all the field cells it covers)
+                    const int wc = GENERAL ? Vc[j] : nxw(j) * nyw;
+                    o[j] = (float)(V[j] / (double)max(wc, 1));
+                    if(wc <= 0) o[j] = NAN;
+                    acc[j] = 0.0f;
+                }
             }
             if(reps > 1) {
+#pragma unroll 2
                 for(int e = 0; e < reps; e++) {
 #pragma unroll
                     for(int j = 0; j < QB_SEG; j++) acc[j] += o[j];
@@ -199,7 +223,9 @@ __global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict_
             }
 #pragma unroll
             for(int j = 0; j < QB_SEG; j++) {
-                float yv = reps > 1 ? acc[j] / freps : o[j];
+                // acc / E through the double reciprocal: exact for E < 2^8 (acc / E can neither hit nor come within 2^-41 of a float32
+                // rounding boundary, the double product is within 2^-52 of it)
+                float yv = reps > 1 ? (float)((double)acc[j] * rreps) : o[j];
                 yv = yv > 1 ? 1.0f : (yv < 0 ? 0.0f : yv);
                 yab[p * QB_SW + s * QB_SEG + j] = qb_nv(o[j]) ? yv : NAN;
             }
@@ -217,11 +243,16 @@ __global__ __launch_bounds__(256) void k_qf_box(const unsigned char* __restrict_
 
 template <int HW>
 void launch_hw(const unsigned char* cnt8, const QfGeom& g, int reps, int T, const float* d_thr, const float* d_q, int qfield, float* d_out) {
-    const int threads = 64 * ((T * 16 + 63) / 64);
+    const int threads = 64 * ((T * (QB_SW / QB_SEG) + 63) / 64);
     const size_t lds = 256 * sizeof(double) + 16 * sizeof(float) + (size_t)2 * T * QB_SW * sizeof(float);
-    const dim3 grid((g.X + QB_SW - 1) / QB_SW, (g.Y + QB_SH - 1) / QB_SH);
-    hipLaunchKernelGGL((k_qf_box<HW, false>), grid, dim3(threads), lds, stream(), cnt8, g, reps, T, d_thr, d_q, qfield, d_out);
-    hipLaunchKernelGGL((k_qf_box<HW, true>), grid, dim3(threads), lds, stream(), cnt8, g, reps, T, d_thr, d_q, qfield, d_out);
+    // rows per workgroup: about QB_SH, chosen so that the workgroups fill the 256 CUs a whole number of times
+    const int strips = (g.X + QB_SW - 1) / QB_SW;
+    int segs = std::max(1, (g.Y + QB_SH - 1) / QB_SH);
+    if(strips * segs > 256) { const int per = 256 / std::__gcd(256, strips); segs = (segs + per - 1) / per * per; }
+    const int SH = std::max(1, (g.Y + segs - 1) / segs);
+    const dim3 grid(strips, (g.Y + SH - 1) / SH);
+    hipLaunchKernelGGL((k_qf_box<HW, false>), grid, dim3(threads), lds, stream(), cnt8, g, reps, T, d_thr, d_q, qfield, d_out, SH);
+    hipLaunchKernelGGL((k_qf_box<HW, true>), grid, dim3(threads), lds, stream(), cnt8, g, reps, T, d_thr, d_q, qfield, d_out, SH);
     GPP_HIP(hipGetLastError());
 }
 }   // namespace
