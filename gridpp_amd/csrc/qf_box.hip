@@ -27,7 +27,9 @@ namespace {
 #define QB_SEG 8        // output columns per thread
 #define QB_NDW ((QB_SEG + 32) / 4)   // dwords of a row a thread reads: its columns and 16 on either side
 #define QB_SW 256       // output columns per workgroup (32 segments)
+#ifndef QB_SH
 #define QB_SH 64        // output rows per workgroup (plus 2 HW + 1 rows of run-in)
+#endif
 
 __device__ __forceinline__ bool qb_nv(float v) { return !isnan(v) && !isinf(v); }
 
@@ -214,7 +216,17 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
                     acc[j] = 0.0f;
                 }
             }
-            if(reps > 1) {
+            // (a wave whose means are all 0 or 1 -- a threshold below or above everything in sight -- has nothing to add up:
+            //  E * 0 and E * 1 are exact, and so is every partial sum)
+            bool plain01 = true;
+#pragma unroll
+            for(int j = 0; j < QB_SEG; j++) plain01 = plain01 && (o[j] == 0.0f || o[j] == 1.0f);
+            const bool skip = __all(plain01);
+            if(skip) {
+#pragma unroll
+                for(int j = 0; j < QB_SEG; j++) acc[j] = o[j] * (float)reps;
+            }
+            else if(reps > 1) {
 #pragma unroll 2
                 for(int e = 0; e < reps; e++) {
 #pragma unroll
