@@ -11,9 +11,9 @@ Inputs are synthetic (seed 1002) and resident in HBM (torch CUDA t
 C-ABI as device pointers) when the timed region starts.
 
 The ONE JSON line of rank 0 carries, besides the contract keys:
-  roofline          HBM view of the dominant kernel (algorithmic 24 B/cell over its HIP-event duration)
-  roofline_compute  the bound that actually binds OI: VALU issue (wave-instructions per launch from the committed
-                    rocprofv3 PMC pass over the live kernel time, against 1024 SIMDs x one instruction per 4 cycles)
+  roofline          HBM view of the dominant kernel (algorithmic 28 B/cell over its HIP-event duration)
+  roofline_compute  the bound that actually binds OI: VALU issue (FP64 and other VALU wave-instructions per launch from the
+                    committed rocprofv3 PMC bundle, 4 and 2 issue cycles each, over the live kernel time and 1024 SIMDs)
   host_inclusive    the same call from numpy buffers (PCIe both ways; never `value`)
   other_configs     the other BASELINE.json configs with the same per-step fields (N = 1 only)
   cpu_baseline      the oracle's OpenMP / cell-list build of the same loop on this box's host cores (1 thread and all threads)
@@ -33,9 +33,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from tools.bench_cases import make_workload, HBM_PEAK, FP64_PEAK  # noqa: E402
 
-BYTES_PER_CELL = 24   # read lat,lon,elev,laf,background (5x4 B) + write analysis (4 B)
+BYTES_PER_CELL = 28   # SURVEY.md 8(d), the x/y/z form: the kernel reads x, y, z, elev, laf, background (6 x 4 B) and writes the analysis (4 B)
 HBM_PEAK_GBS = HBM_PEAK / 1e9
-SIMDS, CLOCK_HZ = 1024, 2.4e9   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; one VALU wave-instruction per 4 cycles per SIMD
+# MI355X_MICROARCH.md "Wave scheduling": 256 CUs x 4 SIMD-32 at 2.4 GHz; a wave64 VALU instruction issues over 2 cycles,
+# an FP64 one over 4 (vector FP64 peak = half the FP32 peak)
+SIMDS, CLOCK_HZ, CYC_VALU, CYC_FP64 = 1024, 2.4e9, 2.0, 4.0
+
+
+def host_cpu_info():
+    """what this process may use of the host: affinity mask and cgroup quota (os.cpu_count() is the machine, not the lease)"""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["sched_getaffinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["sched_getaffinity"] = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    quota = None if q < 0 else q / float(f2.read().split()[0])
+            info["cgroup_cpu_quota_cores"] = quota
+            info["cgroup_source"] = path
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return info
 
 
 def cpu_baseline(ny, nx, S, seed, h, max_points, target_s=12.0):
@@ -44,7 +72,11 @@ def cpu_baseline(ny, nx, S, seed, h, max_points, target_s=12.0):
     box's host cores on a bounded sample of the same workload: every k-th grid row."""
     from oracle import oracle as O
     lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, S, seed, 0, ny)
-    threads = max(1, min(os.cpu_count() or 1, O.omp_max_threads()))
+    hw = host_cpu_info()
+    usable = hw.get("sched_getaffinity") or os.cpu_count() or 1
+    if hw.get("cgroup_cpu_quota_cores"):
+        usable = max(1, min(usable, int(hw["cgroup_cpu_quota_cores"])))
+    threads = max(1, min(usable, O.omp_max_threads()))
     op = O.Pts(plat, plon)
     st = O.Barnes(h)
 
@@ -67,7 +99,7 @@ def cpu_baseline(ny, nx, S, seed, h, max_points, target_s=12.0):
     nall = max(2, min(ny, int(0.6 * target_s * (cc / tc) / nx)))
     ca, ta = run(nall, threads)
     return {"value": ca / ta, "unit": "cells/s", "cores": threads, "kind": "port",
-            "one_thread_value": one,
+            "one_thread_value": one, "host": hw, "scaling_over_threads": (ca / ta) / one,
             "sample": "%d of %d grid rows (%d cells) of the same workload on %d threads in %.1f s; 1 thread: %d rows in %.1f s"
                       % (ca // nx, ny, ca, threads, ta, c1 // nx, t1),
             "algorithm": "cell-list radius query + per-point double inverse, OpenMP dynamic schedule (oracle/gridpp_oracle.c:orc_oi_full_omp)"}
@@ -104,6 +136,13 @@ def main():
     import torch
     import gridpp_amd as gridpp
     from gridpp_amd import dist as gdist
+
+    # GPP_* variables select implementations inside the library (tests, A/B timing): a benchmark line must not carry any.
+    # (GPP_BENCH_* are this script's own: the N > 1 logic test on a one-GPU box; they are recorded in the line.)
+    overrides = gridpp.active_overrides()
+    lib_overrides = [o for o in overrides if not o.startswith("GPP_BENCH_")]
+    if lib_overrides:
+        raise SystemExit("bench.py: library overrides are set in the environment: %s -- unset them" % ", ".join(lib_overrides))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -241,6 +280,9 @@ def main():
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "parallelism": par if world > 1 else "1 GPU",
                        "inputs": "resident in HBM (device pointers through the C-ABI)"},
+            "n_ranks_seen": {"env_WORLD_SIZE": world, "torch_distributed": (dist.get_world_size() if dist is not None else 1),
+                             "backend": (backend if dist is not None else None)},
+            "env_overrides": overrides,
         }
         if case == "oi":
             stats = gridpp.oi_last_stats()
@@ -253,16 +295,28 @@ def main():
             prof = pmc_profile(workload, world)
             res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": prof["traffic_bytes"] if prof else None,
-                               "note": "OI is instruction-issue-bound by construction (observations stay on-chip): see roofline_compute; algorithmic bytes = 24 B/cell; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/)"}
+                               "note": "OI is instruction-issue-bound by construction (observations stay on-chip): see roofline_compute; algorithmic bytes = 28 B/cell (x, y, z, elev, laf, background read; analysis written); traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/)"}
             if prof and "SQ_INSTS_VALU" in prof:
-                peak = SIMDS * CLOCK_HZ / 4.0
-                ach = prof["SQ_INSTS_VALU"] / (k_ms * 1e-3)
-                res["roofline_compute"] = {"bound": "valu_issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
-                                           "frac": ach / peak, "valu_wave_instructions_per_launch": prof["SQ_INSTS_VALU"],
+                # issue cycles = FP64 instructions x 4 + the other VALU instructions x 2, against every SIMD issuing every cycle
+                valu = prof["SQ_INSTS_VALU"]
+                fp64 = prof.get("SQ_INSTS_VALU_FP64")      # ADD_F64 + MUL_F64 + FMA_F64 + TRANS_F64 of the same PMC bundle
+                t = k_ms * 1e-3
+                if fp64 is None:   # (a bundle without the FP64 counters: the true figure lies between the two bounds)
+                    cyc_lo, cyc_hi = valu * CYC_VALU, valu * CYC_FP64
+                    frac = cyc_lo / (SIMDS * CLOCK_HZ * t)
+                else:
+                    cyc_lo = cyc_hi = fp64 * CYC_FP64 + (valu - fp64) * CYC_VALU
+                    frac = cyc_lo / (SIMDS * CLOCK_HZ * t)
+                res["roofline_compute"] = {"bound": "valu_issue", "unit": "SIMD issue cycles", "achieved": cyc_lo / t / 1e9, "peak": SIMDS * CLOCK_HZ / 1e9,
+                                           "achieved_unit": "G issue cycles/s", "frac": frac,
+                                           "frac_bounds": [cyc_lo / (SIMDS * CLOCK_HZ * t), cyc_hi / (SIMDS * CLOCK_HZ * t)],
+                                           "valu_wave_instructions_per_launch": valu, "fp64_wave_instructions_per_launch": fp64,
                                            "salu_wave_instructions_per_launch": prof.get("SQ_INSTS_SALU"),
                                            "lds_wave_instructions_per_launch": prof.get("SQ_INSTS_LDS"),
-                                           "instructions_per_cell": (prof["SQ_INSTS_VALU"] + prof.get("SQ_INSTS_SALU", 0) + prof.get("SQ_INSTS_LDS", 0)) * 64.0 / cells_rank / 64.0,
-                                           "note": "VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, profiles/) over the live kernel time, against 1024 SIMDs issuing one per 4 cycles at 2.4 GHz"}
+                                           "instructions_per_cell": (valu + prof.get("SQ_INSTS_SALU", 0) + prof.get("SQ_INSTS_LDS", 0)) / cells_rank,
+                                           "source": "committed_profile", "profile": prof.get("_source", "profiles/hbm_traffic.json"),
+                                           "note": "counters per launch from the committed rocprofv3 PMC bundle of this workload (not re-measured in this run) over the live kernel time; "
+                                                   "cycles per wave64 instruction: 2 (FP32 / integer VALU), 4 (FP64), MI355X_MICROARCH.md; frac = sum(instructions x cycles) / (1024 SIMDs x 2.4 GHz x t)"}
             res["kernel"] = {"name": k_name, "avg_ms": k_ms, "all_oi_kernels_ms": all_ms, "cells_per_launch": cells_rank,
                              "factorisations_per_launch": stats["solves"], "cells_updated": stats["cells_updated"],
                              "tiles_declined_by_first_pass": stats["fallback_tiles"], "subtiles_left_to_k_oi": stats["fallback_subtiles"]}
@@ -274,11 +328,14 @@ def main():
                                "traffic": None, "note": "algorithmic bytes = %d B/cell" % bpc}
             res["kernel"] = {"avg_ms": k_ms, "cells_per_launch": cells_rank}
             if case == "ensi":
-                E, n = 50, args.max_points
-                flops = cells_rank * (2.0 * n * E * E + 10.0 * E ** 3 + 2.0 * E * E * n)
-                res["roofline_compute"] = {"bound": "fp64", "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
-                                           "frac": flops / (k_ms * 1e-3) / FP64_PEAK,
-                                           "note": "flops by SURVEY.md 8(d)'s count of the reference's E x E formulation (2nE^2 + 10E^3 + 2E^2n per cell); the kernel solves an n x n problem instead"}
+                from tools.bench_cases import ensi_fp64
+                f64 = ensi_fp64(ny, nx, 50, S, args.max_points, k_ms) if world == 1 else {}
+                if "fp64_TFLOPs_executed" in f64:
+                    res["roofline_compute"] = {"bound": "fp64", "achieved": f64["fp64_TFLOPs_executed"], "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
+                                               "frac": f64["frac_fp64_peak_executed"], "source": f64["fp64_source"],
+                                               "reference_formulation_TFLOPs_equivalent": f64["reference_formulation_TFLOPs_equivalent"],
+                                               "note": "EXECUTED FP64 flops (vector ADD / MUL / FMA + MFMA-F64) per call from the committed PMC bundle over the live kernel time; "
+                                                       "the reference's E x E count is kept only as a labelled equivalent"}
         if world == 1 and case == "oi":
             # the same call from numpy buffers (GPP_MEM_HOST): PCIe both ways included -- reported, never `value`
             hl, hlo, hbg, hplat, hplon, hobs, hrat, hpbg = make_workload(ny, nx, S, seed, 0, ny)

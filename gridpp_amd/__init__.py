@@ -624,8 +624,9 @@ class MultipleStructure(StructureFunction):
         sh, sv, sw = structure_h._s, structure_v._s, structure_w._s
         kv = sv.kind_v - 1 if sv.kind_v else sv.kind
         kw = sw.kind_w - 1 if sw.kind_w else sw.kind
-        if sv.kind_v or sv.kind_w or sw.kind_v or sw.kind_w or sh.kind_v or sh.kind_w:
-            raise RuntimeError("a MultipleStructure inside a MultipleStructure is not on the GPU path")
+        # A component may itself be a MultipleStructure (the reference simply delegates, structure.cpp:90-138): structure_h then
+        # contributes its horizontal part, structure_v the vertical part of ITS vertical component (kind_v, v, field_v) and
+        # structure_w the laf part of its laf component.
         # spatially varying parts: the horizontal scale (and the localization distance) from structure_h's field, the vertical
         # scale from structure_v's, the laf scale from structure_w's (each at the nearest point of ITS grid to the first point)
         self._field_owner = [getattr(t, "_field_owner", None) for t in (structure_h, structure_v, structure_w)]
@@ -633,7 +634,9 @@ class MultipleStructure(StructureFunction):
             loc, flags = 0.0, 0
         else:
             loc, flags = structure_h.localization_distance(), _ST_HAS_LOC
-        self._s = _capi.gpp_structure(sh.kind, sh.h, sv.v, sw.w, sh.min_rho, kv + 1, kw + 1, loc, 0.0, flags, sh.field, sv.field, sw.field)
+        fv = sv.field_v if sv.kind_v else sv.field
+        fw = sw.field_w if sw.kind_w else sw.field
+        self._s = _capi.gpp_structure(sh.kind, sh.h, sv.v, sw.w, sh.min_rho, kv + 1, kw + 1, loc, 0.0, flags, sh.field, fv, fw)
 
 
 class CrossValidation(StructureFunction):
@@ -1295,6 +1298,24 @@ def ensi_last_kernel_ms():
     ms = C.c_float(0)
     check(lib().gpp_ensi_last_kernel_ms(C.byref(ms)))
     return ms.value
+
+
+def ensi_set_convergence(to_convergence):
+    """True: the per-cell Jacobi sweeps of optimal_interpolation_ensi run to convergence (about twice the time);
+    False (default): they stop early and a perturbation series supplies the rest."""
+    check(lib().gpp_ensi_set_convergence(1 if to_convergence else 0))
+
+
+def active_overrides():
+    """Names of the GPP_* environment variables that are set (they select implementations, never results)."""
+    buf = C.create_string_buffer(4096)
+    n = lib().gpp_active_overrides(buf, len(buf))
+    return [s for s in buf.value.decode().split(",") if s] if n > 0 else []
+
+
+def release_workspaces():
+    """Frees the large device workspaces this thread keeps between calls."""
+    check(lib().gpp_release_workspaces())
 
 
 # ---- the typemap test helpers of the reference (src/api/swig.cpp:6-100, include/gridpp.h:1680-1702): they exist so that

@@ -73,6 +73,9 @@ SIGNATURES = {
     "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
     "gpp_optimal_interpolation_ensi": [vp, vp, C.c_int, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],
     "gpp_ensi_last_kernel_ms": [fp],
+    "gpp_ensi_set_convergence": [C.c_int],
+    "gpp_active_overrides": [C.c_char_p, C.c_int],
+    "gpp_release_workspaces": [],
     "gpp_row_tile": [C.c_int, C.c_int, C.c_int, ip, ip],
     "gpp_comm_unique_id": [C.c_char_p],
     "gpp_comm_init": [C.c_int, C.c_int, C.c_char_p],

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -38,6 +39,22 @@ int fail(int code, const char* fmt, ...);
 [[noreturn]] inline void invalid(const std::string& m) { throw Error{GPP_EINVAL, m}; }
 [[noreturn]] inline void runtime(const std::string& m) { throw Error{GPP_ERUNTIME, m}; }
 
+// ---- switches --------------------------------------------------------------
+// timing_env(): environment switches that SKIP work, print statistics or change accuracy (GPP_OI_DEBUG, GPP_ENSI_DEBUG,
+// GPP_SCAN_STATS, GPP_ENSI_STATS) exist only in diagnostic builds (-DGPP_TIMING_SWITCHES, tools/variant.sh): the product
+// library never reads them and GPP_DBG() is the constant 0 there.
+// path_env(): switches that choose between implementations returning the same results (tests force the rarely taken paths
+// with them, A/B timings compare them).  gpp_active_overrides() lists every GPP_* variable of the environment; bench.py
+// refuses to run with any of them set.
+#ifdef GPP_TIMING_SWITCHES
+inline const char* timing_env(const char* n) { return getenv(n); }
+#define GPP_DBG(a, bits) ((a).debug & (bits))
+#else
+inline const char* timing_env(const char*) { return nullptr; }
+#define GPP_DBG(a, bits) 0
+#endif
+inline const char* path_env(const char* n) { return getenv(n); }
+
 // ---- device runtime ----------------------------------------------------------
 hipStream_t stream();   // library stream (created on first use, after the device is chosen)
 void ensure_device();   // throws GPP_ENODEVICE when no GPU is visible
@@ -60,6 +77,10 @@ struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
             cap = n;
         }
         return p;
+    }
+    void release() {
+        if(p) (void)hipFree(p);
+        p = nullptr; cap = 0;
     }
     void upload(const T* h, size_t n) {
         get(n);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
                 // selections, parked in HBM, re-read by the others (B = (sD sD^T) o (Y Y^T) differs per cell through sD)
                 if(warm) acc = __hip_atomic_load(&gram[i * n + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else {
-                    if(!(a.debug & 4)) for(int k = 0; k < nV; ++k) acc = __builtin_fma((double)Yt[i][k], (double)Yt[j][k], acc);
+                    if(!GPP_DBG(a, 4)) for(int k = 0; k < nV; ++k) acc = __builtin_fma((double)Yt[i][k], (double)Yt[j][k], acc);
                     gram[i * n + j] = acc;
                 }
                 acc *= s_sD[i] * s_sD[j];
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
             itk[it] = (idx < half * n) ? k : -1;
             itt[it] = idx - k * n;
         }
-        for(int sweep = 0; sweep < 30 && n > 1 && !(a.debug & 1); ++sweep) {
+        for(int sweep = 0; sweep < 30 && n > 1 && !GPP_DBG(a, 1); ++sweep) {
             double off = 0.0;
             for(int idx = lane; idx < n * n; idx += 64) { const int i = idx / n, j = idx - i * n; if(j < i) { double v = s_B[i * BP + j]; off += v * v; } }
             off = wave_sum_d(off);
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         // M_W = U diag(dw) U^T  -> overwrite B
         __syncthreads();
         {
-            const Acc32 mw = mfma_32x32(lane, (a.debug & 8) ? 0 : ((n + 3) & ~3),
+            const Acc32 mw = mfma_32x32(lane, GPP_DBG(a, 8) ? 0 : ((n + 3) & ~3),
                                         [&](int i, int k) { return (i < n && k < n) ? s_U[i * BP + k] * s_dw[k] : 0.0; },
                                         [&](int k, int j) { return (k < n && j < n) ? s_U[j * BP + k] : 0.0; });
             __syncthreads();
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
         for(int i = 0; i < EN; ++i) q[i] = (i < n) ? q[i] * s_sD[i] : 0.0;
         // total_e = sum_k X_k W(k,e), float accumulation in k order (oi_ensi.cpp:505-511)
         float acc = 0.0f;
-        for(int k = 0; k < nV && !(a.debug & 2); ++k) {
+        for(int k = 0; k < nV && !GPP_DBG(a, 2); ++k) {
             double wke = (k == lane) ? 1.0 : 0.0;
 #pragma unroll
             for(int i = 0; i < EN; ++i) wke = __builtin_fma((double)Yt[i][k], q[i], wke);
@@ -751,6 +751,17 @@ struct EnsiWorkspace {
 };
 thread_local EnsiWorkspace g_ews;
 thread_local float g_ensi_ms = 0;
+thread_local int g_ensi_converge = 0;
+}
+
+void gpp_release_ensi_workspace() {
+    EnsiWorkspace& ws = g_ews;
+    ws.cpark.release(); ws.gram.release(); ws.sel.release();
+}
+
+extern "C" int gpp_ensi_set_convergence(int to_convergence) {
+    g_ensi_converge = to_convergence ? 1 : 0;
+    return GPP_OK;
 }
 
 
@@ -807,7 +818,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     const int nV = (int)valid.size();
     // k_ensi_pair (default) takes any number of valid members; the older LDS-resident k_ensi (GPP_ENSI_V1=1, kept for A/B
     // measurements) and k_ensi_big (more than 32 usable observations at a grid point) hold one member per lane
-    const bool use_pair = !getenv("GPP_ENSI_V1");
+    const bool use_pair = !path_env("GPP_ENSI_V1");
     if(!use_pair && nV > EMAXV) runtime("optimal_interpolation_ensi: more than 64 valid ensemble members need the default kernel (unset GPP_ENSI_V1)");
     if(nV == 0) { f_out.finish(); GPP_HIP(hipStreamSynchronize(stream())); return GPP_OK; }
     ws.validIdx.upload(valid.data(), nV);
@@ -844,19 +855,19 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
       const int kk = (max_points > 0 && max_points <= 32) ? max_points : 32;
       a.s.q0 = std::max(1, std::min(8, (int)std::ceil(0.5 * (std::sqrt(1.6 * kk / std::max(occ, 1e-3)) - 1.0)))); }
-    a.s.scan_stats = getenv("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr;
+    a.s.scan_stats = timing_env("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr;
     a.s.K = (max_points > 0 && max_points <= EN) ? max_points : EN;
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
     a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
     a.gram = ws.gram.get((size_t)a.ntiles * EN * EN);
-    a.debug = getenv("GPP_ENSI_DEBUG") ? atoi(getenv("GPP_ENSI_DEBUG")) : 0;
-    a.jtol2 = getenv("GPP_ENSI_JTOL2") ? atof(getenv("GPP_ENSI_JTOL2")) : 1.5e-4;
+    a.debug = timing_env("GPP_ENSI_DEBUG") ? atoi(timing_env("GPP_ENSI_DEBUG")) : 0;
+    a.jtol2 = g_ensi_converge ? 0.0 : 1.5e-4;   // gpp_ensi_set_convergence(1): the Jacobi sweeps run to convergence (no perturbation series to speak of)
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
     // cells with more than 32 usable observations go to k_ensi_big (scalar structure functions; the spatially varying forms
     // fail loudly there)
-    const bool big_ok = (max_points == 0 || max_points > EN) && !getenv("GPP_ENSI_NO_BIG");
+    const bool big_ok = (max_points == 0 || max_points > EN) && !path_env("GPP_ENSI_NO_BIG");
     if(big_ok) {
         a.big_list = ws.big_list.get((size_t)C); a.big_count = ws.big_count.get(1);
         GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, sizeof(int), stream()));
@@ -869,17 +880,22 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         else hipLaunchKernelGGL(k_ensi_scan<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
         GPP_HIP(hipGetLastError());
         // spectral side (pairs of cells, warm-started along a tile) and ensemble side (one wave per cell) in batches of tiles: what
-        // the second kernel needs of a cell (17 KB) waits in HBM: up to 112 GB of the 288 (config 5 in one batch; every batch ends with a
-        // tail of few long tiles, 5 batches cost 3 % over one), never more than half of what is free right now (GPP_ENSI_PARK_MB)
-        size_t park_bytes = (size_t)112 << 30;
+        // the second kernel needs of a cell (17 KB) waits in HBM.  The park is kept between calls (freeing and re-allocating tens of
+        // GB costs seconds) and is therefore bounded: a quarter of the device memory (72 GB of 288: config 5 runs in two batches,
+        // +1 % over one), never more than half of what is free right now; gpp_release_workspaces() gives it back (GPP_ENSI_PARK_MB)
+        size_t park_bytes = (size_t)72 << 30;
         {
             size_t free_b = 0, total_b = 0;
-            if(hipMemGetInfo(&free_b, &total_b) == hipSuccess) park_bytes = std::min(park_bytes, std::max<size_t>((free_b + ws.cpark.cap * sizeof(double)) / 2, (size_t)64 << 20));
+            if(hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                park_bytes = std::min(total_b / 4, std::max<size_t>((free_b + ws.cpark.cap * sizeof(double)) / 2, (size_t)64 << 20));
         }
-        if(getenv("GPP_ENSI_PARK_MB")) park_bytes = (size_t)atol(getenv("GPP_ENSI_PARK_MB")) << 20;
+        if(path_env("GPP_ENSI_PARK_MB")) park_bytes = (size_t)atol(path_env("GPP_ENSI_PARK_MB")) << 20;
         const size_t per_tile = (size_t)64 * ENSI_PARK_D * sizeof(double);
-        const int tcap = (int)std::max<size_t>(1, std::min<size_t>((size_t)a.ntiles, park_bytes / per_tile));
-        a.cpark = ws.cpark.get((size_t)tcap * 64 * ENSI_PARK_D);
+        int tcap = (int)std::max<size_t>(1, std::min<size_t>((size_t)a.ntiles, park_bytes / per_tile));
+        for(;;) {   // (somebody else may hold the memory after all: halve the batch until the park fits)
+            try { a.cpark = ws.cpark.get((size_t)tcap * 64 * ENSI_PARK_D); break; }
+            catch(const Error&) { if(tcap <= 1) throw; (void)hipGetLastError(); tcap = (tcap + 1) / 2; }
+        }
         for(int t0 = 0; t0 < a.ntiles; t0 += tcap) {
             const int nt = std::min(tcap, a.ntiles - t0);
             a.tile0 = t0;
@@ -911,10 +927,10 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
     f_out.finish();
     unsigned long long hc[80];
-    if(getenv("GPP_ENSI_STATS")) GPP_HIP(hipMemcpyAsync(hc, ws.counters.p, sizeof(hc), hipMemcpyDeviceToHost, stream()));
+    if(timing_env("GPP_ENSI_STATS")) GPP_HIP(hipMemcpyAsync(hc, ws.counters.p, sizeof(hc), hipMemcpyDeviceToHost, stream()));
     GPP_HIP(hipStreamSynchronize(stream()));
     GPP_HIP(hipEventElapsedTime(&g_ensi_ms, ws.e0, ws.e1));
-    if(getenv("GPP_ENSI_STATS")) {
+    if(timing_env("GPP_ENSI_STATS")) {
         unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
         fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (use_pair ? 0.25 : 1.0) * (double)sw / (double)hc[1] : 0.0);
         unsigned long long tot = 0; for(int i = 0; i < 12; i++) tot += hc[40 + i];

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             };
             double dg = diag_of_rows();
 #pragma unroll 1
-            for(int sweep = 0; sweep < 120 && n > 1 && !(a.debug & 1); ++sweep) {   // (in quarters of a sweep: 4 of its 16 double phases)
+            for(int sweep = 0; sweep < 120 && n > 1 && !GPP_DBG(a, 1); ++sweep) {   // (in quarters of a sweep: 4 of its 16 double phases)
                 double off = 0.0;   // (not sum(b^2) - dg^2: the off-diagonal part is 20 orders below the diagonal when converged)
 #pragma unroll
                 for(int j = 0; j < 32; ++j) { const double v = (j == i) ? 0.0 : b[j]; off = __builtin_fma(v, v, off); }
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                 for(int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
-                    sA[row * PP + col] = (a.debug & 8) ? 0.0 : mw.t[ti][tj][r] * (s_sD1[row] * s_sD1[col]);
+                    sA[row * PP + col] = GPP_DBG(a, 8) ? 0.0 : mw.t[ti][tj][r] * (s_sD1[row] * s_sD1[col]);
                 }
     }
     __syncthreads();
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                 }
                 __syncthreads();
-                const int kend = (a.debug & 2) ? 0 : min(32, nV - k0);
+                const int kend = GPP_DBG(a, 2) ? 0 : min(32, nV - k0);
                 // one row of the table per step (other waves of the SIMD hide the LDS latency here)
 #pragma unroll 1
                 for(int k = 0; k < kend; ++k) {

@@ -337,7 +337,7 @@ extern "C" int gpp_fill_missing(const float* values, int ny, int nx, float* out,
     o.bind(out, n, mem);
     DevBuf<float> ry, rx;
     ry.get(n); rx.get(n);
-    if(nx <= FM_MAXX && ny <= FM_MAXX && !getenv("GPP_FILL_MISSING_LINES")) {
+    if(nx <= FM_MAXX && ny <= FM_MAXX && !path_env("GPP_FILL_MISSING_LINES")) {
         // rows directly; columns as the rows of the transposed field
         DevBuf<float> vt, rxt;
         vt.get(n); rxt.get(n);

@@ -820,7 +820,7 @@ void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statisti
     double* rs = g_nb.rs.get(n);
     int* rc = g_nb.rc.get(n);
     int hwc = std::min(hw, X);
-    const bool wide = (256 + 2 * (size_t)hwc) * sizeof(float) > 160 * 1024 || getenv("GPP_BOX_ROWS_WIDE");   // no LDS tile holds the window
+    const bool wide = (256 + 2 * (size_t)hwc) * sizeof(float) > 160 * 1024 || path_env("GPP_BOX_ROWS_WIDE");   // no LDS tile holds the window
     static std::once_flag lds_once;
     if(!wide && (256 + 2 * (size_t)hwc) * sizeof(float) > 64 * 1024)
         std::call_once(lds_once, [] { GPP_HIP(hipFuncSetAttribute((const void*)k_box_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
@@ -830,7 +830,7 @@ void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statisti
         const int ny = std::min(65535, Y - ybase);
         if(wide)
             hipLaunchKernelGGL(k_box_rows_wide, dim3(1, ny, nplanes), dim3(256), 0, stream(), d_in, Y, X, hw, rs, rc, flags, ybase);
-        else if(hwc <= 1024 && hwc > 0 && !getenv("GPP_BOX_ROWS_DIRECT")) {
+        else if(hwc <= 1024 && hwc > 0 && !path_env("GPP_BOX_ROWS_DIRECT")) {
             const int ntap = ROWS4_TILE + 2 * hwc;
             hipLaunchKernelGGL(k_box_rows4, dim3((X + ROWS4_TILE - 1) / ROWS4_TILE, ny, nplanes), dim3(256), (size_t)(ntap + (ntap >> 2) + 4) * sizeof(float), stream(),
                                d_in, Y, X, hw, rs, rc, flags, ybase);
@@ -945,8 +945,8 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
     o.bind(out, C, mem);
     // 3-D input with at most 254 members, 16 thresholds and a halfwidth of 16: byte counts in padded planes + the box pass of
     // qf_box.hip.  The counts come from the rank / sum-of-absolute-differences pass (k_qf_count) when the rows are whole float4s
-    const bool fused = nt > 0 && is3d && ne <= 254 && nt <= 16 && halfwidth <= QF_MAXHW && C < (1L << 31) && !getenv("GPP_QF_NO_FUSED");
-    bool ranked = fused && (ne & 3) == 0 && (reinterpret_cast<size_t>(in.d) & 15) == 0 && !getenv("GPP_QF_NO_RANKS");
+    const bool fused = nt > 0 && is3d && ne <= 254 && nt <= 16 && halfwidth <= QF_MAXHW && C < (1L << 31) && !path_env("GPP_QF_NO_FUSED");
+    bool ranked = fused && (ne & 3) == 0 && (reinterpret_cast<size_t>(in.d) & 15) == 0 && !path_env("GPP_QF_NO_RANKS");
     if(nt > 0) th.bind(thresholds, nt, mem & ~GPP_HOST_F64);   // GPP_HOST_F64 applies to `input` only: quantile / thresholds stay float32
     QfLut* lut = nullptr;
     int lut_head[5] = {0, 0, 0, 1, 0};   // scale, off, U, flag, ident

@@ -117,7 +117,7 @@ static gpp_obs_index* build_obs_index_device(gpp_points* pts) {
 
 gpp_obs_index* gpp_build_obs_index(gpp_points* pts) {
     if(pts->obs_index) return pts->obs_index;
-    if(pts->n >= (1 << 17) && !getenv("GPP_HOST_INDEX")) return build_obs_index_device(pts);
+    if(pts->n >= (1 << 17) && !path_env("GPP_HOST_INDEX")) return build_obs_index_device(pts);
     pts->ensure_host_xyz();
     pts->ensure_host_fields();
     std::unique_ptr<gpp_obs_index> ix(new gpp_obs_index);
@@ -178,7 +178,7 @@ gpp_obs_index* gpp_build_obs_index(gpp_points* pts) {
 }
 
 int gpp_tile_wshift(gpp_points* g) {
-    if(getenv("GPP_TILE_WSHIFT")) return std::max(0, std::min(6, atoi(getenv("GPP_TILE_WSHIFT"))));
+    if(path_env("GPP_TILE_WSHIFT")) return std::max(0, std::min(6, atoi(path_env("GPP_TILE_WSHIFT"))));
     if(g->ny < 2 || g->nx < 2) return g->nx >= 64 ? 6 : 3;
     if(g->tile_wshift >= 0) return g->tile_wshift;
     // metric size of a cell from the three corner points (0,0), (0,1), (1,0), in the library's own coordinates
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
 
         // ---- dense solves: one augmented Cholesky per DISTINCT observation set -----------------------------------
         unsigned long long todo = __ballot(cnt > 0);
-        if(a.debug & 1) todo = 0ull;   // GPP_OI_DEBUG bit0: skip the solves (timing experiments only)
+        if(GPP_DBG(a, 1)) todo = 0ull;   // GPP_OI_DEBUG bit0: skip the solves (timing experiments only)
         const int nupd = __popcll(todo);
         int nsolve = 0;
         bool bad = false;
@@ -1298,15 +1298,15 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     { const double occ = (double)S / ((double)ix->nbx * ix->nby);
       const int kk = (max_points > 0 && max_points <= N) ? max_points : N;
       a.s.q0 = std::max(1, std::min(8, (int)std::ceil(0.5 * (std::sqrt(1.6 * kk / std::max(occ, 1e-3)) - 1.0))));
-      if(getenv("GPP_Q0")) a.s.q0 = atoi(getenv("GPP_Q0"));
+      if(path_env("GPP_Q0")) a.s.q0 = atoi(path_env("GPP_Q0"));
       // expected distance of the kk-th nearest observation: k_oi_union looks for its bulk disc below 1.5x that and then
       // visits rings 0.15x wide
       const double r_k = std::sqrt(kk / (3.14159265358979 * std::max(occ, 1e-3))) / ix->inv_s;
       a.s.ring_r0 = (float)(1.5 * r_k); a.s.ring_dr = (float)(0.15 * r_k); }
-    a.s.scan_stats = getenv("GPP_SCAN_STATS") ? d_counters + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
+    a.s.scan_stats = timing_env("GPP_SCAN_STATS") ? d_counters + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
     a.err = d_err; a.counters = d_counters;
-    a.debug = getenv("GPP_OI_DEBUG") ? atoi(getenv("GPP_OI_DEBUG")) : 0;
+    a.debug = timing_env("GPP_OI_DEBUG") ? atoi(timing_env("GPP_OI_DEBUG")) : 0;
 
     GPP_HIP(hipEventRecord(ws.e0, stream()));
     // Cholesky needs a symmetric positive definite P+R: true for every kernel on distances and for the even vertical / laf
@@ -1314,7 +1314,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     // non-symmetric (structure.cpp:35-64), and a truncated kernel can be indefinite -> pivoted LU like the reference.
     auto odd = [](int k) { return k == GPP_SK_CRESSMAN || k == GPP_SK_SOAR || k == GPP_SK_TOAR; };
     const bool spatial = a.s.st.fh != nullptr;   // per-point length scales: P is not symmetric (corr(p1, p2) uses p1's scales)
-    bool use_lu = spatial || (a.s.st.v != 0 && odd(a.s.st.kv)) || (a.s.st.w != 0 && odd(a.s.st.kw)) || getenv("GPP_OI_FORCE_LU");
+    bool use_lu = spatial || (a.s.st.v != 0 && odd(a.s.st.kv)) || (a.s.st.w != 0 && odd(a.s.st.kw)) || path_env("GPP_OI_FORCE_LU");
     int err = 0;
     unsigned long long counters[80 + 2 * GPP_NSLOT];
     const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
@@ -1346,13 +1346,13 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     // the tiles it declines, and every other configuration, run on k_oi (one factorisation per distinct selection)
     // (With elevation / laf dependent rho the cells of a tile agree less; on smooth terrain most tiles still fit, on
     //  white-noise elevations none does and the first pass costs a few per cent before the lists hand everything to k_oi.)
-    const bool want_union = getenv("GPP_OI_UNION") ? atoi(getenv("GPP_OI_UNION")) != 0 : true;
+    const bool want_union = path_env("GPP_OI_UNION") ? atoi(path_env("GPP_OI_UNION")) != 0 : true;
     auto& memo = bgrid->union_memo;
     const bool memo_hit = memo.points_id == points->serial && memo.h == a.s.st.h && memo.v == a.s.st.v && memo.w == a.s.st.w && memo.kh == a.s.st.kh &&
                           memo.kv == a.s.st.kv && memo.kw == a.s.st.kw && memo.cv == a.s.st.cv && memo.max_points == max_points;
     const bool memo_says_no = memo_hit && memo.declined > 0.5f;   // more than half of the tiles went to k_oi last time: skip the first pass
     // (the 62-row form only for 33 <= max_points <= 62: with max_points = 0 a cell may hold more than any tile kernel can)
-    const bool use_union = !use_lu && (N == 32 || (max_points > 32 && max_points <= 62)) && want_union && !memo_says_no && !getenv("GPP_OI_NO_UNION");
+    const bool use_union = !use_lu && (N == 32 || (max_points > 32 && max_points <= 62)) && want_union && !memo_says_no && !path_env("GPP_OI_NO_UNION");
     const int WPB = N == 32 ? UnionCfg<32>::WPB : UnionCfg<64>::WPB;   // work items (waves) per workgroup of k_oi_union
     // cells with more usable observations than the 62-row tile holds are listed: symmetric systems go to k_oi_big (Cholesky, up
     // to BIG_N observations), what that kernel cannot hold and every listed cell of a non-symmetric or spatially varying
@@ -1368,7 +1368,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         const size_t ncap = (max_points > 0) ? (size_t)std::min(max_points, S) : (size_t)S;
         const size_t per_wg = ncap * (ncap + 2) * sizeof(double) + kcap * sizeof(unsigned long long);
         size_t budget = (size_t)16 << 30;   // 16 GB of the 288 GB for this rarely used path
-        if(getenv("GPP_OI_HUGE_BUDGET_MB")) budget = (size_t)atol(getenv("GPP_OI_HUGE_BUDGET_MB")) << 20;
+        if(path_env("GPP_OI_HUGE_BUDGET_MB")) budget = (size_t)atol(path_env("GPP_OI_HUGE_BUDGET_MB")) << 20;
         if(per_wg > budget) runtime("optimal_interpolation: a grid point may select more observations than the scratch budget of the general kernel holds (set max_points, or raise GPP_OI_HUGE_BUDGET_MB)");
         const int nwg = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)ncells, 512), budget / per_wg));
         a.huge_kcap = (int)kcap; a.huge_ncap = (int)ncap;
@@ -1466,7 +1466,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         }
         if(big_ok) {
             const int nbig = h_ints[4];
-            if(nbig > 0 && !use_lu && !getenv("GPP_OI_NO_BIG")) {
+            if(nbig > 0 && !use_lu && !path_env("GPP_OI_NO_BIG")) {
                 const int nwg = std::min(nbig, 256);
                 a.big_keys = ws.big_keys.get((size_t)nwg * BIG_CAND);
                 a.big_mat = ws.big_mat.get((size_t)nwg * (BIG_N + 2) * BIG_N);
@@ -1510,7 +1510,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     if(ran_union) GPP_HIP(hipEventElapsedTime(&g_stats.union_kernel_ms, ws.e0, ws.eu));
     g_stats.cells_updated = 0; g_stats.solves = 0;
     for(int k = 0; k < GPP_NSLOT; k++) { g_stats.cells_updated += (long long)counters[80 + 2 * k]; g_stats.solves += (long long)counters[81 + 2 * k]; }
-    if(getenv("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);
+    if(timing_env("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);
 #ifdef GPP_UNION_PROFILE
     { const char* nm[12] = {"cell loads", "bbox+init", "phase-1 loads", "ring loop", "phase 2", "classify", "union records", "P build", "eliminate", "export", "per-lane", "-"};
       double tot = 0; for(int i = 0; i < 12; i++) tot += (double)counters[20 + i];
@@ -1520,7 +1520,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     fprintf(stderr, "[gpp] union: fallback reasons: slots %llu, union>40 %llu, extras>12 %llu, layout %llu, per-cell extras>6 %llu; per tile: insertions %.1f, evictions %.1f, candidates %.1f, survivors %.1f\n",
                             counters[4], counters[5], counters[6], counters[7], counters[8], counters[9] / (double)a.ntiles, counters[10] / (double)a.ntiles, counters[11] / (double)a.ntiles, counters[12] / (double)a.ntiles);
 #endif
-    if(getenv("GPP_SCAN_STATS")) { fprintf(stderr, "[gpp] wave-level insertions per tile histogram:"); for(int i = 0; i < 70; i++) fprintf(stderr, " %d:%llu", i, counters[4 + i]); fprintf(stderr, "\n"); }
+    if(timing_env("GPP_SCAN_STATS")) { fprintf(stderr, "[gpp] wave-level insertions per tile histogram:"); for(int i = 0; i < 70; i++) fprintf(stderr, " %d:%llu", i, counters[4 + i]); fprintf(stderr, "\n"); }
     if(err & ERR_SINGULAR) runtime("optimal_interpolation: local (P+R) matrix is singular");
     if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more usable observations at a grid point than the scratch of the general kernel was sized for");
     return GPP_OK;

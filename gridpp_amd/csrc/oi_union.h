@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
                         const float2 met = k == 0 ? met0 : (k == 1 ? met1 : met2);
                         const int posv = k == 0 ? pos0 : (k == 1 ? pos1 : pos2);
                         const unsigned long long mk = k == 0 ? m0 : (k == 1 ? m1 : m2);
-                        if(a.debug & 8) continue;
+                        if(GPP_DBG(a, 8)) continue;
                         if(bulk) {
                             if((mk >> lane) & 1ull) {   // the holder of a candidate records where it lives
                                 const int slot = nb + __popcll(mk & ((1ull << lane) - 1ull));
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         UPROF(3);   // ring loop
         // ---- phase 2: every remaining bin that can still matter, rows centre-out (x-extent and stop test from the largest
         //      threshold in the wave), skipping the square phase 1 covered
-        for(int r = 0; !fb && !(a.debug & 4); ++r) {
+        for(int r = 0; !fb && !GPP_DBG(a, 4); ++r) {
             const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
             if(t2 < 0.0f) break;
             const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
     }
     UPROF(5);   // classification
     float res_out = bg, res_var = bvar;   // oi.cpp:198-199
-    if(upd != 0ull && !(a.debug & 1)) {
+    if(upd != 0ull && !GPP_DBG(a, 1)) {
         // ============= shared factorisation: rows 0..c-1 core, c..u-1 extras, lane 63 = obs - background ==========
         const int myslot = lane < c ? nth_set_bit(coreM, lane) : (lane < u ? nth_set_bit(extM, lane - c) : 0);
         float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
                 if(p <= maxp) sv[bse + p] = row[p];
             }
         }
-        if(U_MAXU > NC && u > 32 && !(a.debug & 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
+        if(U_MAXU > NC && u > 32 && !GPP_DBG(a, 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
             // (row p of B has just been exported: it comes back as LDS broadcasts, one read per two multiply-adds, instead of a
             //  v_readlane pair per multiply-add; columns c.. of the padded row are multiplied by zeros)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
 #pragma unroll
         for(int k = 0; k < NC; ++k) {
             double zk = 0.0;
-            if(k < c && !(a.debug & 32)) {
+            if(k < c && !GPP_DBG(a, 32)) {
                 const double gk = (double)gf[k];
                 double acc0 = 0.0, acc1 = 0.0;
                 const double* lrow = sv + oL + k * (k + 1) / 2;
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
             minInc = wave_min(lane < c ? dpf : INFINITY);
         }
         const int mmax = __builtin_amdgcn_readfirstlane((int)wave_max((float)m));
-        if(mmax > 0 && !(a.debug & 64)) {
+        if(mmax > 0 && !GPP_DBG(a, 64)) {
             double ll[U_MAXM * (U_MAXM + 1) / 2], qv[U_MAXM], tv[U_MAXM], il[U_MAXM];
 #pragma unroll
             for(int i = 0; i < U_MAXM; ++i) {

@@ -242,7 +242,7 @@ __global__ void k_fill_value(float* out, size_t n, float v) {
 
 // entries per filling pass (2^28 = 1 GiB of float values; GPP_CSR_CAP overrides it so that the tests can reach the chunked path)
 long long csr_cap() {
-    const char* e = getenv("GPP_CSR_CAP");
+    const char* e = path_env("GPP_CSR_CAP");
     const long long v = e ? atoll(e) : 0;
     return v > 0 ? v : (1ll << 28);
 }
@@ -340,8 +340,8 @@ extern "C" int gpp_gridding(gpp_points* to, gpp_points* from, const float* value
         const IxView iv = view_of(ix);
         const bool streams = statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT || statistic == GPP_STD ||
                              statistic == GPP_VARIANCE || statistic == GPP_MIN || statistic == GPP_MAX;
-        if(streams && !getenv("GPP_GRIDDING_CSR")) {
-            if(getenv("GPP_GRIDDING_THREAD"))
+        if(streams && !path_env("GPP_GRIDDING_CSR")) {
+            if(path_env("GPP_GRIDDING_THREAD"))
                 hipLaunchKernelGGL(k_radius_statistic, dim3((nq + 255) / 256), dim3(256), 0, stream(), iv, to->d_x.p, to->d_y.p, to->d_z.p, nq, radius,
                                    v.d, min_num, statistic, o.d);
             else

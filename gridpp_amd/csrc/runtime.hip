@@ -20,6 +20,7 @@ int fail(int code, const char* fmt, ...) {
 }
 
 static hipStream_t g_stream = nullptr;
+static std::atomic<unsigned long long> g_next_serial{1};   // one counter for every instantiation of make_points<T>
 static std::atomic<int> g_live_handles{0};   // gpp_points alive (gpp_set_device refuses to switch under them)
 static int g_device = -1;
 static std::mutex g_mutex;
@@ -46,6 +47,35 @@ using namespace gpp;
 
 extern "C" const char* gpp_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* gpp_version(void) { return "0.8.0.dev1+mi355x.r1"; }
+
+extern char** environ;
+void gpp_release_ensi_workspace();   // ensi.hip
+
+// every GPP_* variable of the environment, comma separated (path_env() in common.h: they select implementations, never results)
+extern "C" int gpp_active_overrides(char* buf, int len) {
+    GPP_TRY
+    std::string out;
+    int n = 0;
+    for(char** e = environ; e && *e; ++e)
+        if(strncmp(*e, "GPP_", 4) == 0) {
+            const char* eq = strchr(*e, '=');
+            if(!out.empty()) out += ",";
+            out += eq ? std::string(*e, eq - *e) : std::string(*e);
+            n++;
+        }
+    if(buf && len > 0) { strncpy(buf, out.c_str(), (size_t)len - 1); buf[len - 1] = 0; }
+    return n;
+    GPP_CATCH
+}
+
+// frees the thread's large call-to-call workspaces (they grow on demand and are otherwise kept for the next call)
+extern "C" int gpp_release_workspaces(void) {
+    GPP_TRY
+    GPP_HIP(hipStreamSynchronize(stream()));
+    gpp_release_ensi_workspace();
+    return GPP_OK;
+    GPP_CATCH
+}
 
 extern "C" int gpp_device_count(int* count) {
     GPP_TRY
@@ -305,7 +335,7 @@ static gpp_points* make_points(const T* lats, const T* lons, const T* elevs, con
     if(n < 0) invalid("negative size");
     if(n > 0 && (!lats || !lons)) invalid("lats/lons are NULL");
     std::unique_ptr<gpp_points> p(new gpp_points);
-    { static std::atomic<unsigned long long> next_serial{1}; p->serial = next_serial.fetch_add(1); g_live_handles.fetch_add(1); }
+    p->serial = g_next_serial.fetch_add(1); g_live_handles.fetch_add(1);
     p->n = n; p->ny = ny; p->nx = nx; p->type = type;
     // do the vertical / land-area-fraction factors of a structure function vary over this point set at all?
     auto uniform = [](const T* v, int m) {   // absent (all NaN: points.cpp:23-30, grid.cpp:41-54), all invalid, or all valid and equal
@@ -323,7 +353,7 @@ static gpp_points* make_points(const T* lats, const T* lons, const T* elevs, con
     // large sets: conversion on the device straight from the caller's arrays; neither x / y / z nor the four fields get a host
     // copy unless a host-side function asks for one
     bool done = false;
-    if(n >= (1 << 16) && !getenv("GPP_HOST_CONVERT")) {
+    if(n >= (1 << 16) && !path_env("GPP_HOST_CONVERT")) {
         if(type != GPP_GEODETIC && type != GPP_CARTESIAN) invalid("Unknown coordinate type");
         ensure_device();
         p->host_xyz = false;
@@ -505,7 +535,7 @@ __global__ __launch_bounds__(256) void k_nearest_binned(const float4* __restrict
 void gpp_nearest_device(gpp_points* p, const float* d_qx, const float* d_qy, const float* d_qz, int nq, int include_match, int* d_out) {
     p->to_device();
     if(nq == 0) return;
-    if(p->n > 2048 && !getenv("GPP_NN_BRUTE")) {
+    if(p->n > 2048 && !path_env("GPP_NN_BRUTE")) {
         gpp_obs_index* ix = gpp_build_obs_index(p);
         hipLaunchKernelGGL(k_nearest_binned, dim3((nq + 255) / 256), dim3(256), 0, stream(), ix->d_sgeo.p, ix->d_smeta.p, ix->d_bin_start.p,
                            ix->axis_a, ix->axis_b, ix->nbx, ix->nby, ix->amin, ix->bmin, ix->inv_s, d_qx, d_qy, d_qz, nq, include_match, d_out);

@@ -188,7 +188,8 @@ class MultipleStructure : public StructureFunction {   // src/api/structure.cpp:
         mS.loc = sh.localization_distance();
         mS.flags = GPP_ST_HAS_LOC;
         mS.cv_dist = 0;
-        mS.field = h->field; mS.field_v = v->field; mS.field_w = w->field;   // (this header offers the scalar constructors only: all NULL)
+        // (a nested MultipleStructure contributes the field of its own vertical / laf component)
+        mS.field = h->field; mS.field_v = v->kind_v ? v->field_v : v->field; mS.field_w = w->kind_w ? w->field_w : w->field;
     }
 };
 class CrossValidation : public StructureFunction {     // src/api/structure.cpp:910-944
@@ -467,6 +468,10 @@ inline vec2 neighbourhood_quantile_fast(const vec2& input, const vec2& quantile,
 inline vec2 neighbourhood_quantile_fast(const vec2& input, float quantile, int halfwidth, const vec& thresholds) { return neighbourhood_quantile_fast(input, vec2(1, vec(1, quantile)), halfwidth, thresholds); }
 inline vec2 neighbourhood_quantile_fast(const vec3& input, const vec2& quantile, int halfwidth, const vec& thresholds) { size_t Y, X, E; vec f = detail::flatten(input, Y, X, E); return detail::qfast(f, Y, X, E, 1, quantile, halfwidth, thresholds); }
 inline vec2 neighbourhood_quantile_fast(const vec3& input, float quantile, int halfwidth, const vec& thresholds) { return neighbourhood_quantile_fast(input, vec2(1, vec(1, quantile)), halfwidth, thresholds); }
+// deprecated aliases (include/gridpp.h:710-716, src/api/neighbourhood.cpp:541-552)
+inline vec2 neighbourhood_ens(const vec3& input, int halfwidth, Statistic statistic) { return neighbourhood(input, halfwidth, statistic); }
+inline vec2 neighbourhood_quantile_ens(const vec3& input, float quantile, int halfwidth) { return neighbourhood_quantile(input, quantile, halfwidth); }
+inline vec2 neighbourhood_quantile_ens_fast(const vec3& input, float quantile, int radius, const vec& thresholds) { return neighbourhood_quantile_fast(input, quantile, radius, thresholds); }
 namespace detail {
 inline vec thresholds(const vec& f, int num) {
     if(num <= 0) throw std::invalid_argument("num_thresholds must be > 0");

@@ -71,6 +71,11 @@ extern "C" {
 const char* gpp_last_error(void);
 const char* gpp_version(void);            /* include/gridpp.h:15 GRIDPP_VERSION */
 int gpp_device_count(int* count);
+/* every GPP_* variable set in the environment, comma separated, into buf (NUL terminated); returns how many.  They select
+ * between implementations with identical results (tests, A/B timing); a benchmark must run with none of them. */
+int gpp_active_overrides(char* buf, int len);
+/* releases the calling thread's large call-to-call device workspaces (kept otherwise for the next call) */
+int gpp_release_workspaces(void);
 int gpp_set_device(int device);           /* one process per GPU: call once with LOCAL_RANK */
 int gpp_get_stream(void** hip_stream);    /* the hipStream_t all kernels are launched on */
 int gpp_synchronize(void);
@@ -263,6 +268,10 @@ int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* background, i
                                    const gpp_structure* structure, int max_points, int allow_extrapolation,
                                    float* out, int mem);
 int gpp_ensi_last_kernel_ms(float* ms);
+/* 1: the Jacobi sweeps of the per-cell eigenproblem run to convergence (reference-grade last bits, ~2x the time);
+ * 0 (default): they stop at |off-diagonal| <= 0.012 (E - 1) and a perturbation series supplies the rest.
+ * Per calling thread. */
+int gpp_ensi_set_convergence(int to_convergence);
 
 /* gridpp::optimal_interpolation_ensi_multi_ebe / _ebesc / _utem (include/gridpp.h:311-441, src/api/oi_ensi_multi.cpp:329-1311;
  * Points overloads, a Grid is its row-major flattening).  variant: 1 = ebe, 2 = ebesc, 3 = utem.  bratios [bgrid-size];

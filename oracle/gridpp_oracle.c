@@ -1461,13 +1461,17 @@ int orc_bilinear(const float* glat, const float* glon, const float* gx, const fl
 /* optimal_interpolation_ensi (Points): src/api/oi_ensi.cpp:114-568           */
 /* background [nY][nE], pbackground [nS][nE], out [nY][nE]                    */
 /* ------------------------------------------------------------------------ */
-int orc_oi_ensi_range(int y0, int y1, int nY, int nE,
+/* gst == NULL: scalar BarnesStructure(h, v, w, min_rho); else any structure function (structure.cpp:287-944), optionally with
+ * spatially varying scales: the structure as seen from the grid point (localization_distance(p1) :213, corr_background(p1, p2)
+ * :250 take the parameters at the FIRST point), c_h / c_v / c_w / c_R per background point [nY] or NULL */
+static int orc_oi_ensi_core(int y0, int y1, int nY, int nE,
                 const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
                 const float* background,
                 int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
                 const float* pobs, const float* psigmas, const float* pbackground,
                 float h, float v, float w, float min_rho,
-                int max_points, int allow_extrapolation, float* out) {
+                int max_points, int allow_extrapolation, float* out,
+                const orc_struct* gst, const float* c_h, const float* c_v, const float* c_w, const float* c_R) {
     if(max_points < 0) return ORC_EINVAL;
     for(size_t i = (size_t)y0 * nE; i < (size_t)y1 * nE; i++) out[i] = background[i];
     if(nS == 0) return ORC_OK;
@@ -1503,8 +1507,24 @@ int orc_oi_ensi_range(int y0, int y1, int nY, int nE,
     double* wv = (double*)malloc(sizeof(double) * nV);
     double* X = (double*)malloc(sizeof(double) * nV);
     for(int y = y0; y < y1; y++) {
-        int lS = orc_select(gx[y], gy[y], gz[y], gelev[y], glaf[y], nS, ox, oy, oz, oelev, olaf,
+        int lS;
+        if(!gst)
+            lS = orc_select(gx[y], gy[y], gz[y], gelev[y], glaf[y], nS, ox, oy, oz, oelev, olaf,
                             pobs, NULL, h, v, w, loc, max_points, work, sel, srho);   /* :213-269 */
+        else {
+            orc_struct sc = *gst;
+            if(c_h) { sc.h = c_h[y]; sc.v = c_v[y]; sc.w = c_w[y]; sc.loc = c_R[y]; }
+            int n = 0;
+            for(int sI = 0; sI < nS; sI++) {
+                if(!orc_in_radius(gx[y], gy[y], gz[y], ox[sI], oy[sI], oz[sI], sc.loc, 1)) continue;               /* :213-233 */
+                float rho = orc_corr_g(&sc, gx[y], gy[y], gz[y], gelev[y], glaf[y], ox[sI], oy[sI], oz[sI], oelev[sI], olaf[sI], 1);   /* :250 */
+                if(!orc_valid(pobs[sI])) continue;                                                                   /* :235 */
+                if(rho > 0) { work[n].rho = rho; work[n].idx = sI; n++; }
+            }
+            if(max_points > 0 && n > max_points) { qsort(work, n, sizeof(orc_pair), orc_pair_cmp); n = max_points; } /* :262-273 */
+            for(int i = 0; i < n; i++) { sel[i] = work[i].idx; srho[i] = work[i].rho; }
+            lS = n;
+        }
         if(lS == 0) continue;
         if(nV == 0) continue;
         double* lY = (double*)malloc(sizeof(double) * lS * nV);     /* lS x nV, arma column-major: lY[e*lS+i] */
@@ -1578,6 +1598,29 @@ int orc_oi_ensi_range(int y0, int y1, int nY, int nE,
     free(gYp); free(gYhat); free(validEns); free(work); free(sel); free(srho);
     free(Pinv); free(P); free(Aw); free(eval); free(evec); free(W); free(wv); free(X);
     return ORC_OK;
+}
+int orc_oi_ensi_range(int y0, int y1, int nY, int nE,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* background,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* psigmas, const float* pbackground,
+                float h, float v, float w, float min_rho,
+                int max_points, int allow_extrapolation, float* out) {
+    return orc_oi_ensi_core(y0, y1, nY, nE, gx, gy, gz, gelev, glaf, background, nS, ox, oy, oz, oelev, olaf, pobs, psigmas, pbackground,
+                            h, v, w, min_rho, max_points, allow_extrapolation, out, NULL, NULL, NULL, NULL, NULL);
+}
+/* optimal_interpolation_ensi with any structure function / spatially varying scales (see orc_oi_ensi_core) */
+int orc_oi_ensi_generic(int nY, int nE,
+                const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,
+                const float* background,
+                int nS, const float* ox, const float* oy, const float* oz, const float* oelev, const float* olaf,
+                const float* pobs, const float* psigmas, const float* pbackground,
+                int kh, int kv, int kw, float h, float v, float w, float loc, int cv, float cv_dist,
+                int max_points, int allow_extrapolation, float* out,
+                const float* c_h, const float* c_v, const float* c_w, const float* c_R) {
+    orc_struct st = {kh, kv, kw, h, v, w, loc, cv, cv_dist};
+    return orc_oi_ensi_core(0, nY, nY, nE, gx, gy, gz, gelev, glaf, background, nS, ox, oy, oz, oelev, olaf, pobs, psigmas, pbackground,
+                            h, v, w, 0.0f, max_points, allow_extrapolation, out, &st, c_h, c_v, c_w, c_R);
 }
 int orc_oi_ensi(int nY, int nE,
                 const float* gx, const float* gy, const float* gz, const float* gelev, const float* glaf,

@@ -248,6 +248,26 @@ def oi_ensi(g, background, p, obs, sigmas, pbackground, st, max_points, allow_ex
     return out[y0:y1]
 
 
+def oi_ensi_generic(g, background, p, obs, sigmas, pbackground, st, max_points, allow_extrapolation=True, cell_params=None):
+    """optimal_interpolation_ensi with a Struct (any kernel, Multiple mix, CrossValidation); cell_params = (h, v, w, R) arrays per
+    background point for the spatially varying forms (the structure as seen from the grid point, oi_ensi.cpp:213,250)."""
+    background = _f(background)
+    nY, nE = background.shape
+    pbackground = _f(pbackground).reshape(p.n, nE)
+    obs, sigmas = _f(obs), _f(sigmas)
+    out = np.empty((nY, nE), np.float32)
+    cp = [(_f(a) if a is not None else None) for a in (cell_params or [None] * 4)]
+    rc = lib().orc_oi_ensi_generic(C.c_int(nY), C.c_int(nE), g.x.ctypes, g.y.ctypes, g.z.ctypes, g.elevs.ctypes, g.lafs.ctypes,
+                                   background.ctypes, C.c_int(p.n), p.x.ctypes, p.y.ctypes, p.z.ctypes, p.elevs.ctypes, p.lafs.ctypes,
+                                   obs.ctypes, sigmas.ctypes, pbackground.ctypes,
+                                   C.c_int(st.kh), C.c_int(st.kv), C.c_int(st.kw), C.c_float(st.h), C.c_float(st.v), C.c_float(st.w),
+                                   C.c_float(st.loc), C.c_int(st.cv), C.c_float(st.cv_dist), C.c_int(max_points),
+                                   C.c_int(1 if allow_extrapolation else 0), out.ctypes,
+                                   *[(a.ctypes if a is not None else None) for a in cp])
+    _check(rc)
+    return out
+
+
 def oi_ensi_multi(variant, g, bratios, background, background_corr, p, pobs, pratios, pbackground, pbackground_corr, st, max_points,
                   allow_extrapolation=True):
     """optimal_interpolation_ensi_multi_{ebe, ebesc, utem}: variant 'ebe' | 'ebesc' | 'utem' (background_corr / pbackground_corr

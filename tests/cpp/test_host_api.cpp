@@ -46,6 +46,13 @@ int main() {
     CHECK(neighbourhood_quantile(values, 0.5f, 1)[2][3] == 13);
     vec thr = get_neighbourhood_thresholds(values, 100);
     CHECK(neighbourhood_quantile_fast(values, 0.5f, 1, thr)[2][2] == 12);
+    {   // deprecated aliases (include/gridpp.h:710-716): the ensemble forms of the three calls above
+        vec3 ens(5, vec2(5, vec(1)));
+        for(int i = 0; i < 5; i++) for(int j = 0; j < 5; j++) ens[i][j][0] = values[i][j];
+        CHECK(neighbourhood_ens(ens, 1, Mean)[2][2] == 12.5f);
+        CHECK(neighbourhood_quantile_ens(ens, 0.5f, 1)[2][3] == 13);
+        CHECK(neighbourhood_quantile_ens_fast(ens, 0.5f, 1, thr)[2][2] == 12);
+    }
     CHECK(calc_statistic(vec{0, 1, NAN}, Mean) == 0.5f);
     CHECK(calc_quantile(vec{0, NAN, 2}, 0.5f) == 1);
     // EnSI pass-through (tests/test_optimal_interpolation_ens.py:9-35)

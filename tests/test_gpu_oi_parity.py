@@ -190,6 +190,17 @@ def test_multiple_and_cross_validation_structures():
     out, ref, var, rvar = _generic(c, lambda g: g.CrossValidation(g.BarnesStructure(12000, 200, 0.5), 3000),
                                    lambda O: O.Struct("Barnes", 12000, 200, 0.5).cross_validation(3000), 14)
     check(out, ref)
+    # a MultipleStructure as a component of a MultipleStructure (the reference delegates, structure.cpp:90-138): the vertical
+    # factor is the inner structure's vertical component, the laf factor the inner structure's laf component
+    mk_g = lambda g: g.MultipleStructure(g.BarnesStructure(12000),
+                                         g.MultipleStructure(g.BarnesStructure(5000), g.LinearStructure(0, 0.2, 0), g.BarnesStructure(1, 1, 9)),
+                                         g.MultipleStructure(g.CressmanStructure(7000), g.BarnesStructure(1, 77, 1), g.PowerlawStructure(1, 1, 0.7)))
+    mk_o = lambda O: O.Struct.multiple(O.Struct("Barnes", 12000),
+                                       O.Struct.multiple(O.Struct("Barnes", 5000), O.Struct("Linear", 0, 0.2, 0), O.Struct("Barnes", 1, 1, 9)),
+                                       O.Struct.multiple(O.Struct("Cressman", 7000), O.Struct("Barnes", 1, 77, 1), O.Struct("Powerlaw", 1, 1, 0.7)))
+    out, ref, var, rvar = _generic(c, mk_g, mk_o, 14)
+    check(out, ref)
+    check(var, rvar)
 
 
 def test_pivoted_lu_equals_cholesky(monkeypatch):

@@ -20,14 +20,17 @@ def test_oracle_ensi_golden(name):
     import numpy as np
     from oracle import oracle as O
     c = ensi_golden.CASES[name]
-    if "hfield" in c:
-        pytest.skip("spatially varying scales: the oracle's EnSI part takes scalar scales (the GPU test checks these vectors)")
     h, v, w, mp, allow = c["params"]
     nan_b = np.full(c["blat"].size, np.nan, np.float32)
     nan_p = np.full(c["plat"].size, np.nan, np.float32)
     g = O.Pts(c["blat"], c["blon"], c.get("belev", nan_b), c.get("blaf", nan_b))
     p = O.Pts(c["plat"], c["plon"], c.get("pelev", nan_p), c.get("plaf", nan_p))
-    out = O.oi_ensi(g, c["background"], p, c["pobs"], c["psigmas"], c["pbackground"], O.Barnes(h, v, w), int(mp), bool(allow))
+    if "hfield" in c:   # spatially varying scales on the background grid: the structure as seen from each grid point
+        R = np.array([O.structure_localization("Barnes", hh, 0.0013) for hh in c["hfield"]], np.float32)
+        out = O.oi_ensi_generic(g, c["background"], p, c["pobs"], c["psigmas"], c["pbackground"], O.Struct("Barnes", h, v, w), int(mp), bool(allow),
+                                cell_params=[c["hfield"], c["vfield"], c["wfield"], R])
+    else:
+        out = O.oi_ensi(g, c["background"], p, c["pobs"], c["psigmas"], c["pbackground"], O.Barnes(h, v, w), int(mp), bool(allow))
     ensi_golden.check(out, c)
 
 
