@@ -24,7 +24,7 @@ using namespace gpp;
 #define EMAXV 64       // max valid ensemble members (one lane per member)
 #define BP (EN + 1)    // pitch of B / U (doubles)
 
-#define ENSI_PARK_D 2144   // doubles parked per cell: U 1024 | U^T B U 1024 | sD 32 | sD (obs - yhat) 32 | rho 32
+#define ENSI_PARK_D 2208   // doubles parked per cell: U 1024 | U^T B U 1024 | sD 32 | sD (obs - yhat) 32 | rho 32 | (obs index, obs) 32 | (yhat, -) 32
 
 struct EnsiArgs {
     const float *gx, *gy, *gz, *gelev, *glaf;
@@ -36,6 +36,7 @@ struct EnsiArgs {
     const float4* oaux;       // original order: laf, obs, gYhat, sigma
     const float* gY;          // [S][nV] perturbations of the valid members (float)
     const int* validIdx;      // [nV]
+    int valid_identity;       // every member is valid: validIdx[k] == k (no load needed to address a member)
     unsigned* sel;            // [ntiles][EN][64] scratch: the selections of every tile
     double* cpark;            // [tiles of the batch][64][ENSI_PARK_D] k_ensi_pair -> k_ensi_members: U, U^T B U, sD, r, rho of every cell
     int tile0;                // first tile of the batch
@@ -45,6 +46,10 @@ struct EnsiArgs {
     int* big_list;            // cells with more usable observations than the 32-row tile holds (k_ensi_big), or NULL
     int* big_count;
     unsigned long long* big_keys;   // per workgroup of k_ensi_big: EBIG_CAND sorted candidate keys
+    int* huge_list;           // cells k_ensi_big cannot hold (more than EBIG_CAND candidates): k_ensi_huge; count in big_count[1]
+    unsigned long long* huge_keys;  // per workgroup of k_ensi_huge: huge_kcap candidate keys
+    int huge_kcap;
+    double* huge_mat;         // per workgroup of k_ensi_huge: Pinv (nV x nV) | eigenvectors (nV x nV) | five vectors of nV
     double jtol2;             // k_ensi_pair: the Jacobi sweeps stop at (off-diagonal norm)^2 <= jtol2 * c^2, c = nV - 1
     int debug;                // GPP_ENSI_DEBUG (timing experiments only): 1 no Jacobi, 2 no member update, 4 no B build, 8 no M_W
     int nV;
@@ -479,7 +484,6 @@ __global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
 //     P = V D^-1 V^T,   sqrt(c P) = V diag(sqrt(c / D)) V^T,   w = P Y^T R^-1 d,   W = sqrt(c P) + w 1^T.
 // Slower per cell than the 32-row path by two orders of magnitude -- and still far from the reference's serial loop.
 #define EBIG_CAND 8192
-#define EBIG_N 512
 #define EP 65            // pitch of the 64 x 64 matrices (doubles)
 template <bool SPATIAL>
 __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
@@ -531,8 +535,8 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
         const int ncand = s_n;
         const bool truncated = a.s.max_points > 0 && ncand > a.s.max_points;
         const int n = truncated ? a.s.max_points : ncand;
-        if(ncand > EBIG_CAND || n > EBIG_N) {   // beyond what this kernel holds: fail loudly (host raises)
-            if(tid == 0) atomicOr(a.err, 1);
+        if(ncand > EBIG_CAND) {   // more candidates than the LDS sort holds: k_ensi_huge takes the cell
+            if(tid == 0) a.huge_list[atomicAdd(a.big_count + 1, 1)] = cell;
             __syncthreads();
             continue;
         }
@@ -735,6 +739,254 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ensi_huge: the same E x E formulation with no capacity of its own -- any number of candidates, selected observations
+// and valid members (oi_ensi.cpp:187-201,244-261,379-421 have no limit either).  Candidate keys, Pinv, the eigenvectors and
+// the per-member vectors live in HBM scratch sized by the host for the call; the sort is a bitonic network over global memory,
+// the Jacobi sweeps take their rotations 32 pairs at a time.  One 256-thread workgroup per listed cell: the reference's O(E^3)
+// per grid point, slowly -- its point is that such a call returns a result instead of an exception.
+template <bool SPATIAL>
+__global__ __launch_bounds__(256) void k_ensi_huge(EnsiArgs a, const int* __restrict__ list, const int* __restrict__ count) {
+    __shared__ float s_yc[16384];                    // Y chunk: rows of nV floats
+    __shared__ double s_rinv[64], s_dvec[64];
+    __shared__ double s_cs[32], s_sn[32];
+    __shared__ int s_p[32], s_q[32];
+    __shared__ double s_off[256];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const ScanArgs& sa = a.s;
+    const int nV = a.nV, E = a.E;
+    const int nlist = *count;
+    unsigned long long* const keys = a.huge_keys + (size_t)blockIdx.x * a.huge_kcap;
+    double* const B = a.huge_mat + (size_t)blockIdx.x * (2 * (size_t)nV * nV + 5 * (size_t)nV);
+    double* const V = B + (size_t)nV * nV;
+    double* const v_t = V + (size_t)nV * nV;
+    double* const v_w = v_t + nV;
+    double* const v_X = v_w + nV;
+    double* const v_sq = v_X + nV;
+    double* const v_val = v_sq + nV;
+    const double c = (double)((float)(nV - 1));       // oi_ensi.cpp:383 (float product, delta = 1)
+    const int chunk = max(1, min(64, 16384 / max(nV, 1)));   // observations per staged chunk
+    auto block_sum = [&](double v) {   // sum over the workgroup, returned to every thread
+        s_off[tid] = v;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+        const double r = s_off[0];
+        __syncthreads();
+        return r;
+    };
+    for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int cell = list[li];
+        const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
+        DevStructure st = sa.st;
+        if(SPATIAL) d_structure_at(st, st.cell_idx ? st.cell_idx[cell] : cell);
+        if(tid == 0) s_n = 0;
+        __syncthreads();
+        // ---- radius query + filter (valid observation, rho > 0: oi_ensi.cpp:213-237) -----------------------------------------
+        const float R = st.R;
+        const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz), pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
+        const int bx0 = min(max((int)floorf((pa - R - sa.amin) * sa.inv_s) - 1, 0), sa.nbx - 1), bx1 = min(max((int)floorf((pa + R - sa.amin) * sa.inv_s) + 1, 0), sa.nbx - 1);
+        const int by0 = min(max((int)floorf((pb - R - sa.bmin) * sa.inv_s) - 1, 0), sa.nby - 1), by1 = min(max((int)floorf((pb + R - sa.bmin) * sa.inv_s) + 1, 0), sa.nby - 1);
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        for(int by = by0; by <= by1; ++by) {
+            const int js = sa.bin_start[by * sa.nbx + bx0], je = sa.bin_start[by * sa.nbx + bx1 + 1];
+            for(int j = js + tid; j < je; j += 256) {
+                const float4 rec = sa.pgeo[j];   // x = NaN for an unusable observation: fails the box test
+                if(!(rec.x > lox && rec.x < hix && rec.y > loy && rec.y < hiy && rec.z > loz && rec.z < hiz)) continue;
+                const float2 met = sa.smeta[j];
+                if(!(d_chord(rec.x, rec.y, rec.z, gx, gy, gz) <= R)) continue;
+                const float rho = d_corr(st, gx, gy, gz, ge, gl, rec.x, rec.y, rec.z, rec.w, met.x, true);
+                if(!(rho > 0.0f)) continue;
+                const int k = atomicAdd(&s_n, 1);
+                if(k < a.huge_kcap) keys[k] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~__float_as_int(met.y));
+            }
+        }
+        __syncthreads();
+        const int ncand = s_n;
+        const bool truncated = a.s.max_points > 0 && ncand > a.s.max_points;
+        const int n = truncated ? a.s.max_points : ncand;
+        int np2 = 1;
+        while(np2 < ncand) np2 <<= 1;
+        if(np2 > a.huge_kcap) { if(tid == 0) atomicOr(a.err, 1); __syncthreads(); continue; }   // (the host sizes the keys for every observation: cannot happen)
+        if(n == 0 || nV <= 1) continue;
+        // ---- order: rho descending (ties -> lower index) when the reference sorts, candidate (= index) order otherwise (:243-269)
+        for(int i = ncand + tid; i < np2; i += 256) keys[i] = 0ull;
+        __threadfence_block();
+        __syncthreads();
+        for(int k = 2; k <= np2; k <<= 1) {
+            for(int j = k >> 1; j > 0; j >>= 1) {
+                for(int i = tid; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if(ixj > i) {
+                        const unsigned long long x = keys[i], y = keys[ixj];
+                        const unsigned long long kx = truncated ? x : (x & 0xffffffffull), ky = truncated ? y : (y & 0xffffffffull);
+                        const bool desc = (i & k) == 0;
+                        if(desc ? (kx < ky) : (kx > ky)) { keys[i] = y; keys[ixj] = x; }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+        // ---- Pinv = Y^T Rinv Y + c I, t = Y^T Rinv d: chunks of observations staged in LDS, the sums kept in HBM (:380-385, :427-437)
+        for(long e = tid; e < (long)nV * nV; e += 256) { const int ai = (int)(e / nV), bi = (int)(e - (long)ai * nV); B[e] = 0.0; V[e] = (ai == bi) ? 1.0 : 0.0; }
+        for(int k = tid; k < nV; k += 256) v_t[k] = 0.0;
+        __threadfence_block();
+        __syncthreads();
+        for(int i0 = 0; i0 < n; i0 += chunk) {
+            const int m = min(chunk, n - i0);
+            for(int e = tid; e < m * nV; e += 256) {
+                const int i = e / nV, k = e - i * nV;
+                const unsigned orig = ~(unsigned)(keys[i0 + i] & 0xffffffffull);
+                s_yc[i * nV + k] = a.gY[(long)orig * nV + k];
+            }
+            if(tid < m) {
+                const unsigned long long key = keys[i0 + tid];
+                const unsigned orig = ~(unsigned)(key & 0xffffffffull);
+                const float4 x4 = a.oaux[orig];                       // laf, obs, gYhat, sigma
+                const float s2 = x4.w * x4.w;                         // float product (oi_ensi.cpp:300)
+                s_rinv[tid] = (double)__uint_as_float((unsigned)(key >> 32)) / (double)s2;
+                s_dvec[tid] = (double)x4.y - (double)x4.z;
+            }
+            __syncthreads();
+            for(long e = tid; e < (long)nV * nV; e += 256) {
+                const int ai = (int)(e / nV), bi = (int)(e - (long)ai * nV);
+                double sacc = B[e];   // (one chain over all the observations, as in k_ensi_big)
+                for(int i = 0; i < m; ++i) sacc = __builtin_fma((double)s_yc[i * nV + ai] * s_rinv[i], (double)s_yc[i * nV + bi], sacc);
+                B[e] = sacc;
+            }
+            for(int k = tid; k < nV; k += 256) {
+                double acct = v_t[k];
+                for(int i = 0; i < m; ++i) acct = __builtin_fma((double)s_yc[i * nV + k] * s_rinv[i], s_dvec[i], acct);
+                v_t[k] = acct;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        for(int k = tid; k < nV; k += 256) B[(size_t)k * nV + k] += c;
+        __threadfence_block();
+        __syncthreads();
+        // ---- cyclic Jacobi on the nV x nV matrix in HBM, round-robin pairs, 32 pairs at a time -------------------------------------
+        const int mm = nV + (nV & 1), half = mm >> 1;
+        double trl = 0.0;
+        for(int k = tid; k < nV; k += 256) trl += fabs(B[(size_t)k * nV + k]);
+        const double tr = block_sum(trl);
+        for(int sweep = 0; sweep < 60; ++sweep) {
+            double off2 = 0.0;
+            for(long e = tid; e < (long)nV * nV; e += 256) { const int i = (int)(e / nV), j = (int)(e - (long)i * nV); if(j < i) { const double v = B[e]; off2 += v * v; } }
+            off2 = block_sum(off2);
+            if(!(off2 > 1e-22 * tr * tr)) break;
+            for(int step = 0; step < mm - 1; ++step) {
+                for(int g0 = 0; g0 < half; g0 += 32) {
+                    const int npair = min(32, half - g0);
+                    if(tid < npair) {
+                        const int t = g0 + tid;
+                        int p, q;
+                        if(t == 0) { p = mm - 1; q = step; }
+                        else { p = (step + t) % (mm - 1); q = (step - t + (mm - 1)) % (mm - 1); }
+                        if(p > q) { const int t_ = p; p = q; q = t_; }
+                        double cs = 1.0, sn = 0.0;
+                        if(q < nV) {
+                            const double apq = B[(size_t)p * nV + q];
+                            if(apq != 0.0) {
+                                const double theta = (B[(size_t)q * nV + q] - B[(size_t)p * nV + p]) / (2.0 * apq);
+                                const double t_ = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                                cs = 1.0 / sqrt(t_ * t_ + 1.0); sn = t_ * cs;
+                                if(!(fabs(theta) < 1e150)) { cs = 1.0; sn = 0.0; }
+                            }
+                        }
+                        else q = p;
+                        s_p[tid] = p; s_q[tid] = q; s_cs[tid] = cs; s_sn[tid] = sn;
+                    }
+                    __syncthreads();
+                    const int pk = tid >> 3;
+                    const bool work = pk < npair && s_p[pk] != s_q[pk];
+                    const int p = work ? s_p[pk] : 0, q = work ? s_q[pk] : 0;
+                    const double cs = work ? s_cs[pk] : 1.0, sn = work ? s_sn[pk] : 0.0;
+                    if(work)   // columns: B <- B J, V <- V J
+                        for(int r = tid & 7; r < nV; r += 8) {
+                            const double bp = B[(size_t)r * nV + p], bq = B[(size_t)r * nV + q];
+                            const double vp = V[(size_t)r * nV + p], vq = V[(size_t)r * nV + q];
+                            B[(size_t)r * nV + p] = cs * bp - sn * bq; B[(size_t)r * nV + q] = sn * bp + cs * bq;
+                            V[(size_t)r * nV + p] = cs * vp - sn * vq; V[(size_t)r * nV + q] = sn * vp + cs * vq;
+                        }
+                    __threadfence_block();
+                    __syncthreads();
+                    if(work)   // rows: B <- J^T B
+                        for(int cidx = tid & 7; cidx < nV; cidx += 8) {
+                            const double bp = B[(size_t)p * nV + cidx], bq = B[(size_t)q * nV + cidx];
+                            B[(size_t)p * nV + cidx] = cs * bp - sn * bq; B[(size_t)q * nV + cidx] = sn * bp + cs * bq;
+                        }
+                    __threadfence_block();
+                    __syncthreads();
+                }
+            }
+        }
+        // eigenvalues D_k = B_kk; a non-finite or non-positive one is the reference's rcond <= 0 passthrough (oi_ensi.cpp:386-390)
+        double bad = 0.0;
+        for(int k = tid; k < nV; k += 256) { const double dk = B[(size_t)k * nV + k]; if(!(dk > 0.0) || isinf(dk)) bad = 1.0; }
+        if(block_sum(bad) > 0.0) continue;
+        // ---- w = P t = V D^-1 V^T t ; W = V diag(sqrt(c / D)) V^T + w 1^T (:401-444) -> B --------------------------------------------
+        for(int k = tid; k < nV; k += 256) {
+            double u = 0.0;
+            for(int r = 0; r < nV; ++r) u = __builtin_fma(V[(size_t)r * nV + k], v_t[r], u);   // (V^T t)_k
+            v_sq[k] = sqrt(c / B[(size_t)k * nV + k]);
+            v_X[k] = u / B[(size_t)k * nV + k];
+        }
+        __threadfence_block();
+        __syncthreads();
+        for(int k = tid; k < nV; k += 256) {
+            double wv = 0.0;
+            for(int r = 0; r < nV; ++r) wv = __builtin_fma(V[(size_t)k * nV + r], v_X[r], wv);
+            v_w[k] = wv;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for(long e = tid; e < (long)nV * nV; e += 256) {
+            const int ai = (int)(e / nV), bi = (int)(e - (long)ai * nV);
+            double sacc = 0.0;
+            for(int k = 0; k < nV; ++k) sacc = __builtin_fma(V[(size_t)ai * nV + k] * v_sq[k], V[(size_t)bi * nV + k], sacc);
+            B[e] = sacc + v_w[ai];
+        }
+        // ---- ensemble side (oi_ensi.cpp:447-553): thread e owns members e, e + 256, ... -------------------------------------------------
+        for(int k = tid; k < nV; k += 256) v_val[k] = (double)a.bg[(long)cell * E + a.validIdx[k]];
+        __threadfence_block();
+        __syncthreads();
+        float total = 0; int cnt = 0;
+        for(int k = 0; k < nV; ++k) { const float v = (float)v_val[k]; if(d_valid(v)) { total += v; cnt++; } }
+        const float ensMean = total / (float)cnt;
+        for(int k = tid; k < nV; k += 256) v_X[k] = v_val[k] - (double)ensMean;
+        __threadfence_block();
+        __syncthreads();
+        for(int e = tid; e < nV; e += 256) {
+            float acc = 0.0f;
+            for(int k = 0; k < nV; ++k) acc = (float)((double)acc + v_X[k] * B[(size_t)k * nV + e]);   // float += double product (:508-511)
+            float currIncrement = acc;
+            if(!a.allow_extrap) {   // :520-552; lY[e] is a LINEAR index into the n x nV column-major matrix
+                const int li_ = e % n, lk_ = e / n;
+                const unsigned oo = ~(unsigned)(keys[li_] & 0xffffffffull);
+                const double lYe = (double)a.gY[(long)oo * nV + lk_];
+                float maxInc = 0, minInc = 0;
+                for(int i = 0; i < n; ++i) {
+                    const unsigned oi_ = ~(unsigned)(keys[i] & 0xffffffffull);
+                    const float4 x4 = a.oaux[oi_];
+                    const float dv = (float)((double)x4.y - (lYe + (double)x4.z));
+                    if(i == 0 || dv > maxInc) maxInc = dv;
+                    if(i == 0 || dv < minInc) minInc = dv;
+                }
+                const double Xe = v_X[e];
+                const float memberIncrement = (float)((double)currIncrement - Xe);
+                if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + Xe);
+                else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + Xe);
+                else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + Xe);
+                else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + Xe);
+            }
+            a.out[(long)cell * E + a.validIdx[e]] = ensMean + currIncrement;
+        }
+        __syncthreads();
+    }
+}
+
 #include "ensi_multi.h"
 
 namespace {
@@ -744,8 +996,8 @@ struct EnsiWorkspace {
     DevBuf<int> flags, validIdx, err, cell_idx, obs_idx;
     DevBuf<unsigned> sel, meta;
     DevBuf<unsigned long long> hsigs;
-    DevBuf<double> gram, cpark;
-    DevBuf<unsigned long long> counters, big_keys;
+    DevBuf<double> gram, cpark, huge_mat;
+    DevBuf<unsigned long long> counters, big_keys, huge_keys;
     DevBuf<int> big_list, big_count;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -756,7 +1008,7 @@ thread_local int g_ensi_converge = 0;
 
 void gpp_release_ensi_workspace() {
     EnsiWorkspace& ws = g_ews;
-    ws.cpark.release(); ws.gram.release(); ws.sel.release();
+    ws.cpark.release(); ws.gram.release(); ws.sel.release(); ws.huge_mat.release(); ws.big_keys.release(); ws.huge_keys.release();
 }
 
 extern "C" int gpp_ensi_set_convergence(int to_convergence) {
@@ -858,7 +1110,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.s.scan_stats = timing_env("GPP_SCAN_STATS") ? ws.counters.p + 2 : nullptr;
     a.s.K = (max_points > 0 && max_points <= EN) ? max_points : EN;
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
-    a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;
+    a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV; a.valid_identity = (nV == E) ? 1 : 0;
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
     a.gram = ws.gram.get((size_t)a.ntiles * EN * EN);
     a.debug = timing_env("GPP_ENSI_DEBUG") ? atoi(timing_env("GPP_ENSI_DEBUG")) : 0;
@@ -869,8 +1121,8 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     // fail loudly there)
     const bool big_ok = (max_points == 0 || max_points > EN) && !path_env("GPP_ENSI_NO_BIG");
     if(big_ok) {
-        a.big_list = ws.big_list.get((size_t)C); a.big_count = ws.big_count.get(1);
-        GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, sizeof(int), stream()));
+        a.big_list = ws.big_list.get(2 * (size_t)C); a.huge_list = a.big_list + C; a.big_count = ws.big_count.get(2);
+        GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, 2 * sizeof(int), stream()));
     }
     GPP_HIP(hipEventRecord(ws.e0, stream()));
     if(use_pair) {
@@ -912,14 +1164,28 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         int nbig = 0;
         GPP_HIP(hipMemcpyAsync(&nbig, ws.big_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipStreamSynchronize(stream()));
-        if(nbig > 0 && nV > EMAXV)
-            runtime("optimal_interpolation_ensi: grid points with more than 32 usable observations are limited to 64 valid ensemble members on the GPU path");
-        if(nbig > 0) {
+        auto launch_huge = [&](const int* list, const int* count, int nitems) {   // no capacity of its own: scratch sized for this call
+            const int nwg = std::max(1, std::min(nitems, 512));
+            int kcap = 1;
+            while(kcap < S) kcap <<= 1;
+            a.huge_kcap = kcap;
+            a.huge_keys = ws.huge_keys.get((size_t)nwg * kcap);
+            a.huge_mat = ws.huge_mat.get((size_t)nwg * (2 * (size_t)nV * nV + 5 * (size_t)nV));
+            if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_huge<true>, dim3(nwg), dim3(256), 0, stream(), a, list, count);
+            else hipLaunchKernelGGL(k_ensi_huge<false>, dim3(nwg), dim3(256), 0, stream(), a, list, count);
+            GPP_HIP(hipGetLastError());
+        };
+        if(nbig > 0 && nV > EMAXV) launch_huge(a.big_list, a.big_count, nbig);      // more valid members than one lane each: the general kernel
+        else if(nbig > 0) {
             const int nwg = std::min(nbig, 1024);
             a.big_keys = ws.big_keys.get((size_t)nwg * EBIG_CAND);
             if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_big<true>, dim3(nwg), dim3(256), 0, stream(), a);
             else hipLaunchKernelGGL(k_ensi_big<false>, dim3(nwg), dim3(256), 0, stream(), a);
             GPP_HIP(hipGetLastError());
+            int nhuge = 0;   // cells with more candidates than the LDS sort of k_ensi_big holds
+            GPP_HIP(hipMemcpyAsync(&nhuge, ws.big_count.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream()));
+            GPP_HIP(hipStreamSynchronize(stream()));
+            if(nhuge > 0) launch_huge(a.huge_list, a.big_count + 1, nhuge);
         }
     }
     GPP_HIP(hipEventRecord(ws.e1, stream()));
@@ -934,11 +1200,12 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
         fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (use_pair ? 0.25 : 1.0) * (double)sw / (double)hc[1] : 0.0);
         unsigned long long tot = 0; for(int i = 0; i < 12; i++) tot += hc[40 + i];
-        unsigned long long tot2 = 0; for(int i = 0; i < 9; i++) tot2 += hc[60 + i];
-        if(tot2) { fprintf(stderr, "[gpp] ensi members phases (%% of wave cycles):"); for(int i = 0; i < 9; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[60 + i] / (double)tot2); fprintf(stderr, "\n"); }
+        unsigned long long tot2 = 0; for(int i = 0; i < 12; i++) tot2 += hc[60 + i];
+        if(tot2) { fprintf(stderr, "[gpp] ensi members phases (%% of wave cycles):"); for(int i = 0; i < 12; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[60 + i] / (double)tot2); fprintf(stderr, "\n"); }
         if(tot) { fprintf(stderr, "[gpp] ensi phases (%% of wave cycles):"); for(int i = 0; i < 10; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[40 + i] / (double)tot); fprintf(stderr, "\n"); }
     }
-    if(err & 1) runtime("optimal_interpolation_ensi: a grid point has more usable observations than the GPU path holds (512)");
+    if(err & 1) runtime(big_ok ? "Internal error. optimal_interpolation_ensi: candidate scratch of the general kernel too small"
+                               : "optimal_interpolation_ensi: a grid point has more usable observations than the 32-row tile kernel holds and the large-n kernels are switched off (GPP_ENSI_NO_BIG)");
     return GPP_OK;
     GPP_CATCH
 }
@@ -995,7 +1262,6 @@ extern "C" int gpp_optimal_interpolation_ensi_multi(int variant, gpp_points* bgr
     for(int e = 0; e < E; e++) if(flags[e]) valid.push_back(e);
     const int nV = (int)valid.size();
     if(nV == 0) { f_out.finish(); GPP_HIP(hipStreamSynchronize(stream())); return GPP_OK; }      // :419-420
-    if(variant == 3 && nV > EMAXV) runtime("optimal_interpolation_ensi_multi_utem: more than 64 valid ensemble members are not supported on the GPU path");
     if(variant == 1 && nV > 4096) runtime("optimal_interpolation_ensi_multi_ebe: more than 4096 valid ensemble members are not supported on the GPU path");
     ws.validIdx.upload(valid.data(), nV);
     ws.gYhat.get(S); ws.gY.get((size_t)S * nV); ws.gYm.get((size_t)S * nV); ws.obs0.get(S);
@@ -1022,7 +1288,7 @@ extern "C" int gpp_optimal_interpolation_ensi_multi(int variant, gpp_points* bgr
     if(a.s.st.fh) runtime("optimal_interpolation_ensi_multi: spatially varying structure functions are not supported on the GPU path");
     a.s.max_points = max_points;
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
-    a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV;
+    a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV; a.valid_identity = (nV == E) ? 1 : 0;
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p;
     ma.gYm = ws.gYm.p; ma.bgc = corr ? f_bgc.d : f_bg.d; ma.bratios = f_br.d;
@@ -1030,11 +1296,41 @@ extern "C" int gpp_optimal_interpolation_ensi_multi(int variant, gpp_points* bgr
     ma.oob = (variant != 3 && valid[nV - 1] != nV - 1) ? 1 : 0;
     const int nwg = std::min(C, 2048);
     a.big_keys = ws.big_keys.get((size_t)nwg * EBIG_CAND);
+    a.big_list = ws.big_list.get(2 * (size_t)C); a.huge_list = a.big_list + C; a.big_count = ws.big_count.get(2);
+    GPP_HIP(hipMemsetAsync(ws.big_count.p, 0, 2 * sizeof(int), stream()));
     GPP_HIP(hipEventRecord(ws.e0, stream()));
-    if(variant == 1) hipLaunchKernelGGL(k_ensi_multi<1>, dim3(nwg), dim3(256), 0, stream(), ma);
-    else if(variant == 2) hipLaunchKernelGGL(k_ensi_multi<2>, dim3(nwg), dim3(256), 0, stream(), ma);
-    else hipLaunchKernelGGL(k_ensi_multi<3>, dim3(nwg), dim3(256), 0, stream(), ma);
-    GPP_HIP(hipGetLastError());
+    const bool all_huge = variant == 3 && nV > EMAXV;   // utem keeps one member per lane in k_ensi_multi: more go to the general kernel
+    if(!all_huge) {
+        if(variant == 1) hipLaunchKernelGGL(k_ensi_multi<1>, dim3(nwg), dim3(256), 0, stream(), ma);
+        else if(variant == 2) hipLaunchKernelGGL(k_ensi_multi<2>, dim3(nwg), dim3(256), 0, stream(), ma);
+        else hipLaunchKernelGGL(k_ensi_multi<3>, dim3(nwg), dim3(256), 0, stream(), ma);
+        GPP_HIP(hipGetLastError());
+    }
+    int nhuge = C;
+    if(!all_huge) {
+        GPP_HIP(hipMemcpyAsync(&nhuge, ws.big_count.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipStreamSynchronize(stream()));
+    }
+    if(nhuge > 0) {   // the grid points beyond the LDS areas of k_ensi_multi: scratch sized for this call, within a budget
+        int kcap = 1;
+        while(kcap < S) kcap <<= 1;
+        const size_t ncap = (variant == 3) ? 0 : (size_t)((max_points > 0) ? std::min(max_points, S) : S);
+        const size_t stride = std::max(ncap * (ncap + 1) + (size_t)nV, 2 * (size_t)nV * nV + 6 * (size_t)nV);
+        size_t budget = (size_t)16 << 30;
+        if(path_env("GPP_OI_HUGE_BUDGET_MB")) budget = (size_t)atol(path_env("GPP_OI_HUGE_BUDGET_MB")) << 20;
+        const size_t per_wg = stride * sizeof(double) + (size_t)kcap * sizeof(unsigned long long);
+        if(per_wg > budget) runtime("optimal_interpolation_ensi_multi: a grid point may select " + std::to_string(ncap) + " observations: its system does not fit the scratch budget of the GPU path");
+        const int hwg = (int)std::max<size_t>(1, std::min<size_t>({(size_t)nhuge, (size_t)512, budget / per_wg}));
+        ma.e.huge_kcap = kcap; ma.huge_ncap = (int)ncap; ma.huge_stride = stride;
+        ma.e.huge_keys = ws.huge_keys.get((size_t)hwg * kcap);
+        ma.e.huge_mat = ws.huge_mat.get((size_t)hwg * stride);
+        const int* list = all_huge ? nullptr : a.huge_list;
+        const int* cnt = all_huge ? nullptr : a.big_count + 1;
+        if(variant == 1) hipLaunchKernelGGL(k_ensi_multi_huge<1>, dim3(hwg), dim3(256), 0, stream(), ma, list, cnt);
+        else if(variant == 2) hipLaunchKernelGGL(k_ensi_multi_huge<2>, dim3(hwg), dim3(256), 0, stream(), ma, list, cnt);
+        else hipLaunchKernelGGL(k_ensi_multi_huge<3>, dim3(hwg), dim3(256), 0, stream(), ma, list, cnt);
+        GPP_HIP(hipGetLastError());
+    }
     GPP_HIP(hipEventRecord(ws.e1, stream()));
     int err = 0;
     GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
@@ -1043,7 +1339,7 @@ extern "C" int gpp_optimal_interpolation_ensi_multi(int variant, gpp_points* bgr
     GPP_HIP(hipEventElapsedTime(&g_ensi_ms, ws.e0, ws.e1));
     if(err & 4) runtime("optimal_interpolation_ensi_multi: an ensemble member is invalid in front of a valid one: the reference indexes its innovation matrix with the original member index (oi_ensi_multi.cpp:565), which is out of bounds");
     if(err & 2) runtime("optimal_interpolation_ensi_multi: singular matrix at a grid point (arma::inv fails in the reference)");
-    if(err & 1) runtime("optimal_interpolation_ensi_multi: a grid point has more usable observations than the GPU path holds (64 for ebe / ebesc, 512 for utem)");
+    if(err & 1) runtime("Internal error. optimal_interpolation_ensi_multi: scratch of the general kernel too small");
     return GPP_OK;
     GPP_CATCH
 }

@@ -19,6 +19,8 @@ struct MultiArgs {
     const float* pobs2;         // ebe / ebesc: [S][E]
     const float* pbg2;          // ebe / ebesc: [S][E]
     int oob;                    // an invalid member in front of a valid one: the reference indexes out of bounds
+    int huge_ncap;              // k_ensi_multi_huge: most selected observations of a grid point (sizes its scratch)
+    size_t huge_stride;         // doubles of scratch per workgroup
 };
 
 // calc_statistic(Mean) / (Std) of row[0..n) through an accessor (util.cpp:22-75: sequential float accumulation)
@@ -115,7 +117,10 @@ __global__ __launch_bounds__(256) void k_ensi_multi(MultiArgs ma) {
         if(ncand == 0) continue;
         const bool truncated = sa.max_points > 0 && ncand > sa.max_points;
         const int n = truncated ? sa.max_points : ncand;
-        if(ncand > EBIG_CAND || n > (VARIANT == 3 ? EBIG_N : MULTI_N)) { if(tid == 0) atomicOr(a.err, 1); continue; }
+        if(ncand > EBIG_CAND || (VARIANT != 3 && n > MULTI_N)) {   // beyond the LDS areas of this kernel: k_ensi_multi_huge takes the cell
+            if(tid == 0) a.huge_list[atomicAdd(a.big_count + 1, 1)] = cell;
+            continue;
+        }
         if(ma.oob) { if(tid == 0) atomicOr(a.err, 4); continue; }
         // ---- order: rho descending (ties -> lower index) when the reference sorts, index order otherwise -------------------------------
         int np2 = 1;
@@ -402,6 +407,357 @@ __global__ __launch_bounds__(256) void k_ensi_multi(MultiArgs ma) {
                 else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + Xe);
             }
             a.out[(long)cell * E + ek] = ensMean + currIncrement;
+        }
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ensi_multi_huge: the same three filters for the grid points k_ensi_multi cannot hold (more than MULTI_N selected
+// observations for ebe / ebesc, more than EBIG_CAND candidates, more than 64 valid members for utem) -- the reference has
+// no such limits (oi_ensi_multi.cpp:395-418, 489-505).  Keys, matrices and vectors live in HBM scratch sized by the host for
+// the call (a.huge_keys, a.huge_mat); bitonic sort over global memory, pivoted LU / Jacobi in HBM.  Slow and general.
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_ensi_multi_huge(MultiArgs ma, const int* __restrict__ list, const int* __restrict__ count) {
+    const EnsiArgs& a = ma.e;
+    __shared__ float s_yc[16384];
+    __shared__ double s_rinv[64], s_dvec[64];
+    __shared__ double s_cs[32], s_sn[32];
+    __shared__ int s_p[32], s_q[32];
+    __shared__ double s_off[256];
+    __shared__ float s_st[4];
+    __shared__ int s_n, s_piv;
+    const int tid = threadIdx.x;
+    const ScanArgs& sa = a.s;
+    const DevStructure& st = sa.st;
+    const int nV = a.nV, E = a.E;
+    const int nlist = count ? *count : a.C;
+    unsigned long long* const keys = a.huge_keys + (size_t)blockIdx.x * a.huge_kcap;
+    double* const scratch = a.huge_mat + (size_t)blockIdx.x * ma.huge_stride;
+    auto block_sum = [&](double v) {
+        s_off[tid] = v;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+        const double r = s_off[0];
+        __syncthreads();
+        return r;
+    };
+    for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int cell = list ? list[li] : li;
+        const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
+        __syncthreads();
+        if(tid == 0) s_n = 0;
+        __syncthreads();
+        const float R = st.R;
+        const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz), pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
+        const int bx0 = min(max((int)floorf((pa - R - sa.amin) * sa.inv_s) - 1, 0), sa.nbx - 1), bx1 = min(max((int)floorf((pa + R - sa.amin) * sa.inv_s) + 1, 0), sa.nbx - 1);
+        const int by0 = min(max((int)floorf((pb - R - sa.bmin) * sa.inv_s) - 1, 0), sa.nby - 1), by1 = min(max((int)floorf((pb + R - sa.bmin) * sa.inv_s) + 1, 0), sa.nby - 1);
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        for(int by = by0; by <= by1; ++by) {
+            const int js = sa.bin_start[by * sa.nbx + bx0], je = sa.bin_start[by * sa.nbx + bx1 + 1];
+            for(int j = js + tid; j < je; j += 256) {
+                const float4 rec = sa.pgeo[j];
+                if(!(rec.x > lox && rec.x < hix && rec.y > loy && rec.y < hiy && rec.z > loz && rec.z < hiz)) continue;
+                const float2 met = sa.smeta[j];
+                if(!(d_chord(rec.x, rec.y, rec.z, gx, gy, gz) <= R)) continue;
+                const float rho = d_corr(st, gx, gy, gz, ge, gl, rec.x, rec.y, rec.z, rec.w, met.x, true);
+                if(!(rho > 0.0f)) continue;
+                const int k = atomicAdd(&s_n, 1);
+                if(k < a.huge_kcap) keys[k] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~__float_as_int(met.y));
+            }
+        }
+        __syncthreads();
+        const int ncand = s_n;
+        if(ncand == 0) continue;
+        const bool truncated = sa.max_points > 0 && ncand > sa.max_points;
+        const int n = truncated ? sa.max_points : ncand;
+        int np2 = 1;
+        while(np2 < ncand) np2 <<= 1;
+        if(np2 > a.huge_kcap || (VARIANT != 3 && n > ma.huge_ncap)) { if(tid == 0) atomicOr(a.err, 1); continue; }   // (sized for the call: cannot happen)
+        if(ma.oob) { if(tid == 0) atomicOr(a.err, 4); continue; }
+        for(int i = ncand + tid; i < np2; i += 256) keys[i] = 0ull;
+        __threadfence_block();
+        __syncthreads();
+        for(int k = 2; k <= np2; k <<= 1) {
+            for(int j = k >> 1; j > 0; j >>= 1) {
+                for(int i = tid; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if(ixj > i) {
+                        const unsigned long long x = keys[i], y = keys[ixj];
+                        const unsigned long long kx = truncated ? x : (x & 0xffffffffull), ky = truncated ? y : (y & 0xffffffffull);
+                        const bool desc = (i & k) == 0;
+                        if(desc ? (kx < ky) : (kx > ky)) { keys[i] = y; keys[ixj] = x; }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+        const float ratio = ma.bratios[cell];
+        if(VARIANT != 3) {
+            // ---- K = r (A + R_dd)^-1: the transposed system in HBM, right-hand side in column n (oi_ensi_multi.cpp:570-588) -----------
+            double* const A = scratch;                               // [n][n + 1]
+            const int AP = n + 1;
+            double* const xL = scratch + (size_t)ma.huge_ncap * (ma.huge_ncap + 1);   // [nV]
+            if(VARIANT == 1) {
+                const float* rowc = ma.bgc + (long)cell * E;
+                if(tid == 0) {
+                    s_st[0] = seq_mean_f(nV, [&](int k) { return rowc[a.validIdx[k]]; });
+                    s_st[1] = seq_std_f(nV, [&](int k) { return rowc[a.validIdx[k]]; });
+                }
+                __syncthreads();
+                const float mean = s_st[0], sd = s_st[1];
+                const bool ok = d_valid(mean) && d_valid(sd) && sd > 0.0013f;
+                for(int k = tid; k < nV; k += 256) xL[k] = ok ? 1.0 / sqrt((double)(nV - 1)) * (double)(rowc[a.validIdx[k]] - mean) / (double)sd : 0.0;   // :531-541
+                __threadfence_block();
+                __syncthreads();
+            }
+            for(long e2 = tid; e2 < (long)n * n; e2 += 256) {
+                const int i = (int)(e2 / n), j = (int)(e2 - (long)i * n);
+                const unsigned oi = ~(unsigned)(keys[i] & 0xffffffffull), oj = ~(unsigned)(keys[j] & 0xffffffffull);
+                const float4 gi = a.ogeo[oi], gj = a.ogeo[oj];
+                const float4 xi = a.oaux[oi], xj = a.oaux[oj];
+                const float cc = d_corr(st, gi.x, gi.y, gi.z, gi.w, xi.x, gj.x, gj.y, gj.z, gj.w, xj.x, false);
+                double zz = 1.0;
+                if(VARIANT == 1) { zz = 0.0; for(int k = 0; k < nV; ++k) zz += (double)a.gY[(long)oi * nV + k] * (double)a.gY[(long)oj * nV + k]; }
+                A[(size_t)j * AP + i] = (double)cc * zz + (i == j ? (double)xi.w : 0.0);
+            }
+            for(int i = tid; i < n; i += 256) {
+                const unsigned long long key = keys[i];
+                const unsigned oi = ~(unsigned)(key & 0xffffffffull);
+                const float rho = __uint_as_float((unsigned)(key >> 32));
+                double rz = 1.0;
+                if(VARIANT == 1) { rz = 0.0; for(int k = 0; k < nV; ++k) rz += xL[k] * (double)a.gY[(long)oi * nV + k]; }
+                A[(size_t)i * AP + n] = (double)rho * rz;
+            }
+            __threadfence_block();
+            __syncthreads();
+            bool singular = false;
+            for(int k = 0; k < n; ++k) {
+                // pivot search: every thread scans a share of the column, the workgroup reduces (value, then lowest row)
+                double best = -1.0; int bp = -1;
+                for(int r = k + tid; r < n; r += 256) { const double v = fabs(A[(size_t)r * AP + k]); if(v > best) { best = v; bp = r; } }
+                s_off[tid] = best;
+                __syncthreads();
+                for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] = fmax(s_off[tid], s_off[tid + off]); __syncthreads(); }
+                const double gbest = s_off[0];
+                __syncthreads();
+                if(tid == 0) s_piv = 0x7fffffff;
+                __syncthreads();
+                if(bp >= 0 && best == gbest) atomicMin(&s_piv, bp);     // the first row holding the largest magnitude, as a sequential search finds it
+                __syncthreads();
+                const int p = (gbest > 0.0 && gbest < INFINITY) ? s_piv : -1;
+                if(p < 0) { singular = true; break; }
+                if(p != k) for(int cidx = tid; cidx <= n; cidx += 256) { const double t = A[(size_t)k * AP + cidx]; A[(size_t)k * AP + cidx] = A[(size_t)p * AP + cidx]; A[(size_t)p * AP + cidx] = t; }
+                __threadfence_block();
+                __syncthreads();
+                const double pinv = 1.0 / A[(size_t)k * AP + k];
+                const long nn = (long)(n - k - 1) * (n - k);
+                for(long e2 = tid; e2 < nn; e2 += 256) {
+                    const int r = k + 1 + (int)(e2 / (n - k)), cidx = k + 1 + (int)(e2 % (n - k));
+                    A[(size_t)r * AP + cidx] -= A[(size_t)r * AP + k] * pinv * A[(size_t)k * AP + cidx];
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            if(singular) { if(tid == 0) atomicOr(a.err, 2); continue; }
+            if(tid == 0) {
+                for(int r = n - 1; r >= 0; --r) {
+                    double sacc = A[(size_t)r * AP + n];
+                    for(int cidx = r + 1; cidx < n; ++cidx) sacc -= A[(size_t)r * AP + cidx] * A[(size_t)cidx * AP + n];
+                    A[(size_t)r * AP + n] = sacc / A[(size_t)r * AP + r];
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            for(int k = tid; k < nV; k += 256) {
+                const int ei = a.validIdx[k];
+                double sacc = 0.0; float maxInc = 0, minInc = 0;
+                for(int i = 0; i < n; ++i) {
+                    const unsigned oi = ~(unsigned)(keys[i] & 0xffffffffull);
+                    const float inn = ma.pobs2[(long)oi * E + ei] - ma.pbg2[(long)oi * E + ei];
+                    sacc = __builtin_fma(A[(size_t)i * AP + n], (double)inn, sacc);
+                    if(i == 0 || inn > maxInc) maxInc = inn;
+                    if(i == 0 || inn < minInc) minInc = inn;
+                }
+                double dx = (double)ratio * sacc;
+                if(!a.allow_extrap) {
+                    float increment = (float)dx;
+                    if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                    else if(maxInc < 0 && increment > 0) increment = 0;
+                    else if(minInc < 0 && increment < minInc) increment = minInc;
+                    else if(minInc > 0 && increment < 0) increment = 0;
+                    dx = (double)increment;
+                }
+                a.out[(long)cell * E + ei] = (float)((double)a.bg[(long)cell * E + ei] + dx);
+            }
+            continue;
+        }
+        // ================================ utem: E x E square-root filter (:1060-1265), everything in HBM ================================
+        double* const B = scratch;
+        double* const V = B + (size_t)nV * nV;
+        double* const v_t = V + (size_t)nV * nV;
+        double* const v_w = v_t + nV;
+        double* const v_X = v_w + nV;
+        double* const v_sq = v_X + nV;
+        double* const v_val = v_sq + nV;
+        double* const v_valc = v_val + nV;
+        const int chunk = max(1, min(64, 16384 / max(nV, 1)));
+        for(long e = tid; e < (long)nV * nV; e += 256) { const int ai = (int)(e / nV), bi = (int)(e - (long)ai * nV); B[e] = 0.0; V[e] = (ai == bi) ? 1.0 : 0.0; }
+        for(int k = tid; k < nV; k += 256) v_t[k] = 0.0;
+        __threadfence_block();
+        __syncthreads();
+        for(int i0 = 0; i0 < n; i0 += chunk) {
+            const int m = min(chunk, n - i0);
+            for(int e = tid; e < m * nV; e += 256) {
+                const int i = e / nV, k = e - i * nV;
+                const unsigned orig = ~(unsigned)(keys[i0 + i] & 0xffffffffull);
+                s_yc[i * nV + k] = a.gY[(long)orig * nV + k];
+            }
+            if(tid < m) {
+                const unsigned long long key = keys[i0 + tid];
+                const unsigned orig = ~(unsigned)(key & 0xffffffffull);
+                const float4 x4 = a.oaux[orig];                       // laf, obs, gYhat, pratio
+                s_rinv[tid] = (double)__uint_as_float((unsigned)(key >> 32)) / (double)x4.w;   // :1078
+                s_dvec[tid] = (double)x4.y - (double)x4.z;
+            }
+            __syncthreads();
+            for(long e = tid; e < (long)nV * nV; e += 256) {
+                const int ai = (int)(e / nV), bi = (int)(e - (long)ai * nV);
+                double sacc = B[e];
+                for(int i = 0; i < m; ++i) sacc = __builtin_fma((double)s_yc[i * nV + ai] * s_rinv[i], (double)s_yc[i * nV + bi], sacc);
+                B[e] = sacc;
+            }
+            for(int k = tid; k < nV; k += 256) {
+                double acct = v_t[k];
+                for(int i = 0; i < m; ++i) acct = __builtin_fma((double)s_yc[i * nV + k] * s_rinv[i], s_dvec[i], acct);
+                v_t[k] = acct;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        for(int k = tid; k < nV; k += 256) B[(size_t)k * nV + k] += 1.0;    // Pinv = C Yc + I (:1085)
+        __threadfence_block();
+        __syncthreads();
+        const int mm = nV + (nV & 1), half = mm >> 1;
+        double trl = 0.0;
+        for(int k = tid; k < nV; k += 256) trl += fabs(B[(size_t)k * nV + k]);
+        const double tr = block_sum(trl);
+        for(int sweep = 0; sweep < 60 && nV > 1; ++sweep) {
+            double off2 = 0.0;
+            for(long e = tid; e < (long)nV * nV; e += 256) { const int i = (int)(e / nV), j = (int)(e - (long)i * nV); if(j < i) { const double v = B[e]; off2 += v * v; } }
+            off2 = block_sum(off2);
+            if(!(off2 > 1e-22 * tr * tr)) break;
+            for(int step = 0; step < mm - 1; ++step) {
+                for(int g0 = 0; g0 < half; g0 += 32) {
+                    const int npair = min(32, half - g0);
+                    if(tid < npair) {
+                        const int t = g0 + tid;
+                        int p, q;
+                        if(t == 0) { p = mm - 1; q = step; }
+                        else { p = (step + t) % (mm - 1); q = (step - t + (mm - 1)) % (mm - 1); }
+                        if(p > q) { const int t_ = p; p = q; q = t_; }
+                        double cs = 1.0, sn = 0.0;
+                        if(q < nV) {
+                            const double apq = B[(size_t)p * nV + q];
+                            if(apq != 0.0) {
+                                const double theta = (B[(size_t)q * nV + q] - B[(size_t)p * nV + p]) / (2.0 * apq);
+                                const double t_ = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                                cs = 1.0 / sqrt(t_ * t_ + 1.0); sn = t_ * cs;
+                                if(!(fabs(theta) < 1e150)) { cs = 1.0; sn = 0.0; }
+                            }
+                        }
+                        else q = p;
+                        s_p[tid] = p; s_q[tid] = q; s_cs[tid] = cs; s_sn[tid] = sn;
+                    }
+                    __syncthreads();
+                    const int pk = tid >> 3;
+                    const bool work = pk < npair && s_p[pk] != s_q[pk];
+                    const int p = work ? s_p[pk] : 0, q = work ? s_q[pk] : 0;
+                    const double cs = work ? s_cs[pk] : 1.0, sn = work ? s_sn[pk] : 0.0;
+                    if(work)
+                        for(int r = tid & 7; r < nV; r += 8) {
+                            const double bp = B[(size_t)r * nV + p], bq = B[(size_t)r * nV + q];
+                            const double vp = V[(size_t)r * nV + p], vq = V[(size_t)r * nV + q];
+                            B[(size_t)r * nV + p] = cs * bp - sn * bq; B[(size_t)r * nV + q] = sn * bp + cs * bq;
+                            V[(size_t)r * nV + p] = cs * vp - sn * vq; V[(size_t)r * nV + q] = sn * vp + cs * vq;
+                        }
+                    __threadfence_block();
+                    __syncthreads();
+                    if(work)
+                        for(int cidx = tid & 7; cidx < nV; cidx += 8) {
+                            const double bp = B[(size_t)p * nV + cidx], bq = B[(size_t)q * nV + cidx];
+                            B[(size_t)p * nV + cidx] = cs * bp - sn * bq; B[(size_t)q * nV + cidx] = sn * bp + cs * bq;
+                        }
+                    __threadfence_block();
+                    __syncthreads();
+                }
+            }
+        }
+        double bad = 0.0;
+        for(int k = tid; k < nV; k += 256) { const double dk = B[(size_t)k * nV + k]; if(!(dk > 0.0) || isinf(dk)) bad = 1.0; }
+        if(block_sum(bad) > 0.0) continue;   // rcond <= 0 -> raw values (:1087-1090)
+        const double cscale = (double)(nV - 1);
+        for(int k = tid; k < nV; k += 256) {
+            double u = 0.0;
+            for(int r = 0; r < nV; ++r) u = __builtin_fma(V[(size_t)r * nV + k], v_t[r], u);
+            v_sq[k] = sqrt(cscale / B[(size_t)k * nV + k]);
+            v_X[k] = u / B[(size_t)k * nV + k];
+        }
+        __threadfence_block();
+        __syncthreads();
+        for(int k = tid; k < nV; k += 256) {
+            double wv = 0.0;
+            for(int r = 0; r < nV; ++r) wv = __builtin_fma(V[(size_t)k * nV + r], v_X[r], wv);
+            v_w[k] = wv;
+        }
+        for(int k = tid; k < nV; k += 256) { const int ek = a.validIdx[k]; v_val[k] = (double)a.bg[(long)cell * E + ek]; v_valc[k] = (double)ma.bgc[(long)cell * E + ek]; }
+        __threadfence_block();
+        __syncthreads();
+        if(tid == 0) {   // ensemble statistics of this grid point (:1141-1179)
+            float total = 0, totalc = 0;
+            for(int k = 0; k < nV; ++k) { total += (float)v_val[k]; totalc += (float)v_valc[k]; }
+            s_st[0] = total / (float)nV; s_st[2] = totalc / (float)nV;
+            s_st[1] = seq_std_f(nV, [&](int k) { return (float)v_val[k]; });
+            s_st[3] = seq_std_f(nV, [&](int k) { return (float)v_valc[k]; });
+        }
+        __syncthreads();
+        const float ensMean = s_st[0], ensStd = s_st[1], ensMeanC = s_st[2], ensStdC = s_st[3];
+        const float const_fact = (float)(1.0 / sqrt((double)(nV - 1)));
+        for(long e = tid; e < (long)nV * nV; e += 256) {
+            const int ai = (int)(e / nV), bi = (int)(e - (long)ai * nV);
+            double sacc = 0.0;
+            for(int k = 0; k < nV; ++k) sacc = __builtin_fma(V[(size_t)ai * nV + k] * v_sq[k], V[(size_t)bi * nV + k], sacc);
+            B[e] = (double)ensStd * sacc + (double)ratio * v_w[ai];    // :1181-1185
+        }
+        for(int k = tid; k < nV; k += 256) v_X[k] = (ensStdC <= 0.0013f) ? 0.0 : (double)((const_fact * ((float)v_valc[k] - ensMeanC)) / ensStdC);   // X_corr
+        __threadfence_block();
+        __syncthreads();
+        for(int e = tid; e < nV; e += 256) {
+            float acc = 0.0f;
+            for(int k = 0; k < nV; ++k) acc = (float)((double)acc + v_X[k] * B[(size_t)k * nV + e]);   // :1229-1233
+            float currIncrement = acc;
+            const double Xe = v_val[e] - (double)ensMean;
+            if(!a.allow_extrap) {
+                const int li_ = e % n, lk_ = e / n;
+                const unsigned oo = ~(unsigned)(keys[li_] & 0xffffffffull);
+                const double lYe = (double)ma.gYm[(long)oo * nV + lk_];
+                float maxInc = 0, minInc = 0;
+                for(int i = 0; i < n; ++i) {
+                    const unsigned oi_ = ~(unsigned)(keys[i] & 0xffffffffull);
+                    const float4 x4 = a.oaux[oi_];
+                    const float dv = (float)((double)x4.y - (lYe + (double)x4.z));
+                    if(i == 0 || dv > maxInc) maxInc = dv;
+                    if(i == 0 || dv < minInc) minInc = dv;
+                }
+                const float memberIncrement = (float)((double)currIncrement - Xe);
+                if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + Xe);
+                else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + Xe);
+                else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + Xe);
+                else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + Xe);
+            }
+            a.out[(long)cell * E + a.validIdx[e]] = ensMean + currIncrement;
         }
         __syncthreads();
     }

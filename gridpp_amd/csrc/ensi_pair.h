@@ -186,6 +186,10 @@ __device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], d
 }
 
 
+// original index of valid member k (no load when every member is valid: a dependent load costs a trip through a memory system that
+// thousands of waves are streaming their park rows through)
+__device__ __forceinline__ int ensi_member(const EnsiArgs& a, const int k) { return a.valid_identity ? k : a.validIdx[k]; }
+
 // cell of lane `l` of tile `tile` (the same mapping in both kernels)
 __device__ __forceinline__ int ensi_cell_of(const EnsiArgs& a, const int tile, const int l) {
     if(a.tiled2d) {
@@ -447,12 +451,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 double* const park = a.cpark + ((size_t)(tile - a.tile0) * 64 + (h ? lb : la)) * ENSI_PARK_D;
 #pragma unroll
                 for(int j = 0; j < 32; j += 2) {
-                    double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&park[i * 32 + j]) = w;
-                    double2 v; v.x = b[j]; v.y = b[j + 1]; *reinterpret_cast<double2*>(&park[1024 + i * 32 + j]) = v;
+                    // (interleaved: pair j / 2 of every row side by side, U^T B U rows in slots 0..31, U rows in slots 32..63, so that
+                    //  k_ensi_members reads 1 KB of contiguous memory per load instruction and every lane still receives ITS row)
+                    double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&park[(j >> 1) * 128 + (32 + i) * 2]) = w;
+                    double2 v; v.x = b[j]; v.y = b[j + 1]; *reinterpret_cast<double2*>(&park[(j >> 1) * 128 + i * 2]) = v;
                 }
                 park[2048 + i] = sD;
                 park[2080 + i] = (i < n) ? sD * dobs : 0.0;
                 park[2112 + i] = (double)rho;
+                park[2144 + i] = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(o1.y) << 32) | (unsigned long long)orig_i));
+                park[2176 + i] = __longlong_as_double((long long)(unsigned long long)__float_as_uint(o1.z));
             }
             EPROF(4)   // park
         }
@@ -489,22 +497,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int tile = a.tile0 + (int)(blockIdx.x >> 6), lcell = (int)(blockIdx.x & 63);
     const int cell_l = ensi_cell_of(a, tile, lcell);
     if(cell_l < 0) return;
+    // Everything this cell needs comes in ONE round of independent loads: its length / order flag, its member values and its park
+    // (k_ensi_pair left the selection and the observation records there too: the chain meta -> selection -> observation record
+    // was three trips through a saturated memory system, 47 % of this kernel's wave cycles)
     const unsigned meta = a.meta[(size_t)tile * 64 + lcell];
-    const int n = (int)(meta & 0xffu);
-    if(n == 0) return;   // no observation in range (the output already holds the background) or a cell of k_ensi_big
-    // this cell's values of the first 64 valid members: needed late (ensemble mean, X), asked for first
-    const float v0 = (lane < nV) ? a.bg[(long)cell_l * E + a.validIdx[lane]] : 0.0f;
+    const float v0 = (lane < nV) ? a.bg[(long)cell_l * E + ensi_member(a, lane)] : 0.0f;
     const double* const park = a.cpark + ((size_t)blockIdx.x) * ENSI_PARK_D;
-    const unsigned orig_i = (i < n) ? a.sel[(size_t)tile * EN * 64 + i * 64 + lcell] : 0xffffffffu;
-    float4 o1 = make_float4(NAN, 0, 0, 1);
-    if(i < n) o1 = a.oaux[orig_i];
+    const unsigned long long pk0 = __double_as_longlong(park[2144 + i]), pk1 = __double_as_longlong(park[2176 + i]);
     const float rho = (float)park[2112 + i];
-    const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
-    const double sqc = sqrt(c);
+    const double p_sD = park[2048 + i], p_r1 = park[2080 + i];
     // lanes 32..63: row i of U; lanes 0..31: row i of U^T B U (e[i]: eigenvalue estimate d_i, the rest: the off-diagonal part E)
     double e[32];
 #pragma unroll
-    for(int j = 0; j < 32; j += 2) { const double2 w = *reinterpret_cast<const double2*>(&park[(h ? 0 : 1024) + i * 32 + j]); e[j] = w.x; e[j + 1] = w.y; }
+    for(int j = 0; j < 32; j += 2) { const double2 w = *reinterpret_cast<const double2*>(&park[(j >> 1) * 128 + lane * 2]); e[j] = w.x; e[j + 1] = w.y; }
+    const int n = (int)(meta & 0xffu);
+    if(n == 0) return;   // no observation in range (the output already holds the background) or a cell of k_ensi_big
+    const unsigned orig_i = (i < n) ? (unsigned)pk0 : 0xffffffffu;
+    float4 o1 = make_float4(NAN, 0, 0, 1);
+    if(i < n) { o1.y = __uint_as_float((unsigned)(pk0 >> 32)); o1.z = __uint_as_float((unsigned)pk1); }
+    const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
+    const double sqc = sqrt(c);
+#ifdef GPP_ENSI_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    EPROF(9)    // (profile build: the one round of loads, waited for)
+#endif
     // spectral functions (lane i < 32: eigenvalue i)
     double ei = 0.0;
 #pragma unroll
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double rt = sqrt(c + S);                    // a_i
     const double dwv = -1.0 / (rt * (rt + sqc));      // W_sym = I + A^T g(B) A,  g(S) = -1 / (a (a + sqrt(c))),  a = sqrt(c + S)
     const double inv = 1.0 / (c + S);
-    if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = park[2048 + i]; s_r1[i] = park[2080 + i]; s_dw[i] = dwv; s_rt[i] = rt; }
+    if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = p_sD; s_r1[i] = p_r1; s_dw[i] = dwv; s_rt[i] = rt; }
     __syncthreads();
     EPROF(0)   // park loads, spectral scalars
     // ---- g(D + E) to second order in E, without eigenvalue gaps in any denominator.  With M = c I + D + E:
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // ensemble mean: sequential float sum over the valid members in member order (oi_ensi.cpp:447-461)
         float total = 0.0f;
         for(int m0 = 0; m0 < nV; m0 += 64) {
-            const float v = (m0 == 0) ? v0 : ((m0 + lane < nV) ? a.bg[(long)cell_l * E + a.validIdx[m0 + lane]] : 0.0f);
+            const float v = (m0 == 0) ? v0 : ((m0 + lane < nV) ? a.bg[(long)cell_l * E + ensi_member(a, m0 + lane)] : 0.0f);
             const int kend = min(64, nV - m0);
             for(int k = 0; k < kend; ++k) total += readlane_f(v, k);
         }
@@ -742,7 +758,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     q[j] = (half == 0 || h == 1) ? v.x : q[j]; q[j + 1] = (half == 0 || h == 1) ? v.y : q[j + 1];
                 }
             }
-            const float value = (e0_ == 0) ? v0 : ((e < nV) ? a.bg[(long)cell_l * E + a.validIdx[e]] : 0.0f);
+            const float value = (e0_ == 0) ? v0 : ((e < nV) ? a.bg[(long)cell_l * E + ensi_member(a, e)] : 0.0f);
             const double X = (double)value - (double)ensMean;
             EPROF(6)   // transposition
             // total_e = sum_k X_k W(k,e), W(k,e) = [k == e] + sum_i Y(i,k) q_e(i) + w_k, float accumulation in k order (:505-511)
@@ -771,7 +787,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const double wo = __shfl_xor(wk, 32);
                     const float vk64 = __shfl(v0, kk & 63);
                     if(h == 0) {
-                        const float vk = (kk < 64) ? vk64 : ((kk < nV) ? a.bg[(long)cell_l * E + a.validIdx[kk]] : 0.0f);
+                        const float vk = (kk < 64) ? vk64 : ((kk < nV) ? a.bg[(long)cell_l * E + ensi_member(a, kk)] : 0.0f);
                         double2 xw; xw.x = (double)vk - (double)ensMean; xw.y = wk + wo;
                         *reinterpret_cast<double2*>(&sB[i * PP + 32]) = xw;
                     }
@@ -810,11 +826,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + X);
                 else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + X);
             }
-            if(e < nV) a.out[(long)cell_l * E + a.validIdx[e]] = ensMean + currIncrement;   // :553
+            if(e < nV) a.out[(long)cell_l * E + ensi_member(a, e)] = ensMean + currIncrement;   // :553
         }
 
 #ifdef GPP_ENSI_PROFILE
     EPROF(8)   // clamp, store
-    if(lane == 0 && a.counters) for(int k = 0; k < 9; ++k) atomicAdd(&a.counters[60 + k], prof[k]);
+    if(lane == 0 && a.counters) for(int k = 0; k < 12; ++k) atomicAdd(&a.counters[60 + k], prof[k]);
 #endif
 }

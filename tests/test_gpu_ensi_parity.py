@@ -90,9 +90,11 @@ def _structures():
         ("soar", lambda g: g.SoarStructure(6000, 200, 0.5), lambda O: O.Struct("Soar", 6000, 200, 0.5)),
         ("toar", lambda g: g.ToarStructure(5000, 150, 0.4), lambda O: O.Struct("Toar", 5000, 150, 0.4)),
         ("powerlaw", lambda g: g.PowerlawStructure(4000, 1, 0.7), lambda O: O.Struct("Powerlaw", 4000, 1, 0.7)),
-        ("linear", lambda g: g.LinearStructure(40000, 600, 1.4), lambda O: O.Struct("Linear", 40000, 600, 1.4)),
-        ("multiple", lambda g: g.MultipleStructure(g.BarnesStructure(15000), g.LinearStructure(0, 600, 0), g.PowerlawStructure(1, 1, 0.7)),
-         lambda O: O.Struct.multiple(O.Struct("Barnes", 15000), O.Struct("Linear", 0, 600, 0), O.Struct("Powerlaw", 1, 1, 0.7))),
+        # (the Linear kernel has no localization distance of its own, structure.cpp:765-789: it serves as a vertical / laf factor)
+        ("multiple_linear", lambda g: g.MultipleStructure(g.BarnesStructure(15000), g.LinearStructure(0, 0.2, 0), g.PowerlawStructure(1, 1, 0.7)),
+         lambda O: O.Struct.multiple(O.Struct("Barnes", 15000), O.Struct("Linear", 0, 0.2, 0), O.Struct("Powerlaw", 1, 1, 0.7))),
+        ("multiple_nested", lambda g: g.MultipleStructure(g.SoarStructure(6000), g.MultipleStructure(g.BarnesStructure(1), g.CressmanStructure(1, 400, 1), g.BarnesStructure(1)), g.BarnesStructure(1, 1, 0.6)),
+         lambda O: O.Struct.multiple(O.Struct("Soar", 6000), O.Struct.multiple(O.Struct("Barnes", 1), O.Struct("Cressman", 1, 400, 1), O.Struct("Barnes", 1)), O.Struct("Barnes", 1, 1, 0.6))),
         ("crossvalidation", lambda g: g.CrossValidation(g.BarnesStructure(15000, 200, 0.5), 4000),
          lambda O: O.Struct("Barnes", 15000, 200, 0.5).cross_validation(4000)),
     ]
@@ -101,7 +103,7 @@ def _structures():
 @pytest.mark.parametrize("which", [s[0] for s in _structures()])
 @pytest.mark.parametrize("max_points", [12, 0])
 def test_ensi_other_structure_functions(which, max_points):
-    """EnSI with Cressman / SOAR / TOAR / Powerlaw / Linear kernels, a MultipleStructure and a CrossValidation wrapper
+    """EnSI with Cressman / SOAR / TOAR / Powerlaw kernels, MultipleStructures (a Linear vertical factor, a nested one) and a CrossValidation wrapper
     (oi_ensi.cpp:213,250: localization_distance(p1) and corr_background(p1, p2) of ANY structure; structure.cpp:287-944),
     the 32-row tile path (max_points 12) and the large-n kernel (max_points 0), against the oracle."""
     import gridpp_amd as gridpp
@@ -204,14 +206,20 @@ def test_ensi_large_n_with_elevation_nan_obs_and_invalid_member():
 
 
 def test_ensi_large_n_limits():
-    """480 usable observations per grid point work (several 64-observation chunks of Y); 600 fail loudly, not silently."""
-    import gridpp_amd as gridpp
+    """No capacity limit (oi_ensi.cpp:187-201,244-261 have none): 480 usable observations per grid point (several chunks of Y in
+    k_ensi_big), 600 observations with 80 valid members (beyond one member per lane: k_ensi_huge, everything in HBM scratch), and
+    9 000 candidates per grid point (beyond the LDS sort of k_ensi_big) all return the oracle's values."""
     c = case(901, 5, 6, 16, 480)
     out, ref = run(c, 200000, 0)                     # every observation is in range of every cell
     check(out, ref, c[2])
-    c2 = case(902, 4, 4, 8, 600)
-    with pytest.raises(RuntimeError, match="more usable observations"):
-        run(c2, 200000, 0)
+    c2 = case(902, 4, 4, 80, 600)
+    out, ref = run(c2, 200000, 0)
+    check(out, ref, c2[2])
+    out, ref = run(c2, 200000, 45, allow=False)      # the same ensemble with the top-45 cut and the anti-extrapolation clamp
+    check(out, ref, c2[2])
+    c3 = case(903, 2, 3, 6, 9000)
+    out, ref = run(c3, 300000, 40)                   # 9 000 candidates, 40 kept
+    check(out, ref, c3[2])
 
 
 # ---- vectors of an independent LAPACK restatement + the analytic 1-observation update (tests/golden/ensi_cases.npz,
