@@ -1081,9 +1081,9 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
                        f_obs.d, f_sig.d, (const float*)ws.gYhat.p, (const float*)nullptr, 0, ws.pgeo.p, ws.oaux.p);
     GPP_HIP(hipGetLastError());
-    ws.err.get(1); ws.counters.get(80);
+    ws.err.get(1); ws.counters.get(80 + 1024 * 32);
     GPP_HIP(hipMemsetAsync(ws.err.p, 0, sizeof(int), stream()));
-    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * 80, stream()));
+    GPP_HIP(hipMemsetAsync(ws.counters.p, 0, sizeof(unsigned long long) * (80 + 1024 * 32), stream()));
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); }
 
     EnsiArgs a = EnsiArgs();
@@ -1192,13 +1192,15 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     int err = 0;
     GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
     f_out.finish();
-    unsigned long long hc[80];
-    if(timing_env("GPP_ENSI_STATS")) GPP_HIP(hipMemcpyAsync(hc, ws.counters.p, sizeof(hc), hipMemcpyDeviceToHost, stream()));
+    static thread_local std::vector<unsigned long long> hcv(80 + 1024 * 32);
+    unsigned long long* const hc = hcv.data();
+    if(timing_env("GPP_ENSI_STATS")) GPP_HIP(hipMemcpyAsync(hc, ws.counters.p, sizeof(unsigned long long) * hcv.size(), hipMemcpyDeviceToHost, stream()));
     GPP_HIP(hipStreamSynchronize(stream()));
     GPP_HIP(hipEventElapsedTime(&g_ensi_ms, ws.e0, ws.e1));
     if(timing_env("GPP_ENSI_STATS")) {
         unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
         fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (use_pair ? 0.25 : 1.0) * (double)sw / (double)hc[1] : 0.0);
+        for(int sl = 0; sl < 1024; sl++) for(int i = 0; i < 12; i++) { hc[40 + i] += hc[80 + sl * 32 + i]; hc[60 + i] += hc[80 + sl * 32 + 16 + i]; }
         unsigned long long tot = 0; for(int i = 0; i < 12; i++) tot += hc[40 + i];
         unsigned long long tot2 = 0; for(int i = 0; i < 12; i++) tot2 += hc[60 + i];
         if(tot2) { fprintf(stderr, "[gpp] ensi members phases (%% of wave cycles):"); for(int i = 0; i < 12; i++) fprintf(stderr, " %d:%.1f", i, 100.0 * (double)hc[60 + i] / (double)tot2); fprintf(stderr, "\n"); }

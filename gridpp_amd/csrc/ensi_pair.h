@@ -467,7 +467,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         todo &= ~done;
     }
 #ifdef GPP_ENSI_PROFILE
-    if(lane == 0 && a.counters) for(int k = 0; k < 12; ++k) atomicAdd(&a.counters[40 + k], prof[k]);
+    // (spread over 1024 slots: twelve same-address atomics per wave serialise in the L2 and slow every load of the kernel down)
+    if(lane == 0 && a.counters) for(int k = 0; k < 12; ++k) atomicAdd(&a.counters[80 + (blockIdx.x & 1023) * 32 + k], prof[k]);
 #endif
     if(lane == 0 && a.counters) { atomicAdd(&a.counters[1], (unsigned long long)ndone); atomicAdd(&a.counters[4 + (blockIdx.x & 31)], (unsigned long long)nsweeps); }
 }
@@ -501,6 +502,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // (k_ensi_pair left the selection and the observation records there too: the chain meta -> selection -> observation record
     // was three trips through a saturated memory system, 47 % of this kernel's wave cycles)
     const unsigned meta = a.meta[(size_t)tile * 64 + lcell];
+#ifdef GPP_ENSI_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    EPROF(11)   // (profile build: one small load alone, waited for: the latency of the memory system under this kernel's load)
+#endif
     const float v0 = (lane < nV) ? a.bg[(long)cell_l * E + ensi_member(a, lane)] : 0.0f;
     const double* const park = a.cpark + ((size_t)blockIdx.x) * ENSI_PARK_D;
     const unsigned long long pk0 = __double_as_longlong(park[2144 + i]), pk1 = __double_as_longlong(park[2176 + i]);
@@ -509,7 +514,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // lanes 32..63: row i of U; lanes 0..31: row i of U^T B U (e[i]: eigenvalue estimate d_i, the rest: the off-diagonal part E)
     double e[32];
 #pragma unroll
-    for(int j = 0; j < 32; j += 2) { const double2 w = *reinterpret_cast<const double2*>(&park[(j >> 1) * 128 + lane * 2]); e[j] = w.x; e[j + 1] = w.y; }
+    for(int j = 0; j < 32; j += 2) {
+        if(GPP_DBG(a, 16)) { e[j] = (j == i) ? 1.0 : 0.0; e[j + 1] = (j + 1 == i) ? 1.0 : 0.0; continue; }   // (timing experiment: no park rows)
+        const double2 w = *reinterpret_cast<const double2*>(&park[(j >> 1) * 128 + lane * 2]); e[j] = w.x; e[j + 1] = w.y;
+    }
     const int n = (int)(meta & 0xffu);
     if(n == 0) return;   // no observation in range (the output already holds the background) or a cell of k_ensi_big
     const unsigned orig_i = (i < n) ? (unsigned)pk0 : 0xffffffffu;
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                 for(int r = 0; r < EN; ++r) {
                     const bool on = r < n && e < nV;
-                    yv[r] = a.gY[on ? (long)s_sel[r] * nV + e : 0];
+                    yv[r] = a.gY[(on && !GPP_DBG(a, 32)) ? (long)s_sel[r] * nV + e : 0];   // (bit 32, timing experiment: one address)
                     yv[r] = on ? yv[r] : 0.0f;
                 }
 #pragma unroll
@@ -831,6 +839,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 #ifdef GPP_ENSI_PROFILE
     EPROF(8)   // clamp, store
-    if(lane == 0 && a.counters) for(int k = 0; k < 12; ++k) atomicAdd(&a.counters[60 + k], prof[k]);
+    if(lane == 0 && a.counters) for(int k = 0; k < 12; ++k) atomicAdd(&a.counters[80 + (blockIdx.x & 1023) * 32 + 16 + k], prof[k]);
 #endif
 }

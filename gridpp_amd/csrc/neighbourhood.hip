@@ -244,40 +244,44 @@ __device__ __forceinline__ unsigned qf_bucket_into(const float v, const float sc
     return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v, scale, off), sel, old);
 }
 __global__ __launch_bounds__(QF_NB) void k_qf_lut(const float* __restrict__ thr, int T, QfLut* __restrict__ L) {
-    __shared__ float u[16];
-    __shared__ int ub[16];
+    __shared__ float u[16], st[16];
+    __shared__ int ub[16], srank[16];
     __shared__ int s_U, s_flag;
+    __shared__ float s_scale, s_off;
     const int j = threadIdx.x;
+    if(j < 16) st[j] = j < T ? thr[j] : 0.0f;    // (one round of loads: thread 0 works on the LDS copy)
+    __syncthreads();
     if(j == 0) {
-        int flag = 0, U = 0;
-        for(int t = 0; t < T; t++) if(!nv(thr[t]) || fabsf(thr[t]) > 1e37f) flag = 1;
+        int flag = 0, U = 0, ident = 1;
+        float scale = 1.0f, off = 0.0f;
+        for(int t = 0; t < T; t++) if(!nv(st[t]) || fabsf(st[t]) > 1e37f) flag = 1;
         if(!flag) {   // distinct values, ascending (T <= 16: insertion)
             for(int t = 0; t < T; t++) {
-                const float v = thr[t];
+                const float v = st[t];
                 int k = 0; bool dup = false;
                 while(k < U && u[k] < v) k++;
                 if(k < U && u[k] == v) dup = true;
                 if(!dup) { for(int m = U; m > k; m--) u[m] = u[m - 1]; u[k] = v; U++; }
             }
-            int ident = 1;
-            for(int t = 0; t < T; t++) { int k = 0; while(u[k] < thr[t]) k++; L->rank[t] = k; if(k != t) ident = 0; }
-            L->ident = ident;
+            for(int t = 0; t < T; t++) { int k = 0; while(u[k] < st[t]) k++; srank[t] = k; if(k != t) ident = 0; }
             // lowest threshold -> bucket 1.5, highest -> bucket 253.5
             const float lo = u[0], hi = u[U - 1];
-            float scale = (hi > lo) ? 252.0f / (hi - lo) : 1.0f;
+            scale = (hi > lo) ? 252.0f / (hi - lo) : 1.0f;
             if(!nv(scale) || scale <= 0) scale = 1.0f;
-            const float off = (hi > lo ? 1.5f : 127.5f) - lo * scale;
-            L->scale = scale; L->off = off;
+            off = (hi > lo ? 1.5f : 127.5f) - lo * scale;
             for(int k = 0; k < U; k++) {
                 ub[k] = (int)(qf_bucket_into(u[k], scale, off, 0, 0) & 0xffu);
                 if(ub[k] < 1 || ub[k] > 254 || (k > 0 && ub[k] == ub[k - 1])) flag = 1;
             }
             if(!nv(off)) flag = 1;
         }
+        s_scale = scale; s_off = off;
+        L->scale = scale; L->off = off; L->ident = ident;
         s_U = U; s_flag = flag;
         L->U = U; L->flag = flag;
     }
     __syncthreads();
+    if(j < T) L->rank[j] = srank[j];
     if(s_flag) return;
     const int U = s_U;
     int below = 0; float inside = INFINITY;   // `v > +inf` is never true: an empty bucket keeps the rank below it

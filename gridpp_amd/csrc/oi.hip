@@ -211,7 +211,8 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     return x;
 }
 template <int N, bool LU, bool PLAIN, bool SPATIAL>
-__global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
+// (the 62-row tile holds its rows in 124 + 124 registers: one wave per SIMD is what it gets, and what it asks for)
+__global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
     __shared__ double s_col[4][64];   // column staging of the half-wave solves
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                 }
                 const double dmine = (double)o1.y - (double)o1.z;         // d of observation `lane`
                 int mystep = 64;                                           // column this row became the pivot of
+                double mypinv = 0.0;                                       // 1 / pivot of that column
 #pragma unroll
                 for(int j = 0; j < N; ++j) {
                     if(j < n) {
@@ -352,8 +354,9 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                         if(!(av > 0.0)) bad = true;                        // exactly singular (arma::inv throws)
                         const double pjj = readlane_d(rowT[j], piv);
                         const bool elim = lane < n && mystep == 64 && lane != piv;
-                        const double f = elim ? rowT[j] / pjj : 0.0;
-                        if(lane == piv) mystep = j;
+                        const double rpj = 1.0 / pjj;                      // one reciprocal per column (LAPACK's dgetf2 scales by it too)
+                        const double f = elim ? rowT[j] * rpj : 0.0;
+                        if(lane == piv) { mystep = j; mypinv = rpj; }
 #pragma unroll
                         for(int p = j + 1; p < N; ++p) {
                             const double pp = readlane_d(rowT[p], piv);
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_oi(OiArgs a) {
                     for(int j = N - 1; j >= 0; --j) {                      // backward: U k = y
                         if(j < n) {
                             const int piv = __builtin_ctzll(__ballot(mystep == j));
-                            const double xj = readlane_d(bvec, piv) / readlane_d(rowT[j], piv);
+                            const double xj = readlane_d(bvec, piv) * readlane_d(mypinv, piv);
                             if(lane < n && mystep < j) bvec = __builtin_fma(-rowT[j], xj, bvec);
                             inc = __builtin_fma(xj, readlane_d(dmine, j), inc);    // k . (lObs - lY)   (oi.cpp:316)
                             a00 = __builtin_fma(xj, readlane_d(g0, j), a00);       // k . G             (oi.cpp:336)
@@ -1043,6 +1046,10 @@ DevStructure gpp_resolve_structure(const gpp_structure* s) {
     if(s->field && !s->kind_v && !s->kind_w && !s->field_v && !s->field_w) {   // one spatially varying structure: its own fields
         const gpp_field* f = (const gpp_field*)s->field;
         if(f->kind != s->kind) runtime("structure kind and field kind differ");
+        if(f->uniform) {   // the same scales at every point: corr(p1, p2) is the scalar structure's (and symmetric): every fast path applies
+            d.h = f->h[0]; d.v = f->v[0]; d.w = f->w[0]; d.R = f->R[0];
+            return d;
+        }
         d.fh = f->d_h.p; d.fv = f->d_v.p; d.fw = f->d_w.p; d.fR = f->d_R.p;
     }
     else if(s->field || s->field_v || s->field_w) {
@@ -1072,6 +1079,7 @@ __global__ void k_gather_scale(const float* __restrict__ src, const int* __restr
 }
 void gpp_bind_field(DevStructure& d, const gpp_structure* s, gpp_points* bgrid, gpp_points* points, DevBuf<int>& cbuf, DevBuf<int>& obuf) {
     if(!s->field && !s->field_v && !s->field_w) return;
+    if(!d.fh) return;   // a uniform field: gpp_resolve_structure made it a scalar structure
     if(s->kind_v || s->kind_w || s->field_v || s->field_w) {
         // MultipleStructure(sh, sv, sw) with spatially varying parts (structure.cpp:90-138): corr_h comes from sh with the elevation /
         // laf of p1 on both sides (its vertical factors are 1), corr_v from sv at zero horizontal distance, corr_w from sw likewise:
@@ -1136,6 +1144,8 @@ extern "C" int gpp_field_create(gpp_points* grid, const float* h, const float* v
     f->h.assign(h, h + grid->n); f->v.assign(v, v + grid->n); f->w.assign(w, w + grid->n);
     f->R.resize(grid->n);
     for(int i = 0; i < grid->n; i++) f->R[i] = st_localization(kind, f->h[i], min_rho);   // localization_distance(h), e.g. structure.cpp:280-282
+    f->uniform = grid->n > 0 && is_valid(f->h[0]) && is_valid(f->v[0]) && is_valid(f->w[0]) && f->h[0] >= 0 && f->v[0] >= 0 && f->w[0] >= 0;
+    for(int i = 1; i < grid->n && f->uniform; i++) f->uniform = f->h[i] == f->h[0] && f->v[i] == f->v[0] && f->w[i] == f->w[0];
     f->d_h.upload(f->h.data(), grid->n); f->d_v.upload(f->v.data(), grid->n); f->d_w.upload(f->w.data(), grid->n); f->d_R.upload(f->R.data(), grid->n);
     GPP_HIP(hipStreamSynchronize(stream()));
     *out = f.release();

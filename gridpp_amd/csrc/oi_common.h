@@ -28,6 +28,8 @@ struct gpp_field {   // spatially varying structure parameters resident in HBM (
     float min_rho = 0;
     std::vector<float> h, v, w, R;
     gpp::DevBuf<float> d_h, d_v, d_w, d_R;
+    bool uniform = false;   // every point carries the same (valid) h, v and w: the structure is a scalar one (the reference's own
+                            // "var len scale" benchmark row, tests/benchmark.py:66,294, passes h * ones)
 };
 // log2 of the width (in grid columns) of the 64-cell tile of a 2-D grid: the most square tile in metres (8 x 8 cells for
 // an isotropic grid, 2 x 32 or 32 x 2 for strongly anisotropic ones) -- the cells of a tile should select the same observations

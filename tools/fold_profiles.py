@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Folds the CSV summaries of tools/profile_r03.sh (gpurun_out/prof_r03/) into the JSON bundle bench.py reads
+(profiles/hbm_traffic.json): per dominant kernel and per launch, HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, KiB counters,
+the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md) and the SQ instruction counters, FP64 classes included.
+usage: fold_profiles.py <dir with *_pmc_*.csv> > hbm_traffic.json"""
+import csv
+import json
+import os
+import sys
+
+d = sys.argv[1]
+
+
+def rows(name):
+    p = os.path.join(d, name + ".csv")
+    return list(csv.DictReader(open(p))) if os.path.exists(p) else []
+
+
+def pick(name, kernel_part, counter, grid=None):
+    """mean per launch of `counter` for kernels whose name contains kernel_part (largest grid if several)"""
+    best = None
+    for r in rows(name):
+        if kernel_part in r["kernel"] and r["counter"] == counter and (grid is None or r["grid_size"] == grid):
+            v = float(r["mean_per_launch"])
+            if best is None or int(r["grid_size"]) > best[0]:
+                best = (int(r["grid_size"]), v)
+    return best[1] if best else None
+
+
+def total(name, kernel_parts, counter):
+    """sum over the kernels of a call: per-launch mean x launches per call (launches / calls of the driving script)"""
+    s = 0.0
+    for r in rows(name):
+        if any(k in r["kernel"] for k in kernel_parts) and r["counter"] == counter:
+            s += float(r["mean_per_launch"]) * int(r["launches"])
+    return s
+
+
+out = {"_comment": "per-launch counters of the dominant kernels from the rocprofv3 PMC passes of tools/profile_r03.sh (separate --pmc runs; summaries in "
+                   "profiles/r03_*_pmc_*.csv).  FETCH_SIZE / WRITE_SIZE in KiB; traffic = FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section). "
+                   "Folded by tools/fold_profiles.py."}
+U = "k_oi_union<true, false, 32>"
+fs, wsz = pick("oi_pmc_fetch", U, "FETCH_SIZE"), pick("oi_pmc_write", U, "WRITE_SIZE")
+oi = {"kernel": U + " (first pass, all tiles)", "workload": "optimal_interpolation 4000x4000 grid, 10000 obs, BarnesStructure(10000), max_points=30", "n_gpus": 1,
+      "_source": "profiles/r03_oi_pmc_*.csv"}
+if fs is not None and wsz is not None:
+    oi.update({"FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": wsz, "traffic_bytes": int((2 * fs + wsz) * 1024), "algorithmic_bytes": 16000000 * 28})
+for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
+    v = pick("oi_pmc_sq", U, c)
+    if v is not None:
+        oi[c] = int(v)
+f64 = [pick("oi_pmc_fp64", U, c) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
+if all(v is not None for v in f64):
+    oi["SQ_INSTS_VALU_FP64"] = int(sum(f64))
+    oi["_fp64_classes"] = dict(zip(("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64"), [int(v) for v in f64]))
+out["k_oi_union"] = oi
+
+calls = 3.0   # tools/ensi_c5.py and tools/prof_nb.py make three calls each
+en = {"workload": "optimal_interpolation_ensi 2500x2500x50, 5000 obs, max_points=30", "_source": "profiles/r03_ensi_pmc_*.csv",
+      "_note": "wave-instructions per CALL, summed over k_ensi_scan / k_ensi_pair / k_ensi_members (all batches)"}
+for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F64"):
+    en[c] = total("ensi_pmc_sq", ["k_ensi"], c) / calls
+for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"):
+    en[c] = total("ensi_pmc_fp64", ["k_ensi"], c) / calls
+out["ensi_C5"] = en
+
+qf = {"workload": "neighbourhood_quantile_fast 4000x4000x100, halfwidth 15, 11 thresholds", "_source": "profiles/r03_nbh_pmc_*.csv"}
+tr = 0.0
+for k in ("k_qf_count", "k_qf_box"):
+    f_, w_ = pick("nbh_pmc_fetch", k, "FETCH_SIZE"), pick("nbh_pmc_write", k, "WRITE_SIZE")
+    if f_ is not None and w_ is not None:
+        qf[k] = {"FETCH_SIZE_KiB": f_, "WRITE_SIZE_KiB": w_}
+        tr += (2 * f_ + w_) * 1024
+qf["traffic_bytes"] = int(tr)
+qf["algorithmic_bytes"] = 16000000 * 404
+out["quantile_fast_C4"] = qf
+mp = pick("nbh_pmc_fetch", "k_member_pass<0>", "FETCH_SIZE")
+if mp is not None:
+    out["k_member_pass<0>"] = {"workload": "neighbourhood Mean 4000x4000x100 (member pass)", "FETCH_SIZE_KiB": mp, "traffic_bytes_read": int(2 * mp * 1024),
+                               "algorithmic_bytes_read": 6400000000}
+print(json.dumps(out, indent=1))
