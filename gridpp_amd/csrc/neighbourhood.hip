@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, l
     float4 cur[QC_G], nxt[QC_G];
     // A workgroup takes super-tiles of four consecutive tiles (256 cells): the counts of a super-tile leave through an LDS
     // buffer as one dword store per lane and plane (256 contiguous bytes per instruction instead of four times 64)
-    unsigned char* const obuf = reinterpret_cast<unsigned char*>(ranks + 16 * E);   // [T + 1][256]
+    unsigned char* const obuf = reinterpret_cast<unsigned char*>(ranks + max(16 * E, NL * 64));   // [T + 1][256] (behind the rank area, which also serves as the [NL][64] count exchange)
     const long nsuper = (nfull + 3) / 4;
     if(ng > 0 && (long)blockIdx.x < nsuper) {
         const float4* src0 = in4 + (long)blockIdx.x * 4 * 16 * E + lane;

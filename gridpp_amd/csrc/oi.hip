@@ -1330,8 +1330,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
     auto launch_k_oi = [&](const bool lu) {   // k_oi over a.nrun tiles (all, or the fallback list of k_oi_union)
         const dim3 grid((a.nrun + 3) / 4), block(256);
-        if(spatial) {
-            if(N == 32) hipLaunchKernelGGL((k_oi<32, true, false, true>), grid, block, 0, stream(), a);
+        if(spatial) {   // (plain: three Barnes factors with per-point scales -- the straight-line correlation code takes them per lane)
+            if(N == 32) { if(plain) hipLaunchKernelGGL((k_oi<32, true, true, true>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi<32, true, false, true>), grid, block, 0, stream(), a); }
             else hipLaunchKernelGGL((k_oi<62, true, false, true>), grid, block, 0, stream(), a);
         }
         else if(N == 32) {

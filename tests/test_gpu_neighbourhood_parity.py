@@ -145,6 +145,37 @@ def test_quantile_fast(api, T):
         close(gridpp.neighbourhood_quantile_fast(f, qf, 4, thr), O.neighbourhood_quantile_fast(f, qf, 4, thr))
 
 
+@pytest.mark.parametrize("kind", ["permuted", "duplicate", "clustered", "nonfinite", "integer_ties"])
+def test_quantile_fast_threshold_lists(api, kind):
+    """The count pass ranks a member among the DISTINCT FINITE thresholds (k_qf_lut / k_qf_count): lists in any order, with duplicates,
+    with two thresholds in one bucket of the rank table or a non-finite one (both take the compare-per-threshold pass), and members
+    that sit exactly on thresholds; several 256-column strips and 64-row segments of the box pass, rows with missing members."""
+    gridpp, O = api
+    rng = np.random.default_rng(21)
+    f = rng.uniform(0, 10, (90, 300, 8)).astype(np.float32)   # (two strips of the box pass, two row segments)
+    f[rng.random(f.shape) < 0.01] = np.nan
+    f[70:73, 100:110, :] = np.nan
+    thr = np.linspace(0, 10, 9).astype(np.float32)
+    if kind == "permuted":
+        thr = rng.permutation(thr)
+    elif kind == "duplicate":
+        thr[3] = thr[5]
+    elif kind == "clustered":
+        thr[4] = np.nextafter(thr[3], np.float32(np.inf))
+    elif kind == "nonfinite":
+        thr[2], thr[7] = np.inf, np.nan
+    else:
+        f = np.round(f).astype(np.float32)
+    def same(a, b):   # (a non-finite threshold can be the answer: infinities must agree exactly, the rest to 1e-5)
+        a, b = np.asarray(a), np.asarray(b)
+        assert (np.isinf(a) == np.isinf(b)).all() and (a[np.isinf(b)] == b[np.isinf(b)]).all()
+        close(np.where(np.isinf(b), np.float32(0), a), np.where(np.isinf(b), np.float32(0), b))
+    for q, hw in ((0.5, 15), (0.9, 3), (0.0, 16), (1.0, 0)):
+        same(gridpp.neighbourhood_quantile_fast(f, q, hw, thr), O.neighbourhood_quantile_fast(f, [q], hw, thr))
+    g = f[:, :, :7].copy()   # rows that are no whole float4s: the compare-per-threshold pass feeds the same box pass
+    same(gridpp.neighbourhood_quantile_fast(g, 0.5, 7, thr), O.neighbourhood_quantile_fast(g, [0.5], 7, thr))
+
+
 def test_thresholds_match_oracle(api):
     gridpp, O = api
     f = field(11, 50, 60, 7)
