@@ -14,6 +14,7 @@
 // (oi_common.h), then the wave walks its cells; B, U live in LDS, the Jacobi sweeps use the round-robin
 // ordering (n/2 disjoint rotations per step, applied to rows, then columns of B and U by all 64 lanes).
 // The final member update reproduces the reference's float accumulation over k (:508-511) term by term.
+#include <mutex>
 #include "oi_common.h"
 #include <algorithm>
 
@@ -740,6 +741,345 @@ __global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_ensi_big_ns: k_ensi_big with the eigen-decomposition replaced by a matrix-core iteration (round 3).  The cyclic Jacobi of
+// k_ensi_big is a chain of ~400 rotation steps, three workgroup barriers and a handful of dependent LDS round trips each: 1.2 ms per
+// grid point, fifty times the tile path.  What the path needs of Pinv = Y^T R^-1 Y + c I (SPD, eigenvalues >= c) is its inverse
+// and its inverse square root (oi_ensi.cpp:398-421: P = inv(Pinv), sqrt((E - 1) P) by eig_sym) -- functions the coupled
+// Newton-Schulz iteration delivers with nothing but 64 x 64 x 64 products:
+//     Y_0 = Pinv / s,  Z_0 = I;   T = (3 I - Z Y) / 2,  Y <- Y T,  Z <- T Z;     Y -> (Pinv / s)^1/2,  Z -> (Pinv / s)^-1/2,
+// s = (|Pinv|_inf + c) / 2, so that the spectrum of Pinv / s lies in (0, 2).  It converges quadratically once the smallest
+// eigenvalue 2 c / (|Pinv|_inf + c) has grown to order one (a factor 2.25 per step before that): 10-16 steps of three products on
+// v_mfma_f64_16x16x4, four waves sharing each product by rows.  The symmetric square root is unique, so the result is the one
+// eig_sym gives, to the ~1e-13 the iteration is stopped at.  A grid point that does not converge (non-finite input) is listed for
+// k_ensi_huge, whose Jacobi reproduces the reference's rcond <= 0 passthrough.
+#define NSP 65           // pitch of the three 64 x 64 matrices (doubles)
+template <bool SPATIAL, bool FULL>   // FULL: 49..64 valid members (all four tile rows: strips); else the tiles on and above the diagonal
+__global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
+    extern __shared__ double ns_lds[];
+    double* const M0 = ns_lds;                        // Y (first: candidate keys, then the Y chunk of the Pinv build); at the end W
+    double* const M1 = ns_lds + 64 * NSP;             // Z
+    double* const M2 = ns_lds + 2 * 64 * NSP;         // T
+    unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(ns_lds);   // [EBIG_CAND] = 64 KB <= the first two matrices
+    __shared__ double s_t[64], s_w[64], s_X[64];
+    __shared__ double s_off[256];
+    __shared__ int s_n;
+    __shared__ float s_val[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const ScanArgs& sa = a.s;
+    const int nV = a.nV, E = a.E;
+    const int nlist = *a.big_count;
+    unsigned long long* const gkeys = a.big_keys + (size_t)blockIdx.x * EBIG_CAND;
+    const double c = (double)((float)(nV - 1));       // oi_ensi.cpp:383 (float product, delta = 1)
+    auto block_sum = [&](double v) {
+        s_off[tid] = v;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
+        const double r = s_off[0];
+        __syncthreads();
+        return r;
+    };
+    for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int cell = a.big_list[li];
+        const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
+        DevStructure st = sa.st;
+        if(SPATIAL) d_structure_at(st, st.cell_idx ? st.cell_idx[cell] : cell);
+        __syncthreads();
+        if(tid == 0) s_n = 0;
+        __syncthreads();
+        // ---- radius query + filter (valid observation, rho > 0: oi_ensi.cpp:213-237) -----------------------------------------
+        const float R = st.R;
+        const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz), pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
+        const int bx0 = min(max((int)floorf((pa - R - sa.amin) * sa.inv_s) - 1, 0), sa.nbx - 1), bx1 = min(max((int)floorf((pa + R - sa.amin) * sa.inv_s) + 1, 0), sa.nbx - 1);
+        const int by0 = min(max((int)floorf((pb - R - sa.bmin) * sa.inv_s) - 1, 0), sa.nby - 1), by1 = min(max((int)floorf((pb + R - sa.bmin) * sa.inv_s) + 1, 0), sa.nby - 1);
+        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        for(int by = by0; by <= by1; ++by) {
+            const int js = sa.bin_start[by * sa.nbx + bx0], je = sa.bin_start[by * sa.nbx + bx1 + 1];
+            for(int j = js + tid; j < je; j += 256) {
+                const float4 rec = sa.pgeo[j];   // x = NaN for an unusable observation: fails the box test
+                if(!(rec.x > lox && rec.x < hix && rec.y > loy && rec.y < hiy && rec.z > loz && rec.z < hiz)) continue;
+                const float2 met = sa.smeta[j];
+                if(!(d_chord(rec.x, rec.y, rec.z, gx, gy, gz) <= R)) continue;
+                const float rho = d_corr(st, gx, gy, gz, ge, gl, rec.x, rec.y, rec.z, rec.w, met.x, true);
+                if(!(rho > 0.0f)) continue;
+                const int k = atomicAdd(&s_n, 1);
+                if(k < EBIG_CAND) s_key[k] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~__float_as_int(met.y));
+            }
+        }
+        __syncthreads();
+        const int ncand = s_n;
+        const bool truncated = a.s.max_points > 0 && ncand > a.s.max_points;
+        const int n = truncated ? a.s.max_points : ncand;
+        if(ncand > EBIG_CAND) {   // more candidates than the LDS sort holds: k_ensi_huge takes the cell
+            if(tid == 0) a.huge_list[atomicAdd(a.big_count + 1, 1)] = cell;
+            continue;
+        }
+        if(n == 0 || nV <= 1) continue;
+        // ---- order: rho descending (ties -> lower index) when the reference sorts, candidate (= index) order otherwise (:243-269)
+        int np2 = 1;
+        while(np2 < ncand) np2 <<= 1;
+        for(int i = ncand + tid; i < np2; i += 256) s_key[i] = 0ull;
+        __syncthreads();
+        for(int k = 2; k <= np2; k <<= 1) {
+            for(int j = k >> 1; j > 0; j >>= 1) {
+                for(int i = tid; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if(ixj > i) {
+                        const unsigned long long x = s_key[i], y = s_key[ixj];
+                        const unsigned long long kx = truncated ? x : (x & 0xffffffffull), ky = truncated ? y : (y & 0xffffffffull);
+                        const bool desc = (i & k) == 0;
+                        if(desc ? (kx < ky) : (kx > ky)) { s_key[i] = y; s_key[ixj] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for(int i = tid; i < n; i += 256) gkeys[i] = s_key[i];
+        __threadfence_block();
+        __syncthreads();
+        // ---- Pinv = Y^T Rinv Y + c I, t = Y^T Rinv d, in chunks of 64 observations staged in LDS (as k_ensi_big: same order of the sums)
+        float* const yc = reinterpret_cast<float*>(s_key);          // [64][64] Y chunk
+        double* const rinv = reinterpret_cast<double*>(yc + 64 * 64);   // [64]
+        double* const dvec = rinv + 64;                                 // [64]
+        double accP[16];
+#pragma unroll
+        for(int r = 0; r < 16; ++r) accP[r] = 0.0;
+        double acct = 0.0;
+        for(int i0 = 0; i0 < n; i0 += 64) {
+            const int m = min(64, n - i0);
+            __syncthreads();
+            for(int e = tid; e < m * 64; e += 256) {
+                const int i = e >> 6, k = e & 63;
+                const unsigned orig = ~(unsigned)(gkeys[i0 + i] & 0xffffffffull);
+                yc[i * 64 + k] = (k < nV) ? a.gY[(long)orig * nV + k] : 0.0f;
+            }
+            if(tid < m) {
+                const unsigned long long key = gkeys[i0 + tid];
+                const unsigned orig = ~(unsigned)(key & 0xffffffffull);
+                const float4 x4 = a.oaux[orig];                       // laf, obs, gYhat, sigma
+                const float s2 = x4.w * x4.w;                         // float product (oi_ensi.cpp:300)
+                rinv[tid] = (double)__uint_as_float((unsigned)(key >> 32)) / (double)s2;
+                dvec[tid] = (double)x4.y - (double)x4.z;
+            }
+            __syncthreads();
+            for(int r = 0; r < 16; ++r) {
+                const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
+                if(ai < nV && bi < nV) {
+                    double sacc = accP[r];
+                    for(int i = 0; i < m; ++i) sacc = __builtin_fma((double)yc[i * 64 + ai] * rinv[i], (double)yc[i * 64 + bi], sacc);
+                    accP[r] = sacc;
+                }
+            }
+            if(tid < nV) for(int i = 0; i < m; ++i) acct = __builtin_fma((double)yc[i * 64 + tid] * rinv[i], dvec[i], acct);
+        }
+        __syncthreads();
+        // ---- scaling: s = (|Pinv|_inf + c) / 2; Y_0 = Pinv / s (rows / columns beyond nV: the identity, which stays the identity), Z_0 = I
+        double rowabs = 0.0;
+#pragma unroll
+        for(int r = 0; r < 16; ++r) {
+            const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
+            const double v = (ai < nV && bi < nV) ? accP[r] + (ai == bi ? c : 0.0) : 0.0;
+            accP[r] = v;
+            M2[ai * NSP + bi] = fabs(v);
+        }
+        if(tid < 64) s_t[tid] = (tid < nV) ? acct : 0.0;
+        __syncthreads();
+        if(tid < 64) { for(int k = 0; k < 64; ++k) rowabs += M2[tid * NSP + k]; }
+        s_off[tid] = tid < 64 ? rowabs : 0.0;
+        __syncthreads();
+        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] = fmax(s_off[tid], s_off[tid + off]); __syncthreads(); }
+        const double sc = 0.5 * (s_off[0] + c), rsc = 1.0 / sc;
+        __syncthreads();
+#pragma unroll
+        for(int r = 0; r < 16; ++r) {
+            const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
+            M0[ai * NSP + bi] = (ai < nV && bi < nV) ? accP[r] * rsc : (ai == bi ? 1.0 : 0.0);
+            M1[ai * NSP + bi] = ai == bi ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        // ---- coupled Newton-Schulz on the matrix cores.  Y, Z and T are symmetric (polynomials of one matrix), so only the 16 x 16
+        //      tiles on and above the diagonal of the nt x nt tile grid (nt = ceil(nV / 16)) are computed for up to 48 members -- 3 of 16
+        //      for 17..32 -- and stored twice, tile p of the list on wave p mod 4; with 49..64 members (nt = 4) every wave takes a strip of
+        //      16 rows of the full product instead (one A operand per four MFMAs: measured faster than 10 tiles of two operands each).
+        const int r16 = lane & 15, kq = lane >> 4;
+        const int nt = (nV + 15) >> 4, npair = nt * (nt + 1) / 2, K4 = nt * 16;
+        auto tile_of = [&](const int p, int& ti, int& tj) {   // p-th pair (ti <= tj), row by row
+            int q = p; ti = 0;
+            while(q >= nt - ti) { q -= nt - ti; ti++; }
+            tj = ti + q;
+        };
+        auto tile_product = [&](const double* L, const double* Rm, const int ti, const int tj) {   // tile (ti, tj) of L Rm
+            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+            for(int kk = 0; kk < K4; kk += 4) {
+                const int k = kk + kq;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(16 * ti + r16) * NSP + k], Rm[k * NSP + 16 * tj + r16], acc, 0, 0, 0);
+            }
+            return acc;
+        };
+        bool converged = false;
+        const int row0 = 16 * wv;
+        for(int it = 0; it < 64; ++it) {
+            double res2 = 0.0;
+            if constexpr (FULL) {   // 49..64 members: wave wv owns rows [16 wv, 16 wv + 16) of every product (one A operand per four MFMAs)
+                v4d t4[4];
+#pragma unroll
+                for(int j = 0; j < 4; ++j) t4[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+                for(int kk = 0; kk < 64; kk += 4) {   // Z Y
+                    const int k = kk + kq;
+                    const double av = M1[(row0 + r16) * NSP + k];
+#pragma unroll
+                    for(int j = 0; j < 4; ++j) t4[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, M0[k * NSP + 16 * j + r16], t4[j], 0, 0, 0);
+                }
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+#pragma unroll
+                    for(int r = 0; r < 4; ++r) {
+                        const int row = row0 + kq + 4 * r, col = 16 * j + r16;
+                        const double d = (row == col ? 1.0 : 0.0) - t4[j][r];     // I - Z Y
+                        res2 += d * d;
+                        M2[row * NSP + col] = (row == col ? 1.0 : 0.0) + 0.5 * d;   // T = (3 I - Z Y) / 2 = I + (I - Z Y) / 2
+                    }
+            }
+            else {
+                v4d t3[3];
+                int tis[3], tjs[3];
+#pragma unroll
+                for(int u = 0; u < 3; ++u) {
+                    const int p = wv + 4 * u;
+                    tis[u] = tjs[u] = 0;
+                    if(p < npair) { tile_of(p, tis[u], tjs[u]); t3[u] = tile_product(M1, M0, tis[u], tjs[u]); }   // Z Y
+                }
+#pragma unroll
+                for(int u = 0; u < 3; ++u) {
+                    if(wv + 4 * u < npair) {
+#pragma unroll
+                        for(int r = 0; r < 4; ++r) {
+                            const int row = 16 * tis[u] + kq + 4 * r, col = 16 * tjs[u] + r16;
+                            const double d = (row == col ? 1.0 : 0.0) - t3[u][r];     // I - Z Y
+                            res2 += (tis[u] == tjs[u]) ? d * d : 2.0 * d * d;
+                            const double tv = (row == col ? 1.0 : 0.0) + 0.5 * d;    // T = (3 I - Z Y) / 2 = I + (I - Z Y) / 2
+                            M2[row * NSP + col] = tv;
+                            M2[col * NSP + row] = tv;
+                        }
+                    }
+                }
+            }
+            res2 = block_sum(res2);    // (its barriers also publish T)
+            if(res2 < 1e-25) { converged = true; break; }
+            if(!(res2 == res2)) break;   // NaN: a non-finite matrix
+            if constexpr (FULL) {
+                v4d y4[4], z4[4];
+#pragma unroll
+                for(int j = 0; j < 4; ++j) { y4[j] = (v4d){0.0, 0.0, 0.0, 0.0}; z4[j] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+                for(int kk = 0; kk < 64; kk += 4) {   // Y T and T Z
+                    const int k = kk + kq;
+                    const double ay = M0[(row0 + r16) * NSP + k], at = M2[(row0 + r16) * NSP + k];
+#pragma unroll
+                    for(int j = 0; j < 4; ++j) {
+                        y4[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, M2[k * NSP + 16 * j + r16], y4[j], 0, 0, 0);
+                        z4[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, M1[k * NSP + 16 * j + r16], z4[j], 0, 0, 0);
+                    }
+                }
+                __syncthreads();   // every wave has read Y and Z
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+#pragma unroll
+                    for(int r = 0; r < 4; ++r) {
+                        const int row = row0 + kq + 4 * r, col = 16 * j + r16;
+                        M0[row * NSP + col] = y4[j][r];
+                        M1[row * NSP + col] = z4[j][r];
+                    }
+                __syncthreads();
+            }
+            else {
+            v4d y3[3], z3[3];
+            int tis[3], tjs[3];
+#pragma unroll
+            for(int u = 0; u < 3; ++u) {
+                const int p = wv + 4 * u;
+                tis[u] = tjs[u] = 0;
+                if(p < npair) {
+                    tile_of(p, tis[u], tjs[u]);
+                    y3[u] = tile_product(M0, M2, tis[u], tjs[u]);   // Y T
+                    z3[u] = tile_product(M2, M1, tis[u], tjs[u]);   // T Z
+                }
+            }
+            __syncthreads();   // every wave has read Y and Z
+#pragma unroll
+            for(int u = 0; u < 3; ++u) {
+                if(wv + 4 * u < npair) {
+#pragma unroll
+                    for(int r = 0; r < 4; ++r) {
+                        const int row = 16 * tis[u] + kq + 4 * r, col = 16 * tjs[u] + r16;
+                        M0[row * NSP + col] = y3[u][r]; M0[col * NSP + row] = y3[u][r];
+                        M1[row * NSP + col] = z3[u][r]; M1[col * NSP + row] = z3[u][r];
+                    }
+                }
+            }
+            __syncthreads();
+            }
+        }
+        if(!converged) {   // non-finite input (or no convergence): the general kernel decides (its Jacobi has the reference's rcond <= 0 passthrough)
+            if(tid == 0) a.huge_list[atomicAdd(a.big_count + 1, 1)] = cell;
+            continue;
+        }
+        // ---- w = P t = Z (Z t) / s ; W = sqrt(c P) + w 1^T = sqrt(c / s) Z + w 1^T  (oi_ensi.cpp:401-444) -> M0 --------------------
+        if(tid < 64) {
+            double u = 0.0;
+            for(int k = 0; k < 64; ++k) u = __builtin_fma(M1[tid * NSP + k], s_t[k], u);
+            s_X[tid] = u;
+        }
+        __syncthreads();
+        if(tid < 64) {
+            double wv2 = 0.0;
+            for(int k = 0; k < 64; ++k) wv2 = __builtin_fma(M1[tid * NSP + k], s_X[k], wv2);
+            s_w[tid] = wv2 * rsc;
+        }
+        __syncthreads();
+        const double sq = sqrt(c * rsc);
+        for(int e = tid; e < 64 * 64; e += 256) {
+            const int ai = e >> 6, bi = e & 63;
+            M0[ai * NSP + bi] = sq * M1[ai * NSP + bi] + s_w[ai];
+        }
+        // ---- ensemble side (oi_ensi.cpp:447-553): thread e < nV owns member e ---------------------------------------------------
+        const int ek = (tid < nV) ? a.validIdx[tid] : 0;
+        const float value = (tid < nV) ? a.bg[(long)cell * E + ek] : 0.0f;
+        if(tid < 64) s_val[tid] = value;
+        __syncthreads();
+        float total = 0; int count = 0;
+        for(int k = 0; k < nV; ++k) { const float v = s_val[k]; if(d_valid(v)) { total += v; count++; } }
+        const float ensMean = total / (float)count;
+        if(tid < nV) s_X[tid] = (double)value - (double)ensMean;
+        __syncthreads();
+        if(tid < nV) {
+            float acc = 0.0f;
+            for(int k = 0; k < nV; ++k) acc = (float)((double)acc + s_X[k] * M0[k * NSP + tid]);   // float += double product (:508-511)
+            float currIncrement = acc;
+            if(!a.allow_extrap) {   // :520-552; lY[e] is a LINEAR index into the n x nV column-major matrix
+                const int li_ = tid % n, lk_ = tid / n;
+                const unsigned oo = ~(unsigned)(gkeys[li_] & 0xffffffffull);
+                const double lYe = (double)a.gY[(long)oo * nV + lk_];
+                float maxInc = 0, minInc = 0;
+                for(int i = 0; i < n; ++i) {
+                    const unsigned oi_ = ~(unsigned)(gkeys[i] & 0xffffffffull);
+                    const float4 x4 = a.oaux[oi_];
+                    const float dv = (float)((double)x4.y - (lYe + (double)x4.z));
+                    if(i == 0 || dv > maxInc) maxInc = dv;
+                    if(i == 0 || dv < minInc) minInc = dv;
+                }
+                const double Xe = s_X[tid];
+                const float memberIncrement = (float)((double)currIncrement - Xe);
+                if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + Xe);
+                else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + Xe);
+                else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + Xe);
+                else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + Xe);
+            }
+            a.out[(long)cell * E + ek] = ensMean + currIncrement;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_ensi_huge: the same E x E formulation with no capacity of its own -- any number of candidates, selected observations
 // and valid members (oi_ensi.cpp:187-201,244-261,379-421 have no limit either).  Candidate keys, Pinv, the eigenvectors and
 // the per-member vectors live in HBM scratch sized by the host for the call; the sort is a bitonic network over global memory,
@@ -1179,10 +1519,25 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         else if(nbig > 0) {
             const int nwg = std::min(nbig, 1024);
             a.big_keys = ws.big_keys.get((size_t)nwg * EBIG_CAND);
-            if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_big<true>, dim3(nwg), dim3(256), 0, stream(), a);
-            else hipLaunchKernelGGL(k_ensi_big<false>, dim3(nwg), dim3(256), 0, stream(), a);
+            if(path_env("GPP_ENSI_BIG_JACOBI")) {   // the round-1 kernel (cyclic Jacobi in LDS): kept for A/B runs and tests
+                if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_big<true>, dim3(nwg), dim3(256), 0, stream(), a);
+                else hipLaunchKernelGGL(k_ensi_big<false>, dim3(nwg), dim3(256), 0, stream(), a);
+            }
+            else {
+                const size_t ns_lds = (size_t)3 * 64 * NSP * sizeof(double);
+                static std::once_flag ns_once;
+                std::call_once(ns_once, [=] {
+                    GPP_HIP(hipFuncSetAttribute((const void*)k_ensi_big_ns<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ns_lds));
+                    GPP_HIP(hipFuncSetAttribute((const void*)k_ensi_big_ns<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ns_lds));
+                    GPP_HIP(hipFuncSetAttribute((const void*)k_ensi_big_ns<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ns_lds));
+                    GPP_HIP(hipFuncSetAttribute((const void*)k_ensi_big_ns<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ns_lds));
+                });
+                const bool full = nV > 48;
+                if(a.s.st.fh) { if(full) hipLaunchKernelGGL((k_ensi_big_ns<true, true>), dim3(nwg), dim3(256), ns_lds, stream(), a); else hipLaunchKernelGGL((k_ensi_big_ns<true, false>), dim3(nwg), dim3(256), ns_lds, stream(), a); }
+                else { if(full) hipLaunchKernelGGL((k_ensi_big_ns<false, true>), dim3(nwg), dim3(256), ns_lds, stream(), a); else hipLaunchKernelGGL((k_ensi_big_ns<false, false>), dim3(nwg), dim3(256), ns_lds, stream(), a); }
+            }
             GPP_HIP(hipGetLastError());
-            int nhuge = 0;   // cells with more candidates than the LDS sort of k_ensi_big holds
+            int nhuge = 0;   // cells with more candidates than the LDS sort of k_ensi_big holds (or no convergence of the iteration)
             GPP_HIP(hipMemcpyAsync(&nhuge, ws.big_count.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream()));
             GPP_HIP(hipStreamSynchronize(stream()));
             if(nhuge > 0) launch_huge(a.huge_list, a.big_count + 1, nhuge);

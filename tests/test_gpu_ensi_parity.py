@@ -205,6 +205,19 @@ def test_ensi_large_n_with_elevation_nan_obs_and_invalid_member():
     assert np.isnan(out[3, 4, 5])
 
 
+def test_ensi_big_jacobi_kernel_agrees(monkeypatch):
+    """The round-1 large-n kernel (cyclic Jacobi in LDS, GPP_ENSI_BIG_JACOBI) and the Newton-Schulz one that replaced it give the
+    oracle's values on the same cells (40 and 60 usable observations per grid point, 20 and 50 members: the tile path takes none)."""
+    for E in (20, 50):
+        c = case(950 + E, 6, 7, E, 60)
+        out, ref = run(c, 200000, 0)
+        check(out, ref, c[2])
+        monkeypatch.setenv("GPP_ENSI_BIG_JACOBI", "1")
+        out_j, _ = run(c, 200000, 0)
+        monkeypatch.delenv("GPP_ENSI_BIG_JACOBI")
+        check(out_j, ref, c[2])
+
+
 def test_ensi_large_n_limits():
     """No capacity limit (oi_ensi.cpp:187-201,244-261 have none): 480 usable observations per grid point (several chunks of Y in
     k_ensi_big), 600 observations with 80 valid members (beyond one member per lane: k_ensi_huge, everything in HBM scratch), and
