@@ -3,16 +3,17 @@
 // Replaces src/api/neighbourhood.cpp:473-522 (per threshold: stats = neighbourhood(temp, halfwidth, Mean); per cell: the
 // E-fold float sum of the clamped means, then interpolate()) and util.cpp:339-414, on the byte planes of qf_box.h.
 //
-// k_qf_box<HW>: one workgroup marches down a strip of 256 output columns.  Thread (p, s) owns threshold plane p and the
-// 16 columns of segment s and keeps, in registers, the exact window sums V[16] of its cells (doubles: every temp is a
-// float32 in [0, 1] with a resolution of 2^-31 at worst and a window holds at most 33^2 of them, so no partial sum is
+// k_qf_box<HW, GENERAL>: one workgroup marches down a strip of 256 output columns.  Thread (p, s) owns threshold plane p and
+// the 8 columns of segment s (QB_SEG) and keeps, in registers, the exact window sums V[8] of its cells (doubles: every temp
+// is a float32 in [0, 1] with a resolution of 2^-31 at worst and a window holds at most 33^2 of them, so no partial sum is
 // ever rounded -- the reference's summed-area table differs from them by its own rounding only).  One step = one output
-// row: V += H(row y + HW) - H(row y - HW - 1), where H is the horizontal window sum of a row.  Both rows come as 48 bytes
-// (three 16-byte loads, always aligned and always in bounds thanks to the padding), every byte is turned into
-// temp = count / E through a 256-entry table of doubles in LDS (ds_read_b64; 255 = padding -> 0.0), and the 16 window
-// sums of the difference row cost ONE pass over its 16 + 2 HW values: with a pivot inside all 16 windows, the running
-// suffix sums below the pivot and the running prefix sums above it are exactly the two parts of every window.
-// No LDS tile, no barrier and no other thread is involved until the 16 clamped means (yarray) of the step are ready;
+// row: V += H(row y + HW) - H(row y - HW - 1), where H is the horizontal window sum of a row.  Both rows come as 40 bytes
+// (five 8-byte loads, always aligned and always in bounds thanks to the padding: the 8 columns and 16 on either side),
+// every byte is turned into temp = count / E through a 256-entry table of doubles in LDS (ds_read_b64; 255 = padding ->
+// 0.0), and the 8 window sums of the difference row cost ONE pass over its 8 + 2 HW values: with a pivot inside all the
+// windows of a block, the running suffix sums below the pivot and the running prefix sums above it are exactly the two
+// parts of every window.
+// No LDS tile, no barrier and no other thread is involved until the 8 clamped means (yarray) of the step are ready;
 // they meet the other planes' in LDS, where thread c interpolates column c of the strip (util.cpp:377-414).
 // Rows in which some cell has fewer than E valid members (rowflag) form count / valid per cell and count the valid
 // cells of every window; everywhere else the window counts are known from the geometry alone.
@@ -49,7 +50,7 @@ __device__ __forceinline__ unsigned qb_byte(const unsigned (&w)[QB_NDW], const i
 // the table of doubles sits at LDS address 0 (checked at kernel entry): the byte offset is the address
 __device__ __forceinline__ double qb_tab(const unsigned a) { return *(const __attribute__((address_space(3))) double*)(size_t)a; }
 
-// the 16 window sums of one row of 16 + 2 HW values val(i), i = byte index in the 48-byte row (column x0 - 16 + i):
+// the QB_SEG window sums of one row of QB_SEG + 2 HW values val(i), i = byte index in the 40-byte row (column x0 - 16 + i):
 // acc(j, sum of val over [16 - HW + j, 16 + HW + j]).  Blocks of BS <= 2 HW + 1 outputs share a pivot.
 template <int HW, class Val, class Acc>
 __device__ __forceinline__ void qb_windows(Val val, Acc acc) {

@@ -207,7 +207,7 @@ def test_ensi_large_n_with_elevation_nan_obs_and_invalid_member():
 
 def test_ensi_big_jacobi_kernel_agrees(monkeypatch):
     """The round-1 large-n kernel (cyclic Jacobi in LDS, GPP_ENSI_BIG_JACOBI) and the Newton-Schulz one that replaced it give the
-    oracle's values on the same cells (40 and 60 usable observations per grid point, 20 and 50 members: the tile path takes none)."""
+    oracle's values on the same cells (60 usable observations per grid point, 20 and 50 members: the 32-row tile path takes none of the cells)."""
     for E in (20, 50):
         c = case(950 + E, 6, 7, E, 60)
         out, ref = run(c, 200000, 0)
