@@ -327,12 +327,18 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                 // LU (oi.cpp:315).  K = G (P+R)^-1  <=>  (P+R)^T k = g, so lane i holds row i of A^T = column i of A,
                 // the factorisation (partial pivoting, multipliers stored in place) is done once per observation set
                 // and every member cell costs one forward + one backward substitution.
+                // Without a variance output only the increments G (P+R)^-1 d are needed: then lane i holds row i of A = P+R itself,
+                // ONE pair of substitutions gives z = A^-1 d for the whole group and every member cell is left with the dot product
+                // g . z in its own lane (instead of a pair of substitutions per member cell: 600 instructions each).
+                const bool zsolve = a.out_var == nullptr;
                 double rowT[N];
+                const float* const cb = &colbuf[0][0];
+                const int cb0 = zsolve ? lane : 64 * lane, cbs = zsolve ? 64 : 1;   // A[lane][p] (this lane computed it for observation p) or A[p][lane]
 #pragma unroll
                 for(int p = 0; p < N; ++p) {
                     double v = 0.0;
                     if(p < n && lane < n) {
-                        v = (double)colbuf[lane][p];                       // A[p][lane]: computed by lane p for observation `lane`
+                        v = (double)cb[cb0 + cbs * p];
                         if(lane == p) v += (double)o1.w;
                     }
                     rowT[p] = v;
@@ -365,7 +371,38 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                         if(elim) rowT[j] = f;                              // multiplier in place of the eliminated entry
                     }
                 }
-                unsigned long long mm = members;
+                if(zsolve) {
+                    double bvec = dmine, incv = 0.0;
+#pragma unroll
+                    for(int j = 0; j < N; ++j) {                           // forward: L y = (permuted) d
+                        if(j < n) {
+                            const int piv = __builtin_ctzll(__ballot(mystep == j));
+                            const double bp = readlane_d(bvec, piv);
+                            if(lane < n && mystep > j) bvec = __builtin_fma(-rowT[j], bp, bvec);
+                        }
+                    }
+#pragma unroll
+                    for(int j = N - 1; j >= 0; --j) {                      // backward: U z = y; every member cell adds g_j z_j
+                        if(j < n) {
+                            const int piv = __builtin_ctzll(__ballot(mystep == j));
+                            const double zj = readlane_d(bvec, piv) * readlane_d(mypinv, piv);
+                            if(lane < n && mystep < j) bvec = __builtin_fma(-rowT[j], zj, bvec);
+                            incv = __builtin_fma(zj, (double)colbuf[j][lane], incv);   // corr_background(cell, obs j) * z_j   (oi.cpp:296,316)
+                        }
+                    }
+                    if(is_g) {
+                        float increment = (float)incv;
+                        if(!a.allow_extrap) {
+                            if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                            else if(maxInc < 0 && increment > 0) increment = maxInc;
+                            else if(minInc < 0 && increment < minInc) increment = minInc;
+                            else if(minInc > 0 && increment < 0) increment = minInc;
+                        }
+                        s_res[wid][0][src] = cbg + increment;
+                        s_res[wid][1][src] = cbv;
+                    }
+                }
+                unsigned long long mm = zsolve ? 0ull : members;
                 while(mm) {
                     const int ml = __builtin_ctzll(mm);
                     mm &= mm - 1;

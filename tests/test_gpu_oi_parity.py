@@ -163,6 +163,9 @@ def _generic(c, make_gpu, make_orc, max_points, full=False):
     out, var = gridpp.optimal_interpolation_full(grid, c["bg"], ones_g, points, c["obs"], c["ratios"], c["pbg"], ones_p,
                                                  make_gpu(gridpp), max_points)
     ref, rvar = O.oi_full_generic(og, c["bg"].ravel(), ones_g.ravel(), op, c["obs"], c["ratios"], c["pbg"], ones_p, make_orc(O), max_points)
+    # the same call without a variance output (on the pivoted-LU path: one solve per selection and a dot product per cell)
+    plain = gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], make_gpu(gridpp), max_points)
+    check(np.asarray(plain), ref.reshape(Y, X))
     return np.asarray(out), ref.reshape(Y, X), np.asarray(var), rvar.reshape(Y, X)
 
 
@@ -354,6 +357,13 @@ def test_spatially_varying_structure(kind, same_grid):
     check(np.asarray(out), ref.reshape(Y, X))
     check(np.asarray(var), rvar.reshape(Y, X))
     assert np.abs(np.asarray(out) - c["bg"]).max() > 0.05
+    # without a variance output the pivoted-LU path solves (P+R) z = d once per selection and leaves every cell the dot product G.z
+    out2 = gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], st, 10)
+    check(np.asarray(out2), ref.reshape(Y, X))
+    out3 = gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], st, 10, False)
+    ref3, _ = O.oi_full_generic(og, c["bg"].ravel(), ones_g.ravel(), op, c["obs"], c["ratios"], c["pbg"], ones_p, ost, 10,
+                                False, cp, opar)
+    check(np.asarray(out3), ref3.reshape(Y, X))
 
 
 @pytest.mark.parametrize("allow", [True, False])
