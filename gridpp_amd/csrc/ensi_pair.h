@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for(int j = 0; j < 32; ++j) { const double v = (j == i) ? 0.0 : b[j]; off = __builtin_fma(v, v, off); }
                 off = half_sum_d(off, lane);
                 const double tr = half_sum_d(fabs(dg), lane);
-                // The sweeps stop at an off-diagonal norm |E| of sqrt(jtol2) * c = 0.012 c (c = nV - 1 bounds every eigenvalue of c I + B from
+                // The sweeps stop at an off-diagonal norm |E| of sqrt(jtol2) * c = 0.010 c (c = nV - 1 bounds every eigenvalue of c I + B from
                 // below): what is left of E enters the matrix functions in k_ensi_members as a perturbation series without eigenvalue
                 // gaps in any denominator (see there; measured against the LAPACK golden vectors the result stays at the float32
                 // rounding floor up to there, tools/ensi_tol.py), tested after every quarter of a sweep.  Most warm-started cells need no sweep at all that way (C5: 0.52
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     //        g(D + E) = -(M + sqrt(c) M^(1/2))^-1 = -(P + F)^-1,   P = diag(a (a + sqrt(c))) = diag(-1 / dw),   F = E + sqrt(c) (R1 + R2)
     //                 = diag(dw) + H + (H F) diag(dw) + (H F) diag(dw) F diag(dw),   H = diag(dw) F diag(dw)                (Neumann, three terms)
     //      The first-order part is the Daleckii-Krein term (1 + sqrt(c) / (a_i + a_j)) dw_i dw_j E_ij; the second-order part lets the
-    //      sweeps of k_ensi_pair stop at |E| <= 0.012 c -- most warm-started cells need no sweep at all then -- with an error of
+    //      sweeps of k_ensi_pair stop at |E| <= 0.010 c -- most warm-started cells need no sweep at all then -- with an error of
     //      (|F| / (2 c))^4.  Three 32 x 32 products on the matrix cores per cell.
     if(h == 0) {
 #pragma unroll

@@ -1315,9 +1315,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     int* const d_ints = reinterpret_cast<int*>(ws.status.p);
     int* const d_err = d_ints, *const d_fb_count = d_ints + 1, *const d_big_count = d_ints + 4, *const d_huge_count = d_ints + 5;
     unsigned long long* const d_counters = ws.status.p + 8;
-    GPP_HIP(hipMemsetAsync(ws.status.p, 0, SB * sizeof(unsigned long long), stream()));
     hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
-                       f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p, ws.saux.p);
+                       f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p, ws.saux.p, ws.status.p, (int)SB);   // (also clears the status block)
     GPP_HIP(hipGetLastError());
 
     // register-tile size of the solve: 32 rows (max_points <= 32, the common case) or 62 rows (everything up to 62
@@ -1477,12 +1476,14 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             };
             const bool expect_long = memo_hit && 16.0 * (double)memo.declined * (double)a.ntiles > (double)SHORT_ITEMS;
             if(!expect_long) {
-                short_passes(SHORT_ITEMS);
+                // (a geometry that declined no tile the last time: not even the two empty launches; the read-back says if that was wrong)
+                const bool expect_none = memo_hit && memo.declined == 0.0f;
+                if(!expect_none) short_passes(SHORT_ITEMS);
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
                 const int n1 = h_ints[1];
-                if(16 * (long)n1 > SHORT_ITEMS) {   // a long list after all: nothing has touched it yet
-                    long_passes(n1);
+                if(16 * (long)n1 > SHORT_ITEMS || (expect_none && n1 > 0)) {   // a long list after all (or an unexpected one): nothing has touched it yet
+                    if(16 * (long)n1 > SHORT_ITEMS) long_passes(n1); else short_passes(16 * n1);
                     GPP_HIP(hipEventRecord(ws.e1, stream()));
                     fetch();
                 }

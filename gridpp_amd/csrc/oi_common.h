@@ -240,8 +240,10 @@ __device__ __forceinline__ int wave_scan_add(int x) {
 static __global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const int* __restrict__ pos, const float* __restrict__ olaf,
                            const float* __restrict__ obs, const float* __restrict__ obs_var, const float* __restrict__ pbg,
                            const float* __restrict__ bvp, int need_pbg, float4* __restrict__ pgeo, float4* __restrict__ oaux,
-                           float4* __restrict__ saux = nullptr) {   // saux: the same record at the SORTED position (optional)
+                           float4* __restrict__ saux = nullptr,     // saux: the same record at the SORTED position (optional)
+                           unsigned long long* __restrict__ zero = nullptr, int nzero = 0) {   // the call's status block to clear (instead of a memset)
     int o = blockIdx.x * blockDim.x + threadIdx.x;
+    for(int i = o; i < nzero; i += gridDim.x * blockDim.x) zero[i] = 0ull;
     if(o >= S) return;
     float ob = obs[o], pb = pbg ? pbg[o] : 0.0f;
     float bv = bvp ? bvp[o] : 1.0f;

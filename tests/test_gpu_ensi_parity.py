@@ -62,7 +62,7 @@ def plain_err(out, ref):
 def test_strict_measure_with_converged_sweeps_and_count_for_the_fast_path():
     """Config-5-like inputs (E = 50, max_points 30, h = 10 km on a 1 x 1 degree domain, dense observations).
     (a) gpp_ensi_set_convergence(1): the Jacobi sweeps run to convergence and the PLAIN 1e-5 measure holds for every value.
-    (b) default (sweeps stopped at 0.012 c + perturbation series): the values outside the plain measure are counted -- they
+    (b) default (sweeps stopped at 0.010 c + perturbation series): the values outside the plain measure are counted -- they
         are last-bit differences of one float32 term: at most 2 in 10^6 of them, none beyond 2e-5."""
     import gridpp_amd as gridpp
     c = case(4242, 56, 60, 50, 1200)

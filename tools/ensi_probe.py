@@ -1,5 +1,6 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Four C5 EnSI calls with the wall time of each (first-call allocations, the kept park): for timing experiments and rocprofv3."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import gridpp_amd as gridpp
 from tools.bench_cases import ensi_inputs

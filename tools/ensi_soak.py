@@ -13,9 +13,12 @@ from tests.test_gpu_ensi_parity import plain_err
 n_values = n_outside = 0
 worst_fast = worst_strict = 0.0
 strict_bad = []
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+# argument: seconds, or a number of seeds as "400s" ("seeds": a run that does not depend on the speed of the box)
+arg = sys.argv[1] if len(sys.argv) > 1 else "60"
+nseeds = int(arg[:-1]) if arg.endswith("s") else None
+budget = float("inf") if nseeds else float(arg)
 t0, seed, bad, nbig = time.time(), 0, [], 0
-while time.time() - t0 < budget:
+while (seed < nseeds) if nseeds else (time.time() - t0 < budget):
     seed += 1
     rng = np.random.default_rng(seed)
     E = int(rng.choice([2, 5, 10, 30, 50, 64]))
