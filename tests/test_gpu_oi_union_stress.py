@@ -59,7 +59,16 @@ def test_random_configurations_rough_terrain(seed):
     _check(out, ref)
 
 
-def _random_configuration(seed, mps, cressman=False):
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_random_configurations_pivoted_lu(seed, monkeypatch):
+    """The pivoted-LU form of k_oi (non-symmetric / spatially varying structures; forced here on symmetric systems, whose oracle
+    values are known): one solve per distinct selection and a dot product per cell without a variance output, a pair of substitutions
+    per cell with one -- on the same random configurations, max_points up to 62."""
+    monkeypatch.setenv("GPP_OI_FORCE_LU", "1")
+    _random_configuration(seed, [1, 5, 20, 30, 32, 45, 62], lu=True)
+
+
+def _random_configuration(seed, mps, cressman=False, lu=False):
     import gridpp_amd as gridpp
     from oracle import oracle as O
     rng = np.random.default_rng(4000 + seed)
@@ -103,7 +112,7 @@ def _random_configuration(seed, mps, cressman=False):
     ref = O.oi(og, bg.ravel(), op, obs, ratios, pbg, ost, mp, allow).reshape(Y, X)
     _check(out, ref)
     stats = gridpp.oi_last_stats()
-    assert stats["union_kernel_ms"] > 0          # this configuration is routed to k_oi_union
+    assert (stats["union_kernel_ms"] > 0) != lu  # this configuration is routed to k_oi_union (unless the pivoted LU is forced)
     # variance output of the same configuration
     bvar = rng.uniform(0.5, 2, (Y, X)).astype(np.float32)
     bvp = rng.uniform(0.5, 2, S).astype(np.float32)
