@@ -27,6 +27,9 @@
 
 typedef int v2i __attribute__((ext_vector_type(2)));
 
+#ifndef GPP_ENSI_JCHUNK
+#define GPP_ENSI_JCHUNK 4   // double phases between two tests of the off-diagonal norm in k_ensi_pair (4 = a quarter of a sweep)
+#endif
 // ---- cross-lane moves of doubles on the VALU (DPP) -------------------------------------------------------------------------
 template <int CTRL, int BANK>
 __device__ __forceinline__ double dpp_d(const double old, const double v) {
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             };
             double dg = diag_of_rows();
 #pragma unroll 1
-            for(int sweep = 0; sweep < 120 && n > 1 && !GPP_DBG(a, 1); ++sweep) {   // (in quarters of a sweep: 4 of its 16 double phases)
+            for(int sweep = 0; sweep < 480 / GPP_ENSI_JCHUNK && n > 1 && !GPP_DBG(a, 1); ++sweep) {   // (in chunks of GPP_ENSI_JCHUNK of a sweep's 16 double phases)
                 double off = 0.0;   // (not sum(b^2) - dg^2: the off-diagonal part is 20 orders below the diagonal when converged)
 #pragma unroll
                 for(int j = 0; j < 32; ++j) { const double v = (j == i) ? 0.0 : b[j]; off = __builtin_fma(v, v, off); }
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if(__ballot(open && !(dup && h == 1)) == 0ull) break;
                 nsweeps++;
 #pragma unroll 1
-                for(int st = 0; st < 4; ++st) {   // every double phase is a complete similarity transform: the test above may come after any
+                for(int st = 0; st < GPP_ENSI_JCHUNK; ++st) {   // every double phase is a complete similarity transform: the test above may come after any
                     jacobi_phase<false>(b, u, dg, i, h, m1, m2, m3, m4, s_cs);
                     jacobi_phase<true>(b, u, dg, i, h, m1, m2, m3, m4, s_cs);
                 }
