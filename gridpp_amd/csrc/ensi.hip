@@ -1504,7 +1504,8 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
             a.tile0 = t0;
             if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_pair<true>, dim3(nt), dim3(64), 0, stream(), a);
             else hipLaunchKernelGGL(k_ensi_pair<false>, dim3(nt), dim3(64), 0, stream(), a);
-            hipLaunchKernelGGL(k_ensi_members<0>, dim3((unsigned)nt * 64u), dim3(64), 0, stream(), a);
+            if(a.nV <= 64) hipLaunchKernelGGL(k_ensi_members<true>, dim3((unsigned)nt * 64u), dim3(64), 0, stream(), a);
+            else hipLaunchKernelGGL(k_ensi_members<false>, dim3((unsigned)nt * 64u), dim3(64), 0, stream(), a);
             GPP_HIP(hipGetLastError());
         }
     }

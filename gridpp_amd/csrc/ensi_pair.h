@@ -478,7 +478,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 // ---- pass 3: the ensemble side, one wave per cell (lane = member, chunks of 64): no dependence between cells, so the chip runs as
 //      many of these as its registers hold -- inside k_ensi_pair this part ran at one wave per SIMD with nobody to hide its loads
-template <int UNUSED>
+// ONECHUNK: at most 64 valid members (one chunk): the member update is a matrix-core product as well (below); both forms in one kernel
+// do not fit its 256 registers.
+template <bool ONECHUNK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ensi_members(EnsiArgs a) {
     __shared__ __attribute__((aligned(16))) double s_ab[2 * 32 * PP];
     __shared__ __attribute__((aligned(16))) double s_sD1[32], s_z1[32], s_t[32], s_r1[32], s_dw[32], s_rt[32];
@@ -746,6 +748,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
             EPROF(5)   // Y tile, Q
+            float acc = 0.0f;
+            double X = 0.0;
+            if constexpr(ONECHUNK) {
+                // Up to 64 members (one chunk): W' = Y^T Q on the matrix cores as well (round 3: config 5 309 -> 296 ms).  The accumulators of the Q product ARE the B
+                // operands of this one (lane (kq, r16) holds Q(16 ti + kq + 4 r, 16 te + r16): k-step ks = 4 ti + r), the A operands are
+                // the values of the Y tile the Q product read.  One 16-member slab of W' at a time goes through area A (M' is not
+                // needed any more) so that lane = member e finds its 16 values W'(k, e) in k order for the float accumulation of
+                // oi_ensi.cpp:505-511; X_k and w_k come from lane k.
+                const int r16 = lane & 15, kq = lane >> 4;
+                X = (double)v0 - (double)ensMean;
+                double wk = 0.0;   // w_k = sum_r sD_r Y(r,k) z_r for member k = lane
+#pragma unroll
+                for(int r = 0; r < 32; ++r) wk = __builtin_fma(s_sD1[r] * (double)sBf[r * YP + lane], s_z1[r], wk);
+#pragma unroll 1
+                for(int tk = 0; 16 * tk < nV; ++tk) {
+                    v4d wt[4];
+#pragma unroll
+                    for(int te = 0; te < 4; ++te) wt[te] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for(int ks = 0; ks < 8; ++ks) {
+                        const double aop = (double)sBf[(4 * ks + kq) * YP + 16 * tk + r16];   // Y(i = 4 ks + kq, k = 16 tk + r16)
+#pragma unroll
+                        for(int te = 0; te < 4; ++te) wt[te] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, qa[ks >> 2][te][ks & 3], wt[te], 0, 0, 0);
+                    }
+                    __syncthreads();   // (the previous slab has been read)
+#pragma unroll
+                    for(int te = 0; te < 4; ++te)
+#pragma unroll
+                        for(int r = 0; r < 4; ++r) sA[(16 * te + r16) * 17 + kq + 4 * r] = wt[te][r];   // W'(k = 16 tk + kq + 4 r, e = 16 te + r16)
+                    __syncthreads();
+                    double wv[16];
+#pragma unroll
+                    for(int kl = 0; kl < 16; ++kl) wv[kl] = sA[lane * 17 + kl];
+#pragma unroll
+                    for(int kl = 0; kl < 16; ++kl) {
+                        const int k = 16 * tk + kl;
+                        if(k < nV) {
+                            const double wke = ((k == lane ? 1.0 : 0.0) + wv[kl]) + readlane_d(wk, k);
+                            acc = (float)((double)acc + readlane_d(X, k) * wke);
+                        }
+                    }
+                }
+                EPROF(7)   // member update
+            }
+            else {
             // columns i and 32 + i of Y, rows [16 h, 16 h + 16), for the tables of the member update: out of the Y tile while it is still
             // there (first member chunk: the tile holds columns 0..63; otherwise they are loaded again below)
             float ya[16], yb[16];
@@ -770,10 +817,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
             const float value = (e0_ == 0) ? v0 : ((e < nV) ? a.bg[(long)cell_l * E + ensi_member(a, e)] : 0.0f);
-            const double X = (double)value - (double)ensMean;
+            X = (double)value - (double)ensMean;
             EPROF(6)   // transposition
             // total_e = sum_k X_k W(k,e), W(k,e) = [k == e] + sum_i Y(i,k) q_e(i) + w_k, float accumulation in k order (:505-511)
-            float acc = 0.0f;
 #pragma unroll 1
             for(int k0 = 0; k0 < nV; k0 += 32) {
                 const int kk = k0 + i;    // lanes i and 32 + i share column kk: rows [16 h, 16 h + 16)
@@ -822,6 +868,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
             EPROF(7)   // member update
+            }
             float currIncrement = acc;
             if(!a.allow_extrap && e < nV) {
                 const int li = e % n, lk = e / n;
