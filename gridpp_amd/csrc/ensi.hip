@@ -818,10 +818,57 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
             continue;
         }
         if(n == 0 || nV <= 1) continue;
+        // ---- the max_points largest keys (rho descending, ties -> lower index: the keys are unique) by a radix select, eight bits a pass,
+        //      instead of sorting every candidate: 2 700 candidates for 50 kept ones were 85 of the 203 ms of the 500 x 500 x 50 case.
+        //      A pass counts the keys that share the prefix found so far by their next digit; the digit holding the n-th largest key
+        //      extends the prefix; when every key under the prefix belongs to the selection the remaining bits do not matter.
+        int nsort = ncand;
+        if(truncated) {
+            int* const hist = reinterpret_cast<int*>(s_off);   // [256] digit counts, then their suffix sums; [256..258]: the digit found
+            unsigned long long prefix = 0ull;
+            int need = n, ls = 56;
+            for(int shift = 56; shift >= 0; shift -= 8) {
+                hist[tid] = 0;
+                __syncthreads();
+                const unsigned long long mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+                for(int i = tid; i < ncand; i += 256) {
+                    const unsigned long long k = s_key[i];
+                    if((k & mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 255ull)], 1);
+                }
+                __syncthreads();
+                for(int off = 1; off < 256; off <<= 1) {   // hist[b] <- number of such keys with a digit >= b
+                    const int v = (tid + off < 256) ? hist[tid + off] : 0;
+                    __syncthreads();
+                    hist[tid] += v;
+                    __syncthreads();
+                }
+                const int S = hist[tid], Sn = tid < 255 ? hist[tid + 1] : 0;
+                __syncthreads();
+                if(S >= need && Sn < need) { hist[256] = tid; hist[257] = Sn; hist[258] = S - Sn; }
+                __syncthreads();
+                const int d = hist[256], above = hist[257], here = hist[258];
+                __syncthreads();
+                need -= above;
+                prefix |= (unsigned long long)d << shift;
+                ls = shift;
+                if(here == need) break;   // (at the last pass at the latest: one key per value)
+            }
+            if(tid == 0) s_n = 0;
+            __syncthreads();
+            for(int i = tid; i < ncand; i += 256) {
+                const unsigned long long k = s_key[i];
+                if((k >> ls) >= (prefix >> ls)) gkeys[atomicAdd(&s_n, 1)] = k;
+            }
+            __threadfence_block();
+            __syncthreads();
+            for(int i = tid; i < n; i += 256) s_key[i] = gkeys[i];
+            nsort = n;
+            __syncthreads();
+        }
         // ---- order: rho descending (ties -> lower index) when the reference sorts, candidate (= index) order otherwise (:243-269)
         int np2 = 1;
-        while(np2 < ncand) np2 <<= 1;
-        for(int i = ncand + tid; i < np2; i += 256) s_key[i] = 0ull;
+        while(np2 < nsort) np2 <<= 1;
+        for(int i = nsort + tid; i < np2; i += 256) s_key[i] = 0ull;
         __syncthreads();
         for(int k = 2; k <= np2; k <<= 1) {
             for(int j = k >> 1; j > 0; j >>= 1) {
@@ -840,51 +887,64 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
         for(int i = tid; i < n; i += 256) gkeys[i] = s_key[i];
         __threadfence_block();
         __syncthreads();
-        // ---- Pinv = Y^T Rinv Y + c I, t = Y^T Rinv d, in chunks of 64 observations staged in LDS (as k_ensi_big: same order of the sums)
-        float* const yc = reinterpret_cast<float*>(s_key);          // [64][64] Y chunk
-        double* const rinv = reinterpret_cast<double*>(yc + 64 * 64);   // [64]
-        double* const dvec = rinv + 64;                                 // [64]
-        double accP[16];
+        // ---- Pinv = Y^T Rinv Y + c I on the matrix cores, t = Y^T Rinv d; chunks of 64 observations staged in LDS.  Wave wv accumulates
+        //      rows [16 wv, 16 wv + 16) of Pinv: A(row a, k = i) = Y(i, a) rinv_i, B(k = i, col b) = Y(i, b); lane (kq, r16) ends with
+        //      Pinv(16 wv + kq + 4 r, 16 tb + r16) in accT[tb][r].  (Round 1 summed them on the vector unit, sixteen entries a thread:
+        //      49 of the 203 ms of the 500 x 500 x 50 case, 96 of 159 ms with 400 observations per grid point.)
+        constexpr int YCP = 80;                                          // pitch of the Y chunk: the four k rows of an operand fall on different banks
+        float* const yc = reinterpret_cast<float*>(s_key);               // [64][YCP] Y chunk
+        double* const rinv = reinterpret_cast<double*>(yc + 64 * YCP);   // [64]
+        double* const dvec = rinv + 64;                                  // [64]
+        const int r16 = lane & 15, kq = lane >> 4;
+        v4d accT[4];
 #pragma unroll
-        for(int r = 0; r < 16; ++r) accP[r] = 0.0;
+        for(int tb = 0; tb < 4; ++tb) accT[tb] = (v4d){0.0, 0.0, 0.0, 0.0};
         double acct = 0.0;
         for(int i0 = 0; i0 < n; i0 += 64) {
-            const int m = min(64, n - i0);
+            const int m = min(64, n - i0), m4 = (m + 3) & ~3;
             __syncthreads();
-            for(int e = tid; e < m * 64; e += 256) {
+            for(int e = tid; e < m4 * 64; e += 256) {
                 const int i = e >> 6, k = e & 63;
-                const unsigned orig = ~(unsigned)(gkeys[i0 + i] & 0xffffffffull);
-                yc[i * 64 + k] = (k < nV) ? a.gY[(long)orig * nV + k] : 0.0f;
+                float v = 0.0f;
+                if(i < m && k < nV) {
+                    const unsigned orig = ~(unsigned)(gkeys[i0 + i] & 0xffffffffull);
+                    v = a.gY[(long)orig * nV + k];
+                }
+                yc[i * YCP + k] = v;
             }
-            if(tid < m) {
-                const unsigned long long key = gkeys[i0 + tid];
-                const unsigned orig = ~(unsigned)(key & 0xffffffffull);
-                const float4 x4 = a.oaux[orig];                       // laf, obs, gYhat, sigma
-                const float s2 = x4.w * x4.w;                         // float product (oi_ensi.cpp:300)
-                rinv[tid] = (double)__uint_as_float((unsigned)(key >> 32)) / (double)s2;
-                dvec[tid] = (double)x4.y - (double)x4.z;
+            if(tid < 64) {
+                double ri = 0.0, dv = 0.0;
+                if(tid < m) {
+                    const unsigned long long key = gkeys[i0 + tid];
+                    const unsigned orig = ~(unsigned)(key & 0xffffffffull);
+                    const float4 x4 = a.oaux[orig];                       // laf, obs, gYhat, sigma
+                    const float s2 = x4.w * x4.w;                         // float product (oi_ensi.cpp:300)
+                    ri = (double)__uint_as_float((unsigned)(key >> 32)) / (double)s2;
+                    dv = (double)x4.y - (double)x4.z;
+                }
+                rinv[tid] = ri; dvec[tid] = dv;
             }
             __syncthreads();
-            for(int r = 0; r < 16; ++r) {
-                const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
-                if(ai < nV && bi < nV) {
-                    double sacc = accP[r];
-                    for(int i = 0; i < m; ++i) sacc = __builtin_fma((double)yc[i * 64 + ai] * rinv[i], (double)yc[i * 64 + bi], sacc);
-                    accP[r] = sacc;
-                }
+            for(int ks = 0; 4 * ks < m4; ++ks) {
+                const int io = 4 * ks + kq;
+                const double aop = (double)yc[io * YCP + 16 * wv + r16] * rinv[io];
+#pragma unroll
+                for(int tb = 0; tb < 4; ++tb) accT[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, (double)yc[io * YCP + 16 * tb + r16], accT[tb], 0, 0, 0);
             }
-            if(tid < nV) for(int i = 0; i < m; ++i) acct = __builtin_fma((double)yc[i * 64 + tid] * rinv[i], dvec[i], acct);
+            if(tid < nV) for(int i = 0; i < m; ++i) acct = __builtin_fma((double)yc[i * YCP + tid] * rinv[i], dvec[i], acct);
         }
         __syncthreads();
         // ---- scaling: s = (|Pinv|_inf + c) / 2; Y_0 = Pinv / s (rows / columns beyond nV: the identity, which stays the identity), Z_0 = I
         double rowabs = 0.0;
 #pragma unroll
-        for(int r = 0; r < 16; ++r) {
-            const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
-            const double v = (ai < nV && bi < nV) ? accP[r] + (ai == bi ? c : 0.0) : 0.0;
-            accP[r] = v;
-            M2[ai * NSP + bi] = fabs(v);
-        }
+        for(int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for(int r = 0; r < 4; ++r) {
+                const int ai = 16 * wv + kq + 4 * r, bi = 16 * tb + r16;
+                const double v = (ai < nV && bi < nV) ? accT[tb][r] + (ai == bi ? c : 0.0) : 0.0;
+                accT[tb][r] = v;
+                M2[ai * NSP + bi] = fabs(v);
+            }
         if(tid < 64) s_t[tid] = (tid < nV) ? acct : 0.0;
         __syncthreads();
         if(tid < 64) { for(int k = 0; k < 64; ++k) rowabs += M2[tid * NSP + k]; }
@@ -894,17 +954,18 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
         const double sc = 0.5 * (s_off[0] + c), rsc = 1.0 / sc;
         __syncthreads();
 #pragma unroll
-        for(int r = 0; r < 16; ++r) {
-            const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
-            M0[ai * NSP + bi] = (ai < nV && bi < nV) ? accP[r] * rsc : (ai == bi ? 1.0 : 0.0);
-            M1[ai * NSP + bi] = ai == bi ? 1.0 : 0.0;
-        }
+        for(int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for(int r = 0; r < 4; ++r) {
+                const int ai = 16 * wv + kq + 4 * r, bi = 16 * tb + r16;
+                M0[ai * NSP + bi] = (ai < nV && bi < nV) ? accT[tb][r] * rsc : (ai == bi ? 1.0 : 0.0);
+                M1[ai * NSP + bi] = ai == bi ? 1.0 : 0.0;
+            }
         __syncthreads();
         // ---- coupled Newton-Schulz on the matrix cores.  Y, Z and T are symmetric (polynomials of one matrix), so only the 16 x 16
         //      tiles on and above the diagonal of the nt x nt tile grid (nt = ceil(nV / 16)) are computed for up to 48 members -- 3 of 16
         //      for 17..32 -- and stored twice, tile p of the list on wave p mod 4; with 49..64 members (nt = 4) every wave takes a strip of
         //      16 rows of the full product instead (one A operand per four MFMAs: measured faster than 10 tiles of two operands each).
-        const int r16 = lane & 15, kq = lane >> 4;
         const int nt = (nV + 15) >> 4, npair = nt * (nt + 1) / 2, K4 = nt * 16;
         auto tile_of = [&](const int p, int& ti, int& tj) {   // p-th pair (ti <= tj), row by row
             int q = p; ti = 0;
