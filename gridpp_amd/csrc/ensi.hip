@@ -818,53 +818,9 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
             continue;
         }
         if(n == 0 || nV <= 1) continue;
-        // ---- the max_points largest keys (rho descending, ties -> lower index: the keys are unique) by a radix select, eight bits a pass,
-        //      instead of sorting every candidate: 2 700 candidates for 50 kept ones were 85 of the 203 ms of the 500 x 500 x 50 case.
-        //      A pass counts the keys that share the prefix found so far by their next digit; the digit holding the n-th largest key
-        //      extends the prefix; when every key under the prefix belongs to the selection the remaining bits do not matter.
+        // ---- the max_points largest keys by a radix select (oi_common.h) instead of sorting every candidate; only they are sorted
         int nsort = ncand;
-        if(truncated) {
-            int* const hist = reinterpret_cast<int*>(s_off);   // [256] digit counts, then their suffix sums; [256..258]: the digit found
-            unsigned long long prefix = 0ull;
-            int need = n, ls = 56;
-            for(int shift = 56; shift >= 0; shift -= 8) {
-                hist[tid] = 0;
-                __syncthreads();
-                const unsigned long long mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-                for(int i = tid; i < ncand; i += 256) {
-                    const unsigned long long k = s_key[i];
-                    if((k & mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 255ull)], 1);
-                }
-                __syncthreads();
-                for(int off = 1; off < 256; off <<= 1) {   // hist[b] <- number of such keys with a digit >= b
-                    const int v = (tid + off < 256) ? hist[tid + off] : 0;
-                    __syncthreads();
-                    hist[tid] += v;
-                    __syncthreads();
-                }
-                const int S = hist[tid], Sn = tid < 255 ? hist[tid + 1] : 0;
-                __syncthreads();
-                if(S >= need && Sn < need) { hist[256] = tid; hist[257] = Sn; hist[258] = S - Sn; }
-                __syncthreads();
-                const int d = hist[256], above = hist[257], here = hist[258];
-                __syncthreads();
-                need -= above;
-                prefix |= (unsigned long long)d << shift;
-                ls = shift;
-                if(here == need) break;   // (at the last pass at the latest: one key per value)
-            }
-            if(tid == 0) s_n = 0;
-            __syncthreads();
-            for(int i = tid; i < ncand; i += 256) {
-                const unsigned long long k = s_key[i];
-                if((k >> ls) >= (prefix >> ls)) gkeys[atomicAdd(&s_n, 1)] = k;
-            }
-            __threadfence_block();
-            __syncthreads();
-            for(int i = tid; i < n; i += 256) s_key[i] = gkeys[i];
-            nsort = n;
-            __syncthreads();
-        }
+        if(truncated) { block_select_largest(s_key, ncand, n, gkeys, reinterpret_cast<int*>(s_off), &s_n, tid); nsort = n; }
         // ---- order: rho descending (ties -> lower index) when the reference sorts, candidate (= index) order otherwise (:243-269)
         int np2 = 1;
         while(np2 < nsort) np2 <<= 1;

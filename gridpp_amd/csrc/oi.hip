@@ -740,10 +740,13 @@ __global__ __launch_bounds__(256) void k_oi_big(OiArgs a) {
             __syncthreads();
             continue;
         }
-        // ---- bitonic sort, descending: rho descending, ties -> lower observation index (oi.cpp:262-273) ------------------------
+        // ---- the max_points largest keys first (radix select, oi_common.h), then the bitonic sort of those alone, descending: rho
+        //      descending, ties -> lower observation index (oi.cpp:262-273) ----------------------------------------------------
+        int nsort = ncand;
+        if(n < ncand) { block_select_largest(s_key, ncand, n, gkeys, reinterpret_cast<int*>(&s_red[0][0]), &s_n, tid); nsort = n; }
         int np2 = 1;
-        while(np2 < ncand) np2 <<= 1;
-        for(int i = ncand + tid; i < np2; i += 256) s_key[i] = 0ull;
+        while(np2 < nsort) np2 <<= 1;
+        for(int i = nsort + tid; i < np2; i += 256) s_key[i] = 0ull;
         __syncthreads();
         for(int k = 2; k <= np2; k <<= 1) {
             for(int j = k >> 1; j > 0; j >>= 1) {

@@ -236,6 +236,54 @@ __device__ __forceinline__ int wave_scan_add(int x) {
     return x;
 }
 
+// The n largest of ncand unique 64-bit keys (rho bits << 32 | ~observation index: rho descending, ties -> lower index), for a workgroup of
+// 256 threads: an 8-bit radix select instead of sorting every candidate (2 700 candidates for 50 kept ones: 85 of 203 ms of the large-n
+// EnSI case went into the full bitonic sort).  A pass counts the keys under the prefix found so far by their next digit; the digit that
+// holds the n-th largest key extends the prefix; as soon as every key under the prefix belongs to the selection the remaining bits do not
+// matter.  The selection lands in keys[0 .. n) in no particular order (through `out`, n keys of HBM scratch); `hist` is 259 ints of LDS,
+// `counter` one more.  All 256 threads call it; keys[] must not be touched by anyone else meanwhile.
+__device__ __forceinline__ void block_select_largest(unsigned long long* keys, const int ncand, const int n, unsigned long long* out,
+                                                     int* hist, int* counter, const int tid) {
+    unsigned long long prefix = 0ull;
+    int need = n, ls = 56;
+    for(int shift = 56; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+        for(int i = tid; i < ncand; i += 256) {
+            const unsigned long long k = keys[i];
+            if((k & mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 255ull)], 1);
+        }
+        __syncthreads();
+        for(int off = 1; off < 256; off <<= 1) {   // hist[b] <- number of such keys with a digit >= b
+            const int v = (tid + off < 256) ? hist[tid + off] : 0;
+            __syncthreads();
+            hist[tid] += v;
+            __syncthreads();
+        }
+        const int S = hist[tid], Sn = tid < 255 ? hist[tid + 1] : 0;
+        __syncthreads();
+        if(S >= need && Sn < need) { hist[256] = tid; hist[257] = Sn; hist[258] = S - Sn; }
+        __syncthreads();
+        const int d = hist[256], above = hist[257], here = hist[258];
+        __syncthreads();
+        need -= above;
+        prefix |= (unsigned long long)d << shift;
+        ls = shift;
+        if(here == need) break;   // (at the last pass at the latest: one key per value)
+    }
+    if(tid == 0) *counter = 0;
+    __syncthreads();
+    for(int i = tid; i < ncand; i += 256) {
+        const unsigned long long k = keys[i];
+        if((k >> ls) >= (prefix >> ls)) out[atomicAdd(counter, 1)] = k;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for(int i = tid; i < n; i += 256) keys[i] = out[i];
+    __syncthreads();
+}
+
 // Per-call observation pack: validity (oi.cpp:252), variance ratio (oi.cpp:192-195).
 static __global__ void k_pack_obs(int S, const float4* __restrict__ sgeo, const int* __restrict__ pos, const float* __restrict__ olaf,
                            const float* __restrict__ obs, const float* __restrict__ obs_var, const float* __restrict__ pbg,
