@@ -122,10 +122,13 @@ __global__ __launch_bounds__(256) void k_ensi_multi(MultiArgs ma) {
             continue;
         }
         if(ma.oob) { if(tid == 0) atomicOr(a.err, 4); continue; }
-        // ---- order: rho descending (ties -> lower index) when the reference sorts, index order otherwise -------------------------------
+        // ---- order: rho descending (ties -> lower index) when the reference sorts, index order otherwise; the max_points largest
+        //      keys are picked by a radix select first (oi_common.h) and only they are sorted ---------------------------------------
+        int nsort = ncand;
+        if(truncated) { block_select_largest(s_key, ncand, n, gkeys, reinterpret_cast<int*>(s_off), &s_n, tid); nsort = n; }
         int np2 = 1;
-        while(np2 < ncand) np2 <<= 1;
-        for(int i = ncand + tid; i < np2; i += 256) s_key[i] = 0ull;
+        while(np2 < nsort) np2 <<= 1;
+        for(int i = nsort + tid; i < np2; i += 256) s_key[i] = 0ull;
         __syncthreads();
         for(int k = 2; k <= np2; k <<= 1) {
             for(int j = k >> 1; j > 0; j >>= 1) {

@@ -705,7 +705,11 @@ __global__ __launch_bounds__(256) void k_oi_big(OiArgs a) {
     const DevStructure& st = sa.st;
     const int nlist = *a.big_count;
     unsigned long long* const gkeys = a.big_keys + (size_t)blockIdx.x * BIG_CAND;
-    double* const A = a.big_mat + (size_t)blockIdx.x * (BIG_N + 2) * BIG_N;
+    // The augmented matrix ((n + 2) x n doubles) stays in LDS up to BIG_NL observations: the right-looking factorisation is a chain of
+    // n column steps with a read-modify-write of the trailing matrix each -- through HBM scratch every step paid a few memory latencies
+    // (1.0 us per grid point at max_points 100 with one workgroup per CU); larger systems keep the scratch of round 1.
+    __shared__ double s_mat[(BIG_NL + 2) * BIG_NL];
+    double* const gA = a.big_mat + (size_t)blockIdx.x * (BIG_N + 2) * BIG_N;
     for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
         const int cell = a.big_list[li];
         const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
@@ -740,6 +744,7 @@ __global__ __launch_bounds__(256) void k_oi_big(OiArgs a) {
             __syncthreads();
             continue;
         }
+        double* const A = n <= BIG_NL ? s_mat : gA;
         // ---- the max_points largest keys first (radix select, oi_common.h), then the bitonic sort of those alone, descending: rho
         //      descending, ties -> lower observation index (oi.cpp:262-273) ----------------------------------------------------
         int nsort = ncand;

@@ -61,6 +61,7 @@ struct OiArgs {
 #define GPP_NSLOT 512
 #define BIG_CAND 8192   // candidates of one cell k_oi_big can sort
 #define BIG_N 512       // observations of one cell k_oi_big can factorise
+#define BIG_NL 104      // ... with the matrix in LDS (86 KB beside the 64 KB of candidate keys)
 #define ERR_OVERFLOW 1
 #define ERR_SINGULAR 2
 
