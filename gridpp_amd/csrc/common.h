@@ -161,7 +161,7 @@ struct gpp_points {
     // memo of the last OI call with this point set as the background: did k_oi_union pay? (same observations handle and
     // structure scales -> same geometry -> same answer; the observation VALUES do not matter)
     // (keyed on the observation set's serial number, not its address: a new handle may reuse the address of a destroyed one)
-    struct { unsigned long long points_id = 0; float h = 0, v = 0, w = 0; int kh = -1, kv = -1, kw = -1, cv = -1; int max_points = -1; float declined = 0; } union_memo;
+    struct { unsigned long long points_id = 0; float h = 0, v = 0, w = 0; int kh = -1, kv = -1, kw = -1, cv = -1; int max_points = -1; float declined = 0; int leftover = -1; } union_memo;   // (leftover: 4-cell items the last call left to k_oi)
     unsigned long long serial = 0;   // unique per handle, assigned at creation
     gpp_obs_index* obs_index = nullptr;
     gpp_nn_index* nn_index = nullptr;

@@ -1460,6 +1460,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             // on the device; a list too long for that grid is left untouched by both and handled after the one read-back of
             // the call.  (A host round trip here cost ~25 us per call.)  When the last call with this geometry had a long
             // list, the host asks first, as the two-level passes need its length for their grids anyway.
+            // (a geometry whose last call left nothing to k_oi: not even its empty launch; the read-back says if that was wrong)
+            const bool skip_k_oi = memo_hit && memo.leftover == 0;
             auto short_passes = [&](const int nitems) {
                 // every declined tile straight to its sixteen 4-cell items (one pass; the latency of a pass, one lone work
                 // item, is what a short list costs)
@@ -1467,7 +1469,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 launch_union(nitems, true);
                 // what is still left, one factorisation per distinct selection (grid-stride over the list)
                 a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 128;
-                launch_k_oi(false);   // (usually nothing is left: a small grid keeps the empty launch cheap)
+                if(!skip_k_oi) launch_k_oi(false);   // (usually nothing is left: a small grid keeps the empty launch cheap)
             };
             auto long_passes = [&](const int n1) {
                 // pass 2: the declined tiles as 4 items of 16 cells (smaller unions); a list too long for the split to pay is
@@ -1480,7 +1482,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 launch_union(16 * (long)n1, true);
                 // pass 4: what is still left, one factorisation per distinct selection (grid-stride over the list)
                 a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
-                launch_k_oi(false);
+                if(!skip_k_oi) launch_k_oi(false);
             };
             const bool expect_long = memo_hit && 16.0 * (double)memo.declined * (double)a.ntiles > (double)SHORT_ITEMS;
             if(!expect_long) {
@@ -1505,6 +1507,12 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
             }
+            if(skip_k_oi && h_ints[3] > 0) {   // 4-cell items for k_oi after all
+                a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                launch_k_oi(false);
+                GPP_HIP(hipEventRecord(ws.e1, stream()));
+                fetch();
+            }
             ran_union = true;
         }
         else {
@@ -1519,6 +1527,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             memo.points_id = points->serial; memo.h = a.s.st.h; memo.v = a.s.st.v; memo.w = a.s.st.w; memo.max_points = max_points;
             memo.kh = a.s.st.kh; memo.kv = a.s.st.kv; memo.kw = a.s.st.kw; memo.cv = a.s.st.cv;
             memo.declined = (float)nfb[0] / (float)a.ntiles;
+            memo.leftover = nfb[2];
         }
         if(big_ok) {
             const int nbig = h_ints[4];

@@ -147,6 +147,38 @@ def test_scattered_output_points_use_the_work_lists():
     _check(out_s, ref[order])
 
 
+def test_repeated_calls_when_the_last_call_misleads_the_next():
+    """A geometry remembers what its last call did (tiles declined by the first pass, items left to k_oi) and launches the list
+    passes accordingly, without asking the device first.  Here the memory is wrong on purpose: the first call has no valid
+    background anywhere (nothing declined, nothing left), the second one the real field (declined tiles, items for k_oi), the
+    third the real field again (now expected), the fourth nothing again -- all must give the oracle's values."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(78)
+    C, S = 5000, 3000
+    qlat, qlon = 60 + rng.random(C), 10 + 2 * rng.random(C)
+    plat, plon = 60 + rng.random(S), 10 + 2 * rng.random(S)
+    bg = rng.normal(0, 1, C).astype(np.float32)
+    obs, pbg = rng.normal(0, 1, S).astype(np.float32), rng.normal(0, 1, S).astype(np.float32)
+    ratios = rng.uniform(0.1, 1, S).astype(np.float32)
+    st, q, p = gridpp.BarnesStructure(8000), gridpp.Points(qlat, qlon), gridpp.Points(plat, plon)
+    nothing = np.full(C, np.nan, np.float32)
+    out0 = gridpp.optimal_interpolation(q, nothing, p, obs, ratios, pbg, st, 30)
+    assert np.isnan(np.asarray(out0)).all()
+    s0 = gridpp.oi_last_stats()
+    assert s0["fallback_tiles"] == 0 and s0["fallback_subtiles"] == 0
+    ref = O.oi(O.Pts(qlat, qlon), bg, O.Pts(plat, plon), obs, ratios, pbg, O.Barnes(8000), 30)
+    out = gridpp.optimal_interpolation(q, bg, p, obs, ratios, pbg, st, 30)
+    s1 = gridpp.oi_last_stats()
+    assert s1["fallback_tiles"] > 0 and s1["fallback_subtiles"] > 0   # (neither was expected: both lists were found by the read-back)
+    _check(out, ref)
+    out = gridpp.optimal_interpolation(q, bg, p, obs, ratios, pbg, st, 30)   # (now every tile is expected to decline: k_oi alone)
+    _check(out, ref)
+    # and back: a call that expects work and finds none
+    out0 = gridpp.optimal_interpolation(q, nothing, p, obs, ratios, pbg, st, 30)
+    assert np.isnan(np.asarray(out0)).all()
+
+
 def test_union_and_per_selection_kernels_agree_on_the_headline_geometry():
     import os
     import gridpp_amd as gridpp
