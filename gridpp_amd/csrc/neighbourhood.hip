@@ -95,7 +95,6 @@ __device__ __forceinline__ void member_row_work(const float* row, const int E, c
             if(vec_ok) {   // 16-byte LDS reads, 4 members per read, issued ahead of the compares
                 const float4* r4 = reinterpret_cast<const float4*>(row);
                 const int n4 = E >> 2;
-#pragma unroll 2
                 for(int i = 0; i < n4; i++) {
                     const float4 q = r4[i];
                     const float vv[4] = {q.x, q.y, q.z, q.w};
