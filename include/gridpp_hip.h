@@ -269,7 +269,7 @@ int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* background, i
                                    float* out, int mem);
 int gpp_ensi_last_kernel_ms(float* ms);
 /* 1: the Jacobi sweeps of the per-cell eigenproblem run to convergence (reference-grade last bits, ~2x the time);
- * 0 (default): they stop at |off-diagonal| <= 0.012 (E - 1) and a perturbation series supplies the rest.
+ * 0 (default): they stop at |off-diagonal| <= 0.010 (E - 1) and a perturbation series supplies the rest.
  * Per calling thread. */
 int gpp_ensi_set_convergence(int to_convergence);
 
