@@ -349,18 +349,19 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
 #pragma unroll
                 for(int j = 0; j < N; ++j) {
                     if(j < n) {
-                        double av = (lane < n && mystep == 64) ? fabs(rowT[j]) : -1.0;
-                        int al = lane;
-                        for(int off = 32; off > 0; off >>= 1) {
-                            const double oav = __shfl_xor(av, off);
-                            const int oal = __shfl_xor(al, off);
-                            if(oav > av || (oav == av && oal < al)) { av = oav; al = oal; }
-                        }
-                        const int piv = __builtin_amdgcn_readfirstlane(al);
-                        if(!(av > 0.0)) bad = true;                        // exactly singular (arma::inv throws)
+                        // the largest |entry| of column j among the rows not yet used (lowest lane on a tie): a DPP maximum and a ballot
+                        // (as a butterfly of ds_bpermute pairs the search was 18 trips through the LDS crossbar per column)
+                        const double av = (lane < n && mystep == 64) ? fabs(rowT[j]) : -1.0;
+                        const double amax = wave_max_d(av);
+                        const int piv = (int)__builtin_ctzll(__ballot(av == amax) | (1ull << 63));
+                        if(!(amax > 0.0)) bad = true;                      // exactly singular (arma::inv throws)
                         const double pjj = readlane_d(rowT[j], piv);
                         const bool elim = lane < n && mystep == 64 && lane != piv;
-                        const double rpj = 1.0 / pjj;                      // one reciprocal per column (LAPACK's dgetf2 scales by it too)
+                        // one reciprocal per column (LAPACK's dgetf2 scales by it too): v_rcp_f64 and two Newton steps instead of the ~30
+                        // instructions of an IEEE division (as the Cholesky path does with v_rsq_f64)
+                        double rpj = __builtin_amdgcn_rcp(pjj);
+                        rpj = __builtin_fma(rpj, __builtin_fma(-pjj, rpj, 1.0), rpj);
+                        rpj = __builtin_fma(rpj, __builtin_fma(-pjj, rpj, 1.0), rpj);
                         const double f = elim ? rowT[j] * rpj : 0.0;
                         if(lane == piv) { mystep = j; mypinv = rpj; }
 #pragma unroll

@@ -227,6 +227,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
+// maximum of a double over the 64 lanes (DPP moves of its two halves; every lane must hold a value >= -1.0, the identity)
+__device__ __forceinline__ double wave_max_d(double v) {
+#define GPP_DPP_MAXD(ctrl, rmask)                                                                                        \
+    {                                                                                                                   \
+        const double id_ = -1.0;                                                                                        \
+        const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(id_), __double2loint(v), ctrl, rmask, 0xf, false);    \
+        const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(id_), __double2hiint(v), ctrl, rmask, 0xf, false);    \
+        v = fmax(v, __hiloint2double(hi_, lo_));                                                                        \
+    }
+    GPP_DPP_MAXD(0x111, 0xf) GPP_DPP_MAXD(0x112, 0xf) GPP_DPP_MAXD(0x114, 0xf) GPP_DPP_MAXD(0x118, 0xf)
+    GPP_DPP_MAXD(0x142, 0xa) GPP_DPP_MAXD(0x143, 0xc)
+#undef GPP_DPP_MAXD
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 // inclusive prefix sum over the 64 lanes (same DPP path)
 __device__ __forceinline__ int wave_scan_add(int x) {
 #define GPP_DPP_ADD(ctrl, rmask) x += __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false);
