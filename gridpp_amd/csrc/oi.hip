@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                             const double zj = readlane_d(bvec, piv) * readlane_d(mypinv, piv);
                             if(lane < n && mystep < j) bvec = __builtin_fma(-rowT[j], zj, bvec);
                             incv = __builtin_fma(zj, (double)colbuf[j][lane], incv);   // corr_background(cell, obs j) * z_j   (oi.cpp:296,316)
+                            if(extra != 0ull && lane == 0) s_col[wid][j] = zj;
                         }
                     }
                     if(is_g) {
@@ -401,6 +402,33 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                         }
                         s_res[wid][0][src] = cbg + increment;
                         s_res[wid][1][src] = cbv;
+                    }
+                    if(extra != 0ull) {
+                        // the cells of the group beyond the G rows that fit beside the matrix: z is theirs as well -- every such cell, in its
+                        // own lane, adds corr_background(itself, obs j) z_j over the n observations (one pass for all of them instead of
+                        // another factorisation per 31 cells)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        double incx = 0.0;
+                        for(int j = 0; j < n; ++j) {
+                            const float xj = readlane_f(o0.x, j), yj = readlane_f(o0.y, j), zj_ = readlane_f(o0.z, j);
+                            const float ej = readlane_f(o0.w, j), lj = readlane_f(o1.x, j);
+                            const float cg = d_corr_t<PLAIN>(cst, gx, gy, gz, ge, gl, xj, yj, zj_, ej, lj, true);
+                            incx = __builtin_fma(s_col[wid][j], (double)cg, incx);
+                        }
+                        if((extra >> lane) & 1ull) {
+                            float increment = (float)incx;
+                            if(!a.allow_extrap) {
+                                if(maxInc > 0 && increment > maxInc) increment = maxInc;
+                                else if(maxInc < 0 && increment > 0) increment = maxInc;
+                                else if(minInc < 0 && increment < minInc) increment = minInc;
+                                else if(minInc > 0 && increment < 0) increment = minInc;
+                            }
+                            s_res[wid][0][lane] = bg + increment;
+                            s_res[wid][1][lane] = bvar;
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
                 unsigned long long mm = zsolve ? 0ull : members;
@@ -649,7 +677,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
             if(nm > MEMB) {
                 const int cut = nth_set_bit(members, MEMB);
                 const unsigned long long first = members & ((1ull << cut) - 1ull);
-                if(!LU && N == 62) extra = members & ~first;
+                if((!LU && N == 62) || (LU && a.out_var == nullptr)) extra = members & ~first;   // (LU without a variance output: one solve serves them all)
                 members = first;
                 nm = MEMB;
             }
