@@ -619,7 +619,10 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
 #pragma unroll
             for(int j = 0; j < 30; ++j) {
                 if(j < nmax) {
-                    const double ajj = __shfl(row[j], base + j);
+                    // (the diagonal of each half from its lane j by v_readlane -- j is a constant here --: through the LDS crossbar the
+                    //  column started with a round trip of its own)
+                    const double ajj0 = readlane_d(row[j], j), ajj1 = readlane_d(row[j], 32 + j);
+                    const double ajj = base ? ajj1 : ajj0;
                     const bool colok = j < nh;
                     if(colok && !(ajj > 0.0)) bad = true;
                     double rs = __builtin_amdgcn_rsq(colok ? ajj : 1.0);
