@@ -210,12 +210,125 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
     return x;
 }
+// Two single-member groups at once, one per half-wave (lanes 0-31 / 32-63): rows 0..n-1 of (P+R), row 30 = obs -
+// background, row 31 = G of the cell; broadcasts stay inside a half (ds_bpermute instead of v_readlane).  This is
+// the common case when every cell has its own observation set (e.g. elevation-dependent structure functions).
+// Shared by k_oi (selections in its LDS key area) and k_oi_pairs (selections parked in HBM by k_oi); la / lb: the lanes of the
+// two cells (lb < 0: none, the upper half idles), na / nb their observation counts (<= 30), sel(i, lane of the cell): the i-th
+// selected observation (original index); colbuf: 31 rows of column staging, colL: 64 doubles, res: the wave's result rows.
+template <bool PLAIN, class Sel>
+__device__ __forceinline__ void oi_solve_pair(const OiArgs& a, const int lane, const int la, const int lb, const int na, const int nb, const Sel sel,
+                                              float (*colbuf)[64], double* const colL, float (*res)[64], const float cx, const float cy,
+                                              const float cz, const float ce, const float cl, const float cbg, const float cbv, bool& bad) {   // c*: the half's cell
+    const int base = lane & 32, hl = lane & 31;
+    const bool live = !(base && lb < 0);                 // (an odd cell out: the second half idles)
+    const int lh = (base && lb >= 0) ? lb : la;          // this half's cell
+    const int nh = base ? nb : na, nmax = max(na, nb);
+    const unsigned orig_i = (hl < nh) ? sel(hl, lh) : 0u;
+    float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
+    if(hl < nh) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
+    const bool is_g = hl == 31;
+    float maxInc = -INFINITY, minInc = INFINITY;
+    if(!a.allow_extrap) {   // extremes of obs - background over the half's selection (oi.cpp:318-334)
+        const float dpf = (float)((double)o1.y - (double)o1.z);
+        maxInc = hl < nh ? dpf : -INFINITY; minInc = hl < nh ? dpf : INFINITY;
+        for(int off = 16; off > 0; off >>= 1) { maxInc = fmaxf(maxInc, __shfl_xor(maxInc, off)); minInc = fminf(minInc, __shfl_xor(minInc, off)); }
+    }
+    // lower triangle of P (oi.cpp:304-312) and the G row (oi.cpp:250) of each half, one entry per lane and pass: entry
+    // e = i (i + 1) / 2 + p (p <= i) for e < ntri, then G entry p = e - ntri; the records of both points come by ds_bpermute
+    const int ntri = nh * (nh + 1) / 2, nent = ntri + nh, nentmax = nmax * (nmax + 1) / 2 + nmax;
+    for(int e0 = 0; e0 < nentmax; e0 += 32) {
+        const int e = e0 + hl;
+        const bool gent = e >= ntri;
+        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        if(i * (i + 1) / 2 > e) i--;
+        if((i + 1) * (i + 2) / 2 <= e) i++;
+        int pc = e - i * (i + 1) / 2;
+        if(gent) { pc = min(e - ntri, 29); i = 31; }
+        const int si = base + min(i, 29), sp = base + pc;
+        float xi = __shfl(o0.x, si), yi = __shfl(o0.y, si), zi = __shfl(o0.z, si), ei = __shfl(o0.w, si), li = __shfl(o1.x, si);
+        const float xp = __shfl(o0.x, sp), yp = __shfl(o0.y, sp), zp = __shfl(o0.z, sp), ep = __shfl(o0.w, sp), lp = __shfl(o1.x, sp);
+        xi = gent ? cx : xi; yi = gent ? cy : yi; zi = gent ? cz : zi; ei = gent ? ce : ei; li = gent ? cl : li;
+        const float c = d_corr_t<PLAIN>(a.s.st, xi, yi, zi, ei, li, xp, yp, zp, ep, lp, gent);
+        if(e < nent) colbuf[pc][base + i] = c;
+    }
+    // obs and background at the observations for the obs - background row (lane 30 of the half): obs rides in column
+    // position 30 of every matrix column, the background in row 30 of the staging area
+    if(hl < nh) { colbuf[hl][base + 30] = o1.y; colbuf[30][base + hl] = o1.z; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double row[30];
+    const bool used = hl < nh || hl >= 30;
+#pragma unroll
+    for(int p = 0; p < 30; ++p) {
+        double v = 0.0;
+        if(p < nmax) {
+            v = (double)colbuf[p][lane];
+            if(hl == p) v += (double)o1.w;                                       // lP + lR
+            if(hl == 30) v = v - (double)colbuf[30][base + p];                   // lObs - lY
+            if(!used || p >= nh || (hl < p)) v = 0.0;                            // (only the lower triangle is read)
+        }
+        row[p] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // right-looking Cholesky; column j goes to LDS once (s_col) and comes back as broadcast reads inside the half
+    #pragma unroll
+    for(int j = 0; j < 30; ++j) {
+        if(j < nmax) {
+            // (the diagonal of each half from its lane j by v_readlane -- j is a constant here --: through the LDS crossbar the
+            //  column started with a round trip of its own)
+            const double ajj0 = readlane_d(row[j], j), ajj1 = readlane_d(row[j], 32 + j);
+            const double ajj = base ? ajj1 : ajj0;
+            const bool colok = j < nh;
+            if(colok && !(ajj > 0.0)) bad = true;
+            double rs = __builtin_amdgcn_rsq(colok ? ajj : 1.0);
+            const double aj = colok ? ajj : 1.0;
+            rs = rs * (1.5 - 0.5 * aj * rs * rs);
+            rs = rs * (1.5 - 0.5 * aj * rs * rs);
+            const double cj = colok ? row[j] * rs : 0.0;
+            row[j] = cj;
+            colL[lane] = cj;
+#pragma unroll
+            for(int p = j + 1; p < 30; ++p) row[p] = __builtin_fma(-cj, colL[base + p], row[p]);
+        }
+    }
+    double inc = 0.0, a00 = 0.0;
+#pragma unroll
+    for(int p = 0; p < 30; ++p) {
+        if(hl == 30) colL[base + p] = row[p];           // L^-1 (obs - background)
+    }
+    // (one lane writes, the others read: without the fences the compiler orders the two sides per thread -- readers first)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for(int p = 0; p < 30; ++p) {
+        const double tp = colL[base + p];
+        inc = __builtin_fma(row[p], tp, inc);
+        a00 = __builtin_fma(row[p], row[p], a00);
+    }
+    if(is_g) {
+        float increment = (float)inc;
+        if(!a.allow_extrap) {
+            if(maxInc > 0 && increment > maxInc) increment = maxInc;
+            else if(maxInc < 0 && increment > 0) increment = maxInc;
+            else if(minInc < 0 && increment < minInc) increment = minInc;
+            else if(minInc > 0 && increment < 0) increment = minInc;
+        }
+        if(live) res[0][lh] = cbg + increment;
+        if(live) res[1][lh] = (float)((double)cbv * (1.0 - a00));
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int N, bool LU, bool PLAIN, bool SPATIAL>
 // (the 62-row tile holds its rows in 124 + 124 registers: one wave per SIMD is what it gets, and what it asks for)
 __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
     __shared__ double s_col[4][64];   // column staging of the half-wave solves
+    if constexpr(PLAIN) d_exptab_init();   // 2^(j/128) for d_exp_core
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // all tiles (one per wave), or -- behind k_oi_union -- a fixed-size grid striding over the list of what that kernel
     // declined (the list length is read on the device: no host round trip between the kernels).  A list entry >= 0 is
@@ -252,6 +365,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
     }
     const bool active = cell >= 0 && d_valid(bg);   // oi.cpp:223
     float res_out = bg, res_var = bvar;              // oi.cpp:198-199
+    bool parked = false;                             // this cell's selection went to k_oi_pairs
     unsigned long long (*keys)[64] = s_keys[wid];
 
     int cnt = 0;
@@ -555,114 +669,13 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                     }
         };
 
-        // Two single-member groups at once, one per half-wave (lanes 0-31 / 32-63): rows 0..n-1 of (P+R), row 30 = obs -
-        // background, row 31 = G of the cell; broadcasts stay inside a half (ds_bpermute instead of v_readlane).  This is
-        // the common case when every cell has its own observation set (e.g. elevation-dependent structure functions).
+        // two single-member groups at once, one per half-wave: oi_solve_pair
         auto solve_pair = [&](const int la, const int lb) {
             nsolve += 2;
-            const int base = lane & 32, hl = lane & 31;
-            const int lh = base ? lb : la;                       // this half's cell
-            const int na = __builtin_amdgcn_readlane(cnt, la), nb = __builtin_amdgcn_readlane(cnt, lb);
-            const int nh = base ? nb : na, nmax = max(na, nb);
-            const unsigned orig_i = (hl < nh) ? origs[hl][lh] : 0u;
-            float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
-            if(hl < nh) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
-            const bool is_g = hl == 31;
-            const float cx = __shfl(gx, lh), cy = __shfl(gy, lh), cz = __shfl(gz, lh), ce = __shfl(ge, lh), cl = __shfl(gl, lh);
-            const float cbg = __shfl(bg, lh), cbv = __shfl(bvar, lh);
-            float maxInc = -INFINITY, minInc = INFINITY;
-            if(!a.allow_extrap) {   // extremes of obs - background over the half's selection (oi.cpp:318-334)
-                const float dpf = (float)((double)o1.y - (double)o1.z);
-                maxInc = hl < nh ? dpf : -INFINITY; minInc = hl < nh ? dpf : INFINITY;
-                for(int off = 16; off > 0; off >>= 1) { maxInc = fmaxf(maxInc, __shfl_xor(maxInc, off)); minInc = fminf(minInc, __shfl_xor(minInc, off)); }
-            }
-            // lower triangle of P (oi.cpp:304-312) and the G row (oi.cpp:250) of each half, one entry per lane and pass: entry
-            // e = i (i + 1) / 2 + p (p <= i) for e < ntri, then G entry p = e - ntri; the records of both points come by ds_bpermute
-            const int ntri = nh * (nh + 1) / 2, nent = ntri + nh, nentmax = nmax * (nmax + 1) / 2 + nmax;
-            for(int e0 = 0; e0 < nentmax; e0 += 32) {
-                const int e = e0 + hl;
-                const bool gent = e >= ntri;
-                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                if(i * (i + 1) / 2 > e) i--;
-                if((i + 1) * (i + 2) / 2 <= e) i++;
-                int pc = e - i * (i + 1) / 2;
-                if(gent) { pc = min(e - ntri, 29); i = 31; }
-                const int si = base + min(i, 29), sp = base + pc;
-                float xi = __shfl(o0.x, si), yi = __shfl(o0.y, si), zi = __shfl(o0.z, si), ei = __shfl(o0.w, si), li = __shfl(o1.x, si);
-                const float xp = __shfl(o0.x, sp), yp = __shfl(o0.y, sp), zp = __shfl(o0.z, sp), ep = __shfl(o0.w, sp), lp = __shfl(o1.x, sp);
-                xi = gent ? cx : xi; yi = gent ? cy : yi; zi = gent ? cz : zi; ei = gent ? ce : ei; li = gent ? cl : li;
-                const float c = d_corr_t<PLAIN>(a.s.st, xi, yi, zi, ei, li, xp, yp, zp, ep, lp, gent);
-                if(e < nent) colbuf[pc][base + i] = c;
-            }
-            // obs and background at the observations for the obs - background row (lane 30 of the half): obs rides in column
-            // position 30 of every matrix column, the background in row 30 of the staging area
-            if(hl < nh) { colbuf[hl][base + 30] = o1.y; colbuf[30][base + hl] = o1.z; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double row[30];
-            const bool used = hl < nh || hl >= 30;
-#pragma unroll
-            for(int p = 0; p < 30; ++p) {
-                double v = 0.0;
-                if(p < nmax) {
-                    v = (double)colbuf[p][lane];
-                    if(hl == p) v += (double)o1.w;                                       // lP + lR
-                    if(hl == 30) v = v - (double)colbuf[30][base + p];                   // lObs - lY
-                    if(!used || p >= nh || (hl < p)) v = 0.0;                            // (only the lower triangle is read)
-                }
-                row[p] = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            // right-looking Cholesky; column j goes to LDS once (s_col) and comes back as broadcast reads inside the half
-            double* const colL = s_col[wid];
-#pragma unroll
-            for(int j = 0; j < 30; ++j) {
-                if(j < nmax) {
-                    // (the diagonal of each half from its lane j by v_readlane -- j is a constant here --: through the LDS crossbar the
-                    //  column started with a round trip of its own)
-                    const double ajj0 = readlane_d(row[j], j), ajj1 = readlane_d(row[j], 32 + j);
-                    const double ajj = base ? ajj1 : ajj0;
-                    const bool colok = j < nh;
-                    if(colok && !(ajj > 0.0)) bad = true;
-                    double rs = __builtin_amdgcn_rsq(colok ? ajj : 1.0);
-                    const double aj = colok ? ajj : 1.0;
-                    rs = rs * (1.5 - 0.5 * aj * rs * rs);
-                    rs = rs * (1.5 - 0.5 * aj * rs * rs);
-                    const double cj = colok ? row[j] * rs : 0.0;
-                    row[j] = cj;
-                    colL[lane] = cj;
-#pragma unroll
-                    for(int p = j + 1; p < 30; ++p) row[p] = __builtin_fma(-cj, colL[base + p], row[p]);
-                }
-            }
-            double inc = 0.0, a00 = 0.0;
-#pragma unroll
-            for(int p = 0; p < 30; ++p) {
-                if(hl == 30) colL[base + p] = row[p];           // L^-1 (obs - background)
-            }
-            // (one lane writes, the others read: without the fences the compiler orders the two sides per thread -- readers first)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for(int p = 0; p < 30; ++p) {
-                const double tp = colL[base + p];
-                inc = __builtin_fma(row[p], tp, inc);
-                a00 = __builtin_fma(row[p], row[p], a00);
-            }
-            if(is_g) {
-                float increment = (float)inc;
-                if(!a.allow_extrap) {
-                    if(maxInc > 0 && increment > maxInc) increment = maxInc;
-                    else if(maxInc < 0 && increment > 0) increment = maxInc;
-                    else if(minInc < 0 && increment < minInc) increment = minInc;
-                    else if(minInc > 0 && increment < 0) increment = minInc;
-                }
-                s_res[wid][0][lh] = cbg + increment;
-                s_res[wid][1][lh] = (float)((double)cbv * (1.0 - a00));
-            }
-            __builtin_amdgcn_wave_barrier();
+            const int lh = (lane & 32) ? lb : la;
+            oi_solve_pair<PLAIN>(a, lane, la, lb, __builtin_amdgcn_readlane(cnt, la), __builtin_amdgcn_readlane(cnt, lb),
+                                 [&](const int i, const int l) { return origs[i][l]; }, colbuf, s_col[wid], s_res[wid], __shfl(gx, lh), __shfl(gy, lh),
+                                 __shfl(gz, lh), __shfl(ge, lh), __shfl(gl, lh), __shfl(bg, lh), __shfl(bvar, lh), bad);
         };
 
         constexpr bool PAIRS = !LU && !SPATIAL && N == 32;
@@ -689,6 +702,14 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
             else solve_group(l, n, members, nm, extra);
         }
         if constexpr(PAIRS) {
+            if(a.pair_sel) {   // the selections of the single-member groups go to HBM: k_oi_pairs solves them at twice the occupancy
+                parked = (singles >> lane) & 1ull;
+                if(parked) {
+                    unsigned* const dst = a.pair_sel + (size_t)cell * 32;
+                    for(int s = 0; s < cnt; ++s) dst[s] = origs[s][lane];
+                }
+                singles = 0ull;
+            }
             while(singles) {
                 const int la = __builtin_ctzll(singles);
                 singles &= singles - 1;
@@ -712,11 +733,64 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
         }
     }
     if(cell >= 0) {
-        a.out[cell] = res_out;
-        if(a.out_var) a.out_var[cell] = res_var;
+        if(!parked) {
+            a.out[cell] = res_out;
+            if(a.out_var) a.out_var[cell] = res_var;
+        }
+        if(a.pair_n) a.pair_n[cell] = parked ? cnt : 0;
     }
     __builtin_amdgcn_wave_barrier();
     }
+}
+
+// The single-member groups k_oi parked (a.pair_n[cell] = observation count, a.pair_sel[cell][0..n-1] = the selection): one tile per
+// wave as in k_oi, two cells per factorisation pass (oi_solve_pair).  Without the 16 KB of candidate keys per wave that the scan
+// needs, four waves per SIMD instead of two -- the solves are chains of dependent LDS round trips and double-precision operations.
+template <bool PLAIN>
+__global__ __launch_bounds__(256, PLAIN ? 4 : 3) void k_oi_pairs(OiArgs a) {   // (the generic structure functions need more registers)
+    __shared__ float s_cb[4][31][64];
+    __shared__ double s_col[4][64];
+    __shared__ float s_res[4][2][64];
+    if constexpr(PLAIN) d_exptab_init();
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wid;
+    if(tile >= a.ntiles) return;
+    int cell = -1;
+    if(a.tiled2d) {
+        int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        int y = ty * (64 >> a.wshift) + (lane >> a.wshift), x = (tx << a.wshift) + (lane & ((1 << a.wshift) - 1));
+        if(y < a.ny && x < a.nx) cell = y * a.nx + x;
+    }
+    else {
+        int c = tile * 64 + lane;
+        if(c < a.C) cell = c;
+    }
+    const int n = cell >= 0 ? a.pair_n[cell] : 0;
+    unsigned long long singles = __ballot(n > 0);
+    if(singles == 0ull) return;
+    bool bad = false;
+    const int nsolve = __popcll(singles);
+    while(singles) {
+        const int la = __builtin_ctzll(singles);
+        singles &= singles - 1;
+        int lb = -1;
+        if(singles) { lb = __builtin_ctzll(singles); singles &= singles - 1; }
+        const int ca = __builtin_amdgcn_readlane(cell, la), cb = __builtin_amdgcn_readlane(cell, lb < 0 ? la : lb);
+        const int ch = (lane & 32) ? cb : ca;      // the half's cell: its record comes straight from HBM (two addresses per load)
+        const unsigned* const mine = a.pair_sel + (size_t)ch * 32;
+        oi_solve_pair<PLAIN>(a, lane, la, lb, __builtin_amdgcn_readlane(n, la), lb < 0 ? 0 : __builtin_amdgcn_readlane(n, lb),
+                             [&](const int i, const int) { return mine[i]; }, s_cb[wid], s_col[wid], s_res[wid], a.gx[ch], a.gy[ch], a.gz[ch],
+                             a.gelev[ch], a.glaf[ch], a.bg[ch], a.bvar ? a.bvar[ch] : 1.0f, bad);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (results were written by single lanes: see oi_solve_pair)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if(n > 0) {
+        a.out[cell] = s_res[wid][0][lane];
+        if(a.out_var) a.out_var[cell] = s_res[wid][1][lane];
+    }
+    if(__ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
+    if(lane == 0 && a.counters) atomicAdd(&a.counters[80 + 2 * (blockIdx.x % GPP_NSLOT) + 1], (unsigned long long)nsolve);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1078,10 +1152,16 @@ struct OiWorkspace {
     DevBuf<unsigned long long> big_keys, huge_keys;
     DevBuf<double> big_mat, huge_mat;
     DevBuf<int> huge_list;
+    DevBuf<unsigned> pair_sel;   // k_oi -> k_oi_pairs: 128 B per cell
+    DevBuf<int> pair_n;
     hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr;
 };
 thread_local OiWorkspace g_ws;
 thread_local gpp_oi_stats g_stats;
+}
+
+void gpp_release_oi_workspace() {   // the parked selections (128 B per grid cell of the largest call so far)
+    g_ws.pair_sel.release(); g_ws.pair_n.release();
 }
 
 extern "C" int gpp_oi_last_stats(gpp_oi_stats* s) {
@@ -1548,7 +1628,20 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             ran_union = true;
         }
         else {
+            // Cholesky path with the 32-row tile: the cells whose observation set no other cell of their tile shares (all of them on
+            // rough terrain with elevation-dependent rho) are parked by k_oi and solved by k_oi_pairs at twice the occupancy
+            // (128 B of selection per cell; beyond PAIR_PARK_MAX bytes of it k_oi solves them itself as before)
+            constexpr size_t PAIR_PARK_MAX = (size_t)8 << 30;
+            const bool pairs = N == 32 && !use_lu && !spatial && (size_t)C * 128 <= PAIR_PARK_MAX && !path_env("GPP_OI_NO_PAIRS");
+            if(pairs) { a.pair_sel = ws.pair_sel.get((size_t)C * 32); a.pair_n = ws.pair_n.get((size_t)C); }
             launch_k_oi(use_lu);
+            if(pairs) {
+                const dim3 grid((a.ntiles + 3) / 4), block(256);
+                if(plain) hipLaunchKernelGGL(k_oi_pairs<true>, grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL(k_oi_pairs<false>, grid, block, 0, stream(), a);
+                GPP_HIP(hipGetLastError());
+                a.pair_sel = nullptr; a.pair_n = nullptr;
+            }
             GPP_HIP(hipEventRecord(ws.e1, stream()));
             fetch();
         }

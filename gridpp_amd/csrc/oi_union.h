@@ -56,6 +56,9 @@ struct OiArgs {
     unsigned long long* huge_keys;  // per workgroup: huge_kcap candidate keys
     double* huge_mat;        // per workgroup: huge_ncap x (huge_ncap + 2) augmented matrix
     int huge_kcap, huge_ncap;
+    // k_oi -> k_oi_pairs: the selections of cells that share their observation set with no other cell of their tile
+    unsigned* pair_sel;      // [cell][32]: observation indices (original order)
+    int* pair_n;             // [cell]: their number; 0 = the cell was finished by k_oi
 };
 
 #define GPP_NSLOT 512
@@ -140,6 +143,7 @@ template <bool PLAIN, bool LIST, int NC>
 __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
     constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE, WPB = UnionCfg<NC>::WPB;
     __shared__ UnionLds<NC> s_u[WPB];
+    if constexpr(PLAIN) d_exptab_init();   // 2^(j/128) for d_exp_core
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int tile = blockIdx.x * WPB + wid, sub = -1;   // sub: (lane >> shift) of the lanes of this item, -1 = all
     int shift = 0;

@@ -50,6 +50,7 @@ extern "C" const char* gpp_version(void) { return "0.8.0.dev1+mi355x.r1"; }
 
 extern char** environ;
 void gpp_release_ensi_workspace();   // ensi.hip
+void gpp_release_oi_workspace();     // oi.hip
 
 // every GPP_* variable of the environment, comma separated (path_env() in common.h: they select implementations, never results)
 extern "C" int gpp_active_overrides(char* buf, int len) {
@@ -73,6 +74,7 @@ extern "C" int gpp_release_workspaces(void) {
     GPP_TRY
     GPP_HIP(hipStreamSynchronize(stream()));
     gpp_release_ensi_workspace();
+    gpp_release_oi_workspace();
     return GPP_OK;
     GPP_CATCH
 }

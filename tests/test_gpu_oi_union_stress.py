@@ -59,6 +59,45 @@ def test_random_configurations_rough_terrain(seed):
     _check(out, ref)
 
 
+@pytest.mark.parametrize("seed", range(400, 410))
+def test_parked_selections_rough_terrain(seed, monkeypatch):
+    """The second call with a geometry whose tiles all declined goes to k_oi alone, which parks the selections of the cells that
+    share their observation set with nobody (all of them here) for k_oi_pairs: analysis and analysis variance against the oracle,
+    and the same bits as k_oi solving them itself (GPP_OI_NO_PAIRS)."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(9000 + seed)
+    Y, X = int(rng.integers(8, 50)), int(rng.integers(8, 50))
+    S = int(rng.choice([40, 150, 600, 2000]))
+    h, v, w = float(rng.choice([5000.0, 10000.0, 30000.0])), float(rng.choice([100.0, 300.0])), float(rng.choice([0.0, 0.5]))
+    mp = int(rng.choice([3, 10, 29, 30, 32]))
+    ext = 0.3 * float(rng.choice([0.3, 1.0]))
+    lats, lons = np.meshgrid(np.linspace(60, 60 + ext, Y), np.linspace(10, 10 + 2 * ext, X), indexing="ij")
+    ge, gl = rng.uniform(0, 1000, (Y, X)).astype(np.float32), rng.uniform(0, 1, (Y, X)).astype(np.float32)
+    plat, plon = 60 + ext * rng.random(S), 10 + 2 * ext * rng.random(S)
+    pe, pl = rng.uniform(0, 1000, S).astype(np.float32), rng.uniform(0, 1, S).astype(np.float32)
+    bg = rng.normal(0, 2, (Y, X)).astype(np.float32)
+    bg[rng.random((Y, X)) < 0.02] = np.nan                 # cells without a background: untouched, and never parked
+    bvar = rng.uniform(0.5, 2, (Y, X)).astype(np.float32)
+    obs, pbg = rng.normal(0, 2, S).astype(np.float32), rng.normal(0, 2, S).astype(np.float32)
+    ovar, pbvar = rng.uniform(0.05, 2, S).astype(np.float32), rng.uniform(0.5, 2, S).astype(np.float32)
+    allow = bool(seed % 2)
+    grid, points, st = gridpp.Grid(lats, lons, ge, gl), gridpp.Points(plat, plon, pe, pl), gridpp.BarnesStructure(h, v, w)
+    call = lambda: gridpp.optimal_interpolation_full(grid, bg, bvar, points, obs, ovar, pbg, pbvar, st, mp, allow)
+    call()                                                  # (first call: the first pass of k_oi_union declines, lists follow)
+    out, var = call()
+    stats = gridpp.oi_last_stats()
+    assert stats["union_kernel_ms"] == 0 and stats["solves"] > 0
+    ref, rvar = O.oi_full(O.Pts(lats.ravel(), lons.ravel(), ge.ravel(), gl.ravel()), bg.ravel(), bvar.ravel(), O.Pts(plat, plon, pe, pl), obs,
+                          ovar, pbg, pbvar, O.Barnes(h, v, w), mp, allow)
+    _check(out, ref.reshape(Y, X))
+    _check(var, rvar.reshape(Y, X))
+    monkeypatch.setenv("GPP_OI_NO_PAIRS", "1")
+    out2, var2 = call()
+    assert gridpp.oi_last_stats()["solves"] == stats["solves"]
+    assert np.array_equal(out, out2, equal_nan=True) and np.array_equal(var, var2, equal_nan=True)
+
+
 @pytest.mark.parametrize("seed", range(300, 312))
 def test_random_configurations_pivoted_lu(seed, monkeypatch):
     """The pivoted-LU form of k_oi (non-symmetric / spatially varying structures; forced here on symmetric systems, whose oracle
