@@ -1501,6 +1501,23 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         }
         GPP_HIP(hipGetLastError());
     };
+    // Cholesky path with the 32-row tile: the cells whose observation set no other cell of their work item shares (all of them on
+    // rough terrain with elevation-dependent rho) are parked by k_oi and solved by k_oi_pairs at twice the occupancy (128 B of
+    // selection per cell; beyond PAIR_PARK_MAX bytes of it k_oi solves them itself as before).  k_oi over a work list leaves
+    // the counts of the cells it does not visit alone: they are cleared first.
+    constexpr size_t PAIR_PARK_MAX = (size_t)8 << 30;
+    const bool pairs_ok = N == 32 && !spatial && (size_t)C * 128 <= PAIR_PARK_MAX && !path_env("GPP_OI_NO_PAIRS");
+    auto park_on = [&](const bool clear) {
+        a.pair_sel = ws.pair_sel.get((size_t)C * 32); a.pair_n = ws.pair_n.get((size_t)C);
+        if(clear) GPP_HIP(hipMemsetAsync(a.pair_n, 0, (size_t)C * sizeof(int), stream()));
+    };
+    auto launch_pairs = [&]() {
+        const dim3 grid((a.ntiles + 3) / 4), block(256);
+        if(plain) hipLaunchKernelGGL(k_oi_pairs<true>, grid, block, 0, stream(), a);
+        else hipLaunchKernelGGL(k_oi_pairs<false>, grid, block, 0, stream(), a);
+        GPP_HIP(hipGetLastError());
+        a.pair_sel = nullptr; a.pair_n = nullptr;
+    };
     const int* const h_ints = reinterpret_cast<const int*>(ws.h_status);
     auto fetch = [&]() {   // the whole status block in one copy
         GPP_HIP(hipMemcpyAsync(ws.h_status, ws.status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
@@ -1594,7 +1611,10 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 launch_union(16 * (long)n1, true);
                 // pass 4: what is still left, one factorisation per distinct selection (grid-stride over the list)
                 a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                const bool pairs = pairs_ok && !skip_k_oi && 4 * (long)n1 > a.ntiles;   // (a short list: not worth the pass over every cell's count)
+                if(pairs) park_on(true);
                 if(!skip_k_oi) launch_k_oi(false);
+                if(pairs) launch_pairs();
             };
             const bool expect_long = memo_hit && 16.0 * (double)memo.declined * (double)a.ntiles > (double)SHORT_ITEMS;
             if(!expect_long) {
@@ -1628,20 +1648,10 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             ran_union = true;
         }
         else {
-            // Cholesky path with the 32-row tile: the cells whose observation set no other cell of their tile shares (all of them on
-            // rough terrain with elevation-dependent rho) are parked by k_oi and solved by k_oi_pairs at twice the occupancy
-            // (128 B of selection per cell; beyond PAIR_PARK_MAX bytes of it k_oi solves them itself as before)
-            constexpr size_t PAIR_PARK_MAX = (size_t)8 << 30;
-            const bool pairs = N == 32 && !use_lu && !spatial && (size_t)C * 128 <= PAIR_PARK_MAX && !path_env("GPP_OI_NO_PAIRS");
-            if(pairs) { a.pair_sel = ws.pair_sel.get((size_t)C * 32); a.pair_n = ws.pair_n.get((size_t)C); }
+            const bool pairs = pairs_ok && !use_lu;
+            if(pairs) park_on(false);    // (k_oi visits every cell)
             launch_k_oi(use_lu);
-            if(pairs) {
-                const dim3 grid((a.ntiles + 3) / 4), block(256);
-                if(plain) hipLaunchKernelGGL(k_oi_pairs<true>, grid, block, 0, stream(), a);
-                else hipLaunchKernelGGL(k_oi_pairs<false>, grid, block, 0, stream(), a);
-                GPP_HIP(hipGetLastError());
-                a.pair_sel = nullptr; a.pair_n = nullptr;
-            }
+            if(pairs) launch_pairs();
             GPP_HIP(hipEventRecord(ws.e1, stream()));
             fetch();
         }

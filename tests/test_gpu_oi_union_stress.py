@@ -98,6 +98,37 @@ def test_parked_selections_rough_terrain(seed, monkeypatch):
     assert np.array_equal(out, out2, equal_nan=True) and np.array_equal(var, var2, equal_nan=True)
 
 
+def test_parked_selections_behind_a_long_work_list():
+    """First call on rough terrain with enough tiles for the two-level list passes: what they leave to k_oi (everything) is parked
+    for k_oi_pairs as well, the counts of the cells k_oi does not visit cleared first."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    Y, X, S = 150, 170, 900
+    lats, lons = np.meshgrid(np.linspace(60, 60.6, Y), np.linspace(10, 11.2, X), indexing="ij")
+    ge, gl = rng.uniform(0, 1000, (Y, X)).astype(np.float32), rng.uniform(0, 1, (Y, X)).astype(np.float32)
+    ge[:40, :40] = 100.0; gl[:40, :40] = 0.5                # a smooth corner: its tiles are solved by k_oi_union, never visited by k_oi
+    plat, plon = 60 + 0.6 * rng.random(S), 10 + 1.2 * rng.random(S)
+    pe, pl = rng.uniform(0, 1000, S).astype(np.float32), rng.uniform(0, 1, S).astype(np.float32)
+    bg = rng.normal(0, 2, (Y, X)).astype(np.float32)
+    obs, pbg = rng.normal(0, 2, S).astype(np.float32), rng.normal(0, 2, S).astype(np.float32)
+    ratios = rng.uniform(0.05, 2, S).astype(np.float32)
+    ref = O.oi(O.Pts(lats.ravel(), lons.ravel(), ge.ravel(), gl.ravel()), bg.ravel(), O.Pts(plat, plon, pe, pl), obs, ratios, pbg,
+               O.Barnes(8000.0, 200.0, 0.5), 30).reshape(Y, X)
+    points, st = gridpp.Points(plat, plon, pe, pl), gridpp.BarnesStructure(8000.0, 200.0, 0.5)
+    for _ in range(2):                                       # (a call on a large smooth grid in between leaves stale counts behind)
+        out = gridpp.optimal_interpolation(gridpp.Grid(lats, lons, ge, gl), bg, points, obs, ratios, pbg, st, 30)
+        stats = gridpp.oi_last_stats()
+        assert stats["union_kernel_ms"] > 0 and stats["fallback_tiles"] > 100
+        _check(out, ref)
+        gl2 = rng.uniform(0, 1, (Y + 20, X + 20)).astype(np.float32)
+        la2, lo2 = np.meshgrid(np.linspace(60, 60.6, Y + 20), np.linspace(10, 11.2, X + 20), indexing="ij")
+        g2 = gridpp.Grid(la2, lo2, rng.uniform(0, 1000, (Y + 20, X + 20)).astype(np.float32), gl2)
+        b2 = rng.normal(0, 2, (Y + 20, X + 20)).astype(np.float32)
+        gridpp.optimal_interpolation(g2, b2, points, obs, ratios, pbg, st, 30)
+        gridpp.optimal_interpolation(g2, b2, points, obs, ratios, pbg, st, 30)    # direct path: every count of the larger grid written
+
+
 @pytest.mark.parametrize("seed", range(300, 312))
 def test_random_configurations_pivoted_lu(seed, monkeypatch):
     """The pivoted-LU form of k_oi (non-symmetric / spatially varying structures; forced here on symmetric systems, whose oracle
