@@ -240,10 +240,8 @@ __device__ __forceinline__ void oi_solve_pair(const OiArgs& a, const int lane, c
     for(int e0 = 0; e0 < nentmax; e0 += 32) {
         const int e = e0 + hl;
         const bool gent = e >= ntri;
-        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        if(i * (i + 1) / 2 > e) i--;
-        if((i + 1) * (i + 2) / 2 <= e) i++;
-        int pc = e - i * (i + 1) / 2;
+        const unsigned ip = d_tritab()[min(e, 511)];
+        int i = (int)(ip >> 8), pc = (int)(ip & 255u);
         if(gent) { pc = min(e - ntri, 29); i = 31; }
         const int si = base + min(i, 29), sp = base + pc;
         float xi = __shfl(o0.x, si), yi = __shfl(o0.y, si), zi = __shfl(o0.z, si), ei = __shfl(o0.w, si), li = __shfl(o1.x, si);
@@ -328,7 +326,9 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
     __shared__ double s_col[4][64];   // column staging of the half-wave solves
-    if constexpr(PLAIN) d_exptab_init();   // 2^(j/128) for d_exp_core
+    if constexpr(PLAIN) d_exptab_fill();                          // 2^(j/128) for d_exp_core
+    if constexpr(!LU && !SPATIAL && N == 32) d_tritab_fill();     // triangle index -> (row, column) for oi_solve_pair
+    if constexpr(PLAIN || (!LU && !SPATIAL && N == 32)) __syncthreads();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // all tiles (one per wave), or -- behind k_oi_union -- a fixed-size grid striding over the list of what that kernel
     // declined (the list length is read on the device: no host round trip between the kernels).  A list entry >= 0 is
@@ -751,7 +751,9 @@ __global__ __launch_bounds__(256, PLAIN ? 4 : 3) void k_oi_pairs(OiArgs a) {   /
     __shared__ float s_cb[4][31][64];
     __shared__ double s_col[4][64];
     __shared__ float s_res[4][2][64];
-    if constexpr(PLAIN) d_exptab_init();
+    if constexpr(PLAIN) d_exptab_fill();
+    d_tritab_fill();
+    __syncthreads();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + wid;
     if(tile >= a.ntiles) return;

@@ -95,9 +95,27 @@ __device__ __forceinline__ double* d_exptab() {
     __shared__ double s_exp2_tab[128];
     return s_exp2_tab;
 }
-__device__ __forceinline__ void d_exptab_init() {   // every thread of a workgroup of >= 128 threads, before any early return
+__device__ __forceinline__ void d_exptab_fill() {   // every thread of a workgroup of >= 128 threads; a __syncthreads() before the first use
     if(threadIdx.x < 128) d_exptab()[threadIdx.x] = c_exp2_tab[threadIdx.x];
+}
+__device__ __forceinline__ void d_exptab_init() {   // ... before any early return
+    d_exptab_fill();
     __syncthreads();
+}
+// entry e of a lower triangle stored row by row -> (row i) << 8 | (column p <= i), e = i (i + 1) / 2 + p < 512 (the half-wave
+// solves of k_oi / k_oi_pairs walk the triangle 32 entries at a time; the closed form costs a square root and two corrections per entry)
+__device__ __forceinline__ unsigned short* d_tritab() {
+    __shared__ unsigned short s_tri_tab[512];
+    return s_tri_tab;
+}
+__device__ __forceinline__ void d_tritab_fill() {   // every thread of a workgroup of 256 threads; a __syncthreads() before the first use
+    for(int k = 0; k < 2; ++k) {
+        const int e = 2 * (int)threadIdx.x + k;
+        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        if(i * (i + 1) / 2 > e) i--;
+        if((i + 1) * (i + 2) / 2 <= e) i++;
+        d_tritab()[e] = (unsigned short)((i << 8) | (e - i * (i + 1) / 2));
+    }
 }
 __device__ __forceinline__ double d_exp_core(double x) {   // -110 <= x <= 0 (no range check)
     const double kf = rint(x * 184.66496523378730813);                  // 128 / ln2
