@@ -1573,7 +1573,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             // (the short-list pass writes up to 16 entries per declined tile, SHORT_ITEMS at most, whatever the number of tiles)
             ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get(2 * (size_t)a.ntiles + 64);
             ws.fb_list3.get(std::max<size_t>(4 * (size_t)a.ntiles, (size_t)SHORT_ITEMS) + 64);
-            const dim3 block(256);
+            const dim3 block(64 * UnionCfg<32>::WPB);
             auto launch_union = [&](const long items, const bool list) {   // one wave per work item
                 const long nb = (items + WPB - 1) / WPB;
                 const dim3 grid((unsigned)std::min<long>(nb, 0x7fffffffL));

@@ -54,7 +54,7 @@ __device__ __forceinline__ double d_fma_step(double p, double r, double c) {
     return o;
 }
 // Table form (round 3): x = k ln2/128 + r, |r| <= ln2/256, exp(x) = 2^(k >> 7) * T[k & 127] * (1 + r + ... + r^5/120) with
-// T[j] = 2^(j/128) correctly rounded, held in LDS (1 KB per workgroup, d_exptab_init() at the top of every kernel that gets here:
+// T[j] = 2^(j/128) correctly rounded, held in LDS (1 KB per workgroup, d_exptab_fill() + a barrier at the top of every kernel that gets here:
 // k_oi_union, k_oi, the EnSI scan kernels).  7 double operations behind the reduction instead of 14; < 1 ulp(double) (0.999 measured
 // on 3e8 arguments -v^2/2, v float32, against expl; no float32 result different from glibc's among them: tools/ubench/exp_table.c).
 static __device__ const double c_exp2_tab[128] = {
@@ -95,12 +95,10 @@ __device__ __forceinline__ double* d_exptab() {
     __shared__ double s_exp2_tab[128];
     return s_exp2_tab;
 }
-__device__ __forceinline__ void d_exptab_fill() {   // every thread of a workgroup of >= 128 threads; a __syncthreads() before the first use
-    if(threadIdx.x < 128) d_exptab()[threadIdx.x] = c_exp2_tab[threadIdx.x];
-}
-__device__ __forceinline__ void d_exptab_init() {   // ... before any early return
-    d_exptab_fill();
-    __syncthreads();
+template <int NT = 128>
+__device__ __forceinline__ void d_exptab_fill() {   // every thread of a workgroup of NT threads; a __syncthreads() before the first use
+    if constexpr(NT >= 128) { if(threadIdx.x < 128) d_exptab()[threadIdx.x] = c_exp2_tab[threadIdx.x]; }
+    else { for(int i = threadIdx.x; i < 128; i += NT) d_exptab()[i] = c_exp2_tab[i]; }
 }
 // entry e of a lower triangle stored row by row -> (row i) << 8 | (column p <= i), e = i (i + 1) / 2 + p < 512 (the half-wave
 // solves of k_oi / k_oi_pairs walk the triangle 32 entries at a time; the closed form costs a square root and two corrections per entry)

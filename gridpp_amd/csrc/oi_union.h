@@ -98,7 +98,10 @@ template <> struct UnionCfg<32> {
     static constexpr int WCAP = 40;     // candidate slots of a tile (live union during the scan)
     static constexpr int MAXU = 40;     // rows of the shared factorisation: 32 register columns + 8
     static constexpr int SOLVE = 1024;  // doubles of the shared-factor area
-    static constexpr int WPB = 4;       // waves (work items) per workgroup
+#ifndef GPP_UNION_WPB
+#define GPP_UNION_WPB 4
+#endif
+    static constexpr int WPB = GPP_UNION_WPB;       // waves (work items) per workgroup
 };
 template <> struct UnionCfg<64> {
     static constexpr int WCAP = 64;
@@ -143,7 +146,7 @@ template <bool PLAIN, bool LIST, int NC>
 __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
     constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE, WPB = UnionCfg<NC>::WPB;
     __shared__ UnionLds<NC> s_u[WPB];
-    if constexpr(PLAIN) d_exptab_init();   // 2^(j/128) for d_exp_core
+    if constexpr(PLAIN) { d_exptab_fill<64 * WPB>(); __syncthreads(); }   // 2^(j/128) for d_exp_core
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int tile = blockIdx.x * WPB + wid, sub = -1;   // sub: (lane >> shift) of the lanes of this item, -1 = all
     int shift = 0;
