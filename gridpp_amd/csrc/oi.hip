@@ -236,12 +236,16 @@ __device__ __forceinline__ void oi_solve_pair(const OiArgs& a, const int lane, c
     }
     // lower triangle of P (oi.cpp:304-312) and the G row (oi.cpp:250) of each half, one entry per lane and pass: entry
     // e = i (i + 1) / 2 + p (p <= i) for e < ntri, then G entry p = e - ntri; the records of both points come by ds_bpermute
-    const int ntri = nh * (nh + 1) / 2, nent = ntri + nh, nentmax = nmax * (nmax + 1) / 2 + nmax;
+    // (PLAIN: the three Barnes factors of corr(p, p) are exp(-0) = 1 exactly, so the diagonal is written, not evaluated, and the
+    //  walk covers the strict lower triangle: row i + 1 of it has the i + 1 entries of row i of the full one)
+    constexpr int DG = PLAIN ? 1 : 0;
+    const int ntri = nh * (nh + 1 - 2 * DG) / 2, nent = ntri + nh, nentmax = nmax * (nmax + 1 - 2 * DG) / 2 + nmax;
+    if(DG && hl < nh) colbuf[hl][base + hl] = 1.0f;
     for(int e0 = 0; e0 < nentmax; e0 += 32) {
         const int e = e0 + hl;
         const bool gent = e >= ntri;
         const unsigned ip = d_tritab()[min(e, 511)];
-        int i = (int)(ip >> 8), pc = (int)(ip & 255u);
+        int i = (int)(ip >> 8) + DG, pc = (int)(ip & 255u);
         if(gent) { pc = min(e - ntri, 29); i = 31; }
         const int si = base + min(i, 29), sp = base + pc;
         float xi = __shfl(o0.x, si), yi = __shfl(o0.y, si), zi = __shfl(o0.z, si), ei = __shfl(o0.w, si), li = __shfl(o1.x, si);
