@@ -464,6 +464,11 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
     const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
     unsigned long long wkey = 0;   // worst key kept
     int wslot = 0;
+    // (scalar Barnes, 32-slot lists, no truncation flag: the per-selection OI kernel) minima of eight groups of four slots
+    constexpr bool GROUPS = PLAIN && !WANT_TRUNC && N == 32;
+    unsigned long long gk[8];
+    int gs[8];
+    bool ginit = false;
     // d2 > thr2 can neither be within R nor beat the worst kept rho (rho <= rho_h(d), monotone in d)
     const float thr2_R = R * R * 1.000001f + 1e-30f;
     float thr2 = active ? thr2_R : -1.0f;
@@ -547,6 +552,50 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                                 truncated = true;
                                 if(key > wkey) {   // oi.cpp:262-273, tie-break: lower observation index
                                     keys[wslot][lane] = key;
+                                    if constexpr(GROUPS) {
+                                        // new worst through the minima of eight groups of four slots (in registers): only the group of the
+                                        // replaced slot is read again (4 keys instead of N), then the minimum of the eight
+                                        if(!ginit) {
+                                            ginit = true;
+                                            unsigned long long kv[N];
+#pragma unroll
+                                            for(int s = 0; s < N; ++s) kv[s] = keys[s][lane];
+#pragma unroll
+                                            for(int g = 0; g < 8; ++g) {
+                                                gk[g] = ~0ull; gs[g] = 0;
+#pragma unroll
+                                                for(int j = 0; j < 4; ++j) {
+                                                    const bool lt = 4 * g + j < K && kv[4 * g + j] < gk[g];
+                                                    gk[g] = lt ? kv[4 * g + j] : gk[g];
+                                                    gs[g] = lt ? 4 * g + j : gs[g];
+                                                }
+                                            }
+                                        }
+                                        else {
+                                            const int g0 = wslot >> 2;
+                                            unsigned long long k4[4];
+#pragma unroll
+                                            for(int j = 0; j < 4; ++j) k4[j] = keys[4 * g0 + j][lane];
+                                            unsigned long long mk = ~0ull;
+                                            int ms = 0;
+#pragma unroll
+                                            for(int j = 0; j < 4; ++j) {
+                                                const bool lt = 4 * g0 + j < K && k4[j] < mk;
+                                                mk = lt ? k4[j] : mk;
+                                                ms = lt ? 4 * g0 + j : ms;
+                                            }
+#pragma unroll
+                                            for(int g = 0; g < 8; ++g) { gk[g] = g == g0 ? mk : gk[g]; gs[g] = g == g0 ? ms : gs[g]; }
+                                        }
+                                        wkey = gk[0]; wslot = gs[0];
+#pragma unroll
+                                        for(int g = 1; g < 8; ++g) {
+                                            const bool lt = gk[g] < wkey;
+                                            wkey = lt ? gk[g] : wkey;
+                                            wslot = lt ? gs[g] : wslot;
+                                        }
+                                    }
+                                    else {
                                     // new worst: static loop, so the N LDS reads issue back to back (one latency, no branches)
                                     unsigned long long kv[N];
 #pragma unroll
@@ -557,6 +606,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                                         const bool lt = s < K && kv[s] < wkey;
                                         wkey = lt ? kv[s] : wkey;
                                         wslot = lt ? s : wslot;
+                                    }
                                     }
                                 }
                             }
