@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
         bool overflow, truncated;
         DevStructure cst = a.s.st;   // this lane's structure: uniform, or the parameters at its grid point
         if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
-        cnt = scan_tile<N, false, PLAIN>(a.s, cst, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
+        cnt = scan_tile<N, false, PLAIN, PLAIN && !LU && !SPATIAL>(a.s, cst, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
         if(__ballot(overflow) != 0ull) {   // more usable observations than the register tile holds: left to k_oi_big
             if(a.big_list) { if(overflow) a.big_list[atomicAdd(a.big_count, 1)] = cell; }
             else if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);

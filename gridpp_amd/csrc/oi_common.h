@@ -428,7 +428,7 @@ struct ScanArgs {
 // the tile first -- they almost always contain the final selection, so the pruning thresholds are tight before
 // anything far away is looked at; phase 2 walks the bin rows centre-out with the x-extent and the stop test taken
 // from the largest threshold in the wave, skipping the bins phase 1 already did.
-template <int N, bool WANT_TRUNC = false, bool PLAIN = false>
+template <int N, bool WANT_TRUNC = false, bool PLAIN = false, bool GROUP_MINIMA = false>
 __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& st, const bool active, const float gx, const float gy, const float gz,
                                          const float ge, const float gl, unsigned long long (*keys)[64], const int lane, bool& overflow,
                                          bool& truncated) {
@@ -464,8 +464,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
     const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
     unsigned long long wkey = 0;   // worst key kept
     int wslot = 0;
-    // (scalar Barnes, 32-slot lists, no truncation flag: the per-selection OI kernel) minima of eight groups of four slots
-    constexpr bool GROUPS = PLAIN && !WANT_TRUNC && N == 32;
+    // minima of eight groups of four slots for the replace-the-worst step (24 registers: asked for by the Cholesky form of k_oi<32>
+    // with the scalar Barnes structure only -- the pivoted-LU / spatially varying form lost 5 % to the register pressure)
+    constexpr bool GROUPS = GROUP_MINIMA && N == 32;
     unsigned long long gk[8];
     int gs[8];
     bool ginit = false;
