@@ -464,6 +464,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
     const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
     unsigned long long wkey = 0;   // worst key kept
     int wslot = 0;
+    // the slots beyond K never hold a key: an all-ones sentinel there lets the minimum searches run over all N slots without a test per
+    // slot (32 wave-uniform masks that the register allocator spilled and reloaded inside the candidate loop)
+    for(int s = K; s < N; ++s) keys[s][lane] = ~0ull;
     // minima of eight groups of four slots for the replace-the-worst step (24 registers: asked for by the Cholesky form of k_oi<32>
     // with the scalar Barnes structure only -- the pivoted-LU / spatially varying form lost 5 % to the register pressure)
     constexpr bool GROUPS = GROUP_MINIMA && N == 32;
@@ -566,7 +569,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                                                 gk[g] = ~0ull; gs[g] = 0;
 #pragma unroll
                                                 for(int j = 0; j < 4; ++j) {
-                                                    const bool lt = 4 * g + j < K && kv[4 * g + j] < gk[g];
+                                                    const bool lt = kv[4 * g + j] < gk[g];
                                                     gk[g] = lt ? kv[4 * g + j] : gk[g];
                                                     gs[g] = lt ? 4 * g + j : gs[g];
                                                 }
@@ -581,7 +584,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                                             int ms = 0;
 #pragma unroll
                                             for(int j = 0; j < 4; ++j) {
-                                                const bool lt = 4 * g0 + j < K && k4[j] < mk;
+                                                const bool lt = k4[j] < mk;
                                                 mk = lt ? k4[j] : mk;
                                                 ms = lt ? 4 * g0 + j : ms;
                                             }
@@ -604,7 +607,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                                     wkey = key;
 #pragma unroll
                                     for(int s = 0; s < N; ++s) {
-                                        const bool lt = s < K && kv[s] < wkey;
+                                        const bool lt = kv[s] < wkey;
                                         wkey = lt ? kv[s] : wkey;
                                         wslot = lt ? s : wslot;
                                     }
