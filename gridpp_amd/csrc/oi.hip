@@ -709,8 +709,9 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
             if(a.pair_sel) {   // the selections of the single-member groups go to HBM: k_oi_pairs solves them at twice the occupancy
                 parked = (singles >> lane) & 1ull;
                 if(parked) {
-                    unsigned* const dst = a.pair_sel + (size_t)cell * 32;
-                    for(int s = 0; s < cnt; ++s) dst[s] = origs[s][lane];
+                    // (16 B per store: a lane's record is its own 128 B line, and 30 dword stores per lane were 4x the write transactions)
+                    uint4* const dst = reinterpret_cast<uint4*>(a.pair_sel + (size_t)cell * 32);
+                    for(int s = 0; s < cnt; s += 4) dst[s >> 2] = make_uint4(origs[s][lane], origs[s + 1][lane], origs[s + 2][lane], origs[s + 3][lane]);
                 }
                 singles = 0ull;
             }
