@@ -1,3 +1,5 @@
+/* The table form of d_exp_core (gridpp_amd/csrc/oi_common.h) restated for the CPU, against glibc exp (float32-rounded results) and expl
+   (error in ulp of double), next to the degree-13 Horner form it replaced.  usage: exp_table [samples]; tests/test_exp_table.py runs it. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,8 +33,8 @@ static double e_new(double x){
 }
 static uint64_t s = 88172645463325252ull;
 static inline uint64_t rnd(){ s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
-int main(){
-    long n = 300000000, mo = 0, mn = 0; double uo = 0, un = 0;
+int main(int argc, char** argv){
+    long n = argc > 1 ? atol(argv[1]) : 300000000, mo = 0, mn = 0; double uo = 0, un = 0;
     for(long i = 0; i < n; i++){
         // v float in a log-uniform range so that exp(-0.5 v^2) covers everything from 1 to 0
         double u = (rnd() >> 11) * (1.0 / 9007199254740992.0);
