@@ -580,23 +580,25 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                                             unsigned long long k4[4];
 #pragma unroll
                                             for(int j = 0; j < 4; ++j) k4[j] = keys[4 * g0 + j][lane];
-                                            unsigned long long mk = ~0ull;
-                                            int ms = 0;
-#pragma unroll
-                                            for(int j = 0; j < 4; ++j) {
-                                                const bool lt = k4[j] < mk;
-                                                mk = lt ? k4[j] : mk;
-                                                ms = lt ? 4 * g0 + j : ms;
-                                            }
+                                            // (trees, not chains: the next candidate's pruning test waits for the new threshold)
+                                            const bool l01 = k4[1] < k4[0], l23 = k4[3] < k4[2];
+                                            const unsigned long long m01 = l01 ? k4[1] : k4[0], m23 = l23 ? k4[3] : k4[2];
+                                            const int s01 = 4 * g0 + (l01 ? 1 : 0), s23 = 4 * g0 + (l23 ? 3 : 2);
+                                            const bool lh = m23 < m01;
+                                            const unsigned long long mk = lh ? m23 : m01;
+                                            const int ms = lh ? s23 : s01;
 #pragma unroll
                                             for(int g = 0; g < 8; ++g) { gk[g] = g == g0 ? mk : gk[g]; gs[g] = g == g0 ? ms : gs[g]; }
                                         }
-                                        wkey = gk[0]; wslot = gs[0];
+                                        {
+                                            unsigned long long t4[4], t2[2];
+                                            int u4[4], u2[2];
 #pragma unroll
-                                        for(int g = 1; g < 8; ++g) {
-                                            const bool lt = gk[g] < wkey;
-                                            wkey = lt ? gk[g] : wkey;
-                                            wslot = lt ? gs[g] : wslot;
+                                            for(int g = 0; g < 4; ++g) { const bool lt = gk[2 * g + 1] < gk[2 * g]; t4[g] = lt ? gk[2 * g + 1] : gk[2 * g]; u4[g] = lt ? gs[2 * g + 1] : gs[2 * g]; }
+#pragma unroll
+                                            for(int g = 0; g < 2; ++g) { const bool lt = t4[2 * g + 1] < t4[2 * g]; t2[g] = lt ? t4[2 * g + 1] : t4[2 * g]; u2[g] = lt ? u4[2 * g + 1] : u4[2 * g]; }
+                                            const bool lt = t2[1] < t2[0];
+                                            wkey = lt ? t2[1] : t2[0]; wslot = lt ? u2[1] : u2[0];
                                         }
                                     }
                                     else {
