@@ -93,6 +93,10 @@ def test_parked_selections_rough_terrain(seed, monkeypatch):
                           ovar, pbg, pbvar, O.Barnes(h, v, w), mp, allow)
     _check(out, ref.reshape(Y, X))
     _check(var, rvar.reshape(Y, X))
+    if seed % 2:
+        gridpp.release_workspaces()                         # the parked selections are given back and come again on demand
+        out3, var3 = call()
+        assert np.array_equal(out, out3, equal_nan=True) and np.array_equal(var, var3, equal_nan=True)
     monkeypatch.setenv("GPP_OI_NO_PAIRS", "1")
     out2, var2 = call()
     assert gridpp.oi_last_stats()["solves"] == stats["solves"]
