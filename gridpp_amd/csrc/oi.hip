@@ -1171,6 +1171,30 @@ void gpp_release_oi_workspace() {   // the parked selections (128 B per grid cel
     g_ws.pair_sel.release(); g_ws.pair_n.release();
 }
 
+#ifdef GPP_POISON
+// Diagnostic build only (tools/hostile/build.sh, tools/oi_hostile_soak.py): every byte of the call-to-call workspaces of the OI path is
+// set to `byte` (0xFF: NaNs, huge counts, negative list entries), so that a kernel reading something this call did not write meets
+// hostile data instead of the remains of the previous call.
+extern "C" int gpp_debug_poison_oi_workspace(int byte) {
+    GPP_TRY
+    ensure_device();
+    OiWorkspace& w = g_ws;
+    auto fill = [&](void* p, size_t bytes) { if(p && bytes) GPP_HIP(hipMemsetAsync(p, byte, bytes, stream())); };
+    fill(w.pgeo.p, w.pgeo.cap * sizeof(float4)); fill(w.oaux.p, w.oaux.cap * sizeof(float4)); fill(w.saux.p, w.saux.cap * sizeof(float4));
+    fill(w.status.p, w.status.cap * sizeof(unsigned long long));
+    fill(w.cell_idx.p, w.cell_idx.cap * sizeof(int)); fill(w.obs_idx.p, w.obs_idx.cap * sizeof(int));
+    fill(w.fb_list.p, w.fb_list.cap * sizeof(int)); fill(w.fb_list2.p, w.fb_list2.cap * sizeof(int)); fill(w.fb_list3.p, w.fb_list3.cap * sizeof(int));
+    fill(w.big_list.p, w.big_list.cap * sizeof(int)); fill(w.huge_list.p, w.huge_list.cap * sizeof(int));
+    fill(w.big_keys.p, w.big_keys.cap * sizeof(unsigned long long)); fill(w.huge_keys.p, w.huge_keys.cap * sizeof(unsigned long long));
+    fill(w.big_mat.p, w.big_mat.cap * sizeof(double)); fill(w.huge_mat.p, w.huge_mat.cap * sizeof(double));
+    fill(w.pair_sel.p, w.pair_sel.cap * sizeof(unsigned)); fill(w.pair_n.p, w.pair_n.cap * sizeof(int));
+    GPP_HIP(hipStreamSynchronize(stream()));
+    if(w.h_status) memset(w.h_status, byte, (8 + 80 + 2 * GPP_NSLOT) * sizeof(unsigned long long));
+    return GPP_OK;
+    GPP_CATCH
+}
+#endif
+
 extern "C" int gpp_oi_last_stats(gpp_oi_stats* s) {
     GPP_TRY
     if(!s) invalid("stats is NULL");

@@ -11,7 +11,8 @@ RTOL = 1e-5
 
 
 def _check(out, ref):
-    assert out.shape == ref.shape and (np.isnan(out) == np.isnan(ref)).all()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert (np.isnan(out) == np.isnan(ref)).all(), "NaN pattern differs in %d cells" % int((np.isnan(out) != np.isnan(ref)).sum())
     m = ~np.isnan(ref)
     err = np.abs(out[m].astype(np.float64) - ref[m]) / np.maximum(np.abs(ref[m]), 1e-3)
     assert err.max() < RTOL, err.max()
@@ -143,9 +144,8 @@ def test_random_configurations_pivoted_lu(seed, monkeypatch):
     _random_configuration(seed, [1, 5, 20, 30, 32, 45, 62], lu=True)
 
 
-def _random_configuration(seed, mps, cressman=False, lu=False):
-    import gridpp_amd as gridpp
-    from oracle import oracle as O
+def _random_inputs(seed, mps):
+    """The inputs of one random configuration (shared with tools/oi_hostile_soak.py, which caches the oracle's answers)."""
     rng = np.random.default_rng(4000 + seed)
     Y, X = int(rng.integers(5, 70)), int(rng.integers(5, 70))
     S = int(rng.choice([3, 12, 40, 150, 600, 2500]))
@@ -173,6 +173,19 @@ def _random_configuration(seed, mps, cressman=False, lu=False):
         obs[rng.random(S) < 0.1] = np.nan
         bg[rng.random((Y, X)) < 0.05] = np.nan
     allow = bool(seed % 2)
+    # (drawn last, as the variance part of the check always did)
+    bvar = rng.uniform(0.5, 2, (Y, X)).astype(np.float32)
+    bvp = rng.uniform(0.5, 2, S).astype(np.float32)
+    return dict(Y=Y, X=X, S=S, h=h, mp=mp, lats=lats, lons=lons, plat=plat, plon=plon, bg=bg, obs=obs, pbg=pbg, ratios=ratios,
+                allow=allow, bvar=bvar, bvp=bvp)
+
+
+def _random_configuration(seed, mps, cressman=False, lu=False):
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    c = _random_inputs(seed, mps)
+    Y, X, S, h, mp, allow = c["Y"], c["X"], c["S"], c["h"], c["mp"], c["allow"]
+    lats, lons, plat, plon, bg, obs, pbg, ratios = c["lats"], c["lons"], c["plat"], c["plon"], c["bg"], c["obs"], c["pbg"], c["ratios"]
     grid, points, st = gridpp.Grid(lats, lons), gridpp.Points(plat, plon), gridpp.BarnesStructure(h)
     og, op, ost = O.Pts(lats.ravel(), lons.ravel()), O.Pts(plat, plon), O.Barnes(h)
     if cressman:    # a symmetric structure function that is not the Barnes fast path (k_oi_union<false, ...>)
@@ -187,10 +200,9 @@ def _random_configuration(seed, mps, cressman=False, lu=False):
     ref = O.oi(og, bg.ravel(), op, obs, ratios, pbg, ost, mp, allow).reshape(Y, X)
     _check(out, ref)
     stats = gridpp.oi_last_stats()
-    assert (stats["union_kernel_ms"] > 0) != lu  # this configuration is routed to k_oi_union (unless the pivoted LU is forced)
+    assert (stats["union_kernel_ms"] > 0) != lu, stats  # this configuration is routed to k_oi_union (unless the pivoted LU is forced)
     # variance output of the same configuration
-    bvar = rng.uniform(0.5, 2, (Y, X)).astype(np.float32)
-    bvp = rng.uniform(0.5, 2, S).astype(np.float32)
+    bvar, bvp = c["bvar"], c["bvp"]
     out2, var = gridpp.optimal_interpolation_full(grid, bg, bvar, points, obs, ratios, pbg, bvp, st, mp, allow)
     ref2, rvar = O.oi_full(og, bg.ravel(), bvar.ravel(), op, obs, ratios, pbg, bvp, ost, mp, allow)
     _check(out2, ref2.reshape(Y, X))
