@@ -251,7 +251,7 @@ __device__ __forceinline__ void oi_solve_pair(const OiArgs& a, const int lane, c
         float xi = __shfl(o0.x, si), yi = __shfl(o0.y, si), zi = __shfl(o0.z, si), ei = __shfl(o0.w, si), li = __shfl(o1.x, si);
         const float xp = __shfl(o0.x, sp), yp = __shfl(o0.y, sp), zp = __shfl(o0.z, sp), ep = __shfl(o0.w, sp), lp = __shfl(o1.x, sp);
         xi = gent ? cx : xi; yi = gent ? cy : yi; zi = gent ? cz : zi; ei = gent ? ce : ei; li = gent ? cl : li;
-        const float c = d_corr_t<PLAIN>(a.s.st, xi, yi, zi, ei, li, xp, yp, zp, ep, lp, gent);
+        const float c = d_corr_t<PLAIN, true>(a.s.st, xi, yi, zi, ei, li, xp, yp, zp, ep, lp, gent);
         if(e < nent) colbuf[pc][base + i] = c;
     }
     // obs and background at the observations for the obs - background row (lane 30 of the half): obs rides in column
@@ -330,9 +330,9 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
     __shared__ unsigned long long s_keys[4][N][64];
     __shared__ float s_res[4][2][64];
     __shared__ double s_col[4][64];   // column staging of the half-wave solves
-    if constexpr(PLAIN) d_exptab_fill();                          // 2^(j/128) for d_exp_core
+    d_exptab_fill();                                              // 2^(j/128) for d_exp_core (every structure function of this kernel goes through it)
     if constexpr(!LU && !SPATIAL && N == 32) d_tritab_fill();     // triangle index -> (row, column) for oi_solve_pair
-    if constexpr(PLAIN || (!LU && !SPATIAL && N == 32)) __syncthreads();
+    __syncthreads();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // all tiles (one per wave), or -- behind k_oi_union -- a fixed-size grid striding over the list of what that kernel
     // declined (the list length is read on the device: no host round trip between the kernels).  A list entry >= 0 is
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
         bool overflow, truncated;
         DevStructure cst = a.s.st;   // this lane's structure: uniform, or the parameters at its grid point
         if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
-        cnt = scan_tile<N, false, PLAIN, PLAIN && !LU && !SPATIAL>(a.s, cst, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
+        cnt = scan_tile<N, false, PLAIN, PLAIN && !LU && !SPATIAL, true>(a.s, cst, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
         if(__ballot(overflow) != 0ull) {   // more usable observations than the register tile holds: left to k_oi_big
             if(a.big_list) { if(overflow) a.big_list[atomicAdd(a.big_count, 1)] = cell; }
             else if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);
@@ -413,6 +413,11 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
         // reuse the factor through a forward substitution on rows-in-lanes instead of a factorisation of their own
         auto solve_group = [&](const int l, const int n, const unsigned long long members, const int nm, const unsigned long long extra) {
             nsolve++;
+            // (the lane number as an opaque value: the 62 masks `lane == p` of the row loads below are otherwise invariants of the tile
+            //  loop that the compiler computes once per kernel and keeps -- 124 scalar registers spilled into lanes of vector registers,
+            //  which pushed the 62-row forms into the accumulation registers)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
             // lane i < n takes the i-th selected observation of the leader; lane N+1+m takes member cell m
             const unsigned orig_i = (lane < n) ? origs[lane][l] : 0u;
             float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                 const float xp = readlane_f(o0.x, p), yp = readlane_f(o0.y, p), zp = readlane_f(o0.z, p);
                 const float ep = readlane_f(o0.w, p), lp = readlane_f(o1.x, p);
                 // matrix rows: corr(obs_i, obs_p) (oi.cpp:304-312); G rows: corr(cell, obs_p) (oi.cpp:250)
-                const float c = d_corr_t<PLAIN>(pst, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
+                const float c = d_corr_t<PLAIN, true>(pst, px, py, pz, pe, pl, xp, yp, zp, ep, lp, is_g);
                 colbuf[p][lane] = c;
                 const float dpf = (float)((double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p));
                 maxInc = fmaxf(maxInc, dpf); minInc = fminf(minInc, dpf);
@@ -450,16 +455,31 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                 // g . z in its own lane (instead of a pair of substitutions per member cell: 600 instructions each).
                 const bool zsolve = a.out_var == nullptr;
                 double rowT[N];
-                const float* const cb = &colbuf[0][0];
-                const int cb0 = zsolve ? lane : 64 * lane, cbs = zsolve ? 64 : 1;   // A[lane][p] (this lane computed it for observation p) or A[p][lane]
+                // A[lane][p] (this lane computed it for observation p) or A[p][lane]: two loops with compile-time strides -- with a
+                // run-time stride the 62 LDS addresses of the large tile were loop invariants that the compiler kept in (accumulation)
+                // registers for the whole kernel
+                if(zsolve) {
 #pragma unroll
-                for(int p = 0; p < N; ++p) {
-                    double v = 0.0;
-                    if(p < n && lane < n) {
-                        v = (double)cb[cb0 + cbs * p];
-                        if(lane == p) v += (double)o1.w;
+                    for(int p = 0; p < N; ++p) {
+                        double v = 0.0;
+                        if(p < n && lane < n) {
+                            v = (double)colbuf[p][lane];
+                            if(ln == p) v += (double)o1.w;
+                        }
+                        rowT[p] = v;
                     }
-                    rowT[p] = v;
+                }
+                else {
+                    const float* const mine = &colbuf[0][0] + 64 * (lane < N ? lane : 0);
+#pragma unroll
+                    for(int p = 0; p < N; ++p) {
+                        double v = 0.0;
+                        if(p < n && lane < n) {
+                            v = (double)mine[p];
+                            if(ln == p) v += (double)o1.w;
+                        }
+                        rowT[p] = v;
+                    }
                 }
                 const double dmine = (double)o1.y - (double)o1.z;         // d of observation `lane`
                 int mystep = 64;                                           // column this row became the pivot of
@@ -532,7 +552,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                         for(int j = 0; j < n; ++j) {
                             const float xj = readlane_f(o0.x, j), yj = readlane_f(o0.y, j), zj_ = readlane_f(o0.z, j);
                             const float ej = readlane_f(o0.w, j), lj = readlane_f(o1.x, j);
-                            const float cg = d_corr_t<PLAIN>(cst, gx, gy, gz, ge, gl, xj, yj, zj_, ej, lj, true);
+                            const float cg = d_corr_t<PLAIN, true>(cst, gx, gy, gz, ge, gl, xj, yj, zj_, ej, lj, true);
                             incx = __builtin_fma(s_col[wid][j], (double)cg, incx);
                         }
                         if((extra >> lane) & 1ull) {
@@ -550,7 +570,9 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                     }
                 }
                 unsigned long long mm = zsolve ? 0ull : members;
-                while(mm) {
+                // (the 62-row tile has ONE member row: written as a loop, the 62 pivot lanes, reciprocal pivots and right-hand-side entries
+                //  were loop invariants the compiler formed up front and kept -- some 70 vector registers at the kernel's peak)
+                for(bool once = true; mm != 0ull && (MEMB > 1 || once); once = false) {
                     const int ml = __builtin_ctzll(mm);
                     mm &= mm - 1;
                     const int mi2 = __popcll(members & ((1ull << ml) - 1ull));   // index of this member among the G rows
@@ -598,7 +620,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                     double v = 0.0;
                     if(p < n) {
                         v = (double)colbuf[p][lane];
-                        if(lane == p) v += (double)o1.w;                                                   // lP + lR
+                        if(ln == p) v += (double)o1.w;                                                     // lP + lR
                         const double dp = (double)readlane_f(o1.y, p) - (double)readlane_f(o1.z, p);       // lObs - lY
                         if(lane == N) v = dp;
                         if(!used) v = 0.0;
@@ -646,7 +668,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                 for(unsigned long long mm = extra; mm != 0ull; mm &= mm - 1ull) {
                     const int ml = __builtin_ctzll(mm);
                     const float cx = readlane_f(gx, ml), cy = readlane_f(gy, ml), cz = readlane_f(gz, ml), ce = readlane_f(ge, ml), cl = readlane_f(gl, ml);
-                    double gi = (lane < n) ? (double)d_corr_t<PLAIN>(pst, cx, cy, cz, ce, cl, px, py, pz, pe, pl, true) : 0.0;   // lG (oi.cpp:250,296)
+                    double gi = (lane < n) ? (double)d_corr_t<PLAIN, true>(pst, cx, cy, cz, ce, cl, px, py, pz, pe, pl, true) : 0.0;   // lG (oi.cpp:250,296)
                     double inc2 = 0.0, a002 = 0.0;
     #pragma unroll
                     for(int j = 0; j < N; ++j) {
@@ -756,7 +778,7 @@ __global__ __launch_bounds__(256, PLAIN ? 4 : 3) void k_oi_pairs(OiArgs a) {   /
     __shared__ float s_cb[4][31][64];
     __shared__ double s_col[4][64];
     __shared__ float s_res[4][2][64];
-    if constexpr(PLAIN) d_exptab_fill();
+    d_exptab_fill();
     d_tritab_fill();
     __syncthreads();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;

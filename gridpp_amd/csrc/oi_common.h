@@ -170,6 +170,23 @@ __device__ __forceinline__ float d_barnes_rho(float dist, float length) {
     double e = -0.5 * (double)v * (double)v;
     return (float)d_exp_nonpos(e);
 }
+// The same two functions through the table form of exp (d_exp_core: the workgroup must have filled the table, d_exptab_fill): the
+// generic structure functions of k_oi / k_oi_pairs.  The degree-13 Horner form above and the library exp of d_expf_cr below keep some
+// thirty double constants in vector registers for the whole kernel (gfx950 has no 64-bit literals) -- what pushed the 62-row pivoted-LU
+// forms of k_oi into the accumulation registers; the table form has five.  Same accuracy class (< 1 ulp of the double, rounded to float32).
+__device__ __forceinline__ float d_barnes_rho_tab(float dist, float length) {
+    if(!d_valid(length) || length == 0) return 1.0f;
+    if(!d_valid(dist)) return 0.0f;
+    const float v = dist / length;
+    const double e = -0.5 * (double)v * (double)v;
+    const float r = (float)d_exp_core(fmax(e, -110.0));
+    return e < -110.0 ? 0.0f : r;
+}
+__device__ __forceinline__ float d_expf_tab(float x) {   // (float)exp((double)x) for finite x
+    const double xd = (double)x;
+    const float r = (float)d_exp_core(fmin(fmax(xd, -110.0), 90.0));
+    return xd < -110.0 ? 0.0f : (xd > 90.0 ? INFINITY : r);
+}
 // src/api/kdtree.cpp:192-194 (float32, no contraction, correctly rounded sqrt)
 __device__ __forceinline__ float d_chord(float x0, float y0, float z0, float x1, float y1, float z1) {
     float dx = x0 - x1, dy = y0 - y1, dz = z0 - z1;
@@ -213,8 +230,9 @@ __device__ __forceinline__ void d_structure_at(DevStructure& s, const int fi) {
 }
 // exp(x) rounded to float32 for any sign of x (soar / toar use exp(float), structure.cpp:53,63)
 __device__ __forceinline__ float d_expf_cr(float x) { return (float)exp((double)x); }
-__device__ __forceinline__ float d_rho(const int kind, const float dist, const float length) {
-    if(kind == SK_BARNES) return d_barnes_rho(dist, length);
+template <bool TAB>
+__device__ __forceinline__ float d_rho_x(const int kind, const float dist, const float length) {
+    if(kind == SK_BARNES) return TAB ? d_barnes_rho_tab(dist, length) : d_barnes_rho(dist, length);
     if(kind == SK_LINEAR) {                                     // structure.cpp:76-86 (length = min_corr)
         if(!d_valid(length) || length < 0) return 1.0f;
         if(!d_valid(dist)) return 0.0f;
@@ -229,28 +247,34 @@ __device__ __forceinline__ float d_rho(const int kind, const float dist, const f
         return (length * length - dist * dist) / (length * length + dist * dist);
     }
     const float v = dist / length;
-    if(kind == SK_SOAR) return (1.0f + v) * d_expf_cr(-v);      // :46-54
-    if(kind == SK_TOAR) return (1.0f + v + (v * v) / 3.0f) * d_expf_cr(-v);   // :56-64
+    if(kind == SK_SOAR) return (1.0f + v) * (TAB ? d_expf_tab(-v) : d_expf_cr(-v));      // :46-54
+    if(kind == SK_TOAR) return (1.0f + v + (v * v) / 3.0f) * (TAB ? d_expf_tab(-v) : d_expf_cr(-v));   // :56-64
     return (float)(1.0 / (1.0 + 0.5 * (double)v * (double)v));  // powerlaw :66-74
 }
+__device__ __forceinline__ float d_rho(const int kind, const float dist, const float length) { return d_rho_x<false>(kind, dist, length); }
 // corr(p1, p2) / corr_background(p1, p2) of a scalar (possibly Multiple / CrossValidation-wrapped) structure.
 // PLAIN = true is the compile-time specialisation for an unwrapped Barnes structure (the headline configuration).
 template <bool PLAIN>
 __device__ __forceinline__ float d_rho_t(const int kind, const float dist, const float length) {
     return PLAIN ? d_barnes_rho(dist, length) : d_rho(kind, dist, length);
 }
-template <bool PLAIN>
+template <bool PLAIN, bool TAB = false>
 __device__ __forceinline__ float d_corr_t(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
                                           float x2, float y2, float z2, float e2, float l2, const bool background);
-__device__ __forceinline__ float d_corr(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
-                                        float x2, float y2, float z2, float e2, float l2, const bool background) {
+template <bool TAB>
+__device__ __forceinline__ float d_corr_x(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
+                                          float x2, float y2, float z2, float e2, float l2, const bool background) {
     const float hdist = d_chord(x1, y1, z1, x2, y2, z2);
     if(background && s.cv && hdist <= s.cv_dist) return 0.0f;   // structure.cpp:918-925
     if(s.kh != SK_CRESSMAN && hdist > s.R) return 0.0f;         // :216-217 (Cressman has no cut, :300-312)
-    float rho = d_rho(s.kh, hdist, s.h);
-    if(d_valid(e1) && d_valid(e2)) rho *= d_rho(s.kv, e1 - e2, s.v);
-    if(d_valid(l1) && d_valid(l2)) rho *= d_rho(s.kw, l1 - l2, s.w);
+    float rho = d_rho_x<TAB>(s.kh, hdist, s.h);
+    if(d_valid(e1) && d_valid(e2)) rho *= d_rho_x<TAB>(s.kv, e1 - e2, s.v);
+    if(d_valid(l1) && d_valid(l2)) rho *= d_rho_x<TAB>(s.kw, l1 - l2, s.w);
     return rho;
+}
+__device__ __forceinline__ float d_corr(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
+                                        float x2, float y2, float z2, float e2, float l2, const bool background) {
+    return d_corr_x<false>(s, x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, background);
 }
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -397,11 +421,11 @@ __device__ __forceinline__ float d_barnes_corr_flat(float x1, float y1, float z1
     }
     return hdist > R ? 0.0f : rho;
 }
-template <bool PLAIN>
+template <bool PLAIN, bool TAB>
 __device__ __forceinline__ float d_corr_t(const DevStructure& s, float x1, float y1, float z1, float e1, float l1,
                                           float x2, float y2, float z2, float e2, float l2, const bool background) {
     if(PLAIN) return d_barnes_corr_flat(x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, s.h, s.v, s.w, s.R);
-    return d_corr(s, x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, background);
+    return d_corr_x<TAB>(s, x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, background);
 }
 
 // What the candidate scan needs: the bin-sorted observation block and the structure function
@@ -428,7 +452,7 @@ struct ScanArgs {
 // the tile first -- they almost always contain the final selection, so the pruning thresholds are tight before
 // anything far away is looked at; phase 2 walks the bin rows centre-out with the x-extent and the stop test taken
 // from the largest threshold in the wave, skipping the bins phase 1 already did.
-template <int N, bool WANT_TRUNC = false, bool PLAIN = false, bool GROUP_MINIMA = false>
+template <int N, bool WANT_TRUNC = false, bool PLAIN = false, bool GROUP_MINIMA = false, bool TAB = false>   // TAB: generic kernels through d_exp_core (table filled by the caller)
 __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& st, const bool active, const float gx, const float gy, const float gz,
                                          const float ge, const float gl, unsigned long long (*keys)[64], const int lane, bool& overflow,
                                          bool& truncated) {
@@ -539,9 +563,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                             if(p_hw) { const float f = d_barnes_rho_flat(gl - ol, p_rw); rho = (d_valid(gl) && d_valid(ol)) ? rho * f : rho; }
                         }
                         else {
-                            rho = (st.cv && dist <= st.cv_dist) ? 0.0f : d_rho(st.kh, dist, st.h);   // corr_background
-                            if(d_valid(ge) && d_valid(oe)) rho *= d_rho(st.kv, ge - oe, st.v);
-                            if(d_valid(gl) && d_valid(ol)) rho *= d_rho(st.kw, gl - ol, st.w);
+                            rho = (st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_x<TAB>(st.kh, dist, st.h);   // corr_background
+                            if(d_valid(ge) && d_valid(oe)) rho *= d_rho_x<TAB>(st.kv, ge - oe, st.v);
+                            if(d_valid(gl) && d_valid(ol)) rho *= d_rho_x<TAB>(st.kw, gl - ol, st.w);
                         }
                         const bool ins_ = rho > 0.0f && (cnt < K || (((unsigned long long)__float_as_uint(rho) << 32) | 0xffffffffull) > wkey);
                         if(a.scan_stats && __ballot(ins_) != 0ull) nins++;
@@ -602,16 +626,23 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                                         }
                                     }
                                     else {
-                                    // new worst: static loop, so the N LDS reads issue back to back (one latency, no branches)
-                                    unsigned long long kv[N];
-#pragma unroll
-                                    for(int s = 0; s < N; ++s) kv[s] = keys[s][lane];
+                                    // new worst: static loops, so the LDS reads of a batch issue back to back (one latency, no branches); the
+                                    // 62-slot form in two batches of 31 keys (all 62 in flight at once were 124 registers at the kernel's peak)
+                                    constexpr int NB = N > 32 ? (N + 1) / 2 : N;
                                     wkey = key;
 #pragma unroll
-                                    for(int s = 0; s < N; ++s) {
-                                        const bool lt = kv[s] < wkey;
-                                        wkey = lt ? kv[s] : wkey;
-                                        wslot = lt ? s : wslot;
+                                    for(int s0 = 0; s0 < N; s0 += NB) {
+                                        unsigned long long kv[NB];
+#pragma unroll
+                                        for(int s = 0; s < NB; ++s) if(s0 + s < N) kv[s] = keys[s0 + s][lane];
+#pragma unroll
+                                        for(int s = 0; s < NB; ++s) {
+                                            if(s0 + s < N) {
+                                                const bool lt = kv[s] < wkey;
+                                                wkey = lt ? kv[s] : wkey;
+                                                wslot = lt ? s0 + s : wslot;
+                                            }
+                                        }
                                     }
                                     }
                                 }
@@ -637,9 +668,9 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                             if(p_hw) { const float f = d_barnes_rho_flat(gl - ol, p_rw); rho = (d_valid(gl) && d_valid(ol)) ? rho * f : rho; }
                         }
                         else {
-                            rho = (st.cv && dist <= st.cv_dist) ? 0.0f : d_rho(st.kh, dist, st.h);   // corr_background
-                            if(d_valid(ge) && d_valid(oe)) rho *= d_rho(st.kv, ge - oe, st.v);
-                            if(d_valid(gl) && d_valid(ol)) rho *= d_rho(st.kw, gl - ol, st.w);
+                            rho = (st.cv && dist <= st.cv_dist) ? 0.0f : d_rho_x<TAB>(st.kh, dist, st.h);   // corr_background
+                            if(d_valid(ge) && d_valid(oe)) rho *= d_rho_x<TAB>(st.kv, ge - oe, st.v);
+                            if(d_valid(gl) && d_valid(ol)) rho *= d_rho_x<TAB>(st.kw, gl - ol, st.w);
                         }
                         if(rho > 0.0f) truncated = true;
                     }

@@ -564,7 +564,8 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
             else if(mk != 0ull) extM |= 1ull << w;
         }
         c = __popcll(coreM); nE = __popcll(extM); u = c + nE;
-        if(u > U_MAXU || nE > U_MAXE || c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE > U_SOLVE) {
+        // (+ 3: the padding reads of the per-cell finish behind the last row of B, see `brow` below)
+        if(u > U_MAXU || nE > U_MAXE || c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE + 3 > U_SOLVE) {
             fb = true;
             if(UNION_STATS && lane == 0) atomicAdd(&a.counters[u > U_MAXU ? 5 : (nE > U_MAXE ? 6 : 7)], 1ull);
         }
@@ -721,6 +722,12 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
             }
         }
         if(lane >= c && lane < u && (c & 1) == 0) sv[oB + ea * bs + c] = 0.0;   // padding element of the odd stride
+        // The per-cell finish reads the rows of B four columns at a time: up to three doubles past a row, multiplied by z = 0.  Behind the
+        // last row these are the Schur complement and d' -- and, with ONE extras row and c = 4 k + 1, the double after d', which nobody
+        // has written: for c >= 57 (64-column form only) it lies outside the 16 KB of rho slots this kernel initialises, i.e. it holds
+        // whatever the last workgroup on this CU left in LDS, and 0 x NaN = NaN (an all-ones sentinel key of k_oi's scan is such a pattern).
+        // That was the intermittent failure of the max_points 33..62 soak (seed 5019: c = 61, one extra).
+        if(lane < 3) sv[oD + nE + lane] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
                     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
                     for(int j0 = 0; j0 < NC; j0 += 4) {
-                        if(j0 < c) {   // reads at most 3 elements past the row (finite data, multiplied by z = 0)
+                        if(j0 < c) {   // reads at most 3 elements past the row (multiplied by z = 0; written data: the next row, the Schur complement, d', three zeros)
                             acc0 = __builtin_fma(brow[j0], z[j0], acc0);
                             acc1 = __builtin_fma(brow[j0 + 1], z[j0 + 1], acc1);
                             acc0 = __builtin_fma(brow[j0 + 2], z[j0 + 2], acc0);

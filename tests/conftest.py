@@ -28,3 +28,31 @@ def _nan(o):
 def golden():
     with open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")) as f:
         return _nan(json.load(f))
+
+
+# GPP_TEST_POISON=1 (with tools/hostile/build.sh done): before EVERY call into the library the whole LDS of every CU and 500 registers per
+# lane of every SIMD are filled with 0xFF (NaN as float and as double, -1 as an index), so that a kernel which reads something it never
+# wrote -- LDS or registers left by whatever ran on the CU before -- fails here instead of once in a few thousand soak runs (round 4:
+# that is how the intermittent failure of the max_points 33..62 soak was pinned down).
+if os.environ.get("GPP_TEST_POISON"):
+    import ctypes as _C
+
+    @pytest.fixture(scope="session", autouse=True)
+    def _poison_every_library_call():
+        import gridpp_amd
+        plib = _C.CDLL(os.path.join(ROOT, "tools", "hostile", "libpoison.so"))
+        lib = gridpp_amd._capi.lib()
+        skip = {"gpp_last_error", "gpp_version", "gpp_active_overrides"}
+
+        class Poisoned:
+            def __init__(self, fn):
+                self.fn = fn
+
+            def __call__(self, *a):
+                assert plib.poison_lds(_C.c_uint(0xFFFFFFFF)) == 0 and plib.poison_regs(_C.c_uint(0xFFFFFFFF)) == 0
+                return self.fn(*a)
+
+        for name in gridpp_amd._capi.SIGNATURES:
+            if name not in skip and hasattr(lib, name):
+                setattr(lib, name, Poisoned(getattr(lib, name)))
+        yield
