@@ -360,6 +360,19 @@ def main():
                 oc.append(bc.ensi_case(2500, 2500, 50, 5000, 30))
             except Exception as e:   # a failing secondary case must not take the headline line with it
                 oc.append({"case": "error", "message": repr(e)[:300]})
+            if not args.no_cpu_baseline:
+                # the CPU oracle beside C4 and C5 as well (bounded samples)
+                try:
+                    c4 = bc.c4_cpu_baseline(4000, 100, 15, target_s=0.5 * args.cpu_seconds)
+                    c5 = bc.c5_cpu_baseline(2500, 2500, 50, 5000, 30, target_s=0.7 * args.cpu_seconds)
+                    for o in oc:
+                        nm = o.get("case", "")
+                        base = c4["mean"] if nm.startswith("C4 neighbourhood Mean") else (c4["quantile_fast"] if nm.startswith("C4 quantile_fast") else (c5 if nm.startswith("C5 EnSI") else None))
+                        if base is not None:
+                            o["cpu_baseline"] = base
+                            o["speedup_vs_cpu_baseline"] = o["Mcells/s"] * 1e6 / base["value"]
+                except Exception as e:
+                    oc.append({"case": "cpu_baseline error", "message": repr(e)[:300]})
             res["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline and case == "oi":
             res["cpu_baseline"] = cpu_baseline(ny, nx, S, seed, args.h, args.max_points, args.cpu_seconds)

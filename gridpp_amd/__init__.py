@@ -67,6 +67,42 @@ def get_omp_threads():
     return _omp_threads
 
 
+# ---- messages (include/gridpp.h:1394-1430, src/api/gridpp.cpp:70-76, src/api/util.cpp:226-252) ------------
+_debug_level = 0
+
+
+def set_debug_level(level):
+    global _debug_level
+    _debug_level = int(level)
+
+
+def get_debug_level():
+    return _debug_level
+
+
+def debug(string):
+    print(string, flush=True)
+
+
+def warning(string):
+    print("Warning: " + str(string), flush=True)
+
+
+def error(string):
+    print("Error: " + str(string), flush=True)
+    raise RuntimeError(string)
+
+
+def future_deprecation_warning(function, other=""):
+    print("Future deprecation warning: %s will be deprecated%s" % (function, (", use %s instead." % other) if other else "."), flush=True)
+
+
+def clock():
+    """seconds since the epoch (src/api/util.cpp:254-260)"""
+    import time
+    return time.time()
+
+
 # ---- argument conversion (the SWIG typemaps of swig/vector.i) ---------------------------------
 def _is_dev(a):
     return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
@@ -1098,15 +1134,18 @@ def neighbourhood_quantile_fast(input, quantile, halfwidth, thresholds):
     return out
 
 
-def neighbourhood_ens(input, halfwidth, statistic):   # deprecated aliases (neighbourhood.cpp:541-552)
+def neighbourhood_ens(input, halfwidth, statistic):   # deprecated aliases (neighbourhood.cpp:541-552), with the reference's message
+    future_deprecation_warning("neighbourhood_ens", "neighbourhood")
     return neighbourhood(input, halfwidth, statistic)
 
 
 def neighbourhood_quantile_ens(input, quantile, halfwidth):
+    future_deprecation_warning("neighbourhood_quantile_ens", "neighbourhood_quantile")
     return neighbourhood_quantile(input, quantile, halfwidth)
 
 
 def neighbourhood_quantile_ens_fast(input, quantile, halfwidth, thresholds):
+    future_deprecation_warning("neighbourhood_quantile_ens_fast", "neighbourhood_quantile_fast")
     return neighbourhood_quantile_fast(input, quantile, halfwidth, thresholds)
 
 

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <memory>
 #include <stdexcept>
+#include <iostream>
 #include <string>
 #include <vector>
 #include "../../include/gridpp_hip.h"
@@ -77,6 +78,18 @@ inline bool is_valid(float value) { return !std::isnan(value) && !std::isinf(val
 inline std::string version() { return gpp_version(); }
 inline void set_omp_threads(int) {}        // src/api/gridpp.cpp:184-207: no meaning on the GPU path
 inline int get_omp_threads() { return 1; }
+// messages (include/gridpp.h:1394-1430, src/api/gridpp.cpp:70-76, src/api/util.cpp:226-252)
+inline int& debug_level_ref() { static int level = 0; return level; }
+inline void set_debug_level(int level) { debug_level_ref() = level; }
+inline int get_debug_level() { return debug_level_ref(); }
+inline void debug(const std::string& s) { std::cout << s << std::endl; }
+inline void warning(const std::string& s) { std::cout << "Warning: " << s << std::endl; }
+inline void error(const std::string& s) { std::cout << "Error: " << s << std::endl; throw std::runtime_error(s); }
+inline void future_deprecation_warning(const std::string& function, const std::string& other = "") {
+    std::cout << "Future deprecation warning: " << function << " will be deprecated";
+    if(other != "") std::cout << ", use " << other << " instead." << std::endl;
+    else std::cout << "." << std::endl;
+}
 
 class Points {
   public:
@@ -469,9 +482,9 @@ inline vec2 neighbourhood_quantile_fast(const vec2& input, float quantile, int h
 inline vec2 neighbourhood_quantile_fast(const vec3& input, const vec2& quantile, int halfwidth, const vec& thresholds) { size_t Y, X, E; vec f = detail::flatten(input, Y, X, E); return detail::qfast(f, Y, X, E, 1, quantile, halfwidth, thresholds); }
 inline vec2 neighbourhood_quantile_fast(const vec3& input, float quantile, int halfwidth, const vec& thresholds) { return neighbourhood_quantile_fast(input, vec2(1, vec(1, quantile)), halfwidth, thresholds); }
 // deprecated aliases (include/gridpp.h:710-716, src/api/neighbourhood.cpp:541-552)
-inline vec2 neighbourhood_ens(const vec3& input, int halfwidth, Statistic statistic) { return neighbourhood(input, halfwidth, statistic); }
-inline vec2 neighbourhood_quantile_ens(const vec3& input, float quantile, int halfwidth) { return neighbourhood_quantile(input, quantile, halfwidth); }
-inline vec2 neighbourhood_quantile_ens_fast(const vec3& input, float quantile, int radius, const vec& thresholds) { return neighbourhood_quantile_fast(input, quantile, radius, thresholds); }
+inline vec2 neighbourhood_ens(const vec3& input, int halfwidth, Statistic statistic) { future_deprecation_warning("neighbourhood_ens", "neighbourhood"); return neighbourhood(input, halfwidth, statistic); }
+inline vec2 neighbourhood_quantile_ens(const vec3& input, float quantile, int halfwidth) { future_deprecation_warning("neighbourhood_quantile_ens", "neighbourhood_quantile"); return neighbourhood_quantile(input, quantile, halfwidth); }
+inline vec2 neighbourhood_quantile_ens_fast(const vec3& input, float quantile, int radius, const vec& thresholds) { future_deprecation_warning("neighbourhood_quantile_ens_fast", "neighbourhood_quantile_fast"); return neighbourhood_quantile_fast(input, quantile, radius, thresholds); }
 namespace detail {
 inline vec thresholds(const vec& f, int num) {
     if(num <= 0) throw std::invalid_argument("num_thresholds must be > 0");

@@ -562,6 +562,16 @@ int orc_omp_max_threads(void) {
     return 1;
 #endif
 }
+/* Threads of the loops the REFERENCE runs under `#pragma omp parallel for` in the neighbourhood family                   */
+/* (neighbourhood.cpp:101 the window loop of the summed-area table, :453 the threshold loop and :483 the row loop of     */
+/* quantile_fast).  1 (the default) keeps every oracle function the plain serial loop the tests compare against; the     */
+/* cpu_baseline leg of bench.py raises it for its timed calls (same bits: the iterations are independent).               */
+static int orc_nbh_threads = 1;
+int orc_set_neighbourhood_threads(int n) {
+    int old = orc_nbh_threads;
+    orc_nbh_threads = n < 1 ? 1 : n;
+    return old;
+}
 /* ------------------------------------------------------------------------ */
 /* optimal_interpolation_full with a generic scalar structure (same loop as   */
 /* orc_oi_full_range; P is filled with corr(obs_i, obs_j) and may be           */
@@ -863,6 +873,7 @@ int orc_neighbourhood(const float* in, int nY, int nX, int hw, int statistic, fl
                 Cn(i,j) = Cn(i,j-1) + Cn(i-1,j) - Cn(i-1,j-1) + ok;
             }
         }
+#pragma omp parallel for num_threads(orc_nbh_threads) if(orc_nbh_threads > 1)                                        /* :101 */
         for(int i = 0; i < nY; i++) for(int j = 0; j < nX; j++) {        /* :101-144 */
             int i1 = i + hw < nY - 1 ? i + hw : nY - 1;
             int j1 = j + hw < nX - 1 ? j + hw : nX - 1;
@@ -967,8 +978,10 @@ int orc_neighbourhood_quantile_fast(const float* in, int nY, int nX, int nE, int
     for(size_t c = 0; c < C; c++) out[c] = NAN;
     if(nT == 0) return ORC_OK;
     float* stats = (float*)malloc(sizeof(float) * C * nT);
-    float* temp = (float*)malloc(sizeof(float) * C);
+    /* :453 -- one thread per threshold in the reference (the neighbourhood() inside then runs serially: nested regions are off) */
+#pragma omp parallel for num_threads(orc_nbh_threads) if(orc_nbh_threads > 1)
     for(int t = 0; t < nT; t++) {
+        float* temp = (float*)malloc(sizeof(float) * C);
         for(size_t c = 0; c < C; c++) {
             int sum = 0, count = 0;
             for(int e = 0; e < nE; e++) {
@@ -978,9 +991,13 @@ int orc_neighbourhood_quantile_fast(const float* in, int nY, int nX, int nE, int
             temp[c] = count > 0 ? (float)sum / count : NAN;
         }
         orc_neighbourhood(temp, nY, nX, hw, ST_MEAN, stats + (size_t)t * C);
+        free(temp);
     }
+    /* :483 -- rows in parallel */
+#pragma omp parallel for num_threads(orc_nbh_threads) if(orc_nbh_threads > 1)
+    for(int yrow = 0; yrow < nY; yrow++) {
     float* yarray = (float*)malloc(sizeof(float) * nT);
-    for(size_t c = 0; c < C; c++) {
+    for(size_t c = (size_t)yrow * nX; c < (size_t)(yrow + 1) * nX; c++) {
         float q = (nq == 1) ? quantile[0] : quantile[c];
         int missing = 0;
         for(int t = 0; t < nT; t++) {
@@ -1001,7 +1018,9 @@ int orc_neighbourhood_quantile_fast(const float* in, int nY, int nX, int nE, int
             else out[c] = orc_interpolate(q, yarray, thresholds, nT);
         }
     }
-    free(stats); free(temp); free(yarray);
+    free(yarray);
+    }
+    free(stats);
     return ORC_OK;
 }
 

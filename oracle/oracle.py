@@ -211,6 +211,11 @@ def omp_max_threads():
     return int(lib().orc_omp_max_threads())
 
 
+def set_neighbourhood_threads(n):
+    """threads of the loops the reference runs under OpenMP in the neighbourhood family (1 = serial, the default); returns the old value"""
+    return int(lib().orc_set_neighbourhood_threads(C.c_int(int(n))))
+
+
 def oi(g, background, p, obs, ratios, pbackground, st, max_points, allow_extrapolation=True, y0=0, y1=None):
     """optimal_interpolation(Points...) = _full with unit variances (src/api/oi.cpp:123-135)."""
     ones_g = np.ones(g.n, np.float32)

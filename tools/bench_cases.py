@@ -157,3 +157,92 @@ def ensi_fp64(ny, nx, E, S, mp, kms):
     except (OSError, KeyError, ValueError):
         pass
     return out
+
+
+# ---- CPU baselines of C4 / C5 (bench.py: `cpu_baseline` inside their other_configs entries) -------------------------------------------------
+def _usable_threads():
+    import os
+    from oracle import oracle as O
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q = f.read().split()
+        if q[0] != "max":
+            n = max(1, min(n, int(float(q[0]) / float(q[1]))))
+    except (OSError, ValueError, IndexError):
+        pass
+    return max(1, min(n, O.omp_max_threads()))
+
+
+def c4_cpu_baseline(nx, E, hw, target_s=8.0):
+    """The CPU oracle on a band of rows of the C4 cube (same distribution: U(0, 10) members), with OpenMP exactly where the reference has it
+    (neighbourhood.cpp:101 window loop; :453 one thread per threshold, :483 rows): the member statistic and the summed-area table are
+    serial in the reference, so are they here.  One thread and all usable threads."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(1003)
+    thr = np.linspace(0, 10, 11).astype(np.float32)
+    threads = _usable_threads()
+    out = {}
+    band = {}
+    for name, fn in (("mean", lambda c: O.neighbourhood(c, hw, O.Mean)), ("quantile_fast", lambda c: O.neighbourhood_quantile_fast(c, 0.5, hw, thr))):
+        rows = 4 * hw + 2
+        cube = (rng.random((rows, nx, E), dtype=np.float32) * 10)
+        t0 = time.perf_counter(); fn(cube); per_row = (time.perf_counter() - t0) / rows
+        rows = int(max(4 * hw + 2, min(320, 0.3 * target_s / per_row)))   # (<= 0.5 GB of members: generating them is not the point)
+        cube = (rng.random((rows, nx, E), dtype=np.float32) * 10)
+        t0 = time.perf_counter(); fn(cube); t1 = time.perf_counter() - t0
+        O.set_neighbourhood_threads(threads)
+        try:
+            t0 = time.perf_counter(); fn(cube); tn = time.perf_counter() - t0
+        finally:
+            O.set_neighbourhood_threads(1)
+        band[name] = rows
+        out[name] = {"value": rows * nx / tn, "unit": "cells/s", "cores": threads, "kind": "port", "one_thread_value": rows * nx / t1,
+                     "sample": "a band of %d rows x %d columns x %d members of the same distribution; %d threads %.2f s, 1 thread %.2f s" % (rows, nx, E, threads, tn, t1),
+                     "algorithm": "oracle/gridpp_oracle.c: member statistic + summed-area table (serial, as in the reference) + window loop; OpenMP where "
+                                  "neighbourhood.cpp:101,453,483 have it"}
+    return out
+
+
+def c5_cpu_baseline(ny, nx, E, S, mp, target_s=10.0):
+    """The CPU oracle's optimal_interpolation_ensi on a sample of grid points of the C5 workload.  The reference runs this loop SERIALLY
+    (oi_ensi.cpp:204-207: its `#pragma omp parallel for` is commented out), so `value` is the one-thread figure; `all_threads_value` runs
+    disjoint ranges of the sample on all usable threads (what the pragma would give)."""
+    import threading
+    from oracle import oracle as O
+    rng = np.random.default_rng(1004)
+    plat, plon = rng.random(S), rng.random(S)
+    pbg = rng.normal(0, 1, (S, E)).astype(np.float32)
+    obs = rng.normal(0, 1, S).astype(np.float32)
+    sig = np.ones(S, np.float32)
+    op, st = O.Pts(plat, plon), O.Barnes(10000.0)
+    threads = _usable_threads()
+
+    def sample(n, seed):
+        r = np.random.default_rng(seed)
+        la, lo = r.random(n), r.random(n)
+        bg = ((np.sin(6 * la) * np.cos(4 * lo) * 3)[:, None] + r.normal(0, 1, (n, E))).astype(np.float32)
+        return O.Pts(la, lo), bg
+    g, bg = sample(64, 1)
+    t0 = time.perf_counter(); O.oi_ensi(g, bg, op, obs, sig, pbg, st, mp); per_cell = (time.perf_counter() - t0) / 64
+    n1 = int(max(64, min(20000, 0.35 * target_s / per_cell)))
+    g, bg = sample(n1, 2)
+    t0 = time.perf_counter(); O.oi_ensi(g, bg, op, obs, sig, pbg, st, mp); t1 = time.perf_counter() - t0
+    nall = n1 * max(1, min(threads, 8))
+    parts = [sample(nall // threads + 1, 10 + k) for k in range(threads)]
+    ws = [threading.Thread(target=lambda gb=gb: O.oi_ensi(gb[0], gb[1], op, obs, sig, pbg, st, mp)) for gb in parts]
+    t0 = time.perf_counter()
+    for w in ws: w.start()
+    for w in ws: w.join()
+    ta = time.perf_counter() - t0
+    ncells = sum(gb[1].shape[0] for gb in parts)
+    return {"value": n1 / t1, "unit": "cells/s", "cores": 1, "kind": "port",
+            "all_threads_value": ncells / ta, "all_threads_cores": threads,
+            "sample": "%d random grid points of the same workload (%d members, %d obs, max_points %d) on 1 thread in %.1f s; %d points over %d threads in %.1f s"
+                      % (n1, E, S, mp, t1, ncells, threads, ta),
+            "algorithm": "oracle/gridpp_oracle.c:orc_oi_ensi_core (E x E inverse + cyclic-Jacobi eig_sym per grid point); the reference's loop is serial "
+                         "(oi_ensi.cpp:204-207)"}
