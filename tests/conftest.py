@@ -30,18 +30,18 @@ def golden():
         return _nan(json.load(f))
 
 
-# GPP_TEST_POISON=1 (with tools/hostile/build.sh done): before EVERY call into the library the whole LDS of every CU and 500 registers per
+# GRIDPP_TEST_POISON=1 (with tools/hostile/build.sh done): before EVERY call into the library the whole LDS of every CU and 500 registers per
 # lane of every SIMD are filled with 0xFF (NaN as float and as double, -1 as an index), so that a kernel which reads something it never
 # wrote -- LDS or registers left by whatever ran on the CU before -- fails here instead of once in a few thousand soak runs (round 4:
 # that is how the intermittent failure of the max_points 33..62 soak was pinned down).
-if os.environ.get("GPP_TEST_POISON"):
+if os.environ.get("GRIDPP_TEST_POISON"):
     import ctypes as _C
 
     @pytest.fixture(scope="session", autouse=True)
     def _poison_every_library_call():
         import gridpp_amd
+        lib = gridpp_amd._capi.lib()     # (first: it loads torch's HIP runtime, which the helper library then shares)
         plib = _C.CDLL(os.path.join(ROOT, "tools", "hostile", "libpoison.so"))
-        lib = gridpp_amd._capi.lib()
         skip = {"gpp_last_error", "gpp_version", "gpp_active_overrides"}
 
         class Poisoned:

@@ -209,6 +209,46 @@ def _random_configuration(seed, mps, cressman=False, lu=False):
     _check(var, rvar.reshape(Y, X))
 
 
+def _poison_chip():
+    """0xFF over every byte of LDS and 500 registers per lane (tools/hostile/poison.hip, built by build()); False when the helper is absent"""
+    import ctypes as C
+    import os
+    import gridpp_amd
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "hostile", "libpoison.so")
+    if not os.path.exists(so):
+        return False
+    gridpp_amd._capi.lib()            # (first: the helper then shares the HIP runtime torch brought)
+    plib = C.CDLL(so)
+    assert plib.poison_lds(C.c_uint(0xFFFFFFFF)) == 0 and plib.poison_regs(C.c_uint(0xFFFFFFFF)) == 0
+    return True
+
+
+def test_62_row_sequence_in_one_process_after_an_unrelated_call():
+    """Round-3 verdict, item 1c: the sequence that failed once at seed 5019 (max_points 33..62: the 64-column k_oi_union and k_oi<62> behind
+    its lists), in one process, behind a large unrelated call -- every seed against the oracle."""
+    import gridpp_amd as gridpp
+    rng = np.random.default_rng(5)
+    Y, X, S = 700, 900, 4000
+    lats, lons = np.meshgrid(np.linspace(60, 62, Y), np.linspace(10, 14, X), indexing="ij")
+    v = rng.normal(0, 1, S).astype(np.float32)
+    gridpp.optimal_interpolation(gridpp.Grid(lats, lons), rng.normal(0, 1, (Y, X)).astype(np.float32), gridpp.Points(60 + 2 * rng.random(S), 10 + 4 * rng.random(S)),
+                                 v, np.abs(v) + 0.1, v, gridpp.BarnesStructure(12000.0), 25)
+    for seed in range(5000, 5041):
+        _random_configuration(seed, [33, 40, 50, 62])
+
+
+def test_one_extras_row_behind_a_61_row_core_reads_no_stale_lds():
+    """The root cause of that failure: k_oi_union's per-cell finish reads the rows of B four columns at a time, up to
+    three doubles past a row; with ONE extras row behind a core of c = 4 k + 1 rows the third lies behind d' -- for c >= 57 (the 64-column
+    form) outside the 16 KB of rho slots the kernel initialises, i.e. in LDS left by whatever workgroup ran on the CU before, and
+    0 x NaN = NaN.  Seed 5019 (max_points 62: 61 core rows + one extra in a 4-cell item) hits it on its first call; with every byte of
+    LDS set to 0xFF beforehand the failure was deterministic (profiles/r04_oi_hostile_soak_before_fix.txt)."""
+    _poison_chip()
+    _random_configuration(5019, [33, 40, 50, 62])
+    _poison_chip()
+    _random_configuration(5019, [33, 40, 50, 62])
+
+
 def test_scattered_output_points_use_the_work_lists():
     """Output points in random order: the 64 cells of a tile are unrelated, their union is far above 40 rows, so the
     tiles go down the 16-cell and 4-cell lists and what is left to k_oi -- and every path must give the same values."""

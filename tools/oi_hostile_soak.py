@@ -38,8 +38,8 @@ from tests.test_gpu_oi_union_stress import _random_inputs       # noqa: E402
 RTOL = 1e-5
 plib = None
 if poison:
+    glib = gridpp._capi.lib()        # (first: it loads torch's HIP runtime, which the helper library then shares)
     plib = C.CDLL(os.path.join(ROOT, "tools", "hostile", "libpoison.so"))
-    glib = gridpp._capi.lib()
     glib.gpp_debug_poison_oi_workspace.argtypes = [C.c_int]
 
 
