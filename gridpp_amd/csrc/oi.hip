@@ -1524,7 +1524,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
       a.s.ring_r0 = (float)(1.5 * r_k); a.s.ring_dr = (float)(0.15 * r_k); }
     a.s.scan_stats = timing_env("GPP_SCAN_STATS") ? d_counters + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
-    a.err = d_err; a.counters = d_counters;
+    a.err = d_err; a.counters = d_counters; a.tail_count = d_ints + 6;
     a.debug = timing_env("GPP_OI_DEBUG") ? atoi(timing_env("GPP_OI_DEBUG")) : 0;
 
     GPP_HIP(hipEventRecord(ws.e0, stream()));
@@ -1629,7 +1629,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 const long nb = (items + WPB - 1) / WPB;
                 const dim3 grid((unsigned)std::min<long>(nb, 0x7fffffffL));
                 if(N != 32) gpp_launch_union64(a, grid.x, plain, list, stream());
-                else if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true, 32>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<true, false, 32>), grid, block, 0, stream(), a); }
+                // (the first pass is persistent: a grid that fills the chip, every wave strides over the tiles)
+                else if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true, 32>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<true, false, 32>), UnionCfg<32>::persistent<true>() ? dim3(union_persist_grid<k_oi_union<true, false, 32>>(block.x, nb)) : grid, block, 0, stream(), a); }
                 else { if(list) hipLaunchKernelGGL((k_oi_union<false, true, 32>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<false, false, 32>), grid, block, 0, stream(), a); }
                 GPP_HIP(hipGetLastError());
             };

@@ -187,12 +187,27 @@ __device__ __forceinline__ float d_expf_tab(float x) {   // (float)exp((double)x
     const float r = (float)d_exp_core(fmin(fmax(xd, -110.0), 90.0));
     return xd < -110.0 ? 0.0f : (xd > 90.0 ? INFINITY : r);
 }
+// Correctly rounded float32 square root for x = 0 or x >= 2^-96 (NaN gives NaN): v_sqrt_f32 (within one ulp) and the two residual
+// tests of the compiler's own expansion of sqrtf, without its rescaling of small arguments (below 2^-96 the residuals underflow) and
+// its zero / infinity class test -- 9 instead of 16 instructions; the kernels take ~46 chord lengths per tile.  Every float from 2^-96
+// up gives the very bits of sqrtf (tools/ubench/sqrt_cr.hip walks all of them on the GPU); a squared distance below 2^-96 (points
+// closer than 4e-15 of their coordinate unit) may come out one ulp off -- rho is 1 there either way, like the quotient of d_div_by.
+__device__ __forceinline__ float d_sqrt_cr(const float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    float r = (0.0f >= rm) ? sm : s;
+    r = (0.0f < rp) ? sp : r;
+    return r;
+}
+// v_sqrt_f32 as it is (within one ulp): for the quantities that only bound the work (tile radii, ring limits, row extents -- all padded)
+__device__ __forceinline__ float d_sqrt_raw(const float x) { return __builtin_amdgcn_sqrtf(x); }
 // src/api/kdtree.cpp:192-194 (float32, no contraction, correctly rounded sqrt)
 __device__ __forceinline__ float d_chord(float x0, float y0, float z0, float x1, float y1, float z1) {
     float dx = x0 - x1, dy = y0 - y1, dz = z0 - z1;
     float s = dx * dx + dy * dy;
     s = s + dz * dz;
-    return sqrtf(s);
+    return d_sqrt_cr(s);
 }
 // src/api/structure.cpp:215-228 (scalar Barnes)
 __device__ __forceinline__ float d_barnes_corr(float x1, float y1, float z1, float e1, float l1,
@@ -554,7 +569,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                 if(a.scan_stats && __ballot(has && d2 <= thr2) != 0ull && lane == 0) atomicAdd(&a.scan_stats[1], 1ull);
                 if(has && d2 <= thr2) {
                     const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
-                    const float dist = sqrtf(d2);
+                    const float dist = d_sqrt_cr(d2);
                     if(inbox && dist <= R) {   // within_radius (kdtree.cpp:255) and the cut inside corr (structure.cpp:216)
                         float rho;
                         if constexpr(PLAIN) {   // straight-line code: the three exp chains interleave (same values as d_barnes_rho)
@@ -659,7 +674,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                 else if(WANT_TRUNC && has && !truncated && cnt == K && d2 <= thr2_R) {
                     // pruned by the rho threshold: does it still count as a usable observation?
                     const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
-                    const float dist = sqrtf(d2);
+                    const float dist = d_sqrt_cr(d2);
                     if(inbox && dist <= R) {
                         float rho;
                         if constexpr(PLAIN) {   // straight-line code: the three exp chains interleave (same values as d_barnes_rho)
@@ -694,7 +709,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
         if(gap * gap > t2) break;
         const int rowA = tby0 - r, rowB = tby1 + r;
         if(rowA < 0 && rowB >= a.nby) break;
-        const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
+        const float wx = d_sqrt_raw(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f;
         int x0 = (int)floorf((amin_t - wx - a.amin) * a.inv_s) - 1, x1 = (int)floorf((amax_t + wx - a.amin) * a.inv_s) + 1;
         x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), a.nbx - 1));
         x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), a.nbx - 1));

@@ -42,6 +42,7 @@ struct OiArgs {
     int* out_list;
     int* out_count;
     int nrun;                // tiles to run when in_list is NULL
+    int* tail_count;         // persistent first pass: counter of its dynamic tail (cleared with the status block)
     int level;               // k_oi_union<., true>: 1 or 2 (see there)
     const int* parent_count; // level 2: length of the level-1 input list (how many tiles were split)
     int debug;               // GPP_OI_DEBUG: bit0 = skip the solve (timing experiments only)
@@ -98,16 +99,25 @@ template <> struct UnionCfg<32> {
     static constexpr int WCAP = 40;     // candidate slots of a tile (live union during the scan)
     static constexpr int MAXU = 40;     // rows of the shared factorisation: 32 register columns + 8
     static constexpr int SOLVE = 1024;  // doubles of the shared-factor area
+#ifndef GPP_UNION_PERSIST
+// 0 (product): one tile per wave; 1: persistent grid, static striding; 2: persistent grid, the last eighth of the tiles from a counter.
+// Measured on one box, round 4 (tools/ab_bench.sh, first pass of the headline): 0: 4.65 ms, 1: 5.31 ms, 2: 4.87 ms -- the tile loop costs 21
+// registers of hoisted invariants (163 instead of 142) and scalar spills into vector lanes, which the end of the per-workgroup idling
+// does not pay back; the hardware's workgroup dispatcher is the better load balancer here.
+#define GPP_UNION_PERSIST 0
+#endif
 #ifndef GPP_UNION_WPB
 #define GPP_UNION_WPB 4
 #endif
     static constexpr int WPB = GPP_UNION_WPB;       // waves (work items) per workgroup
+    template <bool PLAIN> static constexpr bool persistent() { return PLAIN && GPP_UNION_PERSIST != 0; }   // first pass as a persistent grid (see k_oi_union)
 };
 template <> struct UnionCfg<64> {
     static constexpr int WCAP = 64;
     static constexpr int MAXU = 62;     // lane 63 carries obs - background
     static constexpr int SOLVE = 2240;  // worst case c = 50, 12 extras: 2143 doubles, + the 64 of the column staging
     static constexpr int WPB = 2;
+    template <bool PLAIN> static constexpr bool persistent() { return false; }
 };
 constexpr int U_MAXE = 12;     // union minus core
 constexpr int U_MAXM = 6;      // extras of one cell
@@ -142,43 +152,11 @@ __device__ __forceinline__ double rsqrt_nr(const double a) {
 // everything ends on this kernel; what it declines at level 2 goes to k_oi (one factorisation per distinct selection).
 // List entries: tile (produced by the first pass); tile * 32 + code with code 16..19 = 16-cell item, 0..15 = 4-cell item;
 // ~tile = whole tile forwarded unsplit because splitting would not pay (see `forward` below).
+// One work item (a tile, or a 16-cell / 4-cell part of one) on one wave.
 template <bool PLAIN, bool LIST, int NC>
-__global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
-    constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE, WPB = UnionCfg<NC>::WPB;
-    __shared__ UnionLds<NC> s_u[WPB];
-    if constexpr(PLAIN) { d_exptab_fill<64 * WPB>(); __syncthreads(); }   // 2^(j/128) for d_exp_core
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int tile = blockIdx.x * WPB + wid, sub = -1;   // sub: (lane >> shift) of the lanes of this item, -1 = all
-    int shift = 0;
-    if(LIST) {
-        const int nlist = *a.in_count;
-        // Splitting pays while most items succeed.  Level 1: more than half of the tiles declined -> forward them whole.
-        // Level 2: more than half of the 16-cell items declined (or whole tiles arrived) -> forward what arrived, unsplit.
-        const bool whole = nlist > 0 && a.in_list[0] < 0;
-        const bool forward = a.level != 3 && (whole || (a.level == 1 ? nlist > a.ntiles / 2 : nlist > 2 * *a.parent_count));
-        if(forward) {
-            for(int i = blockIdx.x * (64 * WPB) + threadIdx.x; i < nlist; i += gridDim.x * (64 * WPB)) {
-                const int e = a.in_list[i];
-                a.out_list[atomicAdd(a.out_count, 1)] = (a.level == 1) ? ~e : e;
-            }
-            return;
-        }
-        if(a.level == 3) {   // a short list of declined tiles goes straight to its sixteen 4-cell items: one pass instead of two
-            // (launched before the host knows the length of the list, with a grid that holds a short one: a longer list is left
-            //  alone here and taken by the two-level passes once the host has seen its length)
-            if(16 * nlist > (int)gridDim.x * WPB || tile >= 16 * nlist) return;
-            sub = tile & 15; tile = a.in_list[tile >> 4]; shift = 2;
-        }
-        else {
-            if(tile >= 4 * nlist) return;
-            const int child = tile & 3, e = a.in_list[tile >> 2];
-            if(a.level == 1) { tile = e; sub = child; shift = 4; }
-            else { tile = e >> 5; sub = ((e & 31) - 16) * 4 + child; shift = 2; }
-        }
-    }
-    else if(tile >= a.ntiles) return;
+__device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, const int shift, UnionLds<NC>& L, const int lane) {
+    constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE;
     tile = __builtin_amdgcn_readfirstlane(tile); sub = __builtin_amdgcn_readfirstlane(sub);
-    UnionLds<NC>& L = s_u[wid];
 #ifdef GPP_UNION_PROFILE
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -201,8 +179,12 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         if(a.bvar) bvar = a.bvar[cell];
     }
     const bool active = cell >= 0 && d_valid(bg);   // oi.cpp:223
-    const DevStructure& st = a.s.st;
+    // (a copy whose scales the optimiser cannot see through when the item runs inside the tile loop of the persistent first pass: their
+    //  reciprocals, squares and pruning constants are otherwise invariants of that loop, kept in a dozen vector registers)
+    DevStructure st = a.s.st;
     const ScanArgs& sa = a.s;
+    float sa_inv_s = sa.inv_s;
+    if constexpr(!LIST) asm volatile("" : "+s"(st.h), "+s"(st.v), "+s"(st.w), "+s"(st.R), "+s"(sa_inv_s));
 
     // ================= candidate scan (the walk of scan_tile; selections kept as rho[slot][lane]) =================
     UPROF(0);   // cell loads issued
@@ -232,14 +214,15 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         return live;
     };
     if(__ballot(active) != 0ull) {
-        const float sbin = 1.0f / sa.inv_s;
-        int tby0 = (int)floorf((bmin_t - sa.bmin) * sa.inv_s), tby1 = (int)floorf((bmax_t - sa.bmin) * sa.inv_s);
+        const float sbin = 1.0f / sa_inv_s;
+        int tby0 = (int)floorf((bmin_t - sa.bmin) * sa_inv_s), tby1 = (int)floorf((bmax_t - sa.bmin) * sa_inv_s);
         tby0 = __builtin_amdgcn_readfirstlane(min(max(tby0, 0), sa.nby - 1));
         tby1 = __builtin_amdgcn_readfirstlane(min(max(tby1, tby0), sa.nby - 1));
-        int tbx0 = (int)floorf((amin_t - sa.amin) * sa.inv_s), tbx1 = (int)floorf((amax_t - sa.amin) * sa.inv_s);
+        int tbx0 = (int)floorf((amin_t - sa.amin) * sa_inv_s), tbx1 = (int)floorf((amax_t - sa.amin) * sa_inv_s);
         tbx0 = __builtin_amdgcn_readfirstlane(min(max(tbx0, 0), sa.nbx - 1));
         tbx1 = __builtin_amdgcn_readfirstlane(min(max(tbx1, tbx0), sa.nbx - 1));
         const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
+        const float near_r = R - 4.76837158e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + R);   // (see eval)
         float wr = 0.0f;       // worst kept rho, its slot and observation index
         int ws = 0;
         unsigned wo = 0u;
@@ -249,7 +232,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         // projected (bin-axis) position of the tile centre and its half diagonal: a candidate whose projected distance to
         // the centre exceeds sqrt(largest threshold in the wave) + rad cannot be wanted by any cell (wave-level prune)
         const float ca = 0.5f * (amin_t + amax_t), cb = 0.5f * (bmin_t + bmax_t);
-        const float rad = 0.5f * sqrtf((amax_t - amin_t) * (amax_t - amin_t) + (bmax_t - bmin_t) * (bmax_t - bmin_t)) * 1.001f + 1e-30f;
+        const float rad = 0.5f * d_sqrt_raw((amax_t - amin_t) * (amax_t - amin_t) + (bmax_t - bmin_t) * (bmax_t - bmin_t)) * 1.001f + 1e-30f;
         auto proj_d2 = [&](const float4& rec) {
             const float ra = sa.axis_a == 0 ? rec.x : (sa.axis_a == 1 ? rec.y : rec.z);
             const float rb = sa.axis_b == 1 ? rec.y : (sa.axis_b == 2 ? rec.z : rec.x);
@@ -258,7 +241,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         auto wave_lim2 = [&]() {   // < 0: nothing can be wanted any more
             const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
             if(t2 < 0.0f) return -1.0f;
-            const float lim = (sqrtf(t2) + rad) * 1.0001f;
+            const float lim = (d_sqrt_raw(t2) + rad) * 1.0001f;
             return lim * lim;
         };
 
@@ -272,9 +255,14 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
             const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
             float d2 = dx * dx + dy * dy;
             d2 = d2 + dz * dz;
-            const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;   // kdtree.cpp:46,53
-            const float dist = sqrtf(d2);
-            const bool ok = d2 <= thr2 && inbox && dist <= R;   // within_radius (kdtree.cpp:255), the cut inside corr (structure.cpp:216)
+            const float dist = d_sqrt_cr(d2);
+            bool ok = d2 <= thr2 && dist <= R;   // within_radius (kdtree.cpp:255), the cut inside corr (structure.cpp:216)
+            // The strictly-inside box of the radius query (kdtree.cpp:46,53; its corners gx -+ R are float32 roundings) is implied by
+            // dist <= R unless the candidate sits within a few ulps OF THE COORDINATES of the radius: dist <= near_r = R - 2^-21 (|gx| + |gy| +
+            // |gz| + R) gives |ox - gx| <= dist (1 + 2^-22) < R - 2^-24 (|gx| + R) <= the distance of either rounded corner, on every axis.
+            // The six compares are made only when some cell of the wave holds a candidate that close to R (pruning by the worst kept rho
+            // keeps the candidates far inside: never on the headline workload).
+            if(__ballot(ok && dist > near_r) != 0ull) ok = ok && ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
             float rho = 0.0f;
             if constexpr(PLAIN) {
                 rho = hh ? d_barnes_rho_flat(dist, rh) : 1.0f;
@@ -468,7 +456,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
                     }
                 }
                 for(int ring = -1; ring < NR && !fb; ++ring) {   // ring -1: the bulk disc
-                    const float hi = sqrtf(tlo) + (float)(ring + 1) * sa.ring_dr;
+                    const float hi = d_sqrt_raw(tlo) + (float)(ring + 1) * sa.ring_dr;
                     const float hi2 = ring < 0 ? tlo : ((ring == NR - 1) ? INFINITY : hi * hi);
                     const float lim2 = wave_lim2();
                     if(lim2 < 0.0f || lo2 >= lim2) break;
@@ -516,8 +504,8 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
             const int rowA = tby0 - r, rowB = tby1 + r;
             if(rowA < 0 && rowB >= sa.nby) break;
             // bins are assigned with the same monotone float expression, so no extra bin is needed once wx is padded
-            const float wx = sqrtf(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f + 1e-3f * sbin;
-            int x0 = (int)floorf((amin_t - wx - sa.amin) * sa.inv_s), x1 = (int)floorf((amax_t + wx - sa.amin) * sa.inv_s);
+            const float wx = d_sqrt_raw(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f + 1e-3f * sbin;
+            int x0 = (int)floorf((amin_t - wx - sa.amin) * sa_inv_s), x1 = (int)floorf((amax_t + wx - sa.amin) * sa_inv_s);
             x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), sa.nbx - 1));
             x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), sa.nbx - 1));
             const float lim2 = wave_lim2();
@@ -618,7 +606,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         const int ntri = u * (u + 1) / 2;
         for(int e0 = 0; e0 < ntri; e0 += 64) {
             const int e = e0 + lane;
-            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            int i = (int)((d_sqrt_raw(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);   // (the two tests below put an estimate one off right)
             if(i * (i + 1) / 2 > e) i--;
             if((i + 1) * (i + 2) / 2 <= e) i++;
             const int pcol = e - i * (i + 1) / 2;
@@ -838,3 +826,91 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
     }
 }
 
+// First pass (LIST = false): PERSISTENT waves -- a grid that just fills the chip, every wave strides over the tiles on its own.  With
+// one tile per wave and four waves per workgroup the LDS of a workgroup stayed allocated until its slowest tile was done (the other
+// three waves idle: tile times differ by their evictions and ring work), and the next workgroup could not start before.
+// LIST = true: one item per wave, the grid sized by the host for the longest list that can arrive.
+template <bool PLAIN, bool LIST, int NC>
+__global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
+    constexpr int WPB = UnionCfg<NC>::WPB;
+    __shared__ UnionLds<NC> s_u[WPB];
+    if constexpr(PLAIN) { d_exptab_fill<64 * WPB>(); __syncthreads(); }   // 2^(j/128) for d_exp_core
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if constexpr(LIST) {
+        int tile = blockIdx.x * WPB + wid, sub = -1;   // sub: (lane >> shift) of the lanes of this item, -1 = all
+        int shift = 0;
+        const int nlist = *a.in_count;
+        // Splitting pays while most items succeed.  Level 1: more than half of the tiles declined -> forward them whole.
+        // Level 2: more than half of the 16-cell items declined (or whole tiles arrived) -> forward what arrived, unsplit.
+        const bool whole = nlist > 0 && a.in_list[0] < 0;
+        const bool forward = a.level != 3 && (whole || (a.level == 1 ? nlist > a.ntiles / 2 : nlist > 2 * *a.parent_count));
+        if(forward) {
+            for(int i = blockIdx.x * (64 * WPB) + threadIdx.x; i < nlist; i += gridDim.x * (64 * WPB)) {
+                const int e = a.in_list[i];
+                a.out_list[atomicAdd(a.out_count, 1)] = (a.level == 1) ? ~e : e;
+            }
+            return;
+        }
+        if(a.level == 3) {   // a short list of declined tiles goes straight to its sixteen 4-cell items: one pass instead of two
+            // (launched before the host knows the length of the list, with a grid that holds a short one: a longer list is left
+            //  alone here and taken by the two-level passes once the host has seen its length)
+            if(16 * nlist > (int)gridDim.x * WPB || tile >= 16 * nlist) return;
+            sub = tile & 15; tile = a.in_list[tile >> 4]; shift = 2;
+        }
+        else {
+            if(tile >= 4 * nlist) return;
+            const int child = tile & 3, e = a.in_list[tile >> 2];
+            if(a.level == 1) { tile = e; sub = child; shift = 4; }
+            else { tile = e >> 5; sub = ((e & 31) - 16) * 4 + child; shift = 2; }
+        }
+        union_item<PLAIN, true, NC>(a, tile, sub, shift, s_u[wid], lane);
+    }
+    else if constexpr(!UnionCfg<NC>::template persistent<PLAIN>()) {   // (the other forms keep one tile per wave: the loop costs them registers they do not have)
+        const int tile = blockIdx.x * WPB + wid;
+        if(tile < a.ntiles) union_item<PLAIN, false, NC>(a, tile, -1, 0, s_u[wid], lane);
+    }
+    else {
+        // static part: whole rounds of the grid; dynamic tail: the remaining tiles one by one from a counter (a wave whose tiles were
+        // cheap takes more of them: with static striding alone the kernel ended when the unluckiest of 3 072 waves did)
+        const int stride = gridDim.x * WPB;
+#if GPP_UNION_PERSIST == 2
+        const int nstatic = (int)((long)a.ntiles * 7 / 8 / stride) * stride;
+#else
+        const int nstatic = a.ntiles;
+#endif
+        int tile = blockIdx.x * WPB + wid;
+        for(;;) {
+            if(tile >= nstatic) {
+#if GPP_UNION_PERSIST == 2
+                int t = 0;
+                if(lane == 0) t = atomicAdd(a.tail_count, 1);
+                tile = nstatic + __builtin_amdgcn_readfirstlane(t);
+#endif
+                if(tile >= a.ntiles) break;
+            }
+            // (the lane number as a value the optimiser cannot see through: everything derived from it -- LDS addresses, `lane == k` masks,
+            //  triangle indices -- is otherwise an invariant of this loop, computed once and kept: 15 registers over the budget of three
+            //  waves per SIMD, i.e. scratch)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            union_item<PLAIN, false, NC>(a, tile, -1, 0, s_u[wid], ln);
+            __builtin_amdgcn_wave_barrier();
+            tile += stride;
+        }
+    }
+}
+
+
+// grid of the persistent first pass: as many workgroups as the chip holds of this kernel at once (asked once per kernel), at most one per WPB tiles
+template <void (*K)(OiArgs)>
+inline unsigned union_persist_grid(const int threads, const long nb) {
+    static int resident = 0;
+    if(resident == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        GPP_HIP(hipGetDevice(&dev));
+        GPP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        GPP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(K), threads, 0));
+        resident = std::max(1, cus * std::max(1, per_cu));
+    }
+    return (unsigned)std::min<long>(std::max<long>(nb, 1), (long)resident);
+}

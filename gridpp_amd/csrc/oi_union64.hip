@@ -2,7 +2,8 @@
 #include "oi_union.h"
 
 void gpp_launch_union64(const OiArgs& a, const unsigned nblocks, const bool plain, const bool list, hipStream_t stream) {
-    const dim3 grid(nblocks), block(64 * UnionCfg<64>::WPB);
+    constexpr int T = 64 * UnionCfg<64>::WPB;
+    const dim3 grid(nblocks), block(T);
     if(plain) {
         if(list) hipLaunchKernelGGL((k_oi_union<true, true, 64>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_oi_union<true, false, 64>), grid, block, 0, stream, a);
