@@ -301,27 +301,28 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
-// Wave-wide min / max on the VALU cross-lane path (DPP row shifts + row broadcasts, then lane 63 holds the result):
-// no LDS round trips.  Must be called by all 64 lanes.
-#define GPP_DPP_STEP(OP, ctrl, rmask)                                                                                   \
-    {                                                                                                                   \
-        const int t_ = __builtin_amdgcn_update_dpp(id, x, ctrl, rmask, 0xf, false);                                      \
-        x = __float_as_int(OP(__int_as_float(x), __int_as_float(t_)));                                                  \
-    }
+// Wave-wide min / max on the VALU cross-lane path (DPP row shifts + row broadcasts, then lane 63 holds the result): no LDS round trips.
+// Must be called by all 64 lanes; no NaN among the inputs.  The DPP operand sits on the min / max itself and the value is reduced in
+// place -- a lane whose shifted source does not exist is switched off by the hardware and keeps its value (bound_ctrl off) -- so a step
+// is ONE instruction behind the two wait states a DPP read of a fresh VALU result needs.  Written with update_dpp + fminf the compiler
+// made four of each step (identity move, DPP move, canonicalisation, min): 28 instructions per reduction, 13 of them per tile.
+#define GPP_DPP_RED(OP)                                                                                   \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                         \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                         \
+        "s_nop 1" : "+v"(v))
 __device__ __forceinline__ float wave_min(float v) {
-    int x = __float_as_int(v);
-    const int id = __float_as_int(INFINITY);
-    GPP_DPP_STEP(fminf, 0x111, 0xf) GPP_DPP_STEP(fminf, 0x112, 0xf) GPP_DPP_STEP(fminf, 0x114, 0xf) GPP_DPP_STEP(fminf, 0x118, 0xf)
-    GPP_DPP_STEP(fminf, 0x142, 0xa) GPP_DPP_STEP(fminf, 0x143, 0xc)
-    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+    GPP_DPP_RED("v_min_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-    int x = __float_as_int(v);
-    const int id = __float_as_int(-INFINITY);
-    GPP_DPP_STEP(fmaxf, 0x111, 0xf) GPP_DPP_STEP(fmaxf, 0x112, 0xf) GPP_DPP_STEP(fmaxf, 0x114, 0xf) GPP_DPP_STEP(fmaxf, 0x118, 0xf)
-    GPP_DPP_STEP(fmaxf, 0x142, 0xa) GPP_DPP_STEP(fmaxf, 0x143, 0xc)
-    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+    GPP_DPP_RED("v_max_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+#undef GPP_DPP_RED
 
 // maximum of a double over the 64 lanes (DPP moves of its two halves; every lane must hold a value >= -1.0, the identity)
 __device__ __forceinline__ double wave_max_d(double v) {

@@ -213,6 +213,36 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         for(int w = 0; w < U_WCAP; ++w) if(__ballot(rv[w] < INFINITY) != 0ull) live |= 1ull << w;
         return live;
     };
+    // The worst kept entry of this lane: smallest rho r0, a slot s0 that holds it, and whether more than one slot does.  Two levels --
+    // minima of groups of eight slots, then the eight values of the group that holds the minimum, read again from LDS (its index is
+    // the lane's own): ~70 instructions.  One flat pass (compare, select, count for each of the 40 slots, each triple with a wait
+    // state behind the compare) was 180, and a tile runs this 5.5 times (once behind the bulk disc, once per eviction).
+    auto worst_slot = [&](float& r0, int& s0, bool& multi) {
+        constexpr int NG = U_WCAP / 8;
+        float gm[NG];
+#pragma unroll
+        for(int g = 0; g < NG; ++g) {
+            float v[8];
+#pragma unroll
+            for(int j = 0; j < 8; ++j) v[j] = L.rho[8 * g + j][lane];
+            gm[g] = fminf(fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), fminf(fminf(v[4], v[5]), fminf(v[6], v[7])));
+        }
+        r0 = gm[0];
+#pragma unroll
+        for(int g = 1; g < NG; ++g) r0 = fminf(r0, gm[g]);
+        int gs = 0, ng = 0;
+#pragma unroll
+        for(int g = 0; g < NG; ++g) { const bool eq = gm[g] == r0; gs = eq ? g : gs; ng += eq ? 1 : 0; }
+        const float* const grp = &L.rho[0][lane] + gs * (8 * 64);
+        float v[8];
+#pragma unroll
+        for(int j = 0; j < 8; ++j) v[j] = grp[j * 64];
+        int sj = 0, nin = 0;
+#pragma unroll
+        for(int j = 0; j < 8; ++j) { const bool eq = v[j] == r0; sj = eq ? j : sj; nin += eq ? 1 : 0; }
+        s0 = 8 * gs + sj;
+        multi = ng > 1 || nin > 1;
+    };
     if(__ballot(active) != 0ull) {
         const float sbin = 1.0f / sa_inv_s;
         int tby0 = (int)floorf((bmin_t - sa.bmin) * sa_inv_s), tby1 = (int)floorf((bmax_t - sa.bmin) * sa_inv_s);
@@ -311,21 +341,12 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                         }
                         else {
                             L.rho[ws][lane] = INFINITY;
-                            float rv[U_WCAP];
-#pragma unroll
-                            for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
-                            float r0 = INFINITY;
-#pragma unroll
-                            for(int w = 0; w < U_WCAP; ++w) r0 = fminf(r0, rv[w]);
-                            int s0 = 0, neq = 0;
-#pragma unroll
-                            for(int w = 0; w < U_WCAP; ++w) {
-                                const bool eq = rv[w] == r0;
-                                s0 = eq ? w : s0;
-                                neq += eq ? 1 : 0;
-                            }
+                            float r0;
+                            int s0;
+                            bool multi;
+                            worst_slot(r0, s0, multi);
                             wr = r0; ws = s0;
-                            if(neq > 1) {   // equal rho: the higher observation index is the worse one
+                            if(multi) {   // equal rho: the higher observation index is the worse one
                                 unsigned bo = 0u;
                                 for(unsigned long long mm = alloc; mm; mm &= mm - 1ull) {
                                     const int w = __builtin_ctzll(mm);
@@ -411,22 +432,13 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                 auto end_bulk = [&]() {   // worst kept entry of every cell after the bulk rings
                     bulk = false;
                     alloc = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
-                    float rv[U_WCAP];
-#pragma unroll
-                    for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
-                    float r0 = INFINITY;
-#pragma unroll
-                    for(int w = 0; w < U_WCAP; ++w) r0 = fminf(r0, rv[w]);
-                    int s0 = 0, neq = 0;
-#pragma unroll
-                    for(int w = 0; w < U_WCAP; ++w) {
-                        const bool eq = rv[w] == r0;
-                        s0 = eq ? w : s0;
-                        neq += eq ? 1 : 0;
-                    }
+                    float r0;
+                    int s0;
+                    bool multi;
+                    worst_slot(r0, s0, multi);
                     wr = r0; ws = s0;
                     wo = (unsigned)L.worig[s0];
-                    if(cnt > 0 && neq > 1) {   // equal rho: the higher observation index is the worse one
+                    if(cnt > 0 && multi) {   // equal rho: the higher observation index is the worse one
                         unsigned bo = 0u;
                         for(unsigned long long mm = alloc; mm; mm &= mm - 1ull) {
                             const int w = __builtin_ctzll(mm);
