@@ -373,13 +373,13 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
     unsigned long long (*keys)[64] = s_keys[wid];
 
     int cnt = 0;
-    if(__ballot(active) != 0ull) {
+    if(wave_ballot(active) != 0ull) {
         const int K = a.s.K;
         bool overflow, truncated;
         DevStructure cst = a.s.st;   // this lane's structure: uniform, or the parameters at its grid point
         if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
         cnt = scan_tile<N, false, PLAIN, PLAIN && !LU && !SPATIAL, true>(a.s, cst, active, gx, gy, gz, ge, gl, keys, lane, overflow, truncated);
-        if(__ballot(overflow) != 0ull) {   // more usable observations than the register tile holds: left to k_oi_big
+        if(wave_ballot(overflow) != 0ull) {   // more usable observations than the register tile holds: left to k_oi_big
             if(a.big_list) { if(overflow) a.big_list[atomicAdd(a.big_count, 1)] = cell; }
             else if(lane == 0) atomicOr(a.err, ERR_OVERFLOW);
             cnt = overflow ? 0 : cnt;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
         }
 
         // ---- dense solves: one augmented Cholesky per DISTINCT observation set -----------------------------------
-        unsigned long long todo = __ballot(cnt > 0);
+        unsigned long long todo = wave_ballot(cnt > 0);
         if(GPP_DBG(a, 1)) todo = 0ull;   // GPP_OI_DEBUG bit0: skip the solves (timing experiments only)
         const int nupd = __popcll(todo);
         int nsolve = 0;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
                         // (as a butterfly of ds_bpermute pairs the search was 18 trips through the LDS crossbar per column)
                         const double av = (lane < n && mystep == 64) ? fabs(rowT[j]) : -1.0;
                         const double amax = wave_max_d(av);
-                        const int piv = (int)__builtin_ctzll(__ballot(av == amax) | (1ull << 63));
+                        const int piv = (int)__builtin_ctzll(wave_ballot(av == amax) | (1ull << 63));
                         if(!(amax > 0.0)) bad = true;                      // exactly singular (arma::inv throws)
                         const double pjj = readlane_d(rowT[j], piv);
                         const bool elim = lane < n && mystep == 64 && lane != piv;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
 #pragma unroll
                     for(int j = 0; j < N; ++j) {                           // forward: L y = (permuted) d
                         if(j < n) {
-                            const int piv = __builtin_ctzll(__ballot(mystep == j));
+                            const int piv = __builtin_ctzll(wave_ballot(mystep == j));
                             const double bp = readlane_d(bvec, piv);
                             if(lane < n && mystep > j) bvec = __builtin_fma(-rowT[j], bp, bvec);
                         }
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
 #pragma unroll
                     for(int j = N - 1; j >= 0; --j) {                      // backward: U z = y; every member cell adds g_j z_j
                         if(j < n) {
-                            const int piv = __builtin_ctzll(__ballot(mystep == j));
+                            const int piv = __builtin_ctzll(wave_ballot(mystep == j));
                             const double zj = readlane_d(bvec, piv) * readlane_d(mypinv, piv);
                             if(lane < n && mystep < j) bvec = __builtin_fma(-rowT[j], zj, bvec);
                             incv = __builtin_fma(zj, (double)colbuf[j][lane], incv);   // corr_background(cell, obs j) * z_j   (oi.cpp:296,316)
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
 #pragma unroll
                     for(int j = 0; j < N; ++j) {                           // forward: L y = P g
                         if(j < n) {
-                            const int piv = __builtin_ctzll(__ballot(mystep == j));
+                            const int piv = __builtin_ctzll(wave_ballot(mystep == j));
                             const double bp = readlane_d(bvec, piv);
                             if(lane < n && mystep > j) bvec = __builtin_fma(-rowT[j], bp, bvec);
                         }
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
 #pragma unroll
                     for(int j = N - 1; j >= 0; --j) {                      // backward: U k = y
                         if(j < n) {
-                            const int piv = __builtin_ctzll(__ballot(mystep == j));
+                            const int piv = __builtin_ctzll(wave_ballot(mystep == j));
                             const double xj = readlane_d(bvec, piv) * readlane_d(mypinv, piv);
                             if(lane < n && mystep < j) bvec = __builtin_fma(-rowT[j], xj, bvec);
                             inc = __builtin_fma(xj, readlane_d(dmine, j), inc);    // k . (lObs - lY)   (oi.cpp:316)
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
             const int n = __builtin_amdgcn_readlane(cnt, l);
             const unsigned long long l1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h1 >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h1, l);
             const unsigned long long l2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(h2s >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)h2s, l);
-            unsigned long long members = __ballot(cnt == n && h1 == l1 && h2s == l2) & todo;
+            unsigned long long members = wave_ballot(cnt == n && h1 == l1 && h2s == l2) & todo;
             // at most MEMB members ride along as G rows; with the 62-row tile (MEMB = 1) the other cells of the group reuse the
             // factor through forward substitutions (Cholesky path), otherwise they form the next pass
             int nm = __popcll(members);
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, (N <= 32 ? 2 : 1)) void k_oi(OiArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if(cnt > 0) { res_out = s_res[wid][0][lane]; res_var = s_res[wid][1][lane]; }
-        if(__ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
+        if(wave_ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
         if(lane == 0 && a.counters) {
             unsigned long long* cs = a.counters + 80 + 2 * (blockIdx.x % GPP_NSLOT);
             atomicAdd(&cs[0], (unsigned long long)nupd);
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256, PLAIN ? 4 : 3) void k_oi_pairs(OiArgs a) {   /
         if(c < a.C) cell = c;
     }
     const int n = cell >= 0 ? a.pair_n[cell] : 0;
-    unsigned long long singles = __ballot(n > 0);
+    unsigned long long singles = wave_ballot(n > 0);
     if(singles == 0ull) return;
     bool bad = false;
     const int nsolve = __popcll(singles);
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256, PLAIN ? 4 : 3) void k_oi_pairs(OiArgs a) {   /
         a.out[cell] = s_res[wid][0][lane];
         if(a.out_var) a.out_var[cell] = s_res[wid][1][lane];
     }
-    if(__ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
+    if(wave_ballot(bad) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
     if(lane == 0 && a.counters) atomicAdd(&a.counters[80 + 2 * (blockIdx.x % GPP_NSLOT) + 1], (unsigned long long)nsolve);
 }
 

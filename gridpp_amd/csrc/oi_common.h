@@ -158,10 +158,11 @@ __device__ __forceinline__ double d_exp_nonpos(double x) {
 __device__ __forceinline__ float d_div_by(float dist, double rlen) { return (float)((double)dist * rlen); }
 // d_barnes_rho for a valid, non-zero length, without divergent branches (same values; NaN dist gives NaN)
 __device__ __forceinline__ float d_barnes_rho_flat(float dist, double rlen) {
-    const float v = d_div_by(dist, rlen);
+    // (|v| cut at 15: exp(-112.5) = 1e-49 is 0 in float32 like everything below exp(-103.98) -- one float32 minimum instead of a double
+    //  maximum in front of the exp and a compare + select behind it)
+    const float v = fminf(fabsf(d_div_by(dist, rlen)), 15.0f);
     const double e = -0.5 * (double)v * (double)v;
-    const float r = (float)d_exp_core(fmax(e, -110.0));
-    return e < -110.0 ? 0.0f : r;
+    return (float)d_exp_core(e);
 }
 __device__ __forceinline__ float d_barnes_rho(float dist, float length) {
     if(!d_valid(length) || length == 0) return 1.0f;
@@ -292,6 +293,9 @@ __device__ __forceinline__ float d_corr(const DevStructure& s, float x1, float y
     return d_corr_x<false>(s, x1, y1, z1, e1, l1, x2, y2, z2, e2, l2, background);
 }
 
+// mask of the lanes where p holds: the compare's own scalar mask (HIP's __ballot goes through a 0 / 1 vector and a second compare:
+// two vector instructions per ballot, and a tile of k_oi_union asks for more than a hundred)
+__device__ __forceinline__ unsigned long long wave_ballot(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ double readlane_d(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -556,7 +560,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                 pm |= pass ? (1ull << c) : 0ull;
             }
             // Pass B
-            while(__ballot(pm != 0ull) != 0ull) {
+            while(wave_ballot(pm != 0ull) != 0ull) {
                 const bool has = pm != 0ull;
                 const int c = has ? __builtin_ctzll(pm) : 0;
                 pm &= pm - 1ull;
@@ -567,7 +571,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                 const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
                 float d2 = dx * dx + dy * dy;
                 d2 = d2 + dz * dz;
-                if(a.scan_stats && __ballot(has && d2 <= thr2) != 0ull && lane == 0) atomicAdd(&a.scan_stats[1], 1ull);
+                if(a.scan_stats && wave_ballot(has && d2 <= thr2) != 0ull && lane == 0) atomicAdd(&a.scan_stats[1], 1ull);
                 if(has && d2 <= thr2) {
                     const bool inbox = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
                     const float dist = d_sqrt_cr(d2);
@@ -584,7 +588,7 @@ __device__ __forceinline__ int scan_tile(const ScanArgs& a, const DevStructure& 
                             if(d_valid(gl) && d_valid(ol)) rho *= d_rho_x<TAB>(st.kw, gl - ol, st.w);
                         }
                         const bool ins_ = rho > 0.0f && (cnt < K || (((unsigned long long)__float_as_uint(rho) << 32) | 0xffffffffull) > wkey);
-                        if(a.scan_stats && __ballot(ins_) != 0ull) nins++;
+                        if(a.scan_stats && wave_ballot(ins_) != 0ull) nins++;
                         if(rho > 0.0f) {   // oi.cpp:253
                             const unsigned long long key = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~orig);
                             if(cnt < K) {

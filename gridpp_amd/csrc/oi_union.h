@@ -210,7 +210,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
 #pragma unroll
         for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
 #pragma unroll
-        for(int w = 0; w < U_WCAP; ++w) if(__ballot(rv[w] < INFINITY) != 0ull) live |= 1ull << w;
+        for(int w = 0; w < U_WCAP; ++w) if(wave_ballot(rv[w] < INFINITY) != 0ull) live |= 1ull << w;
         return live;
     };
     // The worst kept entry of this lane: smallest rho r0, a slot s0 that holds it, and whether more than one slot does.  Two levels --
@@ -243,7 +243,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         s0 = 8 * gs + sj;
         multi = ng > 1 || nin > 1;
     };
-    if(__ballot(active) != 0ull) {
+    if(wave_ballot(active) != 0ull) {
         const float sbin = 1.0f / sa_inv_s;
         int tby0 = (int)floorf((bmin_t - sa.bmin) * sa_inv_s), tby1 = (int)floorf((bmax_t - sa.bmin) * sa_inv_s);
         tby0 = __builtin_amdgcn_readfirstlane(min(max(tby0, 0), sa.nby - 1));
@@ -292,7 +292,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             // |gz| + R) gives |ox - gx| <= dist (1 + 2^-22) < R - 2^-24 (|gx| + R) <= the distance of either rounded corner, on every axis.
             // The six compares are made only when some cell of the wave holds a candidate that close to R (pruning by the worst kept rho
             // keeps the candidates far inside: never on the headline workload).
-            if(__ballot(ok && dist > near_r) != 0ull) ok = ok && ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+            if(wave_ballot(ok && dist > near_r) != 0ull) ok = ok && ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
             float rho = 0.0f;
             if constexpr(PLAIN) {
                 rho = hh ? d_barnes_rho_flat(dist, rh) : 1.0f;
@@ -325,10 +325,10 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                 const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
                 // oi.cpp:253 (rho > 0) and :262-273 (keep the max_points largest, ties -> lower observation index)
                 const bool want = rho > 0.0f && (cnt < K || rho > wr || (rho == wr && orig < wo));
-                if(__ballot(want) != 0ull) {
+                if(wave_ballot(want) != 0ull) {
                     if(alloc == FULL) alloc = live_mask();   // free the slots no cell holds any more
                     if(UNION_STATS && lane == 0) atomicAdd(&a.counters[9], 1ull);
-                    if(UNION_STATS && __ballot(want && cnt >= K) != 0ull && lane == 0) atomicAdd(&a.counters[10], 1ull);
+                    if(UNION_STATS && wave_ballot(want && cnt >= K) != 0ull && lane == 0) atomicAdd(&a.counters[10], 1ull);
                     if(alloc == FULL) { fb = true; if(UNION_STATS && lane == 0) atomicAdd(&a.counters[4], 1ull); return; }
                     const int slot = __builtin_ctzll(~alloc);
                     alloc |= 1ull << slot;
@@ -458,7 +458,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                     float thi = sa.ring_r0 * sa.ring_r0;   // 1.5 x the expected distance of the max_points-th nearest observation
                     const float lim2 = wave_lim2();
                     thi = fminf(thi, lim2);
-                    auto count_le = [&](const float t) { return __popcll(__ballot(pd0 <= t)) + __popcll(__ballot(pd1 <= t)) + __popcll(__ballot(pd2 <= t)); };
+                    auto count_le = [&](const float t) { return __popcll(wave_ballot(pd0 <= t)) + __popcll(wave_ballot(pd1 <= t)) + __popcll(wave_ballot(pd2 <= t)); };
                     if(count_le(thi) <= kb) tlo = thi;
                     else {
                         for(int it = 0; it < 9; ++it) {
@@ -472,9 +472,9 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                     const float hi2 = ring < 0 ? tlo : ((ring == NR - 1) ? INFINITY : hi * hi);
                     const float lim2 = wave_lim2();
                     if(lim2 < 0.0f || lo2 >= lim2) break;
-                    const unsigned long long m0 = __ballot(pd0 > lo2 && pd0 <= hi2 && pd0 <= lim2);
-                    const unsigned long long m1 = __ballot(pd1 > lo2 && pd1 <= hi2 && pd1 <= lim2);
-                    const unsigned long long m2 = __ballot(pd2 > lo2 && pd2 <= hi2 && pd2 <= lim2);
+                    const unsigned long long m0 = wave_ballot(pd0 > lo2 && pd0 <= hi2 && pd0 <= lim2);
+                    const unsigned long long m1 = wave_ballot(pd1 > lo2 && pd1 <= hi2 && pd1 <= lim2);
+                    const unsigned long long m2 = wave_ballot(pd2 > lo2 && pd2 <= hi2 && pd2 <= lim2);
                     if(ring >= 0 && bulk) end_bulk();
                     for(int k = 0; k < nchunk && !fb; ++k) {
                         const float4 rec = k == 0 ? rec0 : (k == 1 ? rec1 : rec2);
@@ -540,7 +540,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                     float2 met = make_float2(NAN, 0);
                     float pd = INFINITY;
                     if(mine < je) { rec = sa.pgeo[mine]; met = sa.smeta[mine]; pd = proj_d2(rec); }
-                    run_chunk(rec, met, mine, __ballot(pd <= lim2));
+                    run_chunk(rec, met, mine, wave_ballot(pd <= lim2));
                 }
             }
         }
@@ -548,7 +548,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
 
     UPROF(4);   // phase 2
     // ================= classification: union, core, extras ========================================================
-    const unsigned long long upd = __ballot(cnt > 0);
+    const unsigned long long upd = wave_ballot(cnt > 0);
     unsigned long long coreM = 0ull, extM = 0ull;
     int c = 0, nE = 0, u = 0;
     int m = 0;             // this cell's extras: count and their indices (4 bits each)
@@ -559,7 +559,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
 #pragma unroll
         for(int w = 0; w < U_WCAP; ++w) {
-            const unsigned long long mk = __ballot(rv[w] < INFINITY) & upd;
+            const unsigned long long mk = wave_ballot(rv[w] < INFINITY) & upd;
             if(mk == upd) coreM |= 1ull << w;
             else if(mk != 0ull) extM |= 1ull << w;
         }
@@ -575,7 +575,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                 const int w = __builtin_ctzll(mm);
                 if(L.rho[w][lane] < INFINITY) { elist |= (unsigned)ai << (4 * (m & 7)); m++; }
             }
-            if(__ballot(m > U_MAXM) != 0ull) { fb = true; if(UNION_STATS && lane == 0) atomicAdd(&a.counters[8], 1ull); }
+            if(wave_ballot(m > U_MAXM) != 0ull) { fb = true; if(UNION_STATS && lane == 0) atomicAdd(&a.counters[8], 1ull); }
         }
     }
     if(fb) {
@@ -822,7 +822,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             res_out = bg + increment;                               // oi.cpp:335
             res_var = (float)((double)bvar * (1.0 - a00));          // oi.cpp:337
         }
-        if(__ballot(bad && cnt > 0) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
+        if(wave_ballot(bad && cnt > 0) != 0ull && lane == 0) atomicOr(a.err, ERR_SINGULAR);
         if(lane == 0 && a.counters) {
             unsigned long long* cs = a.counters + 80 + 2 * (blockIdx.x % GPP_NSLOT);
             atomicAdd(&cs[0], (unsigned long long)__popcll(upd));

@@ -46,9 +46,8 @@ def terrain(lat, lon):
     return z, laf
 
 
-def oi_case(name, ny, nx, S, mp, seed, elev=False, reps=3):
-    import torch
-    import gridpp_amd as gridpp
+def oi_inputs(ny, nx, S, seed, elev=False):
+    """the OI workload with its terrain variant: (lats, lons, bg, plat, plon, obs, ratios, pbg, ge, gl, pe, pl, v, w)"""
     lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, S, seed, 0, ny)
     rng = np.random.default_rng(seed + 7)
     ge = gl = pe = pl = ()
@@ -62,6 +61,13 @@ def oi_case(name, ny, nx, S, mp, seed, elev=False, reps=3):
         pe, pl = terrain(np.deg2rad(plat) * 40, np.deg2rad(plon) * 40)
         pe = pe + rng.normal(0, 30, S)   # stations are not exactly on the model terrain
         v, w = 200, 0.5
+    return lats, lons, bg, plat, plon, obs, ratios, pbg, ge, gl, pe, pl, v, w
+
+
+def oi_case(name, ny, nx, S, mp, seed, elev=False, reps=3):
+    import torch
+    import gridpp_amd as gridpp
+    lats, lons, bg, plat, plon, obs, ratios, pbg, ge, gl, pe, pl, v, w = oi_inputs(ny, nx, S, seed, elev)
     grid = gridpp.Grid(lats, lons, ge, gl)
     points = gridpp.Points(plat, plon, pe, pl)
     st = gridpp.BarnesStructure(10000, v, w)
