@@ -1256,7 +1256,25 @@ def optimal_interpolation_ensi(bgrid, background, points, pobs, psigmas, pbackgr
     check(lib().gpp_optimal_interpolation_ensi(bgrid._h, _ptr(background), int(E), points._h, _ptr(pobs), _ptr(psigmas),
                                                _ptr(pbackground), _structure(structure), int(max_points),
                                                int(bool(allow_extrapolation)), _ptr(out), mem))
+    _ensi_warnings()
     return out
+
+
+def ensi_last_stats():
+    """cells, the grid points the last optimal_interpolation_ensi left at their background values (singular / non-finite E x E system:
+    the reference's num_condition_warning, oi_ensi.cpp:153,386-390), its second counter (always 0 here) and the kernel time"""
+    s = _capi.gpp_ensi_stats()
+    check(lib().gpp_ensi_last_stats(C.byref(s)))
+    return dict(cells=s.cells, condition_passthrough=s.condition_passthrough, real_part_passthrough=s.real_part_passthrough, kernel_ms=s.kernel_ms)
+
+
+def _ensi_warnings():
+    """the two warnings the reference prints at the end of optimal_interpolation_ensi (oi_ensi.cpp:557-566)"""
+    s = ensi_last_stats()
+    if s["condition_passthrough"] > 0:
+        warning("Condition number error in %d points. Using raw values in those points." % s["condition_passthrough"])
+    if s["real_part_passthrough"] > 0:
+        warning("Could not find the real part of W in %d points. Using raw values in those points." % s["real_part_passthrough"])
 
 
 def _ensi_multi(variant, name, bgrid, bratios, background, background_corr, points, pobs, pratios, pbackground, pbackground_corr,

@@ -24,6 +24,10 @@ class gpp_oi_stats(C.Structure):
                 ("fallback_tiles", C.c_longlong), ("kernel_ms", C.c_float), ("union_kernel_ms", C.c_float), ("fallback_subtiles", C.c_longlong), ("big_cells", C.c_longlong)]
 
 
+class gpp_ensi_stats(C.Structure):
+    _fields_ = [("cells", C.c_longlong), ("condition_passthrough", C.c_longlong), ("real_part_passthrough", C.c_longlong), ("kernel_ms", C.c_float)]
+
+
 _lib = None
 fp = C.POINTER(C.c_float)
 ip = C.POINTER(C.c_int)
@@ -73,6 +77,7 @@ SIGNATURES = {
     "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
     "gpp_optimal_interpolation_ensi": [vp, vp, C.c_int, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],
     "gpp_ensi_last_kernel_ms": [fp],
+    "gpp_ensi_last_stats": [C.POINTER(gpp_ensi_stats)],
     "gpp_ensi_set_convergence": [C.c_int],
     "gpp_active_overrides": [C.c_char_p, C.c_int],
     "gpp_release_workspaces": [],

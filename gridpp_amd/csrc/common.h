@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -28,8 +29,13 @@ int fail(int code, const char* fmt, ...);
             throw gpp::Error{GPP_ERUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)};     \
     } while(0)
 
-// Wrap the body of every extern "C" entry point: no exception crosses the ABI.
-#define GPP_TRY try {
+// Wrap the body of every extern "C" entry point: no exception crosses the ABI, and ONE call runs at a time.  The reference's objects
+// are immutable and its queries const, so it may be called from several host threads at once (src/api/oi.cpp:221-233 does so itself);
+// here the handles carry lazily built state (device copies, the observation index, the memo of the last OI call) and every call
+// goes to the one library stream, so the library serialises the calls itself (a recursive lock: entry points call each other).
+// Workspaces, statistics and the error message are per thread.  tests/test_gpu_threads.py.
+std::recursive_mutex& api_mutex_ref();
+#define GPP_TRY try { std::lock_guard<std::recursive_mutex> gpp_api_lock_(gpp::api_mutex_ref());
 #define GPP_CATCH                                                             \
     }                                                                         \
     catch(const gpp::Error& e) { gpp::set_error(e.msg.c_str()); return e.code; } \
@@ -161,7 +167,7 @@ struct gpp_points {
     // memo of the last OI call with this point set as the background: did k_oi_union pay? (same observations handle and
     // structure scales -> same geometry -> same answer; the observation VALUES do not matter)
     // (keyed on the observation set's serial number, not its address: a new handle may reuse the address of a destroyed one)
-    struct { unsigned long long points_id = 0; float h = 0, v = 0, w = 0; int kh = -1, kv = -1, kw = -1, cv = -1; int max_points = -1; float declined = 0; int leftover = -1; } union_memo;   // (leftover: 4-cell items the last call left to k_oi)
+    struct { unsigned long long points_id = 0; float h = 0, v = 0, w = 0; int kh = -1, kv = -1, kw = -1, cv = -1; int max_points = -1; float declined = 0; int leftover = -1; int n1 = 0; } union_memo;   // (leftover: 4-cell items the last call left to k_oi; n1: tiles its first pass declined)
     unsigned long long serial = 0;   // unique per handle, assigned at creation
     gpp_obs_index* obs_index = nullptr;
     gpp_nn_index* nn_index = nullptr;

@@ -79,6 +79,15 @@ __global__ void k_ensi_obs_prep(const float* __restrict__ pbg, int S, int E, con
         gY[(long)s * nV + k] = (d_valid(v) && d_valid(mean)) ? v - mean : v;
     }
 }
+// cells that found at least one usable observation (k_ensi_scan's meta: the count in the low byte): what the reference counts as
+// "condition number error" when fewer than two members are valid (Pinv is the zero matrix: rcond <= 0, oi_ensi.cpp:386-390)
+__global__ void k_ensi_count_cells(const unsigned* __restrict__ meta, long n, unsigned long long* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    for(; i < n; i += (long)gridDim.x * blockDim.x) c += (meta[i] & 0xffu) ? 1ull : 0ull;
+    for(int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
 __global__ void k_copy(const float* __restrict__ in, long n, float* __restrict__ out) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) out[i] = in[i];
@@ -136,609 +145,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-template <bool SPATIAL>
-__global__ __launch_bounds__(64) void k_ensi(EnsiArgs a) {
-    // 26 KB per wave -> 6 waves per CU: the 16 KB of scan keys are only needed until the selections are parked in HBM
-    // (a.sel, 8 KB per tile, read back one column per cell), after that B and U take their place
-    __shared__ union {
-        unsigned long long keys[EN][64];
-        struct { double B[EN * BP]; double U[EN * BP]; } m;
-    } s_un;
-    __shared__ float s_Yt[EN][64];                        // Y tile of the current cell
-    unsigned long long (*s_keys)[64] = s_un.keys;
-    double* const s_B = s_un.m.B;                         // B, later M_W
-    double* const s_U = s_un.m.U;
-    __shared__ double s_sD[EN], s_r[EN], s_z[EN], s_S[EN], s_t[EN], s_dw[EN];
-    __shared__ double s_rot[2 * (EN / 2)];
-    __shared__ int s_pq[2 * (EN / 2)];
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
-
-    int cell = -1;
-    if(a.tiled2d) {
-        int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        int y = ty * (64 >> a.wshift) + (lane >> a.wshift), x = (tx << a.wshift) + (lane & ((1 << a.wshift) - 1));
-        if(y < a.ny && x < a.nx) cell = y * a.nx + x;
-    }
-    else {
-        int c = tile * 64 + lane;
-        if(c < a.C) cell = c;
-    }
-    float gx = 0, gy = 0, gz = 0, ge = NAN, gl = NAN;
-    if(cell >= 0) { gx = a.gx[cell]; gy = a.gy[cell]; gz = a.gz[cell]; ge = a.gelev[cell]; gl = a.glaf[cell]; }
-    const bool active = cell >= 0;   // no background validity test here (oi_ensi.cpp:207-213)
-    if(__ballot(active) == 0ull) return;
-    const int nV = a.nV, E = a.E;
-
-    bool overflow, truncated;
-    DevStructure cst = a.s.st;
-    if(SPATIAL && cell >= 0) d_structure_at(cst, cst.cell_idx ? cst.cell_idx[cell] : cell);
-    int cnt = scan_tile<EN, true>(a.s, cst, active, gx, gy, gz, ge, gl, s_keys, lane, overflow, truncated);
-    if(__ballot(overflow) != 0ull) {   // more usable observations than the 32-row tile holds: those cells go to k_ensi_big
-        if(a.big_list) { if(overflow) a.big_list[atomicAdd(a.big_count, 1)] = cell; }
-        else if(lane == 0) atomicOr(a.err, 1);
-        cnt = overflow ? 0 : cnt;
-    }
-    // park the selections (observation indices) of the 64 cells in HBM: sel[tile][slot][lane]
-    unsigned* const sel = a.sel + (size_t)tile * EN * 64;
-    double* const gram = a.gram + (size_t)tile * EN * EN;
-    float (*Yt)[64] = s_Yt;
-    unsigned long long hsig = 0;   // order-independent signature of this lane's selection
-    for(int s = 0; s < a.s.K; ++s) {
-        const unsigned o = ~(unsigned)(s_keys[s][lane] & 0xffffffffull);
-        sel[s * 64 + lane] = o;
-        unsigned long long x = (unsigned long long)o + 0x9e3779b97f4a7c15ull;
-        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-        if(s < cnt) hsig += x;
-    }
-    __threadfence();
-    __syncthreads();
-
-    const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
-    const double sqc = sqrt(c);
-    // Cells that selected the same observations are visited back to back: their B matrices differ only by the diagonal
-    // scaling with rho, so the eigenvectors of one cell are an excellent starting basis for the next (warm start below).
-    unsigned long long todo = __ballot(cnt > 0);
-    int ndone = 0, nsweeps = 0;
-    unsigned long long cur_h = 0; int cur_n = -1;
-    unsigned prev_orig = 0xffffffffu; int prev_n = -1;   // sorted selection of the previous cell (lane i = i-th observation)
-    while(todo) {
-        unsigned long long grp = __ballot(cnt == cur_n && hsig == cur_h) & todo;
-        if(grp == 0ull) {
-            const int l0 = __builtin_ctzll(todo);
-            cur_n = __builtin_amdgcn_readlane(cnt, l0);
-            cur_h = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hsig >> 32), l0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)hsig, l0);
-            grp = __ballot(cnt == cur_n && hsig == cur_h) & todo;
-        }
-        const int l = __builtin_ctzll(grp);
-        todo &= ~(1ull << l);
-        const int n = __builtin_amdgcn_readlane(cnt, l);
-        if(nV <= 1) continue;   // Pinv is the zero matrix: rcond <= 0 -> raw values (oi_ensi.cpp:386-390)
-        ndone++;
-        const int cell_l = __builtin_amdgcn_readlane(cell, l);
-        const float cx = readlane_f(gx, l), cy = readlane_f(gy, l), cz = readlane_f(gz, l), ce = readlane_f(ge, l), cl = readlane_f(gl, l);
-        // ---- per-observation quantities (lane i < n) ----------------------------------------------------------
-        // rows in ascending observation index: a canonical order, so that equal selections give equal row orders
-        unsigned orig_i = (lane < n) ? __hip_atomic_load(&sel[lane * 64 + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-        {
-            int rank = 0;
-            for(int j = 0; j < n; ++j) rank += ((unsigned)__builtin_amdgcn_readlane((int)orig_i, j) < orig_i) ? 1 : 0;
-            if(lane < n) s_pq[rank] = (int)orig_i;
-            __syncthreads();
-            orig_i = (lane < n) ? (unsigned)s_pq[lane] : 0u;
-            __syncthreads();
-        }
-        const bool warm = n > 1 && n == prev_n && __ballot(lane < n && orig_i != prev_orig) == 0ull;   // s_U still holds the previous cell's eigenvectors
-        prev_n = n; prev_orig = orig_i;
-        float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 1);
-        if(lane < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
-        DevStructure lst = a.s.st;
-        if(SPATIAL) { lst.h = readlane_f(cst.h, l); lst.v = readlane_f(cst.v, l); lst.w = readlane_f(cst.w, l); lst.R = readlane_f(cst.R, l); }
-        const float rho = d_corr(lst, cx, cy, cz, ce, cl, o0.x, o0.y, o0.z, o0.w, o1.x, true);   // :227
-        const float sig2 = o1.w * o1.w;                                    // float product (:300)
-        const double D = (double)rho / (double)sig2;                       // Rinv(i,i)
-        const double sD = sqrt(D);
-        const double dobs = (double)o1.y - (double)o1.z;                   // lObs - lYhat (:437)
-        if(lane < n) { s_sD[lane] = sD; s_r[lane] = sD * dobs; }
-        // ---- Y tile: Yt[i][k] = gY[obs_i][k] (coalesced over k) -----------------------------------------------
-        for(int i = 0; i < n; ++i) {
-            const unsigned oi = (unsigned)__builtin_amdgcn_readlane((int)orig_i, i);
-            Yt[i][lane] = (lane < nV) ? a.gY[(long)oi * nV + lane] : 0.0f;
-        }
-        for(int i = n; i < EN; ++i) Yt[i][lane] = 0.0f;   // rows beyond n are multiplied by q[i] = 0 below: keep them finite
-        __syncthreads();
-        // ---- B = (sD sD^T) o (Y Y^T), U = I ---------------------------------------------------------------------
-        for(int idx = lane; idx < n * n; idx += 64) {
-            const int i = idx / n, j = idx - i * n;
-            double acc = 0.0;
-            if(j <= i) {
-                // the Gram matrix Y Y^T depends on the selection only: computed by the first cell of a run of equal
-                // selections, parked in HBM, re-read by the others (B = (sD sD^T) o (Y Y^T) differs per cell through sD)
-                if(warm) acc = __hip_atomic_load(&gram[i * n + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else {
-                    if(!GPP_DBG(a, 4)) for(int k = 0; k < nV; ++k) acc = __builtin_fma((double)Yt[i][k], (double)Yt[j][k], acc);
-                    gram[i * n + j] = acc;
-                }
-                acc *= s_sD[i] * s_sD[j];
-                s_B[i * BP + j] = acc; s_B[j * BP + i] = acc;
-            }
-            if(!warm) s_U[i * BP + j] = (i == j) ? 1.0 : 0.0;
-        }
-        if(!warm) __threadfence();   // the Gram matrix must be visible to the other lanes when the next cell reads it
-        __syncthreads();
-        if(warm) {
-            // B <- U^T B U in place (U from the previous cell): nearly diagonal already, one or two sweeps finish it.
-            // T = B U, then B' = U^T T, both on the matrix cores (results held in registers until every operand is read).
-            {
-                const Acc32 t = mfma_32x32(lane, (n + 3) & ~3,
-                                           [&](int i, int k) { return (i < n && k < n) ? s_B[i * BP + k] : 0.0; },
-                                           [&](int k, int j) { return (k < n && j < n) ? s_U[k * BP + j] : 0.0; });
-                __syncthreads();
-                acc32_store(t, lane, n, s_B);
-                __syncthreads();
-                const Acc32 b = mfma_32x32(lane, (n + 3) & ~3,
-                                           [&](int i, int k) { return (i < n && k < n) ? s_U[k * BP + i] : 0.0; },
-                                           [&](int k, int j) { return (k < n && j < n) ? s_B[k * BP + j] : 0.0; });
-                __syncthreads();
-                acc32_store(b, lane, n, s_B);
-                __syncthreads();
-            }
-            // symmetrise (the two one-sided products round differently)
-            for(int idx = lane; idx < n * n; idx += 64) {
-                const int i = idx / n, j = idx - i * n;
-                if(j < i) { const double v = 0.5 * (s_B[i * BP + j] + s_B[j * BP + i]); s_B[i * BP + j] = v; s_B[j * BP + i] = v; }
-            }
-            __syncthreads();
-        }
-        // ---- cyclic Jacobi, round-robin ordering -----------------------------------------------------------------
-        const int m = n + (n & 1);
-        const int half = m >> 1;
-        double tr = 0.0;
-        for(int i = lane; i < n; i += 64) tr += fabs(s_B[i * BP + i]);
-        tr = wave_sum_d(tr);
-        // work items of one Jacobi step: (pair k, index t) for k < half, t < n -> at most 8 per lane; the mapping is
-        // fixed for the cell, so the integer divisions are done once
-        constexpr int IT = (EN / 2) * EN / 64;   // 8
-        int itk[IT], itt[IT];
-#pragma unroll
-        for(int it = 0; it < IT; ++it) {
-            const int idx = lane + 64 * it;
-            const int k = idx / n;
-            itk[it] = (idx < half * n) ? k : -1;
-            itt[it] = idx - k * n;
-        }
-        for(int sweep = 0; sweep < 30 && n > 1 && !GPP_DBG(a, 1); ++sweep) {
-            double off = 0.0;
-            for(int idx = lane; idx < n * n; idx += 64) { const int i = idx / n, j = idx - i * n; if(j < i) { double v = s_B[i * BP + j]; off += v * v; } }
-            off = wave_sum_d(off);
-            // off-diagonal norm < 1e-11 * trace: Jacobi converges quadratically, so the eigenvalues are good to ~1e-22 and the
-            // eigenvectors to ~1e-11 relative -- five orders below what a float32 output can show; one more sweep would only
-            // polish digits nobody reads (it was a third of the work of a warm-started cell)
-            if(!(off > 1e-22 * tr * tr)) break;
-            nsweeps++;
-            for(int step = 0; step < m - 1; ++step) {
-                if(lane < half) {
-                    int p, q;
-                    if(lane == 0) { p = m - 1; q = step; }
-                    else { p = (step + lane) % (m - 1); q = (step - lane + (m - 1)) % (m - 1); }
-                    if(p > q) { int t = p; p = q; q = t; }
-                    double cs = 1.0, sn = 0.0;
-                    if(q < n) {
-                        const double apq = s_B[p * BP + q];
-                        if(apq != 0.0) {
-                            // rotation angle through v_rcp_f64 / v_rsq_f64 + Newton steps instead of the library division and
-                            // square roots (a third of the instructions; a rotation only has to be orthogonal, and
-                            // cs^2 + sn^2 = 1 holds to the accuracy of cs, the iteration corrects everything else)
-                            const double theta = (s_B[q * BP + q] - s_B[p * BP + p]) * 0.5 * d_rcp_nr(apq);
-                            const double h2 = theta * theta + 1.0;
-                            const double t = (theta >= 0 ? 1.0 : -1.0) * d_rcp_nr(fabs(theta) + h2 * d_rsq_nr(h2));
-                            cs = d_rsq_nr(t * t + 1.0); sn = t * cs;
-                            if(!(fabs(theta) < 1e150)) { cs = 1.0; sn = 0.0; }   // apq negligible against the diagonal gap (theta^2 would overflow)
-                        }
-                    }
-                    else q = p;   // dummy partner: identity
-                    s_rot[2 * lane] = cs; s_rot[2 * lane + 1] = sn;
-                    s_pq[2 * lane] = p; s_pq[2 * lane + 1] = q;
-                }
-                __syncthreads();
-                // this lane's rotations of the step
-                int ip[IT], iq[IT]; double ics[IT], isn[IT];
-#pragma unroll
-                for(int it = 0; it < IT; ++it) {
-                    const int k = itk[it] < 0 ? 0 : itk[it];
-                    ip[it] = s_pq[2 * k]; iq[it] = s_pq[2 * k + 1];
-                    ics[it] = s_rot[2 * k]; isn[it] = s_rot[2 * k + 1];
-                    if(itk[it] < 0) iq[it] = ip[it];   // no work
-                }
-                // columns: B <- B J, U <- U J   (all loads first, then the arithmetic, then the stores)
-                {
-                    double bx[IT], by[IT], ux[IT], uy[IT];
-#pragma unroll
-                    for(int it = 0; it < IT; ++it) {
-                        const int row = itt[it];
-                        bx[it] = s_B[row * BP + ip[it]]; by[it] = s_B[row * BP + iq[it]];
-                        ux[it] = s_U[row * BP + ip[it]]; uy[it] = s_U[row * BP + iq[it]];
-                    }
-#pragma unroll
-                    for(int it = 0; it < IT; ++it) {
-                        if(ip[it] != iq[it]) {
-                            const int row = itt[it];
-                            s_B[row * BP + ip[it]] = ics[it] * bx[it] - isn[it] * by[it]; s_B[row * BP + iq[it]] = isn[it] * bx[it] + ics[it] * by[it];
-                            s_U[row * BP + ip[it]] = ics[it] * ux[it] - isn[it] * uy[it]; s_U[row * BP + iq[it]] = isn[it] * ux[it] + ics[it] * uy[it];
-                        }
-                    }
-                }
-                __syncthreads();
-                // rows: B <- J^T B
-                {
-                    double bx[IT], by[IT];
-#pragma unroll
-                    for(int it = 0; it < IT; ++it) { const int col = itt[it]; bx[it] = s_B[ip[it] * BP + col]; by[it] = s_B[iq[it] * BP + col]; }
-#pragma unroll
-                    for(int it = 0; it < IT; ++it) {
-                        if(ip[it] != iq[it]) {
-                            const int col = itt[it];
-                            s_B[ip[it] * BP + col] = ics[it] * bx[it] - isn[it] * by[it]; s_B[iq[it] * BP + col] = isn[it] * bx[it] + ics[it] * by[it];
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        // ---- spectral functions -----------------------------------------------------------------------------------
-        if(lane < n) {
-            double S = s_B[lane * BP + lane];
-            if(S < 0.0) S = 0.0;
-            s_S[lane] = S;
-            const double rt = sqrt(c + S);
-            s_dw[lane] = -1.0 / (rt * (rt + sqc));      // W_sym = I + A^T U diag(dw) U^T A
-        }
-        __syncthreads();
-        // z = U diag(1/(c+S)) U^T r
-        double ur = 0.0;   // lane j: (U^T r)_j / (c + S_j)
-        if(lane < n) { for(int i = 0; i < n; ++i) ur = __builtin_fma(s_U[i * BP + lane], s_r[i], ur); ur /= (c + s_S[lane]); }
-        __syncthreads();
-        if(lane < n) s_t[lane] = ur;
-        __syncthreads();
-        if(lane < n) { double zz = 0.0; for(int j = 0; j < n; ++j) zz = __builtin_fma(s_U[lane * BP + j], s_t[j], zz); s_z[lane] = zz; }
-        // M_W = U diag(dw) U^T  -> overwrite B
-        __syncthreads();
-        {
-            const Acc32 mw = mfma_32x32(lane, GPP_DBG(a, 8) ? 0 : ((n + 3) & ~3),
-                                        [&](int i, int k) { return (i < n && k < n) ? s_U[i * BP + k] * s_dw[k] : 0.0; },
-                                        [&](int k, int j) { return (k < n && j < n) ? s_U[j * BP + k] : 0.0; });
-            __syncthreads();
-            acc32_store(mw, lane, n, s_B);
-        }
-        __syncthreads();
-        // ---- ensemble side: lane k < nV owns member k -----------------------------------------------------------------
-        const int ek = (lane < nV) ? a.validIdx[lane] : 0;
-        const float value = (lane < nV) ? a.bg[(long)cell_l * E + ek] : 0.0f;
-        float total = 0; int count = 0;                      // oi_ensi.cpp:447-461: sequential float sum
-        for(int k = 0; k < nV; ++k) { const float v = readlane_f(value, k); if(d_valid(v)) { total += v; count++; } }
-        const float ensMean = total / (float)count;
-        const double X = (double)value - (double)ensMean;
-        // w_k = sum_i sD_i Y_ik z_i ;  q_i = sD_i * (M_W A)_ik  (A_jk = sD_j Y_jk)
-        double wk = 0.0;
-        double q[EN];
-#pragma unroll
-        for(int i = 0; i < EN; ++i) q[i] = 0.0;
-        for(int j = 0; j < n; ++j) {
-            const double ajk = s_sD[j] * (double)Yt[j][lane];
-            wk = __builtin_fma(ajk, s_z[j], wk);
-#pragma unroll
-            for(int i = 0; i < EN; ++i) q[i] = __builtin_fma(s_B[j * BP + i], ajk, q[i]);   // M_W symmetric: row j
-        }
-#pragma unroll
-        for(int i = 0; i < EN; ++i) q[i] = (i < n) ? q[i] * s_sD[i] : 0.0;
-        // total_e = sum_k X_k W(k,e), float accumulation in k order (oi_ensi.cpp:505-511)
-        float acc = 0.0f;
-        for(int k = 0; k < nV && !GPP_DBG(a, 2); ++k) {
-            double wke = (k == lane) ? 1.0 : 0.0;
-#pragma unroll
-            for(int i = 0; i < EN; ++i) wke = __builtin_fma((double)Yt[i][k], q[i], wke);
-            wke += readlane_d(wk, k);
-            const double xk = readlane_d(X, k);
-            acc = (float)((double)acc + xk * wke);
-        }
-        float currIncrement = acc;
-        if(!a.allow_extrap) {   // oi_ensi.cpp:520-552; lY[e] is a LINEAR index into the n x nV column-major matrix,
-            // so it depends on the ORDER of the selected observations: rho descending when the reference sorted
-            // (more usable observations than max_points), candidate (= index) order otherwise.
-            const bool tr_l = (__ballot(truncated) >> l) & 1ull;
-            const unsigned long long okey = (tr_l ? ((unsigned long long)__float_as_uint(rho) << 32) : 0ull) | (unsigned)(~orig_i);
-            int rank = 0;
-            for(int j = 0; j < n; ++j) {
-                const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(okey >> 32), j) << 32) |
-                                              (unsigned)__builtin_amdgcn_readlane((int)okey, j);
-                rank += (kj > okey) ? 1 : 0;
-            }
-            int* perm = s_pq;   // rank -> lane (s_pq is free outside the Jacobi sweeps)
-            if(lane < n) perm[rank] = lane;
-            __syncthreads();
-            const int li = perm[lane % n], lk = lane / n;
-            const double lYe = (lane < nV) ? (double)Yt[li][lk] : 0.0;
-            float maxInc = -INFINITY, minInc = INFINITY;
-            for(int i = 0; i < n; ++i) {
-                const float ob = readlane_f(o1.y, i), yh = readlane_f(o1.z, i);
-                const float dv = (float)((double)ob - (lYe + (double)yh));
-                maxInc = fmaxf(maxInc, dv); minInc = fminf(minInc, dv);
-            }
-            const float memberIncrement = (float)((double)currIncrement - X);
-            if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + X);
-            else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + X);
-            else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + X);
-            else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + X);
-        }
-        if(lane < nV) a.out[(long)cell_l * E + ek] = ensMean + currIncrement;   // :553
-        __syncthreads();
-    }
-    if(lane == 0 && a.counters) { atomicAdd(&a.counters[1], (unsigned long long)ndone); atomicAdd(&a.counters[4 + (blockIdx.x & 31)], (unsigned long long)nsweeps); }
-}
 
 #include "ensi_pair.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_ensi_big: grid points with more than 32 usable observations (max_points == 0 or > 32).  One 256-thread workgroup per
-// cell, the E x E formulation the reference itself uses (oi_ensi.cpp:379-553), E <= 64 valid members, up to EBIG_N selected
-// observations.  With Pinv = Y^T R^-1 Y + c I = V D V^T (one cyclic Jacobi in LDS, c = E - 1):
-//     P = V D^-1 V^T,   sqrt(c P) = V diag(sqrt(c / D)) V^T,   w = P Y^T R^-1 d,   W = sqrt(c P) + w 1^T.
-// Slower per cell than the 32-row path by two orders of magnitude -- and still far from the reference's serial loop.
+// Grid points with more than 32 usable observations (max_points == 0 or > 32): one 256-thread workgroup per cell, the E x E formulation
+// the reference itself uses (oi_ensi.cpp:379-553), E <= 64 valid members.  (Round 1 diagonalised Pinv with a cyclic Jacobi in LDS --
+// `k_ensi_big`, like the LDS-resident tile kernel `k_ensi` taken out of the library in round 4; k_ensi_big_ns below replaced it.)
 #define EBIG_CAND 8192
 #define EP 65            // pitch of the 64 x 64 matrices (doubles)
-template <bool SPATIAL>
-__global__ __launch_bounds__(256) void k_ensi_big(EnsiArgs a) {
-    // one 65 KB area, three lives: candidate keys (sort) -> Y chunk + tables (Pinv build, Pinv itself in registers) -> B and V;
-    // two workgroups fit a CU
-    __shared__ double s_area[2 * 64 * EP];
-    unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(s_area);   // [EBIG_CAND]
-    double* const s_B = s_area;                       // Pinv, diagonalised in place; later W
-    double* const s_V = s_area + 64 * EP;             // eigenvectors
-    static_assert(sizeof(double) * 2 * 64 * EP >= sizeof(unsigned long long) * EBIG_CAND, "the key area must hold EBIG_CAND keys");
-    __shared__ double s_t[64], s_w[64], s_X[64], s_cs[32], s_sn[32];
-    __shared__ int s_p[32], s_q[32];
-    __shared__ double s_off[256];
-    __shared__ int s_n;
-    __shared__ float s_mm[2][64];
-    const int tid = threadIdx.x;
-    const ScanArgs& sa = a.s;
-    const int nV = a.nV, E = a.E;
-    const int nlist = *a.big_count;
-    unsigned long long* const gkeys = a.big_keys + (size_t)blockIdx.x * EBIG_CAND;
-    const double c = (double)((float)(nV - 1));       // oi_ensi.cpp:383 (float product, delta = 1)
-    for(int li = blockIdx.x; li < nlist; li += gridDim.x) {
-        const int cell = a.big_list[li];
-        const float gx = a.gx[cell], gy = a.gy[cell], gz = a.gz[cell], ge = a.gelev[cell], gl = a.glaf[cell];
-        DevStructure st = sa.st;   // spatially varying forms: the scales at this grid point (corr_background(p1 = grid point, .), structure.cpp:188-214)
-        if(SPATIAL) d_structure_at(st, st.cell_idx ? st.cell_idx[cell] : cell);
-        if(tid == 0) s_n = 0;
-        __syncthreads();
-        // ---- radius query + filter (valid observation, rho > 0: oi_ensi.cpp:213-237) -----------------------------------------
-        const float R = st.R;
-        const float pa = sa.axis_a == 0 ? gx : (sa.axis_a == 1 ? gy : gz), pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
-        const int bx0 = min(max((int)floorf((pa - R - sa.amin) * sa.inv_s) - 1, 0), sa.nbx - 1), bx1 = min(max((int)floorf((pa + R - sa.amin) * sa.inv_s) + 1, 0), sa.nbx - 1);
-        const int by0 = min(max((int)floorf((pb - R - sa.bmin) * sa.inv_s) - 1, 0), sa.nby - 1), by1 = min(max((int)floorf((pb + R - sa.bmin) * sa.inv_s) + 1, 0), sa.nby - 1);
-        const float lox = gx - R, hix = gx + R, loy = gy - R, hiy = gy + R, loz = gz - R, hiz = gz + R;
-        for(int by = by0; by <= by1; ++by) {
-            const int js = sa.bin_start[by * sa.nbx + bx0], je = sa.bin_start[by * sa.nbx + bx1 + 1];
-            for(int j = js + tid; j < je; j += 256) {
-                const float4 rec = sa.pgeo[j];   // x = NaN for an unusable observation: fails the box test
-                if(!(rec.x > lox && rec.x < hix && rec.y > loy && rec.y < hiy && rec.z > loz && rec.z < hiz)) continue;
-                const float2 met = sa.smeta[j];
-                if(!(d_chord(rec.x, rec.y, rec.z, gx, gy, gz) <= R)) continue;
-                const float rho = d_corr(st, gx, gy, gz, ge, gl, rec.x, rec.y, rec.z, rec.w, met.x, true);
-                if(!(rho > 0.0f)) continue;
-                const int k = atomicAdd(&s_n, 1);
-                if(k < EBIG_CAND) s_key[k] = ((unsigned long long)__float_as_uint(rho) << 32) | (unsigned)(~__float_as_int(met.y));
-            }
-        }
-        __syncthreads();
-        const int ncand = s_n;
-        const bool truncated = a.s.max_points > 0 && ncand > a.s.max_points;
-        const int n = truncated ? a.s.max_points : ncand;
-        if(ncand > EBIG_CAND) {   // more candidates than the LDS sort holds: k_ensi_huge takes the cell
-            if(tid == 0) a.huge_list[atomicAdd(a.big_count + 1, 1)] = cell;
-            __syncthreads();
-            continue;
-        }
-        // ---- order: rho descending (ties -> lower index) when the reference sorts (more candidates than max_points), candidate
-        //      (= index) order otherwise (oi_ensi.cpp:243-269); the order only matters for the clamp's lY[e] quirk and for rounding
-        int np2 = 1;
-        while(np2 < ncand) np2 <<= 1;
-        for(int i = ncand + tid; i < np2; i += 256) s_key[i] = 0ull;
-        __syncthreads();
-        for(int k = 2; k <= np2; k <<= 1) {
-            for(int j = k >> 1; j > 0; j >>= 1) {
-                for(int i = tid; i < np2; i += 256) {
-                    const int ixj = i ^ j;
-                    if(ixj > i) {
-                        const unsigned long long x = s_key[i], y = s_key[ixj];
-                        // truncated: whole key (rho, ~index) descending; otherwise ~index descending = index ascending
-                        const unsigned long long kx = truncated ? x : (x & 0xffffffffull), ky = truncated ? y : (y & 0xffffffffull);
-                        const bool desc = (i & k) == 0;
-                        if(desc ? (kx < ky) : (kx > ky)) { s_key[i] = y; s_key[ixj] = x; }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        for(int i = tid; i < n; i += 256) gkeys[i] = s_key[i];
-        __syncthreads();
-        // ---- Pinv = Y^T Rinv Y + c I, t = Y^T Rinv d, in chunks of 64 observations staged in LDS ------------------------------
-        float* const yc = reinterpret_cast<float*>(s_key);          // [64][64] Y chunk (member-major rows: yc[i * 64 + a])
-        double* const rinv = reinterpret_cast<double*>(yc + 64 * 64);   // [64]
-        double* const dvec = rinv + 64;                                 // [64]
-        double accP[16];
-#pragma unroll
-        for(int r = 0; r < 16; ++r) accP[r] = 0.0;
-        double acct = 0.0;
-        for(int i0 = 0; i0 < n; i0 += 64) {
-            const int m = min(64, n - i0);
-            __syncthreads();
-            for(int e = tid; e < m * 64; e += 256) {
-                const int i = e >> 6, k = e & 63;
-                const unsigned orig = ~(unsigned)(gkeys[i0 + i] & 0xffffffffull);
-                yc[i * 64 + k] = (k < nV) ? a.gY[(long)orig * nV + k] : 0.0f;
-            }
-            if(tid < m) {
-                const unsigned long long key = gkeys[i0 + tid];
-                const unsigned orig = ~(unsigned)(key & 0xffffffffull);
-                const float4 x4 = a.oaux[orig];                       // laf, obs, gYhat, sigma
-                const float s2 = x4.w * x4.w;                         // float product (oi_ensi.cpp:300)
-                rinv[tid] = (double)__uint_as_float((unsigned)(key >> 32)) / (double)s2;
-                dvec[tid] = (double)x4.y - (double)x4.z;
-            }
-            __syncthreads();
-            for(int r = 0; r < 16; ++r) {
-                const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
-                if(ai < nV && bi < nV) {
-                    double sacc = accP[r];
-                    for(int i = 0; i < m; ++i) sacc = __builtin_fma((double)yc[i * 64 + ai] * rinv[i], (double)yc[i * 64 + bi], sacc);
-                    accP[r] = sacc;
-                }
-            }
-            if(tid < nV) for(int i = 0; i < m; ++i) acct = __builtin_fma((double)yc[i * 64 + tid] * rinv[i], dvec[i], acct);
-        }
-        __syncthreads();
-        for(int r = 0; r < 16; ++r) {
-            const int e = tid + 256 * r, ai = e >> 6, bi = e & 63;
-            if(ai < nV && bi < nV) {
-                s_B[ai * EP + bi] = accP[r] + (ai == bi ? c : 0.0);
-                s_V[ai * EP + bi] = ai == bi ? 1.0 : 0.0;
-            }
-        }
-        if(tid < nV) s_t[tid] = acct;
-        __syncthreads();
-        // ---- cyclic Jacobi on the nV x nV matrix, round-robin pairs -----------------------------------------------------------
-        const int mm = nV + (nV & 1), half = mm >> 1;
-        double tr = 0.0;
-        if(tid < nV) tr = fabs(s_B[tid * EP + tid]);
-        s_off[tid] = tr;
-        __syncthreads();
-        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
-        tr = s_off[0];
-        __syncthreads();
-        for(int sweep = 0; sweep < 40 && nV > 1; ++sweep) {
-            double off2 = 0.0;
-            for(int e = tid; e < nV * nV; e += 256) { const int i = e / nV, j = e - i * nV; if(j < i) { const double v = s_B[i * EP + j]; off2 += v * v; } }
-            s_off[tid] = off2;
-            __syncthreads();
-            for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
-            off2 = s_off[0];
-            __syncthreads();
-            if(!(off2 > 1e-22 * tr * tr)) break;   // as in k_ensi: eigenvalues good to 1e-22, eigenvectors to 1e-11
-            for(int step = 0; step < mm - 1; ++step) {
-                if(tid < half) {
-                    int p, q;
-                    if(tid == 0) { p = mm - 1; q = step; }
-                    else { p = (step + tid) % (mm - 1); q = (step - tid + (mm - 1)) % (mm - 1); }
-                    if(p > q) { const int t_ = p; p = q; q = t_; }
-                    double cs = 1.0, sn = 0.0;
-                    if(q < nV) {
-                        const double apq = s_B[p * EP + q];
-                        if(apq != 0.0) {
-                            const double theta = (s_B[q * EP + q] - s_B[p * EP + p]) / (2.0 * apq);
-                            const double t_ = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                            cs = 1.0 / sqrt(t_ * t_ + 1.0); sn = t_ * cs;
-                            if(!(fabs(theta) < 1e150)) { cs = 1.0; sn = 0.0; }
-                        }
-                    }
-                    else q = p;
-                    s_p[tid] = p; s_q[tid] = q; s_cs[tid] = cs; s_sn[tid] = sn;
-                }
-                __syncthreads();
-                // 8 threads per pair (32 pairs at most), each owning the rows / columns r = (tid & 7) + 8 j
-                const int pk = tid >> 3;
-                const bool work = pk < half && s_p[pk] != s_q[pk];
-                const int p = work ? s_p[pk] : 0, q = work ? s_q[pk] : 0;
-                const double cs = work ? s_cs[pk] : 1.0, sn = work ? s_sn[pk] : 0.0;
-                // columns: B <- B J, V <- V J
-                if(work)
-                    for(int r = tid & 7; r < nV; r += 8) {
-                        const double bp = s_B[r * EP + p], bq = s_B[r * EP + q];
-                        const double vp = s_V[r * EP + p], vq = s_V[r * EP + q];
-                        s_B[r * EP + p] = cs * bp - sn * bq; s_B[r * EP + q] = sn * bp + cs * bq;
-                        s_V[r * EP + p] = cs * vp - sn * vq; s_V[r * EP + q] = sn * vp + cs * vq;
-                    }
-                __syncthreads();
-                // rows: B <- J^T B
-                if(work)
-                    for(int cidx = tid & 7; cidx < nV; cidx += 8) {
-                        const double bp = s_B[p * EP + cidx], bq = s_B[q * EP + cidx];
-                        s_B[p * EP + cidx] = cs * bp - sn * bq; s_B[q * EP + cidx] = sn * bp + cs * bq;
-                    }
-                __syncthreads();
-            }
-        }
-        // eigenvalues D_k = B_kk (>= c > 0 for a finite matrix); a non-finite or non-positive one is the reference's rcond <= 0
-        // passthrough (oi_ensi.cpp:386-390): the cell keeps its background values
-        bool singular = false;
-        if(tid < nV) { const double dk = s_B[tid * EP + tid]; singular = !(dk > 0.0) || isinf(dk); }
-        s_off[tid] = singular ? 1.0 : 0.0;
-        __syncthreads();
-        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
-        const bool skip = s_off[0] > 0.0 || nV <= 1;
-        __syncthreads();
-        if(skip) continue;
-        // ---- w = P t = V D^-1 V^T t ; W = V diag(sqrt(c / D)) V^T + w 1^T (into s_B; sqrt(c / D) in s_off) ------------
-        if(tid < nV) {
-            double u = 0.0;
-            for(int k = 0; k < nV; ++k) u = __builtin_fma(s_V[k * EP + tid], s_t[k], u);   // (V^T t)_tid
-            s_off[tid] = sqrt(c / s_B[tid * EP + tid]);                                    // sqrt(c / D)
-            s_X[tid] = u / s_B[tid * EP + tid];                                            // D^-1 V^T t
-        }
-        __syncthreads();
-        if(tid < nV) {
-            double wv = 0.0;
-            for(int k = 0; k < nV; ++k) wv = __builtin_fma(s_V[tid * EP + k], s_X[k], wv);
-            s_w[tid] = wv;
-        }
-        __syncthreads();
-        for(int e = tid; e < nV * nV; e += 256) {
-            const int ai = e / nV, bi = e - ai * nV;
-            double sacc = 0.0;
-            for(int k = 0; k < nV; ++k) sacc = __builtin_fma(s_V[ai * EP + k] * s_off[k], s_V[bi * EP + k], sacc);
-            s_B[ai * EP + bi] = sacc + s_w[ai];                                            // oi_ensi.cpp:419-444
-        }
-        // ---- ensemble side (oi_ensi.cpp:447-553): thread e < nV owns member e ---------------------------------------------------
-        const int ek = (tid < nV) ? a.validIdx[tid] : 0;
-        const float value = (tid < nV) ? a.bg[(long)cell * E + ek] : 0.0f;
-        __shared__ float s_val[64];
-        if(tid < 64) s_val[tid] = value;
-        __syncthreads();
-        float total = 0; int count = 0;
-        for(int k = 0; k < nV; ++k) { const float v = s_val[k]; if(d_valid(v)) { total += v; count++; } }
-        const float ensMean = total / (float)count;
-        if(tid < nV) s_X[tid] = (double)value - (double)ensMean;
-        __syncthreads();
-        if(tid < nV) {
-            float acc = 0.0f;
-            for(int k = 0; k < nV; ++k) acc = (float)((double)acc + s_X[k] * s_B[k * EP + tid]);   // float += double product (:508-511)
-            float currIncrement = acc;
-            if(!a.allow_extrap) {   // :520-552; lY[e] is a LINEAR index into the n x nV column-major matrix
-                const int li_ = tid % n, lk_ = tid / n;
-                const unsigned oo = ~(unsigned)(gkeys[li_] & 0xffffffffull);
-                const double lYe = (double)a.gY[(long)oo * nV + lk_];
-                float maxInc = 0, minInc = 0;
-                for(int i = 0; i < n; ++i) {
-                    const unsigned oi_ = ~(unsigned)(gkeys[i] & 0xffffffffull);
-                    const float4 x4 = a.oaux[oi_];
-                    const float dv = (float)((double)x4.y - (lYe + (double)x4.z));
-                    if(i == 0 || dv > maxInc) maxInc = dv;
-                    if(i == 0 || dv < minInc) minInc = dv;
-                }
-                const double Xe = s_X[tid];
-                const float memberIncrement = (float)((double)currIncrement - Xe);
-                if(maxInc > 0 && memberIncrement > maxInc) currIncrement = (float)((double)maxInc + Xe);
-                else if(maxInc < 0 && memberIncrement > 0) currIncrement = (float)(0.0 + Xe);
-                else if(minInc < 0 && memberIncrement < minInc) currIncrement = (float)((double)minInc + Xe);
-                else if(minInc > 0 && memberIncrement < 0) currIncrement = (float)(0.0 + Xe);
-            }
-            a.out[(long)cell * E + ek] = ensMean + currIncrement;
-        }
-        __syncthreads();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_ensi_big_ns: k_ensi_big with the eigen-decomposition replaced by a matrix-core iteration (round 3).  The cyclic Jacobi of
@@ -890,7 +305,7 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
             if(tid < nV) for(int i = 0; i < m; ++i) acct = __builtin_fma((double)yc[i * YCP + tid] * rinv[i], dvec[i], acct);
         }
         __syncthreads();
-        // ---- scaling: s = (|Pinv|_inf + c) / 2; Y_0 = Pinv / s (rows / columns beyond nV: the identity, which stays the identity), Z_0 = I
+        // ---- scaling: s = (|Pinv|_inf + c) / 2; Y_0 = Pinv / s (rows / columns beyond nV: a decoupled identity block -- with the scaled steps it does not stay the identity, it converges to it again), Z_0 = I
         double rowabs = 0.0;
 #pragma unroll
         for(int tb = 0; tb < 4; ++tb)
@@ -1293,7 +708,7 @@ __global__ __launch_bounds__(256) void k_ensi_huge(EnsiArgs a, const int* __rest
         // eigenvalues D_k = B_kk; a non-finite or non-positive one is the reference's rcond <= 0 passthrough (oi_ensi.cpp:386-390)
         double bad = 0.0;
         for(int k = tid; k < nV; k += 256) { const double dk = B[(size_t)k * nV + k]; if(!(dk > 0.0) || isinf(dk)) bad = 1.0; }
-        if(block_sum(bad) > 0.0) continue;
+        if(block_sum(bad) > 0.0) { if(tid == 0 && a.counters) atomicAdd(&a.counters[72], 1ull); continue; }   // ([72]: grid points left untouched, see gpp_ensi_last_stats)
         // ---- w = P t = V D^-1 V^T t ; W = V diag(sqrt(c / D)) V^T + w 1^T (:401-444) -> B --------------------------------------------
         for(int k = tid; k < nV; k += 256) {
             double u = 0.0;
@@ -1371,6 +786,7 @@ struct EnsiWorkspace {
 };
 thread_local EnsiWorkspace g_ews;
 thread_local float g_ensi_ms = 0;
+thread_local gpp_ensi_stats g_ensi_stats = {0, 0, 0, 0};
 thread_local int g_ensi_converge = 0;
 }
 
@@ -1385,6 +801,13 @@ extern "C" int gpp_ensi_set_convergence(int to_convergence) {
 }
 
 
+extern "C" int gpp_ensi_last_stats(gpp_ensi_stats* st) {
+    GPP_TRY
+    if(!st) invalid("NULL");
+    *st = g_ensi_stats;
+    return GPP_OK;
+    GPP_CATCH
+}
 extern "C" int gpp_ensi_last_kernel_ms(float* ms) {
     GPP_TRY
     if(!ms) invalid("NULL");
@@ -1407,6 +830,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     const int C = bgrid->n, S = points->n, E = ne;
     ensure_device();
     g_ensi_ms = 0;
+    g_ensi_stats = gpp_ensi_stats{(long long)C, 0, 0, 0.0f};
     if(C == 0 || E == 0) return GPP_OK;
     EnsiWorkspace& ws = g_ews;
     InField f_bg, f_obs, f_sig, f_pbg;
@@ -1436,10 +860,8 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     std::vector<int> valid;
     for(int e = 0; e < E; e++) if(flags[e]) valid.push_back(e);
     const int nV = (int)valid.size();
-    // k_ensi_pair (default) takes any number of valid members; the older LDS-resident k_ensi (GPP_ENSI_V1=1, kept for A/B
-    // measurements) and k_ensi_big (more than 32 usable observations at a grid point) hold one member per lane
-    const bool use_pair = !path_env("GPP_ENSI_V1");
-    if(!use_pair && nV > EMAXV) runtime("optimal_interpolation_ensi: more than 64 valid ensemble members need the default kernel (unset GPP_ENSI_V1)");
+    // k_ensi_pair takes any number of valid members; k_ensi_big_ns (more than 32 usable observations at a grid point) holds one member per lane
+    const bool use_pair = true;
     if(nV == 0) { f_out.finish(); GPP_HIP(hipStreamSynchronize(stream())); return GPP_OK; }
     ws.validIdx.upload(valid.data(), nV);
     ws.gYhat.get(S); ws.gY.get((size_t)S * nV);
@@ -1499,6 +921,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_scan<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
         else hipLaunchKernelGGL(k_ensi_scan<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
         GPP_HIP(hipGetLastError());
+        if(nV <= 1) hipLaunchKernelGGL(k_ensi_count_cells, dim3(256), dim3(256), 0, stream(), (const unsigned*)a.meta, (long)a.ntiles * 64, ws.counters.p + 72);
         // spectral side (pairs of cells, warm-started along a tile) and ensemble side (one wave per cell) in batches of tiles: what
         // the second kernel needs of a cell (17 KB) waits in HBM.  The park is kept between calls (freeing and re-allocating tens of
         // GB costs seconds) and is therefore bounded: a quarter of the device memory (72 GB of 288: config 5 runs in two batches,
@@ -1526,17 +949,23 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
             GPP_HIP(hipGetLastError());
         }
     }
-    else if(a.s.st.fh) hipLaunchKernelGGL(k_ensi<true>, dim3(a.ntiles), dim3(64), 0, stream(), a);
-    else hipLaunchKernelGGL(k_ensi<false>, dim3(a.ntiles), dim3(64), 0, stream(), a);
     GPP_HIP(hipGetLastError());
+    int nbig_cells = 0;
     if(big_ok) {
         int nbig = 0;
         GPP_HIP(hipMemcpyAsync(&nbig, ws.big_count.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipStreamSynchronize(stream()));
+        nbig_cells = nbig;
         auto launch_huge = [&](const int* list, const int* count, int nitems) {   // no capacity of its own: scratch sized for this call
-            const int nwg = std::max(1, std::min(nitems, 512));
             int kcap = 1;
             while(kcap < S) kcap <<= 1;
+            // scratch per workgroup: candidate keys for every observation + the E x E matrices; within the 16 GB budget of the general
+            // kernels (like optimal_interpolation_ensi_multi): fewer workgroups when a grid point needs much
+            const size_t per_wg = (size_t)kcap * sizeof(unsigned long long) + (2 * (size_t)nV * nV + 5 * (size_t)nV) * sizeof(double);
+            size_t budget = (size_t)16 << 30;
+            if(path_env("GPP_OI_HUGE_BUDGET_MB")) budget = (size_t)atol(path_env("GPP_OI_HUGE_BUDGET_MB")) << 20;
+            if(per_wg > budget) runtime("optimal_interpolation_ensi: the scratch of one grid point (" + std::to_string(per_wg >> 20) + " MB) does not fit the budget of the general kernel (GPP_OI_HUGE_BUDGET_MB)");
+            const int nwg = (int)std::max<size_t>(1, std::min<size_t>({(size_t)nitems, (size_t)512, budget / per_wg}));
             a.huge_kcap = kcap;
             a.huge_keys = ws.huge_keys.get((size_t)nwg * kcap);
             a.huge_mat = ws.huge_mat.get((size_t)nwg * (2 * (size_t)nV * nV + 5 * (size_t)nV));
@@ -1544,15 +973,12 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
             else hipLaunchKernelGGL(k_ensi_huge<false>, dim3(nwg), dim3(256), 0, stream(), a, list, count);
             GPP_HIP(hipGetLastError());
         };
+        if(nbig > 0 && nV > 16384) runtime("optimal_interpolation_ensi: more than 16384 valid ensemble members at a grid point with more than 32 observations are not supported on the GPU path (the general kernel stages one row of Y in 64 KB of LDS)");
         if(nbig > 0 && nV > EMAXV) launch_huge(a.big_list, a.big_count, nbig);      // more valid members than one lane each: the general kernel
         else if(nbig > 0) {
             const int nwg = std::min(nbig, 1024);
             a.big_keys = ws.big_keys.get((size_t)nwg * EBIG_CAND);
-            if(path_env("GPP_ENSI_BIG_JACOBI")) {   // the round-1 kernel (cyclic Jacobi in LDS): kept for A/B runs and tests
-                if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_big<true>, dim3(nwg), dim3(256), 0, stream(), a);
-                else hipLaunchKernelGGL(k_ensi_big<false>, dim3(nwg), dim3(256), 0, stream(), a);
-            }
-            else {
+            {
                 const size_t ns_lds = (size_t)3 * 64 * NSP * sizeof(double);
                 static std::once_flag ns_once;
                 std::call_once(ns_once, [=] {
@@ -1574,13 +1000,20 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     }
     GPP_HIP(hipEventRecord(ws.e1, stream()));
     int err = 0;
+    unsigned long long npass = 0;
     GPP_HIP(hipMemcpyAsync(&err, ws.err.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    GPP_HIP(hipMemcpyAsync(&npass, ws.counters.p + 72, sizeof(npass), hipMemcpyDeviceToHost, stream()));
     f_out.finish();
     static thread_local std::vector<unsigned long long> hcv(80 + 1024 * 32);
     unsigned long long* const hc = hcv.data();
     if(timing_env("GPP_ENSI_STATS")) GPP_HIP(hipMemcpyAsync(hc, ws.counters.p, sizeof(unsigned long long) * hcv.size(), hipMemcpyDeviceToHost, stream()));
     GPP_HIP(hipStreamSynchronize(stream()));
     GPP_HIP(hipEventElapsedTime(&g_ensi_ms, ws.e0, ws.e1));
+    // grid points the call left untouched because their E x E system is singular or not finite (the reference's "Condition number error in
+    // N points. Using raw values in those points.", oi_ensi.cpp:386-390,557-561; the mirrors print it): with fewer than two valid members
+    // that is every grid point with an observation in range, the large-n cells (all of them have observations) included
+    g_ensi_stats.kernel_ms = g_ensi_ms;
+    g_ensi_stats.condition_passthrough = (long long)npass + ((nV <= 1 && big_ok) ? (long long)nbig_cells : 0);
     if(timing_env("GPP_ENSI_STATS")) {
         unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
         fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (use_pair ? 0.25 : 1.0) * (double)sw / (double)hc[1] : 0.0);
@@ -1648,6 +1081,7 @@ extern "C" int gpp_optimal_interpolation_ensi_multi(int variant, gpp_points* bgr
     for(int e = 0; e < E; e++) if(flags[e]) valid.push_back(e);
     const int nV = (int)valid.size();
     if(nV == 0) { f_out.finish(); GPP_HIP(hipStreamSynchronize(stream())); return GPP_OK; }      // :419-420
+    if(nV > 16384) runtime("optimal_interpolation_ensi_multi: more than 16384 valid ensemble members are not supported on the GPU path (the general kernel stages one row of Y in 64 KB of LDS)");
     if(variant == 1 && nV > 4096) runtime("optimal_interpolation_ensi_multi_ebe: more than 4096 valid ensemble members are not supported on the GPU path");
     ws.validIdx.upload(valid.data(), nV);
     ws.gYhat.get(S); ws.gY.get((size_t)S * nV); ws.gYm.get((size_t)S * nV); ws.obs0.get(S);

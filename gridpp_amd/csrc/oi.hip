@@ -1685,13 +1685,21 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 }
             }
             else {
-                GPP_HIP(hipMemcpyAsync(ws.h_status, ws.status.p, 16, hipMemcpyDeviceToHost, stream()));
-                GPP_HIP(hipStreamSynchronize(stream()));
-                const int n1 = h_ints[1];
-                if(16 * (long)n1 > SHORT_ITEMS) long_passes(n1);
-                else if(n1 > 0) short_passes(16 * n1);
+                // A long list is expected, and the same geometry declines the same tiles: the two-level passes are launched for the length
+                // of the last call (+ 1/8) without asking the host first -- they read the true length on the device.  Only if MORE tiles were
+                // declined than those grids hold (other observations turned invalid) are the passes run again with the true length: every
+                // pass writes the same values for the cells it handles, so that is merely slower.
+                const int cap = memo.n1 + memo.n1 / 8 + 64;
+                long_passes(cap);
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
+                const int n1 = h_ints[1];
+                if(n1 > cap) {
+                    GPP_HIP(hipMemsetAsync(d_fb_count + 1, 0, 2 * sizeof(int), stream()));
+                    long_passes(n1);
+                    GPP_HIP(hipEventRecord(ws.e1, stream()));
+                    fetch();
+                }
             }
             if(skip_k_oi && h_ints[3] > 0) {   // 4-cell items for k_oi after all
                 a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
@@ -1717,6 +1725,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             memo.kh = a.s.st.kh; memo.kv = a.s.st.kv; memo.kw = a.s.st.kw; memo.cv = a.s.st.cv;
             memo.declined = (float)nfb[0] / (float)a.ntiles;
             memo.leftover = nfb[2];
+            memo.n1 = nfb[0];
         }
         if(big_ok) {
             const int nbig = h_ints[4];

@@ -7,6 +7,7 @@
 
 namespace gpp {
 
+std::recursive_mutex& api_mutex_ref() { static std::recursive_mutex m; return m; }   // one compute call at a time (GPP_TRY, common.h)
 static thread_local std::string g_last_error;
 void set_error(const char* msg) { g_last_error = msg ? msg : ""; }
 int fail(int code, const char* fmt, ...) {

@@ -298,6 +298,15 @@ inline vec2 optimal_interpolation_full(const Grid& bgrid, const vec2& background
     return detail::unflatten(out, Y, X);
 }
 // include/gridpp.h:263-294
+namespace detail {
+// the two warnings the reference prints at the end of optimal_interpolation_ensi (src/api/oi_ensi.cpp:557-566)
+inline void ensi_warnings() {
+    gpp_ensi_stats st;
+    if(gpp_ensi_last_stats(&st) != GPP_OK) return;
+    if(st.condition_passthrough > 0) warning("Condition number error in " + std::to_string(st.condition_passthrough) + " points. Using raw values in those points.");
+    if(st.real_part_passthrough > 0) warning("Could not find the real part of W in " + std::to_string(st.real_part_passthrough) + " points. Using raw values in those points.");
+}
+}
 inline vec2 optimal_interpolation_ensi(const Points& bpoints, const vec2& background, const Points& points, const vec& pobs, const vec& psigmas,
                                        const vec2& pbackground, const StructureFunction& structure, int max_points, bool allow_extrapolation = true) {
     if(max_points < 0) throw std::invalid_argument("max_points must be >= 0");
@@ -313,6 +322,7 @@ inline vec2 optimal_interpolation_ensi(const Points& bpoints, const vec2& backgr
     vec out(bg.size());
     detail::check(gpp_optimal_interpolation_ensi(bpoints.handle(), bg.data(), (int)E, points.handle(), pobs.data(), psigmas.data(), pbg.data(),
                                                  structure.c_struct(), max_points, allow_extrapolation, out.data(), GPP_MEM_HOST));
+    detail::ensi_warnings();
     return detail::unflatten(out, N, E);
 }
 inline vec3 optimal_interpolation_ensi(const Grid& bgrid, const vec3& background, const Points& points, const vec& pobs, const vec& psigmas,
@@ -331,6 +341,7 @@ inline vec3 optimal_interpolation_ensi(const Grid& bgrid, const vec3& background
     vec out(bg.size());
     detail::check(gpp_optimal_interpolation_ensi(bgrid.handle(), bg.data(), (int)E, points.handle(), pobs.data(), psigmas.data(), pbg.data(),
                                                  structure.c_struct(), max_points, allow_extrapolation, out.data(), GPP_MEM_HOST));
+    detail::ensi_warnings();
     return detail::unflatten(out, Y, X, E);
 }
 

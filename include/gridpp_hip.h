@@ -268,6 +268,18 @@ int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* background, i
                                    const gpp_structure* structure, int max_points, int allow_extrapolation,
                                    float* out, int mem);
 int gpp_ensi_last_kernel_ms(float* ms);
+/* Statistics of the calling thread's last gpp_optimal_interpolation_ensi: condition_passthrough = grid points left at their background
+ * values because their E x E system is singular or not finite -- the count behind the reference's warning "Condition number error in N
+ * points. Using raw values in those points." (src/api/oi_ensi.cpp:153,386-390,557-561), which the mirrors print; real_part_passthrough
+ * = the reference's second counter (:154,423-426,562-566: an empty real part of the matrix square root), which cannot happen for the
+ * symmetric square root the kernels form and is always 0. */
+typedef struct gpp_ensi_stats {
+    long long cells;
+    long long condition_passthrough;
+    long long real_part_passthrough;
+    float kernel_ms;
+} gpp_ensi_stats;
+int gpp_ensi_last_stats(gpp_ensi_stats* stats);
 /* 1: the Jacobi sweeps of the per-cell eigenproblem run to convergence (reference-grade last bits, ~2x the time);
  * 0 (default): they stop at |off-diagonal| <= 0.010 (E - 1) and a perturbation series supplies the rest.
  * Per calling thread. */

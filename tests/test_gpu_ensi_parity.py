@@ -205,17 +205,41 @@ def test_ensi_large_n_with_elevation_nan_obs_and_invalid_member():
     assert np.isnan(out[3, 4, 5])
 
 
-def test_ensi_big_jacobi_kernel_agrees(monkeypatch):
-    """The round-1 large-n kernel (cyclic Jacobi in LDS, GPP_ENSI_BIG_JACOBI) and the Newton-Schulz one that replaced it give the
-    oracle's values on the same cells (60 usable observations per grid point, 20 and 50 members: the 32-row tile path takes none of the cells)."""
+def test_ensi_large_n_newton_schulz_kernel():
+    """60 usable observations per grid point, 20 and 50 members: the 32-row tile path takes none of the cells, k_ensi_big_ns all of them
+    (the cyclic-Jacobi kernel of round 1 it replaced left the library in round 4)."""
     for E in (20, 50):
         c = case(950 + E, 6, 7, E, 60)
         out, ref = run(c, 200000, 0)
         check(out, ref, c[2])
-        monkeypatch.setenv("GPP_ENSI_BIG_JACOBI", "1")
-        out_j, _ = run(c, 200000, 0)
-        monkeypatch.delenv("GPP_ENSI_BIG_JACOBI")
-        check(out_j, ref, c[2])
+
+
+def test_passthrough_count_and_the_reference_warning(capsys):
+    """oi_ensi.cpp:386-390,557-561: a grid point whose E x E system has rcond <= 0 keeps its background values and is counted; the count
+    comes back through gpp_ensi_last_stats and the mirror prints the reference's warning.  With ONE valid member Pinv is the zero matrix:
+    every grid point with an observation in range is such a point (and only those)."""
+    import gridpp_amd as gridpp
+    rng = np.random.default_rng(5)
+    Y, X, E, S = 20, 24, 4, 30
+    lats, lons = np.meshgrid(np.linspace(60, 60.5, Y), np.linspace(10, 11, X), indexing="ij")
+    bg = rng.normal(0, 1, (Y, X, E)).astype(np.float32)
+    bg[3, 4, 1:] = np.nan                       # members 1..3 are invalid somewhere: one valid member left (oi_ensi.cpp:187-201)
+    plat, plon = 60.05 + 0.1 * rng.random(S), 10.1 + 0.2 * rng.random(S)      # a cluster in one corner: most grid points see no observation
+    pbg = rng.normal(0, 1, (S, E)).astype(np.float32)
+    obs, sig = rng.normal(0, 1, S).astype(np.float32), np.ones(S, np.float32)
+    grid, points = gridpp.Grid(lats, lons), gridpp.Points(plat, plon)
+    out = gridpp.optimal_interpolation_ensi(grid, bg, points, obs, sig, pbg, gridpp.BarnesStructure(3000), 10)
+    assert np.array_equal(out, bg, equal_nan=True)
+    st = gridpp.ensi_last_stats()
+    in_range = int((gridpp.count(points, grid, gridpp.BarnesStructure(3000).localization_distance()) > 0).sum())
+    assert st["cells"] == Y * X and 0 < st["condition_passthrough"] < Y * X
+    assert st["condition_passthrough"] == in_range
+    assert "Warning: Condition number error in %d points. Using raw values in those points." % st["condition_passthrough"] in capsys.readouterr().out
+    # a healthy call: no count, no warning
+    bg2 = rng.normal(0, 1, (Y, X, E)).astype(np.float32)
+    out2 = gridpp.optimal_interpolation_ensi(grid, bg2, points, obs, sig, pbg, gridpp.BarnesStructure(3000), 10)
+    assert gridpp.ensi_last_stats()["condition_passthrough"] == 0 and "Warning" not in capsys.readouterr().out
+    assert np.abs(out2 - bg2).max() > 0
 
 
 def test_ensi_large_n_limits():

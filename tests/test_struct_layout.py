@@ -20,6 +20,8 @@ int main(void) {
     F(gpp_structure, kind_v); F(gpp_structure, kind_w); F(gpp_structure, loc); F(gpp_structure, cv_dist); F(gpp_structure, flags);
     F(gpp_structure, field); F(gpp_structure, field_v); F(gpp_structure, field_w);
     printf("gpp_oi_stats %zu\n", sizeof(gpp_oi_stats));
+    printf("gpp_ensi_stats %zu\n", sizeof(gpp_ensi_stats));
+    F(gpp_ensi_stats, cells); F(gpp_ensi_stats, condition_passthrough); F(gpp_ensi_stats, real_part_passthrough); F(gpp_ensi_stats, kernel_ms);
     return 0;
 }
 """
@@ -42,6 +44,9 @@ def test_ctypes_mirror_matches_the_header(tmp_path):
     for name, _ in _capi.gpp_structure._fields_:
         assert getattr(_capi.gpp_structure, name).offset == lay["gpp_structure." + name], name
     assert C.sizeof(_capi.gpp_oi_stats) == lay["gpp_oi_stats"]
+    assert C.sizeof(_capi.gpp_ensi_stats) == lay["gpp_ensi_stats"]
+    for name, _ in _capi.gpp_ensi_stats._fields_:
+        assert getattr(_capi.gpp_ensi_stats, name).offset == lay["gpp_ensi_stats." + name], name
 
 
 def test_integration_md_stub_matches_the_header(tmp_path):
