@@ -139,8 +139,8 @@ def main():
 
     # GPP_* variables select implementations inside the library (tests, A/B timing): a benchmark line must not carry any.
     # (GPP_BENCH_* are this script's own: the N > 1 logic test on a one-GPU box; they are recorded in the line.)
-    overrides = gridpp.active_overrides()
-    lib_overrides = [o for o in overrides if not o.startswith("GPP_BENCH_")]
+    lib_overrides = gridpp.active_overrides()
+    overrides = lib_overrides + sorted(k for k in os.environ if k.startswith("GPP_BENCH_"))
     if lib_overrides:
         raise SystemExit("bench.py: library overrides are set in the environment: %s -- unset them" % ", ".join(lib_overrides))
 
@@ -314,6 +314,7 @@ def main():
                                            "salu_wave_instructions_per_launch": prof.get("SQ_INSTS_SALU"),
                                            "lds_wave_instructions_per_launch": prof.get("SQ_INSTS_LDS"),
                                            "instructions_per_cell": (valu + prof.get("SQ_INSTS_SALU", 0) + prof.get("SQ_INSTS_LDS", 0)) / cells_rank,
+                                           "wave_cycle_shares": prof.get("wave_cycle_shares"),
                                            "source": "committed_profile", "profile": prof.get("_source", "profiles/hbm_traffic.json"),
                                            "note": "counters per launch from the committed rocprofv3 PMC bundle of this workload (not re-measured in this run) over the live kernel time; "
                                                    "cycles per wave64 instruction: 2 (FP32 / integer VALU), 4 (FP64), MI355X_MICROARCH.md; frac = sum(instructions x cycles) / (1024 SIMDs x 2.4 GHz x t)"}

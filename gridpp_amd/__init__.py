@@ -1363,8 +1363,14 @@ def ensi_set_convergence(to_convergence):
     check(lib().gpp_ensi_set_convergence(1 if to_convergence else 0))
 
 
+def set_path_override(name, value):
+    """The library's one test / A-B hook: `name` = a GPP_* path switch (they select between implementations with identical results),
+    `value` = its setting as a string, None clears it.  The library reads no environment variable itself."""
+    check(lib().gpp_set_path_override(str(name).encode(), None if value is None else str(value).encode()))
+
+
 def active_overrides():
-    """Names of the GPP_* environment variables that are set (they select implementations, never results)."""
+    """Names of the GPP_* path switches that are set (they select implementations, never results)."""
     buf = C.create_string_buffer(4096)
     n = lib().gpp_active_overrides(buf, len(buf))
     return [s for s in buf.value.decode().split(",") if s] if n > 0 else []

@@ -79,6 +79,7 @@ SIGNATURES = {
     "gpp_ensi_last_kernel_ms": [fp],
     "gpp_ensi_last_stats": [C.POINTER(gpp_ensi_stats)],
     "gpp_ensi_set_convergence": [C.c_int],
+    "gpp_set_path_override": [C.c_char_p, C.c_char_p],
     "gpp_active_overrides": [C.c_char_p, C.c_int],
     "gpp_release_workspaces": [],
     "gpp_row_tile": [C.c_int, C.c_int, C.c_int, ip, ip],
@@ -121,6 +122,11 @@ def lib():
             getattr(L, name).restype = C.c_char_p
             getattr(L, name).argtypes = []
         _lib = L
+        # the library itself reads no environment variable; the GPP_* switches of THIS process' environment (tools/README.md: A/B runs,
+        # `GPP_OI_NO_UNION=1 python tools/...`) are handed to its one override hook here, once
+        for k, v in os.environ.items():
+            if k.startswith("GPP_") and k not in ("GPP_LIB",) and not k.startswith("GPP_BENCH_"):
+                L.gpp_set_path_override(k.encode(), v.encode())
     return _lib
 
 

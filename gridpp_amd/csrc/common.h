@@ -50,8 +50,7 @@ std::recursive_mutex& api_mutex_ref();
 // GPP_SCAN_STATS, GPP_ENSI_STATS) exist only in diagnostic builds (-DGPP_TIMING_SWITCHES, tools/variant.sh): the product
 // library never reads them and GPP_DBG() is the constant 0 there.
 // path_env(): switches that choose between implementations returning the same results (tests force the rarely taken paths
-// with them, A/B timings compare them).  gpp_active_overrides() lists every GPP_* variable of the environment; bench.py
-// refuses to run with any of them set.
+// with them, A/B timings compare them).  gpp_active_overrides() lists the ones that are set; bench.py refuses to run with any.
 #ifdef GPP_TIMING_SWITCHES
 inline const char* timing_env(const char* n) { return getenv(n); }
 #define GPP_DBG(a, bits) ((a).debug & (bits))
@@ -59,7 +58,11 @@ inline const char* timing_env(const char* n) { return getenv(n); }
 inline const char* timing_env(const char*) { return nullptr; }
 #define GPP_DBG(a, bits) 0
 #endif
-inline const char* path_env(const char* n) { return getenv(n); }
+// (round 4: NOT the environment any more -- the library reads no environment variable.  An override exists only after an explicit
+//  gpp_set_path_override(name, value) call, the hook the tests and the A/B tools use; the Python mirror forwards the GPP_* variables of
+//  its process to it once at load time so that `GPP_OI_NO_UNION=1 python tools/...` keeps working.)
+const char* path_override(const char* name);   // runtime.hip; NULL when not set
+inline const char* path_env(const char* n) { return path_override(n); }
 
 // ---- device runtime ----------------------------------------------------------
 hipStream_t stream();   // library stream (created on first use, after the device is chosen)

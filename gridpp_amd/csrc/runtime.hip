@@ -53,18 +53,41 @@ extern char** environ;
 void gpp_release_ensi_workspace();   // ensi.hip
 void gpp_release_oi_workspace();     // oi.hip
 
-// every GPP_* variable of the environment, comma separated (path_env() in common.h: they select implementations, never results)
+// ---- path overrides: the one test hook (common.h: path_env) ---------------------------------------------------------------------
+namespace gpp {
+static std::mutex g_override_mutex;
+static std::vector<std::pair<std::string, std::string>>& override_table() { static std::vector<std::pair<std::string, std::string>> t; return t; }
+const char* path_override(const char* name) {
+    std::lock_guard<std::mutex> lock(g_override_mutex);
+    for(auto& kv : override_table()) if(kv.first == name) return kv.second.c_str();   // (the strings live until the entry is changed: callers use them at once)
+    return nullptr;
+}
+}
+// name = one of the GPP_* switches of the library (they choose between implementations with identical results), value = its setting,
+// NULL to clear it.  Process-wide.
+extern "C" int gpp_set_path_override(const char* name, const char* value) {
+    GPP_TRY
+    if(!name || strncmp(name, "GPP_", 4) != 0) invalid("override names start with GPP_");
+    std::lock_guard<std::mutex> lock(g_override_mutex);
+    auto& t = override_table();
+    for(size_t i = 0; i < t.size(); i++)
+        if(t[i].first == name) {
+            if(value) t[i].second = value; else t.erase(t.begin() + (long)i);
+            return GPP_OK;
+        }
+    if(value) t.emplace_back(name, value);
+    return GPP_OK;
+    GPP_CATCH
+}
+// the overrides that are set, comma separated; returns how many
 extern "C" int gpp_active_overrides(char* buf, int len) {
     GPP_TRY
     std::string out;
     int n = 0;
-    for(char** e = environ; e && *e; ++e)
-        if(strncmp(*e, "GPP_", 4) == 0) {
-            const char* eq = strchr(*e, '=');
-            if(!out.empty()) out += ",";
-            out += eq ? std::string(*e, eq - *e) : std::string(*e);
-            n++;
-        }
+    {
+        std::lock_guard<std::mutex> lock(g_override_mutex);
+        for(auto& kv : override_table()) { if(!out.empty()) out += ","; out += kv.first; n++; }
+    }
     if(buf && len > 0) { strncpy(buf, out.c_str(), (size_t)len - 1); buf[len - 1] = 0; }
     return n;
     GPP_CATCH

@@ -71,8 +71,11 @@ extern "C" {
 const char* gpp_last_error(void);
 const char* gpp_version(void);            /* include/gridpp.h:15 GRIDPP_VERSION */
 int gpp_device_count(int* count);
-/* every GPP_* variable set in the environment, comma separated, into buf (NUL terminated); returns how many.  They select
- * between implementations with identical results (tests, A/B timing); a benchmark must run with none of them. */
+/* Path overrides: switches that select between implementations with identical results (the tests reach rarely taken paths with them, A/B
+ * timings compare them).  The library reads NO environment variable: an override exists only after gpp_set_path_override(name, value)
+ * (name = "GPP_...", value NULL clears it; process-wide).  gpp_active_overrides: the names that are set, comma separated, into buf (NUL
+ * terminated); returns how many -- a benchmark must run with none.  No counterpart in the reference. */
+int gpp_set_path_override(const char* name, const char* value);
 int gpp_active_overrides(char* buf, int len);
 /* releases the calling thread's large call-to-call device workspaces (kept otherwise for the next call) */
 int gpp_release_workspaces(void);

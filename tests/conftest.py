@@ -56,3 +56,42 @@ if os.environ.get("GRIDPP_TEST_POISON"):
             if name not in skip and hasattr(lib, name):
                 setattr(lib, name, Poisoned(getattr(lib, name)))
         yield
+
+
+# The library reads no environment variable (round 4): its GPP_* path switches are set through gpp_set_path_override.  The tests keep
+# writing them as environment variables (monkeypatch.setenv / os.environ): every call into the library first hands the CURRENT GPP_*
+# variables of the process to that hook (and clears the ones that went away).
+@pytest.fixture(scope="session", autouse=True)
+def _path_overrides_follow_the_environment():
+    try:
+        import gridpp_amd
+        lib = gridpp_amd._capi.lib()
+    except Exception:      # noqa: BLE001  (no library built: the CPU-only tests that need none still run)
+        yield
+        return
+    setter = lib.gpp_set_path_override
+    state = {}
+
+    def sync():
+        now = {k: v for k, v in os.environ.items() if k.startswith("GPP_") and k != "GPP_LIB" and not k.startswith("GPP_BENCH_")}
+        for k in list(state):
+            if k not in now:
+                setter(k.encode(), None)
+                del state[k]
+        for k, v in now.items():
+            if state.get(k) != v:
+                setter(k.encode(), v.encode())
+                state[k] = v
+
+    class Synced:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __call__(self, *a):
+            sync()
+            return self.fn(*a)
+
+    for name in gridpp_amd._capi.SIGNATURES:
+        if name not in ("gpp_set_path_override", "gpp_last_error", "gpp_version") and hasattr(lib, name):
+            setattr(lib, name, Synced(getattr(lib, name)))
+    yield

@@ -128,7 +128,7 @@ def ensi_inputs(ny, nx, E, S, row0=0, row1=None):
     return lats, lons, bg, plat, plon, pbg, obs, sig
 
 
-def ensi_case(ny, nx, E, S, mp, reps=2):
+def ensi_case(ny, nx, E, S, mp, reps=2, converged=True):
     import gridpp_amd as gridpp
     lats, lons, bg, plat, plon, pbg, obs, sig = ensi_inputs(ny, nx, E, S)
     grid = gridpp.Grid(lats, lons)
@@ -139,11 +139,13 @@ def ensi_case(ny, nx, E, S, mp, reps=2):
     # the same call with the per-cell Jacobi sweeps run to convergence (gpp_ensi_set_convergence(1)): the mode that meets north_star's
     # plain 1e-5 measure everywhere; the default (`ms`) stops the sweeps at |E| <= 0.010 c and adds a perturbation series, which leaves
     # about one value in 10^6 outside the plain measure by one float32 ulp of a term
-    gridpp.ensi_set_convergence(True)
-    try:
-        tc = timeit(lambda: gridpp.optimal_interpolation_ensi(grid, bg, points, obs, sig, pbg, st, mp), reps=1, warm=0)
-    finally:
-        gridpp.ensi_set_convergence(False)
+    tc = float("nan")
+    if converged:     # (the profiling tools pass False: their kernel statistics are those of the default mode alone)
+        gridpp.ensi_set_convergence(True)
+        try:
+            tc = timeit(lambda: gridpp.optimal_interpolation_ensi(grid, bg, points, obs, sig, pbg, st, mp), reps=1, warm=0)
+        finally:
+            gridpp.ensi_set_convergence(False)
     res = {"case": "C5 EnSI %dx%dx%d, %d obs, max_points=%d" % (ny, nx, E, S, mp), "cells": ny * nx, "ms": t * 1e3, "kernel_ms": kms,
            "ms_converged": tc * 1e3, "Mcells/s_converged": ny * nx / tc / 1e6,
            "mode": "ms / Mcells/s: default mode (Jacobi sweeps stopped at |E| <= 0.010 c + perturbation series; ulp-aware 1e-5 measure, ~1 value in 1e6 "

@@ -5,4 +5,4 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.bench_paths import ensi_case  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
-ensi_case(n, n, 50, 5000, 30)
+ensi_case(n, n, 50, 5000, 30, converged=False)

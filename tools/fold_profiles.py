@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Folds the CSV summaries of tools/profile_r03.sh (gpurun_out/prof_r03/) into the JSON bundle bench.py reads
+"""Folds the CSV summaries of tools/profile_r04.sh (gpurun_out/prof_r04/) into the JSON bundle bench.py reads
 (profiles/hbm_traffic.json): per dominant kernel and per launch, HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, KiB counters,
 the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md) and the SQ instruction counters, FP64 classes included.
 usage: fold_profiles.py <dir with *_pmc_*.csv> > hbm_traffic.json"""
@@ -36,13 +36,13 @@ def total(name, kernel_parts, counter):
     return s
 
 
-out = {"_comment": "per-launch counters of the dominant kernels from the rocprofv3 PMC passes of tools/profile_r03.sh (separate --pmc runs; summaries in "
-                   "profiles/r03_*_pmc_*.csv).  FETCH_SIZE / WRITE_SIZE in KiB; traffic = FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section). "
+out = {"_comment": "per-launch counters of the dominant kernels from the rocprofv3 PMC passes of tools/profile_r04.sh (separate --pmc runs; summaries in "
+                   "profiles/r04_*_pmc_*.csv).  FETCH_SIZE / WRITE_SIZE in KiB; traffic = FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section). "
                    "Folded by tools/fold_profiles.py."}
 U = "k_oi_union<true, false, 32>"
 fs, wsz = pick("oi_pmc_fetch", U, "FETCH_SIZE"), pick("oi_pmc_write", U, "WRITE_SIZE")
 oi = {"kernel": U + " (first pass, all tiles)", "workload": "optimal_interpolation 4000x4000 grid, 10000 obs, BarnesStructure(10000), max_points=30", "n_gpus": 1,
-      "_source": "profiles/r03_oi_pmc_*.csv"}
+      "_source": "profiles/r04_oi_pmc_*.csv"}
 if fs is not None and wsz is not None:
     oi.update({"FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": wsz, "traffic_bytes": int((2 * fs + wsz) * 1024), "algorithmic_bytes": 16000000 * 28})
 for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
@@ -53,10 +53,26 @@ f64 = [pick("oi_pmc_fp64", U, c) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VA
 if all(v is not None for v in f64):
     oi["SQ_INSTS_VALU_FP64"] = int(sum(f64))
     oi["_fp64_classes"] = dict(zip(("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64"), [int(v) for v in f64]))
+# where the kernel's wave cycles go (round-3 verdict, item 3): SQ_WAVE_CYCLES = cycles waves spent resident, SQ_ACTIVE_INST_ANY = of those, cycles
+# with an instruction of the wave in flight, SQ_WAIT_INST_ANY = waiting for an instruction to issue, SQ_WAIT_ANY = waiting on s_waitcnt
+for name, cs in (("oi_pmc_busy", ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY")),
+                 ("oi_pmc_wait", ("SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS")),
+                 ("oi_pmc_act", ("SQ_ACTIVE_INST_SCA", "SQ_INST_CYCLES_SALU", "SQ_THREAD_CYCLES_VALU"))):
+    for c in cs:
+        v = pick(name, U, c)
+        if v is not None:
+            oi[c] = int(v)
+if "SQ_WAVE_CYCLES" in oi and oi["SQ_WAVE_CYCLES"] > 0:
+    w = float(oi["SQ_WAVE_CYCLES"])
+    oi["wave_cycle_shares"] = {"active_inst_any": oi.get("SQ_ACTIVE_INST_ANY", 0) / w, "wait_inst_any": oi.get("SQ_WAIT_INST_ANY", 0) / w,
+                               "wait_any": oi.get("SQ_WAIT_ANY", 0) / w, "active_inst_valu": oi.get("SQ_ACTIVE_INST_VALU", 0) / w,
+                               "active_inst_lds": oi.get("SQ_ACTIVE_INST_LDS", 0) / w, "wait_inst_lds": oi.get("SQ_WAIT_INST_LDS", 0) / w,
+                               "_note": "fractions of SQ_WAVE_CYCLES (the cycles waves are resident); with 3 waves per SIMD the SIMD's own VALU utilisation is "
+                                        "about three times active_inst_valu"}
 out["k_oi_union"] = oi
 
 calls = 3.0   # tools/ensi_c5.py and tools/prof_nb.py make three calls each
-en = {"workload": "optimal_interpolation_ensi 2500x2500x50, 5000 obs, max_points=30", "_source": "profiles/r03_ensi_pmc_*.csv",
+en = {"workload": "optimal_interpolation_ensi 2500x2500x50, 5000 obs, max_points=30", "_source": "profiles/r04_ensi_pmc_*.csv",
       "_note": "wave-instructions per CALL, summed over k_ensi_scan / k_ensi_pair / k_ensi_members (all batches)"}
 for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F64"):
     en[c] = total("ensi_pmc_sq", ["k_ensi"], c) / calls
@@ -64,7 +80,7 @@ for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F
     en[c] = total("ensi_pmc_fp64", ["k_ensi"], c) / calls
 out["ensi_C5"] = en
 
-qf = {"workload": "neighbourhood_quantile_fast 4000x4000x100, halfwidth 15, 11 thresholds", "_source": "profiles/r03_nbh_pmc_*.csv"}
+qf = {"workload": "neighbourhood_quantile_fast 4000x4000x100, halfwidth 15, 11 thresholds", "_source": "profiles/r04_nbh_pmc_*.csv"}
 tr = 0.0
 for k in ("k_qf_count", "k_qf_box"):
     f_, w_ = pick("nbh_pmc_fetch", k, "FETCH_SIZE"), pick("nbh_pmc_write", k, "WRITE_SIZE")
