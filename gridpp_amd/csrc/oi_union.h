@@ -210,7 +210,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
 #pragma unroll
         for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
 #pragma unroll
-        for(int w = 0; w < U_WCAP; ++w) if(wave_ballot(rv[w] < INFINITY) != 0ull) live |= 1ull << w;
+        for(int w = 0; w < U_WCAP; ++w) live |= ((wave_ballot(rv[w] < INFINITY) != 0ull) ? 1ull : 0ull) << w;
         return live;
     };
     // The worst kept entry of this lane: smallest rho r0, a slot s0 that holds it, and whether more than one slot does.  Two levels --
@@ -557,11 +557,14 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         float rv[U_WCAP];
 #pragma unroll
         for(int w = 0; w < U_WCAP; ++w) rv[w] = L.rho[w][lane];
+        // (selects, not branches: written with `if` this loop compiled to two scalar branches per slot -- eighty instruction-buffer
+        //  refills per tile)
 #pragma unroll
         for(int w = 0; w < U_WCAP; ++w) {
             const unsigned long long mk = wave_ballot(rv[w] < INFINITY) & upd;
-            if(mk == upd) coreM |= 1ull << w;
-            else if(mk != 0ull) extM |= 1ull << w;
+            const unsigned long long isc = (mk == upd) ? 1ull : 0ull, ise = (mk != 0ull) ? (isc ^ 1ull) : 0ull;
+            coreM |= isc << w;
+            extM |= ise << w;
         }
         c = __popcll(coreM); nE = __popcll(extM); u = c + nE;
         // (+ 3: the padding reads of the per-cell finish behind the last row of B, see `brow` below)
