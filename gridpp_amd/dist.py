@@ -18,6 +18,40 @@ def all_tiles(ny, world):
     return [row_tile(ny, r, world) for r in range(world)]
 
 
+def weighted_row_tiles(row_weights, world, min_rows=1):
+    """Row tiles of unequal height for a field whose rows do not cost the same: [(row0, row1)] * world, contiguous, such that every tile
+    carries about 1 / world of sum(row_weights) (each boundary at the row where the running sum crosses its share; at least
+    `min_rows` rows per tile while there are enough rows).  Every rank computes the same boundaries from the same weights.
+    A cost model for optimal interpolation: row_cost_from_observations()."""
+    w = np.maximum(np.asarray(row_weights, dtype=np.float64).ravel(), 0.0)
+    ny = w.size
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    if ny == 0:
+        return [(0, 0)] * world
+    if not np.isfinite(w).all() or w.sum() <= 0:
+        return all_tiles(ny, world)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    bounds = [0]
+    for r in range(1, world):
+        b = int(np.searchsorted(cum, cum[-1] * r / world, side="left"))
+        b = max(b, bounds[-1] + min_rows)                       # not before the previous boundary (+ the minimum height) ...
+        b = min(b, ny - (world - r) * min_rows)                 # ... and leave the minimum for the tiles that follow
+        bounds.append(max(bounds[-1], min(b, ny)))
+    bounds.append(ny)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def row_cost_from_observations(row_lats, obs_lats, radius_deg, base=1.0, per_obs=0.0):
+    """A simple cost model of an OI row for weighted_row_tiles(): base + per_obs x (observations within `radius_deg` of the row's
+    latitude) -- the candidate scan of a tile grows with the observations in range, the solve does not (max_points caps it).
+    With per_obs = 0 every row costs the same (equal tiles)."""
+    row_lats = np.asarray(row_lats, dtype=np.float64).ravel()
+    o = np.sort(np.asarray(obs_lats, dtype=np.float64).ravel())
+    n = np.searchsorted(o, row_lats + radius_deg, side="right") - np.searchsorted(o, row_lats - radius_deg, side="left")
+    return base + per_obs * n
+
+
 def broadcast_observations(values, src=0, group=None):
     """In-place broadcast of the packed per-step observation block (e.g. a (3, S) tensor holding obs, ratios,
     background-at-points) from `src`.  `values` is a torch tensor on every rank (CUDA -> RCCL, CPU -> gloo)."""

@@ -170,3 +170,28 @@ def test_device_side_halo_exchange(tmp_path, world):
     ref = O.neighbourhood(full, 4, O.Mean)
     got = np.concatenate([np.load(tmp_path / ("nb%d.npy" % r)) for r in range(world)])
     np.testing.assert_array_equal(got, ref)
+
+
+def test_weighted_row_tiles_partition_and_balance():
+    """weighted_row_tiles: contiguous, covering, every tile about 1 / world of the total weight; equal weights give the equal tiles;
+    degenerate inputs (zero weights, fewer rows than ranks) stay valid partitions."""
+    from gridpp_amd import dist as gdist
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8):
+        for ny in (1, 5, 64, 1000):
+            w = rng.uniform(0.2, 3.0, ny)
+            tiles = gdist.weighted_row_tiles(w, world)
+            assert len(tiles) == world and tiles[0][0] == 0 and tiles[-1][1] == ny
+            assert all(tiles[r][1] == tiles[r + 1][0] for r in range(world - 1)) and all(a <= b for a, b in tiles)
+            if ny >= 50 * world:
+                share = np.array([w[a:b].sum() for a, b in tiles]) / w.sum()
+                assert np.abs(share - 1.0 / world).max() < 3.0 * w.max() / w.sum() + 1e-12
+            assert gdist.weighted_row_tiles(np.ones(ny), world) == [(min(a, ny), min(b, ny)) for a, b in gdist.weighted_row_tiles(np.ones(ny), world)]
+    assert gdist.weighted_row_tiles(np.ones(1000), 8) == gdist.all_tiles(1000, 8)
+    assert gdist.weighted_row_tiles(np.zeros(10), 4) == gdist.all_tiles(10, 4)
+    # a cost model: rows near the observations cost more -> the tiles there are shorter
+    lat = np.linspace(0, 1, 400)
+    cost = gdist.row_cost_from_observations(lat, 0.2 + 0.1 * rng.random(500), 0.05, base=1.0, per_obs=0.05)
+    tiles = gdist.weighted_row_tiles(cost, 4)
+    heights = [b - a for a, b in tiles]
+    assert min(heights) < 100 < max(heights) and sum(heights) == 400
