@@ -213,15 +213,23 @@ def c4_cpu_baseline(nx, E, hw, target_s=8.0):
         t0 = time.perf_counter(); fn(cube); per_row = (time.perf_counter() - t0) / rows
         rows = int(max(4 * hw + 2, min(320, 0.3 * target_s / per_row)))   # (<= 0.5 GB of members: generating them is not the point)
         cube = (rng.random((rows, nx, E), dtype=np.float32) * 10)
-        t0 = time.perf_counter(); fn(cube); t1 = time.perf_counter() - t0
+
+        def timed(budget):      # the band again and again until `budget` seconds are spent: seconds per pass
+            n, t0 = 0, time.perf_counter()
+            while True:
+                fn(cube); n += 1
+                dt = time.perf_counter() - t0
+                if dt >= budget:
+                    return dt / n, n
+        t1, n1 = timed(0.25 * target_s)
         O.set_neighbourhood_threads(threads)
         try:
-            t0 = time.perf_counter(); fn(cube); tn = time.perf_counter() - t0
+            tn, nn = timed(0.25 * target_s)
         finally:
             O.set_neighbourhood_threads(1)
         band[name] = rows
         out[name] = {"value": rows * nx / tn, "unit": "cells/s", "cores": threads, "kind": "port", "one_thread_value": rows * nx / t1,
-                     "sample": "a band of %d rows x %d columns x %d members of the same distribution; %d threads %.2f s, 1 thread %.2f s" % (rows, nx, E, threads, tn, t1),
+                     "sample": "a band of %d rows x %d columns x %d members of the same distribution, %d passes on %d threads (%.2f s each), %d passes on 1 thread (%.2f s each)" % (rows, nx, E, nn, threads, tn, n1, t1),
                      "algorithm": "oracle/gridpp_oracle.c: member statistic + summed-area table (serial, as in the reference) + window loop; OpenMP where "
                                   "neighbourhood.cpp:101,453,483 have it"}
     return out

@@ -1,6 +1,6 @@
 """The 'round-N numbers' table of DESIGN.md section 6 from a bench line (profiles/rNN_bench_n1.json): markdown rows on stdout."""
 import json, sys
-d = json.load(open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r03_bench_n1.json"))
+d = json.load(open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r04_bench_n1.json"))
 k, cb = d["kernel"], d["cpu_baseline"]
 print("| case | time | throughput | algorithmic GB/s (of 8 TB/s) | note |")
 print("|---|---|---|---|---|")
