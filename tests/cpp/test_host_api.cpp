@@ -168,6 +168,29 @@ int main() {
         CHECK(t[0][0] == u[0][0] && t[1][1] == u[1][1] && std::fabs(t[0][0] - 0.5f) < 1e-6);
         multi::destroy();
     }
+    // debug level, messages, and the EnSI pass-through warning (include/gridpp.h:1394-1430, src/api/oi_ensi.cpp:557-561)
+    {
+        CHECK(get_debug_level() == 0);
+        set_debug_level(2);
+        CHECK(get_debug_level() == 2);
+        set_debug_level(0);
+        bool thrown = false;
+        try { error("expected"); } catch(const std::runtime_error& e) { thrown = std::string(e.what()) == "expected"; }
+        CHECK(thrown);
+        // one valid member (the others are NaN somewhere): Pinv is the zero matrix, every grid point with an observation in range
+        // keeps its background values and is counted
+        vec2 la = {{0, 0}, {0.01f, 0.01f}}, lo = {{0, 0.01f}, {0, 0.01f}};
+        Grid g(la, lo);
+        Points ob(vec{0.005f}, vec{0.005f});
+        const float nanv = std::nanf("");
+        vec3 bg3 = {{{1, 2, nanv}, {3, 4, 5}}, {{6, nanv, 8}, {9, 10, 11}}};
+        vec2 pbg = {{0.5f, 0.6f, 0.7f}};
+        vec3 o3 = optimal_interpolation_ensi(g, bg3, ob, vec{1}, vec{1}, pbg, BarnesStructure(10000), 5);
+        gpp_ensi_stats est;
+        CHECK(gpp_ensi_last_stats(&est) == GPP_OK);
+        CHECK(est.cells == 4 && est.condition_passthrough == 4 && est.real_part_passthrough == 0);
+        CHECK(o3[0][1][0] == 3 && o3[1][1][2] == 11);
+    }
     std::printf("gridpp.hpp host API: all checks passed (version %s)\n", version().c_str());
     return 0;
 }
