@@ -62,8 +62,8 @@ def plain_err(out, ref):
 def test_strict_measure_with_converged_sweeps_and_count_for_the_fast_path():
     """Config-5-like inputs (E = 50, max_points 30, h = 10 km on a 1 x 1 degree domain, dense observations).
     (a) gpp_ensi_set_convergence(1): the Jacobi sweeps run to convergence and the PLAIN 1e-5 measure holds for every value.
-    (b) default (sweeps stopped at 0.010 c + perturbation series): the values outside the plain measure are counted -- they
-        are last-bit differences of one float32 term: at most 2 in 10^6 of them, none beyond 2e-5."""
+    (b) default (sweeps stopped at 0.020 c + the five-product perturbation series of round 4): the PLAIN measure holds as well (round 3,
+        with three products and 0.010 c, left about one value in 10^6 outside it by one float32 ulp of a term: DESIGN.md 4.2)."""
     import gridpp_amd as gridpp
     c = case(4242, 56, 60, 50, 1200)
     try:
@@ -77,9 +77,7 @@ def test_strict_measure_with_converged_sweeps_and_count_for_the_fast_path():
     assert np.nanmax(np.abs(out - c[2])) > 0.05
     out2, _ = run(c, 10000, 30)
     e2 = plain_err(out2, ref)
-    outside = int((e2 >= RTOL).sum())
-    assert outside <= max(1, int(2e-6 * e2.size)), (outside, e2.size)
-    assert e2.max() < 2e-5, e2.max()
+    assert e2.max() < RTOL, (e2.max(), int((e2 >= RTOL).sum()), e2.size)
     check(out2, ref, c[2])
 
 

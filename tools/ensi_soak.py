@@ -1,8 +1,8 @@
 """Randomised EnSI parity soak: both the 32-row tile path and k_ensi_big, vs the oracle (1e-5 relative).
 Every configuration runs twice: the default fast path (asserted with the ulp-aware measure of tests/ensi_golden.py; its
 values outside the PLAIN measure |out - ref| / max(|ref|, 1e-2) are counted) and with the sweeps run to convergence
-(gpp_ensi_set_convergence(1); asserted with the plain measure).  The run FAILS if the fast path puts more than 1 value in
-10^6 outside the plain measure or any value beyond 2e-5."""
+(gpp_ensi_set_convergence(1); asserted with the plain measure).  The run FAILS if the fast path puts ANY value outside
+the plain measure (round 4; round 3 allowed 1 in 10^6 and 2e-5)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -51,6 +51,6 @@ for b in bad[:10]:
     print(b)
 print("plain measure |out - ref| / max(|ref|, 1e-2): fast path %d of %d values outside 1e-5 (worst %.3g); converged sweeps: worst %.3g, %d configurations outside"
       % (n_outside, n_values, worst_fast, worst_strict, len(strict_bad)))
-ok = not bad and not strict_bad and n_outside <= max(1, 1e-6 * n_values) and worst_fast < 2e-5
+ok = not bad and not strict_bad and n_outside == 0
 print("SOAK", "PASS" if ok else "FAIL")
 sys.exit(0 if ok else 1)
