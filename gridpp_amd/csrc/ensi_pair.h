@@ -606,18 +606,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const double ra = (j == i) ? (f[j] - rt) + ((c + ei) - q2.x) * hrt : f[j] + (e[j] - q2.x) * (double)r0;
             const double rb = (j + 1 == i) ? (f[j + 1] - rt) + ((c + ei) - q2.y) * hrt : f[j + 1] + (e[j + 1] - q2.y) * (double)r1;
             double2 ff, hh;
-            ff.x = ((j == i) ? 0.0 : e[j]) + sqc * ra;
-            ff.y = ((j + 1 == i) ? 0.0 : e[j + 1]) + sqc * rb;
-            hh.x = dwv * ff.x * s_dw[j]; hh.y = dwv * ff.y * s_dw[j + 1];
-            *reinterpret_cast<double2*>(&sB[i * PP + j]) = ff;                                   // F (row i is this lane's own)
-            *reinterpret_cast<double2*>(&sA[i * PP + j]) = hh;                                   // T0 = H
+            ff.x = (((j == i) ? 0.0 : e[j]) + sqc * ra) * s_dw[j];                                // F' = F diag(dw): T(k+1) = T(k) F' needs no scaling pass
+            ff.y = (((j + 1 == i) ? 0.0 : e[j + 1]) + sqc * rb) * s_dw[j + 1];
+            hh.x = dwv * ff.x; hh.y = dwv * ff.y;
+            *reinterpret_cast<double2*>(&sB[i * PP + j]) = ff;                                   // F' (row i is this lane's own)
+            *reinterpret_cast<double2*>(&sA[i * PP + j]) = hh;                                   // T0 = H = diag(dw) F' 
             f[j] = ((j == i) ? dwv : 0.0) + hh.x;                                                // running sum: diag(dw) + T0
             f[j + 1] = ((j + 1 == i) ? dwv : 0.0) + hh.y;
         }
     }
     __syncthreads();
 #pragma unroll 1
-    for(int term = 0; term < 3; ++term) {   // T(k+1) = (T(k) F) diag(dw)
+    for(int term = 0; term < 3; ++term) {   // T(k+1) = T(k) F'
         const Acc32 tt = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
         __syncthreads();
         acc32_store_full(tt, lane, sA);
@@ -625,14 +625,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if(h == 0) {
 #pragma unroll
             for(int j = 0; j < 32; j += 2) {
-                double2 t2 = *reinterpret_cast<const double2*>(&sA[i * PP + j]);
-                t2.x *= s_dw[j]; t2.y *= s_dw[j + 1];
-                *reinterpret_cast<double2*>(&sA[i * PP + j]) = t2;
+                const double2 t2 = *reinterpret_cast<const double2*>(&sA[i * PP + j]);
                 f[j] += t2.x; f[j + 1] += t2.y;
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     if(h == 0) {
 #pragma unroll
         for(int j = 0; j < 32; j += 2) { double2 g; g.x = f[j]; g.y = f[j + 1]; *reinterpret_cast<double2*>(&sA[i * PP + j]) = g; }   // the middle matrix of W_sym
