@@ -100,8 +100,11 @@ __device__ __forceinline__ void jacobi_rotation(const double apq, const double d
     tap = ok ? t * apq : 0.0;
 }
 
-// full 32 x 32 x 32 product on the matrix cores, operands through accessors (no bounds: the staged matrices are zero padded)
-template <class FA, class FB>
+// full 32 x 32 x 32 product on the matrix cores, operands through accessors (no bounds: the staged matrices are zero padded).
+// SYM: the product is known to be symmetric (a power of a symmetric matrix, U M U^T, ...): the tile below the diagonal is not computed --
+// a quarter of the matrix-core time, and on gfx950 v_mfma_f64_16x16x4 occupies the FP64 pipe of its SIMD for 66 cycles, vector FP64
+// instructions queue behind it (tools/ubench/mfma_f64_rate.hip) -- and the stores below write the tile above the diagonal twice.
+template <bool SYM = false, class FA, class FB>
 __device__ __forceinline__ Acc32 mfma_32_full(const int lane, FA a_at, FB b_at) {
     Acc32 c;
     c.t[0][0] = c.t[0][1] = c.t[1][0] = c.t[1][1] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -109,21 +112,28 @@ __device__ __forceinline__ Acc32 mfma_32_full(const int lane, FA a_at, FB b_at) 
 #pragma unroll
     for(int kk = 0; kk < 32; kk += 4) {
         const int k = kk + kq;
-        const double a0 = a_at(r, k), a1 = a_at(r + 16, k), b0 = b_at(k, r), b1 = b_at(k, r + 16);
+        const double a0 = a_at(r, k), b0 = b_at(k, r), b1 = b_at(k, r + 16);
         c.t[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c.t[0][0], 0, 0, 0);
         c.t[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c.t[0][1], 0, 0, 0);
-        c.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c.t[1][0], 0, 0, 0);
+        const double a1 = a_at(r + 16, k);
+        if constexpr(!SYM) c.t[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c.t[1][0], 0, 0, 0);
         c.t[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c.t[1][1], 0, 0, 0);
     }
     return c;
 }
+template <bool SYM = false>
 __device__ __forceinline__ void acc32_store_full(const Acc32& c, const int lane, double* M) {
 #pragma unroll
     for(int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for(int tj = 0; tj < 2; ++tj)
+        for(int tj = 0; tj < 2; ++tj) {
+            if(SYM && ti == 1 && tj == 0) continue;
 #pragma unroll
-            for(int r = 0; r < 4; ++r) M[(16 * ti + (lane >> 4) + 4 * r) * PP + 16 * tj + (lane & 15)] = c.t[ti][tj][r];
+            for(int r = 0; r < 4; ++r) {
+                M[(16 * ti + (lane >> 4) + 4 * r) * PP + 16 * tj + (lane & 15)] = c.t[ti][tj][r];
+                if(SYM && ti == 0 && tj == 1) M[(16 + (lane & 15)) * PP + (lane >> 4) + 4 * r] = c.t[0][1][r];   // its mirror image
+            }
+        }
 }
 
 // one phase of the odd-even Jacobi ordering on the register-resident rows (b: B, u: U, dg: diagonal of B)
@@ -404,13 +414,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     __syncthreads();
                     acc32_store_full(t, lane, sA);
                     __syncthreads();
-                    const Acc32 bb = mfma_32_full(lane, [&](int r, int k) { return sB[k * PP + r]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
+                    const Acc32 bb = mfma_32_full<true>(lane, [&](int r, int k) { return sB[k * PP + r]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
                     __syncthreads();
-                    acc32_store_full(bb, lane, sA);
+                    acc32_store_full<true>(bb, lane, sA);   // (symmetric by construction: the tile below the diagonal is the mirror image of the one above)
                     __syncthreads();
-                    if(h == hh) {   // symmetrised (the two one-sided products round differently)
+                    if(h == hh) {
 #pragma unroll
-                        for(int j = 0; j < 32; ++j) b[j] = 0.5 * (sA[i * PP + j] + sA[j * PP + i]);
+                        for(int j = 0; j < 32; j += 2) { const double2 v = *reinterpret_cast<const double2*>(&sA[i * PP + j]); b[j] = v.x; b[j + 1] = v.y; }
                     }
                 }
                 __syncthreads();
@@ -568,9 +578,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __syncthreads();
     {
-        const Acc32 pp = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
+        const Acc32 pp = mfma_32_full<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
         __syncthreads();
-        acc32_store_full(pp, lane, sB);                                                            // R1 R1
+        acc32_store_full<true>(pp, lane, sB);                                                            // R1 R1
     }
     __syncthreads();
     double f[32];   // row i (lanes 0..31) of X2, then of F, then of the sum of the series
@@ -592,9 +602,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __syncthreads();
     {
-        const Acc32 x2 = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
+        const Acc32 x2 = mfma_32_full<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
         __syncthreads();
-        acc32_store_full(x2, lane, sB);                                                            // X2 X2
+        acc32_store_full<true>(x2, lane, sB);                                                            // X2 X2
     }
     __syncthreads();
     if(h == 0) {
@@ -618,9 +628,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __syncthreads();
 #pragma unroll 1
     for(int term = 0; term < 3; ++term) {   // T(k+1) = T(k) F'
-        const Acc32 tt = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
+        // (T(k) = (diag(dw) F)^k diag(dw) F diag(dw) is symmetric: F is, and (D F)^k D = D (F D)^k)
+        const Acc32 tt = mfma_32_full<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
         __syncthreads();
-        acc32_store_full(tt, lane, sA);
+        acc32_store_full<true>(tt, lane, sA);
         __syncthreads();
         if(h == 0) {
 #pragma unroll
@@ -683,16 +694,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __syncthreads();
         acc32_store_full(tm, lane, sA);
         __syncthreads();
-        const Acc32 mw = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[cc * PP + k]; });
+        const Acc32 mw = mfma_32_full<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[cc * PP + k]; });
         __syncthreads();
 #pragma unroll
         for(int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for(int tj = 0; tj < 2; ++tj)
+            for(int tj = ti; tj < 2; ++tj)
 #pragma unroll
                 for(int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
-                    sA[row * PP + col] = GPP_DBG(a, 8) ? 0.0 : mw.t[ti][tj][r] * (s_sD1[row] * s_sD1[col]);
+                    const double v = GPP_DBG(a, 8) ? 0.0 : mw.t[ti][tj][r] * (s_sD1[row] * s_sD1[col]);
+                    sA[row * PP + col] = v;
+                    if(ti != tj) sA[col * PP + row] = v;   // (U Mmid U^T is symmetric: the tile below the diagonal is the mirror image)
                 }
     }
     __syncthreads();
