@@ -17,6 +17,7 @@
 #include <mutex>
 #include "oi_common.h"
 #include <algorithm>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 using namespace gpp;

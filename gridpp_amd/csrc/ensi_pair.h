@@ -493,7 +493,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 template <bool ONECHUNK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ensi_members(EnsiArgs a) {
     __shared__ __attribute__((aligned(16))) double s_ab[2 * 32 * PP];
-    __shared__ __attribute__((aligned(16))) double s_sD1[32], s_z1[32], s_t[32], s_r1[32], s_dw[32], s_rt[32];
+    __shared__ __attribute__((aligned(16))) double s_small[6 * 32];
+    double* const s_sD1 = s_small, * const s_z1 = s_small + 32, * const s_t = s_small + 64, * const s_r1 = s_small + 96, * const s_dw = s_small + 128,
+          * const s_rt = s_small + 160;
+    double* const s_qt = s_t;                                     // member update: the Q columns of up to four tail members, [pair][row][2] (s_t .. s_rt are free then)
     __shared__ int s_i[128];                                      // perm[32] | obs[32] | yhat[32] (floats) | selection[32]
     double* const sA = s_ab;
     double* const sB = s_ab + 32 * PP;
@@ -555,6 +558,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = p_sD; s_r1[i] = p_r1; s_dw[i] = dwv; s_rt[i] = rt; }
     __syncthreads();
     EPROF(0)   // park loads, spectral scalars
+#ifdef GPP_ENSI_ESTATS
+    {   // (statistics build: histogram of |E|_F / c in octaves below 0.02, printed by GPP_ENSI_STATS=1 in the members-phases line)
+        double off = 0.0;
+#pragma unroll
+        for(int j = 0; j < 32; ++j) { const double v = (j == i || h == 1) ? 0.0 : e[j]; off = __builtin_fma(v, v, off); }
+        off = half_sum_d(off, lane);
+        const double r = sqrt((double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)off)))) / c;
+        int bk = 0;
+        for(double lim = 0.01; bk < 11 && r <= lim; lim *= 0.5) bk++;
+        if(lane == 0 && a.counters) atomicAdd(&a.counters[80 + (blockIdx.x & 1023) * 32 + 16 + bk], 1ull);
+    }
+#endif
     // ---- g(D + E) as a series in E, without eigenvalue gaps in any denominator.  With M = c I + D + E:
     //        M^(1/2) = X = diag(a) + R1 + R2 + R3:  Newton steps on X^2 = M with the Sylvester operator of diag(a) kept fixed,
     //                 R1 = E o rinv,   R2 = -(R1 R1) o rinv,   R3 = (M - X2^2) o rinv,   rinv(i, j) = 1 / (a_i + a_j)
@@ -754,73 +769,149 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for(int r = 0; r < EN; ++r) sBf[r * YP + lane] = yv[r];
             }
             __syncthreads();
-            // Q = M' Y  (32 x 64) on the matrix cores
-            v4d qa[2][4];
+            float acc = 0.0f;
+            double X = 0.0;
+            // Q = M' Y  (32 x 16 NT) on the matrix cores: NT tiles of 16 members
+            auto q_product = [&](auto ntc, auto& qa) __attribute__((always_inline)) {
+                constexpr int NT = decltype(ntc)::value;
 #pragma unroll
-            for(int ti = 0; ti < 2; ++ti)
+                for(int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                for(int tj = 0; tj < 4; ++tj) qa[ti][tj] = (v4d){0.0, 0.0, 0.0, 0.0};
-            {
+                    for(int tj = 0; tj < NT; ++tj) qa[ti][tj] = (v4d){0.0, 0.0, 0.0, 0.0};
                 const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
                 for(int ks = 0; ks < 8; ++ks) {
-                    double bop[4];
+                    double bop[NT];
 #pragma unroll
-                    for(int tj = 0; tj < 4; ++tj) bop[tj] = (double)sBf[(4 * ks + kq) * YP + 16 * tj + r];
+                    for(int tj = 0; tj < NT; ++tj) bop[tj] = (double)sBf[(4 * ks + kq) * YP + 16 * tj + r];
                     const double am0 = sA[r * PP + 4 * ks + kq], am1 = sA[(r + 16) * PP + 4 * ks + kq];
 #pragma unroll
-                    for(int tj = 0; tj < 4; ++tj) {
+                    for(int tj = 0; tj < NT; ++tj) {
                         qa[0][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(am0, bop[tj], qa[0][tj], 0, 0, 0);
                         qa[1][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(am1, bop[tj], qa[1][tj], 0, 0, 0);
                     }
                 }
-            }
-            EPROF(5)   // Y tile, Q
-            float acc = 0.0f;
-            double X = 0.0;
+            };
             if constexpr(ONECHUNK) {
                 // Up to 64 members (one chunk): W' = Y^T Q on the matrix cores as well (round 3: config 5 309 -> 296 ms).  The accumulators of the Q product ARE the B
                 // operands of this one (lane (kq, r16) holds Q(16 ti + kq + 4 r, 16 te + r16): k-step ks = 4 ti + r), the A operands are
                 // the values of the Y tile the Q product read.  One 16-member slab of W' at a time goes through area A (M' is not
                 // needed any more) so that lane = member e finds its 16 values W'(k, e) in k order for the float accumulation of
                 // oi_ensi.cpp:505-511; X_k and w_k come from lane k.
-                const int r16 = lane & 15, kq = lane >> 4;
-                X = (double)v0 - (double)ensMean;
-                double wk = 0.0;   // w_k = sum_r sD_r Y(r,k) z_r for member k = lane
-#pragma unroll
-                for(int r = 0; r < 32; ++r) wk = __builtin_fma(s_sD1[r] * (double)sBf[r * YP + lane], s_z1[r], wk);
+                // Round 4, tail members: both products cover NT tiles of 16 members.  With 50 valid members four tiles spend 72 of their 192
+                // v_mfma_f64 on the 14 padding columns next to members 48 and 49 -- and every one of them holds the FP64 pipe of its SIMD for
+                // 66 cycles (tools/ubench/mfma_f64_rate.hip).  Up to four members beyond the last full tile are taken by the vector unit
+                // instead: their columns of Q as two 32-term dot products per row, their rows AND columns of W' (it is symmetric:
+                // W'(k, e) = sum_r Y(r, k) Q(r, e)) as one dot product per member and tail column, transposed through LDS for the tail lanes.
+                const int mraw = nV & 15, nfull = nV >> 4;
+                const bool tail = mraw >= 1 && mraw <= 4 && nfull >= 1;
+                const int nt = tail ? nfull : (nV + 15) >> 4;
+                auto update = [&](auto ntc) __attribute__((always_inline)) {
+                    constexpr int NT = decltype(ntc)::value;
+                    constexpr int NB = 16 * NT;              // first tail member
+                    const int m = tail ? nV - NB : 0;       // tail members (0..4)
+                    v4d qa[2][NT];
+                    q_product(ntc, qa);
+                    EPROF(5)   // Y tile, Q
+                    const int r16 = lane & 15, kq = lane >> 4;
+                    X = (double)v0 - (double)ensMean;
+                    if(m > 0) {   // Q(:, NB + j): row i by lanes (h, i), columns j0 + h
 #pragma unroll 1
-                for(int tk = 0; 16 * tk < nV; ++tk) {
-                    v4d wt[4];
-#pragma unroll
-                    for(int te = 0; te < 4; ++te) wt[te] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for(int ks = 0; ks < 8; ++ks) {
-                        const double aop = (double)sBf[(4 * ks + kq) * YP + 16 * tk + r16];   // Y(i = 4 ks + kq, k = 16 tk + r16)
-#pragma unroll
-                        for(int te = 0; te < 4; ++te) wt[te] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, qa[ks >> 2][te][ks & 3], wt[te], 0, 0, 0);
+                        for(int j0 = 0; j0 < m; j0 += 2) {
+                            const int col = NB + j0 + h;     // (a column beyond nV holds zeros)
+                            double q0 = 0.0, q1 = 0.0;
+#pragma unroll 4
+                            for(int cc = 0; cc < 32; cc += 2) {
+                                const double2 mm = *reinterpret_cast<const double2*>(&sA[i * PP + cc]);
+                                q0 = __builtin_fma(mm.x, (double)sBf[cc * YP + col], q0);
+                                q1 = __builtin_fma(mm.y, (double)sBf[(cc + 1) * YP + col], q1);
+                            }
+                            s_qt[(j0 >> 1) * 64 + 2 * i + h] = q0 + q1;
+                        }
                     }
-                    __syncthreads();   // (the previous slab has been read)
+                    __syncthreads();   // (the tail columns of Q are visible, and nobody reads M' in area A any more)
+                    double wk = 0.0;   // w_k = sum_r sD_r Y(r,k) z_r for member k = lane
+                    double wtl[4] = {0.0, 0.0, 0.0, 0.0};   // W'(lane, NB + j)
+                    if(m > 0) {
+#pragma unroll 8
+                        for(int r = 0; r < 32; ++r) {
+                            const double yv = (double)sBf[r * YP + lane];
+                            const double2 q2 = *reinterpret_cast<const double2*>(&s_qt[2 * r]);
+                            wk = __builtin_fma(s_sD1[r] * yv, s_z1[r], wk);
+                            wtl[0] = __builtin_fma(yv, q2.x, wtl[0]);
+                            wtl[1] = __builtin_fma(yv, q2.y, wtl[1]);
+                        }
+                        if(m > 2) {
+#pragma unroll 8
+                            for(int r = 0; r < 32; ++r) {
+                                const double yv = (double)sBf[r * YP + lane];
+                                const double2 q2 = *reinterpret_cast<const double2*>(&s_qt[64 + 2 * r]);
+                                wtl[2] = __builtin_fma(yv, q2.x, wtl[2]);
+                                wtl[3] = __builtin_fma(yv, q2.y, wtl[3]);
+                            }
+                        }
+                    }
+                    else {
 #pragma unroll
-                    for(int te = 0; te < 4; ++te)
+                        for(int r = 0; r < 32; ++r) wk = __builtin_fma(s_sD1[r] * (double)sBf[r * YP + lane], s_z1[r], wk);
+                    }
+                    // W'(k, NB + j) for the tail lanes: behind the slab exchange area [NB][17] in area A (NB <= 48 with a tail: 816 + 256 <= 1088 doubles)
+                    double* const s_tail = sA + (NB <= 48 ? NB : 48) * 17;
+                    if(m > 0) {
 #pragma unroll
-                        for(int r = 0; r < 4; ++r) sA[(16 * te + r16) * 17 + kq + 4 * r] = wt[te][r];   // W'(k = 16 tk + kq + 4 r, e = 16 te + r16)
-                    __syncthreads();
-                    double wv[16];
+                        for(int j = 0; j < 4; ++j) if(j < m) s_tail[j * 64 + lane] = wtl[j];
+                    }
+                    const double* const src0 = (lane < NB || !tail) ? sA + lane * 17 : s_tail + min(lane - NB, 3) * 64;
+                    const int sstep = (lane < NB || !tail) ? 0 : 16;
+#pragma unroll 1
+                    for(int tk = 0; tk < NT; ++tk) {
+                        v4d wt[NT];
 #pragma unroll
-                    for(int kl = 0; kl < 16; ++kl) wv[kl] = sA[lane * 17 + kl];
+                        for(int te = 0; te < NT; ++te) wt[te] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for(int kl = 0; kl < 16; ++kl) {
-                        const int k = 16 * tk + kl;
-                        if(k < nV) {
-                            const double wke = ((k == lane ? 1.0 : 0.0) + wv[kl]) + readlane_d(wk, k);
+                        for(int ks = 0; ks < 8; ++ks) {
+                            const double aop = (double)sBf[(4 * ks + kq) * YP + 16 * tk + r16];   // Y(i = 4 ks + kq, k = 16 tk + r16)
+#pragma unroll
+                            for(int te = 0; te < NT; ++te) wt[te] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, qa[ks >> 2][te][ks & 3], wt[te], 0, 0, 0);
+                        }
+                        __syncthreads();   // (the previous slab has been read)
+#pragma unroll
+                        for(int te = 0; te < NT; ++te)
+#pragma unroll
+                            for(int r = 0; r < 4; ++r) sA[(16 * te + r16) * 17 + kq + 4 * r] = wt[te][r];   // W'(k = 16 tk + kq + 4 r, e = 16 te + r16)
+                        __syncthreads();
+                        double wv[16];
+                        const double* const src = src0 + sstep * tk;
+#pragma unroll
+                        for(int kl = 0; kl < 16; ++kl) wv[kl] = src[kl];
+#pragma unroll
+                        for(int kl = 0; kl < 16; ++kl) {
+                            const int k = 16 * tk + kl;
+                            if(k < nV) {
+                                const double wke = ((k == lane ? 1.0 : 0.0) + wv[kl]) + readlane_d(wk, k);
+                                acc = (float)((double)acc + readlane_d(X, k) * wke);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for(int j = 0; j < 4; ++j) {   // the tail members' own steps: W'(NB + j, e) = W'(e, NB + j)
+                        if(j < m) {
+                            const int k = NB + j;
+                            const double wke = ((k == lane ? 1.0 : 0.0) + wtl[j]) + readlane_d(wk, k);
                             acc = (float)((double)acc + readlane_d(X, k) * wke);
                         }
                     }
-                }
+                };
+                if(nt == 4) update(std::integral_constant<int, 4>{});
+                else if(nt == 3) update(std::integral_constant<int, 3>{});
+                else if(nt == 2) update(std::integral_constant<int, 2>{});
+                else update(std::integral_constant<int, 1>{});
                 EPROF(7)   // member update
             }
             else {
+            v4d qa[2][4];
+            q_product(std::integral_constant<int, 4>{}, qa);
+            EPROF(5)   // Y tile, Q
             // columns i and 32 + i of Y, rows [16 h, 16 h + 16), for the tables of the member update: out of the Y tile while it is still
             // there (first member chunk: the tile holds columns 0..63; otherwise they are loaded again below)
             float ya[16], yb[16];
