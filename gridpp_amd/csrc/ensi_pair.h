@@ -87,17 +87,19 @@ __device__ __forceinline__ double mux16(const bool b0, const bool b1, const bool
 __device__ __forceinline__ double d_rcp_n1(const double a) { double r = __builtin_amdgcn_rcp(a); return r * (2.0 - a * r); }
 __device__ __forceinline__ double d_rsq_n1(const double a) { double r = __builtin_amdgcn_rsq(a); return r * (1.5 - 0.5 * a * r * r); }
 
-// Jacobi rotation that annihilates apq (dp, dq: the two diagonal entries).  The angle only has to be accurate enough for
-// the quadratic convergence (one Newton step on the reciprocals); cs^2 + sn^2 = 1 holds to the accuracy of cs (two steps).
-__device__ __forceinline__ void jacobi_rotation(const double apq, const double dp, const double dq, double& cs, double& sn, double& tap) {
+// Jacobi rotation that annihilates apq (dp, dq: the two diagonal entries): t = tan, cs = cos, ci = 1 / cos, tap = t apq.  The angle
+// only has to be accurate enough for the quadratic convergence (one Newton step on the reciprocals).
+__device__ __forceinline__ void jacobi_rotation(const double apq, const double dp, const double dq, double& t, double& cs, double& ci, double& tap) {
     const double theta = (dq - dp) * 0.5 * d_rcp_n1(apq);
     const double h2 = theta * theta + 1.0;
-    const double t = (theta >= 0 ? 1.0 : -1.0) * d_rcp_n1(fabs(theta) + h2 * d_rsq_n1(h2));
-    const double c_ = d_rsq_nr(t * t + 1.0);
+    const double t_ = (theta >= 0 ? 1.0 : -1.0) * d_rcp_n1(fabs(theta) + h2 * d_rsq_n1(h2));
+    const double g2 = t_ * t_ + 1.0;
+    const double c_ = d_rsq_nr(g2);
     const bool ok = fabs(theta) < 1e150;      // false for apq == 0 (theta inf / NaN) and for a negligible apq
+    t = ok ? t_ : 0.0;
     cs = ok ? c_ : 1.0;
-    sn = ok ? t * c_ : 0.0;
-    tap = ok ? t * apq : 0.0;
+    ci = ok ? g2 * c_ : 1.0;
+    tap = ok ? t_ * apq : 0.0;
 }
 
 // full 32 x 32 x 32 product on the matrix cores, operands through accessors (no bounds: the staged matrices are zero padded).
@@ -136,34 +138,45 @@ __device__ __forceinline__ void acc32_store_full(const Acc32& c, const int lane,
         }
 }
 
-// one phase of the odd-even Jacobi ordering on the register-resident rows (b: B, u: U, dg: diagonal of B)
+// one phase of the odd-even Jacobi ordering on the register-resident rows (b: B, u: U, dg: diagonal of B).
+// Round 4: FAST rotations.  A rotation applied as (x, y) <- (c x + s y, c y - s x) is two multiplications and two multiply-adds per pair
+// of entries; written (x, y) <- c (x + t y), c (y - t x) the factor c can stay outside, in one scale per row / column: the registers hold
+// Bs and Us with  B = D Bs D,  U = Us D,  D = diag(d)  (lane i carries d_i and 1 / d_i), and a rotation of the pair (p, q) is
+//      position p <- (entry q) + kL (entry p),   position q <- (entry p) + kP (entry q),    kL = t d_p / d_q,   kP = -t d_q / d_p
+// (positions swapped as before), d_p <- c d_q, d_q <- c d_p: ONE multiply-add per entry, 96 FP64 instructions per phase instead of 192 --
+// the kernel runs one wave per SIMD and is bound by its FP64 instruction stream.  The diagonal dg stays in true values; the stopping test
+// and the hand-over to the park multiply the scales back in (jacobi_unscale below).
 template <bool ODD>
-__device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], double& dg, const int i, const int h,
+__device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], double& dg, double& dsc, double& dinv, const int i, const int h,
                                              const bool m1, const bool m2, const bool m3, const bool m4, double* s_cs) {
     // the off-diagonal entry of this lane's pair: leaders (even rows in the even phase, odd rows in the odd phase) hold it in
     // register i + 1
-    const double apq = ODD ? MUX16(b[2], b[4], b[6], b[8], b[10], b[12], b[14], b[16], b[18], b[20], b[22], b[24], b[26], b[28], b[30], 0.0)
-                           : MUX16(b[1], b[3], b[5], b[7], b[9], b[11], b[13], b[15], b[17], b[19], b[21], b[23], b[25], b[27], b[29], b[31]);
+    const double araw = ODD ? MUX16(b[2], b[4], b[6], b[8], b[10], b[12], b[14], b[16], b[18], b[20], b[22], b[24], b[26], b[28], b[30], 0.0)
+                            : MUX16(b[1], b[3], b[5], b[7], b[9], b[11], b[13], b[15], b[17], b[19], b[21], b[23], b[25], b[27], b[29], b[31]);
     const bool idle = ODD && (i == 0 || i == 31);
     const bool leader = ODD ? ((i & 1) != 0 && !idle) : ((i & 1) == 0);
     const int paddr = (ODD ? (idle ? (32 * h + i) : ((i & 1) ? 32 * h + i + 1 : 32 * h + i - 1)) : ((32 * h + i) ^ 1)) << 2;
-    // both lanes of a pair compute the same rotation from the same three numbers (the partner receives the leader's off-diagonal
-    // entry together with its diagonal entry: one exchange instead of two)
+    // both lanes of a pair compute the same rotation from the same numbers in the same order (the partner receives the leader's
+    // off-diagonal entry together with its diagonal entry and its scales)
     const double dpart = ODD ? partner_of(dg, paddr) : partner_quad(dg);
-    const double apart = ODD ? partner_of(apq, paddr) : partner_quad(apq);
-    double cs, sn, tap;
-    jacobi_rotation(leader ? apq : apart, leader ? dg : dpart, leader ? dpart : dg, cs, sn, tap);
-    if(idle) { cs = 1.0; sn = 0.0; tap = 0.0; }
-    if(leader) { double2 v; v.x = cs; v.y = sn; *reinterpret_cast<double2*>(&s_cs[(h * 16 + (i >> 1)) * 2]) = v; }
+    const double apart = ODD ? partner_of(araw, paddr) : partner_quad(araw);
+    const double spart = ODD ? partner_of(dsc, paddr) : partner_quad(dsc);
+    const double ipart = ODD ? partner_of(dinv, paddr) : partner_quad(dinv);
+    const double dL = leader ? dsc : spart, dP = leader ? spart : dsc, iL = leader ? dinv : ipart, iP = leader ? ipart : dinv;
+    double t, cs, ci, tap;
+    jacobi_rotation((dL * dP) * (leader ? araw : apart), leader ? dg : dpart, leader ? dpart : dg, t, cs, ci, tap);
+    if(idle) { t = 0.0; cs = 1.0; ci = 1.0; tap = 0.0; }
+    const double kL = t * (dL * iP), kP = -(t * (dP * iL));
+    if(leader) { double2 v; v.x = kL; v.y = kP; *reinterpret_cast<double2*>(&s_cs[(h * 16 + (i >> 1)) * 2]) = v; }
     // rotation + swap: position p receives the rotated row / column q and vice versa, so the pairs of the next phase are neighbours again
-    //   row p' = c row p - s row q,  row q' = s row p + c row q;  lane p keeps q' = s own + c partner, lane q keeps p' = c partner - s own
-    const double alpha = idle ? 1.0 : (leader ? sn : -sn);
-    const double beta = idle ? 0.0 : cs;
+    //   row p' = c row p - s row q,  row q' = s row p + c row q;  lane p keeps q' (scale c d_q), lane q keeps p' (scale c d_p)
+    const double kown = idle ? 0.0 : (leader ? kL : kP);
     dg = idle ? dg : dpart + (leader ? tap : -tap);      // a_pp' = a_pp - t a_pq, a_qq' = a_qq + t a_pq, swapped
+    dsc = cs * spart; dinv = ci * ipart;                 // (an idle lane is its own partner, with c = 1)
     // The partner values travel through the LDS crossbar (~100 cycles): all 32 requests of a half of the row are issued before
     // the first one is consumed, and the second half is in flight while the first is rotated.  The scheduling barriers pin
     // that order (left alone, the scheduler issues one request, waits for it, rotates, issues the next).
-    __syncthreads();   // (c, s) of all pairs visible (one wave: this waits for the LDS write, nothing else)
+    __syncthreads();   // (kL, kP) of all pairs visible (one wave: this waits for the LDS write, nothing else)
     double pa[16], pb[16];
     double2 ca[8], cb[8];
 #pragma unroll
@@ -172,28 +185,28 @@ __device__ __forceinline__ void jacobi_phase(double (&b)[32], double (&u)[32], d
 #pragma unroll
     for(int j = 0; j < 16; ++j) pb[j] = ODD ? partner_of(b[16 + j], paddr) : partner_quad(b[16 + j]);
 #pragma unroll
-    for(int j = 0; j < 16; ++j) b[j] = __builtin_fma(alpha, b[j], beta * pa[j]);
+    for(int j = 0; j < 16; ++j) b[j] = __builtin_fma(kown, b[j], pa[j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for(int k = 0; k < 8; ++k) ca[k] = *reinterpret_cast<const double2*>(&s_cs[(h * 16 + k) * 2]);
 #pragma unroll
-    for(int j = 0; j < 16; ++j) b[16 + j] = __builtin_fma(alpha, b[16 + j], beta * pb[j]);
+    for(int j = 0; j < 16; ++j) b[16 + j] = __builtin_fma(kown, b[16 + j], pb[j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for(int k = 0; k < 8; ++k) cb[k] = *reinterpret_cast<const double2*>(&s_cs[(h * 16 + 8 + k) * 2]);
-    // columns: (x, y) = columns (p, q):  p' = c x - s y,  q' = s x + c y, stored swapped
+    // columns (x, y) = (p, q):  position p <- y + kL x,  position q <- x + kP y
 #pragma unroll
     for(int k = 0; k < 16; ++k) {
         if(k == 8) __builtin_amdgcn_sched_barrier(0);
         if(ODD && k == 15) continue;
-        const double2 cs2 = k < 8 ? ca[k & 7] : cb[k & 7];
+        const double2 k2 = k < 8 ? ca[k & 7] : cb[k & 7];
         const int p = ODD ? 2 * k + 1 : 2 * k, q = p + 1;
         const double x = b[p], y = b[q];
-        b[p] = __builtin_fma(cs2.y, x, cs2.x * y);
-        b[q] = __builtin_fma(cs2.x, x, -(cs2.y * y));
+        b[p] = __builtin_fma(k2.x, x, y);
+        b[q] = __builtin_fma(k2.y, y, x);
         const double ux = u[p], uy = u[q];
-        u[p] = __builtin_fma(cs2.y, ux, cs2.x * uy);
-        u[q] = __builtin_fma(cs2.x, ux, -(cs2.y * uy));
+        u[p] = __builtin_fma(k2.x, ux, uy);
+        u[q] = __builtin_fma(k2.y, uy, ux);
     }
     __syncthreads();   // before the next phase overwrites s_cs
 }
@@ -434,11 +447,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 return m4 ? dhi : dlo;
             };
             double dg = diag_of_rows();
+            // scales of the fast rotations (jacobi_phase): the registers hold Bs, Us with B = D Bs D, U = Us D while `scaled`
+            double dsc = 1.0, dinv = 1.0;
+            bool scaled = false;
+            double* const s_dsc = &s_dwa[0][0][0] + 32 * h;   // this half's scales, for the stopping test and the hand-over
+            auto jacobi_unscale = [&]() {
+                __syncthreads();
+                s_dsc[i] = dsc;
+                __syncthreads();
+#pragma unroll
+                for(int j = 0; j < 32; j += 2) {
+                    const double2 dj = *reinterpret_cast<const double2*>(&s_dsc[j]);
+                    b[j] *= dsc * dj.x; b[j + 1] *= dsc * dj.y;
+                    u[j] *= dj.x; u[j + 1] *= dj.y;
+                }
+                dsc = 1.0; dinv = 1.0; scaled = false;
+            };
 #pragma unroll 1
             for(int sweep = 0; sweep < 480 / GPP_ENSI_JCHUNK && n > 1 && !GPP_DBG(a, 1); ++sweep) {   // (in chunks of GPP_ENSI_JCHUNK of a sweep's 16 double phases)
                 double off = 0.0;   // (not sum(b^2) - dg^2: the off-diagonal part is 20 orders below the diagonal when converged)
+                if(scaled) {        // true entries: d_i Bs(i, j) d_j
+                    __syncthreads();
+                    s_dsc[i] = dsc;
+                    __syncthreads();
 #pragma unroll
-                for(int j = 0; j < 32; ++j) { const double v = (j == i) ? 0.0 : b[j]; off = __builtin_fma(v, v, off); }
+                    for(int j = 0; j < 32; j += 2) {
+                        const double2 dj = *reinterpret_cast<const double2*>(&s_dsc[j]);
+                        const double v0_ = (j == i) ? 0.0 : b[j] * dj.x, v1_ = (j + 1 == i) ? 0.0 : b[j + 1] * dj.y;
+                        off = __builtin_fma(v0_, v0_, off); off = __builtin_fma(v1_, v1_, off);
+                    }
+                    off *= dsc * dsc;
+                }
+                else {
+#pragma unroll
+                    for(int j = 0; j < 32; ++j) { const double v = (j == i) ? 0.0 : b[j]; off = __builtin_fma(v, v, off); }
+                }
                 off = half_sum_d(off, lane);
                 const double tr = half_sum_d(fabs(dg), lane);
                 // The sweeps stop at an off-diagonal norm |E| of sqrt(jtol2) * c = 0.020 c (c = nV - 1 bounds every eigenvalue of c I + B from
@@ -451,12 +494,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 nsweeps++;
 #pragma unroll 1
                 for(int st = 0; st < GPP_ENSI_JCHUNK; ++st) {   // every double phase is a complete similarity transform: the test above may come after any
-                    jacobi_phase<false>(b, u, dg, i, h, m1, m2, m3, m4, s_cs);
-                    jacobi_phase<true>(b, u, dg, i, h, m1, m2, m3, m4, s_cs);
+                    jacobi_phase<false>(b, u, dg, dsc, dinv, i, h, m1, m2, m3, m4, s_cs);
+                    jacobi_phase<true>(b, u, dg, dsc, dinv, i, h, m1, m2, m3, m4, s_cs);
                 }
+                scaled = true;
                 // the diagonal from the rows again (the running update drifts in the last bits)
-                dg = diag_of_rows();
+                dg = diag_of_rows() * (dsc * dsc);
+                // (every rotation takes a factor cos >= 0.7 into the scales: long before they leave the range of a double they go back into the rows)
+                if(__ballot(dsc < 1e-60) != 0ull) jacobi_unscale();
             }
+            if(scaled) jacobi_unscale();
             EPROF(3)   // Jacobi
             // ---- park for k_ensi_members: the eigenvector rows, the rows of U^T B U (diagonal: the eigenvalue estimates, off-diagonal: what
             //      the sweeps left, which enters the matrix functions there as a perturbation), sD, sD * (obs - yhat), rho ------------
