@@ -138,6 +138,44 @@ __device__ __forceinline__ void acc32_store_full(const Acc32& c, const int lane,
         }
 }
 
+// The same product on the FP32 matrix path (v_mfma_f32_16x16x4_f32: 32 cycles of the matrix pipe instead of 66), for the higher-order
+// terms of the perturbation series in k_ensi_members: a term of relative size eps^2 <= 4e-4 carries the 6e-8 of float32 as 2e-11 of the
+// result.  Operands are rounded on the way in; the result tiles come back as doubles.  (C/D map of the f32 form: row = 4 (lane >> 4) + reg.)
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct Acc32f { v4f t[2][2]; };
+template <bool SYM = false, class FA, class FB>
+__device__ __forceinline__ Acc32f mfma_32_f32(const int lane, FA a_at, FB b_at) {
+    Acc32f c;
+    c.t[0][0] = c.t[0][1] = c.t[1][0] = c.t[1][1] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for(int kk = 0; kk < 32; kk += 4) {
+        const int k = kk + kq;
+        const float a0 = (float)a_at(r, k), b0 = (float)b_at(k, r), b1 = (float)b_at(k, r + 16);
+        c.t[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, c.t[0][0], 0, 0, 0);
+        c.t[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, c.t[0][1], 0, 0, 0);
+        const float a1 = (float)a_at(r + 16, k);
+        if constexpr(!SYM) c.t[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, c.t[1][0], 0, 0, 0);
+        c.t[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, c.t[1][1], 0, 0, 0);
+    }
+    return c;
+}
+template <bool SYM = false>
+__device__ __forceinline__ void acc32f_store(const Acc32f& c, const int lane, double* M) {
+#pragma unroll
+    for(int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for(int tj = 0; tj < 2; ++tj) {
+            if(SYM && ti == 1 && tj == 0) continue;
+#pragma unroll
+            for(int r = 0; r < 4; ++r) {
+                const double v = (double)c.t[ti][tj][r];
+                M[(16 * ti + 4 * (lane >> 4) + r) * PP + 16 * tj + (lane & 15)] = v;
+                if(SYM && ti == 0 && tj == 1) M[(16 + (lane & 15)) * PP + 4 * (lane >> 4) + r] = v;   // its mirror image
+            }
+        }
+}
+
 // one phase of the odd-even Jacobi ordering on the register-resident rows (b: B, u: U, dg: diagonal of B).
 // Round 4: FAST rotations.  A rotation applied as (x, y) <- (c x + s y, c y - s x) is two multiplications and two multiply-adds per pair
 // of entries; written (x, y) <- c (x + t y), c (y - t x) the factor c can stay outside, in one scale per row / column: the registers hold
@@ -640,20 +678,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __syncthreads();
     {
-        const Acc32 pp = mfma_32_full<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
+        const Acc32f pp = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
         __syncthreads();
-        acc32_store_full<true>(pp, lane, sB);                                                            // R1 R1
+        acc32f_store<true>(pp, lane, sB);                                                           // R1 R1
     }
     __syncthreads();
-    double f[32];   // row i (lanes 0..31) of X2, then of F, then of the sum of the series
+    double f[32];   // row i (lanes 0..31) of R12 = R1 + R2 (X2 = diag(a) + R12), then of F, then of the sum of the series
     const double hrt = 0.5 / rt;
     if(h == 0) {
 #pragma unroll
         for(int j = 0; j < 32; j += 2) {
             const double2 p2 = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
             const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j + 1]));
-            f[j] = (j == i) ? rt - p2.x * hrt : (double)r0 * (e[j] - p2.x);                      // X2 = diag(a) + R1 + R2
-            f[j + 1] = (j + 1 == i) ? rt - p2.y * hrt : (double)r1 * (e[j + 1] - p2.y);
+            f[j] = (j == i) ? -(p2.x * hrt) : (double)r0 * (e[j] - p2.x);                          // R12 = R1 + R2,  R2 = -(R1 R1) o rinv
+            f[j + 1] = (j + 1 == i) ? -(p2.y * hrt) : (double)r1 * (e[j + 1] - p2.y);
             double2 xx; xx.x = f[j]; xx.y = f[j + 1];
             *reinterpret_cast<double2*>(&sA[i * PP + j]) = xx;
         }
@@ -664,19 +702,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __syncthreads();
     {
-        const Acc32 x2 = mfma_32_full<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
+        const Acc32f x2 = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
         __syncthreads();
-        acc32_store_full<true>(x2, lane, sB);                                                            // X2 X2
+        acc32f_store<true>(x2, lane, sB);                                                           // R12 R12
     }
     __syncthreads();
     if(h == 0) {
 #pragma unroll
         for(int j = 0; j < 32; j += 2) {
             const double2 q2 = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
-            const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j + 1]));
-            // R = X2 - diag(a) + (M - X2 X2) o rinv;   F = E + sqrt(c) R   (M(i, i) = c + d_i, rinv(i, i) = 1 / (2 a_i))
-            const double ra = (j == i) ? (f[j] - rt) + ((c + ei) - q2.x) * hrt : f[j] + (e[j] - q2.x) * (double)r0;
-            const double rb = (j + 1 == i) ? (f[j + 1] - rt) + ((c + ei) - q2.y) * hrt : f[j + 1] + (e[j + 1] - q2.y) * (double)r1;
+            const double s0 = rt + s_rt[j], s1 = rt + s_rt[j + 1];
+            const float r0 = __builtin_amdgcn_rcpf((float)s0), r1 = __builtin_amdgcn_rcpf((float)s1);
+            // R = R12 + (M - X2 X2) o rinv with X2 = diag(a) + R12:  M - X2 X2 = (M - diag(a)^2 - diag(a) R12 - R12 diag(a)) - R12 R12 -- the bracket
+            // is where the cancellation happens and is taken entry by entry in double precision, R12 R12 is a second-order term (float32 product);
+            // F = E + sqrt(c) R   (M(i, i) = c + d_i, rinv(i, i) = 1 / (2 a_i))
+            const double ma = (j == i) ? __builtin_fma(-rt, rt, c + ei) : e[j], mb = (j + 1 == i) ? __builtin_fma(-rt, rt, c + ei) : e[j + 1];
+            const double ra = f[j] + (__builtin_fma(-s0, f[j], ma) - q2.x) * ((j == i) ? hrt : (double)r0);
+            const double rb = f[j + 1] + (__builtin_fma(-s1, f[j + 1], mb) - q2.y) * ((j + 1 == i) ? hrt : (double)r1);
             double2 ff, hh;
             ff.x = (((j == i) ? 0.0 : e[j]) + sqc * ra) * s_dw[j];                                // F' = F diag(dw): T(k+1) = T(k) F' needs no scaling pass
             ff.y = (((j + 1 == i) ? 0.0 : e[j + 1]) + sqc * rb) * s_dw[j + 1];
@@ -691,9 +733,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll 1
     for(int term = 0; term < 3; ++term) {   // T(k+1) = T(k) F'
         // (T(k) = (diag(dw) F)^k diag(dw) F diag(dw) is symmetric: F is, and (D F)^k D = D (F D)^k)
-        const Acc32 tt = mfma_32_full<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
+        const Acc32f tt = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
         __syncthreads();
-        acc32_store_full<true>(tt, lane, sA);
+        acc32f_store<true>(tt, lane, sA);
         __syncthreads();
         if(h == 0) {
 #pragma unroll
