@@ -907,7 +907,8 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
     a.gram = ws.gram.get((size_t)a.ntiles * EN * EN);
     a.debug = timing_env("GPP_ENSI_DEBUG") ? atoi(timing_env("GPP_ENSI_DEBUG")) : 0;
-    a.jtol2 = g_ensi_converge ? 0.0 : GPP_ENSI_JTOL2;   // gpp_ensi_set_convergence(1): the Jacobi sweeps run to convergence (no perturbation series to speak of)
+    a.jtol2 = g_ensi_converge ? 0.0 : GPP_ENSI_JTOL2;
+    if(const char* jt = timing_env("GPP_ENSI_JTOL")) { if(!g_ensi_converge) { const double v = atof(jt); a.jtol2 = v * v; } }   // (experiments: |E| <= v c)   // gpp_ensi_set_convergence(1): the Jacobi sweeps run to convergence (no perturbation series to speak of)
     a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.err = ws.err.p; a.counters = ws.counters.p;
     // cells with more than 32 usable observations go to k_ensi_big (scalar structure functions; the spatially varying forms

@@ -27,6 +27,12 @@
 
 typedef int v2i __attribute__((ext_vector_type(2)));
 
+#ifndef GPP_ENSI_NSQ
+#define GPP_ENSI_NSQ 3    // steps of the square-root iteration in k_ensi_members (NSQ - 1 products)
+#endif
+#ifndef GPP_ENSI_NNEU
+#define GPP_ENSI_NNEU 3   // products of the Neumann series of the inverse in k_ensi_members (terms T1 .. T(NNEU))
+#endif
 #ifndef GPP_ENSI_JCHUNK
 #define GPP_ENSI_JCHUNK 4   // double phases between two tests of the off-diagonal norm in k_ensi_pair (4 = a quarter of a sweep)
 #endif
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double* const s_sD1 = s_small, * const s_z1 = s_small + 32, * const s_t = s_small + 64, * const s_r1 = s_small + 96, * const s_dw = s_small + 128,
           * const s_rt = s_small + 160;
     double* const s_qt = s_t;                                     // member update: the Q columns of up to four tail members, [pair][row][2] (s_t .. s_rt are free then)
-    __shared__ int s_i[128];                                      // perm[32] | obs[32] | yhat[32] (floats) | selection[32]
+    __shared__ int s_i[160];                                      // perm[32] | obs[32] | yhat[32] | rho[32] (floats) | selection[32]
     double* const sA = s_ab;
     double* const sB = s_ab + 32 * PP;
     float* const sBf = reinterpret_cast<float*>(sB);             // Y tile [32][YP] floats
@@ -590,6 +596,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float* const s_ob = reinterpret_cast<float*>(s_i + 32);
     float* const s_yh = reinterpret_cast<float*>(s_i + 64);
     unsigned* const s_sel = reinterpret_cast<unsigned*>(s_i + 96);
+    float* const s_rho = reinterpret_cast<float*>(s_i + 128);
     const int lane = threadIdx.x;
     const int h = lane >> 5, i = lane & 31;
     const int nV = a.nV, E = a.E;
@@ -640,7 +647,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double rt = sqrt(c + S);                    // a_i
     const double dwv = -1.0 / (rt * (rt + sqc));      // W_sym = I + A^T g(B) A,  g(S) = -1 / (a (a + sqrt(c))),  a = sqrt(c + S)
     const double inv = 1.0 / (c + S);
-    if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = p_sD; s_r1[i] = p_r1; s_dw[i] = dwv; s_rt[i] = rt; }
+    // (what the anti-extrapolation tables need of the observations waits in LDS, not in registers, through the series below)
+    if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = p_sD; s_r1[i] = p_r1; s_dw[i] = dwv; s_rt[i] = rt; s_ob[i] = o1.y; s_yh[i] = o1.z; s_rho[i] = rho; }
     __syncthreads();
     EPROF(0)   // park loads, spectral scalars
 #ifdef GPP_ENSI_ESTATS
@@ -666,62 +674,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     //      instead of the third / fourth powers -- the one value in 10^6 of the round-3 soak outside the plain 1e-5 measure was a float32
     //      rounding of a member sum falling the other way under a residual of that size in W.
     //      (rinv comes from v_rcp_f32: its 1e-7 enters every step, and every following step corrects it: left over is 1e-7 of R3.)
-    if(h == 0) {
-#pragma unroll
-        for(int j = 0; j < 32; j += 2) {
-            double2 v;
-            const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j + 1]));
-            v.x = (j == i) ? 0.0 : e[j] * (double)r0;
-            v.y = (j + 1 == i) ? 0.0 : e[j + 1] * (double)r1;
-            *reinterpret_cast<double2*>(&sA[i * PP + j]) = v;                                   // R1
-        }
-    }
-    __syncthreads();
-    {
-        const Acc32f pp = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
-        __syncthreads();
-        acc32f_store<true>(pp, lane, sB);                                                           // R1 R1
-    }
-    __syncthreads();
-    double f[32];   // row i (lanes 0..31) of R12 = R1 + R2 (X2 = diag(a) + R12), then of F, then of the sum of the series
+    // square root: R(k+1) = R(k) + (M - diag(a)^2 - diag(a) R(k) - R(k) diag(a) - R(k) R(k)) o rinv, R(0) = 0 -- the bracket without the product is
+    // where the cancellation happens and is taken entry by entry in double precision; R(k) R(k) is a second-order term (float32 product)
+    double f[32];   // row i (lanes 0..31) of R(k), then of F, then of the sum of the series
     const double hrt = 0.5 / rt;
-    if(h == 0) {
+    const double mdiag = __builtin_fma(-rt, rt, c + ei);   // M(i, i) - a_i^2 (0 up to the rounding of the square root; d_i itself for a negative estimate)
 #pragma unroll
-        for(int j = 0; j < 32; j += 2) {
-            const double2 p2 = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
-            const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j + 1]));
-            f[j] = (j == i) ? -(p2.x * hrt) : (double)r0 * (e[j] - p2.x);                          // R12 = R1 + R2,  R2 = -(R1 R1) o rinv
-            f[j + 1] = (j + 1 == i) ? -(p2.y * hrt) : (double)r1 * (e[j + 1] - p2.y);
-            double2 xx; xx.x = f[j]; xx.y = f[j + 1];
-            *reinterpret_cast<double2*>(&sA[i * PP + j]) = xx;
+    for(int j = 0; j < 32; j += 2) {
+        const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j + 1]));
+        f[j] = (h != 0) ? 0.0 : ((j == i) ? mdiag * hrt : e[j] * (double)r0);                     // R(1) = (M - diag(a)^2) o rinv
+        f[j + 1] = (h != 0) ? 0.0 : ((j + 1 == i) ? mdiag * hrt : e[j + 1] * (double)r1);
+    }
+#pragma unroll
+    for(int step = 1; step < GPP_ENSI_NSQ; ++step) {
+        if(h == 0) {
+#pragma unroll
+            for(int j = 0; j < 32; j += 2) { double2 xx; xx.x = f[j]; xx.y = f[j + 1]; *reinterpret_cast<double2*>(&sA[i * PP + j]) = xx; }
         }
-    }
-    else {
-#pragma unroll
-        for(int j = 0; j < 32; ++j) f[j] = 0.0;
-    }
-    __syncthreads();
-    {
-        const Acc32f x2 = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
         __syncthreads();
-        acc32f_store<true>(x2, lane, sB);                                                           // R12 R12
+        {
+            const Acc32f rr = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
+            __syncthreads();
+            acc32f_store<true>(rr, lane, sB);                                                       // R(k) R(k)
+        }
+        __syncthreads();
+        if(h == 0) {
+#pragma unroll
+            for(int j = 0; j < 32; j += 2) {
+                const double2 q2 = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
+                const double s0 = rt + s_rt[j], s1 = rt + s_rt[j + 1];
+                const float r0 = __builtin_amdgcn_rcpf((float)s0), r1 = __builtin_amdgcn_rcpf((float)s1);
+                const double ma = (j == i) ? mdiag : e[j], mb = (j + 1 == i) ? mdiag : e[j + 1];
+                f[j] += (__builtin_fma(-s0, f[j], ma) - q2.x) * ((j == i) ? hrt : (double)r0);
+                f[j + 1] += (__builtin_fma(-s1, f[j + 1], mb) - q2.y) * ((j + 1 == i) ? hrt : (double)r1);
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if(h == 0) {
 #pragma unroll
         for(int j = 0; j < 32; j += 2) {
-            const double2 q2 = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
-            const double s0 = rt + s_rt[j], s1 = rt + s_rt[j + 1];
-            const float r0 = __builtin_amdgcn_rcpf((float)s0), r1 = __builtin_amdgcn_rcpf((float)s1);
-            // R = R12 + (M - X2 X2) o rinv with X2 = diag(a) + R12:  M - X2 X2 = (M - diag(a)^2 - diag(a) R12 - R12 diag(a)) - R12 R12 -- the bracket
-            // is where the cancellation happens and is taken entry by entry in double precision, R12 R12 is a second-order term (float32 product);
-            // F = E + sqrt(c) R   (M(i, i) = c + d_i, rinv(i, i) = 1 / (2 a_i))
-            const double ma = (j == i) ? __builtin_fma(-rt, rt, c + ei) : e[j], mb = (j + 1 == i) ? __builtin_fma(-rt, rt, c + ei) : e[j + 1];
-            const double ra = f[j] + (__builtin_fma(-s0, f[j], ma) - q2.x) * ((j == i) ? hrt : (double)r0);
-            const double rb = f[j + 1] + (__builtin_fma(-s1, f[j + 1], mb) - q2.y) * ((j + 1 == i) ? hrt : (double)r1);
+            // F = E + sqrt(c) R
             double2 ff, hh;
-            ff.x = (((j == i) ? 0.0 : e[j]) + sqc * ra) * s_dw[j];                                // F' = F diag(dw): T(k+1) = T(k) F' needs no scaling pass
-            ff.y = (((j + 1 == i) ? 0.0 : e[j + 1]) + sqc * rb) * s_dw[j + 1];
+            ff.x = (((j == i) ? 0.0 : e[j]) + sqc * f[j]) * s_dw[j];                              // F' = F diag(dw): T(k+1) = T(k) F' needs no scaling pass
+            ff.y = (((j + 1 == i) ? 0.0 : e[j + 1]) + sqc * f[j + 1]) * s_dw[j + 1];
             hh.x = dwv * ff.x; hh.y = dwv * ff.y;
             *reinterpret_cast<double2*>(&sB[i * PP + j]) = ff;                                   // F' (row i is this lane's own)
             *reinterpret_cast<double2*>(&sA[i * PP + j]) = hh;                                   // T0 = H = diag(dw) F' 
@@ -731,7 +727,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __syncthreads();
 #pragma unroll 1
-    for(int term = 0; term < 3; ++term) {   // T(k+1) = T(k) F'
+    for(int term = 0; term < GPP_ENSI_NNEU; ++term) {   // T(k+1) = T(k) F'
         // (T(k) = (diag(dw) F)^k diag(dw) F diag(dw) is symmetric: F is, and (D F)^k D = D (F D)^k)
         const Acc32f tt = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
         __syncthreads();
@@ -820,14 +816,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if(!a.allow_extrap) {
             const bool tr_l = (meta & 0x100u) != 0u;
             unsigned long long* const s_k64 = reinterpret_cast<unsigned long long*>(s_t);   // 32 keys (s_t is free again)
-            if(h == 0) s_k64[i] = (i < n) ? (((tr_l ? (unsigned long long)__float_as_uint(rho) << 32 : 0ull)) | (unsigned)(~orig_i)) : 0ull;
+            if(h == 0) s_k64[i] = (i < n) ? (((tr_l ? (unsigned long long)__float_as_uint(s_rho[i]) << 32 : 0ull)) | (unsigned)(~s_sel[i])) : 0ull;
             __syncthreads();
             if(h == 0 && i < n) {
                 const unsigned long long mine = s_k64[i];
                 int rank = 0;
                 for(int j = 0; j < n; ++j) rank += (s_k64[j] > mine) ? 1 : 0;
-                s_perm[rank] = (int)orig_i;
-                s_ob[i] = o1.y; s_yh[i] = o1.z;
+                s_perm[rank] = (int)s_sel[i];
             }
             __syncthreads();
         }
