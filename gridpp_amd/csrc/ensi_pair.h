@@ -675,76 +675,111 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     //      rounding of a member sum falling the other way under a residual of that size in W.
     //      (rinv comes from v_rcp_f32: its 1e-7 enters every step, and every following step corrects it: left over is 1e-7 of R3.)
     // square root: R(k+1) = R(k) + (M - diag(a)^2 - diag(a) R(k) - R(k) diag(a) - R(k) R(k)) o rinv, R(0) = 0 -- the bracket without the product is
-    // where the cancellation happens and is taken entry by entry in double precision; R(k) R(k) is a second-order term (float32 product)
-    double f[32];   // row i (lanes 0..31) of R(k), then of F, then of the sum of the series
-    const double hrt = 0.5 / rt;
-    const double mdiag = __builtin_fma(-rt, rt, c + ei);   // M(i, i) - a_i^2 (0 up to the rounding of the square root; d_i itself for a negative estimate)
-#pragma unroll
-    for(int j = 0; j < 32; j += 2) {
-        const float r0 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j])), r1 = __builtin_amdgcn_rcpf((float)(rt + s_rt[j + 1]));
-        f[j] = (h != 0) ? 0.0 : ((j == i) ? mdiag * hrt : e[j] * (double)r0);                     // R(1) = (M - diag(a)^2) o rinv
-        f[j + 1] = (h != 0) ? 0.0 : ((j + 1 == i) ? mdiag * hrt : e[j + 1] * (double)r1);
-    }
-#pragma unroll
-    for(int step = 1; step < GPP_ENSI_NSQ; ++step) {
-        if(h == 0) {
-#pragma unroll
-            for(int j = 0; j < 32; j += 2) { double2 xx; xx.x = f[j]; xx.y = f[j + 1]; *reinterpret_cast<double2*>(&sA[i * PP + j]) = xx; }
-        }
-        __syncthreads();
-        {
-            const Acc32f rr = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
-            __syncthreads();
-            acc32f_store<true>(rr, lane, sB);                                                       // R(k) R(k)
-        }
-        __syncthreads();
-        if(h == 0) {
-#pragma unroll
-            for(int j = 0; j < 32; j += 2) {
-                const double2 q2 = *reinterpret_cast<const double2*>(&sB[i * PP + j]);
-                const double s0 = rt + s_rt[j], s1 = rt + s_rt[j + 1];
-                const float r0 = __builtin_amdgcn_rcpf((float)s0), r1 = __builtin_amdgcn_rcpf((float)s1);
-                const double ma = (j == i) ? mdiag : e[j], mb = (j + 1 == i) ? mdiag : e[j + 1];
-                f[j] += (__builtin_fma(-s0, f[j], ma) - q2.x) * ((j == i) ? hrt : (double)r0);
-                f[j + 1] += (__builtin_fma(-s1, f[j + 1], mb) - q2.y) * ((j + 1 == i) ? hrt : (double)r1);
-            }
-        }
-        __syncthreads();
-    }
+    // where the cancellation happens and is taken entry by entry in double precision; R(k) R(k) is a second-order term (float32 product).
+    // The whole series runs in the register layout of the matrix-core results (lane (kq, r16), register r of tile (ti, tj): row 16 ti + 4 kq + r,
+    // column 16 tj + r16; the three tiles on and above the diagonal, the fourth is their mirror image): twelve entries a lane and ALL lanes at
+    // work on the entry-wise parts, where the row layout kept 32 entries in each of 32 lanes -- those parts, not the products, were what a step
+    // of the series cost (tools/ensi_order_sweep.sh: 5 / 10 ms per step on config 5 against 2 ms of matrix-core time).  The operands of the
+    // products are staged as floats (pitch PPF).
+    constexpr int PPF = 33;
+    float* const sAf = reinterpret_cast<float*>(sA);
+    float* const sBf2 = reinterpret_cast<float*>(sB);
+    const int tr16 = lane & 15, tkq = lane >> 4;
+    double et[3][4], ft[3][4];   // E (diagonal: M(i, i) - a_i^2) and R(k) / the sum of the series; tiles (0,0), (0,1), (1,1)
+    float rinvt[3][4];
     if(h == 0) {
 #pragma unroll
-        for(int j = 0; j < 32; j += 2) {
-            // F = E + sqrt(c) R
-            double2 ff, hh;
-            ff.x = (((j == i) ? 0.0 : e[j]) + sqc * f[j]) * s_dw[j];                              // F' = F diag(dw): T(k+1) = T(k) F' needs no scaling pass
-            ff.y = (((j + 1 == i) ? 0.0 : e[j + 1]) + sqc * f[j + 1]) * s_dw[j + 1];
-            hh.x = dwv * ff.x; hh.y = dwv * ff.y;
-            *reinterpret_cast<double2*>(&sB[i * PP + j]) = ff;                                   // F' (row i is this lane's own)
-            *reinterpret_cast<double2*>(&sA[i * PP + j]) = hh;                                   // T0 = H = diag(dw) F' 
-            f[j] = ((j == i) ? dwv : 0.0) + hh.x;                                                // running sum: diag(dw) + T0
-            f[j + 1] = ((j + 1 == i) ? dwv : 0.0) + hh.y;
+        for(int j = 0; j < 32; j += 2) { double2 v; v.x = e[j]; v.y = e[j + 1]; *reinterpret_cast<double2*>(&sA[i * PP + j]) = v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for(int t = 0; t < 3; ++t) {
+        const int ti = t >> 1, tj = (t + 1) >> 1;   // (0,0), (0,1), (1,1)
+        const double acol = s_rt[16 * tj + tr16];
+#pragma unroll
+        for(int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + 4 * tkq + r, col = 16 * tj + tr16;
+            const double arow = s_rt[row];
+            const double v = sA[row * PP + col];
+            const bool isd = ti == tj && row == col;
+            et[t][r] = isd ? __builtin_fma(-arow, arow, c + v) : v;   // M(i, i) - a_i^2: 0 up to the rounding of the square root; d_i itself for a negative estimate
+            rinvt[t][r] = __builtin_amdgcn_rcpf((float)(arow + acol));
+            ft[t][r] = et[t][r] * (double)rinvt[t][r];                 // R(1) = (M - diag(a)^2) o rinv
+        }
+    }
+    __syncthreads();   // (area A is read)
+    auto stage_sym = [&](float* const M, const int t, const int r, const float v) {   // entry (t, r) of a symmetric matrix and its mirror image
+        const int ti = t >> 1, tj = (t + 1) >> 1;
+        const int row = 16 * ti + 4 * tkq + r, col = 16 * tj + tr16;
+        M[row * PPF + col] = v;
+        if(t == 1) M[col * PPF + row] = v;
+    };
+#pragma unroll 1
+    for(int step = 1; step < GPP_ENSI_NSQ; ++step) {
+#pragma unroll
+        for(int t = 0; t < 3; ++t)
+#pragma unroll
+            for(int r = 0; r < 4; ++r) stage_sym(sAf, t, r, (float)ft[t][r]);
+        __syncthreads();
+        const Acc32f rr = mfma_32_f32<true>(lane, [&](int r, int k) { return sAf[r * PPF + k]; }, [&](int k, int cc) { return sAf[k * PPF + cc]; });   // R(k) R(k)
+#pragma unroll
+        for(int t = 0; t < 3; ++t) {
+            const int ti = t >> 1, tj = (t + 1) >> 1;
+            const double acol = s_rt[16 * tj + tr16];
+#pragma unroll
+            for(int r = 0; r < 4; ++r) {
+                const double ssum = s_rt[16 * ti + 4 * tkq + r] + acol;
+                ft[t][r] += (__builtin_fma(-ssum, ft[t][r], et[t][r]) - (double)rr.t[ti][tj][r]) * (double)rinvt[t][r];
+            }
+        }
+        __syncthreads();   // (the operands are read)
+    }
+    // F = E + sqrt(c) R;  F' = F diag(dw) (T(k+1) = T(k) F' needs no scaling pass) -> area B, T0 = H = diag(dw) F' -> area A, running sum: diag(dw) + T0
+#pragma unroll
+    for(int t = 0; t < 3; ++t) {
+        const int ti = t >> 1, tj = (t + 1) >> 1;
+        const double dwc = s_dw[16 * tj + tr16];
+#pragma unroll
+        for(int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + 4 * tkq + r, col = 16 * tj + tr16;
+            const bool isd = ti == tj && row == col;
+            const double dwr = s_dw[row];
+            const double fv = (isd ? 0.0 : et[t][r]) + sqc * ft[t][r];
+            const double t0 = dwr * fv * dwc;
+            sBf2[row * PPF + col] = (float)(fv * dwc);
+            if(t == 1) sBf2[col * PPF + row] = (float)(fv * dwr);      // (F is symmetric, F' is not)
+            stage_sym(sAf, t, r, (float)t0);
+            ft[t][r] = (isd ? dwr : 0.0) + t0;
         }
     }
     __syncthreads();
 #pragma unroll 1
     for(int term = 0; term < GPP_ENSI_NNEU; ++term) {   // T(k+1) = T(k) F'
         // (T(k) = (diag(dw) F)^k diag(dw) F diag(dw) is symmetric: F is, and (D F)^k D = D (F D)^k)
-        const Acc32f tt = mfma_32_f32<true>(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
-        __syncthreads();
-        acc32f_store<true>(tt, lane, sA);
-        __syncthreads();
-        if(h == 0) {
+        const Acc32f tt = mfma_32_f32<true>(lane, [&](int r, int k) { return sAf[r * PPF + k]; }, [&](int k, int cc) { return sBf2[k * PPF + cc]; });
 #pragma unroll
-            for(int j = 0; j < 32; j += 2) {
-                const double2 t2 = *reinterpret_cast<const double2*>(&sA[i * PP + j]);
-                f[j] += t2.x; f[j + 1] += t2.y;
-            }
+        for(int t = 0; t < 3; ++t)
+#pragma unroll
+            for(int r = 0; r < 4; ++r) ft[t][r] += (double)tt.t[t >> 1][(t + 1) >> 1][r];
+        __syncthreads();   // (T(k) is read)
+        if(term + 1 < GPP_ENSI_NNEU) {
+#pragma unroll
+            for(int t = 0; t < 3; ++t)
+#pragma unroll
+                for(int r = 0; r < 4; ++r) stage_sym(sAf, t, r, tt.t[t >> 1][(t + 1) >> 1][r]);
         }
+        __syncthreads();
     }
-    __syncthreads();
-    if(h == 0) {
+    // the middle matrix of W_sym -> area A (doubles, row major)
 #pragma unroll
-        for(int j = 0; j < 32; j += 2) { double2 g; g.x = f[j]; g.y = f[j + 1]; *reinterpret_cast<double2*>(&sA[i * PP + j]) = g; }   // the middle matrix of W_sym
+    for(int t = 0; t < 3; ++t) {
+        const int ti = t >> 1, tj = (t + 1) >> 1;
+#pragma unroll
+        for(int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + 4 * tkq + r, col = 16 * tj + tr16;
+            sA[row * PP + col] = ft[t][r];
+            if(t == 1) sA[col * PP + row] = ft[t][r];
+        }
     }
     __syncthreads();
     EPROF(1)   // perturbation series (five products)
