@@ -169,10 +169,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // eig_sym gives, to the ~1e-13 the iteration is stopped at.  A grid point that does not converge (non-finite input) is listed for
 // k_ensi_huge, whose Jacobi reproduces the reference's rcond <= 0 passthrough.
 #ifndef GPP_ENSI_JTOL2
-#define GPP_ENSI_JTOL2 4.0e-4   // stopping threshold of the Jacobi sweeps of k_ensi_pair, relative to c^2: |E| <= 0.020 c.  Round 3: 0.010 c with a series of
-                                // three products (tools/ensi_soak.py: 1 value in 0.9 M outside the plain 1e-5 measure, worst 1.19e-5).  Round 4: the series has
-                                // five products (ensi_pair.h) and the threshold is 0.020 c -- the same time on config 5 (294.6 ms; 0.010 c: 322 ms,
-                                // 0.015 c: 304 ms, 0.030 c: 283 ms) and NO value of the soak outside the plain measure (worst 5.4e-7 up to 0.020 c, 6.0e-6 at 0.030 c)
+#define GPP_ENSI_JTOL2 1.6e-3   // stopping threshold of the Jacobi sweeps of k_ensi_pair, relative to c^2: |E| <= 0.040 c.  Round 3: 0.010 c with a series of
+                                // three products (tools/ensi_soak.py: 1 value in 0.9 M outside the plain 1e-5 measure, worst 1.19e-5).  Round 4: five products
+                                // and 0.020 c (NO value of the soak outside the plain measure), then seven float32 products in the tile layout and 0.040 c
+                                // (ensi_pair.h, k_ensi_members: the same worst deviation as the converged sweeps, 2.5e-6; 0.050 c: 4.1e-6)
 #endif
 #define NSP 65           // pitch of the three 64 x 64 matrices (doubles)
 template <bool SPATIAL, bool FULL>   // FULL: 49..64 valid members (all four tile rows: strips); else the tiles on and above the diagonal

@@ -28,10 +28,10 @@
 typedef int v2i __attribute__((ext_vector_type(2)));
 
 #ifndef GPP_ENSI_NSQ
-#define GPP_ENSI_NSQ 3    // steps of the square-root iteration in k_ensi_members (NSQ - 1 products)
+#define GPP_ENSI_NSQ 4    // steps of the square-root iteration in k_ensi_members (NSQ - 1 products)
 #endif
 #ifndef GPP_ENSI_NNEU
-#define GPP_ENSI_NNEU 3   // products of the Neumann series of the inverse in k_ensi_members (terms T1 .. T(NNEU))
+#define GPP_ENSI_NNEU 4   // products of the Neumann series of the inverse in k_ensi_members (terms T1 .. T(NNEU))
 #endif
 #ifndef GPP_ENSI_JCHUNK
 #define GPP_ENSI_JCHUNK 4   // double phases between two tests of the off-diagonal norm in k_ensi_pair (4 = a quarter of a sweep)
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 off = half_sum_d(off, lane);
                 const double tr = half_sum_d(fabs(dg), lane);
-                // The sweeps stop at an off-diagonal norm |E| of sqrt(jtol2) * c = 0.020 c (c = nV - 1 bounds every eigenvalue of c I + B from
+                // The sweeps stop at an off-diagonal norm |E| of sqrt(jtol2) * c = 0.040 c (c = nV - 1 bounds every eigenvalue of c I + B from
                 // below): what is left of E enters the matrix functions in k_ensi_members as a perturbation series without eigenvalue
                 // gaps in any denominator (see there; measured against the LAPACK golden vectors the result stays at the float32
                 // rounding floor up to there, tools/ensi_tol.py), tested after every quarter of a sweep.  Most warm-started cells need no sweep at all that way (C5: 0.52
@@ -664,16 +664,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 #endif
     // ---- g(D + E) as a series in E, without eigenvalue gaps in any denominator.  With M = c I + D + E:
-    //        M^(1/2) = X = diag(a) + R1 + R2 + R3:  Newton steps on X^2 = M with the Sylvester operator of diag(a) kept fixed,
-    //                 R1 = E o rinv,   R2 = -(R1 R1) o rinv,   R3 = (M - X2^2) o rinv,   rinv(i, j) = 1 / (a_i + a_j)
-    //        g(D + E) = -(M + sqrt(c) M^(1/2))^-1 = -(P + F)^-1,   P = diag(a (a + sqrt(c))) = diag(-1 / dw),   F = E + sqrt(c) (R1 + R2 + R3)
-    //                 = diag(dw) + T0 + T1 + T2 + T3,   T0 = H = diag(dw) F diag(dw),   T(k+1) = (T(k) F) diag(dw)                     (Neumann)
+    //        M^(1/2) = X = diag(a) + R:  simplified Newton steps on X^2 = M with the Sylvester operator of diag(a) kept fixed,
+    //                 R(k+1) = R(k) + (M - (diag(a) + R(k))^2) o rinv,   R(0) = 0,   rinv(i, j) = 1 / (a_i + a_j)        (GPP_ENSI_NSQ steps)
+    //        g(D + E) = -(M + sqrt(c) M^(1/2))^-1 = -(P + F)^-1,   P = diag(a (a + sqrt(c))) = diag(-1 / dw),   F = E + sqrt(c) R
+    //                 = diag(dw) + T0 + T1 + ...,   T0 = H = diag(dw) F diag(dw),   T(k+1) = (T(k) F) diag(dw)          (Neumann, GPP_ENSI_NNEU products)
     //      The first-order part is the Daleckii-Krein term (1 + sqrt(c) / (a_i + a_j)) dw_i dw_j E_ij; the higher orders let the sweeps of
-    //      k_ensi_pair stop at |E| <= 0.020 c (0.010 c in round 3) -- most warm-started cells need no sweep at all then.  Round 4 added R3 and T3 (two more 32^3
-    //      products, five in all): what the series leaves is (|R1| / a)^4 ~ 6e-10 in the square root and (|F| / (2 c))^5 ~ 2e-11 in the inverse
-    //      instead of the third / fourth powers -- the one value in 10^6 of the round-3 soak outside the plain 1e-5 measure was a float32
-    //      rounding of a member sum falling the other way under a residual of that size in W.
-    //      (rinv comes from v_rcp_f32: its 1e-7 enters every step, and every following step corrects it: left over is 1e-7 of R3.)
+    //      k_ensi_pair stop early -- most warm-started cells need no sweep at all then.  Round 3: two steps / two products, |E| <= 0.010 c (one value
+    //      in 10^6 of the soak outside the plain 1e-5 measure: a float32 rounding of a member sum falling the other way under a residual of 1e-8
+    //      in W).  Round 4: three / three at 0.020 c -- what the series leaves is (|R1| / a)^4 / 2 <= 5e-9 and (|F| / (2 c))^5 <= 8e-10, nothing of
+    //      the soak outside --, then, with the steps at a quarter of their price (float32 products, tile layout: below), FOUR / FOUR at 0.040 c:
+    //      (|R1| / a)^5 / 2 <= 2e-9 and (|F| / (2 c))^6 <= 7e-10, the soak's worst deviation equal to that of the converged sweeps (2.5e-6),
+    //      config 5 237.8 -> 228 ms (tools/ensi_order_sweep.sh: every order against every threshold).
+    //      (rinv comes from v_rcp_f32: its 1e-7 enters every step, and every following step corrects it: left over is 1e-7 of the last step.)
     // square root: R(k+1) = R(k) + (M - diag(a)^2 - diag(a) R(k) - R(k) diag(a) - R(k) R(k)) o rinv, R(0) = 0 -- the bracket without the product is
     // where the cancellation happens and is taken entry by entry in double precision; R(k) R(k) is a second-order term (float32 product).
     // The whole series runs in the register layout of the matrix-core results (lane (kq, r16), register r of tile (ti, tj): row 16 ti + 4 kq + r,

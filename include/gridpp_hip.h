@@ -284,8 +284,8 @@ typedef struct gpp_ensi_stats {
 } gpp_ensi_stats;
 int gpp_ensi_last_stats(gpp_ensi_stats* stats);
 /* 1: the Jacobi sweeps of the per-cell eigenproblem run to convergence (reference-grade last bits, ~2x the time);
- * 0 (default): they stop at |off-diagonal| <= 0.020 (E - 1) and a perturbation series supplies the rest (since round 4 this
- * mode meets the plain 1e-5 measure on every value of the randomised soak as well: worst 5.4e-7).
+ * 0 (default): they stop at |off-diagonal| <= 0.040 (E - 1) and a perturbation series supplies the rest (since round 4 this
+ * mode meets the plain 1e-5 measure on every value of the randomised soak as well: worst 2.5e-6, the same as with converged sweeps).
  * Per calling thread. */
 int gpp_ensi_set_convergence(int to_convergence);
 

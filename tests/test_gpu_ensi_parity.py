@@ -27,7 +27,7 @@ def case(seed, Y, X, E, S, nan_member=None, nan_obs=False):
     return lats, lons, bg, plat, plon, pbg, obs, sig
 
 
-def run(c, h, max_points, allow=True, v=0, w=0, elev=False):
+def run(c, h, max_points, allow=True, v=0, w=0, elev=False, want_ref=True):
     import gridpp_amd as gridpp
     from oracle import oracle as O
     lats, lons, bg, plat, plon, pbg, obs, sig = c
@@ -38,6 +38,8 @@ def run(c, h, max_points, allow=True, v=0, w=0, elev=False):
     grid = gridpp.Grid(lats, lons, ge, ())
     points = gridpp.Points(plat, plon, pe, ())
     out = gridpp.optimal_interpolation_ensi(grid, bg, points, obs, sig, pbg, gridpp.BarnesStructure(h, v, w), max_points, allow)
+    if not want_ref:
+        return np.asarray(out), None
     og = O.Pts(lats.ravel(), lons.ravel(), ge.ravel() if elev else None)
     op = O.Pts(plat, plon, pe if elev else None)
     ref = O.oi_ensi(og, bg.reshape(-1, E), op, obs, sig, pbg, O.Barnes(h, v, w), max_points, allow).reshape(Y, X, E)

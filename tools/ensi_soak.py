@@ -11,7 +11,7 @@ from tests.ensi_golden import rel_err
 import gridpp_amd as gridpp
 from tests.test_gpu_ensi_parity import plain_err
 n_values = n_outside = 0
-worst_fast = worst_strict = 0.0
+worst_fast = worst_strict = worst_tile = 0.0
 strict_bad = []
 # argument: seconds, or a number of seeds as "400s" ("seeds": a run that does not depend on the speed of the box)
 arg = sys.argv[1] if len(sys.argv) > 1 else "60"
@@ -35,9 +35,10 @@ while (seed < nseeds) if nseeds else (time.time() - t0 < budget):
         assert err.max() < 1e-5, err.max()
         pe = plain_err(out, ref)
         n_values += pe.size; n_outside += int((pe >= 1e-5).sum()); worst_fast = max(worst_fast, float(pe.max()))
+        if 0 < mp <= 32: worst_tile = max(worst_tile, float(pe.max()))
         gridpp.ensi_set_convergence(True)
         try:
-            out_s, _ = run(c, h, mp, allow=allow, v=(200 if seed % 3 == 0 else 0), elev=(seed % 3 == 0))
+            out_s, _ = run(c, h, mp, allow=allow, v=(200 if seed % 3 == 0 else 0), elev=(seed % 3 == 0), want_ref=False)
         finally:
             gridpp.ensi_set_convergence(False)
         ps = plain_err(out_s, ref)
@@ -49,8 +50,8 @@ while (seed < nseeds) if nseeds else (time.time() - t0 < budget):
 print("seeds: %d (%d with max_points beyond the tile), failures: %d" % (seed, nbig, len(bad)))
 for b in bad[:10]:
     print(b)
-print("plain measure |out - ref| / max(|ref|, 1e-2): fast path %d of %d values outside 1e-5 (worst %.3g); converged sweeps: worst %.3g, %d configurations outside"
-      % (n_outside, n_values, worst_fast, worst_strict, len(strict_bad)))
+print("plain measure |out - ref| / max(|ref|, 1e-2): fast path %d of %d values outside 1e-5 (worst %.3g; worst of the configurations on the 32-row tile path alone %.3g); "
+      "converged sweeps: worst %.3g, %d configurations outside" % (n_outside, n_values, worst_fast, worst_tile, worst_strict, len(strict_bad)))
 ok = not bad and not strict_bad and n_outside == 0
 print("SOAK", "PASS" if ok else "FAIL")
 sys.exit(0 if ok else 1)
