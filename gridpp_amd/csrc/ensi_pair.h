@@ -70,6 +70,15 @@ __device__ __forceinline__ double half_sum_d(double v, const int lane) {
     return lane < 32 ? s0 : s1;
 }
 
+// v(lane) + v(lane ^ 32) in every lane: the upper half of one copy swapped with the lower half of another (v_permlane32_swap, gfx950)
+__device__ __forceinline__ double both_halves_sum_d(const double v, const int lane) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto sl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto sh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const unsigned olo = lane < 32 ? sl[1] : sl[0], ohi = lane < 32 ? sh[1] : sh[0];
+    return v + __hiloint2double((int)ohi, (int)olo);
+}
+
 // a value the optimiser cannot trace back to its load: keeps `select(load, load)` from becoming `load(select(address))`, which
 // would turn the register-resident rows into a dynamically indexed stack array
 __device__ __forceinline__ double opq(double x) { asm("" : "+v"(x)); return x; }
@@ -597,6 +606,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float* const s_yh = reinterpret_cast<float*>(s_i + 64);
     unsigned* const s_sel = reinterpret_cast<unsigned*>(s_i + 96);
     float* const s_rho = reinterpret_cast<float*>(s_i + 128);
+    __shared__ float s_v0[64];                                    // the members' values (first chunk) wait here through the spectral part
     const int lane = threadIdx.x;
     const int h = lane >> 5, i = lane & 31;
     const int nV = a.nV, E = a.E;
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     EPROF(11)   // (profile build: one small load alone, waited for: the latency of the memory system under this kernel's load)
 #endif
-    const float v0 = (lane < nV) ? a.bg[(long)cell_l * E + ensi_member(a, lane)] : 0.0f;
+    const float v0_ld = (lane < nV) ? a.bg[(long)cell_l * E + ensi_member(a, lane)] : 0.0f;
     const double* const park = a.cpark + ((size_t)blockIdx.x) * ENSI_PARK_D;
     const unsigned long long pk0 = __double_as_longlong(park[2144 + i]), pk1 = __double_as_longlong(park[2176 + i]);
     const float rho = (float)park[2112 + i];
@@ -648,6 +658,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double dwv = -1.0 / (rt * (rt + sqc));      // W_sym = I + A^T g(B) A,  g(S) = -1 / (a (a + sqrt(c))),  a = sqrt(c + S)
     const double inv = 1.0 / (c + S);
     // (what the anti-extrapolation tables need of the observations waits in LDS, not in registers, through the series below)
+    s_v0[lane] = v0_ld;
     if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = p_sD; s_r1[i] = p_r1; s_dw[i] = dwv; s_rt[i] = rt; s_ob[i] = o1.y; s_yh[i] = o1.z; s_rho[i] = rho; }
     __syncthreads();
     EPROF(0)   // park loads, spectral scalars
@@ -689,11 +700,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int tr16 = lane & 15, tkq = lane >> 4;
     double et[3][4], ft[3][4];   // E (diagonal: M(i, i) - a_i^2) and R(k) / the sum of the series; tiles (0,0), (0,1), (1,1)
     float rinvt[3][4];
-    if(h == 0) {
+    {   // rows of U^T B U (lanes 0..31) -> area A, rows of U (lanes 32..63) -> area B
+        double* const dst = h == 0 ? sA : sB;
 #pragma unroll
-        for(int j = 0; j < 32; j += 2) { double2 v; v.x = e[j]; v.y = e[j + 1]; *reinterpret_cast<double2*>(&sA[i * PP + j]) = v; }
+        for(int j = 0; j < 32; j += 2) { double2 v; v.x = e[j]; v.y = e[j + 1]; *reinterpret_cast<double2*>(&dst[i * PP + j]) = v; }
     }
     __syncthreads();
+    // ---- z = U (C + E)^-1 U^T r,  C = diag(c + S):  (C + E)^-1 = C^-1 - C^-1 E C^-1 + C^-1 E C^-1 E C^-1 - ...  (first: E and U are both staged now).
+    //      Every sum of 32 terms is split between the two lanes (h, i) of an index i, sixteen terms each, and put together with one
+    //      v_permlane32_swap per dword; the iterate alternates between two LDS vectors (one barrier a term).  Round 4: this block took
+    //      10 % of the kernel with the sums in lanes 0..31 alone, two barriers a term and the scalar unit in every step.
+    {
+        int jb = 16 * h;
+        asm volatile("" : "+v"(jb));   // (its own value: shared with the 16 h of the member update below, the index arithmetic stayed in registers across everything between)
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for(int rr = 0; rr < 16; rr += 2) {
+            p0 = __builtin_fma(sB[(jb + rr) * PP + i], s_r1[jb + rr], p0);
+            p1 = __builtin_fma(sB[(jb + rr + 1) * PP + i], s_r1[jb + rr + 1], p1);
+        }
+        double eh[16];   // E(i, 16 h + jj), diagonal zeroed
+#pragma unroll
+        for(int jj = 0; jj < 16; jj += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(&sA[i * PP + jb + jj]);
+            eh[jj] = (jb + jj == i) ? 0.0 : v.x; eh[jj + 1] = (jb + jj + 1 == i) ? 0.0 : v.y;
+        }
+        double vk = both_halves_sum_d(p0 + p1, lane) * inv;                                          // v0 = C^-1 U^T r
+        double tz = vk;
+        double* cur = s_t, * nxt = s_r1;   // (s_r1 is read: every lane's loads above are waited for by the barrier below)
+        __syncthreads();
+        if(h == 0) cur[i] = vk;
+        __syncthreads();
+        // (the series in E C^-1 has the ratio |E| / (c + S) <= 0.04 -- the stopping threshold of the sweeps --: eight terms leave 7e-12)
+#pragma unroll 1
+        for(int term = 1; term < 8; ++term) {
+            double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+            for(int jj = 0; jj < 16; jj += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(&cur[jb + jj]);
+                c0 = __builtin_fma(eh[jj], v.x, c0);
+                c1 = __builtin_fma(eh[jj + 1], v.y, c1);
+            }
+            vk = -inv * both_halves_sum_d(c0 + c1, lane);
+            tz += vk;
+            if(h == 0) nxt[i] = vk;
+            __syncthreads();
+            double* const tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if(h == 0) nxt[i] = tz;
+        __syncthreads();
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for(int jj = 0; jj < 16; jj += 2) {
+            const double2 u2 = *reinterpret_cast<const double2*>(&sB[i * PP + jb + jj]);
+            const double2 v = *reinterpret_cast<const double2*>(&nxt[jb + jj]);
+            z0 = __builtin_fma(u2.x, v.x, z0);
+            z1 = __builtin_fma(u2.y, v.y, z1);
+        }
+        const double zz = both_halves_sum_d(z0 + z1, lane);
+        if(h == 0) s_z1[i] = zz;
+    }
+    EPROF(2)   // z
 #pragma unroll
     for(int t = 0; t < 3; ++t) {
         const int ti = t >> 1, tj = (t + 1) >> 1;   // (0,0), (0,1), (1,1)
@@ -790,41 +857,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for(int j = 0; j < 32; j += 2) { double2 w; w.x = e[j]; w.y = e[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w; }
     }
     __syncthreads();
-    // ---- z = U (C + E)^-1 U^T r,  C = diag(c + S):  (C + E)^-1 = C^-1 - C^-1 E C^-1 + C^-1 E C^-1 E C^-1 - ...
-    if(h == 0) {
-        double ur0 = 0.0, ur1 = 0.0;
-#pragma unroll 8
-        for(int r = 0; r < 32; r += 2) { ur0 = __builtin_fma(sB[r * PP + i], s_r1[r], ur0); ur1 = __builtin_fma(sB[(r + 1) * PP + i], s_r1[r + 1], ur1); }
-        s_t[i] = (ur0 + ur1) * inv;                                                                // v0
-    }
-    __syncthreads();
-    double tz = s_t[i], vk = tz;
-    // (the series in E C^-1 has the ratio |E| / (c + S) <= 0.01: six terms leave 1e-12)
-#pragma unroll 1
-    for(int term = 1; term < 6; ++term) {
-        double c0 = 0.0, c1 = 0.0;
-        if(h == 0) {
-#pragma unroll
-            for(int j = 0; j < 32; j += 2) {
-                c0 = __builtin_fma((j == i) ? 0.0 : e[j], s_t[j], c0);
-                c1 = __builtin_fma((j + 1 == i) ? 0.0 : e[j + 1], s_t[j + 1], c1);
-            }
-        }
-        vk = -inv * (c0 + c1);
-        tz += vk;
-        __syncthreads();
-        if(h == 0) s_t[i] = vk;
-        __syncthreads();
-    }
-    if(h == 0) s_t[i] = tz;
-    __syncthreads();
-    if(h == 0) {
-        double zz0 = 0.0, zz1 = 0.0;
-#pragma unroll 8
-        for(int j = 0; j < 32; j += 2) { zz0 = __builtin_fma(sB[i * PP + j], s_t[j], zz0); zz1 = __builtin_fma(sB[i * PP + j + 1], s_t[j + 1], zz1); }
-        s_z1[i] = zz0 + zz1;
-    }
-    EPROF(2)   // z
     // M_W = U Mmid U^T, scaled: M'(i, j) = sD_i M_W(i, j) sD_j   -> area A (stays there for the whole member update)
     {
         const Acc32 tm = mfma_32_full(lane, [&](int r, int k) { return sB[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
@@ -865,11 +897,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         // ---- ensemble side: all 64 lanes, lane = member (chunks of 64) -----------------------------------------------------------------
         // ensemble mean: sequential float sum over the valid members in member order (oi_ensi.cpp:447-461)
+        const float v0 = s_v0[lane];
         float total = 0.0f;
         for(int m0 = 0; m0 < nV; m0 += 64) {
             const float v = (m0 == 0) ? v0 : ((m0 + lane < nV) ? a.bg[(long)cell_l * E + ensi_member(a, m0 + lane)] : 0.0f);
             const int kend = min(64, nV - m0);
-            for(int k = 0; k < kend; ++k) total += readlane_f(v, k);
+            // (blocks of 16 with the lane numbers as constants: with a loop counter as the lane select every step waits for the scalar unit,
+            //  and the chain of dependent additions is what this costs anyway)
+#pragma unroll
+            for(int b = 0; b < 4; ++b) {
+                if(16 * b + 16 <= kend) {
+#pragma unroll
+                    for(int j = 0; j < 16; ++j) total += readlane_f(v, 16 * b + j);
+                }
+            }
+            for(int k = kend & ~15; k < kend; ++k) total += readlane_f(v, k);
         }
         const float ensMean = total / (float)nV;
         EPROF(4)   // tables, ensemble mean
