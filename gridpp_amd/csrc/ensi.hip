@@ -1020,7 +1020,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     g_ensi_stats.condition_passthrough = (long long)npass + ((nV <= 1 && big_ok) ? (long long)nbig_cells : 0);
     if(timing_env("GPP_ENSI_STATS")) {
         unsigned long long sw = 0; for(int i = 0; i < 32; i++) sw += hc[4 + i];
-        fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (use_pair ? 0.25 : 1.0) * (double)sw / (double)hc[1] : 0.0);
+        fprintf(stderr, "[gpp] ensi: %llu cells solved, %.2f Jacobi sweeps per cell\n", hc[1], hc[1] ? (use_pair ? GPP_ENSI_JCHUNK / 16.0 : 1.0) * (double)sw / (double)hc[1] : 0.0);
         for(int sl = 0; sl < 1024; sl++) for(int i = 0; i < 12; i++) { hc[40 + i] += hc[80 + sl * 32 + i]; hc[60 + i] += hc[80 + sl * 32 + 16 + i]; }
         unsigned long long tot = 0; for(int i = 0; i < 12; i++) tot += hc[40 + i];
         unsigned long long tot2 = 0; for(int i = 0; i < 12; i++) tot2 += hc[60 + i];

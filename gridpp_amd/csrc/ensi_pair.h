@@ -34,7 +34,8 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #define GPP_ENSI_NNEU 4   // products of the Neumann series of the inverse in k_ensi_members (terms T1 .. T(NNEU))
 #endif
 #ifndef GPP_ENSI_JCHUNK
-#define GPP_ENSI_JCHUNK 4   // double phases between two tests of the off-diagonal norm in k_ensi_pair (4 = a quarter of a sweep)
+#define GPP_ENSI_JCHUNK 8   // double phases between two tests of the off-diagonal norm in k_ensi_pair (8 = half a sweep; config 5 with the 0.040 c threshold:
+                            // 1: 271 ms, 2: 244, 4: 224.5, 6: 221.2, 8: 219.9, 16: 220.9 -- the test is a chain of reductions the single wave of a SIMD waits for)
 #endif
 // ---- cross-lane moves of doubles on the VALU (DPP) -------------------------------------------------------------------------
 template <int CTRL, int BANK>
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 // The sweeps stop at an off-diagonal norm |E| of sqrt(jtol2) * c = 0.040 c (c = nV - 1 bounds every eigenvalue of c I + B from
                 // below): what is left of E enters the matrix functions in k_ensi_members as a perturbation series without eigenvalue
                 // gaps in any denominator (see there; measured against the LAPACK golden vectors the result stays at the float32
-                // rounding floor up to there, tools/ensi_tol.py), tested after every quarter of a sweep.  Most warm-started cells need no sweep at all that way (C5: 0.52
+                // rounding floor up to there, tools/ensi_tol.py), tested after every half of a sweep.  Most warm-started cells need no sweep at all that way (C5: 0.52
                 // sweeps per cell instead of 1.13 with a threshold of 1e-6 of the trace and only the first-order term)
                 const bool open = off > a.jtol2 * c * c && off > 1e-24 * tr * tr;   // (and never beyond what double precision resolves)
                 if(__ballot(open && !(dup && h == 1)) == 0ull) break;

@@ -171,6 +171,8 @@ def ensi_fp64(ny, nx, E, S, mp, kms):
             p = json.load(f)["ensi_C5"]
         if p["workload"] == "optimal_interpolation_ensi %dx%dx%d, %d obs, max_points=%d" % (ny, nx, E, S, mp):
             ex = 64.0 * (p["SQ_INSTS_VALU_ADD_F64"] + p["SQ_INSTS_VALU_MUL_F64"] + 2.0 * p["SQ_INSTS_VALU_FMA_F64"]) + 512.0 * p["SQ_INSTS_VALU_MFMA_MOPS_F64"]
+            if "SQ_INSTS_VALU_MFMA_MOPS_F32" in p:   # the perturbation series (round 4): float32 products beside the FP64 work, not part of the FP64 fraction
+                out["fp32_matrix_TFLOP_executed_per_call"] = 512.0 * p["SQ_INSTS_VALU_MFMA_MOPS_F32"] / 1e12
             out.update({"fp64_TFLOP_executed_per_call": ex / 1e12, "fp64_TFLOPs_executed": ex / (kms * 1e-3) / 1e12,
                         "frac_fp64_peak_executed": ex / (kms * 1e-3) / FP64_PEAK, "fp64_source": "committed_profile " + p.get("_source", "")})
     except (OSError, KeyError, ValueError):

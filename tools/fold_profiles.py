@@ -78,6 +78,11 @@ for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F64"):
     en[c] = total("ensi_pmc_sq", ["k_ensi"], c) / calls
 for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"):
     en[c] = total("ensi_pmc_fp64", ["k_ensi"], c) / calls
+try:    # (round 4: the perturbation series runs on the FP32 matrix path)
+    for c in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES"):
+        en[c] = total("ensi_pmc_mfma", ["k_ensi"], c) / calls
+except (OSError, KeyError):
+    pass
 out["ensi_C5"] = en
 
 qf = {"workload": "neighbourhood_quantile_fast 4000x4000x100, halfwidth 15, 11 thresholds", "_source": "profiles/r04_nbh_pmc_*.csv"}
