@@ -697,7 +697,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // products are staged as floats (pitch PPF).
     constexpr int PPF = 33;
     float* const sAf = reinterpret_cast<float*>(sA);
-    float* const sBf2 = reinterpret_cast<float*>(sB);
+    float* const sBf2 = sAf + 32 * PPF;                            // F' beside the T / R operands in area A: area B keeps the rows of U through the series
     const int tr16 = lane & 15, tkq = lane >> 4;
     double et[3][4], ft[3][4];   // E (diagonal: M(i, i) - a_i^2) and R(k) / the sum of the series; tiles (0,0), (0,1), (1,1)
     float rinvt[3][4];
@@ -853,11 +853,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __syncthreads();
     EPROF(1)   // perturbation series (five products)
-    if(h == 1) {   // U -> area B
-#pragma unroll
-        for(int j = 0; j < 32; j += 2) { double2 w; w.x = e[j]; w.y = e[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w; }
-    }
-    __syncthreads();
     // M_W = U Mmid U^T, scaled: M'(i, j) = sD_i M_W(i, j) sD_j   -> area A (stays there for the whole member update)
     {
         const Acc32 tm = mfma_32_full(lane, [&](int r, int k) { return sB[r * PP + k]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
