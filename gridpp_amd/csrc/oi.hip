@@ -1780,7 +1780,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
       fprintf(stderr, "[gpp] union phases (shader clocks per tile, %%):"); for(int i = 0; i < 11; i++) fprintf(stderr, " %s %.0f (%.1f%%);", nm[i], counters[20 + i] / (double)a.ntiles, 100.0 * counters[20 + i] / tot); fprintf(stderr, "\n"); }
 #endif
 #ifdef GPP_UNION_STATS
-    fprintf(stderr, "[gpp] union: fallback reasons: slots %llu, union>40 %llu, extras>12 %llu, layout %llu, per-cell extras>6 %llu; per tile: insertions %.1f, evictions %.1f, candidates %.1f, survivors %.1f\n",
+    fprintf(stderr, "[gpp] union: fallback reasons: slots %llu, union>40 %llu, extras>12 %llu, layout %llu, per-cell extras>6 %llu; per tile: insertions %.1f, evictions %.1f, candidates evaluated outside the bulk disc %.1f, records loaded in phase 2 %.1f\n",
                             counters[4], counters[5], counters[6], counters[7], counters[8], counters[9] / (double)a.ntiles, counters[10] / (double)a.ntiles, counters[11] / (double)a.ntiles, counters[12] / (double)a.ntiles);
 #endif
     if(timing_env("GPP_SCAN_STATS")) { fprintf(stderr, "[gpp] wave-level insertions per tile histogram:"); for(int i = 0; i < 70; i++) fprintf(stderr, " %d:%llu", i, counters[4 + i]); fprintf(stderr, "\n"); }

@@ -196,6 +196,21 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
     const float pb = sa.axis_b == 1 ? gy : (sa.axis_b == 2 ? gz : gx);
     const float amin_t = wave_min(active ? pa : INFINITY), amax_t = wave_max(active ? pa : -INFINITY);
     const float bmin_t = wave_min(active ? pb : INFINITY), bmax_t = wave_max(active ? pb : -INFINITY);
+    // Elevation / land-fraction extent of the tile (PLAIN: Barnes factors): a candidate outside it by dz can reach no cell with more than
+    // exp(-dz^2 / 2 v^2) of its horizontal factor -- the wave-level prune below adds that to the horizontal distance (round 4: on smooth
+    // terrain the worst kept rho of a cell is small, so the horizontal cut alone let 5 x as many candidates through as on flat ground, each
+    // evaluated for all 64 cells).  A cell without elevation takes the factor 1: then there is no extent.
+    float emin_t = -INFINITY, emax_t = INFINITY, lmin_t = -INFINITY, lmax_t = INFINITY, kv2 = 0.0f, kw2 = 0.0f;
+    if constexpr(PLAIN) {
+        if(d_valid(st.v) && st.v != 0.0f && d_valid(st.h) && st.h != 0.0f) {
+            emin_t = wave_min(active ? (d_valid(ge) ? ge : -INFINITY) : INFINITY); emax_t = wave_max(active ? (d_valid(ge) ? ge : INFINITY) : -INFINITY);
+            kv2 = (st.h / st.v) * (st.h / st.v) * 0.9999f;
+        }
+        if(d_valid(st.w) && st.w != 0.0f && d_valid(st.h) && st.h != 0.0f) {
+            lmin_t = wave_min(active ? (d_valid(gl) ? gl : -INFINITY) : INFINITY); lmax_t = wave_max(active ? (d_valid(gl) ? gl : INFINITY) : -INFINITY);
+            kw2 = (st.h / st.w) * (st.h / st.w) * 0.9999f;
+        }
+    }
     int cnt = 0;
     unsigned long long alloc = 0ull;   // allocated slots (wave-uniform)
     bool fb = false;                   // wave-uniform: this tile goes to k_oi
@@ -258,6 +273,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         unsigned wo = 0u;
         const float thr2_R = R * R * 1.000001f + 1e-30f;
         float thr2 = active ? thr2_R : -1.0f;
+        float bud2 = active ? INFINITY : -1.0f;   // the same threshold without the clamp to R^2: the budget for horizontal + vertical + laf terms (h^2 units)
 
         // projected (bin-axis) position of the tile centre and its half diagonal: a candidate whose projected distance to
         // the centre exceeds sqrt(largest threshold in the wave) + rad cannot be wanted by any cell (wave-level prune)
@@ -273,6 +289,19 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             if(t2 < 0.0f) return -1.0f;
             const float lim = (d_sqrt_raw(t2) + rad) * 1.0001f;
             return lim * lim;
+        };
+
+        // wave-level prune of the candidate a lane holds (pd: its projected distance^2 to the tile centre): inside the horizontal limit, and --
+        // once every cell of the wave has its max_points -- inside the largest budget with the elevation / laf distance to the tile's extent added
+        auto wave_bud2 = [&]() { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(bud2)))); };
+        auto keep = [&](const float pd, const float4& rec, const float2& met, const float lim2, const float B2) {
+            bool k = pd <= lim2;
+            if(PLAIN && B2 < INFINITY && (kv2 != 0.0f || kw2 != 0.0f)) {
+                const float sd = fmaxf(d_sqrt_raw(pd) * 0.9999f - rad, 0.0f);
+                const float dz = fmaxf(fmaxf(emin_t - rec.w, rec.w - emax_t), 0.0f), dl = fmaxf(fmaxf(lmin_t - met.x, met.x - lmax_t), 0.0f);   // (NaN: no distance)
+                k = k && (sd * sd + kv2 * dz * dz + kw2 * dl * dl <= B2);
+            }
+            return k;
         };
 
         // the candidates `mask` of one chunk of 64 records (lane c holds record c: rec, met, sorted position posv)
@@ -321,6 +350,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                 const int c = __builtin_ctzll(mask);
                 mask &= mask - 1ull;
                 const float rho = eval(rec, met, c);
+                if(UNION_STATS && lane == 0) atomicAdd(&a.counters[11], 1ull);   // candidates evaluated behind the wave-level prune
                 {
                 const unsigned orig = (unsigned)__builtin_amdgcn_readlane(__float_as_int(met.y), c);
                 // oi.cpp:253 (rho > 0) and :262-273 (keep the max_points largest, ties -> lower observation index)
@@ -359,7 +389,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                             }
                             else wo = (unsigned)L.worig[ws];
                         }
-                        if(prune && cnt == K) thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
+                        if(prune && cnt == K) { bud2 = -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2; thr2 = fminf(thr2_R, bud2); }
                     }
                 }
             }
@@ -449,7 +479,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                         }
                         wo = bo;
                     }
-                    if(prune && cnt == K) thr2 = fminf(thr2_R, -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2);
+                    if(prune && cnt == K) { bud2 = -2.0f * h2 * logf(wr) * 1.00002f + 2e-5f * h2; thr2 = fminf(thr2_R, bud2); }
                 };
                 // radius^2 (projected) holding at most min(max_points, slots) records: bisection with wave-wide counts
                 const int kb = min(K, U_WCAP);
@@ -472,9 +502,10 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                     const float hi2 = ring < 0 ? tlo : ((ring == NR - 1) ? INFINITY : hi * hi);
                     const float lim2 = wave_lim2();
                     if(lim2 < 0.0f || lo2 >= lim2) break;
-                    const unsigned long long m0 = wave_ballot(pd0 > lo2 && pd0 <= hi2 && pd0 <= lim2);
-                    const unsigned long long m1 = wave_ballot(pd1 > lo2 && pd1 <= hi2 && pd1 <= lim2);
-                    const unsigned long long m2 = wave_ballot(pd2 > lo2 && pd2 <= hi2 && pd2 <= lim2);
+                    const float B2 = wave_bud2();
+                    const unsigned long long m0 = wave_ballot(pd0 > lo2 && pd0 <= hi2 && keep(pd0, rec0, met0, lim2, B2));
+                    const unsigned long long m1 = wave_ballot(pd1 > lo2 && pd1 <= hi2 && keep(pd1, rec1, met1, lim2, B2));
+                    const unsigned long long m2 = wave_ballot(pd2 > lo2 && pd2 <= hi2 && keep(pd2, rec2, met2, lim2, B2));
                     if(ring >= 0 && bulk) end_bulk();
                     for(int k = 0; k < nchunk && !fb; ++k) {
                         const float4 rec = k == 0 ? rec0 : (k == 1 ? rec1 : rec2);
@@ -507,41 +538,65 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
 
         UPROF(3);   // ring loop
         // ---- phase 2: every remaining bin that can still matter, rows centre-out (x-extent and stop test from the largest
-        //      threshold in the wave), skipping the square phase 1 covered
-        for(int r = 0; !fb && !GPP_DBG(a, 4); ++r) {
+        //      threshold in the wave), skipping the square phase 1 covered.  Round 4: 32 bin rows at a time, one lane per row segment (left /
+        //      right of the phase-1 square: lanes 0..31 / 32..63) -- the bin offsets of all of them in one round of loads, their records packed
+        //      into chunks of 64.  Row by row, every band cost two dependent trips to memory for a handful of records (smooth terrain: the
+        //      thresholds stay wide, dozens of bands, 34 % of the kernel for 16 records per tile).  The order only changes the amount of work.
+        for(int b = 0; !fb && !GPP_DBG(a, 4); ++b) {
             const float t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
             if(t2 < 0.0f) break;
+            const int n0 = tby1 - tby0 + 1;
+            const int idx = 32 * b + (lane & 31), seg = lane >> 5;
+            const int jr = idx - n0;
+            const int r = idx < n0 ? 0 : 1 + (jr >> 1);
+            const int row = idx < n0 ? tby0 + idx : ((jr & 1) ? tby1 + r : tby0 - r);
             const float gap = (r > 1) ? (float)(r - 1) * sbin * 0.999f : 0.0f;   // min projected distance tile -> row band r
-            if(gap * gap > t2) break;
-            const int rowA = tby0 - r, rowB = tby1 + r;
-            if(rowA < 0 && rowB >= sa.nby) break;
+            bool v = gap * gap <= t2 && row >= 0 && row < sa.nby;
             // bins are assigned with the same monotone float expression, so no extra bin is needed once wx is padded
             const float wx = d_sqrt_raw(fmaxf(t2 - gap * gap, 0.0f)) * 1.0001f + 1e-3f * sbin;
             int x0 = (int)floorf((amin_t - wx - sa.amin) * sa_inv_s), x1 = (int)floorf((amax_t + wx - sa.amin) * sa_inv_s);
-            x0 = __builtin_amdgcn_readfirstlane(min(max(x0, 0), sa.nbx - 1));
-            x1 = __builtin_amdgcn_readfirstlane(min(max(x1, x0), sa.nbx - 1));
-            const float lim2 = wave_lim2();
-            const int nrows = (r == 0) ? (tby1 - tby0 + 1) : 2;
-            for(int k = 0; k < 2 * nrows && !fb; ++k) {   // two segments per row: left and right of the phase-1 square
-                const int kr = k >> 1, seg = k & 1;
-                const int row = (r == 0) ? tby0 + kr : (kr == 0 ? rowA : rowB);
-                if(row < 0 || row >= sa.nby) continue;
-                int xa = x0, xb = x1;
-                if(row >= sy0 && row <= sy1) {
-                    if(seg == 0) xb = min(x1, sx0 - 1);
-                    else xa = max(x0, sx1 + 1);
+            x0 = min(max(x0, 0), sa.nbx - 1);
+            x1 = min(max(x1, x0), sa.nbx - 1);
+            int xa = x0, xb = x1;
+            if(row >= sy0 && row <= sy1) {
+                if(seg == 0) xb = min(x1, sx0 - 1);
+                else xa = max(x0, sx1 + 1);
+            }
+            else if(seg == 1) v = false;
+            v = v && xa <= xb;
+            int js = 0, len = 0;
+            if(v) { js = sa.bin_start[row * sa.nbx + xa]; len = sa.bin_start[row * sa.nbx + xb + 1] - js; }
+            int pre = wave_scan_add(len);
+            const int total = __builtin_amdgcn_readlane(pre, 63);
+            pre -= len;
+            for(int base = 0; base < total && !fb; base += 64) {
+                const int g = base + lane;
+                int pos = -1;
+                for(unsigned long long mm = wave_ballot(len > 0); mm != 0ull; mm &= mm - 1ull) {   // the segment of this lane's record
+                    const int sl = __builtin_ctzll(mm);
+                    const int p = __builtin_amdgcn_readlane(pre, sl), l = __builtin_amdgcn_readlane(len, sl);
+                    if(p + l <= base) continue;
+                    if(p >= base + 64) break;
+                    const int j = __builtin_amdgcn_readlane(js, sl);
+                    if(g >= p && g < p + l) pos = j + g - p;
                 }
-                else if(seg == 1) continue;
-                if(xa > xb) continue;
-                const int js = sa.bin_start[row * sa.nbx + xa], je = sa.bin_start[row * sa.nbx + xb + 1];
-                for(int base = js; base < je && !fb; base += 64) {
-                    const int mine = base + lane;
-                    float4 rec = make_float4(NAN, 0, 0, NAN);
-                    float2 met = make_float2(NAN, 0);
-                    float pd = INFINITY;
-                    if(mine < je) { rec = sa.pgeo[mine]; met = sa.smeta[mine]; pd = proj_d2(rec); }
-                    run_chunk(rec, met, mine, wave_ballot(pd <= lim2));
-                }
+                float4 rec = make_float4(NAN, 0, 0, NAN);
+                float2 met = make_float2(NAN, 0);
+                float pd = INFINITY;
+                if(pos >= 0) { rec = sa.pgeo[pos]; met = sa.smeta[pos]; pd = proj_d2(rec); }
+                const float lim2 = wave_lim2();
+                const float B2 = wave_bud2();
+                if(UNION_STATS && lane == 0) atomicAdd(&a.counters[12], (unsigned long long)min(64, total - base));   // records loaded in phase 2
+                run_chunk(rec, met, pos, wave_ballot(keep(pd, rec, met, lim2, B2)));
+            }
+            // the next 32 rows: only if their first band can still matter (rows of the tile itself, band 0, always do)
+            const int nidx = 32 * (b + 1);
+            if(nidx >= n0) {
+                const int rn = 1 + ((nidx - n0) >> 1);
+                const float t2n = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(thr2))));
+                const float gapn = (rn > 1) ? (float)(rn - 1) * sbin * 0.999f : 0.0f;
+                if(t2n < 0.0f || gapn * gapn > t2n) break;
+                if(tby0 - rn < 0 && tby1 + rn >= sa.nby) break;
             }
         }
     }
