@@ -293,10 +293,11 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
 
         // wave-level prune of the candidate a lane holds (pd: its projected distance^2 to the tile centre): inside the horizontal limit, and --
         // once every cell of the wave has its max_points -- inside the largest budget with the elevation / laf distance to the tile's extent added
-        auto wave_bud2 = [&]() { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(bud2)))); };
+        const bool eprune = PLAIN && (kv2 != 0.0f || kw2 != 0.0f);   // (wave-uniform; flat ground pays nothing for the extent)
+        auto wave_bud2 = [&]() { return eprune ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_max(bud2)))) : INFINITY; };
         auto keep = [&](const float pd, const float4& rec, const float2& met, const float lim2, const float B2) {
             bool k = pd <= lim2;
-            if(PLAIN && B2 < INFINITY && (kv2 != 0.0f || kw2 != 0.0f)) {
+            if(eprune && B2 < INFINITY) {
                 const float sd = fmaxf(d_sqrt_raw(pd) * 0.9999f - rad, 0.0f);
                 const float dz = fmaxf(fmaxf(emin_t - rec.w, rec.w - emax_t), 0.0f), dl = fmaxf(fmaxf(lmin_t - met.x, met.x - lmax_t), 0.0f);   // (NaN: no distance)
                 k = k && (sd * sd + kv2 * dz * dz + kw2 * dl * dl <= B2);
