@@ -107,7 +107,8 @@ template <> struct UnionCfg<32> {
 #define GPP_UNION_PERSIST 0
 #endif
 #ifndef GPP_UNION_WPB
-#define GPP_UNION_WPB 4
+#define GPP_UNION_WPB 4   // (tools/ab_bench.sh, round 4: 3 waves per workgroup -- four workgroups per CU, the same twelve waves, finer release -- 4.52 ms per step
+                        //  against 4.47; 6: 7.5 ms, one workgroup per CU)
 #endif
     static constexpr int WPB = GPP_UNION_WPB;       // waves (work items) per workgroup
     template <bool PLAIN> static constexpr bool persistent() { return PLAIN && GPP_UNION_PERSIST != 0; }   // first pass as a persistent grid (see k_oi_union)
