@@ -155,13 +155,14 @@ def test_ensi_matches_oracle(E, max_points):
     check(out, ref, c[2])
 
 
-@pytest.mark.parametrize("E", [15, 16, 17, 20, 21, 32, 33, 36, 37, 47, 48, 49, 50, 51, 52, 53, 63, 64])
+@pytest.mark.parametrize("E", [15, 16, 17, 20, 21, 32, 33, 36, 37, 47, 48, 49, 50, 51, 52, 53, 63, 64, 65, 66, 80, 100, 130])
 @pytest.mark.parametrize("allow", [True, False])
 def test_ensi_member_counts_around_the_tiles_of_sixteen(E, allow):
     """k_ensi_members covers the members in tiles of 16 on the matrix cores and takes up to four members beyond the last full tile on
     the vector unit (17..20, 33..36, 49..52 valid members): every tile count with a tail of 1..4, without one, and with the padded form
-    (5..15 beyond a full tile); one member invalid somewhere for E = 51 / 53 so that the valid count differs from E"""
-    c = case(300 + E, 12, 11, E, 40, nan_member=1 if E in (51, 53) else None)
+    (5..15 beyond a full tile), and more than 64 members (member chunks of 64, the table form of the update: `k_ensi_members<false>`);
+    one member invalid somewhere for E = 51 / 53 / 66 so that the valid count differs from E"""
+    c = case(300 + E, 12, 11, E, 40, nan_member=1 if E in (51, 53, 66) else None)
     out, ref = run(c, 20000, 30, allow=allow)
     check(out, ref, c[2])
     assert plain_err(out, ref).max() < 1e-5
