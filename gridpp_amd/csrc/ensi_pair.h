@@ -395,6 +395,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const bool dup = lb == la;     // half 1 repeats cell la, its result is not stored
             done |= (1ull << la) | (1ull << lb);
             const bool same = n == prev_n && __ballot(orig_i != prev_orig) == 0ull;   // u still holds the eigenvectors of this selection
+            const int old_n = prev_n;
+            const unsigned old_orig = prev_orig;
             prev_n = n; prev_orig = orig_i;
             const int cell_c = ensi_cell_of(a, tile, h ? lb : la);
             const float cx = a.gx[cell_c], cy = a.gy[cell_c], cz = a.gz[cell_c], ce = a.gelev[cell_c], cl = a.glaf[cell_c];
@@ -452,7 +454,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 __syncthreads();
             }
             double b[32];
-            if(!same) {
+            // A NEW selection of the same length as the last one (the next group of a tile: typically one or two observations exchanged at the
+            // edge of the radius, i.e. the rows with the smallest weights): the eigenvectors of the last cell, with the rows of the observations
+            // both selections share moved to their new positions and the rows of the departed observations handed to the newcomers, are an
+            // orthogonal matrix again and a far better start than the identity -- 16 % of config 5's cells started cold (two per group), and
+            // their sweeps from scratch were all of the Jacobi time (histogram of |E| / c before any sweep: 82 % below the threshold, 16 % above 0.48).
+            bool remap = false;
+#ifndef GPP_ENSI_NO_REMAP
+            if(!same && n == old_n && n > 1) {
+                remap = true;
+                int src = -1;            // the row of the old eigenvector matrix this row takes (lane i < n: observation orig_i)
+                bool kept = false;       // old row i stays in the new selection
+                for(int j = 0; j < n; ++j) {
+                    const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)old_orig, j), p1 = (unsigned)__builtin_amdgcn_readlane((int)old_orig, 32 + j);
+                    const unsigned q0 = (unsigned)__builtin_amdgcn_readlane((int)orig_i, j), q1 = (unsigned)__builtin_amdgcn_readlane((int)orig_i, 32 + j);
+                    if((h ? p1 : p0) == orig_i) src = j;
+                    if((h ? q1 : q0) == old_orig) kept = true;
+                }
+                const unsigned long long hm = h ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+                const unsigned long long newm = __ballot(i < n && src < 0) & hm, oldm = __ballot(i < n && !kept) & hm;   // newcomers / departed rows (equally many)
+                if(i < n && src < 0) {
+                    int r = __builtin_popcountll(newm & ((1ull << lane) - 1ull));
+                    unsigned long long mm = oldm;
+                    while(r-- > 0) mm &= mm - 1ull;
+                    src = (mm != 0ull ? __builtin_ctzll(mm) : lane) & 31;
+                }
+                if(i >= n) src = i;
+                const int paddr2 = (32 * h + src) << 2;
+#pragma unroll
+                for(int j = 0; j < 32; ++j) u[j] = partner_of(u[j], paddr2);
+            }
+#endif
+            if(!same && !remap) {
 #pragma unroll
                 for(int j = 0; j < 32; ++j) u[j] = (j == i) ? 1.0 : 0.0;
             }
@@ -465,7 +498,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             EPROF(1)   // Gram (new selections), B build
             // ---- warm start: B <- U^T B U with the eigenvectors of the previous cell of this half (nearly diagonal already) ------------
-            if(same) {
+            if(same || remap) {
 #pragma unroll 1
                 for(int hh = 0; hh < 2; ++hh) {
                     __syncthreads();
@@ -543,6 +576,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 // gaps in any denominator (see there; measured against the LAPACK golden vectors the result stays at the float32
                 // rounding floor up to there, tools/ensi_tol.py), tested after every half of a sweep.  Most warm-started cells need no sweep at all that way (C5: 0.52
                 // sweeps per cell instead of 1.13 with a threshold of 1e-6 of the trace and only the first-order term)
+#ifdef GPP_ENSI_ESTATS
+                if(sweep == 0 && i == 0 && !(dup && h == 1) && a.counters) {   // (statistics build: |E|_F / c of every cell BEFORE any sweep, printed in the phases line of GPP_ENSI_STATS=1)
+                    const double r = sqrt(off) / c;
+                    const double lim[9] = {0.02, 0.04, 0.06, 0.08, 0.12, 0.16, 0.24, 0.32, 0.48};
+                    int bk = 0;
+                    for(int q = 0; q < 9; ++q) bk += r > lim[q] ? 1 : 0;
+                    atomicAdd(&a.counters[80 + (blockIdx.x & 1023) * 32 + bk], 1ull);
+                }
+#endif
                 const bool open = off > a.jtol2 * c * c && off > 1e-24 * tr * tr;   // (and never beyond what double precision resolves)
                 if(__ballot(open && !(dup && h == 1)) == 0ull) break;
                 nsweeps++;
