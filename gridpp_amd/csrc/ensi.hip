@@ -44,7 +44,7 @@ struct EnsiArgs {
     int tile0;                // first tile of the batch
     unsigned* meta;           // [ntiles][64] k_ensi_scan -> k_ensi_pair: selection length | 0x100 if the reference sorted
     unsigned long long* hsigs;   // [ntiles][64] order-independent signature of every selection
-    double* gram;             // [ntiles][EN*EN] scratch: Y Y^T of the current run of equal selections
+    double* gram;             // [ntiles][2][EN*EN] scratch: Y Y^T of the current run(s) of equal selections
     int* big_list;            // cells with more usable observations than the 32-row tile holds (k_ensi_big), or NULL
     int* big_count;
     unsigned long long* big_keys;   // per workgroup of k_ensi_big: EBIG_CAND sorted candidate keys
@@ -905,7 +905,7 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
     a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p;
     a.gY = ws.gY.p; a.validIdx = ws.validIdx.p; a.nV = nV; a.valid_identity = (nV == E) ? 1 : 0;
     a.sel = ws.sel.get((size_t)a.ntiles * EN * 64);
-    a.gram = ws.gram.get((size_t)a.ntiles * EN * EN);
+    a.gram = ws.gram.get((size_t)a.ntiles * 2 * EN * EN);   // two matrices per tile: k_ensi_pair works on two groups at a time
     a.debug = timing_env("GPP_ENSI_DEBUG") ? atoi(timing_env("GPP_ENSI_DEBUG")) : 0;
     a.jtol2 = g_ensi_converge ? 0.0 : GPP_ENSI_JTOL2;
     if(const char* jt = timing_env("GPP_ENSI_JTOL")) { if(!g_ensi_converge) { const double v = atof(jt); a.jtol2 = v * v; } }   // (experiments: |E| <= v c)   // gpp_ensi_set_convergence(1): the Jacobi sweeps run to convergence (no perturbation series to speak of)

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const unsigned long long hsig = a.hsigs[(size_t)tile * 64 + lane];
     const unsigned long long trunc_mask = __ballot((meta & 0x100u) != 0u);
     const unsigned* const sel = a.sel + (size_t)tile * EN * 64;
-    double* const gram = a.gram + (size_t)tile * EN * EN;
+    double* const gram = a.gram + (size_t)tile * 2 * EN * EN;   // two matrices: one per group in flight
 
     const double c = (double)((float)(nV - 1));   // diag = 1/delta*(nValidEns-1), float (oi_ensi.cpp:383)
     const double sqc = sqrt(c);
@@ -370,54 +370,97 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     unsigned long long todo = __ballot(cnt > 0);
     int ndone = 0, nsweeps = 0;
     while(todo) {
-        // ---- next group: the cells whose selection equals that of the lowest cell still to do ------------------------------------
+        // ---- next group: the cells whose selection equals that of the lowest cell still to do; and the group after it -----------------
+        // Round 4: TWO groups at a time, one per half wave, while there are two (the last odd group is split over the halves as before).
+        // A group's first cell starts cold -- sweeps from scratch, ~200 k cycles against ~25 k for a warm cell --, and both halves run every
+        // sweep together: with one group split over both halves every group cost one cold step; with two groups side by side two groups do.
         const int l0 = __builtin_ctzll(todo);
-        const int n = __builtin_amdgcn_readlane(cnt, l0);
-        const unsigned long long cur_h = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hsig >> 32), l0) << 32) |
-                                         (unsigned)__builtin_amdgcn_readlane((int)hsig, l0);
-        const unsigned long long grp = __ballot(cnt == n && hsig == cur_h) & todo;
-        const int npairs = (__builtin_popcountll(grp) + 1) >> 1;
-        const int rk = __builtin_popcountll(grp & ((1ull << lane) - 1ull));   // this lane's rank inside the group
+        const int nA = __builtin_amdgcn_readlane(cnt, l0);
+        const unsigned long long hA = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hsig >> 32), l0) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)hsig, l0);
+        const unsigned long long grpA = __ballot(cnt == nA && hsig == hA) & todo;
+        const unsigned long long rest = todo & ~grpA;
+#ifdef GPP_ENSI_ONE_GROUP
+        const bool two = false;
+#else
+        const bool two = rest != 0ull;
+#endif
+        int nB = nA;
+        unsigned long long grpB = 0ull;
+        if(two) {
+            const int l1 = __builtin_ctzll(rest);
+            nB = __builtin_amdgcn_readlane(cnt, l1);
+            const unsigned long long hB = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hsig >> 32), l1) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)hsig, l1);
+            grpB = __ballot(cnt == nB && hsig == hB) & rest;
+        }
+        const int cA = __builtin_popcountll(grpA), cB = __builtin_popcountll(grpB);
+        const int nsteps = two ? max(cA, cB) : (cA + 1) >> 1;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int rkA = __builtin_popcountll(grpA & below), rkB = __builtin_popcountll(grpB & below);   // this lane's rank inside its group
+        const bool inA = ((grpA >> lane) & 1ull) != 0ull, inB = ((grpB >> lane) & 1ull) != 0ull;
+        const int n = max(nA, nB);                    // bound of the wave-uniform loops
+        const int nh = (two && h) ? nB : nA;          // observations of this half's cells
+        double* const gh = gram + ((two && h) ? EN * EN : 0);   // this half's Gram matrix
+        const unsigned long long hm = h ? 0xffffffff00000000ull : 0x00000000ffffffffull;
         unsigned long long done = 0ull;
-        // half 0 walks the first half of the group, half 1 the second half: consecutive cells of a half are neighbours,
-        // so the eigenvectors of one cell are an excellent starting basis for the next (warm start below)
+        // consecutive cells of a half are neighbours, so the eigenvectors of one cell are an excellent starting basis for the next (warm start below)
 #pragma unroll 1
-        for(int jp = 0; jp < npairs; ++jp) {
-            const int la = __builtin_ctzll(__ballot(((grp >> lane) & 1ull) && rk == jp));
-            const unsigned long long mb = __ballot(((grp >> lane) & 1ull) && rk == jp + npairs);
-            int lb = mb ? __builtin_ctzll(mb) : la;
-            // ---- selection (ascending observation index); both cells must have the very same list -------------------------------
-            const unsigned orig_i = (i < n) ? sel[i * 64 + la] : 0xffffffffu;
-            if(lb != la) {
-                const unsigned ob = (i < n) ? sel[i * 64 + lb] : 0xffffffffu;
-                if(__ballot(orig_i != ob) != 0ull) lb = la;   // equal signature, different lists (never seen): that cell waits for its own group
+        for(int jp = 0; jp < nsteps; ++jp) {
+            int la, lb;
+            bool st0 = true, st1 = true;     // the halves' results are stored (a half whose group is exhausted repeats its last cell)
+            unsigned orig_i;
+            if(two) {
+                la = __builtin_ctzll(__ballot(inA && rkA == min(jp, cA - 1)));
+                lb = __builtin_ctzll(__ballot(inB && rkB == min(jp, cB - 1)));
+                st0 = jp < cA; st1 = jp < cB;
+                orig_i = (i < nh) ? sel[i * 64 + (h ? lb : la)] : 0xffffffffu;   // (ascending observation index)
             }
-            const bool dup = lb == la;     // half 1 repeats cell la, its result is not stored
-            done |= (1ull << la) | (1ull << lb);
-            const bool same = n == prev_n && __ballot(orig_i != prev_orig) == 0ull;   // u still holds the eigenvectors of this selection
+            else {
+                la = __builtin_ctzll(__ballot(inA && rkA == jp));
+                const unsigned long long mb = __ballot(inA && rkA == jp + nsteps);
+                lb = mb ? __builtin_ctzll(mb) : la;
+                // both cells must have the very same list (they share the Gram matrix)
+                orig_i = (i < nA) ? sel[i * 64 + la] : 0xffffffffu;
+                if(lb != la) {
+                    const unsigned ob = (i < nA) ? sel[i * 64 + lb] : 0xffffffffu;
+                    if(__ballot(orig_i != ob) != 0ull) lb = la;   // equal signature, different lists (never seen): that cell waits for its own group
+                }
+                st1 = lb != la;              // (else half 1 repeats cell la, its result is not stored)
+            }
+            const bool store = h ? st1 : st0;
+            done |= (st0 ? (1ull << la) : 0ull) | (st1 ? (1ull << lb) : 0ull);
+            const bool same = nh == prev_n && (__ballot(orig_i != prev_orig) & hm) == 0ull;   // u still holds the eigenvectors of this half's selection
             const int old_n = prev_n;
             const unsigned old_orig = prev_orig;
-            prev_n = n; prev_orig = orig_i;
+            prev_n = nh; prev_orig = orig_i;
             const int cell_c = ensi_cell_of(a, tile, h ? lb : la);
             const float cx = a.gx[cell_c], cy = a.gy[cell_c], cz = a.gz[cell_c], ce = a.gelev[cell_c], cl = a.glaf[cell_c];
-            ndone += dup ? 1 : 2;
+            ndone += (st0 ? 1 : 0) + (st1 ? 1 : 0);
             // ---- per-observation quantities (lane i < n of each half) ----------------------------------------------------------------
             float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 1);
-            if(i < n) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
+            if(i < nh) { o0 = a.ogeo[orig_i]; o1 = a.oaux[orig_i]; }
             DevStructure lst = a.s.st;
             if(SPATIAL) d_structure_at(lst, lst.cell_idx ? lst.cell_idx[cell_c] : cell_c);
             const float rho = d_corr(lst, cx, cy, cz, ce, cl, o0.x, o0.y, o0.z, o0.w, o1.x, true);   // :227
             const float sig2 = o1.w * o1.w;                                    // float product (:300)
             const double D = (double)rho / (double)sig2;                       // Rinv(i,i)
-            const double sD = (i < n) ? sqrt(D) : 0.0;
+            const double sD = (i < nh) ? sqrt(D) : 0.0;
             const double dobs = (double)o1.y - (double)o1.z;                   // lObs - lYhat (:437)
             __syncthreads();
-            s_sD[h][i] = sD; s_r[h][i] = (i < n) ? sD * dobs : 0.0;
-            if(h == 0) s_sel[i] = orig_i;
+            s_sD[h][i] = sD; s_r[h][i] = (i < nh) ? sD * dobs : 0.0;
             __syncthreads();
             EPROF(0)   // pair setup: selection, rho
             // ---- new selection: Gram matrix Y Y^T on the matrix cores (all members, chunks of 64), parked in HBM -----------------------
-            if(!same) {
+            const unsigned long long nsm = __ballot(!same);
+            for(int w = 0; w < 2; ++w) {   // (two groups: each half's own matrix; one group: the shared one, from half 0's list)
+                const bool need = two ? ((nsm >> (32 * w)) & 1ull) != 0ull : (w == 0 && nsm != 0ull);
+                if(!need) continue;
+                const int nw = w ? nB : nA;
+                double* const gw = gram + w * EN * EN;
+                __syncthreads();
+                if(h == w) s_sel[i] = orig_i;
+                __syncthreads();
                 Acc32 g;
                 g.t[0][0] = g.t[0][1] = g.t[1][0] = g.t[1][1] = (v4d){0.0, 0.0, 0.0, 0.0};
                 for(int m0 = 0; m0 < nV; m0 += 64) {
@@ -426,7 +469,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         float yv[EN];
 #pragma unroll
                         for(int r = 0; r < EN; ++r) {
-                            const bool on = r < n && m0 + lane < nV;
+                            const bool on = r < nw && m0 + lane < nV;
                             yv[r] = a.gY[on ? (long)s_sel[r] * nV + m0 + lane : 0];
                             yv[r] = on ? yv[r] : 0.0f;
                         }
@@ -449,7 +492,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                     for(int tj = 0; tj < 2; ++tj)
 #pragma unroll
-                        for(int r = 0; r < 4; ++r) gram[(16 * ti + (lane >> 4) + 4 * r) * EN + 16 * tj + (lane & 15)] = g.t[ti][tj][r];
+                        for(int r = 0; r < 4; ++r) gw[(16 * ti + (lane >> 4) + 4 * r) * EN + 16 * tj + (lane & 15)] = g.t[ti][tj][r];
                 __threadfence();
                 __syncthreads();
             }
@@ -459,48 +502,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // both selections share moved to their new positions and the rows of the departed observations handed to the newcomers, are an
             // orthogonal matrix again and a far better start than the identity -- 16 % of config 5's cells started cold (two per group), and
             // their sweeps from scratch were all of the Jacobi time (histogram of |E| / c before any sweep: 82 % below the threshold, 16 % above 0.48).
-            bool remap = false;
+            bool remap = false;   // (per half, like `same`)
 #ifndef GPP_ENSI_NO_REMAP
-            if(!same && n == old_n && n > 1) {
-                remap = true;
+            remap = !same && nh == old_n && nh > 1;
+            if(__ballot(remap) != 0ull) {
                 int src = -1;            // the row of the old eigenvector matrix this row takes (lane i < n: observation orig_i)
                 bool kept = false;       // old row i stays in the new selection
                 for(int j = 0; j < n; ++j) {
                     const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)old_orig, j), p1 = (unsigned)__builtin_amdgcn_readlane((int)old_orig, 32 + j);
                     const unsigned q0 = (unsigned)__builtin_amdgcn_readlane((int)orig_i, j), q1 = (unsigned)__builtin_amdgcn_readlane((int)orig_i, 32 + j);
-                    if((h ? p1 : p0) == orig_i) src = j;
-                    if((h ? q1 : q0) == old_orig) kept = true;
+                    if(j < nh && (h ? p1 : p0) == orig_i) src = j;
+                    if(j < nh && (h ? q1 : q0) == old_orig) kept = true;
                 }
-                const unsigned long long hm = h ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-                const unsigned long long newm = __ballot(i < n && src < 0) & hm, oldm = __ballot(i < n && !kept) & hm;   // newcomers / departed rows (equally many)
-                if(i < n && src < 0) {
-                    int r = __builtin_popcountll(newm & ((1ull << lane) - 1ull));
+                const unsigned long long newm = __ballot(remap && i < nh && src < 0) & hm, oldm = __ballot(remap && i < nh && !kept) & hm;   // newcomers / departed rows (equally many)
+                if(remap && i < nh && src < 0) {
+                    int r = __builtin_popcountll(newm & below);
                     unsigned long long mm = oldm;
                     while(r-- > 0) mm &= mm - 1ull;
                     src = (mm != 0ull ? __builtin_ctzll(mm) : lane) & 31;
                 }
-                if(i >= n) src = i;
+                if(!remap || i >= nh) src = i;
                 const int paddr2 = (32 * h + src) << 2;
 #pragma unroll
                 for(int j = 0; j < 32; ++j) u[j] = partner_of(u[j], paddr2);
             }
 #endif
-            if(!same && !remap) {
+            {
+                const bool cold = !same && !remap;
 #pragma unroll
-                for(int j = 0; j < 32; ++j) u[j] = (j == i) ? 1.0 : 0.0;
+                for(int j = 0; j < 32; ++j) u[j] = cold ? ((j == i) ? 1.0 : 0.0) : u[j];
             }
             // ---- B = (sD sD^T) o (Y Y^T): row i of each half ------------------------------------------------------------------------------
             // (plain loads: the Gram matrix, like the parked rows below, was written by lanes of this workgroup before a barrier)
 #pragma unroll
             for(int j = 0; j < 32; j += 2) {
-                const double2 g2 = *reinterpret_cast<const double2*>(&gram[i * EN + j]);
+                const double2 g2 = *reinterpret_cast<const double2*>(&gh[i * EN + j]);
                 b[j] = g2.x * (sD * s_sD[h][j]); b[j + 1] = g2.y * (sD * s_sD[h][j + 1]);
             }
             EPROF(1)   // Gram (new selections), B build
             // ---- warm start: B <- U^T B U with the eigenvectors of the previous cell of this half (nearly diagonal already) ------------
-            if(same || remap) {
+            const unsigned long long wm = __ballot(same || remap);
+            if(wm != 0ull) {
 #pragma unroll 1
                 for(int hh = 0; hh < 2; ++hh) {
+                    if(((wm >> (32 * hh)) & 1ull) == 0ull) continue;   // (this half starts cold)
                     __syncthreads();
                     if(h == hh) {
 #pragma unroll
@@ -577,16 +622,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 // rounding floor up to there, tools/ensi_tol.py), tested after every half of a sweep.  Most warm-started cells need no sweep at all that way (C5: 0.52
                 // sweeps per cell instead of 1.13 with a threshold of 1e-6 of the trace and only the first-order term)
 #ifdef GPP_ENSI_ESTATS
-                if(sweep == 0 && i == 0 && !(dup && h == 1) && a.counters) {   // (statistics build: |E|_F / c of every cell BEFORE any sweep, printed in the phases line of GPP_ENSI_STATS=1)
+                if(sweep == 0 && i == 0 && store && a.counters) {   // (statistics build: |E|_F / c of every cell BEFORE any sweep, printed in the phases line of GPP_ENSI_STATS=1)
                     const double r = sqrt(off) / c;
-                    const double lim[9] = {0.02, 0.04, 0.06, 0.08, 0.12, 0.16, 0.24, 0.32, 0.48};
+                    const double lim[9] = {0.04, 0.08, 0.16, 0.32, 0.64, 1.28, 2.56, 5.12, 10.24};
                     int bk = 0;
                     for(int q = 0; q < 9; ++q) bk += r > lim[q] ? 1 : 0;
                     atomicAdd(&a.counters[80 + (blockIdx.x & 1023) * 32 + bk], 1ull);
                 }
 #endif
                 const bool open = off > a.jtol2 * c * c && off > 1e-24 * tr * tr;   // (and never beyond what double precision resolves)
-                if(__ballot(open && !(dup && h == 1)) == 0ull) break;
+                if(__ballot(open && store) == 0ull) break;
                 nsweeps++;
 #pragma unroll 1
                 for(int st = 0; st < GPP_ENSI_JCHUNK; ++st) {   // every double phase is a complete similarity transform: the test above may come after any
@@ -603,7 +648,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             EPROF(3)   // Jacobi
             // ---- park for k_ensi_members: the eigenvector rows, the rows of U^T B U (diagonal: the eigenvalue estimates, off-diagonal: what
             //      the sweeps left, which enters the matrix functions there as a perturbation), sD, sD * (obs - yhat), rho ------------
-            if(!(dup && h == 1)) {
+            if(store) {
                 double* const park = a.cpark + ((size_t)(tile - a.tile0) * 64 + (h ? lb : la)) * ENSI_PARK_D;
 #pragma unroll
                 for(int j = 0; j < 32; j += 2) {
@@ -613,7 +658,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     double2 v; v.x = b[j]; v.y = b[j + 1]; *reinterpret_cast<double2*>(&park[(j >> 1) * 128 + i * 2]) = v;
                 }
                 park[2048 + i] = sD;
-                park[2080 + i] = (i < n) ? sD * dobs : 0.0;
+                park[2080 + i] = (i < nh) ? sD * dobs : 0.0;
                 park[2112 + i] = (double)rho;
                 park[2144 + i] = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(o1.y) << 32) | (unsigned long long)orig_i));
                 park[2176 + i] = __longlong_as_double((long long)(unsigned long long)__float_as_uint(o1.z));
