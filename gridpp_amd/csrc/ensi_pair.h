@@ -330,6 +330,7 @@ template <bool SPATIAL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ensi_pair(EnsiArgs a) {
     // 17 KB: staging areas A / B of the products; B doubles as Y tile and as the transposed operands of the member update
     __shared__ __attribute__((aligned(16))) double s_ab[2 * 32 * PP];
+    __shared__ __attribute__((aligned(16))) double s_ab2[2 * 32 * PP];   // the second pair of staging areas: the warm-start transforms of both halves side by side
     __shared__ __attribute__((aligned(16))) double s_sD[2][32], s_r[2][32], s_z[2][32];
     __shared__ __attribute__((aligned(16))) double s_cs[64];      // (c, s) of the Jacobi pairs [h][16][2]; later t[32]
     __shared__ __attribute__((aligned(16))) double s_dwa[2][2][32];   // [cell][dw | a = sqrt(c + S)][eigenvalue]
@@ -541,32 +542,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             EPROF(1)   // Gram (new selections), B build
             // ---- warm start: B <- U^T B U with the eigenvectors of the previous cell of this half (nearly diagonal already) ------------
+            // (both halves' products side by side in two pairs of staging areas: one after the other they were 29 % of the kernel, two thirds of it
+            //  barriers and staging around 7 k cycles of matrix-core time)
             const unsigned long long wm = __ballot(same || remap);
             if(wm != 0ull) {
-#pragma unroll 1
-                for(int hh = 0; hh < 2; ++hh) {
-                    if(((wm >> (32 * hh)) & 1ull) == 0ull) continue;   // (this half starts cold)
-                    __syncthreads();
-                    if(h == hh) {
+                const bool w0 = (wm & 1ull) != 0ull, w1 = ((wm >> 32) & 1ull) != 0ull;   // (a half that starts cold keeps its B)
+                double* const tA = h ? s_ab2 : sA;                 // this half's areas
+                double* const tB = h ? s_ab2 + 32 * PP : sB;
+                double* const a0p = sA, * const b0p = sB, * const a1p = s_ab2, * const b1p = s_ab2 + 32 * PP;
+                __syncthreads();
 #pragma unroll
-                        for(int j = 0; j < 32; j += 2) {
-                            double2 v; v.x = b[j]; v.y = b[j + 1]; *reinterpret_cast<double2*>(&sA[i * PP + j]) = v;
-                            double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&sB[i * PP + j]) = w;
-                        }
-                    }
-                    __syncthreads();
-                    const Acc32 t = mfma_32_full(lane, [&](int r, int k) { return sA[r * PP + k]; }, [&](int k, int cc) { return sB[k * PP + cc]; });
-                    __syncthreads();
-                    acc32_store_full(t, lane, sA);
-                    __syncthreads();
-                    const Acc32 bb = mfma_32_full<true>(lane, [&](int r, int k) { return sB[k * PP + r]; }, [&](int k, int cc) { return sA[k * PP + cc]; });
-                    __syncthreads();
-                    acc32_store_full<true>(bb, lane, sA);   // (symmetric by construction: the tile below the diagonal is the mirror image of the one above)
-                    __syncthreads();
-                    if(h == hh) {
+                for(int j = 0; j < 32; j += 2) {
+                    double2 v; v.x = b[j]; v.y = b[j + 1]; *reinterpret_cast<double2*>(&tA[i * PP + j]) = v;
+                    double2 w; w.x = u[j]; w.y = u[j + 1]; *reinterpret_cast<double2*>(&tB[i * PP + j]) = w;
+                }
+                __syncthreads();
+                Acc32 t0, t1;
+                if(w0) t0 = mfma_32_full(lane, [&](int r, int k) { return a0p[r * PP + k]; }, [&](int k, int cc) { return b0p[k * PP + cc]; });
+                if(w1) t1 = mfma_32_full(lane, [&](int r, int k) { return a1p[r * PP + k]; }, [&](int k, int cc) { return b1p[k * PP + cc]; });
+                __syncthreads();
+                if(w0) acc32_store_full(t0, lane, a0p);
+                if(w1) acc32_store_full(t1, lane, a1p);
+                __syncthreads();
+                if(w0) t0 = mfma_32_full<true>(lane, [&](int r, int k) { return b0p[k * PP + r]; }, [&](int k, int cc) { return a0p[k * PP + cc]; });
+                if(w1) t1 = mfma_32_full<true>(lane, [&](int r, int k) { return b1p[k * PP + r]; }, [&](int k, int cc) { return a1p[k * PP + cc]; });
+                __syncthreads();
+                if(w0) acc32_store_full<true>(t0, lane, a0p);   // (symmetric by construction: the tile below the diagonal is the mirror image of the one above)
+                if(w1) acc32_store_full<true>(t1, lane, a1p);
+                __syncthreads();
+                if(same || remap) {
 #pragma unroll
-                        for(int j = 0; j < 32; j += 2) { const double2 v = *reinterpret_cast<const double2*>(&sA[i * PP + j]); b[j] = v.x; b[j + 1] = v.y; }
-                    }
+                    for(int j = 0; j < 32; j += 2) { const double2 v = *reinterpret_cast<const double2*>(&tA[i * PP + j]); b[j] = v.x; b[j + 1] = v.y; }
                 }
                 __syncthreads();
             }
