@@ -435,6 +435,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const int old_n = prev_n;
             const unsigned old_orig = prev_orig;
             prev_n = nh; prev_orig = orig_i;
+            // row i of this half's Gram matrix, asked for now (used behind the per-observation loads below; a new selection reads it again once it is rebuilt)
+            double b[32];
+#pragma unroll
+            for(int j = 0; j < 32; j += 2) { const double2 g2 = *reinterpret_cast<const double2*>(&gh[i * EN + j]); b[j] = g2.x; b[j + 1] = g2.y; }
             const int cell_c = ensi_cell_of(a, tile, h ? lb : la);
             const float cx = a.gx[cell_c], cy = a.gy[cell_c], cz = a.gz[cell_c], ce = a.gelev[cell_c], cl = a.glaf[cell_c];
             ndone += (st0 ? 1 : 0) + (st1 ? 1 : 0);
@@ -497,7 +501,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 __threadfence();
                 __syncthreads();
             }
-            double b[32];
             // A NEW selection of the same length as the last one (the next group of a tile: typically one or two observations exchanged at the
             // edge of the radius, i.e. the rows with the smallest weights): the eigenvectors of the last cell, with the rows of the observations
             // both selections share moved to their new positions and the rows of the departed observations handed to the newcomers, are an
@@ -535,11 +538,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             // ---- B = (sD sD^T) o (Y Y^T): row i of each half ------------------------------------------------------------------------------
             // (plain loads: the Gram matrix, like the parked rows below, was written by lanes of this workgroup before a barrier)
+            if(nsm != 0ull) {   // (some Gram matrix was rebuilt: read again -- wave-uniform, both halves)
 #pragma unroll
-            for(int j = 0; j < 32; j += 2) {
-                const double2 g2 = *reinterpret_cast<const double2*>(&gh[i * EN + j]);
-                b[j] = g2.x * (sD * s_sD[h][j]); b[j + 1] = g2.y * (sD * s_sD[h][j + 1]);
+                for(int j = 0; j < 32; j += 2) { const double2 g2 = *reinterpret_cast<const double2*>(&gh[i * EN + j]); b[j] = g2.x; b[j + 1] = g2.y; }
             }
+#pragma unroll
+            for(int j = 0; j < 32; j += 2) { b[j] *= sD * s_sD[h][j]; b[j + 1] *= sD * s_sD[h][j + 1]; }
             EPROF(1)   // Gram (new selections), B build
             // ---- warm start: B <- U^T B U with the eigenvectors of the previous cell of this half (nearly diagonal already) ------------
             // (both halves' products side by side in two pairs of staging areas: one after the other they were 29 % of the kernel, two thirds of it
