@@ -388,14 +388,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
         int nB = nA;
         unsigned long long grpB = 0ull;
-        if(two) {
-            const int l1 = __builtin_ctzll(rest);
-            nB = __builtin_amdgcn_readlane(cnt, l1);
-            const unsigned long long hB = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hsig >> 32), l1) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)hsig, l1);
-            grpB = __ballot(cnt == nB && hsig == hB) & rest;
+        const int cA = __builtin_popcountll(grpA);
+        if(two) {   // the partner: of the next groups (up to six) the one closest in size -- a half whose group is exhausted idles through the other's steps
+            unsigned long long r = rest;
+            int best = 1 << 30;
+            for(int it = 0; it < 6 && r != 0ull; ++it) {
+                const int l1 = __builtin_ctzll(r);
+                const int n1 = __builtin_amdgcn_readlane(cnt, l1);
+                const unsigned long long h1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hsig >> 32), l1) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane((int)hsig, l1);
+                const unsigned long long g1 = __ballot(cnt == n1 && hsig == h1) & r;
+                const int d = abs(__builtin_popcountll(g1) - cA);
+                if(d < best) { best = d; grpB = g1; nB = n1; }
+                r &= ~g1;
+            }
         }
-        const int cA = __builtin_popcountll(grpA), cB = __builtin_popcountll(grpB);
+        const int cB = __builtin_popcountll(grpB);
         const int nsteps = two ? max(cA, cB) : (cA + 1) >> 1;
         const unsigned long long below = (1ull << lane) - 1ull;
         const int rkA = __builtin_popcountll(grpA & below), rkB = __builtin_popcountll(grpB & below);   // this lane's rank inside its group
