@@ -382,9 +382,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const unsigned long long grpA = __ballot(cnt == nA && hsig == hA) & todo;
         const unsigned long long rest = todo & ~grpA;
 #ifdef GPP_ENSI_ONE_GROUP
-        const bool two = false;
+        bool two = false;
 #else
-        const bool two = rest != 0ull;
+        bool two = rest != 0ull;
 #endif
         int nB = nA;
         unsigned long long grpB = 0ull;
@@ -402,6 +402,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if(d < best) { best = d; grpB = g1; nB = n1; }
                 r &= ~g1;
             }
+            // Side by side costs max(cA, cB) steps and one cold start, one after the other (each split over the halves) (cA + cB) / 2 steps and two: worth it
+            // while half the difference in size is below what a cold start costs in warm steps -- ~8 with the sweeps stopped early, ~2.5 with
+            // the sweeps run to convergence (every step sweeps then)
+            if(best >= (a.jtol2 > 0.0 ? 14 : 3)) { two = false; grpB = 0ull; nB = nA; }
         }
         const int cB = __builtin_popcountll(grpB);
         const int nsteps = two ? max(cA, cB) : (cA + 1) >> 1;
