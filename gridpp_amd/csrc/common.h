@@ -72,6 +72,7 @@ template <class T>
 struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
     T* p = nullptr;
     size_t cap = 0;
+    unsigned long long gen = 0;   // counts allocations: a cache of "what this buffer holds" keys on it (a new allocation may come back at the old address)
     ~DevBuf() { if(p) (void)hipFree(p); }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
@@ -84,12 +85,14 @@ struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
             if(old) GPP_HIP(hipFree(old));
             GPP_HIP(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
             cap = n;
+            gen++;
         }
         return p;
     }
     void release() {
         if(p) (void)hipFree(p);
         p = nullptr; cap = 0;
+        gen++;
     }
     void upload(const T* h, size_t n) {
         get(n);

@@ -776,7 +776,8 @@ struct NbWorkspace {
     DevBuf<float> flat, tmp, tmp2, planes, thr, qf;
     DevBuf<double> rs;
     DevBuf<int> rc, plane_flags;
-    const void* pad_ptr = nullptr;   // the padding of the quantile_fast count planes is in place for this buffer and shape
+    const void* pad_ptr = nullptr;   // the padding of the quantile_fast count planes is in place for this buffer (this ALLOCATION of it) and shape
+    unsigned long long pad_gen = 0;
     int pad_y = 0, pad_x = 0, pad_t = 0, pad_e = 0;
 };
 thread_local NbWorkspace g_nb;
@@ -976,12 +977,12 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
     if(fused) {
         QfGeom g = qf_geom(ny, nx);
         unsigned char* cnt8 = reinterpret_cast<unsigned char*>(g_nb.planes.get(((size_t)(nt + 1) * g.Pp + 3) / 4));
-        if(g_nb.pad_ptr != cnt8 || g_nb.pad_y != ny || g_nb.pad_x != nx || g_nb.pad_t != nt || g_nb.pad_e != ne) {
+        if(g_nb.pad_ptr != cnt8 || g_nb.pad_gen != g_nb.planes.gen || g_nb.pad_y != ny || g_nb.pad_x != nx || g_nb.pad_t != nt || g_nb.pad_e != ne) {
             // the padding is written when the planes are laid out (the passes below only ever write the cells of the field)
             g_nb.pad_ptr = nullptr;
             GPP_HIP(hipMemsetAsync(cnt8, 255, (size_t)nt * g.Pp, stream()));
             GPP_HIP(hipMemsetAsync(cnt8 + (size_t)nt * g.Pp, ne, (size_t)g.Pp, stream()));
-            g_nb.pad_ptr = cnt8; g_nb.pad_y = ny; g_nb.pad_x = nx; g_nb.pad_t = nt; g_nb.pad_e = ne;
+            g_nb.pad_ptr = cnt8; g_nb.pad_gen = g_nb.planes.gen; g_nb.pad_y = ny; g_nb.pad_x = nx; g_nb.pad_t = nt; g_nb.pad_e = ne;
         }
         g.rowflag = g_nb.plane_flags.get(ny + 1);
         GPP_HIP(hipMemsetAsync(g.rowflag, 0, sizeof(int) * (ny + 1), stream()));
