@@ -86,9 +86,17 @@ struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
             GPP_HIP(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
             cap = n;
             gen++;
+#ifdef GPP_POISON
+            // diagnostic build (tools/hostile/build.sh): a fresh allocation is as hostile as a poisoned workspace (hipMalloc tends to
+            // hand out zero pages, which hide a read of something never written)
+            GPP_HIP(hipMemsetAsync(p, 0xFF, (n ? n : 1) * sizeof(T), stream()));
+#endif
         }
         return p;
     }
+#ifdef GPP_POISON
+    void poison(int byte) { if(p && cap) GPP_HIP(hipMemsetAsync(p, byte, cap * sizeof(T), stream())); }
+#endif
     void release() {
         if(p) (void)hipFree(p);
         p = nullptr; cap = 0;

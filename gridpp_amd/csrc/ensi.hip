@@ -175,6 +175,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
                                 // (ensi_pair.h, k_ensi_members: the same worst deviation as the converged sweeps, 2.5e-6; 0.050 c: 4.1e-6)
 #endif
 #define NSP 65           // pitch of the three 64 x 64 matrices (doubles)
+#ifndef GPP_NS_TOL
+#define GPP_NS_TOL 1e-25
+#endif
+#ifndef GPP_NS_EXTRA
+#define GPP_NS_EXTRA 0
+#endif
 template <bool SPATIAL, bool FULL>   // FULL: 49..64 valid members (all four tile rows: strips); else the tiles on and above the diagonal
 __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
     extern __shared__ double ns_lds[];
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
         // the limit is the same.  mu = 3 / (lo + sqrt(lo hi) + hi) makes f(mu lo) = f(mu hi), the largest lower bound one step can
         // reach: it grows by 6.75 per step instead of 2.25 while it is small, and mu -> 1 as the bounds close on 1.
         double lo = c * rsc, hi = 2.0 - lo;
+        int extra_left = GPP_NS_EXTRA;
         for(int it = 0; it < 64; ++it) {
             double res2 = 0.0;
             const double mu = 3.0 / (lo + sqrt(lo * hi) + hi), smu = sqrt(mu), hmu = 0.5 * mu;
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
                 }
             }
             res2 = block_sum(res2);    // (its barriers also publish T)
-            if(res2 < 1e-25) { converged = true; break; }
+            if(res2 < GPP_NS_TOL) { if(extra_left-- <= 0) { converged = true; break; } }
             if(!(res2 == res2)) break;   // NaN: a non-finite matrix
             if constexpr (FULL) {
                 v4d y4[4], z4[4];
@@ -437,14 +444,23 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
                 __syncthreads();
             }
             else {
+            // Y T and T Z as FULL products over the nt x nt tile grid (tile p = wv + 4 u, row by row; nt <= 3): no mirroring here.  The coupled
+            // iteration is only stable with Y multiplied from the right and Z from the left by the SAME T (Higham, "Stable iterations for the
+            // matrix square root"): until round 5 this path computed the tiles on and above the diagonal and stored their transposes below it,
+            // i.e. (Y T) above and (T Y) below.  Equal in exact arithmetic -- in double the non-commuting part of the rounding errors then
+            // grows by a factor of several hundred per step: with cond(Pinv) ~ 1e4 (observation sigmas x 0.01) the residual bottomed out at
+            // |I - Z Y|_F ~ 2e-8, never reached the tolerance, the cell went to k_ensi_huge -- and converged cells carried errors of 1e-10
+            // instead of 1e-13 (tools/ensi_hostile_soak.py found it; profiles/r05_ensi_illcond.txt).  T itself stays exactly symmetric
+            // (Z Y is computed on the upper tiles and mirrored above): a perturbation of T that is the same in both products is harmless.
             v4d y3[3], z3[3];
             int tis[3], tjs[3];
+            const int nfull = nt * nt;
 #pragma unroll
             for(int u = 0; u < 3; ++u) {
                 const int p = wv + 4 * u;
                 tis[u] = tjs[u] = 0;
-                if(p < npair) {
-                    tile_of(p, tis[u], tjs[u]);
+                if(p < nfull) {
+                    tis[u] = p / nt; tjs[u] = p - tis[u] * nt;
                     y3[u] = tile_product(M0, M2, tis[u], tjs[u]);   // Y T
                     z3[u] = tile_product(M2, M1, tis[u], tjs[u]);   // T Z
                 }
@@ -452,12 +468,12 @@ __global__ __launch_bounds__(256) void k_ensi_big_ns(EnsiArgs a) {
             __syncthreads();   // every wave has read Y and Z
 #pragma unroll
             for(int u = 0; u < 3; ++u) {
-                if(wv + 4 * u < npair) {
+                if(wv + 4 * u < nfull) {
 #pragma unroll
                     for(int r = 0; r < 4; ++r) {
                         const int row = 16 * tis[u] + kq + 4 * r, col = 16 * tjs[u] + r16;
-                        M0[row * NSP + col] = y3[u][r]; M0[col * NSP + row] = y3[u][r];
-                        M1[row * NSP + col] = z3[u][r]; M1[col * NSP + row] = z3[u][r];
+                        M0[row * NSP + col] = y3[u][r];
+                        M1[row * NSP + col] = z3[u][r];
                     }
                 }
             }
@@ -657,11 +673,16 @@ __global__ __launch_bounds__(256) void k_ensi_huge(EnsiArgs a, const int* __rest
         double trl = 0.0;
         for(int k = tid; k < nV; k += 256) trl += fabs(B[(size_t)k * nV + k]);
         const double tr = block_sum(trl);
+        (void)tr;
         for(int sweep = 0; sweep < 60; ++sweep) {
             double off2 = 0.0;
-            for(long e = tid; e < (long)nV * nV; e += 256) { const int i = (int)(e / nV), j = (int)(e - (long)i * nV); if(j < i) { const double v = B[e]; off2 += v * v; } }
+            // Stopping test in the SCALED measure sum (b_ij^2 / |b_ii b_jj|) <= 1e-26 (Demmel / Veselic: every eigenvalue and eigenvector of a positive
+            // definite matrix to high RELATIVE accuracy).  Until round 5 the test was |off|_F <= 1e-11 trace: with observation sigmas x 0.01 the
+            // spectrum of Pinv spans c ... 1e7 and the eigenvectors of the SMALL eigenvalues -- the ones that carry the weight in sqrt(c / D) --
+            // were left with errors of 1e-5 (36 % of the float32 outputs off by an ulp, 1.5e-4 in the plain measure; tools/ensi_hostile_soak.py)
+            for(long e = tid; e < (long)nV * nV; e += 256) { const int i = (int)(e / nV), j = (int)(e - (long)i * nV); if(j < i) { const double v = B[e]; off2 += v * v / fabs(B[(size_t)i * nV + i] * B[(size_t)j * nV + j]); } }
             off2 = block_sum(off2);
-            if(!(off2 > 1e-22 * tr * tr)) break;
+            if(!(off2 > 1e-26)) break;   // (also on NaN: a non-finite matrix)
             for(int step = 0; step < mm - 1; ++step) {
                 for(int g0 = 0; g0 < half; g0 += 32) {
                     const int npair = min(32, half - g0);
@@ -797,6 +818,29 @@ void gpp_release_ensi_workspace() {
     EnsiWorkspace& ws = g_ews;
     ws.cpark.release(); ws.gram.release(); ws.sel.release(); ws.huge_mat.release(); ws.big_keys.release(); ws.huge_keys.release();
 }
+
+#ifdef GPP_POISON
+// Diagnostic build only (tools/hostile/build.sh, tools/ensi_hostile_soak.py, tools/ensi_multi_hostile_soak.py): every byte of the
+// call-to-call workspaces of optimal_interpolation_ensi and optimal_interpolation_ensi_multi (they share one workspace) is set to `byte` --
+// the park of k_ensi_pair (cpark), the two Gram matrices per tile, the parked selections with their metadata and signatures, the packed
+// observations, the lists, counters and flags -- so that a kernel reading something THIS call did not write meets NaNs, absurd counts
+// and negative indices instead of the previous call's values.
+extern "C" int gpp_debug_poison_ensi_workspace(int byte) {
+    GPP_TRY
+    ensure_device();
+    EnsiWorkspace& w = g_ews;
+    w.pgeo.poison(byte); w.oaux.poison(byte);
+    w.gYhat.poison(byte); w.gY.poison(byte); w.gYm.poison(byte); w.obs0.poison(byte);
+    w.flags.poison(byte); w.validIdx.poison(byte); w.err.poison(byte); w.cell_idx.poison(byte); w.obs_idx.poison(byte);
+    w.sel.poison(byte); w.meta.poison(byte); w.hsigs.poison(byte);
+    w.gram.poison(byte); w.cpark.poison(byte); w.huge_mat.poison(byte);
+    w.counters.poison(byte); w.big_keys.poison(byte); w.huge_keys.poison(byte);
+    w.big_list.poison(byte); w.big_count.poison(byte);
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+#endif
 
 extern "C" int gpp_ensi_set_convergence(int to_convergence) {
     g_ensi_converge = to_convergence ? 1 : 0;

@@ -782,6 +782,37 @@ struct NbWorkspace {
 };
 thread_local NbWorkspace g_nb;
 
+#ifdef GPP_POISON
+// Diagnostic build only (tools/hostile/build.sh, tools/nbh_hostile_soak.py): the call-to-call workspaces of the neighbourhood family set to
+// `byte`.  The byte planes of the fused quantile_fast path carry state across calls BY DESIGN (their padding is written once per layout,
+// gpp_neighbourhood_quantile_fast below): keep_padding = 0 poisons the whole buffer and forgets the layout (the next call must lay the
+// padding out again); keep_padding = 1 poisons everything EXCEPT the padding of the remembered layout -- every cell byte of every plane
+// -- so that the cache is exercised while a count pass that leaves a cell unwritten is still caught.
+__global__ void k_poison_plane_cells(unsigned char* __restrict__ cnt8, QfGeom g, int nplanes, int byte) {
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(cell >= (long)g.Y * g.X) return;
+    const long o = qf_cell_offset(g, cell);
+    for(int t = 0; t < nplanes; t++) cnt8[(size_t)t * g.Pp + o] = (unsigned char)byte;
+}
+extern "C" int gpp_debug_poison_nbh_workspace(int byte, int keep_padding) {
+    GPP_TRY
+    ensure_device();
+    NbWorkspace& w = g_nb;
+    w.flat.poison(byte); w.tmp.poison(byte); w.tmp2.poison(byte); w.thr.poison(byte); w.qf.poison(byte);
+    w.rs.poison(byte); w.rc.poison(byte); w.plane_flags.poison(byte);
+    if(keep_padding && w.pad_ptr && w.pad_ptr == (const void*)w.planes.p && w.pad_gen == w.planes.gen) {
+        const QfGeom g = qf_geom(w.pad_y, w.pad_x);
+        const long C = (long)g.Y * g.X;
+        hipLaunchKernelGGL(k_poison_plane_cells, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream(), reinterpret_cast<unsigned char*>(w.planes.p), g, w.pad_t + 1, byte);
+        GPP_HIP(hipGetLastError());
+    }
+    else { w.planes.poison(byte); w.pad_ptr = nullptr; }
+    GPP_HIP(hipStreamSynchronize(stream()));
+    return GPP_OK;
+    GPP_CATCH
+}
+#endif
+
 template <int MODE>
 void member_pass_launch(const float* d_in, long C, int E, int statistic, const float* d_thr, int T, float* d_out, const QfGeom& g) {
     const long tiles = (C + 63) / 64;

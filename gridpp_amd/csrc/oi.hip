@@ -1172,7 +1172,6 @@ __global__ __launch_bounds__(256) void k_oi_huge(OiArgs a, const int* __restrict
 namespace {
 struct OiWorkspace {
     DevBuf<float4> pgeo, oaux, saux;
-    DevBuf<float> ones;
     // status block of a call, one memset and one read-back: ints [0] err, [1..3] work-list lengths, [4] large-n cell count;
     // statistics counters from byte 64 on
     DevBuf<unsigned long long> status;
@@ -1193,23 +1192,23 @@ void gpp_release_oi_workspace() {   // the parked selections (128 B per grid cel
     g_ws.pair_sel.release(); g_ws.pair_n.release();
 }
 
+// MultipleStructure with spatially varying parts: the per-point scales of a call (gpp_bind_field below)
+namespace { struct MultiFieldWs { DevBuf<float> mh, mv, mw, mR; DevBuf<int> tmpi; }; thread_local MultiFieldWs g_mfw; }
+
 #ifdef GPP_POISON
-// Diagnostic build only (tools/hostile/build.sh, tools/oi_hostile_soak.py): every byte of the call-to-call workspaces of the OI path is
+// Diagnostic build only (tools/hostile/build.sh, tools/*_hostile_soak.py): every byte of the call-to-call workspaces of the OI path is
 // set to `byte` (0xFF: NaNs, huge counts, negative list entries), so that a kernel reading something this call did not write meets
 // hostile data instead of the remains of the previous call.
 extern "C" int gpp_debug_poison_oi_workspace(int byte) {
     GPP_TRY
     ensure_device();
     OiWorkspace& w = g_ws;
-    auto fill = [&](void* p, size_t bytes) { if(p && bytes) GPP_HIP(hipMemsetAsync(p, byte, bytes, stream())); };
-    fill(w.pgeo.p, w.pgeo.cap * sizeof(float4)); fill(w.oaux.p, w.oaux.cap * sizeof(float4)); fill(w.saux.p, w.saux.cap * sizeof(float4));
-    fill(w.status.p, w.status.cap * sizeof(unsigned long long));
-    fill(w.cell_idx.p, w.cell_idx.cap * sizeof(int)); fill(w.obs_idx.p, w.obs_idx.cap * sizeof(int));
-    fill(w.fb_list.p, w.fb_list.cap * sizeof(int)); fill(w.fb_list2.p, w.fb_list2.cap * sizeof(int)); fill(w.fb_list3.p, w.fb_list3.cap * sizeof(int));
-    fill(w.big_list.p, w.big_list.cap * sizeof(int)); fill(w.huge_list.p, w.huge_list.cap * sizeof(int));
-    fill(w.big_keys.p, w.big_keys.cap * sizeof(unsigned long long)); fill(w.huge_keys.p, w.huge_keys.cap * sizeof(unsigned long long));
-    fill(w.big_mat.p, w.big_mat.cap * sizeof(double)); fill(w.huge_mat.p, w.huge_mat.cap * sizeof(double));
-    fill(w.pair_sel.p, w.pair_sel.cap * sizeof(unsigned)); fill(w.pair_n.p, w.pair_n.cap * sizeof(int));
+    w.pgeo.poison(byte); w.oaux.poison(byte); w.saux.poison(byte); w.status.poison(byte);
+    w.cell_idx.poison(byte); w.obs_idx.poison(byte);
+    w.fb_list.poison(byte); w.fb_list2.poison(byte); w.fb_list3.poison(byte); w.big_list.poison(byte); w.huge_list.poison(byte);
+    w.big_keys.poison(byte); w.huge_keys.poison(byte); w.big_mat.poison(byte); w.huge_mat.poison(byte);
+    w.pair_sel.poison(byte); w.pair_n.poison(byte);
+    g_mfw.mh.poison(byte); g_mfw.mv.poison(byte); g_mfw.mw.poison(byte); g_mfw.mR.poison(byte); g_mfw.tmpi.poison(byte);
     GPP_HIP(hipStreamSynchronize(stream()));
     if(w.h_status) memset(w.h_status, byte, (8 + 80 + 2 * GPP_NSLOT) * sizeof(unsigned long long));
     return GPP_OK;
@@ -1295,8 +1294,8 @@ void gpp_bind_field(DevStructure& d, const gpp_structure* s, gpp_points* bgrid, 
         // laf of p1 on both sides (its vertical factors are 1), corr_v from sv at zero horizontal distance, corr_w from sw likewise:
         // per point, h and the localization distance are sh's, v is sv's, w is sw's -- each looked up at the nearest point of ITS
         // grid.  Materialised once per call for [background points | observations]; the kernels index it like one field.
-        static thread_local DevBuf<float> mh, mv, mw, mR;
-        static thread_local DevBuf<int> tmpi;
+        DevBuf<float>&mh = g_mfw.mh, &mv = g_mfw.mv, &mw = g_mfw.mw, &mR = g_mfw.mR;
+        DevBuf<int>& tmpi = g_mfw.tmpi;
         const int C = bgrid->n, S = points->n, n = C + S;
         mh.get(n); mv.get(n); mw.get(n); mR.get(n);
         const float Rconst = (s->flags & GPP_ST_HAS_LOC) ? s->loc : st_localization(s->kind, s->h, s->min_rho);

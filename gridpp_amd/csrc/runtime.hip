@@ -4,6 +4,7 @@
 #include <thread>
 #include <mutex>
 #include <atomic>
+#include <memory>
 
 namespace gpp {
 
@@ -56,10 +57,18 @@ void gpp_release_oi_workspace();     // oi.hip
 // ---- path overrides: the one test hook (common.h: path_env) ---------------------------------------------------------------------
 namespace gpp {
 static std::mutex g_override_mutex;
-static std::vector<std::pair<std::string, std::string>>& override_table() { static std::vector<std::pair<std::string, std::string>> t; return t; }
+// (name, value): the value strings are interned -- every value ever set stays alive in `override_values` (a few bytes per
+//  gpp_set_path_override call of a test process) -- so the pointer path_override() hands out stays valid whatever another thread
+//  sets or clears afterwards; callers may hold it across their whole call (it used to point into the table entry)
+static std::vector<std::pair<std::string, const char*>>& override_table() { static std::vector<std::pair<std::string, const char*>> t; return t; }
+static const char* intern_override_value(const char* v) {
+    static std::vector<std::unique_ptr<std::string>> override_values;
+    override_values.emplace_back(new std::string(v));
+    return override_values.back()->c_str();
+}
 const char* path_override(const char* name) {
     std::lock_guard<std::mutex> lock(g_override_mutex);
-    for(auto& kv : override_table()) if(kv.first == name) return kv.second.c_str();   // (the strings live until the entry is changed: callers use them at once)
+    for(auto& kv : override_table()) if(kv.first == name) return kv.second;
     return nullptr;
 }
 }
@@ -72,10 +81,11 @@ extern "C" int gpp_set_path_override(const char* name, const char* value) {
     auto& t = override_table();
     for(size_t i = 0; i < t.size(); i++)
         if(t[i].first == name) {
-            if(value) t[i].second = value; else t.erase(t.begin() + (long)i);
+            if(value) { if(strcmp(t[i].second, value) != 0) t[i].second = intern_override_value(value); }
+            else t.erase(t.begin() + (long)i);
             return GPP_OK;
         }
-    if(value) t.emplace_back(name, value);
+    if(value) t.emplace_back(name, intern_override_value(value));
     return GPP_OK;
     GPP_CATCH
 }
@@ -92,6 +102,19 @@ extern "C" int gpp_active_overrides(char* buf, int len) {
     return n;
     GPP_CATCH
 }
+
+#ifdef GPP_POISON
+extern "C" int gpp_debug_poison_oi_workspace(int byte);                      // oi.hip
+extern "C" int gpp_debug_poison_ensi_workspace(int byte);                    // ensi.hip (optimal_interpolation_ensi and _ensi_multi)
+extern "C" int gpp_debug_poison_nbh_workspace(int byte, int keep_padding);   // neighbourhood.hip
+// every call-to-call workspace of the calling thread (diagnostic build only, tools/hostile/build.sh)
+extern "C" int gpp_debug_poison_workspaces(int byte, int keep_padding) {
+    int rc = gpp_debug_poison_oi_workspace(byte);
+    if(rc == GPP_OK) rc = gpp_debug_poison_ensi_workspace(byte);
+    if(rc == GPP_OK) rc = gpp_debug_poison_nbh_workspace(byte, keep_padding);
+    return rc;
+}
+#endif
 
 // frees the thread's large call-to-call workspaces (they grow on demand and are otherwise kept for the next call)
 extern "C" int gpp_release_workspaces(void) {

@@ -42,7 +42,16 @@ if os.environ.get("GRIDPP_TEST_POISON"):
         import gridpp_amd
         lib = gridpp_amd._capi.lib()     # (first: it loads torch's HIP runtime, which the helper library then shares)
         plib = _C.CDLL(os.path.join(ROOT, "tools", "hostile", "libpoison.so"))
-        skip = {"gpp_last_error", "gpp_version", "gpp_active_overrides"}
+        skip = {"gpp_last_error", "gpp_version", "gpp_active_overrides", "gpp_oi_last_stats", "gpp_ensi_last_stats", "gpp_ensi_last_kernel_ms", "gpp_set_path_override", "gpp_ensi_set_convergence"}
+
+        # with the -DGPP_POISON build of the library (GPP_LIB=gridpp_amd/lib/var_poison.so, tools/hostile/build.sh) every byte of every
+        # call-to-call HBM workspace is 0xFF before each call as well (OI, EnSI + ensi_multi, neighbourhood; the remembered padding of
+        # the quantile_fast byte planes alternately kept and forgotten)
+        ws_poison = getattr(lib, "gpp_debug_poison_workspaces", None) if os.path.basename(gridpp_amd._capi.LIB_PATH) == "var_poison.so" else None
+        if ws_poison is not None:
+            ws_poison.argtypes = [_C.c_int, _C.c_int]
+            ws_poison.restype = _C.c_int
+        count = [0]
 
         class Poisoned:
             def __init__(self, fn):
@@ -50,6 +59,9 @@ if os.environ.get("GRIDPP_TEST_POISON"):
 
             def __call__(self, *a):
                 assert plib.poison_lds(_C.c_uint(0xFFFFFFFF)) == 0 and plib.poison_regs(_C.c_uint(0xFFFFFFFF)) == 0
+                if ws_poison is not None:
+                    count[0] += 1
+                    assert ws_poison(0xFF, count[0] & 1) == 0
                 return self.fn(*a)
 
         for name in gridpp_amd._capi.SIGNATURES:
