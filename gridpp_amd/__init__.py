@@ -58,6 +58,13 @@ def is_valid(value):
 _omp_threads = 1
 
 
+def get_statistic(name):
+    """gridpp::get_statistic (include/gridpp.h:1410, src/api/gridpp.cpp:11-43): the Statistic of a name.  The reference's table has no
+    "variance": that name, like any other it does not know, gives Unknown."""
+    return {"mean": Mean, "min": Min, "max": Max, "median": Median, "quantile": Quantile, "std": Std, "sum": Sum, "count": Count,
+            "randomchoice": RandomChoice}.get(name, Unknown)
+
+
 def set_omp_threads(num):   # src/api/gridpp.cpp:184-207 -- meaningless on the GPU path, kept for drop-in
     global _omp_threads
     _omp_threads = int(num)

@@ -66,6 +66,7 @@ inline const char* path_env(const char* n) { return path_override(n); }
 
 // ---- device runtime ----------------------------------------------------------
 hipStream_t stream();   // library stream (created on first use, after the device is chosen)
+hipStream_t stream2();  // a second one: work that runs BESIDE the library stream inside one call (ordered against it with events)
 void ensure_device();   // throws GPP_ENODEVICE when no GPU is visible
 
 template <class T>
@@ -181,7 +182,10 @@ struct gpp_points {
     // memo of the last OI call with this point set as the background: did k_oi_union pay? (same observations handle and
     // structure scales -> same geometry -> same answer; the observation VALUES do not matter)
     // (keyed on the observation set's serial number, not its address: a new handle may reuse the address of a destroyed one)
-    struct { unsigned long long points_id = 0; float h = 0, v = 0, w = 0; int kh = -1, kv = -1, kw = -1, cv = -1; int max_points = -1; float declined = 0; int leftover = -1; int n1 = 0; } union_memo;   // (leftover: 4-cell items the last call left to k_oi; n1: tiles its first pass declined)
+    struct { unsigned long long points_id = 0; float h = 0, v = 0, w = 0; int kh = -1, kv = -1, kw = -1, cv = -1; int max_points = -1; float declined = 0; int leftover = -1; int n1 = 0;
+             // the declined tiles themselves (round 5): a list in HBM, one flag byte per tile for the first pass, and the list's length as a device
+             // int -- the list passes of the NEXT call with this geometry run from it on a second stream while the first pass skips those tiles
+             gpp::DevBuf<int> list, count; gpp::DevBuf<unsigned char> flags; int nlist = 0, list_ntiles = 0; } union_memo;   // (leftover: 4-cell items the last call left to k_oi; n1: tiles its first pass declined)
     unsigned long long serial = 0;   // unique per handle, assigned at creation
     gpp_obs_index* obs_index = nullptr;
     gpp_nn_index* nn_index = nullptr;

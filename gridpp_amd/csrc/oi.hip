@@ -1169,12 +1169,17 @@ __global__ __launch_bounds__(256) void k_oi_huge(OiArgs a, const int* __restrict
 // -------------------------------------------------------------------------------------------
 // host entry point
 // -------------------------------------------------------------------------------------------
+// one flag byte per tile of a remembered work list (union_memo): the first pass of the next call leaves these tiles to the list passes
+__global__ void k_flag_tiles(const int* __restrict__ list, int n, int ntiles, unsigned char* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) { const int t = list[i]; if(t >= 0 && t < ntiles) flags[t] = 1; }
+}
 namespace {
 struct OiWorkspace {
     DevBuf<float4> pgeo, oaux, saux;
     // status block of a call, one memset and one read-back: ints [0] err, [1..3] work-list lengths, [4] large-n cell count;
     // statistics counters from byte 64 on
-    DevBuf<unsigned long long> status;
+    DevBuf<unsigned long long> status, status_snap;
     unsigned long long* h_status = nullptr;   // pinned host mirror
     DevBuf<int> cell_idx, obs_idx, fb_list, fb_list2, fb_list3, big_list;
     DevBuf<unsigned long long> big_keys, huge_keys;
@@ -1182,7 +1187,7 @@ struct OiWorkspace {
     DevBuf<int> huge_list;
     DevBuf<unsigned> pair_sel;   // k_oi -> k_oi_pairs: 128 B per cell
     DevBuf<int> pair_n;
-    hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr, ev_fork = nullptr, ev_join = nullptr;
 };
 thread_local OiWorkspace g_ws;
 thread_local gpp_oi_stats g_stats;
@@ -1203,7 +1208,7 @@ extern "C" int gpp_debug_poison_oi_workspace(int byte) {
     GPP_TRY
     ensure_device();
     OiWorkspace& w = g_ws;
-    w.pgeo.poison(byte); w.oaux.poison(byte); w.saux.poison(byte); w.status.poison(byte);
+    w.pgeo.poison(byte); w.oaux.poison(byte); w.saux.poison(byte); w.status.poison(byte); w.status_snap.poison(byte);
     w.cell_idx.poison(byte); w.obs_idx.poison(byte);
     w.fb_list.poison(byte); w.fb_list2.poison(byte); w.fb_list3.poison(byte); w.big_list.poison(byte); w.huge_list.poison(byte);
     w.big_keys.poison(byte); w.huge_keys.poison(byte); w.big_mat.poison(byte); w.huge_mat.poison(byte);
@@ -1483,7 +1488,7 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     ws.pgeo.get(S); ws.oaux.get(S); ws.saux.get(S);
     constexpr size_t SB = 8 + 80 + 2 * GPP_NSLOT;   // status block, in 8-byte words
     ws.status.get(SB);
-    if(!ws.h_status) GPP_HIP(hipHostMalloc((void**)&ws.h_status, SB * sizeof(unsigned long long), hipHostMallocDefault));
+    if(!ws.h_status) GPP_HIP(hipHostMalloc((void**)&ws.h_status, (SB + 1) * sizeof(unsigned long long), hipHostMallocDefault));
     int* const d_ints = reinterpret_cast<int*>(ws.status.p);
     int* const d_err = d_ints, *const d_fb_count = d_ints + 1, *const d_big_count = d_ints + 4, *const d_huge_count = d_ints + 5;
     unsigned long long* const d_counters = ws.status.p + 8;
@@ -1536,20 +1541,21 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     int err = 0;
     unsigned long long counters[80 + 2 * GPP_NSLOT];
     const bool plain = a.s.st.kh == GPP_SK_BARNES && a.s.st.kv == GPP_SK_BARNES && a.s.st.kw == GPP_SK_BARNES && !a.s.st.cv;
+    hipStream_t cur = stream();   // the stream the launch helpers below use: the library stream, or stream2() for the list passes that run beside the first pass
     auto launch_k_oi = [&](const bool lu) {   // k_oi over a.nrun tiles (all, or the fallback list of k_oi_union)
         const dim3 grid((a.nrun + 3) / 4), block(256);
         if(spatial) {   // (plain: three Barnes factors with per-point scales -- the straight-line correlation code takes them per lane)
-            if(N == 32) { if(plain) hipLaunchKernelGGL((k_oi<32, true, true, true>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi<32, true, false, true>), grid, block, 0, stream(), a); }
-            else hipLaunchKernelGGL((k_oi<62, true, false, true>), grid, block, 0, stream(), a);
+            if(N == 32) { if(plain) hipLaunchKernelGGL((k_oi<32, true, true, true>), grid, block, 0, cur, a); else hipLaunchKernelGGL((k_oi<32, true, false, true>), grid, block, 0, cur, a); }
+            else hipLaunchKernelGGL((k_oi<62, true, false, true>), grid, block, 0, cur, a);
         }
         else if(N == 32) {
-            if(lu) hipLaunchKernelGGL((k_oi<32, true, false, false>), grid, block, 0, stream(), a);
-            else if(plain) hipLaunchKernelGGL((k_oi<32, false, true, false>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_oi<32, false, false, false>), grid, block, 0, stream(), a);
+            if(lu) hipLaunchKernelGGL((k_oi<32, true, false, false>), grid, block, 0, cur, a);
+            else if(plain) hipLaunchKernelGGL((k_oi<32, false, true, false>), grid, block, 0, cur, a);
+            else hipLaunchKernelGGL((k_oi<32, false, false, false>), grid, block, 0, cur, a);
         }
         else {
-            if(lu) hipLaunchKernelGGL((k_oi<62, true, false, false>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_oi<62, false, false, false>), grid, block, 0, stream(), a);
+            if(lu) hipLaunchKernelGGL((k_oi<62, true, false, false>), grid, block, 0, cur, a);
+            else hipLaunchKernelGGL((k_oi<62, false, false, false>), grid, block, 0, cur, a);
         }
         GPP_HIP(hipGetLastError());
     };
@@ -1561,12 +1567,12 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const bool pairs_ok = N == 32 && !spatial && (size_t)C * 128 <= PAIR_PARK_MAX && !path_env("GPP_OI_NO_PAIRS");
     auto park_on = [&](const bool clear) {
         a.pair_sel = ws.pair_sel.get((size_t)C * 32); a.pair_n = ws.pair_n.get((size_t)C);
-        if(clear) GPP_HIP(hipMemsetAsync(a.pair_n, 0, (size_t)C * sizeof(int), stream()));
+        if(clear) GPP_HIP(hipMemsetAsync(a.pair_n, 0, (size_t)C * sizeof(int), cur));
     };
     auto launch_pairs = [&]() {
         const dim3 grid((a.ntiles + 3) / 4), block(256);
-        if(plain) hipLaunchKernelGGL(k_oi_pairs<true>, grid, block, 0, stream(), a);
-        else hipLaunchKernelGGL(k_oi_pairs<false>, grid, block, 0, stream(), a);
+        if(plain) hipLaunchKernelGGL(k_oi_pairs<true>, grid, block, 0, cur, a);
+        else hipLaunchKernelGGL(k_oi_pairs<false>, grid, block, 0, cur, a);
         GPP_HIP(hipGetLastError());
         a.pair_sel = nullptr; a.pair_n = nullptr;
     };
@@ -1613,10 +1619,11 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         else hipLaunchKernelGGL(k_oi_huge<false>, dim3(nwg), dim3(256), 0, stream(), a, d_list, d_count);
         GPP_HIP(hipGetLastError());
     };
-    bool ran_union = false;
+    bool ran_union = false, ran_overlap = false;
+    int overlap_left = 0, overlap_new = 0, overlap_remembered = 0;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
-        ran_union = false;
+        ran_union = false; ran_overlap = false;
         if(use_union && !use_lu) {
             // worst case per list: every tile declined and split into 4 (level 1) resp. 16 (level 2) items
             const int SHORT_ITEMS = 3072;   // as many work items as the chip holds waves of this kernel
@@ -1627,16 +1634,12 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             auto launch_union = [&](const long items, const bool list) {   // one wave per work item
                 const long nb = (items + WPB - 1) / WPB;
                 const dim3 grid((unsigned)std::min<long>(nb, 0x7fffffffL));
-                if(N != 32) gpp_launch_union64(a, grid.x, plain, list, stream());
+                if(N != 32) gpp_launch_union64(a, grid.x, plain, list, cur);
                 // (the first pass is persistent: a grid that fills the chip, every wave strides over the tiles)
-                else if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true, 32>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<true, false, 32>), UnionCfg<32>::persistent<true>() ? dim3(union_persist_grid<k_oi_union<true, false, 32>>(block.x, nb)) : grid, block, 0, stream(), a); }
-                else { if(list) hipLaunchKernelGGL((k_oi_union<false, true, 32>), grid, block, 0, stream(), a); else hipLaunchKernelGGL((k_oi_union<false, false, 32>), grid, block, 0, stream(), a); }
+                else if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true, 32>), grid, block, 0, cur, a); else hipLaunchKernelGGL((k_oi_union<true, false, 32>), UnionCfg<32>::persistent<true>() ? dim3(union_persist_grid<k_oi_union<true, false, 32>>(block.x, nb)) : grid, block, 0, cur, a); }
+                else { if(list) hipLaunchKernelGGL((k_oi_union<false, true, 32>), grid, block, 0, cur, a); else hipLaunchKernelGGL((k_oi_union<false, false, 32>), grid, block, 0, cur, a); }
                 GPP_HIP(hipGetLastError());
             };
-            // pass 1: every tile
-            a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
-            launch_union(a.ntiles, false);
-            GPP_HIP(hipEventRecord(ws.eu, stream()));
             // The tiles it declined.  The usual case is a short list (or none): it is taken WITHOUT asking the host how long it
             // is -- the short-list pass and the k_oi pass behind it are launched with fixed small grids and read the lengths
             // on the device; a list too long for that grid is left untouched by both and handled after the one read-back of
@@ -1670,7 +1673,78 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 if(pairs) launch_pairs();
             };
             const bool expect_long = memo_hit && 16.0 * (double)memo.declined * (double)a.ntiles > (double)SHORT_ITEMS;
-            if(!expect_long) {
+            // Round 5: the list passes BESIDE the first pass.  The tiles a geometry declines do not depend on the values (only on the
+            // coordinates, the structure and which observations are usable), so the list of the last call is this call's list: it is kept
+            // with the geometry (memo.list, one flag byte per tile), the first pass leaves the flagged tiles alone, and the list passes over
+            // the REMEMBERED list are launched on a second stream at the same time -- their latency (one lone work item per pass: 55 us of a
+            // 0.62 ms step at 500 rows per rank, 146 us of the 4.46 ms headline) disappears behind the first pass.  Nothing depends on the
+            // memory being right: a flagged tile is solved by the list passes whatever the first pass would have made of it (all paths give
+            // the same bits), and a tile the first pass declines that was NOT flagged arrives in its out_list as before, is taken by the serial
+            // passes after the read-back and joins the remembered list.
+            const bool overlap = memo_hit && memo.nlist > 0 && memo.list_ntiles == a.ntiles && !path_env("GPP_OI_NO_OVERLAP");
+            int n_remembered = 0;
+            if(overlap) {
+                n_remembered = memo.nlist;
+                if(!ws.ev_fork) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming)); }
+                GPP_HIP(hipEventRecord(ws.ev_fork, stream()));             // (behind k_pack_obs, which also cleared the status block)
+                a.skip_flags = memo.flags.p;
+                a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
+                launch_union(a.ntiles, false);                             // pass 1 on the library stream
+                GPP_HIP(hipEventRecord(ws.eu, stream()));
+                a.skip_flags = nullptr;
+                cur = stream2();
+                GPP_HIP(hipStreamWaitEvent(cur, ws.ev_fork, 0));
+                const int* const d_mcount = memo.count.p;
+                if(16 * (long)n_remembered <= SHORT_ITEMS) {
+                    a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
+                    launch_union(16 * (long)n_remembered, true);
+                    a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 128;
+                    if(!skip_k_oi) launch_k_oi(false);
+                }
+                else {
+                    a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
+                    launch_union(4 * (long)n_remembered, true);
+                    a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
+                    a.parent_count = d_mcount;
+                    launch_union(16 * (long)n_remembered, true);
+                    a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                    const bool pairs = pairs_ok && !skip_k_oi && 4 * (long)n_remembered > a.ntiles;
+                    if(pairs) park_on(true);
+                    if(!skip_k_oi) launch_k_oi(false);
+                    if(pairs) launch_pairs();
+                }
+                GPP_HIP(hipEventRecord(ws.ev_join, cur));
+                cur = stream();
+                GPP_HIP(hipStreamWaitEvent(cur, ws.ev_join, 0));
+                GPP_HIP(hipEventRecord(ws.e1, stream()));
+                fetch();
+                if(skip_k_oi && h_ints[3] > 0) {   // 4-cell items for k_oi after all (before the counts below are cleared)
+                    a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                    launch_k_oi(false);
+                }
+                const int n_new = h_ints[1];
+                const int left_remembered = h_ints[3];
+                if(n_new > 0) {   // tiles the first pass declined that the memory did not hold: the serial passes, as without the overlap
+                    GPP_HIP(hipMemsetAsync(d_fb_count + 1, 0, 2 * sizeof(int), stream()));
+                    if(16 * (long)n_new > SHORT_ITEMS) { long_passes(n_new); if(skip_k_oi) launch_k_oi(false); }
+                    else {
+                        a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
+                        launch_union(16 * (long)n_new, true);
+                        a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                        launch_k_oi(false);
+                    }
+                }
+                if(n_new > 0 || (skip_k_oi && left_remembered > 0)) {
+                    GPP_HIP(hipEventRecord(ws.e1, stream()));
+                    fetch();
+                }
+                overlap_left = left_remembered + (n_new > 0 ? h_ints[3] : 0);
+                overlap_new = n_new; overlap_remembered = n_remembered; ran_overlap = true;
+            }
+            else if(!expect_long) {
+                a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
+                launch_union(a.ntiles, false);                             // pass 1: every tile
+                GPP_HIP(hipEventRecord(ws.eu, stream()));
                 // (a geometry that declined no tile the last time: not even the two empty launches; the read-back says if that was wrong)
                 const bool expect_none = memo_hit && memo.declined == 0.0f;
                 if(!expect_none) short_passes(SHORT_ITEMS);
@@ -1684,23 +1758,30 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 }
             }
             else {
+                a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
+                launch_union(a.ntiles, false);                             // pass 1: every tile
+                GPP_HIP(hipEventRecord(ws.eu, stream()));
                 // A long list is expected, and the same geometry declines the same tiles: the two-level passes are launched for the length
                 // of the last call (+ 1/8) without asking the host first -- they read the true length on the device.  Only if MORE tiles were
                 // declined than those grids hold (other observations turned invalid) are the passes run again with the true length: every
                 // pass writes the same values for the cells it handles, so that is merely slower.
-                const int cap = memo.n1 + memo.n1 / 8 + 64;
+                const int cap = path_env("GPP_OI_LONG_CAP") ? atoi(path_env("GPP_OI_LONG_CAP")) : memo.n1 + memo.n1 / 8 + 64;   // (the override: tests force the second run)
+                // (the statistics counters as the first pass left them: a second run of the list passes must not count its cells twice)
+                ws.status_snap.get(SB);
+                GPP_HIP(hipMemcpyAsync(ws.status_snap.p, d_counters, (SB - 8) * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream()));
                 long_passes(cap);
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
                 const int n1 = h_ints[1];
                 if(n1 > cap) {
                     GPP_HIP(hipMemsetAsync(d_fb_count + 1, 0, 2 * sizeof(int), stream()));
+                    GPP_HIP(hipMemcpyAsync(d_counters, ws.status_snap.p, (SB - 8) * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream()));
                     long_passes(n1);
                     GPP_HIP(hipEventRecord(ws.e1, stream()));
                     fetch();
                 }
             }
-            if(skip_k_oi && h_ints[3] > 0) {   // 4-cell items for k_oi after all
+            if(!overlap && skip_k_oi && h_ints[3] > 0) {   // 4-cell items for k_oi after all
                 a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
                 launch_k_oi(false);
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
@@ -1716,15 +1797,42 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
             GPP_HIP(hipEventRecord(ws.e1, stream()));
             fetch();
         }
-        const int nfb[3] = {ran_union ? h_ints[1] : 0, ran_union ? h_ints[2] : 0, ran_union ? h_ints[3] : 0};
+        // (with the list passes beside the first pass its out_list holds only the tiles the memory did not know: overlap_new of them)
+        const int n_listed = ran_union ? h_ints[1] : 0;             // entries of ws.fb_list written by this call's first pass
+        const int nfb[3] = {ran_overlap ? overlap_remembered + overlap_new : n_listed, ran_union ? h_ints[2] : 0, ran_overlap ? overlap_left : (ran_union ? h_ints[3] : 0)};
         g_stats.fallback_tiles = nfb[0];
         g_stats.fallback_subtiles = nfb[2];
         if(ran_union) {
+            if(!memo_hit) { memo.nlist = 0; memo.list_ntiles = 0; }
             memo.points_id = points->serial; memo.h = a.s.st.h; memo.v = a.s.st.v; memo.w = a.s.st.w; memo.max_points = max_points;
             memo.kh = a.s.st.kh; memo.kv = a.s.st.kv; memo.kw = a.s.st.kw; memo.cv = a.s.st.cv;
             memo.declined = (float)nfb[0] / (float)a.ntiles;
             memo.leftover = nfb[2];
             memo.n1 = nfb[0];
+            // the declined tiles themselves, for the next call with this geometry (see `overlap` above).  The serial path lists EVERY declined
+            // tile in ws.fb_list: the memory is rebuilt from it; the overlapped path lists only the tiles the memory did not hold: appended.
+            // (room for every tile; nothing is launched when nothing changes -- the steady state of a repeated call)
+            const bool keep_list = !path_env("GPP_OI_NO_OVERLAP");
+            int n_add = 0;
+            if(!ran_overlap) {
+                memo.nlist = 0;
+                if(keep_list && n_listed > 0) {
+                    memo.list.get((size_t)a.ntiles); memo.flags.get((size_t)a.ntiles); memo.count.get(1);
+                    GPP_HIP(hipMemsetAsync(memo.flags.p, 0, (size_t)a.ntiles, stream()));
+                    memo.list_ntiles = a.ntiles;
+                    n_add = std::min(n_listed, a.ntiles);
+                }
+            }
+            else n_add = std::min(overlap_new, a.ntiles - memo.nlist);
+            if(n_add > 0) {
+                GPP_HIP(hipMemcpyAsync(memo.list.p + memo.nlist, ws.fb_list.p, (size_t)n_add * sizeof(int), hipMemcpyDeviceToDevice, stream()));
+                hipLaunchKernelGGL(k_flag_tiles, dim3((n_add + 255) / 256), dim3(256), 0, stream(), (const int*)(memo.list.p + memo.nlist), n_add, a.ntiles, memo.flags.p);
+                GPP_HIP(hipGetLastError());
+                memo.nlist += n_add;
+                ws.h_status[SB] = (unsigned long long)memo.nlist;      // (pinned: one word behind the mirror of the status block)
+                GPP_HIP(hipMemcpyAsync(memo.count.p, ws.h_status + SB, sizeof(int), hipMemcpyHostToDevice, stream()));
+                GPP_HIP(hipStreamSynchronize(stream()));
+            }
         }
         if(big_ok) {
             const int nbig = h_ints[4];

@@ -156,7 +156,10 @@ __device__ __forceinline__ double d_exp_nonpos(double x) {
 // (relative) to a float32 rounding boundary, so rounding the product gives the correctly rounded quotient (a result in
 // the subnormal range may differ in the last bit; rho is 1 there either way).  6 instead of 14 instructions.
 __device__ __forceinline__ float d_div_by(float dist, double rlen) { return (float)((double)dist * rlen); }
-// d_barnes_rho for a valid, non-zero length, without divergent branches (same values; NaN dist gives NaN)
+// d_barnes_rho for a valid, non-zero length, without divergent branches.  Same values for every valid dist.  A NaN dist gives exp(-112.5) = 0
+// (fminf drops the NaN) -- what the reference returns for !is_valid(dist) (structure.cpp:28-29) -- and not NaN: callers that need to
+// know about a missing coordinate test d_valid() themselves (d_barnes_corr_flat does for the elevation / laf factors).  d_exp_core is
+// called down to -112.5 here (tests/test_exp_table.py checks [-112.5, -110] too).
 __device__ __forceinline__ float d_barnes_rho_flat(float dist, double rlen) {
     // (|v| cut at 15: exp(-112.5) = 1e-49 is 0 in float32 like everything below exp(-103.98) -- one float32 minimum instead of a double
     //  maximum in front of the exp and a compare + select behind it)

@@ -43,6 +43,8 @@ struct OiArgs {
     int* out_count;
     int nrun;                // tiles to run when in_list is NULL
     int* tail_count;         // persistent first pass: counter of its dynamic tail (cleared with the status block)
+    const unsigned char* skip_flags;   // first pass: tiles it leaves alone (NULL: none) -- the tiles this geometry declined in earlier calls, which the
+                                       // list passes take from the remembered list on a second stream WHILE the first pass runs (oi.hip, `overlap`)
     int level;               // k_oi_union<., true>: 1 or 2 (see there)
     const int* parent_count; // level 2: length of the level-1 input list (how many tiles were split)
     int debug;               // GPP_OI_DEBUG: bit0 = skip the solve (timing experiments only)
@@ -939,7 +941,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
     }
     else if constexpr(!UnionCfg<NC>::template persistent<PLAIN>()) {   // (the other forms keep one tile per wave: the loop costs them registers they do not have)
         const int tile = blockIdx.x * WPB + wid;
-        if(tile < a.ntiles) union_item<PLAIN, false, NC>(a, tile, -1, 0, s_u[wid], lane);
+        if(tile < a.ntiles && !(a.skip_flags && a.skip_flags[tile])) union_item<PLAIN, false, NC>(a, tile, -1, 0, s_u[wid], lane);
     }
     else {
         // static part: whole rounds of the grid; dynamic tail: the remaining tiles one by one from a counter (a wave whose tiles were
@@ -960,6 +962,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
 #endif
                 if(tile >= a.ntiles) break;
             }
+            if(a.skip_flags && a.skip_flags[tile]) { tile += stride; continue; }
             // (the lane number as a value the optimiser cannot see through: everything derived from it -- LDS addresses, `lane == k` masks,
             //  triangle indices -- is otherwise an invariant of this loop, computed once and kept: 15 registers over the budget of three
             //  waves per SIMD, i.e. scratch)

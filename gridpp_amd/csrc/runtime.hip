@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_stream = nullptr, g_stream2 = nullptr;
 static std::atomic<unsigned long long> g_next_serial{1};   // one counter for every instantiation of make_points<T>
 static std::atomic<int> g_live_handles{0};   // gpp_points alive (gpp_set_device refuses to switch under them)
 static int g_device = -1;
@@ -41,6 +41,12 @@ void ensure_device() {
 hipStream_t stream() {
     ensure_device();
     return g_stream;
+}
+hipStream_t stream2() {
+    ensure_device();
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if(!g_stream2) GPP_HIP(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
+    return g_stream2;
 }
 
 }   // namespace gpp
@@ -147,6 +153,7 @@ extern "C" int gpp_set_device(int device) {
         // afterwards would mix pointers of two devices
         if(g_stream && g_live_handles.load() > 0) invalid("gpp_set_device: the device cannot change while point sets / fields created on the current one are alive");
         if(g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+        if(g_stream2) { (void)hipStreamDestroy(g_stream2); g_stream2 = nullptr; }
         g_device = device;
         GPP_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     }

@@ -76,6 +76,13 @@ struct Handle {
 
 inline bool is_valid(float value) { return !std::isnan(value) && !std::isinf(value); }   // src/api/util.cpp:16-18
 inline std::string version() { return gpp_version(); }
+// include/gridpp.h:1410, src/api/gridpp.cpp:11-43 (the reference's table has no "variance": Unknown, like every other name it does not know)
+inline Statistic get_statistic(const std::string& name) {
+    static const struct { const char* n; Statistic s; } table[] = {{"mean", Mean}, {"min", Min}, {"max", Max}, {"median", Median}, {"quantile", Quantile},
+                                                                   {"std", Std}, {"sum", Sum}, {"count", Count}, {"randomchoice", RandomChoice}};
+    for(const auto& e : table) if(name == e.n) return e.s;
+    return Unknown;
+}
 inline void set_omp_threads(int) {}        // src/api/gridpp.cpp:184-207: no meaning on the GPU path
 inline int get_omp_threads() { return 1; }
 // messages (include/gridpp.h:1394-1430, src/api/gridpp.cpp:70-76, src/api/util.cpp:226-252)

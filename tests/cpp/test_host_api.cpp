@@ -191,6 +191,9 @@ int main() {
         CHECK(est.cells == 4 && est.condition_passthrough == 4 && est.real_part_passthrough == 0);
         CHECK(o3[0][1][0] == 3 && o3[1][1][2] == 11);
     }
+    // get_statistic (include/gridpp.h:1410, src/api/gridpp.cpp:11-43)
+    if(get_statistic("mean") != Mean || get_statistic("randomchoice") != RandomChoice || get_statistic("quantile") != Quantile ||
+       get_statistic("variance") != Unknown || get_statistic("x") != Unknown) { std::printf("FAIL get_statistic\n"); return 1; }
     std::printf("gridpp.hpp host API: all checks passed (version %s)\n", version().c_str());
     return 0;
 }

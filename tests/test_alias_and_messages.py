@@ -14,7 +14,7 @@ def test_import_gridpp_is_this_implementation():
     for name in ("Grid", "Points", "Point", "BarnesStructure", "CressmanStructure", "CrossValidation", "MultipleStructure", "optimal_interpolation",
                  "optimal_interpolation_full", "optimal_interpolation_ensi", "neighbourhood", "neighbourhood_quantile", "neighbourhood_quantile_fast",
                  "neighbourhood_brute_force", "get_neighbourhood_thresholds", "nearest", "bilinear", "Mean", "Median", "Geodetic", "Cartesian",
-                 "set_omp_threads", "get_omp_threads", "set_debug_level", "get_debug_level", "version", "is_valid", "MV"):
+                 "set_omp_threads", "get_omp_threads", "set_debug_level", "get_debug_level", "version", "is_valid", "MV", "get_statistic"):
         assert getattr(gridpp, name) is getattr(gridpp_amd, name), name
 
 
@@ -53,3 +53,13 @@ def test_debug_level_and_messages(capsys):
         assert str(e) == "bad"
     assert capsys.readouterr().out.strip() == "Error: bad"
     assert abs(gridpp.clock() - __import__("time").time()) < 5
+
+
+def test_get_statistic_name_table():
+    """include/gridpp.h:1410, src/api/gridpp.cpp:11-43: nine names; "variance" is not among them in the reference either"""
+    import gridpp
+    for name, st in (("mean", gridpp.Mean), ("min", gridpp.Min), ("max", gridpp.Max), ("median", gridpp.Median), ("quantile", gridpp.Quantile),
+                     ("std", gridpp.Std), ("sum", gridpp.Sum), ("count", gridpp.Count), ("randomchoice", gridpp.RandomChoice)):
+        assert gridpp.get_statistic(name) == st
+    for name in ("variance", "Mean", "", "nonsense"):
+        assert gridpp.get_statistic(name) == gridpp.Unknown

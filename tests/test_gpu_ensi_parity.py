@@ -321,3 +321,39 @@ def test_ensi_in_many_batches_of_tiles(monkeypatch):
     many = np.asarray(gridpp.optimal_interpolation_ensi(*args))
     assert np.array_equal(one, many, equal_nan=True)
     ensi_golden.check(one, c)
+
+
+@pytest.mark.parametrize("E,mp,S", [(50, 30, 150), (20, 10, 100), (30, 50, 150), (70, 40, 120)])
+@pytest.mark.parametrize("kw", [dict(sig_scale=0.1), dict(sig_scale=0.01), dict(spread=0.01), dict(spread=100.0), dict(sig_scale=0.1, spread=0.01),
+                                dict(offset=20.0), dict(dup=True), dict(sig_scale=0.01, offset=20.0, dup=True)], ids=lambda kw: ",".join("%s=%g" % kv for kv in kw.items()))
+def test_ensi_off_the_benign_manifold(E, mp, S, kw):
+    """Round 5 (tools/ensi_illcond.py, profiles/r05_ensi_illcond.txt): observation sigmas far below the ensemble spread (large Y^T R^-1 Y, many
+    sweeps, a large diagonal against the fixed 0.040 c cut of the default mode), a spread far from the observation error, observations 20
+    spreads away, two near-duplicate members -- on the tile path (max_points <= 32, both modes) and on the large-n kernels, in the PLAIN measure.
+    (E = 30, max_points = 50 with sigma x 0.01 is the case whose Newton-Schulz iteration did not converge until round 5, E = 70 the one whose
+    Jacobi stopped at 1e-11 * trace: /root/reference/src/api/oi_ensi.cpp:379-437 is all float64.)  The axis ends where the reference stops
+    reproducing itself: with spread / sigma >= 1e3 two faithful implementations of its inv + eig_sym (the oracle and the LAPACK restatement)
+    differ by 1e-5 and more (tools/ensi_illcond.py prints that column; profiles/r05_ensi_illcond.txt)."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    lats, lons, bg, plat, plon, pbg, obs, sig = case(4100 + E, 6, 6, E, S)
+    sig = (sig * kw.get("sig_scale", 1.0)).astype(np.float32)
+    sp = kw.get("spread", 1.0)
+    if sp != 1.0:
+        m = bg.mean(axis=2, keepdims=True); bg = (m + sp * (bg - m)).astype(np.float32)
+        pm = pbg.mean(axis=1, keepdims=True); pbg = (pm + sp * (pbg - pm)).astype(np.float32)
+    if kw.get("offset"):
+        obs = (obs + kw["offset"] * np.where(np.arange(S) % 2, -1, 1)).astype(np.float32)
+    if kw.get("dup"):
+        bg[:, :, E - 1] = bg[:, :, 0] * np.float32(1 + 1e-6); pbg[:, E - 1] = pbg[:, 0] * np.float32(1 + 1e-6)
+    h = 60000.0
+    ref = O.oi_ensi(O.Pts(lats.ravel(), lons.ravel()), bg.reshape(-1, E), O.Pts(plat, plon), obs, sig, pbg, O.Barnes(h), mp, True).reshape(bg.shape)
+    for converged in (False, True):
+        gridpp.ensi_set_convergence(converged)
+        try:
+            out = np.asarray(gridpp.optimal_interpolation_ensi(gridpp.Grid(lats, lons), bg, gridpp.Points(plat, plon), obs, sig, pbg, gridpp.BarnesStructure(h), mp, True))
+        finally:
+            gridpp.ensi_set_convergence(False)
+        assert (np.isnan(out) == np.isnan(ref)).all()
+        err = plain_err(out, ref)
+        assert err.max() < RTOL, (converged, float(err.max()))

@@ -135,6 +135,87 @@ def test_parked_selections_behind_a_long_work_list():
         gridpp.optimal_interpolation(g2, b2, points, obs, ratios, pbg, st, 30)    # direct path: every count of the larger grid written
 
 
+def test_long_list_longer_than_remembered_is_run_again_without_counting_twice(monkeypatch):
+    """A geometry that remembers a long work list launches the two-level list passes for the remembered length without asking the host
+    (csrc/oi.hip, `expect_long`); when MORE tiles are declined than those grids hold, the passes run again with the true length.  Forced
+    here with GPP_OI_LONG_CAP: same bits as the first call, and the statistics of the call count every cell once (the
+    atomics of both runs used to add up)."""
+    import gridpp_amd as gridpp
+    rng = np.random.default_rng(79)
+    Y, X, S = 640, 240, 800       # (sparse observations: the 64 cells of a smooth tile select almost the same 30)
+    lats, lons = np.meshgrid(np.linspace(60, 60 + Y / 240.0, Y), np.linspace(10, 12, X), indexing="ij")
+    ge, gl = rng.uniform(0, 1000, (Y, X)).astype(np.float32), rng.uniform(0, 1, (Y, X)).astype(np.float32)
+    ge[:560] = 100.0; gl[:560] = 0.5                          # smooth: k_oi_union keeps these tiles; the rough rest is declined (less than half)
+    plat, plon = 60 + Y / 240.0 * rng.random(S), 10 + 2 * rng.random(S)
+    pe, pl = rng.uniform(0, 1000, S).astype(np.float32), rng.uniform(0, 1, S).astype(np.float32)
+    pe[plat < 60 + 560 / 240.0] = 100.0; pl[plat < 60 + 560 / 240.0] = 0.5      # (the observations over the smooth rows as well)
+    bg = rng.normal(0, 2, (Y, X)).astype(np.float32)
+    obs, pbg = rng.normal(0, 2, S).astype(np.float32), rng.normal(0, 2, S).astype(np.float32)
+    ratios = rng.uniform(0.05, 2, S).astype(np.float32)
+    grid, points, st = gridpp.Grid(lats, lons, ge, gl), gridpp.Points(plat, plon, pe, pl), gridpp.BarnesStructure(8000.0, 200.0, 0.5)
+    out1 = np.asarray(gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 30))
+    s1 = gridpp.oi_last_stats()
+    assert s1["union_kernel_ms"] > 0 and 192 < s1["fallback_tiles"] < 0.5 * (Y * X / 64)      # a long list, and the first pass still pays
+    out2 = np.asarray(gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 30))   # (remembered length: one run)
+    s2 = gridpp.oi_last_stats()
+    monkeypatch.setenv("GPP_OI_LONG_CAP", "8")
+    out3 = np.asarray(gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 30))   # (grids for 8 tiles: run again)
+    s3 = gridpp.oi_last_stats()
+    assert np.array_equal(out1, out2, equal_nan=True) and np.array_equal(out1, out3, equal_nan=True)
+    for k in ("cells", "cells_updated", "solves", "fallback_tiles", "fallback_subtiles"):
+        assert s1[k] == s2[k] == s3[k], (k, s1[k], s2[k], s3[k])
+
+
+@pytest.mark.parametrize("long_list", [False, True], ids=["short_list", "long_list"])
+def test_list_passes_beside_the_first_pass_from_the_remembered_list(long_list, monkeypatch):
+    """Round 5 (csrc/oi.hip, `overlap`): a geometry keeps the list of the tiles its first pass declined; the next call with the same Grid
+    handle runs the list passes over the REMEMBERED list on a second stream while the first pass skips those tiles.  Nothing may depend
+    on the memory being right: (1) the second and third call equal the first bit for bit and report the same statistics; (2) with other
+    observations unusable (the first pass declines OTHER tiles: new ones go through the serial passes and join the memory, remembered
+    ones that would fit now are solved by the list passes all the same) the result equals that of a fresh handle; (3) back to the first
+    inputs; (4) the same with the overlap switched off.  /root/reference/src/api/oi.cpp:221-338 has no state between grid points."""
+    import gridpp_amd as gridpp
+    rng = np.random.default_rng(81 + long_list)
+    Y, X, S = (640, 240, 800) if long_list else (200, 120, 130)       # (sparse observations: the 64 cells of a smooth tile select almost the same 30)
+    lats, lons = np.meshgrid(np.linspace(60, 60 + Y / 240.0, Y), np.linspace(10, 10 + X / 120.0, X), indexing="ij")
+    ge, gl = rng.uniform(0, 1000, (Y, X)).astype(np.float32), rng.uniform(0, 1, (Y, X)).astype(np.float32)
+    smooth = 560 if long_list else 190
+    ge[:smooth] = 100.0; gl[:smooth] = 0.5                     # smooth rows: the first pass keeps them; the rough rest is declined
+    plat, plon = 60 + Y / 240.0 * rng.random(S), 10 + X / 120.0 * rng.random(S)
+    pe, pl = rng.uniform(0, 1000, S).astype(np.float32), rng.uniform(0, 1, S).astype(np.float32)
+    pe[plat < 60 + smooth / 240.0] = 100.0; pl[plat < 60 + smooth / 240.0] = 0.5
+    bg = rng.normal(0, 2, (Y, X)).astype(np.float32)
+    obs, pbg = rng.normal(0, 2, S).astype(np.float32), rng.normal(0, 2, S).astype(np.float32)
+    obs2 = obs.copy(); obs2[rng.random(S) < 0.3] = np.nan     # other usable observations: other selections, other declined tiles
+    ratios = rng.uniform(0.05, 2, S).astype(np.float32)
+    points, st = gridpp.Points(plat, plon, pe, pl), gridpp.BarnesStructure(8000.0, 200.0, 0.5)
+
+    def fresh(o):
+        out = np.asarray(gridpp.optimal_interpolation(gridpp.Grid(lats, lons, ge, gl), bg, points, o, ratios, pbg, st, 30))
+        return out, gridpp.oi_last_stats()
+    ref1, sr1 = fresh(obs)
+    ref2, sr2 = fresh(obs2)
+    assert sr1["union_kernel_ms"] > 0 and sr1["fallback_tiles"] > (192 if long_list else 0) and 16 * sr1["fallback_tiles"] > (3072 if long_list else 0)
+    if not long_list:
+        assert 16 * sr1["fallback_tiles"] <= 3072
+    grid = gridpp.Grid(lats, lons, ge, gl)
+    keys = ("cells", "cells_updated", "solves")
+    for step, (o, ref, sr) in enumerate([(obs, ref1, sr1), (obs, ref1, sr1), (obs, ref1, sr1), (obs2, ref2, sr2), (obs2, ref2, sr2), (obs, ref1, sr1), (obs, ref1, sr1)]):
+        out = np.asarray(gridpp.optimal_interpolation(grid, bg, points, o, ratios, pbg, st, 30))
+        s = gridpp.oi_last_stats()
+        assert np.array_equal(out, ref, equal_nan=True), step
+        assert s["cells"] == sr["cells"] and s["cells_updated"] == sr["cells_updated"], (step, s, sr)
+        # (the memory only grows: remembered tiles stay listed -- until more than half of the tiles are, and the call goes to k_oi alone)
+        assert s["fallback_tiles"] >= sr["fallback_tiles"] or s["union_kernel_ms"] == 0, (step, s, sr)
+    monkeypatch.setenv("GPP_OI_NO_OVERLAP", "1")
+    out = np.asarray(gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 30))
+    s = gridpp.oi_last_stats()
+    assert np.array_equal(out, ref1, equal_nan=True)
+    if s["union_kernel_ms"] > 0:       # (not when the memory holds more than half of the tiles by now: that call went to k_oi alone)
+        for k in keys + ("fallback_tiles",):
+            assert s[k] == sr1[k], (k, s[k], sr1[k])
+
+
 @pytest.mark.parametrize("seed", range(300, 312))
 def test_random_configurations_pivoted_lu(seed, monkeypatch):
     """The pivoted-LU form of k_oi (non-symmetric / spatially varying structures; forced here on symmetric systems, whose oracle

@@ -28,27 +28,17 @@ flags = args[3:]
 mps = [33, 40, 50, 62] if "62" in flags else [1, 2, 7, 20, 30, 32]
 poison = "poison" in flags
 dump = next((f.split("=", 1)[1] for f in flags if f.startswith("dump=")), os.path.join(ROOT, "gpurun_out", "hostile"))
-if poison:
-    os.environ["GPP_LIB"] = os.path.join(ROOT, "gridpp_amd", "lib", "var_poison.so")
-
-import gridpp_amd as gridpp                                     # noqa: E402
+from tools.hostile.harness import Hostile                      # noqa: E402  (sets GPP_LIB for the poisoned build before gridpp_amd loads)
+H = Hostile(poison)
+gridpp = H.gridpp
 from oracle import oracle as O                                  # noqa: E402
 from tests.test_gpu_oi_union_stress import _random_inputs       # noqa: E402
 
 RTOL = 1e-5
-plib = None
-if poison:
-    glib = gridpp._capi.lib()        # (first: it loads torch's HIP runtime, which the helper library then shares)
-    plib = C.CDLL(os.path.join(ROOT, "tools", "hostile", "libpoison.so"))
-    glib.gpp_debug_poison_oi_workspace.argtypes = [C.c_int]
 
 
 def hostile():
-    if not poison:
-        return
-    assert plib.poison_lds(C.c_uint(0xFFFFFFFF)) == 0
-    assert plib.poison_regs(C.c_uint(0xFFFFFFFF)) == 0
-    assert glib.gpp_debug_poison_oi_workspace(0xFF) == 0
+    H.before_call()
 
 
 def compare(out, ref):
