@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--obs", type=int, default=0)
     ap.add_argument("--max-points", type=int, default=30)
     ap.add_argument("--h", type=float, default=10000.0)
+    ap.add_argument("--equal-tiles", action="store_true", help="case oi, N > 1: keep the equal row tiles (no rebalancing by measured kernel time)")
+    ap.add_argument("--sync-calls", action="store_true", help="case oi: one blocking call per step instead of one analysis ahead (A/B of the GPP_ASYNC path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -186,19 +188,60 @@ def main():
         points = gridpp.Points(plat, plon)             # bin-sorted observation index resident in HBM
         structure = gridpp.BarnesStructure(args.h)
         d_bg = torch.from_numpy(bg).to(dev)
+        tiles_note = None
+        if world > 1 and not args.equal_tiles:
+            # Row tiles by measured cost (round 5): equal tiles do not cost the same (the ranks at the edge of the domain see fewer candidates per
+            # tile than the ones in the middle) and the step ends with the slowest rank.  Two analyses on the equal tiles, the kernel time of
+            # every rank gathered, and -- if they are more than 3 % apart -- the rows cut again where the running cost crosses each rank's
+            # share (gridpp_amd.dist.weighted_row_tiles; every rank computes the same boundaries from the same gathered times).
+            t_obs, t_rat, t_pbg = (torch.from_numpy(a).to(dev) for a in (obs, ratios, pbg))
+            for _ in range(3):
+                gridpp.optimal_interpolation(grid, d_bg, points, t_obs, t_rat, t_pbg, structure, args.max_points)
+            mine = torch.tensor([gridpp.oi_last_stats()["kernel_ms"]], dtype=torch.float64, device=dev)
+            allms = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allms, mine)
+            allms = [float(t.item()) for t in allms]
+            spread = (max(allms) - min(allms)) / (sum(allms) / world)
+            tiles_note = {"equal_tiles_kernel_ms": allms, "spread": spread, "rebalanced": False}
+            if spread > 0.03:
+                w = np.concatenate([np.full(r1 - r0, allms[r] / max(1, r1 - r0)) for r, (r0, r1) in enumerate(gdist.all_tiles(ny, world))])
+                tiles = gdist.weighted_row_tiles(w, world, min_rows=8)
+                row0, row1 = tiles[rank]
+                lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(ny, nx, S, seed, row0, row1)
+                grid = gridpp.Grid(lats, lons)
+                d_bg = torch.from_numpy(bg).to(dev)
+                tiles_note.update(rebalanced=True, row_tiles=[list(t) for t in tiles])
         # rank 0 owns the observation values of each step; the others receive them over RCCL.  Double-buffered: the broadcast
         # of the NEXT step's values is in flight on RCCL's stream while this step's kernels run on the library stream.
         host_vals = np.stack([obs, ratios, pbg])
-        d_vals = [torch.from_numpy(host_vals).to(dev) if rank == 0 else torch.empty((3, S), dtype=torch.float32, device=dev) for _ in range(2)]
+        # One analysis ahead (round 5): the call of step k is ENQUEUED (gpp_optimal_interpolation_full with GPP_ASYNC) and the host waits for the
+        # call of step k - 1 -- the GPU goes from one analysis to the next without waiting for the host's read-back, wake-up and launch
+        # latencies (~50 us of a 0.6 ms step at 500 rows per rank).  All K analyses complete inside the timed region (drain before the fence).
+        # Three observation slots: block k + 1 is posted while call k - 1 may not have read its block yet (gridpp_amd/dist.py).
+        ahead = 0 if args.sync_calls else 1
+        d_vals = [torch.from_numpy(host_vals).to(dev) if rank == 0 else torch.empty((3, S), dtype=torch.float32, device=dev) for _ in range(ahead + 2)]
         stream = gdist.ObservationStream(d_vals, rank)
+        pipe = gdist.AnalysisPipeline(ahead)
         kernel_ms, union_ms = [], []
+        last_out = [None]
+
+        def completed(pend):
+            st_ = pend.stats()
+            kernel_ms.append(st_["kernel_ms"]); union_ms.append(st_["union_kernel_ms"])
+            last_out[0] = pend.wait()
+
+        class _Tracked:
+            def __init__(self, pend): self.pend = pend
+            def wait(self): completed(self.pend); return last_out[0]
 
         def step():
             v = stream.next()
-            out = gridpp.optimal_interpolation(grid, d_bg, points, v[0], v[1], v[2], structure, args.max_points)
-            st_ = gridpp.oi_last_stats()
-            kernel_ms.append(st_["kernel_ms"]); union_ms.append(st_["union_kernel_ms"])
-            return out
+            pipe.push(_Tracked(gridpp.optimal_interpolation_async(grid, d_bg, points, v[0], v[1], v[2], structure, args.max_points)))
+            return last_out[0]
+
+        def drain_steps():
+            pipe.drain()
+            return last_out[0]
         cells_total, cells_rank = ny * nx, (row1 - row0) * nx
         workload = "optimal_interpolation %dx%d grid, %d obs, BarnesStructure(%g), max_points=%d" % (ny, nx, S, args.h, args.max_points)
         metric = "grid cells/sec for optimal_interpolation, 4000x4000 grid, 10k obs"
@@ -251,13 +294,17 @@ def main():
         dtype = "f32 (member means) + f64 (box sums)"
         extra["bytes_per_cell"] = 4 * E + 4
 
+    finish = drain_steps if case == "oi" else (lambda: None)
     for _ in range(args.warmup):
         step()
+    finish()
     kernel_ms.clear(); union_ms.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    if case == "oi":
+        out = finish()                                        # the analysis still in flight behind the last step (all K complete inside the timed region)
     if stream is not None:
         stream.drain()                                        # the one broadcast posted ahead of the last step
     fence()
@@ -279,6 +326,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "parallelism": par if world > 1 else "1 GPU",
+                       "calls": ("one analysis ahead (GPP_ASYNC + gpp_wait): call k is enqueued while call k - 1 completes" if case == "oi" and not args.sync_calls else "one blocking call per step"),
                        "inputs": "resident in HBM (device pointers through the C-ABI)"},
             "n_ranks_seen": {"env_WORLD_SIZE": world, "torch_distributed": (dist.get_world_size() if dist is not None else 1),
                              "backend": (backend if dist is not None else None)},
@@ -321,6 +369,8 @@ def main():
             res["kernel"] = {"name": k_name, "avg_ms": k_ms, "all_oi_kernels_ms": all_ms, "cells_per_launch": cells_rank,
                              "factorisations_per_launch": stats["solves"], "cells_updated": stats["cells_updated"],
                              "tiles_declined_by_first_pass": stats["fallback_tiles"], "subtiles_left_to_k_oi": stats["fallback_subtiles"]}
+            if tiles_note is not None:
+                res["config"]["row_tiles"] = tiles_note
         else:
             bpc = extra["bytes_per_cell"]
             k_ms = float(np.mean(kernel_ms)) if kernel_ms else ms_per_step

@@ -702,7 +702,7 @@ def _structure(s):
 
 # ---- optimal interpolation (include/gridpp.h:162-248, src/api/oi.cpp) -----------------------------
 def _oi_common(bg, background, bvariance, points, pobs, obs_variance, pbackground, bvariance_at_points,
-               structure, max_points, allow_extrapolation, want_variance):
+               structure, max_points, allow_extrapolation, want_variance, deferred=False):
     if max_points < 0:
         raise ValueError("max_points must be >= 0")
     if not isinstance(bg, (Grid, Points)) or not isinstance(points, Points):
@@ -737,11 +737,57 @@ def _oi_common(bg, background, bvariance, points, pobs, obs_variance, pbackgroun
         mem |= _capi.HOST_F64
     out = _empty_like_field(shape, background)
     var = _empty_like_field(shape, background) if want_variance else None
+    if deferred:
+        if mem != _capi.MEM_DEVICE:
+            raise ValueError("optimal_interpolation_async takes device-resident fields (torch tensors on the GPU)")
+        mem |= _capi.ASYNC
     check(lib().gpp_optimal_interpolation_full(bg._h, _ptr(background), _ptr(bvariance), points._h, _ptr(pobs),
                                                _ptr(obs_variance), _ptr(pbackground), _ptr(bvariance_at_points),
                                                _structure(structure), int(max_points), int(bool(allow_extrapolation)),
                                                _ptr(out), _ptr(var), mem))
+    if deferred:   # (the inputs, the handles and the structure stay referenced until the wait)
+        return PendingAnalysis(out, var, (bg, background, bvariance, points, pobs, obs_variance, pbackground, bvariance_at_points, structure))
     return out, var
+
+
+class PendingAnalysis:
+    """An optimal_interpolation call that was enqueued with GPP_ASYNC (include/gridpp_hip.h: gpp_wait): wait() returns the analysis (and the
+    variance, if asked for) once it is complete and raises what the call would have raised.  The library completes its deferred calls in
+    order: waiting for a later one first completes the earlier ones."""
+    _queue = []
+
+    def __init__(self, out, var, keep):
+        self._out, self._var, self._keep, self._rc, self._msg = out, var, keep, None, None
+        PendingAnalysis._queue.append(self)
+
+    def _complete_front(self):
+        front = PendingAnalysis._queue.pop(0)
+        front._rc = lib().gpp_wait()
+        front._msg = lib().gpp_last_error().decode("utf-8", "replace") if front._rc != _capi.GPP_OK else None
+        front._stats = oi_last_stats() if front._rc == _capi.GPP_OK else None
+        front._keep = None
+
+    def wait(self):
+        while self._rc is None:
+            self._complete_front()
+        if self._rc == _capi.GPP_EINVAL:
+            raise ValueError(self._msg)
+        if self._rc != _capi.GPP_OK:
+            raise RuntimeError(self._msg)
+        return self._out if self._var is None else (self._out, self._var)
+
+    def stats(self):
+        """gpp_oi_last_stats of THIS call (valid after wait())"""
+        self.wait()
+        return self._stats
+
+
+def optimal_interpolation_async(bgrid, background, points, pobs, pratios, pbackground, structure, max_points, allow_extrapolation=True):
+    """optimal_interpolation on device-resident fields without waiting for the result: returns a PendingAnalysis.  For a caller that streams
+    analyses through one GPU (one per observation set; bench.py, gridpp_amd.dist): in the steady state of such a stream -- the same Grid and
+    Points objects as the call before -- the library needs the host for nothing and the next call can be enqueued while this one runs.
+    The tensors passed in must not be modified before wait() returns."""
+    return _oi_common(bgrid, background, None, points, pobs, pratios, pbackground, None, structure, max_points, allow_extrapolation, False, deferred=True)
 
 
 def optimal_interpolation(bgrid, background, points, pobs, pratios, pbackground, structure, max_points, allow_extrapolation=True):

@@ -75,6 +75,8 @@ SIGNATURES = {
     "gpp_field_destroy": [vp],
     "gpp_optimal_interpolation_full": [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, vp, C.c_int],
     "gpp_oi_last_stats": [C.POINTER(gpp_oi_stats)],
+    "gpp_wait": [],
+    "gpp_pending": [ip],
     "gpp_optimal_interpolation_ensi": [vp, vp, C.c_int, vp, vp, vp, vp, C.POINTER(gpp_structure), C.c_int, C.c_int, vp, C.c_int],
     "gpp_ensi_last_kernel_ms": [fp],
     "gpp_ensi_last_stats": [C.POINTER(gpp_ensi_stats)],

@@ -1191,6 +1191,32 @@ struct OiWorkspace {
 };
 thread_local OiWorkspace g_ws;
 thread_local gpp_oi_stats g_stats;
+
+// ---- asynchronous calls (GPP_MEM_DEVICE | GPP_ASYNC; round 5) ----------------------------------------------------------------------
+// A call in the steady state of a repeated analysis -- same Grid / Points handles as the call before, the work list remembered -- needs the
+// host for nothing: every kernel of it is launched from the geometry's memory.  With GPP_ASYNC such a call ENQUEUES its kernels, a copy of
+// its status block into a page-locked slot and an event, and returns; gpp_wait() completes the oldest pending call of the thread.  What the
+// status block would have triggered in the synchronous call (a tile the memory did not hold, an item left to k_oi, an error flag) is rare
+// and handled the simple way: gpp_wait() runs the call again synchronously with the arguments it kept (every path writes the same bits, so
+// running twice is only slower).  Calls that are not in the steady state run synchronously at once and are queued as already complete, so
+// that every GPP_ASYNC call pairs with one gpp_wait().  The caller keeps the inputs, the output and both handles alive and unchanged until
+// the wait returns; up to ASYNC_SLOTS calls may be pending.
+constexpr int ASYNC_SLOTS = 4;
+struct PendingOi {
+    bool done = false;                // completed synchronously (status = rc)
+    int rc = GPP_OK;
+    std::string msg;
+    gpp_oi_stats stats;
+    // arguments (for the second run)
+    gpp_points* bgrid; const float* background; const float* bvariance; gpp_points* points; const float* obs; const float* obs_variance;
+    const float* background_at_points; const float* bvariance_at_points; gpp_structure st; int max_points, allow_extrapolation;
+    float* out; float* out_variance; int mem;
+    int slot = -1; int n_remembered = 0; bool skip_k_oi = false; int ntiles = 0;
+};
+struct AsyncSlot { unsigned long long* h = nullptr; hipEvent_t e0 = nullptr, eu = nullptr, e1 = nullptr, ec = nullptr; };   // first kernel, end of the first pass, last kernel, status copy arrived
+thread_local AsyncSlot g_aslots[ASYNC_SLOTS];
+thread_local std::vector<PendingOi> g_pending;     // FIFO
+thread_local unsigned g_async_seq = 0;
 }
 
 void gpp_release_oi_workspace() {   // the parked selections (128 B per grid cell of the largest call so far)
@@ -1204,9 +1230,11 @@ namespace { struct MultiFieldWs { DevBuf<float> mh, mv, mw, mR; DevBuf<int> tmpi
 // Diagnostic build only (tools/hostile/build.sh, tools/*_hostile_soak.py): every byte of the call-to-call workspaces of the OI path is
 // set to `byte` (0xFF: NaNs, huge counts, negative list entries), so that a kernel reading something this call did not write meets
 // hostile data instead of the remains of the previous call.
+void gpp_oi_drain_pending();
 extern "C" int gpp_debug_poison_oi_workspace(int byte) {
     GPP_TRY
     ensure_device();
+    gpp_oi_drain_pending();
     OiWorkspace& w = g_ws;
     w.pgeo.poison(byte); w.oaux.poison(byte); w.saux.poison(byte); w.status.poison(byte); w.status_snap.poison(byte);
     w.cell_idx.poison(byte); w.obs_idx.poison(byte);
@@ -1439,11 +1467,11 @@ extern "C" int gpp_structure_corr(const gpp_structure* s, const float p1[7], con
     GPP_CATCH
 }
 
-extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* background, const float* bvariance,
-                                              gpp_points* points, const float* obs, const float* obs_variance,
-                                              const float* background_at_points, const float* bvariance_at_points,
-                                              const gpp_structure* st, int max_points, int allow_extrapolation,
-                                              float* out, float* out_variance, int mem) {
+static int oi_full_impl(gpp_points* bgrid, const float* background, const float* bvariance,
+                        gpp_points* points, const float* obs, const float* obs_variance,
+                        const float* background_at_points, const float* bvariance_at_points,
+                        const gpp_structure* st, int max_points, int allow_extrapolation,
+                        float* out, float* out_variance, int mem) {
     GPP_TRY
     // argument checks of oi.cpp:152-186 (sizes are implied by the handles; pointers must be present)
     if(max_points < 0) invalid("max_points must be >= 0");
@@ -1620,6 +1648,8 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
         GPP_HIP(hipGetLastError());
     };
     bool ran_union = false, ran_overlap = false;
+    const bool async_req = (mem & GPP_ASYNC) && (mem & GPP_MEM_DEVICE) && !path_env("GPP_OI_NO_ASYNC");
+    int async_slot = -1;
     int overlap_left = 0, overlap_new = 0, overlap_remembered = 0;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
@@ -1687,10 +1717,22 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 n_remembered = memo.nlist;
                 if(!ws.ev_fork) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming)); }
                 GPP_HIP(hipEventRecord(ws.ev_fork, stream()));             // (behind k_pack_obs, which also cleared the status block)
+                if(async_req && N == 32 && !f_out.host && !f_var.host) {
+                    async_slot = (int)(g_async_seq++ % ASYNC_SLOTS);
+                    for(const PendingOi& q : g_pending) if(!q.done && q.slot == async_slot) { async_slot = -1; break; }   // (all slots in flight: this call runs synchronously)
+                    if(async_slot >= 0) {
+                        AsyncSlot& sl = g_aslots[async_slot];
+                        if(!sl.h) {
+                            GPP_HIP(hipHostMalloc((void**)&sl.h, SB * sizeof(unsigned long long), hipHostMallocDefault));
+                            GPP_HIP(hipEventCreate(&sl.e0)); GPP_HIP(hipEventCreate(&sl.eu)); GPP_HIP(hipEventCreate(&sl.e1)); GPP_HIP(hipEventCreateWithFlags(&sl.ec, hipEventDisableTiming));
+                        }
+                        GPP_HIP(hipEventRecord(sl.e0, stream()));
+                    }
+                }
                 a.skip_flags = memo.flags.p;
                 a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
                 launch_union(a.ntiles, false);                             // pass 1 on the library stream
-                GPP_HIP(hipEventRecord(ws.eu, stream()));
+                GPP_HIP(hipEventRecord(async_slot >= 0 ? g_aslots[async_slot].eu : ws.eu, stream()));
                 a.skip_flags = nullptr;
                 cur = stream2();
                 GPP_HIP(hipStreamWaitEvent(cur, ws.ev_fork, 0));
@@ -1716,6 +1758,20 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
                 GPP_HIP(hipEventRecord(ws.ev_join, cur));
                 cur = stream();
                 GPP_HIP(hipStreamWaitEvent(cur, ws.ev_join, 0));
+                if(async_slot >= 0) {   // GPP_ASYNC in the steady state: the status block into the call's page-locked slot, an event, and back to the caller
+                    AsyncSlot& sl = g_aslots[async_slot];
+                    GPP_HIP(hipEventRecord(sl.e1, stream()));
+                    GPP_HIP(hipMemcpyAsync(sl.h, ws.status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
+                    PendingOi pc;
+                    pc.bgrid = bgrid; pc.background = background; pc.bvariance = bvariance; pc.points = points; pc.obs = obs; pc.obs_variance = obs_variance;
+                    pc.background_at_points = background_at_points; pc.bvariance_at_points = bvariance_at_points; pc.st = *st; pc.max_points = max_points;
+                    pc.allow_extrapolation = allow_extrapolation; pc.out = out; pc.out_variance = out_variance; pc.mem = mem & ~GPP_ASYNC;
+                    pc.slot = async_slot; pc.n_remembered = n_remembered; pc.skip_k_oi = skip_k_oi; pc.ntiles = a.ntiles;
+                    pc.stats = g_stats;
+                    GPP_HIP(hipEventRecord(sl.ec, stream()));
+                    g_pending.push_back(pc);
+                    return GPP_OK;
+                }
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
                 if(skip_k_oi && h_ints[3] > 0) {   // 4-cell items for k_oi after all (before the counts below are cleared)
@@ -1895,4 +1951,73 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     if(err & ERR_OVERFLOW) runtime("optimal_interpolation: more usable observations at a grid point than the scratch of the general kernel was sized for");
     return GPP_OK;
     GPP_CATCH
+}
+
+// gridpp::optimal_interpolation / optimal_interpolation_full (src/api/oi.cpp:26-412).  With GPP_MEM_DEVICE | GPP_ASYNC: see PendingOi above.
+extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* background, const float* bvariance,
+                                              gpp_points* points, const float* obs, const float* obs_variance,
+                                              const float* background_at_points, const float* bvariance_at_points,
+                                              const gpp_structure* st, int max_points, int allow_extrapolation,
+                                              float* out, float* out_variance, int mem) {
+    const bool async_req = (mem & GPP_ASYNC) && (mem & GPP_MEM_DEVICE);
+    const size_t before = g_pending.size();
+    const int rc = oi_full_impl(bgrid, background, bvariance, points, obs, obs_variance, background_at_points, bvariance_at_points, st, max_points,
+                                allow_extrapolation, out, out_variance, mem);
+    if(async_req && rc == GPP_OK && g_pending.size() == before) {   // it ran synchronously: queued as complete, so that the call pairs with a gpp_wait()
+        PendingOi pc;
+        pc.done = true; pc.rc = rc; pc.stats = g_stats;
+        g_pending.push_back(pc);
+    }
+    return rc;
+}
+
+// completes a deferred call in place: its status, statistics and message are kept with the queue entry
+static int complete_pending(PendingOi& pc) {
+    GPP_TRY
+    if(pc.done) return pc.rc;
+    AsyncSlot& sl = g_aslots[pc.slot];
+    GPP_HIP(hipEventSynchronize(sl.ec));
+    const int* const hi = reinterpret_cast<const int*>(sl.h);
+    const int err = hi[0], n_new = hi[1], left = hi[3];
+    if(err == 0 && n_new == 0 && !(pc.skip_k_oi && left > 0)) {
+        pc.stats.fallback_tiles = pc.n_remembered; pc.stats.fallback_subtiles = left;
+        GPP_HIP(hipEventElapsedTime(&pc.stats.kernel_ms, sl.e0, sl.e1));
+        GPP_HIP(hipEventElapsedTime(&pc.stats.union_kernel_ms, sl.e0, sl.eu));
+        pc.stats.cells_updated = 0; pc.stats.solves = 0;
+        const unsigned long long* const c = sl.h + 8;
+        for(int k = 0; k < GPP_NSLOT; k++) { pc.stats.cells_updated += (long long)c[80 + 2 * k]; pc.stats.solves += (long long)c[81 + 2 * k]; }
+        pc.done = true; pc.rc = GPP_OK;
+        return GPP_OK;
+    }
+    // the status block asks for something the enqueued kernels did not do (a tile the memory did not hold, items for k_oi, an error flag):
+    // the synchronous call does it -- and raises what is to be raised
+    pc.rc = oi_full_impl(pc.bgrid, pc.background, pc.bvariance, pc.points, pc.obs, pc.obs_variance, pc.background_at_points, pc.bvariance_at_points, &pc.st,
+                         pc.max_points, pc.allow_extrapolation, pc.out, pc.out_variance, pc.mem);
+    pc.done = true; pc.stats = g_stats;
+    if(pc.rc != GPP_OK) pc.msg = gpp_last_error();
+    return pc.rc;
+    GPP_CATCH
+}
+// Completes the OLDEST pending GPP_ASYNC call of the calling thread: its results are in `out` when this returns GPP_OK; errors of that call
+// (a singular local system, ...) are reported here, with gpp_last_error().  gpp_oi_last_stats() then describes that call.
+extern "C" int gpp_wait(void) {
+    GPP_TRY
+    if(g_pending.empty()) invalid("gpp_wait: no asynchronous call is pending");
+    PendingOi pc = g_pending.front();
+    g_pending.erase(g_pending.begin());
+    const int rc = complete_pending(pc);
+    g_stats = pc.stats;
+    if(rc != GPP_OK) gpp::set_error(pc.msg.c_str());
+    return rc;
+    GPP_CATCH
+}
+// number of GPP_ASYNC calls of the calling thread that gpp_wait() has not completed yet
+extern "C" int gpp_pending(int* count) {
+    if(!count) return gpp::fail(GPP_EINVAL, "count is NULL");
+    *count = (int)g_pending.size();
+    return GPP_OK;
+}
+// (library-internal: before a handle or a workspace of the thread goes away -- the calls are completed, their results and status wait for gpp_wait)
+void gpp_oi_drain_pending() {
+    for(PendingOi& pc : g_pending) (void)complete_pending(pc);     // (the entries stay queued, complete: every GPP_ASYNC call still pairs with its gpp_wait)
 }

@@ -59,6 +59,7 @@ extern "C" const char* gpp_version(void) { return "0.8.0.dev1+mi355x.r1"; }
 extern char** environ;
 void gpp_release_ensi_workspace();   // ensi.hip
 void gpp_release_oi_workspace();     // oi.hip
+void gpp_oi_drain_pending();         // oi.hip: completes the GPP_ASYNC calls of the calling thread
 
 // ---- path overrides: the one test hook (common.h: path_env) ---------------------------------------------------------------------
 namespace gpp {
@@ -125,6 +126,7 @@ extern "C" int gpp_debug_poison_workspaces(int byte, int keep_padding) {
 // frees the thread's large call-to-call workspaces (they grow on demand and are otherwise kept for the next call)
 extern "C" int gpp_release_workspaces(void) {
     GPP_TRY
+    gpp_oi_drain_pending();
     GPP_HIP(hipStreamSynchronize(stream()));
     gpp_release_ensi_workspace();
     gpp_release_oi_workspace();
@@ -472,6 +474,7 @@ extern "C" int gpp_grid_create_f64(const double* lats, const double* lons, const
 }
 extern "C" int gpp_points_destroy(gpp_points* p) {
     GPP_TRY
+    gpp_oi_drain_pending();   // (a pending GPP_ASYNC call of this thread may still use the handle)
     delete p;
     return GPP_OK;
     GPP_CATCH

@@ -62,20 +62,25 @@ def broadcast_observations(values, src=0, group=None):
 
 
 class ObservationStream:
-    """Per-step observation blocks from rank 0, double-buffered: while step k computes from slot k&1, the broadcast of
-    step k+1's block into the other slot is already in flight (RCCL's own stream on a GPU box; gloo's worker thread in
+    """Per-step observation blocks from rank 0, buffered ahead: while step k computes from slot k % n, the broadcast of
+    step k+1's block into the next slot is already in flight (RCCL's own stream on a GPU box; gloo's worker thread in
     the CPU tests), so the exchange is off the critical path of the kernels.
 
-    slots: two equally shaped torch tensors on every rank.  fill(slot, step) is called on rank 0 only, right before
-    the block of `step` is posted, and writes that step's values into slots[slot] (None = the slots already hold them).
-    next() returns the tensor holding the values of the next step, valid until the following next()."""
+    slots: n >= 2 equally shaped torch tensors on every rank.  Two slots serve a loop that finishes step k before it asks for
+    step k+1; a loop that leaves `ahead` analyses in flight (AnalysisPipeline, gridpp_amd.optimal_interpolation_async) needs
+    ahead + 2 slots: block k+1 is posted while the calls of steps k-ahead .. k-1 may not have read their blocks yet.
+    fill(slot, step) is called on rank 0 only, right before the block of `step` is posted, and writes that step's values into
+    slots[slot] (None = the slots already hold them).  next() returns the tensor holding the values of the next step, valid
+    until n - 1 further next() calls."""
 
     def __init__(self, slots, rank, fill=None, src=0, group=None):
         import torch.distributed as dist
+        if len(slots) < 2:
+            raise ValueError("ObservationStream needs at least two slots")
         self.slots, self.rank, self.fill, self.src, self.group = slots, rank, fill, src, group
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.dist = dist
-        self.pending = [None, None]
+        self.pending = [None] * len(slots)
         self.k = 0
 
     def _post(self, slot, step):
@@ -85,9 +90,9 @@ class ObservationStream:
             self.pending[slot] = self.dist.broadcast(self.slots[slot], src=self.src, group=self.group, async_op=True)
 
     def next(self):
-        k = self.k
+        k, n = self.k, len(self.slots)
         self.k = k + 1
-        cur, nxt = k & 1, (k + 1) & 1
+        cur, nxt = k % n, (k + 1) % n
         if self.on:
             if self.pending[cur] is None:
                 self._post(cur, k)
@@ -104,6 +109,30 @@ class ObservationStream:
             if w is not None:
                 w.wait()
                 self.pending[i] = None
+
+
+class AnalysisPipeline:
+    """Keeps deferred analyses in flight (objects with a wait() method: gridpp_amd.optimal_interpolation_async on a GPU box).
+    push(pending) hands over the analysis just enqueued and returns the result of the one that has to complete now -- the one pushed
+    `ahead` calls earlier -- or None while the pipeline fills; drain() completes the rest, in order.  ahead = 0 is the synchronous loop;
+    ahead = 1 keeps the GPU busy with call k while the host waits for call k-1 and prepares call k+1 (an ObservationStream then needs
+    three slots: see there).  Every analysis is independent of the others (src/api/oi.cpp:221-338 keeps no state between calls), so the
+    results are those of the one-at-a-time loop bit for bit; what the pipeline removes is the idle time of the GPU between two calls (the
+    host's read-back, wake-up and launch latencies)."""
+
+    def __init__(self, ahead=1):
+        if ahead < 0:
+            raise ValueError("ahead must be >= 0")
+        self.ahead, self.q = ahead, []
+
+    def push(self, pending):
+        self.q.append(pending)
+        return self.q.pop(0).wait() if len(self.q) > self.ahead else None
+
+    def drain(self):
+        out = [p.wait() for p in self.q]
+        self.q = []
+        return out
 
 
 def tiled_optimal_interpolation(lats, lons, background, plats, plons, values, structure_args, max_points,

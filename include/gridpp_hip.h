@@ -356,6 +356,17 @@ typedef struct gpp_oi_stats {
 } gpp_oi_stats;
 int gpp_oi_last_stats(gpp_oi_stats* stats);
 
+/* Asynchronous optimal interpolation (no counterpart in the reference, whose calls return their result; this is for a caller that streams
+ * analyses -- one per observation set -- through one GPU, e.g. a rank of the multi-GPU tiling, src/api/oi.cpp:221-338 has no state between
+ * calls).  gpp_optimal_interpolation_full(..., mem = GPP_MEM_DEVICE | GPP_ASYNC) enqueues the call on the library stream and returns; every
+ * such call is completed, in order, by ONE gpp_wait() of the same thread, which returns the status of that call (the results are in `out`
+ * when it returns GPP_OK; gpp_oi_last_stats() then describes that call).  Only a call in the steady state of a repeated analysis (the same
+ * Grid / Points handles as the call before) is really deferred; any other runs synchronously at once and its gpp_wait() returns immediately.
+ * Until the wait returns the caller keeps inputs, outputs and handles alive and unchanged; at most 4 calls are deferred at a time (further
+ * ones run synchronously).  gpp_pending() tells how many waits are outstanding. */
+int gpp_wait(void);
+int gpp_pending(int* count);
+
 #ifdef __cplusplus
 }
 #endif

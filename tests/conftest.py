@@ -42,7 +42,7 @@ if os.environ.get("GRIDPP_TEST_POISON"):
         import gridpp_amd
         lib = gridpp_amd._capi.lib()     # (first: it loads torch's HIP runtime, which the helper library then shares)
         plib = _C.CDLL(os.path.join(ROOT, "tools", "hostile", "libpoison.so"))
-        skip = {"gpp_last_error", "gpp_version", "gpp_active_overrides", "gpp_oi_last_stats", "gpp_ensi_last_stats", "gpp_ensi_last_kernel_ms", "gpp_set_path_override", "gpp_ensi_set_convergence"}
+        skip = {"gpp_last_error", "gpp_version", "gpp_active_overrides", "gpp_oi_last_stats", "gpp_ensi_last_stats", "gpp_ensi_last_kernel_ms", "gpp_set_path_override", "gpp_ensi_set_convergence", "gpp_wait", "gpp_pending"}
 
         # with the -DGPP_POISON build of the library (GPP_LIB=gridpp_amd/lib/var_poison.so, tools/hostile/build.sh) every byte of every
         # call-to-call HBM workspace is 0xFF before each call as well (OI, EnSI + ensi_multi, neighbourhood; the remembered padding of

@@ -195,3 +195,76 @@ def test_weighted_row_tiles_partition_and_balance():
     tiles = gdist.weighted_row_tiles(cost, 4)
     heights = [b - a for a, b in tiles]
     assert min(heights) < 100 < max(heights) and sum(heights) == 400
+
+
+class _LazyAnalysis:
+    """a deferred analysis that reads its observation block as LATE as the contract allows: at wait()"""
+    def __init__(self, view, fn):
+        self.view, self.fn = view, fn
+
+    def wait(self):
+        return self.fn(self.view.clone().numpy())
+
+
+def _pipeline_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lats, lons, bg, plats, plons, vals = _workload()
+    steps, ahead = 6, 1
+    row0, row1 = gdist.row_tile(lats.shape[0], rank, world)
+    slots = [torch.full((3, vals.shape[1]), float("nan")) for _ in range(ahead + 2)]
+
+    def fill(slot, step):                       # rank 0: a new observation set per step
+        slots[slot].copy_(torch.from_numpy(vals) + float(step))
+
+    def compute(v):
+        return _oracle_compute(lats[row0:row1], lons[row0:row1], bg[row0:row1], plats, plons, v[0], v[1], v[2], (30000.0,), 8)
+    stream, pipe, tiles = gdist.ObservationStream(slots, rank, fill), gdist.AnalysisPipeline(ahead), []
+    for k in range(steps):
+        v = stream.next()
+        r = pipe.push(_LazyAnalysis(v, compute))          # the block of step k is read when step k is WAITED for: after block k+1 was posted
+        if r is not None:
+            tiles.append(r)
+    tiles += pipe.drain()
+    stream.drain()
+    assert len(tiles) == steps
+    np.save(os.path.join(outdir, "ptiles%d.npy" % rank), np.stack(tiles))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_analyses_equal_the_synchronous_loop(tmp_path):
+    """gridpp_amd.dist.AnalysisPipeline + a three-slot ObservationStream (what bench.py --gpus N does with optimal_interpolation_async): the
+    analysis of step k is completed one step late, its observation block must still be the block of step k -- every tile of every step equals
+    the single-process, one-at-a-time result bit for bit."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    lats, lons, bg, plats, plons, vals = _workload()
+    got = np.concatenate([np.load(tmp_path / ("ptiles%d.npy" % r)) for r in range(2)], axis=1)
+    for k in range(6):
+        v = vals + np.float32(k)
+        np.testing.assert_array_equal(got[k], _oracle_compute(lats, lons, bg, plats, plons, v[0], v[1], v[2], (30000.0,), 8))
+
+
+def test_analysis_pipeline_order_and_depth():
+    class P:
+        def __init__(self, i, log): self.i, self.log = i, log
+        def wait(self): self.log.append(self.i); return self.i
+    for ahead in (0, 1, 3):
+        log, pipe, got = [], gdist.AnalysisPipeline(ahead), []
+        for i in range(6):
+            r = pipe.push(P(i, log))
+            assert (r is None) == (i < ahead)
+            if r is not None:
+                got.append(r)
+            assert len(pipe.q) == min(i + 1, ahead)
+        got += pipe.drain()
+        assert got == log == list(range(6))
+    with pytest.raises(ValueError):
+        gdist.ObservationStream([None], 0)

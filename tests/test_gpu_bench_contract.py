@@ -48,11 +48,22 @@ def test_two_rank_logic_on_one_gpu():
     env = dict(os.environ, GPP_BENCH_SHARE_GPU="1", GPP_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
-    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    out = subprocess.run(cmd + ["--equal-tiles"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     r = _json_line(out.stdout)
     assert KEYS <= set(r) and r["n_gpus"] == 2 and r["scaling"] == "strong" and r["value"] > 0
     assert r["kernel"]["cells_per_launch"] == 8_000_000          # rank 0's row tile: half of the 4000 x 4000 grid
+    assert "one analysis ahead" in r["config"]["calls"]
+    # row tiles by measured kernel time (two ranks sharing one GPU differ by far more than the 3 % that trigger it) and blocking calls
+    out = subprocess.run(cmd + ["--sync-calls"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _json_line(out.stdout)
+    note = r["config"]["row_tiles"]
+    assert len(note["equal_tiles_kernel_ms"]) == 2 and note["spread"] >= 0
+    if note["rebalanced"]:
+        (a0, a1), (b0, b1) = note["row_tiles"]
+        assert a0 == 0 and a1 == b0 and b1 == 4000 and r["kernel"]["cells_per_launch"] == (a1 - a0) * 4000
+    assert "blocking" in r["config"]["calls"]
 
 
 @pytest.mark.parametrize("case,extra", [("ensi", ["--ny", "256", "--nx", "256", "--obs", "500"]), ("nbh", ["--ny", "512", "--nx", "256"])])

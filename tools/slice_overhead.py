@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import gridpp_amd as gridpp
 from bench import make_workload
-base = None
+base = base_a = None
 for N in (1, 2, 4, 8):
     rows = 4000 // N
     lats, lons, bg, plat, plon, obs, ratios, pbg = make_workload(4000, 4000, 10000, 1002, 0, rows)
@@ -18,4 +18,15 @@ for N in (1, 2, 4, 8):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K * 1e3
     s = gridpp.oi_last_stats()
     base = base or dt
-    print("N=%d rows=%d: %.3f ms/step, kernels %.3f ms (first pass %.3f), overhead %.3f ms, speed-up bound %.2f, declined tiles %d" % (N, rows, dt, s["kernel_ms"], s["union_kernel_ms"], dt - s["kernel_ms"], base / dt, s["fallback_tiles"]))
+    # the same steps with one analysis ahead (gpp_optimal_interpolation_full + GPP_ASYNC, gpp_wait: what bench.py --gpus N does)
+    from gridpp_amd.dist import AnalysisPipeline
+    pipe = AnalysisPipeline(1)
+    for _ in range(3): pipe.push(gridpp.optimal_interpolation_async(grid, d[0], points, d[1], d[2], d[3], st, 30))
+    pipe.drain()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(K): pipe.push(gridpp.optimal_interpolation_async(grid, d[0], points, d[1], d[2], d[3], st, 30))
+    pipe.drain()
+    torch.cuda.synchronize(); dta = (time.perf_counter() - t0) / K * 1e3
+    base_a = base_a or dta
+    print("N=%d rows=%d: %.3f ms/step, kernels %.3f ms (first pass %.3f), overhead %.3f ms, speed-up bound %.2f, declined tiles %d | one analysis ahead: %.3f ms/step, speed-up bound %.2f" % (
+        N, rows, dt, s["kernel_ms"], s["union_kernel_ms"], dt - s["kernel_ms"], base / dt, s["fallback_tiles"], dta, base_a / dta))
