@@ -22,7 +22,7 @@
 #include <atomic>
 #include "common.h"
 #include <algorithm>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #pragma clang fp contract(off)
 using namespace gpp;
@@ -1102,7 +1102,7 @@ __global__ void k_count_equal(const float* __restrict__ v, long n, float x, unsi
 struct IsValidF { __device__ bool operator()(const float& v) const { return !isnan(v) && !isinf(v); } };
 
 // gridpp::calc_even_quantiles (util.cpp:261-338) on the valid values of `values`; the global sort and the
-// unique pass run on the device (hipCUB radix sort / select), the index picks on the host.
+// unique pass run on the device (rocPRIM radix sort / select / unique), the index picks on the host.
 // out must hold `num` floats; *count is the number written.
 extern "C" int gpp_calc_even_quantiles(const float* values, long n, int num, int only_valid, float* out, int* count, int mem) {
     GPP_TRY
@@ -1122,9 +1122,9 @@ extern "C" int gpp_calc_even_quantiles(const float* values, long n, int num, int
     int nvalid = (int)n;
     const float* src = in.d;
     if(only_valid) {
-        GPP_HIP(hipcub::DeviceSelect::If(nullptr, bytes, in.d, valid.p, dnum.p, (int)n, IsValidF(), stream()));
+        GPP_HIP(rocprim::select((void*)nullptr, bytes, in.d, valid.p, dnum.p, (size_t)n, IsValidF(), stream()));
         tmp.get(bytes);
-        GPP_HIP(hipcub::DeviceSelect::If(tmp.p, bytes, in.d, valid.p, dnum.p, (int)n, IsValidF(), stream()));
+        GPP_HIP(rocprim::select((void*)tmp.p, bytes, in.d, valid.p, dnum.p, (size_t)n, IsValidF(), stream()));
         GPP_HIP(hipMemcpyAsync(&nvalid, dnum.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipStreamSynchronize(stream()));
         src = valid.p;
@@ -1132,13 +1132,13 @@ extern "C" int gpp_calc_even_quantiles(const float* values, long n, int num, int
     const int size = nvalid;
     if(size == 0) return GPP_OK;
     bytes = 0;
-    GPP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, src, sorted.p, size, 0, 32, stream()));
+    GPP_HIP(rocprim::radix_sort_keys((void*)nullptr, bytes, src, sorted.p, (size_t)size, 0u, 32u, stream()));
     tmp.get(bytes);
-    GPP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, bytes, src, sorted.p, size, 0, 32, stream()));
+    GPP_HIP(rocprim::radix_sort_keys((void*)tmp.p, bytes, src, sorted.p, (size_t)size, 0u, 32u, stream()));
     bytes = 0;
-    GPP_HIP(hipcub::DeviceSelect::Unique(nullptr, bytes, sorted.p, uniq.p, dnum.p, size, stream()));
+    GPP_HIP(rocprim::unique((void*)nullptr, bytes, sorted.p, uniq.p, dnum.p, (size_t)size, rocprim::equal_to<float>(), stream()));
     tmp.get(bytes);
-    GPP_HIP(hipcub::DeviceSelect::Unique(tmp.p, bytes, sorted.p, uniq.p, dnum.p, size, stream()));
+    GPP_HIP(rocprim::unique((void*)tmp.p, bytes, sorted.p, uniq.p, dnum.p, (size_t)size, rocprim::equal_to<float>(), stream()));
     int nu = 0;
     GPP_HIP(hipMemcpyAsync(&nu, dnum.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
     GPP_HIP(hipStreamSynchronize(stream()));

@@ -21,7 +21,8 @@
 #include "oi_union.h"
 
 void gpp_launch_union64(const OiArgs& a, unsigned nblocks, bool plain, bool list, hipStream_t stream);   // oi_union64.hip
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
+#include <cfloat>
 #include <algorithm>
 #include <memory>
 
@@ -71,11 +72,11 @@ static gpp_obs_index* build_obs_index_device(gpp_points* pts) {
     DevBuf<char> tmp;
     d_mm.get(6);
     size_t tb = 0;
-    GPP_HIP(hipcub::DeviceReduce::Min((void*)nullptr, tb, dax[0], d_mm.p, S, stream()));
+    GPP_HIP(rocprim::reduce((void*)nullptr, tb, dax[0], d_mm.p, FLT_MAX, (size_t)S, rocprim::minimum<float>(), stream()));
     tmp.get(tb);
     for(int d = 0; d < 3; d++) {
-        GPP_HIP(hipcub::DeviceReduce::Min((void*)tmp.p, tb, dax[d], d_mm.p + 2 * d, S, stream()));
-        GPP_HIP(hipcub::DeviceReduce::Max((void*)tmp.p, tb, dax[d], d_mm.p + 2 * d + 1, S, stream()));
+        GPP_HIP(rocprim::reduce((void*)tmp.p, tb, dax[d], d_mm.p + 2 * d, FLT_MAX, (size_t)S, rocprim::minimum<float>(), stream()));
+        GPP_HIP(rocprim::reduce((void*)tmp.p, tb, dax[d], d_mm.p + 2 * d + 1, -FLT_MAX, (size_t)S, rocprim::maximum<float>(), stream()));
     }
     float mm[6];
     GPP_HIP(hipMemcpyAsync(mm, d_mm.p, sizeof(mm), hipMemcpyDeviceToHost, stream()));
@@ -100,10 +101,10 @@ static gpp_obs_index* build_obs_index_device(gpp_points* pts) {
     int bits = 1;
     while((1ll << bits) < nbins) bits++;
     size_t sb = 0;
-    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)nullptr, sb, bin.p, sbin.p, iota.p, order.p, S, 0, bits, stream()));
+    GPP_HIP(rocprim::radix_sort_pairs((void*)nullptr, sb, bin.p, sbin.p, iota.p, order.p, (size_t)S, 0u, (unsigned)bits, stream()));
     DevBuf<char> stmp;
     stmp.get(sb);
-    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)stmp.p, sb, bin.p, sbin.p, iota.p, order.p, S, 0, bits, stream()));
+    GPP_HIP(rocprim::radix_sort_pairs((void*)stmp.p, sb, bin.p, sbin.p, iota.p, order.p, (size_t)S, 0u, (unsigned)bits, stream()));
     ix->d_bin_start.get(nbins + 1);
     hipLaunchKernelGGL(k_ix_starts, dim3((nbins + 1 + 255) / 256), dim3(256), 0, stream(), sbin.p, S, nbins, ix->d_bin_start.p);
     ix->d_sgeo.get(S); ix->d_smeta.get(S); ix->d_pos.get(S); ix->d_ogeo.get(S); ix->d_olaf.get(S);

@@ -5,12 +5,12 @@
 // All of them walk the point set's bin index (gpp_obs_index, the same one the OI kernels and the nearest-neighbour search
 // use): one thread per output location visits the bins that overlap the axis-aligned box +-radius in the two indexed
 // axes and applies the reference's test to every point in them -- strictly inside the box, then chord length <= radius
-// in float32.  Variable-length results go through a CSR layout: a counting pass, a device-wide exclusive scan (hipCUB),
+// in float32.  Variable-length results go through a CSR layout: a counting pass, a device-wide exclusive scan (rocPRIM),
 // a filling pass.  Statistics of a location's values are the sequential float loops of util.cpp:19-178 (row_stats.h).
 #include "common.h"
 #include "oi_common.h"
 #include "row_stats.h"
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include <algorithm>
 
 using namespace gpp;
@@ -255,10 +255,10 @@ long long scan_counts(const int* cnt, int nq, DevBuf<long long>& wide, DevBuf<lo
     GPP_HIP(hipMemsetAsync(wide.p + nq, 0, sizeof(long long), stream()));
     hipLaunchKernelGGL(k_widen, dim3((nq + 255) / 256), dim3(256), 0, stream(), cnt, nq, wide.p);
     size_t sb = 0;
-    GPP_HIP(hipcub::DeviceScan::ExclusiveSum((void*)nullptr, sb, wide.p, offset.p, nq + 1, stream()));
+    GPP_HIP(rocprim::exclusive_scan((void*)nullptr, sb, wide.p, offset.p, 0LL, (size_t)(nq + 1), rocprim::plus<long long>(), stream()));
     DevBuf<char> tmp;
     tmp.get(sb);
-    GPP_HIP(hipcub::DeviceScan::ExclusiveSum((void*)tmp.p, sb, wide.p, offset.p, nq + 1, stream()));
+    GPP_HIP(rocprim::exclusive_scan((void*)tmp.p, sb, wide.p, offset.p, 0LL, (size_t)(nq + 1), rocprim::plus<long long>(), stream()));
     long long total = 0;
     GPP_HIP(hipMemcpyAsync(&total, offset.p + nq, sizeof(long long), hipMemcpyDeviceToHost, stream()));
     GPP_HIP(hipStreamSynchronize(stream()));
@@ -412,10 +412,10 @@ extern "C" int gpp_gridding_nearest(gpp_points* to, gpp_points* from, const floa
     int bits = 1;
     while((1ll << bits) < no) bits++;
     size_t sb = 0;
-    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)nullptr, sb, target.p, starget.p, iota.p, order.p, S, 0, bits, stream()));
+    GPP_HIP(rocprim::radix_sort_pairs((void*)nullptr, sb, target.p, starget.p, iota.p, order.p, (size_t)S, 0u, (unsigned)bits, stream()));
     DevBuf<char> tmp;
     tmp.get(sb);
-    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)tmp.p, sb, target.p, starget.p, iota.p, order.p, S, 0, bits, stream()));
+    GPP_HIP(rocprim::radix_sort_pairs((void*)tmp.p, sb, target.p, starget.p, iota.p, order.p, (size_t)S, 0u, (unsigned)bits, stream()));
     GPP_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int) * no, stream()));
     hipLaunchKernelGGL(k_histogram, dim3((S + 255) / 256), dim3(256), 0, stream(), target.p, S, cnt.p);
     DevBuf<long long> wide, offset;
@@ -546,10 +546,10 @@ extern "C" int gpp_points_get_closest_neighbours(gpp_points* p, float lat, float
     hipLaunchKernelGGL(k_dist2_keys, dim3((n + 255) / 256), dim3(256), 0, stream(), p->d_x.p, p->d_y.p, p->d_z.p, n, qx, qy, qz, include_match, key.p, idx.p);
     GPP_HIP(hipGetLastError());
     size_t sb = 0;
-    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)nullptr, sb, key.p, skey.p, idx.p, sidx.p, n, 0, 32, stream()));
+    GPP_HIP(rocprim::radix_sort_pairs((void*)nullptr, sb, key.p, skey.p, idx.p, sidx.p, (size_t)n, 0u, 32u, stream()));
     DevBuf<char> tmp;
     tmp.get(sb);
-    GPP_HIP(hipcub::DeviceRadixSort::SortPairs((void*)tmp.p, sb, key.p, skey.p, idx.p, sidx.p, n, 0, 32, stream()));
+    GPP_HIP(rocprim::radix_sort_pairs((void*)tmp.p, sb, key.p, skey.p, idx.p, sidx.p, (size_t)n, 0u, 32u, stream()));
     const int k = std::min(num, n);
     std::vector<unsigned> hk(k);
     std::vector<int> hi(k);

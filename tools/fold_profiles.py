@@ -9,6 +9,7 @@ import os
 import sys
 
 d = sys.argv[1]
+TAG = os.environ.get("PROFILE_TAG") or os.path.basename(os.path.normpath(d)).replace("prof_", "") or "r04"   # gpurun_out/prof_r05 -> r05
 
 
 def rows(name):
@@ -37,12 +38,12 @@ def total(name, kernel_parts, counter):
 
 
 out = {"_comment": "per-launch counters of the dominant kernels from the rocprofv3 PMC passes of tools/profile_r04.sh (separate --pmc runs; summaries in "
-                   "profiles/r04_*_pmc_*.csv).  FETCH_SIZE / WRITE_SIZE in KiB; traffic = FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section). "
+                   "profiles/" + TAG + "_*_pmc_*.csv).  FETCH_SIZE / WRITE_SIZE in KiB; traffic = FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section). "
                    "Folded by tools/fold_profiles.py."}
 U = "k_oi_union<true, false, 32>"
 fs, wsz = pick("oi_pmc_fetch", U, "FETCH_SIZE"), pick("oi_pmc_write", U, "WRITE_SIZE")
 oi = {"kernel": U + " (first pass, all tiles)", "workload": "optimal_interpolation 4000x4000 grid, 10000 obs, BarnesStructure(10000), max_points=30", "n_gpus": 1,
-      "_source": "profiles/r04_oi_pmc_*.csv"}
+      "_source": "profiles/" + TAG + "_oi_pmc_*.csv"}
 if fs is not None and wsz is not None:
     oi.update({"FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": wsz, "traffic_bytes": int((2 * fs + wsz) * 1024), "algorithmic_bytes": 16000000 * 28})
 for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
@@ -72,7 +73,7 @@ if "SQ_WAVE_CYCLES" in oi and oi["SQ_WAVE_CYCLES"] > 0:
 out["k_oi_union"] = oi
 
 calls = 3.0   # tools/ensi_c5.py and tools/prof_nb.py make three calls each
-en = {"workload": "optimal_interpolation_ensi 2500x2500x50, 5000 obs, max_points=30", "_source": "profiles/r04_ensi_pmc_*.csv",
+en = {"workload": "optimal_interpolation_ensi 2500x2500x50, 5000 obs, max_points=30", "_source": "profiles/" + TAG + "_ensi_pmc_*.csv",
       "_note": "wave-instructions per CALL, summed over k_ensi_scan / k_ensi_pair / k_ensi_members (all batches)"}
 for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F64"):
     en[c] = total("ensi_pmc_sq", ["k_ensi"], c) / calls
@@ -85,7 +86,7 @@ except (OSError, KeyError):
     pass
 out["ensi_C5"] = en
 
-qf = {"workload": "neighbourhood_quantile_fast 4000x4000x100, halfwidth 15, 11 thresholds", "_source": "profiles/r04_nbh_pmc_*.csv"}
+qf = {"workload": "neighbourhood_quantile_fast 4000x4000x100, halfwidth 15, 11 thresholds", "_source": "profiles/" + TAG + "_nbh_pmc_*.csv"}
 tr = 0.0
 for k in ("k_qf_count", "k_qf_box"):
     f_, w_ = pick("nbh_pmc_fetch", k, "FETCH_SIZE"), pick("nbh_pmc_write", k, "WRITE_SIZE")

@@ -8,7 +8,8 @@
 set -u
 ONLY=${PROFILE_ONLY:-all}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$REPO/gpurun_out/prof_r04
+TAG=${PROFILE_TAG:-r04}
+OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 [ "$ONLY" = all ] && python $REPO/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
@@ -66,6 +67,13 @@ pmc oi_pmc_act "k_oi" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SAL
 [ "$ONLY" = all ] && pmc nbh_pmc_sq "k_qf|k_member" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" python $REPO/tools/prof_nb.py
 [ "$ONLY" = all ] && pmc nbh_pmc_busy "k_qf|k_member" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $REPO/tools/prof_nb.py
 [ "$ONLY" = all ] && python $REPO/tools/oi_variants.py > $OUT/oi_variants.jsonl 2>/dev/null
+# round 5: the white-noise terrain variant of config 3 (k_oi scans and parks, k_oi_pairs solves): kernel times and what the two kernels execute
+if [ "$ONLY" = all -o "$ONLY" = noise ]; then
+  stats noise python $REPO/tools/oi_noise.py 4000
+  pmc noise_pmc_sq "k_oi" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" python $REPO/tools/oi_noise.py 4000
+  pmc noise_pmc_fp64 "k_oi" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" python $REPO/tools/oi_noise.py 4000
+  pmc noise_pmc_busy "k_oi" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" python $REPO/tools/oi_noise.py 4000
+fi
 python $REPO/tools/fold_profiles.py $OUT > $OUT/hbm_traffic.json
 ls -la $OUT
 cut -c1-300 $OUT/bench_n1.json | head -2
