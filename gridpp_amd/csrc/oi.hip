@@ -1177,10 +1177,16 @@ __global__ void k_flag_tiles(const int* __restrict__ list, int n, int ntiles, un
 }
 namespace {
 struct OiWorkspace {
-    DevBuf<float4> pgeo, oaux, saux;
+    // per-call observation block and status block, TWO of each, used alternately: a deferred call (GPP_ASYNC) packs the block of call k + 1 on the
+    // second stream while the first pass of call k still reads its own (oi_full_impl, `steady`)
+    DevBuf<float4> pgeo_s[2], oaux_s[2], saux_s[2];
+    DevBuf<unsigned long long> status_s[2];
+    hipEvent_t slot_e1[2] = {nullptr, nullptr}, slot_ec[2] = {nullptr, nullptr};   // last deferred call on the slot: end of its first pass / its status copy
+    hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_join2[2] = {nullptr, nullptr};
+    int slot = 0;
     // status block of a call, one memset and one read-back: ints [0] err, [1..3] work-list lengths, [4] large-n cell count;
     // statistics counters from byte 64 on
-    DevBuf<unsigned long long> status, status_snap;
+    DevBuf<unsigned long long> status_snap;
     unsigned long long* h_status = nullptr;   // pinned host mirror
     DevBuf<int> cell_idx, obs_idx, fb_list, fb_list2, fb_list3, big_list;
     DevBuf<unsigned long long> big_keys, huge_keys;
@@ -1237,7 +1243,8 @@ extern "C" int gpp_debug_poison_oi_workspace(int byte) {
     ensure_device();
     gpp_oi_drain_pending();
     OiWorkspace& w = g_ws;
-    w.pgeo.poison(byte); w.oaux.poison(byte); w.saux.poison(byte); w.status.poison(byte); w.status_snap.poison(byte);
+    for(int k = 0; k < 2; k++) { w.pgeo_s[k].poison(byte); w.oaux_s[k].poison(byte); w.saux_s[k].poison(byte); w.status_s[k].poison(byte); }
+    w.status_snap.poison(byte);
     w.cell_idx.poison(byte); w.obs_idx.poison(byte);
     w.fb_list.poison(byte); w.fb_list2.poison(byte); w.fb_list3.poison(byte); w.big_list.poison(byte); w.huge_list.poison(byte);
     w.big_keys.poison(byte); w.huge_keys.poison(byte); w.big_mat.poison(byte); w.huge_mat.poison(byte);
@@ -1468,6 +1475,7 @@ extern "C" int gpp_structure_corr(const gpp_structure* s, const float p1[7], con
     GPP_CATCH
 }
 
+void gpp_oi_drain_pending();
 static int oi_full_impl(gpp_points* bgrid, const float* background, const float* bvariance,
                         gpp_points* points, const float* obs, const float* obs_variance,
                         const float* background_at_points, const float* bvariance_at_points,
@@ -1514,16 +1522,33 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     gpp_obs_index* ix = gpp_build_obs_index(points);
 
     if(!ws.e0) { GPP_HIP(hipEventCreate(&ws.e0)); GPP_HIP(hipEventCreate(&ws.e1)); GPP_HIP(hipEventCreate(&ws.eu)); }
-    ws.pgeo.get(S); ws.oaux.get(S); ws.saux.get(S);
     constexpr size_t SB = 8 + 80 + 2 * GPP_NSLOT;   // status block, in 8-byte words
-    ws.status.get(SB);
+    if((mem & GPP_ASYNC) && !g_aslots[0].h) {
+        // everything a deferred call needs, on the FIRST call that asks for one (which itself runs synchronously: no memory of its geometry yet):
+        // page-locked status slots, events, the two streams beside the library stream -- milliseconds that must not fall into a later call
+        for(int k = 0; k < ASYNC_SLOTS; k++) {
+            AsyncSlot& sl = g_aslots[k];
+            GPP_HIP(hipHostMalloc((void**)&sl.h, SB * sizeof(unsigned long long), hipHostMallocDefault));
+            GPP_HIP(hipEventCreate(&sl.e0)); GPP_HIP(hipEventCreate(&sl.eu)); GPP_HIP(hipEventCreate(&sl.e1)); GPP_HIP(hipEventCreateWithFlags(&sl.ec, hipEventDisableTiming));
+        }
+        for(int k = 0; k < 2; k++) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_pack[k], hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_join2[k], hipEventDisableTiming)); }
+        (void)stream2(); (void)stream3();
+    }
+    ws.slot ^= 1;
+    const int wsl = ws.slot;
+    DevBuf<float4>& pgeo = ws.pgeo_s[wsl]; DevBuf<float4>& oaux = ws.oaux_s[wsl]; DevBuf<float4>& saux = ws.saux_s[wsl];
+    DevBuf<unsigned long long>& status = ws.status_s[wsl];
+    pgeo.get(S); oaux.get(S); saux.get(S);
+    status.get(SB);
     if(!ws.h_status) GPP_HIP(hipHostMalloc((void**)&ws.h_status, (SB + 1) * sizeof(unsigned long long), hipHostMallocDefault));
-    int* const d_ints = reinterpret_cast<int*>(ws.status.p);
+    int* const d_ints = reinterpret_cast<int*>(status.p);
     int* const d_err = d_ints, *const d_fb_count = d_ints + 1, *const d_big_count = d_ints + 4, *const d_huge_count = d_ints + 5;
-    unsigned long long* const d_counters = ws.status.p + 8;
-    hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, stream(), S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
-                       f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, ws.pgeo.p, ws.oaux.p, ws.saux.p, ws.status.p, (int)SB);   // (also clears the status block)
-    GPP_HIP(hipGetLastError());
+    unsigned long long* const d_counters = status.p + 8;
+    auto launch_pack = [&](hipStream_t on) {   // the observation block of this call (also clears the status block)
+        hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, on, S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
+                           f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, pgeo.p, oaux.p, saux.p, status.p, (int)SB);
+        GPP_HIP(hipGetLastError());
+    };
 
     // register-tile size of the solve: 32 rows (max_points <= 32, the common case) or 62 rows (everything up to 62
     // usable observations per grid point; one member cell per factorisation)
@@ -1540,8 +1565,8 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         a.tiles_x = (a.nx + tw - 1) / tw; a.ntiles = a.tiles_x * ((a.ny + th - 1) / th);
     }
     else { a.tiles_x = 0; a.ntiles = (C + 63) / 64; }
-    a.s.pgeo = ws.pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
-    a.ogeo = ix->d_ogeo.p; a.oaux = ws.oaux.p; a.saux = ws.saux.p;
+    a.s.pgeo = pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
+    a.ogeo = ix->d_ogeo.p; a.oaux = oaux.p; a.saux = saux.p;
     a.S = S; a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
     a.s.st = gpp_resolve_structure(st);
@@ -1560,7 +1585,6 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     a.err = d_err; a.counters = d_counters; a.tail_count = d_ints + 6;
     a.debug = timing_env("GPP_OI_DEBUG") ? atoi(timing_env("GPP_OI_DEBUG")) : 0;
 
-    GPP_HIP(hipEventRecord(ws.e0, stream()));
     // Cholesky needs a symmetric positive definite P+R: true for every kernel on distances and for the even vertical / laf
     // kernels (Barnes, Powerlaw, Linear); Cressman / SOAR / TOAR factors on SIGNED elevation / laf differences make P
     // non-symmetric (structure.cpp:35-64), and a truncated kernel can be indefinite -> pivoted LU like the reference.
@@ -1607,7 +1631,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     };
     const int* const h_ints = reinterpret_cast<const int*>(ws.h_status);
     auto fetch = [&]() {   // the whole status block in one copy
-        GPP_HIP(hipMemcpyAsync(ws.h_status, ws.status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipMemcpyAsync(ws.h_status, status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipStreamSynchronize(stream()));
         err = h_ints[0];
         memcpy(counters, ws.h_status + 8, sizeof(counters));
@@ -1651,6 +1675,17 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     bool ran_union = false, ran_overlap = false;
     const bool async_req = (mem & GPP_ASYNC) && (mem & GPP_MEM_DEVICE) && !path_env("GPP_OI_NO_ASYNC");
     int async_slot = -1;
+    // `steady`: a GPP_ASYNC call that will take the overlapped branch below (the conditions of `overlap`): it is deferred, and its observation
+    // block is packed on the second stream, AHEAD of the first pass of the call before it.  Every other call first completes the deferred calls
+    // of this thread (they share the workspace) and packs on the library stream.
+    bool steady = async_req && N == 32 && !f_out.host && !f_var.host && use_union && !use_lu && memo_hit && memo.nlist > 0 && memo.list_ntiles == a.ntiles &&
+                  !path_env("GPP_OI_NO_OVERLAP");
+    if(steady) {
+        async_slot = (int)(g_async_seq++ % ASYNC_SLOTS);
+        for(const PendingOi& q : g_pending) if(!q.done && q.slot == async_slot) { async_slot = -1; break; }   // (all slots in flight: this call runs synchronously)
+        if(async_slot < 0) steady = false;
+    }
+    if(!steady) { gpp_oi_drain_pending(); launch_pack(stream()); GPP_HIP(hipEventRecord(ws.e0, stream())); }
     int overlap_left = 0, overlap_new = 0, overlap_remembered = 0;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
@@ -1717,62 +1752,77 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             if(overlap) {
                 n_remembered = memo.nlist;
                 if(!ws.ev_fork) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming)); }
-                GPP_HIP(hipEventRecord(ws.ev_fork, stream()));             // (behind k_pack_obs, which also cleared the status block)
-                if(async_req && N == 32 && !f_out.host && !f_var.host) {
-                    async_slot = (int)(g_async_seq++ % ASYNC_SLOTS);
-                    for(const PendingOi& q : g_pending) if(!q.done && q.slot == async_slot) { async_slot = -1; break; }   // (all slots in flight: this call runs synchronously)
-                    if(async_slot >= 0) {
-                        AsyncSlot& sl = g_aslots[async_slot];
-                        if(!sl.h) {
-                            GPP_HIP(hipHostMalloc((void**)&sl.h, SB * sizeof(unsigned long long), hipHostMallocDefault));
-                            GPP_HIP(hipEventCreate(&sl.e0)); GPP_HIP(hipEventCreate(&sl.eu)); GPP_HIP(hipEventCreate(&sl.e1)); GPP_HIP(hipEventCreateWithFlags(&sl.ec, hipEventDisableTiming));
-                        }
-                        GPP_HIP(hipEventRecord(sl.e0, stream()));
-                    }
-                }
-                a.skip_flags = memo.flags.p;
-                a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
-                launch_union(a.ntiles, false);                             // pass 1 on the library stream
-                GPP_HIP(hipEventRecord(async_slot >= 0 ? g_aslots[async_slot].eu : ws.eu, stream()));
-                a.skip_flags = nullptr;
-                cur = stream2();
-                GPP_HIP(hipStreamWaitEvent(cur, ws.ev_fork, 0));
                 const int* const d_mcount = memo.count.p;
-                if(16 * (long)n_remembered <= SHORT_ITEMS) {
-                    a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
-                    launch_union(16 * (long)n_remembered, true);
-                    a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 128;
-                    if(!skip_k_oi) launch_k_oi(false);
-                }
-                else {
-                    a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
-                    launch_union(4 * (long)n_remembered, true);
-                    a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
-                    a.parent_count = d_mcount;
-                    launch_union(16 * (long)n_remembered, true);
-                    a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
-                    const bool pairs = pairs_ok && !skip_k_oi && 4 * (long)n_remembered > a.ntiles;
-                    if(pairs) park_on(true);
-                    if(!skip_k_oi) launch_k_oi(false);
-                    if(pairs) launch_pairs();
-                }
-                GPP_HIP(hipEventRecord(ws.ev_join, cur));
-                cur = stream();
-                GPP_HIP(hipStreamWaitEvent(cur, ws.ev_join, 0));
-                if(async_slot >= 0) {   // GPP_ASYNC in the steady state: the status block into the call's page-locked slot, an event, and back to the caller
+                auto remembered_passes = [&]() {   // the list passes over the REMEMBERED list, on `cur`
+                    if(16 * (long)n_remembered <= SHORT_ITEMS) {
+                        a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
+                        launch_union(16 * (long)n_remembered, true);
+                        a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 128;
+                        if(!skip_k_oi) launch_k_oi(false);
+                    }
+                    else {
+                        a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
+                        launch_union(4 * (long)n_remembered, true);
+                        a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
+                        a.parent_count = d_mcount;
+                        launch_union(16 * (long)n_remembered, true);
+                        a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                        const bool pairs = pairs_ok && !skip_k_oi && 4 * (long)n_remembered > a.ntiles;
+                        if(pairs) park_on(true);
+                        if(!skip_k_oi) launch_k_oi(false);
+                        if(pairs) launch_pairs();
+                    }
+                };
+                if(steady) {
+                    // GPP_ASYNC in the steady state.  Three streams: B packs this call's observation block and runs its list passes -- AHEAD of the
+                    // first pass of the call before it, which still runs on A (the blocks and status blocks alternate between two workspace
+                    // slots) --, A runs the first passes back to back, C copies each call's status block into its page-locked slot once its first
+                    // pass (A) and its list passes (B) are done.  Nothing here waits for the host, and the host waits for nothing here.
                     AsyncSlot& sl = g_aslots[async_slot];
-                    GPP_HIP(hipEventRecord(sl.e1, stream()));
-                    GPP_HIP(hipMemcpyAsync(sl.h, ws.status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
+                    const hipStream_t sA = stream(), sB = stream2(), sC = stream3();
+                    // (the buffers of this workspace slot: the deferred call that used them last must have finished its first pass and its status copy)
+                    if(ws.slot_e1[wsl]) GPP_HIP(hipStreamWaitEvent(sB, ws.slot_e1[wsl], 0));
+                    if(ws.slot_ec[wsl]) GPP_HIP(hipStreamWaitEvent(sB, ws.slot_ec[wsl], 0));
+                    launch_pack(sB);
+                    GPP_HIP(hipEventRecord(ws.ev_pack[wsl], sB));
+                    cur = sB;
+                    remembered_passes();
+                    GPP_HIP(hipEventRecord(ws.ev_join2[wsl], sB));
+                    cur = sA;
+                    GPP_HIP(hipStreamWaitEvent(sA, ws.ev_pack[wsl], 0));
+                    GPP_HIP(hipEventRecord(sl.e0, sA));
+                    a.skip_flags = memo.flags.p;
+                    a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
+                    launch_union(a.ntiles, false);
+                    a.skip_flags = nullptr;
+                    GPP_HIP(hipEventRecord(sl.eu, sA));
+                    GPP_HIP(hipEventRecord(sl.e1, sA));
+                    GPP_HIP(hipStreamWaitEvent(sC, sl.e1, 0));
+                    GPP_HIP(hipStreamWaitEvent(sC, ws.ev_join2[wsl], 0));
+                    GPP_HIP(hipMemcpyAsync(sl.h, status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, sC));
+                    GPP_HIP(hipEventRecord(sl.ec, sC));
+                    ws.slot_e1[wsl] = sl.e1; ws.slot_ec[wsl] = sl.ec;
                     PendingOi pc;
                     pc.bgrid = bgrid; pc.background = background; pc.bvariance = bvariance; pc.points = points; pc.obs = obs; pc.obs_variance = obs_variance;
                     pc.background_at_points = background_at_points; pc.bvariance_at_points = bvariance_at_points; pc.st = *st; pc.max_points = max_points;
                     pc.allow_extrapolation = allow_extrapolation; pc.out = out; pc.out_variance = out_variance; pc.mem = mem & ~GPP_ASYNC;
                     pc.slot = async_slot; pc.n_remembered = n_remembered; pc.skip_k_oi = skip_k_oi; pc.ntiles = a.ntiles;
                     pc.stats = g_stats;
-                    GPP_HIP(hipEventRecord(sl.ec, stream()));
                     g_pending.push_back(pc);
                     return GPP_OK;
                 }
+                GPP_HIP(hipEventRecord(ws.ev_fork, stream()));             // (behind k_pack_obs, which also cleared the status block)
+                a.skip_flags = memo.flags.p;
+                a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
+                launch_union(a.ntiles, false);                             // pass 1 on the library stream
+                GPP_HIP(hipEventRecord(ws.eu, stream()));
+                a.skip_flags = nullptr;
+                cur = stream2();
+                GPP_HIP(hipStreamWaitEvent(cur, ws.ev_fork, 0));
+                remembered_passes();
+                GPP_HIP(hipEventRecord(ws.ev_join, cur));
+                cur = stream();
+                GPP_HIP(hipStreamWaitEvent(cur, ws.ev_join, 0));
                 GPP_HIP(hipEventRecord(ws.e1, stream()));
                 fetch();
                 if(skip_k_oi && h_ints[3] > 0) {   // 4-cell items for k_oi after all (before the counts below are cleared)
@@ -1921,7 +1971,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
             g_stats.fallback_tiles = a.ntiles;
-            GPP_HIP(hipMemsetAsync(ws.status.p, 0, SB * sizeof(unsigned long long), stream()));
+            GPP_HIP(hipMemsetAsync(status.p, 0, SB * sizeof(unsigned long long), stream()));
             continue;
         }
         break;
@@ -1992,9 +2042,10 @@ static int complete_pending(PendingOi& pc) {
     }
     // the status block asks for something the enqueued kernels did not do (a tile the memory did not hold, items for k_oi, an error flag):
     // the synchronous call does it -- and raises what is to be raised
+    pc.done = true;    // (first: the blocking call below completes the deferred calls of the thread before it starts, and must not come back to this one)
     pc.rc = oi_full_impl(pc.bgrid, pc.background, pc.bvariance, pc.points, pc.obs, pc.obs_variance, pc.background_at_points, pc.bvariance_at_points, &pc.st,
                          pc.max_points, pc.allow_extrapolation, pc.out, pc.out_variance, pc.mem);
-    pc.done = true; pc.stats = g_stats;
+    pc.stats = g_stats;
     if(pc.rc != GPP_OK) pc.msg = gpp_last_error();
     return pc.rc;
     GPP_CATCH

@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-static hipStream_t g_stream = nullptr, g_stream2 = nullptr;
+static hipStream_t g_stream = nullptr, g_stream2 = nullptr, g_stream3 = nullptr;
 static std::atomic<unsigned long long> g_next_serial{1};   // one counter for every instantiation of make_points<T>
 static std::atomic<int> g_live_handles{0};   // gpp_points alive (gpp_set_device refuses to switch under them)
 static int g_device = -1;
@@ -47,6 +47,12 @@ hipStream_t stream2() {
     std::lock_guard<std::mutex> lock(g_mutex);
     if(!g_stream2) GPP_HIP(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
     return g_stream2;
+}
+hipStream_t stream3() {
+    ensure_device();
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if(!g_stream3) GPP_HIP(hipStreamCreateWithFlags(&g_stream3, hipStreamNonBlocking));
+    return g_stream3;
 }
 
 }   // namespace gpp
@@ -156,6 +162,7 @@ extern "C" int gpp_set_device(int device) {
         if(g_stream && g_live_handles.load() > 0) invalid("gpp_set_device: the device cannot change while point sets / fields created on the current one are alive");
         if(g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
         if(g_stream2) { (void)hipStreamDestroy(g_stream2); g_stream2 = nullptr; }
+        if(g_stream3) { (void)hipStreamDestroy(g_stream3); g_stream3 = nullptr; }
         g_device = device;
         GPP_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     }
@@ -190,6 +197,9 @@ extern "C" int gpp_host_free(void* p) {
 extern "C" int gpp_synchronize(void) {
     GPP_TRY
     GPP_HIP(hipStreamSynchronize(stream()));
+    // (the streams beside the library stream carry work of deferred optimal-interpolation calls only; created on first use)
+    if(g_stream2) GPP_HIP(hipStreamSynchronize(g_stream2));
+    if(g_stream3) GPP_HIP(hipStreamSynchronize(g_stream3));
     return GPP_OK;
     GPP_CATCH
 }
