@@ -1678,8 +1678,9 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     // `steady`: a GPP_ASYNC call that will take the overlapped branch below (the conditions of `overlap`): it is deferred, and its observation
     // block is packed on the second stream, AHEAD of the first pass of the call before it.  Every other call first completes the deferred calls
     // of this thread (they share the workspace) and packs on the library stream.
-    bool steady = async_req && N == 32 && !f_out.host && !f_var.host && use_union && !use_lu && memo_hit && memo.nlist > 0 && memo.list_ntiles == a.ntiles &&
-                  !path_env("GPP_OI_NO_OVERLAP");
+    // (either the geometry remembers a list of declined tiles, or its last call declined none and left nothing to k_oi)
+    bool steady = async_req && N == 32 && !f_out.host && !f_var.host && use_union && !use_lu && memo_hit && !path_env("GPP_OI_NO_OVERLAP") &&
+                  ((memo.nlist > 0 && memo.list_ntiles == a.ntiles) || (memo.nlist == 0 && memo.declined == 0.0f && memo.leftover == 0));
     if(steady) {
         async_slot = (int)(g_async_seq++ % ASYNC_SLOTS);
         for(const PendingOi& q : g_pending) if(!q.done && q.slot == async_slot) { async_slot = -1; break; }   // (all slots in flight: this call runs synchronously)
@@ -1749,68 +1750,69 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             // passes after the read-back and joins the remembered list.
             const bool overlap = memo_hit && memo.nlist > 0 && memo.list_ntiles == a.ntiles && !path_env("GPP_OI_NO_OVERLAP");
             int n_remembered = 0;
-            if(overlap) {
-                n_remembered = memo.nlist;
-                if(!ws.ev_fork) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming)); }
-                const int* const d_mcount = memo.count.p;
-                auto remembered_passes = [&]() {   // the list passes over the REMEMBERED list, on `cur`
-                    if(16 * (long)n_remembered <= SHORT_ITEMS) {
-                        a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
-                        launch_union(16 * (long)n_remembered, true);
-                        a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 128;
-                        if(!skip_k_oi) launch_k_oi(false);
-                    }
-                    else {
-                        a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
-                        launch_union(4 * (long)n_remembered, true);
-                        a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
-                        a.parent_count = d_mcount;
-                        launch_union(16 * (long)n_remembered, true);
-                        a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
-                        const bool pairs = pairs_ok && !skip_k_oi && 4 * (long)n_remembered > a.ntiles;
-                        if(pairs) park_on(true);
-                        if(!skip_k_oi) launch_k_oi(false);
-                        if(pairs) launch_pairs();
-                    }
-                };
-                if(steady) {
-                    // GPP_ASYNC in the steady state.  Three streams: B packs this call's observation block and runs its list passes -- AHEAD of the
-                    // first pass of the call before it, which still runs on A (the blocks and status blocks alternate between two workspace
-                    // slots) --, A runs the first passes back to back, C copies each call's status block into its page-locked slot once its first
-                    // pass (A) and its list passes (B) are done.  Nothing here waits for the host, and the host waits for nothing here.
-                    AsyncSlot& sl = g_aslots[async_slot];
-                    const hipStream_t sA = stream(), sB = stream2(), sC = stream3();
-                    // (the buffers of this workspace slot: the deferred call that used them last must have finished its first pass and its status copy)
-                    if(ws.slot_e1[wsl]) GPP_HIP(hipStreamWaitEvent(sB, ws.slot_e1[wsl], 0));
-                    if(ws.slot_ec[wsl]) GPP_HIP(hipStreamWaitEvent(sB, ws.slot_ec[wsl], 0));
-                    launch_pack(sB);
-                    GPP_HIP(hipEventRecord(ws.ev_pack[wsl], sB));
-                    cur = sB;
-                    remembered_passes();
-                    GPP_HIP(hipEventRecord(ws.ev_join2[wsl], sB));
-                    cur = sA;
-                    GPP_HIP(hipStreamWaitEvent(sA, ws.ev_pack[wsl], 0));
-                    GPP_HIP(hipEventRecord(sl.e0, sA));
-                    a.skip_flags = memo.flags.p;
-                    a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
-                    launch_union(a.ntiles, false);
-                    a.skip_flags = nullptr;
-                    GPP_HIP(hipEventRecord(sl.eu, sA));
-                    GPP_HIP(hipEventRecord(sl.e1, sA));
-                    GPP_HIP(hipStreamWaitEvent(sC, sl.e1, 0));
-                    GPP_HIP(hipStreamWaitEvent(sC, ws.ev_join2[wsl], 0));
-                    GPP_HIP(hipMemcpyAsync(sl.h, status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, sC));
-                    GPP_HIP(hipEventRecord(sl.ec, sC));
-                    ws.slot_e1[wsl] = sl.e1; ws.slot_ec[wsl] = sl.ec;
-                    PendingOi pc;
-                    pc.bgrid = bgrid; pc.background = background; pc.bvariance = bvariance; pc.points = points; pc.obs = obs; pc.obs_variance = obs_variance;
-                    pc.background_at_points = background_at_points; pc.bvariance_at_points = bvariance_at_points; pc.st = *st; pc.max_points = max_points;
-                    pc.allow_extrapolation = allow_extrapolation; pc.out = out; pc.out_variance = out_variance; pc.mem = mem & ~GPP_ASYNC;
-                    pc.slot = async_slot; pc.n_remembered = n_remembered; pc.skip_k_oi = skip_k_oi; pc.ntiles = a.ntiles;
-                    pc.stats = g_stats;
-                    g_pending.push_back(pc);
-                    return GPP_OK;
+            n_remembered = overlap ? memo.nlist : 0;
+            const int* const d_mcount = memo.count.p;
+            auto remembered_passes = [&]() {   // the list passes over the REMEMBERED list, on `cur`
+                if(16 * (long)n_remembered <= SHORT_ITEMS) {
+                    a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
+                    launch_union(16 * (long)n_remembered, true);
+                    a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 128;
+                    if(!skip_k_oi) launch_k_oi(false);
                 }
+                else {
+                    a.in_list = memo.list.p; a.in_count = d_mcount; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
+                    launch_union(4 * (long)n_remembered, true);
+                    a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
+                    a.parent_count = d_mcount;
+                    launch_union(16 * (long)n_remembered, true);
+                    a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                    const bool pairs = pairs_ok && !skip_k_oi && 4 * (long)n_remembered > a.ntiles;
+                    if(pairs) park_on(true);
+                    if(!skip_k_oi) launch_k_oi(false);
+                    if(pairs) launch_pairs();
+                }
+            };
+            auto defer = [&]() -> int {
+                // GPP_ASYNC in the steady state.  Three streams: B packs this call's observation block and runs its list passes -- AHEAD of the
+                // first pass of the call before it, which still runs on A (the blocks and status blocks alternate between two workspace
+                // slots) --, A runs the first passes back to back, C copies each call's status block into its page-locked slot once its first
+                // pass (A) and its list passes (B) are done.  Nothing here waits for the host, and the host waits for nothing here.
+                AsyncSlot& sl = g_aslots[async_slot];
+                const hipStream_t sA = stream(), sB = stream2(), sC = stream3();
+                // (the buffers of this workspace slot: the deferred call that used them last must have finished its first pass and its status copy)
+                if(ws.slot_e1[wsl]) GPP_HIP(hipStreamWaitEvent(sB, ws.slot_e1[wsl], 0));
+                if(ws.slot_ec[wsl]) GPP_HIP(hipStreamWaitEvent(sB, ws.slot_ec[wsl], 0));
+                launch_pack(sB);
+                GPP_HIP(hipEventRecord(ws.ev_pack[wsl], sB));
+                cur = sB;
+                if(n_remembered > 0) remembered_passes();
+                GPP_HIP(hipEventRecord(ws.ev_join2[wsl], sB));
+                cur = sA;
+                GPP_HIP(hipStreamWaitEvent(sA, ws.ev_pack[wsl], 0));
+                GPP_HIP(hipEventRecord(sl.e0, sA));
+                a.skip_flags = n_remembered > 0 ? memo.flags.p : nullptr;
+                a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
+                launch_union(a.ntiles, false);
+                a.skip_flags = nullptr;
+                GPP_HIP(hipEventRecord(sl.eu, sA));
+                GPP_HIP(hipEventRecord(sl.e1, sA));
+                GPP_HIP(hipStreamWaitEvent(sC, sl.e1, 0));
+                GPP_HIP(hipStreamWaitEvent(sC, ws.ev_join2[wsl], 0));
+                GPP_HIP(hipMemcpyAsync(sl.h, status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, sC));
+                GPP_HIP(hipEventRecord(sl.ec, sC));
+                ws.slot_e1[wsl] = sl.e1; ws.slot_ec[wsl] = sl.ec;
+                PendingOi pc;
+                pc.bgrid = bgrid; pc.background = background; pc.bvariance = bvariance; pc.points = points; pc.obs = obs; pc.obs_variance = obs_variance;
+                pc.background_at_points = background_at_points; pc.bvariance_at_points = bvariance_at_points; pc.st = *st; pc.max_points = max_points;
+                pc.allow_extrapolation = allow_extrapolation; pc.out = out; pc.out_variance = out_variance; pc.mem = mem & ~GPP_ASYNC;
+                pc.slot = async_slot; pc.n_remembered = n_remembered; pc.skip_k_oi = skip_k_oi; pc.ntiles = a.ntiles;
+                pc.stats = g_stats;
+                g_pending.push_back(pc);
+                return GPP_OK;
+            };
+            if(overlap) {
+                if(!ws.ev_fork) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming)); }
+                if(steady) return defer();
                 GPP_HIP(hipEventRecord(ws.ev_fork, stream()));             // (behind k_pack_obs, which also cleared the status block)
                 a.skip_flags = memo.flags.p;
                 a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
@@ -1849,6 +1851,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 overlap_new = n_new; overlap_remembered = n_remembered; ran_overlap = true;
             }
             else if(!expect_long) {
+                if(steady) return defer();      // (nothing declined the last time: the first pass alone, deferred)
                 a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
                 launch_union(a.ntiles, false);                             // pass 1: every tile
                 GPP_HIP(hipEventRecord(ws.eu, stream()));

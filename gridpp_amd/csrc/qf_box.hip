@@ -228,6 +228,8 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
                 for(int j = 0; j < QB_SEG; j++) acc[j] = o[j] * (float)reps;
             }
             else if(reps > 1) {
+                // (round 5: the same loop on v_pk_add_f32, two additions per instruction, measured: 970 against 968 us -- a packed instruction issues
+                //  like two, tools/ubench/valu_rate.hip; taken out again)
 #pragma unroll 2
                 for(int e = 0; e < reps; e++) {
 #pragma unroll

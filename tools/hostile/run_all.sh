@@ -10,5 +10,7 @@ python tools/ensi_hostile_soak.py 0 120 $R poison tile  > $OUT/r05_ensi_tile_hos
 python tools/ensi_hostile_soak.py 0 120 $R poison       > $OUT/r05_ensi_hostile_soak.txt 2>&1       || rc=1
 python tools/oi_hostile_soak.py 5000 5100 $R 62 poison  > $OUT/r05_oi_hostile_soak_62.txt 2>&1      || rc=1
 python tools/oi_hostile_soak.py 5000 5100 $R poison     > $OUT/r05_oi_hostile_soak_32.txt 2>&1      || rc=1
+python tools/oi_hostile_soak.py 5000 5100 $R poison reuse > $OUT/r05_oi_hostile_soak_32_reuse.txt 2>&1 || rc=1
+python tools/oi_hostile_soak.py 5000 5100 $R 62 poison reuse > $OUT/r05_oi_hostile_soak_62_reuse.txt 2>&1 || rc=1
 for f in $OUT/r05_*hostile_soak*.txt; do echo "$f: $(grep -c '^pass' $f) passes, $(tail -n 30 $f | grep FAILURES)"; done
 exit $rc

@@ -1,6 +1,6 @@
 """Hostile soak of the randomised OI parity test (tests/test_gpu_oi_union_stress.py::_random_inputs) against the CPU oracle.
 
-    python tools/oi_hostile_soak.py LO HI REPEATS [62] [poison] [serial] [dump=DIR]
+    python tools/oi_hostile_soak.py LO HI REPEATS [62] [poison] [reuse] [dump=DIR]
 
 What is hostile about it (round-3 verdict, item 1: one unreproduced failure of the max_points 33..62 sequence):
   * the oracle's answers are computed once per seed and cached, so REPEATS passes over the sequence cost GPU time only;
@@ -10,6 +10,10 @@ What is hostile about it (round-3 verdict, item 1: one unreproduced failure of t
     0xFF -- a kernel that reads what this call never wrote meets NaNs, negative list entries and absurd counts;
   * every call is made twice and the two results must agree bit for bit (a race shows up as a difference even when both are within
     tolerance);
+  * `reuse` (round 5): the Grid / Points handles of a seed are kept from pass to pass, so that the state a GEOMETRY carries between calls is
+    exercised under the same hostility -- the memory of the tiles its first pass declined (list + flag bytes in HBM, csrc/oi.hip `overlap`), the
+    list passes beside the first pass on the second stream, and the third call of a seed goes through GPP_ASYNC + gpp_wait (deferred on three
+    streams when the geometry is in its steady state);
   * a failure records WHICH check failed, the statistics of the call, and dumps inputs + both outputs + the oracle's to DIR.
 Prints one summary line per pass and `FAILURES n` at the end (exit code 1 if n > 0).
 """
@@ -27,6 +31,7 @@ lo, hi, repeats = int(args[0]), int(args[1]), int(args[2])
 flags = args[3:]
 mps = [33, 40, 50, 62] if "62" in flags else [1, 2, 7, 20, 30, 32]
 poison = "poison" in flags
+reuse = "reuse" in flags
 dump = next((f.split("=", 1)[1] for f in flags if f.startswith("dump=")), os.path.join(ROOT, "gpurun_out", "hostile"))
 from tools.hostile.harness import Hostile                      # noqa: E402  (sets GPP_LIB for the poisoned build before gridpp_amd loads)
 H = Hostile(poison)
@@ -73,6 +78,8 @@ def reference(seed):
 
 
 failures = []
+handles = {}
+seen = set()
 
 
 def record(seed, what, detail, c, arrays, stats):
@@ -85,15 +92,23 @@ def record(seed, what, detail, c, arrays, stats):
 
 def one(seed):
     c, ref, ref2, rvar = reference(seed)
-    grid, points, st = gridpp.Grid(c["lats"], c["lons"]), gridpp.Points(c["plat"], c["plon"]), gridpp.BarnesStructure(c["h"])
+    if reuse:
+        if seed not in handles:
+            handles[seed] = (gridpp.Grid(c["lats"], c["lons"]), gridpp.Points(c["plat"], c["plon"]))
+        grid, points = handles[seed]
+    else:
+        grid, points = gridpp.Grid(c["lats"], c["lons"]), gridpp.Points(c["plat"], c["plon"])
+    st = gridpp.BarnesStructure(c["h"])
     hostile()
     out = gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], st, c["mp"], c["allow"])
     s1 = gridpp.oi_last_stats()
     d = compare(out, ref)
     if d:
         record(seed, "analysis", d, c, dict(out=out, ref=ref), s1)
-    if not s1["union_kernel_ms"] > 0:
+    if not s1["union_kernel_ms"] > 0 and not (reuse and seed in seen):
+        # (with the handles kept, a geometry whose first pass declined more than half of its tiles goes to k_oi alone from its second call on)
         record(seed, "first pass did not run", "", c, dict(out=out, ref=ref), s1)
+    seen.add(seed)
     hostile()
     out2, var = gridpp.optimal_interpolation_full(grid, c["bg"], c["bvar"], points, c["obs"], c["ratios"], c["pbg"], c["bvp"], st, c["mp"], c["allow"])
     s2 = gridpp.oi_last_stats()
@@ -107,6 +122,16 @@ def one(seed):
     hostile()
     out3, var3 = gridpp.optimal_interpolation_full(grid, c["bg"], c["bvar"], points, c["obs"], c["ratios"], c["pbg"], c["bvp"], st, c["mp"], c["allow"])
     s3 = gridpp.oi_last_stats()
+    if reuse:   # the deferred form on device-resident copies of the same inputs: the bits of the blocking call
+        import torch
+        dev = [torch.from_numpy(np.ascontiguousarray(c[k], dtype=np.float32)).cuda() for k in ("bg", "obs", "ratios", "pbg")]
+        hostile()
+        pend = gridpp.optimal_interpolation_async(grid, dev[0], points, dev[1], dev[2], dev[3], st, c["mp"], c["allow"])
+        pend2 = gridpp.optimal_interpolation_async(grid, dev[0], points, dev[1], dev[2], dev[3], st, c["mp"], c["allow"])
+        oa, ob = pend.wait().cpu().numpy(), pend2.wait().cpu().numpy()
+        if not (np.array_equal(oa, out, equal_nan=True) and np.array_equal(ob, out, equal_nan=True)):
+            record(seed, "deferred call differs", "%d / %d values" % (int((~((oa == out) | (np.isnan(oa) & np.isnan(out)))).sum()), int((~((ob == out) | (np.isnan(ob) & np.isnan(out)))).sum())),
+                   c, dict(out=out, deferred=oa, deferred2=ob, ref=ref), gridpp.oi_last_stats())
     if not (np.array_equal(out2, out3, equal_nan=True) and np.array_equal(var, var3, equal_nan=True)):
         nd = int((~((out2 == out3) | (np.isnan(out2) & np.isnan(out3)))).sum()) + int((~((var == var3) | (np.isnan(var) & np.isnan(var3)))).sum())
         record(seed, "repeat differs", "%d values; second call: %s" % (nd, s3), c, dict(out=out2, out_again=out3, var=var, var_again=var3, ref=ref2), s2)
