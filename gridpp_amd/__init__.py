@@ -754,14 +754,24 @@ class PendingAnalysis:
     """An optimal_interpolation call that was enqueued with GPP_ASYNC (include/gridpp_hip.h: gpp_wait): wait() returns the analysis (and the
     variance, if asked for) once it is complete and raises what the call would have raised.  The library completes its deferred calls in
     order: waiting for a later one first completes the earlier ones."""
-    _queue = []
+    _tls = None      # per thread: the library queues deferred calls per calling thread (gpp_wait completes the oldest one of ITS thread)
+
+    @classmethod
+    def _q(cls):
+        import threading
+        if cls._tls is None:
+            cls._tls = threading.local()
+        if not hasattr(cls._tls, "q"):
+            cls._tls.q = []
+        return cls._tls.q
 
     def __init__(self, out, var, keep):
         self._out, self._var, self._keep, self._rc, self._msg = out, var, keep, None, None
-        PendingAnalysis._queue.append(self)
+        self._queue = PendingAnalysis._q()      # (wait() from another thread than the one that made the call is an error of the caller)
+        self._queue.append(self)
 
     def _complete_front(self):
-        front = PendingAnalysis._queue.pop(0)
+        front = self._queue.pop(0)
         front._rc = lib().gpp_wait()
         front._msg = lib().gpp_last_error().decode("utf-8", "replace") if front._rc != _capi.GPP_OK else None
         front._stats = oi_last_stats() if front._rc == _capi.GPP_OK else None
