@@ -70,3 +70,53 @@ def test_oi_golden_vectors(name):
         out, var = O.oi_full(og, c["background"], c["bvariance"], op, c["pobs"], c["obs_variance"], c["pbackground"], c["bvariance_at_points"],
                              O.Barnes(h, v, w), int(mp), bool(allow))
     oi_golden.check(out, var, c)
+
+
+# ---- a third opinion on the EnSI matrix functions: 50-digit arithmetic ------------------------------------------------------------------
+# The reference holds no numeric EnSI value (tests/test_optimal_interpolation_ens.py:9-35), so the oracle is pinned by the numpy / LAPACK
+# restatement (tools/make_ensi_fixtures.py).  Both could share a misreading of the SOURCE, but not an arithmetic accident: here the
+# restatement's `inv` and `eig_sym` (oi_ensi.cpp:399-421) are replaced by mpmath at 50 digits -- exact for every purpose -- and the
+# oracle's float32 outputs must still be the restatement's, also on inputs where the E x E system is ill-conditioned (sigmas x 0.01:
+# cond ~ 1e4; round 5 found the large-n KERNELS wrong there while oracle, LAPACK and the 50-digit evaluation agreed to the last bit).
+@pytest.mark.parametrize("E,S,mp,sig_scale", [(8, 40, 10, 1.0), (17, 60, 0, 1.0), (12, 50, 40, 0.01), (20, 60, 20, 0.1)])
+def test_oracle_ensi_against_50_digit_matrix_functions(E, S, mp, sig_scale):
+    mp_ = pytest.importorskip("mpmath")
+    import os
+    import sys
+    import numpy as np
+    import scipy.linalg as sla
+    from oracle import oracle as O
+    from tests.test_gpu_ensi_parity import case
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_ensi_fixtures as M
+    mp_.mp.dps = 50
+
+    class Exact:
+        lapack = sla.lapack
+
+        @staticmethod
+        def inv(A):
+            return np.array((mp_.matrix(A.tolist()) ** -1).tolist(), dtype=np.float64)
+
+        @staticmethod
+        def eigh(A):
+            ev, Q = mp_.eigsy(mp_.matrix(A.tolist()))
+            return np.array([float(e) for e in ev]), np.array(Q.tolist(), dtype=np.float64)
+    Y, X = 4, 5
+    lats, lons, bg, plat, plon, pbg, obs, sig = case(900 + E, Y, X, E, S)
+    sig = (sig * sig_scale).astype(np.float32)
+    h = 40000.0
+    ref = O.oi_ensi(O.Pts(lats.ravel(), lons.ravel()), bg.reshape(-1, E), O.Pts(plat, plon), obs, sig, pbg, O.Barnes(h), mp, True)
+    nanb, nanp = np.full(Y * X, np.nan, np.float32), np.full(S, np.nan, np.float32)
+    saved = M.sla
+    try:
+        M.sla = Exact
+        exact = M.ensi(lats.ravel().astype(np.float32), lons.ravel().astype(np.float32), nanb, nanb, bg.reshape(-1, E), plat.astype(np.float32),
+                       plon.astype(np.float32), nanp, nanp, obs, sig, pbg, h, 0.0, 0.0, mp, True)
+    finally:
+        M.sla = saved
+    m = ~np.isnan(exact)
+    assert (np.isnan(ref) == np.isnan(exact)).all() and m.any()
+    err = np.abs(ref[m].astype(np.float64) - exact[m]) / np.maximum(np.abs(exact[m]), 1e-2)
+    assert err.max() < 1e-6, err.max()                                   # (in practice 0: the same float32 on every value)
+    assert (ref[m] != exact[m]).mean() < 0.01
