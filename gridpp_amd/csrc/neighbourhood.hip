@@ -835,7 +835,8 @@ void member_pass(const float* d_in, long C, int E, int mode, int statistic, cons
 template <int NL>
 void qf_count_launch_nl(const float* d_in, long C, int E, const float* d_thr, int T, const QfLut* lut, unsigned char* cnt8, const QfGeom& g) {
     const size_t lds = (size_t)(2 * QF_NB + std::max(16 * E, NL * 64)) * sizeof(unsigned) + (size_t)(T + 1) * 256;
-    const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(24, (160 * 1024) / lds));
+    int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(24, (160 * 1024) / lds));
+    if(path_env("GPP_QF_WAVES")) waves_per_cu = std::max(1, std::min(waves_per_cu, atoi(path_env("GPP_QF_WAVES"))));   // (A/B: fewer, longer streams)
     const long grid = std::max<long>(1, std::min<long>((C / 64 + 3) / 4, (long)256 * waves_per_cu));
     hipLaunchKernelGGL((k_qf_count<NL>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, d_thr, T, lut, cnt8, g);
     GPP_HIP(hipGetLastError());
