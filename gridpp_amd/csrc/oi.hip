@@ -1794,8 +1794,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
                 launch_union(a.ntiles, false);
                 a.skip_flags = nullptr;
-                GPP_HIP(hipEventRecord(sl.eu, sA));
-                GPP_HIP(hipEventRecord(sl.e1, sA));
+                GPP_HIP(hipEventRecord(sl.e1, sA));      // (one timestamp behind the first pass: every command between two first passes is a gap on the GPU)
                 GPP_HIP(hipStreamWaitEvent(sC, sl.e1, 0));
                 GPP_HIP(hipStreamWaitEvent(sC, ws.ev_join2[wsl], 0));
                 GPP_HIP(hipMemcpyAsync(sl.h, status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, sC));
@@ -2036,7 +2035,7 @@ static int complete_pending(PendingOi& pc) {
     if(err == 0 && n_new == 0 && !(pc.skip_k_oi && left > 0)) {
         pc.stats.fallback_tiles = pc.n_remembered; pc.stats.fallback_subtiles = left;
         GPP_HIP(hipEventElapsedTime(&pc.stats.kernel_ms, sl.e0, sl.e1));
-        GPP_HIP(hipEventElapsedTime(&pc.stats.union_kernel_ms, sl.e0, sl.eu));
+        pc.stats.union_kernel_ms = pc.stats.kernel_ms;   // (the first pass is what stream A ran between the two timestamps; the list passes ran beside the call before)
         pc.stats.cells_updated = 0; pc.stats.solves = 0;
         const unsigned long long* const c = sl.h + 8;
         for(int k = 0; k < GPP_NSLOT; k++) { pc.stats.cells_updated += (long long)c[80 + 2 * k]; pc.stats.solves += (long long)c[81 + 2 * k]; }
