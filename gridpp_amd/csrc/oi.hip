@@ -1218,9 +1218,9 @@ struct PendingOi {
     gpp_points* bgrid; const float* background; const float* bvariance; gpp_points* points; const float* obs; const float* obs_variance;
     const float* background_at_points; const float* bvariance_at_points; gpp_structure st; int max_points, allow_extrapolation;
     float* out; float* out_variance; int mem;
-    int slot = -1; int n_remembered = 0; bool skip_k_oi = false; int ntiles = 0;
+    int slot = -1; int n_remembered = 0; bool skip_k_oi = false;
 };
-struct AsyncSlot { unsigned long long* h = nullptr; hipEvent_t e0 = nullptr, eu = nullptr, e1 = nullptr, ec = nullptr; };   // first kernel, end of the first pass, last kernel, status copy arrived
+struct AsyncSlot { unsigned long long* h = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, ec = nullptr; };   // page-locked copy of the status block; start / end of the first pass, status copy arrived
 thread_local AsyncSlot g_aslots[ASYNC_SLOTS];
 thread_local std::vector<PendingOi> g_pending;     // FIFO
 thread_local unsigned g_async_seq = 0;
@@ -1529,7 +1529,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         for(int k = 0; k < ASYNC_SLOTS; k++) {
             AsyncSlot& sl = g_aslots[k];
             GPP_HIP(hipHostMalloc((void**)&sl.h, SB * sizeof(unsigned long long), hipHostMallocDefault));
-            GPP_HIP(hipEventCreate(&sl.e0)); GPP_HIP(hipEventCreate(&sl.eu)); GPP_HIP(hipEventCreate(&sl.e1)); GPP_HIP(hipEventCreateWithFlags(&sl.ec, hipEventDisableTiming));
+            GPP_HIP(hipEventCreate(&sl.e0)); GPP_HIP(hipEventCreate(&sl.e1)); GPP_HIP(hipEventCreateWithFlags(&sl.ec, hipEventDisableTiming));
         }
         for(int k = 0; k < 2; k++) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_pack[k], hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_join2[k], hipEventDisableTiming)); }
         (void)stream2(); (void)stream3();
@@ -1749,8 +1749,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             // the same bits), and a tile the first pass declines that was NOT flagged arrives in its out_list as before, is taken by the serial
             // passes after the read-back and joins the remembered list.
             const bool overlap = memo_hit && memo.nlist > 0 && memo.list_ntiles == a.ntiles && !path_env("GPP_OI_NO_OVERLAP");
-            int n_remembered = 0;
-            n_remembered = overlap ? memo.nlist : 0;
+            const int n_remembered = overlap ? memo.nlist : 0;
             const int* const d_mcount = memo.count.p;
             auto remembered_passes = [&]() {   // the list passes over the REMEMBERED list, on `cur`
                 if(16 * (long)n_remembered <= SHORT_ITEMS) {
@@ -1804,7 +1803,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 pc.bgrid = bgrid; pc.background = background; pc.bvariance = bvariance; pc.points = points; pc.obs = obs; pc.obs_variance = obs_variance;
                 pc.background_at_points = background_at_points; pc.bvariance_at_points = bvariance_at_points; pc.st = *st; pc.max_points = max_points;
                 pc.allow_extrapolation = allow_extrapolation; pc.out = out; pc.out_variance = out_variance; pc.mem = mem & ~GPP_ASYNC;
-                pc.slot = async_slot; pc.n_remembered = n_remembered; pc.skip_k_oi = skip_k_oi; pc.ntiles = a.ntiles;
+                pc.slot = async_slot; pc.n_remembered = n_remembered; pc.skip_k_oi = skip_k_oi;
                 pc.stats = g_stats;
                 g_pending.push_back(pc);
                 return GPP_OK;
