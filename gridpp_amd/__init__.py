@@ -806,6 +806,14 @@ def optimal_interpolation(bgrid, background, points, pobs, pratios, pbackground,
                       allow_extrapolation, False)[0]
 
 
+def optimal_interpolation_full_async(bgrid, background, bvariance, points, obs, obs_variance, background_at_points,
+                                     bvariance_at_points, structure, max_points, allow_extrapolation=True):
+    """optimal_interpolation_full without waiting for the result (see optimal_interpolation_async): PendingAnalysis.wait() returns
+    (analysis, analysis_variance)."""
+    return _oi_common(bgrid, background, bvariance, points, obs, obs_variance, background_at_points, bvariance_at_points, structure, max_points,
+                      allow_extrapolation, True, deferred=True)
+
+
 def optimal_interpolation_full(bgrid, background, bvariance, points, obs, obs_variance, background_at_points,
                                bvariance_at_points, structure, max_points, allow_extrapolation=True):
     """gridpp::optimal_interpolation_full (src/api/oi.cpp:138-412); returns (analysis, analysis_variance)."""

@@ -90,3 +90,29 @@ def test_pipeline_over_a_stream_of_observation_sets():
     assert len(got) == 18
     for k, g in enumerate(got):
         assert np.array_equal(g, sync[k % 6], equal_nan=True), k
+
+
+def test_deferred_full_form_with_variance():
+    """optimal_interpolation_full (analysis + analysis variance, oi.cpp:138-412) deferred: the bits of the blocking call, with a Points background too"""
+    import torch
+    gridpp, grid, points, st, bg, sets = _setup(13, rough_rows=10)
+    rng = np.random.default_rng(3)
+    bvar = torch.from_numpy(rng.uniform(0.5, 2, tuple(bg.shape)).astype(np.float32)).cuda()
+    S = sets[0][0].shape[0]
+    ovar = torch.from_numpy(rng.uniform(0.1, 1, S).astype(np.float32)).cuda()
+    bvp = torch.from_numpy(rng.uniform(0.5, 2, S).astype(np.float32)).cuda()
+    sync = [gridpp.optimal_interpolation_full(grid, bg, bvar, points, o, ovar, p, bvp, st, 30) for o, r, p in sets[:3]]
+    for rep in range(2):
+        pend = [gridpp.optimal_interpolation_full_async(grid, bg, bvar, points, o, ovar, p, bvp, st, 30) for o, r, p in sets[:3]]
+        for k, pd in enumerate(pend):
+            a, v = pd.wait()
+            assert np.array_equal(a.cpu().numpy(), sync[k][0].cpu().numpy(), equal_nan=True) and np.array_equal(v.cpu().numpy(), sync[k][1].cpu().numpy(), equal_nan=True), (rep, k)
+    # a Points background (64 consecutive points per tile)
+    Y, X = bg.shape
+    lats, lons = np.meshgrid(np.linspace(60, 60 + Y / 240.0, Y), np.linspace(10, 10 + X / 120.0, X), indexing="ij")
+    pts_bg = gridpp.Points(lats.ravel(), lons.ravel(), np.full(Y * X, 100.0, np.float32), np.full(Y * X, 0.5, np.float32))
+    flat = bg.reshape(-1).contiguous()
+    ref = gridpp.optimal_interpolation(pts_bg, flat, points, *sets[0], st, 30).cpu().numpy()
+    for _ in range(3):
+        out = gridpp.optimal_interpolation_async(pts_bg, flat, points, *sets[0], st, 30).wait().cpu().numpy()
+        assert np.array_equal(out, ref, equal_nan=True)
