@@ -263,6 +263,13 @@ void launch_hw(const unsigned char* cnt8, const QfGeom& g, int reps, int T, cons
     // rows per workgroup: about QB_SH, chosen so that the workgroups fill the 256 CUs a whole number of times
     const int strips = (g.X + QB_SW - 1) / QB_SW;
     int segs = std::max(1, (g.Y + QB_SH - 1) / QB_SH);
+    // (round 5: a field with few rows -- a rank's row tile of the 8-GPU run: 530 rows -- gave 144 workgroups for 256 CUs, each marching 59 + 2 HW + 1
+    //  rows; shorter segments, down to 8 rows, until there are about three workgroups per CU (GPP_QB_FILL; tools/qb_fill_sweep.sh: 1 -> 0.544,
+    //  2 -> 0.467, 3 -> 0.457, 4 -> 0.490, 6 -> 0.546 ms for quantile_fast on that tile -- every extra segment costs its 2 HW + 1 run-in rows))
+    { const char* e = gpp::path_env("GPP_QB_FILL");
+      const int fill = e && atoi(e) > 0 ? atoi(e) : 3;
+      const int want = std::max(1, (fill * 256) / std::max(1, strips));
+      if(segs < want) segs = std::max(segs, std::min(want, std::max(1, g.Y / 8))); }
     if(strips * segs > 256) { const int per = 256 / std::__gcd(256, strips); segs = (segs + per - 1) / per * per; }
     const int SH = std::max(1, (g.Y + segs - 1) / segs);
     const dim3 grid(strips, (g.Y + SH - 1) / SH);
