@@ -1020,6 +1020,10 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
         GPP_HIP(hipMemsetAsync(g.rowflag, 0, sizeof(int) * (ny + 1), stream()));
         if(ranked) qf_count_launch(in.d, C, ne, th.d, nt, lut, lut_head[2], cnt8, g);
         else member_pass(in.d, C, ne, 2, 0, th.d, nt, reinterpret_cast<float*>(cnt8), g);
+#ifdef QF_SIDE_EXPERIMENT   // timing experiment only: the box pass on the second stream WITHOUT waiting for the counts (wrong results)
+        if(path_env("GPP_QF_SIDE")) { qf_box_launch(cnt8, g, ne, halfwidth, nt, th.d, qf.d, nq == 1 ? 0 : 1, o.d, stream2()); GPP_HIP(hipStreamSynchronize(stream2())); }
+        else
+#endif
         qf_box_launch(cnt8, g, ne, halfwidth, nt, th.d, qf.d, nq == 1 ? 0 : 1, o.d);
         o.finish();
         GPP_HIP(hipStreamSynchronize(stream()));

@@ -30,4 +30,4 @@ __device__ __forceinline__ long qf_cell_offset(const QfGeom& g, const long cell)
 }
 
 // box pass: cnt8 = the T + 1 planes above -> out [Y][X]   (neighbourhood.cpp:473-522, util.cpp:339-414)
-void qf_box_launch(const unsigned char* cnt8, const QfGeom& g, int reps, int hw, int T, const float* d_thr, const float* d_q, int qfield, float* d_out);
+void qf_box_launch(const unsigned char* cnt8, const QfGeom& g, int reps, int hw, int T, const float* d_thr, const float* d_q, int qfield, float* d_out, hipStream_t st = nullptr);

@@ -185,9 +185,16 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
     const bool xfull = x0 - HW >= 0 && x0 + QB_SEG - 1 + HW <= X - 1;   // every window of the segment lies inside the field's columns
     // run-in (y < ybeg): rows ybeg - HW .. ybeg + HW - 1 enter and nothing leaves; from ybeg on every step completes a row of output
     for(int y = ybeg - 2 * HW; y < yend; y++) {
+#if defined(QB_ABL) && (QB_ABL & 4)      // timing experiment: no window sums (no loads, no table, no prefix sums)
+        if(active) {
+#pragma unroll
+            for(int j = 0; j < QB_SEG; j++) V[j] += (double)(y + j);
+        }
+#else
         if(active) {
             step(y + HW, y > ybeg ? y - HW - 1 : -QF_PADY - 1000000);
         }
+#endif
         if(y < ybeg) continue;
         float* const yab = ya + ((y - ybeg) & 1) * T * QB_SW;
         if(active) {
@@ -227,10 +234,19 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
 #pragma unroll
                 for(int j = 0; j < QB_SEG; j++) acc[j] = o[j] * (float)reps;
             }
+#if defined(QB_ABL) && (QB_ABL & 1)      // timing experiment: no E-fold sum
+            else if(true) {
+#pragma unroll
+                for(int j = 0; j < QB_SEG; j++) acc[j] = o[j] * (float)reps;
+            }
+#endif
             else if(reps > 1) {
                 // (round 5: the same loop on v_pk_add_f32, two additions per instruction, measured: 970 against 968 us -- a packed instruction issues
                 //  like two, tools/ubench/valu_rate.hip; taken out again)
-#pragma unroll 2
+#ifndef QB_UNR
+#define QB_UNR 2
+#endif
+#pragma unroll QB_UNR
                 for(int e = 0; e < reps; e++) {
 #pragma unroll
                     for(int j = 0; j < QB_SEG; j++) acc[j] += o[j];
@@ -250,14 +266,18 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
             const int x = xs + c;
             if(x < X) {
                 const long cell = (long)y * X + x;
+#if defined(QB_ABL) && (QB_ABL & 2)      // timing experiment: no interpolation
+                out[cell] = yab[c] + yab[c + (T - 1) * QB_SW];
+#else
                 out[cell] = qb_interp(yab + c, QB_SW, T, sthr, qfield ? q[cell] : q[0]);
+#endif
             }
         }
     }
 }
 
 template <int HW>
-void launch_hw(const unsigned char* cnt8, const QfGeom& g, int reps, int T, const float* d_thr, const float* d_q, int qfield, float* d_out) {
+void launch_hw(const unsigned char* cnt8, const QfGeom& g, int reps, int T, const float* d_thr, const float* d_q, int qfield, float* d_out, hipStream_t st) {
     const int threads = 64 * ((T * (QB_SW / QB_SEG) + 63) / 64);
     const size_t lds = 256 * sizeof(double) + 16 * sizeof(float) + (size_t)2 * T * QB_SW * sizeof(float);
     // rows per workgroup: about QB_SH, chosen so that the workgroups fill the 256 CUs a whole number of times
@@ -273,15 +293,16 @@ void launch_hw(const unsigned char* cnt8, const QfGeom& g, int reps, int T, cons
     if(strips * segs > 256) { const int per = 256 / std::__gcd(256, strips); segs = (segs + per - 1) / per * per; }
     const int SH = std::max(1, (g.Y + segs - 1) / segs);
     const dim3 grid(strips, (g.Y + SH - 1) / SH);
-    hipLaunchKernelGGL((k_qf_box<HW, false>), grid, dim3(threads), lds, stream(), cnt8, g, reps, T, d_thr, d_q, qfield, d_out, SH);
-    hipLaunchKernelGGL((k_qf_box<HW, true>), grid, dim3(threads), lds, stream(), cnt8, g, reps, T, d_thr, d_q, qfield, d_out, SH);
+    hipLaunchKernelGGL((k_qf_box<HW, false>), grid, dim3(threads), lds, st, cnt8, g, reps, T, d_thr, d_q, qfield, d_out, SH);
+    hipLaunchKernelGGL((k_qf_box<HW, true>), grid, dim3(threads), lds, st, cnt8, g, reps, T, d_thr, d_q, qfield, d_out, SH);
     GPP_HIP(hipGetLastError());
 }
 }   // namespace
 
-void qf_box_launch(const unsigned char* cnt8, const QfGeom& g, int reps, int hw, int T, const float* d_thr, const float* d_q, int qfield, float* d_out) {
+void qf_box_launch(const unsigned char* cnt8, const QfGeom& g, int reps, int hw, int T, const float* d_thr, const float* d_q, int qfield, float* d_out, hipStream_t st) {
+    if(!st) st = stream();
     switch(hw) {
-#define QB_CASE(n) case n: launch_hw<n>(cnt8, g, reps, T, d_thr, d_q, qfield, d_out); break;
+#define QB_CASE(n) case n: launch_hw<n>(cnt8, g, reps, T, d_thr, d_q, qfield, d_out, st); break;
         QB_CASE(0) QB_CASE(1) QB_CASE(2) QB_CASE(3) QB_CASE(4) QB_CASE(5) QB_CASE(6) QB_CASE(7) QB_CASE(8)
         QB_CASE(9) QB_CASE(10) QB_CASE(11) QB_CASE(12) QB_CASE(13) QB_CASE(14) QB_CASE(15) QB_CASE(16)
 #undef QB_CASE
