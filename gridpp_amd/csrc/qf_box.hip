@@ -181,6 +181,13 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
             if(out_field) { if(fout) flagged_row(yout, -1); else plain_row(yout, -1); }
         }
     };
+    // run-in step: a row enters the window and nothing leaves (half the table look-ups and no subtraction)
+    auto step_in = [&](const int yin) __attribute__((always_inline)) {
+        bool fin = false;
+        if constexpr (GENERAL) fin = yin >= 0 && yin < Y && g.rowflag[yin] != 0;
+        if(!fin) plain_row(yin, 1);
+        else if constexpr (GENERAL) flagged_row(yin, 1);
+    };
     const double rreps = 1.0 / (double)reps;
     const bool xfull = x0 - HW >= 0 && x0 + QB_SEG - 1 + HW <= X - 1;   // every window of the segment lies inside the field's columns
     // run-in (y < ybeg): rows ybeg - HW .. ybeg + HW - 1 enter and nothing leaves; from ybeg on every step completes a row of output
@@ -192,7 +199,11 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
         }
 #else
         if(active) {
+#ifdef QB_NO_RUNIN_SHORTCUT
             step(y + HW, y > ybeg ? y - HW - 1 : -QF_PADY - 1000000);
+#else
+            if(y > ybeg) step(y + HW, y - HW - 1); else step_in(y + HW);
+#endif
         }
 #endif
         if(y < ybeg) continue;
