@@ -607,6 +607,198 @@ __global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs,
         out[plane + (long)y * X + x] = o;
     }
 }
+// Row pass + column pass in one kernel for halfwidths up to BM_MAXHW (round 5).  A workgroup marches down a strip of BM_W output columns in
+// chunks of BM_C rows: the (BM_W + 2 hw) values of every new row go through LDS once, their row-window sums (doubles, sliding along segments of
+// eight columns as k_box_rows4 does) and the numbers of valid values in those windows go into a ring of BM_RING rows, and the outputs whose
+// 2 hw + 1 rows are in the ring are finished from it (sliding down segments of eight rows as k_box_cols does).  The values of the next chunk are
+// asked for before the sums of the current one are formed, so the trip to memory hides behind them.  The plane is read 1 + 2 hw / BM_W times and
+// written once; the two-kernel form writes and re-reads a plane of doubles and one of counts in between (config 4 Mean: 0.09 + 0.05 ms for the
+// two passes, this kernel: see DESIGN 11.5).  (A first version without the march -- tiles of 32 x 64 outputs, each loading its halo rows again --
+// took 0.22 ms: 60 KB of LDS per workgroup leave two of them on a CU, and a workgroup that loads, sums and stores once is mostly latency.)
+#define BM_W 64
+#define BM_C 32
+#define BM_RING 64
+#define BM_MAXHW 16          // BM_C + 2 BM_MAXHW <= BM_RING
+#define BM_RP (BM_W + 1)     // pitch of the ring rows (doubles)
+#define BM_P (BM_W + 2 * BM_MAXHW + 1)   // pitch of the chunk's rows (floats; odd, and wide enough for every thread's unconditional store)
+__host__ __device__ inline size_t bm_tin_bytes(int) { return (((size_t)BM_C * BM_P * sizeof(float)) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t bm_lds_bytes(int hw) { return bm_tin_bytes(hw) + (size_t)BM_RING * (BM_RP * sizeof(double) + BM_W + 1); }
+template <int HW>
+__global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in, int Y, int X, int statistic, float* __restrict__ out, int qf_reps, int SH) {
+    constexpr int hw = HW;   // (a template parameter: every window loop unrolls, its LDS reads are issued together and waited for once)
+    extern __shared__ __attribute__((aligned(16))) unsigned char bm_lds[];
+    constexpr int Wt = BM_W + 2 * hw, P = BM_P;
+    float* const tin = reinterpret_cast<float*>(bm_lds);                                       // [BM_C][P]: the rows of the chunk, 0 outside the field
+    double* const ring = reinterpret_cast<double*>(bm_lds + bm_tin_bytes(hw));                 // [BM_RING][BM_RP]: row-window sums of the strip's columns
+    unsigned char* const rcnt = reinterpret_cast<unsigned char*>(ring + (size_t)BM_RING * BM_RP);   // [BM_RING][BM_W]: valid values in those windows (rows of counted chunks only)
+    unsigned char* const rflag = rcnt + BM_RING * BM_W;                                        // [BM_RING]: the ring row comes from a counted chunk
+    const long plane = (long)blockIdx.z * Y * X;
+    const int x0 = blockIdx.x * BM_W;
+    const int ya = blockIdx.y * SH, yb = min(Y, ya + SH);          // this workgroup's output rows
+    if(ya >= yb) return;
+    const int tid = threadIdx.x;
+    const int yl0 = ya - hw;                                        // first row it loads; ring slot of field row y: (y - yl0) % BM_RING
+    const int nchunk = (yb - 1 + hw - yl0) / BM_C + 1;
+    const int clo = max(0, hw - x0), chi = min(Wt, X - x0 + hw);    // loaded columns [clo, chi) lie inside the field
+    constexpr int NR = BM_C / 8, NCc = (BM_W + 2 * BM_MAXHW + 31) / 32;
+    float v[NR][NCc];
+    auto fetch = [&](const int k) {   // thread: rows tid / 32 + 8 i, columns tid % 32 + 32 j of chunk k (every load is made, from a clamped address: no branch per value)
+#pragma unroll
+        for(int i = 0; i < NR; i++) {
+            const int y = yl0 + k * BM_C + (tid >> 5) + 8 * i;
+            const bool rowok = y >= 0 && y < Y;
+            const float* const row = in + plane + (long)min(max(y, 0), Y - 1) * X;
+#pragma unroll
+            for(int j = 0; j < NCc; j++) {
+                const int c = (tid & 31) + 32 * j;
+#if defined(BM_ABL) && (BM_ABL & 1)     // timing experiment: no loads
+                const float t = (float)(y + c);
+#else
+                const float t = row[min(max(x0 - hw + c, 0), X - 1)];
+#endif
+                v[i][j] = (rowok && c >= clo && c < chi) ? t : 0.0f;
+            }
+        }
+    };
+    fetch(0);
+    int ynext = ya;                                                 // first output row not yet written
+    // The outputs of a chunk wait in registers and are stored one chunk later, in front of the next fetch: stores and loads complete in the order
+    // they were issued, so the wait for a chunk's values would otherwise be a wait for the stores issued behind its fetch as well (measured: 0.080 ms
+    // with the stores straight from the sums, whatever the arithmetic cost)
+    float po[8];
+    int py8 = 0, pnrow = 0;                                         // first row and number of rows of the waiting outputs (0: none)
+    const int pc = tid & 63, px = x0 + pc;
+    auto flush = [&]() {
+#if defined(BM_ABL) && (BM_ABL & 2)     // timing experiment: no stores (but for values that do not occur)
+#pragma unroll
+        for(int j = 0; j < 8; j++) if(j < pnrow && po[j] == -12345.0f) out[plane + (long)(py8 + j) * X + px] = po[j];
+#else
+        if(pnrow == 8) {   // (the usual case under one branch)
+            float* const o8 = out + plane + (long)py8 * X + px;
+#pragma unroll
+            for(int j = 0; j < 8; j++) o8[(long)j * X] = po[j];
+        }
+        else {
+#pragma unroll
+            for(int j = 0; j < 8; j++) if(j < pnrow) out[plane + (long)(py8 + j) * X + px] = po[j];
+        }
+#endif
+        pnrow = 0;
+    };
+    unsigned hist = 0u;                                             // bit i: chunk k - i held a missing value (a window reaches back two chunks at most)
+    for(int k = 0; k < nchunk; k++) {
+        int bad = 0;
+#pragma unroll
+        for(int i = 0; i < NR; i++) {
+            const int r = (tid >> 5) + 8 * i;
+#pragma unroll
+            for(int j = 0; j < NCc; j++) {
+                const int c = (tid & 31) + 32 * j;
+                tin[r * P + c] = v[i][j];                           // (c < 96 <= P)
+                bad |= nv(v[i][j]) ? 0 : 1;                         // (outside the field: 0)
+            }
+        }
+        const bool counted = __syncthreads_or(bad) != 0;            // (also: the chunk is in LDS, and the previous chunk's outputs are finished)
+        hist = (hist << 1) | (counted ? 1u : 0u);
+        flush();                                                    // the previous chunk's outputs
+        if(k + 1 < nchunk) fetch(k + 1);                            // in flight while this chunk is summed
+        {   // row-window sums of row tid / 8 of the chunk, output columns 8 (tid % 8) .. + 7
+            const int r = tid >> 3, sg = tid & 7;
+            const int slot = (k * BM_C + r) & (BM_RING - 1);
+            const float* const t = tin + r * P + 8 * sg;            // output column 8 sg + j: loaded columns 8 sg + j .. 8 sg + j + 2 hw
+            double* const rs = ring + (size_t)slot * BM_RP + 8 * sg;
+            if(sg == 0) rflag[slot] = counted ? 1 : 0;
+            if(!counted) {   // nothing missing in the chunk: the windows are counted in closed form when they are needed (below)
+                float tv[8 + 2 * HW];
+#pragma unroll
+                for(int q = 0; q < 8 + 2 * HW; q++) tv[q] = t[q];
+                double sc[4] = {0.0, 0.0, 0.0, 0.0};                // (four chains: the adds of one wait for each other)
+#pragma unroll
+                for(int q = 0; q <= 2 * HW; q++) sc[q & 3] += (double)tv[q];
+                double s = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+                rs[0] = s;
+#pragma unroll
+                for(int j = 1; j < 8; j++) { s += (double)tv[j + 2 * HW]; s -= (double)tv[j - 1]; rs[j] = s; }
+            }
+            else {
+                const int y = yl0 + k * BM_C + r;
+                const bool rowok = y >= 0 && y < Y;
+                unsigned char* const rc = rcnt + slot * BM_W + 8 * sg;
+                auto ok = [&](const int q) { const int c = 8 * sg + q; return rowok && c >= clo && c < chi && nv(t[q]); };
+                double s = 0.0; int n = 0;
+                for(int q = 0; q <= 2 * hw; q++) if(ok(q)) { s += (double)t[q]; n++; }
+                rs[0] = s; rc[0] = (unsigned char)n;
+#pragma unroll
+                for(int j = 1; j < 8; j++) {
+                    if(ok(j + 2 * hw)) { s += (double)t[j + 2 * hw]; n++; }
+                    if(ok(j - 1)) { s -= (double)t[j - 1]; n--; }
+                    rs[j] = s; rc[j] = (unsigned char)n;
+                }
+            }
+        }
+        __syncthreads();                                            // the ring holds the rows up to ytop; the chunk's LDS rows are free again
+        const int ytop = yl0 + (k + 1) * BM_C - 1;
+        const int ylim = min(yb, ytop - hw + 1);                    // outputs [ynext, ylim) have their 2 hw + 1 rows in the ring (at most BM_C of them)
+        {
+            const int c = pc, x = px;
+            const int y8 = ynext + (tid >> 6) * 8;                  // this thread's eight output rows
+            if(x < X && y8 < ylim) {
+                py8 = y8; pnrow = min(8, ylim - y8);
+                const bool slow = (hist & 7u) != 0u;                // some row of the windows may lack values: counts from the ring
+                const int cx = min(x + hw, X - 1) - max(x - hw, 0) + 1;   // field columns in a row window of this column
+                // valid values in the row window of field row y: counted by its chunk, or all of its field columns
+                auto rown = [&](const int y) {
+                    const int sl = (y - yl0) & (BM_RING - 1);
+                    return rflag[sl] ? (int)rcnt[sl * BM_W + c] : ((y >= 0 && y < Y) ? cx : 0);
+                };
+                const double* const rp = ring + c;
+                const int stop = (y8 - hw - yl0) & (BM_RING - 1);   // ring slot of the first row of the first window
+                int n = 0;
+                double rv[2 * HW + 8];                              // the row-window sums of the 2 hw + 8 rows under this thread's eight windows
+#pragma unroll
+                for(int q = 0; q < 2 * HW + 8; q++) rv[q] = rp[((stop + q) & (BM_RING - 1)) * BM_RP];   // (rows behind ylim + hw: whatever the ring holds there, not used)
+                double sc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for(int q = 0; q <= 2 * HW; q++) sc[q & 3] += rv[q];
+                double s = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+                if(slow) for(int q = -hw; q <= hw; q++) n += rown(y8 + q);
+                int nprev = -1;
+                double rinv = 0.0;
+#pragma unroll
+                for(int j = 0; j < 8; j++) {
+                    const int y = y8 + j;
+                    if(y >= ylim) break;
+                    if(j > 0) {
+                        s += rv[j + 2 * HW]; s -= rv[j - 1];
+                        if(slow) n += rown(y + hw) - rown(y - hw - 1);
+                    }
+                    if(!slow) n = cx * (min(y + hw, Y - 1) - max(y - hw, 0) + 1);
+                    float o = NAN;
+                    if(statistic == GPP_COUNT) o = (float)n;
+                    else if(n > 0) {
+                        if(statistic == GPP_MEAN) {
+                            // s / n through the reciprocal of n (the same for almost every row) and one correction by the exact residual: within
+                            // an ulp(double) of the quotient -- the float it rounds to is the division's except on a rounding boundary
+                            const double nd = (double)n;
+                            if(n != nprev) { rinv = 1.0 / nd; nprev = n; }
+                            const double q0 = s * rinv;
+                            o = (float)__builtin_fma(__builtin_fma(-q0, nd, s), rinv, q0);
+                        }
+                        else o = (float)s;
+                    }
+                    if(qf_reps > 0 && nv(o)) {   // quantile_fast epilogue (neighbourhood.cpp:378-389 / 494-506): E-fold float sum / E, clamp
+                        float yv = o;
+                        if(qf_reps > 1) { float sum = 0; for(int e = 0; e < qf_reps; e++) sum += o; yv = sum / (float)qf_reps; }
+                        o = yv > 1 ? 1.0f : (yv < 0 ? 0.0f : yv);
+                    }
+                    po[j] = o;
+                }
+            }
+        }
+        ynext = max(ynext, ylim);
+    }
+    flush();
+}
 // separable min / max ignoring non-finite values (dir 0: along x, dir 1: along y)
 __global__ __launch_bounds__(256) void k_minmax_pass(const float* __restrict__ in, int Y, int X, int hw, int is_max, int dir, float* __restrict__ out, int ybase) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -852,6 +1044,24 @@ void qf_count_launch(const float* d_in, long C, int E, const float* d_thr, int T
 }
 // Mean / Sum / Count of `nplanes` [Y][X] planes
 void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statistic, float* d_out, int qf_reps = 0) {
+    if(hw <= BM_MAXHW && nplanes <= 65535 && !path_env("GPP_BOX_TWO_PASS")) {   // both passes in one kernel (k_box_march)
+        // about three workgroups per CU: strips x row segments x planes; a segment is a whole number of chunks (its first chunk is run-in: 2 hw rows)
+        const int strips = (X + BM_W - 1) / BM_W;
+        const long fill = path_env("GPP_BM_FILL") ? std::max(1, atoi(path_env("GPP_BM_FILL"))) : 768;   // (A/B: workgroups the launch aims for)
+        const long want = std::max<long>(1, fill / std::max<long>(1, (long)strips * nplanes));
+        const int segs = (int)std::min<long>(want, (Y + BM_C - 1) / BM_C);
+        int SH = ((Y + segs - 1) / segs + BM_C - 1) / BM_C * BM_C;
+        while((Y + SH - 1) / SH > 65535) SH += BM_C;
+        const dim3 grid(strips, (Y + SH - 1) / SH, nplanes);
+        switch(hw) {
+#define BM_CASE(n) case n: hipLaunchKernelGGL(k_box_march<n>, grid, dim3(256), bm_lds_bytes(n), stream(), d_in, Y, X, statistic, d_out, qf_reps, SH); break;
+            BM_CASE(0) BM_CASE(1) BM_CASE(2) BM_CASE(3) BM_CASE(4) BM_CASE(5) BM_CASE(6) BM_CASE(7) BM_CASE(8)
+            BM_CASE(9) BM_CASE(10) BM_CASE(11) BM_CASE(12) BM_CASE(13) BM_CASE(14) BM_CASE(15) BM_CASE(16)
+#undef BM_CASE
+        }
+        GPP_HIP(hipGetLastError());
+        return;
+    }
     long n = (long)Y * X * nplanes;
     double* rs = g_nb.rs.get(n);
     int* rc = g_nb.rc.get(n);

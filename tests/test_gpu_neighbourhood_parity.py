@@ -201,3 +201,48 @@ def test_device_resident_path(api):
     thr = np.linspace(0, 10, 11).astype(np.float32)
     out = gridpp.neighbourhood_quantile_fast(d, 0.5, 5, thr)
     np.testing.assert_array_equal(out.cpu().numpy(), gridpp.neighbourhood_quantile_fast(f, 0.5, 5, thr))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 3), (31, 64), (33, 65), (97, 130), (64, 200), (700, 70)])
+def test_fused_box_pass_against_the_two_pass_form(api, shape):
+    """k_box_march (both passes of the box statistics in one kernel, halfwidth <= 16) against the row pass + column pass it replaces
+    (GPP_BOX_TWO_PASS) and the oracle: every halfwidth it serves, fields smaller than a strip and with ragged last strips and chunks, chunks with and
+    without missing / infinite values (the counted and the closed-form windows), Mean / Sum / Count, and several planes at once
+    (Std, Variance: two planes).  The two forms add the same doubles in another order: equal to the last float32 bit except where a
+    sum sits on a rounding boundary, so they are compared at 1e-6 and each with the oracle at 1e-5; counts are exact."""
+    gridpp, O = api
+    Y, X = shape
+    rng = np.random.default_rng(Y * 1000 + X)
+    clean = rng.uniform(-5, 10, (Y, X)).astype(np.float32)
+    holes = clean.copy()
+    holes[rng.random((Y, X)) < 0.05] = np.nan
+    if Y > 8 and X > 8:
+        holes[2:6, 1:7] = np.nan
+        holes[Y // 2, X // 2] = np.inf
+    for f in (clean, holes):
+        for hw in list(range(0, 17)):
+            for stat in (gridpp.Mean, gridpp.Sum, gridpp.Count) + ((gridpp.Variance,) if hw in (3, 16) else ()):
+                fused = gridpp.neighbourhood(f, hw, stat)
+                gridpp.set_path_override("GPP_BOX_TWO_PASS", "1")
+                try:
+                    two = gridpp.neighbourhood(f, hw, stat)
+                finally:
+                    gridpp.set_path_override("GPP_BOX_TWO_PASS", None)
+                assert (np.isnan(fused) == np.isnan(two)).all()
+                m = ~np.isnan(two)
+                if stat == gridpp.Count:
+                    assert (fused[m] == two[m]).all()
+                    close(fused, O.neighbourhood(f, hw, stat), exact=True)
+                elif stat == gridpp.Variance:
+                    assert np.allclose(fused[m], two[m], rtol=0, atol=2e-5 * 100.0)   # (|f| <= 10: E[x^2] <= 100)
+                else:
+                    if m.any():
+                        assert (np.abs(fused[m].astype(np.float64) - two[m]) <= 1e-6 * np.maximum(np.abs(two[m]), 1e-3)).all(), (hw, stat)
+                    close(fused, O.neighbourhood(f, hw, stat))
+
+
+def test_fused_box_pass_three_dimensional_mean(api):
+    gridpp, O = api
+    f = field(7, 70, 90, E=6)
+    for hw in (2, 16):
+        close(gridpp.neighbourhood(f, hw, gridpp.Mean), O.neighbourhood(f, hw, gridpp.Mean))

@@ -44,28 +44,28 @@ with open(sys.argv[2], "w") as f:
         if any(t in kn for t in sys.argv[3].split("|")): f.write('"%s",%s,%s,%d,%.1f\n' % (kn[:90], gs, cn, n, v / n))
 PY
 }
-# PROFILE_ONLY=oi: the OI passes only (kernel iteration); PROFILE_ONLY=ensi: the EnSI passes only; default: everything
+# PROFILE_ONLY=oi: the OI passes only (kernel iteration); ensi: + the EnSI passes; noise: + the white-noise variant; nbh: the neighbourhood passes alone; default: everything
 
 OI="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
-stats oi $OI
+[ "$ONLY" != nbh ] && stats oi $OI
 [ "$ONLY" = all -o "$ONLY" = ensi ] && stats ensi python $REPO/tools/ensi_c5.py
-[ "$ONLY" = all ] && stats nbh python $REPO/tools/bench_paths.py nb
-pmc oi_pmc_fetch "k_oi" "FETCH_SIZE" $OI
-pmc oi_pmc_write "k_oi" "WRITE_SIZE" $OI
-pmc oi_pmc_sq "k_oi" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" $OI
-[ "$ONLY" = all ] && pmc nbh_pmc_fetch "k_member|k_qf|k_box" "FETCH_SIZE" python $REPO/tools/bench_paths.py nb
-[ "$ONLY" = all ] && pmc nbh_pmc_write "k_member|k_qf|k_box" "WRITE_SIZE" python $REPO/tools/bench_paths.py nb
-pmc oi_pmc_fp64 "k_oi" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" $OI
+[ "$ONLY" = all -o "$ONLY" = nbh ] && stats nbh python $REPO/tools/bench_paths.py nb
+[ "$ONLY" != nbh ] && pmc oi_pmc_fetch "k_oi" "FETCH_SIZE" $OI
+[ "$ONLY" != nbh ] && pmc oi_pmc_write "k_oi" "WRITE_SIZE" $OI
+[ "$ONLY" != nbh ] && pmc oi_pmc_sq "k_oi" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" $OI
+[ "$ONLY" = all -o "$ONLY" = nbh ] && pmc nbh_pmc_fetch "k_member|k_qf|k_box" "FETCH_SIZE" python $REPO/tools/bench_paths.py nb
+[ "$ONLY" = all -o "$ONLY" = nbh ] && pmc nbh_pmc_write "k_member|k_qf|k_box" "WRITE_SIZE" python $REPO/tools/bench_paths.py nb
+[ "$ONLY" != nbh ] && pmc oi_pmc_fp64 "k_oi" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" $OI
 # where the headline kernel's cycles go (round-3 verdict, item 3): busy / active / issue-stalled wave cycles, then what the waits are for
-pmc oi_pmc_busy "k_oi" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" $OI
-pmc oi_pmc_wait "k_oi" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" $OI
-pmc oi_pmc_act "k_oi" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" $OI
+[ "$ONLY" != nbh ] && pmc oi_pmc_busy "k_oi" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" $OI
+[ "$ONLY" != nbh ] && pmc oi_pmc_wait "k_oi" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" $OI
+[ "$ONLY" != nbh ] && pmc oi_pmc_act "k_oi" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" $OI
 [ "$ONLY" = all -o "$ONLY" = ensi ] && pmc ensi_pmc_sq "k_ensi" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F64" python $REPO/tools/ensi_c5.py
 [ "$ONLY" = all -o "$ONLY" = ensi ] && pmc ensi_pmc_fp64 "k_ensi" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" python $REPO/tools/ensi_c5.py
 [ "$ONLY" = all -o "$ONLY" = ensi ] && pmc ensi_pmc_busy "k_ensi" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $REPO/tools/ensi_c5.py
 [ "$ONLY" = all -o "$ONLY" = ensi ] && pmc ensi_pmc_mfma "k_ensi" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" python $REPO/tools/ensi_c5.py
-[ "$ONLY" = all ] && pmc nbh_pmc_sq "k_qf|k_member" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" python $REPO/tools/prof_nb.py
-[ "$ONLY" = all ] && pmc nbh_pmc_busy "k_qf|k_member" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $REPO/tools/prof_nb.py
+[ "$ONLY" = all -o "$ONLY" = nbh ] && pmc nbh_pmc_sq "k_qf|k_member" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" python $REPO/tools/prof_nb.py
+[ "$ONLY" = all -o "$ONLY" = nbh ] && pmc nbh_pmc_busy "k_qf|k_member" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $REPO/tools/prof_nb.py
 [ "$ONLY" = all ] && python $REPO/tools/oi_variants.py > $OUT/oi_variants.jsonl 2>/dev/null
 # round 5: the white-noise terrain variant of config 3 (k_oi scans and parks, k_oi_pairs solves): kernel times and what the two kernels execute
 if [ "$ONLY" = all -o "$ONLY" = noise ]; then
