@@ -615,6 +615,13 @@ __global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs,
 // written once; the two-kernel form writes and re-reads a plane of doubles and one of counts in between (config 4 Mean: 0.09 + 0.05 ms for the
 // two passes, this kernel: see DESIGN 11.5).  (A first version without the march -- tiles of 32 x 64 outputs, each loading its halo rows again --
 // took 0.22 ms: 60 KB of LDS per workgroup leave two of them on a CU, and a workgroup that loads, sums and stores once is mostly latency.)
+// a workgroup barrier that orders LDS accesses only (__syncthreads also waits for every global load and store of the wave: here that would be a
+// wait for the next chunk's values in the middle of the current chunk)
+__device__ __forceinline__ void bm_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 #define BM_W 64
 #define BM_C 32
 #define BM_RING 64
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(256) void k_box_cols(const double* __restrict__ rs,
 #define BM_RP (BM_W + 1)     // pitch of the ring rows (doubles)
 #define BM_P (BM_W + 2 * BM_MAXHW + 1)   // pitch of the chunk's rows (floats; odd, and wide enough for every thread's unconditional store)
 __host__ __device__ inline size_t bm_tin_bytes(int) { return (((size_t)BM_C * BM_P * sizeof(float)) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t bm_lds_bytes(int hw) { return bm_tin_bytes(hw) + (size_t)BM_RING * (BM_RP * sizeof(double) + BM_W + 1); }
+__host__ __device__ inline size_t bm_lds_bytes(int hw) { return bm_tin_bytes(hw) + (size_t)BM_RING * (BM_RP * sizeof(double) + BM_W + 1) + 2 * sizeof(int); }
 template <int HW>
 __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in, int Y, int X, int statistic, float* __restrict__ out, int qf_reps, int SH) {
     constexpr int hw = HW;   // (a template parameter: every window loop unrolls, its LDS reads are issued together and waited for once)
@@ -632,6 +639,7 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
     double* const ring = reinterpret_cast<double*>(bm_lds + bm_tin_bytes(hw));                 // [BM_RING][BM_RP]: row-window sums of the strip's columns
     unsigned char* const rcnt = reinterpret_cast<unsigned char*>(ring + (size_t)BM_RING * BM_RP);   // [BM_RING][BM_W]: valid values in those windows (rows of counted chunks only)
     unsigned char* const rflag = rcnt + BM_RING * BM_W;                                        // [BM_RING]: the ring row comes from a counted chunk
+    int* const bflag = reinterpret_cast<int*>(rflag + BM_RING);                                // [2]: chunk k (slot k % 2) holds a missing value
     const long plane = (long)blockIdx.z * Y * X;
     const int x0 = blockIdx.x * BM_W;
     const int ya = blockIdx.y * SH, yb = min(Y, ya + SH);          // this workgroup's output rows
@@ -642,6 +650,9 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
     const int clo = max(0, hw - x0), chi = min(Wt, X - x0 + hw);    // loaded columns [clo, chi) lie inside the field
     constexpr int NR = BM_C / 8, NCc = (BM_W + 2 * BM_MAXHW + 31) / 32;
     float v[NR][NCc];
+    int xo[NCc]; bool colok[NCc];                                   // this thread's columns: clamped field column, inside the field
+#pragma unroll
+    for(int j = 0; j < NCc; j++) { const int c = (tid & 31) + 32 * j; xo[j] = min(max(x0 - hw + c, 0), X - 1); colok[j] = c >= clo && c < chi; }
     auto fetch = [&](const int k) {   // thread: rows tid / 32 + 8 i, columns tid % 32 + 32 j of chunk k (every load is made, from a clamped address: no branch per value)
 #pragma unroll
         for(int i = 0; i < NR; i++) {
@@ -650,17 +661,18 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
             const float* const row = in + plane + (long)min(max(y, 0), Y - 1) * X;
 #pragma unroll
             for(int j = 0; j < NCc; j++) {
-                const int c = (tid & 31) + 32 * j;
 #if defined(BM_ABL) && (BM_ABL & 1)     // timing experiment: no loads
-                const float t = (float)(y + c);
+                const float t = (float)(y + j);
 #else
-                const float t = row[min(max(x0 - hw + c, 0), X - 1)];
+                const float t = row[xo[j]];
 #endif
-                v[i][j] = (rowok && c >= clo && c < chi) ? t : 0.0f;
+                v[i][j] = (rowok && colok[j]) ? t : 0.0f;
             }
         }
     };
     fetch(0);
+    if(tid < 2) bflag[tid] = 0;
+    bm_lds_barrier();
     int ynext = ya;                                                 // first output row not yet written
     // The outputs of a chunk wait in registers and are stored one chunk later, in front of the next fetch: stores and loads complete in the order
     // they were issued, so the wait for a chunk's values would otherwise be a wait for the stores issued behind its fetch as well (measured: 0.080 ms
@@ -698,7 +710,10 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
                 bad |= nv(v[i][j]) ? 0 : 1;                         // (outside the field: 0)
             }
         }
-        const bool counted = __syncthreads_or(bad) != 0;            // (also: the chunk is in LDS, and the previous chunk's outputs are finished)
+        if(bad) bflag[k & 1] = 1;
+        bm_lds_barrier();                                           // the chunk is in LDS, and the previous chunk's outputs are finished
+        const bool counted = bflag[k & 1] != 0;
+        if(tid == 0) bflag[(k + 1) & 1] = 0;                        // (read by everybody one chunk ago, before the barrier below; written again behind it)
         hist = (hist << 1) | (counted ? 1u : 0u);
         flush();                                                    // the previous chunk's outputs
         if(k + 1 < nchunk) fetch(k + 1);                            // in flight while this chunk is summed
@@ -736,7 +751,7 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
                 }
             }
         }
-        __syncthreads();                                            // the ring holds the rows up to ytop; the chunk's LDS rows are free again
+        bm_lds_barrier();                                           // the ring holds the rows up to ytop; the chunk's LDS rows are free again
         const int ytop = yl0 + (k + 1) * BM_C - 1;
         const int ylim = min(yb, ytop - hw + 1);                    // outputs [ynext, ylim) have their 2 hw + 1 rows in the ring (at most BM_C of them)
         {
@@ -762,6 +777,18 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
                 for(int q = 0; q <= 2 * HW; q++) sc[q & 3] += rv[q];
                 double s = (sc[0] + sc[1]) + (sc[2] + sc[3]);
                 if(slow) for(int q = -hw; q <= hw; q++) n += rown(y8 + q);
+                if(!slow && statistic == GPP_MEAN && qf_reps == 0 && ynext - hw >= 0 && ylim - 1 + hw <= Y - 1) {
+                    // the usual chunk: every window has its 2 hw + 1 rows inside the field and nothing is missing -- one count, one reciprocal
+                    // (s / n through the reciprocal and one correction by the exact residual: see below)
+                    const double nd = (double)(cx * (2 * HW + 1)), rinv = 1.0 / nd;
+#pragma unroll
+                    for(int j = 0; j < 8; j++) {
+                        if(j > 0) { s += rv[j + 2 * HW]; s -= rv[j - 1]; }
+                        const double q0 = s * rinv;
+                        po[j] = (float)__builtin_fma(__builtin_fma(-q0, nd, s), rinv, q0);   // (rows from ylim on: computed, not stored)
+                    }
+                }
+                else {
                 int nprev = -1;
                 double rinv = 0.0;
 #pragma unroll
@@ -792,6 +819,7 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
                         o = yv > 1 ? 1.0f : (yv < 0 ? 0.0f : yv);
                     }
                     po[j] = o;
+                }
                 }
             }
         }
