@@ -6,3 +6,6 @@ python tools/qf_soak.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05/r05_qf_soak.t
 python tools/neighbourhood_soak.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05/r05_neighbourhood_soak.txt
 PROFILE_ONLY=nbh bash tools/profile_r05.sh > /dev/null 2>&1
 for f in gpurun_out/r05/*.txt; do echo "== $f"; tail -n 2 $f; done
+python tools/slice_overhead_other.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05/r05_slice_overhead_other.txt
+python bench.py > gpurun_out/r05/r05_bench_n1_final.json 2> gpurun_out/r05/bench.err
+cut -c1-400 gpurun_out/r05/r05_bench_n1_final.json
