@@ -246,3 +246,39 @@ def test_fused_box_pass_three_dimensional_mean(api):
     f = field(7, 70, 90, E=6)
     for hw in (2, 16):
         close(gridpp.neighbourhood(f, hw, gridpp.Mean), O.neighbourhood(f, hw, gridpp.Mean))
+
+
+@pytest.mark.parametrize("shape", [(700, 70), (97, 130), (300, 40), (129, 64)])
+def test_fused_box_pass_marching_through_many_chunks(api, shape):
+    """The same kernel with ONE row segment per strip (GPP_BM_FILL=1: a workgroup marches through all rows, as it does on the 4000-row
+    fields of config 4 -- small fields are otherwise cut into segments of one chunk): the ring of row sums wraps every two chunks, chunks with
+    and without missing values follow each other (counts from the ring beside counts in closed form), the last chunk is ragged.  Against the
+    two-pass form and the oracle, as above."""
+    gridpp, O = api
+    Y, X = shape
+    rng = np.random.default_rng(Y * 7 + X)
+    f = rng.uniform(-5, 10, (Y, X)).astype(np.float32)
+    # missing values in some bands of rows only: chunks (32 rows) with and without them alternate
+    for y0 in range(10, Y, 75):
+        f[y0:y0 + 3, rng.integers(0, X, 5)] = np.nan
+    f[Y // 2, X // 3] = np.inf
+    f[Y - 1, 0] = np.nan
+    gridpp.set_path_override("GPP_BM_FILL", "1")
+    try:
+        for hw in (0, 1, 5, 8, 15, 16):
+            for stat in (gridpp.Mean, gridpp.Sum, gridpp.Count):
+                fused = gridpp.neighbourhood(f, hw, stat)
+                gridpp.set_path_override("GPP_BOX_TWO_PASS", "1")
+                try:
+                    two = gridpp.neighbourhood(f, hw, stat)
+                finally:
+                    gridpp.set_path_override("GPP_BOX_TWO_PASS", None)
+                assert (np.isnan(fused) == np.isnan(two)).all()
+                m = ~np.isnan(two)
+                if stat == gridpp.Count:
+                    assert (fused[m] == two[m]).all()
+                else:
+                    assert (np.abs(fused[m].astype(np.float64) - two[m]) <= 1e-6 * np.maximum(np.abs(two[m]), 1e-3)).all(), (hw, stat)
+                close(fused, O.neighbourhood(f, hw, stat), exact=(stat == gridpp.Count))
+    finally:
+        gridpp.set_path_override("GPP_BM_FILL", None)
