@@ -827,6 +827,131 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
     }
     flush();
 }
+// Min / Max for halfwidths up to BM_MAXHW in the same marching form (round 5): the row-window extrema of every new row go into a ring of floats,
+// the outputs are the extrema of 2 hw + 1 ring rows.  Values that do not count (missing, infinite, outside the field) enter as the identity of
+// the operation (+inf for Min, -inf for Max -- no valid value is infinite), a window that holds nothing else gives NaN (neighbourhood.cpp:144-196).
+// The eight windows of a segment share the values [7, 2 hw]: their extremum once, then the running extrema of the values below and above it.
+template <int HW, bool IS_MAX>
+__device__ __forceinline__ void bm_window_extrema(const float (&t)[8 + 2 * HW], float (&o)[8]) {
+    auto op = [](const float a, const float b) { return IS_MAX ? fmaxf(a, b) : fminf(a, b); };
+    if constexpr (2 * HW >= 7) {
+        float core = t[7];
+#pragma unroll
+        for(int q = 8; q <= 2 * HW; q++) core = op(core, t[q]);
+        float lo[8], hi[8];                       // lo[j]: extremum of t[j .. 6], hi[j]: of t[2 hw + 1 .. 2 hw + j]
+        lo[7] = core;
+#pragma unroll
+        for(int j = 6; j >= 0; j--) lo[j] = op(lo[j + 1], t[j]);
+        hi[0] = core;
+#pragma unroll
+        for(int j = 1; j < 8; j++) hi[j] = op(hi[j - 1], t[2 * HW + j]);
+#pragma unroll
+        for(int j = 0; j < 8; j++) o[j] = op(lo[j], hi[j]);
+    }
+    else {
+#pragma unroll
+        for(int j = 0; j < 8; j++) {
+            float m = t[j];
+#pragma unroll
+            for(int q = 1; q <= 2 * HW; q++) m = op(m, t[j + q]);
+            o[j] = m;
+        }
+    }
+}
+#define BM_FP (BM_W + 1)     // pitch of the float ring rows
+__host__ __device__ inline size_t bm_minmax_lds_bytes() { return bm_tin_bytes(0) + (size_t)BM_RING * BM_FP * sizeof(float); }
+template <int HW, bool IS_MAX>
+__global__ __launch_bounds__(256) void k_minmax_march(const float* __restrict__ in, int Y, int X, float* __restrict__ out, int SH) {
+    constexpr int hw = HW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bm_lds[];
+    constexpr int P = BM_P;
+    const float ident = IS_MAX ? -INFINITY : INFINITY;
+    float* const tin = reinterpret_cast<float*>(bm_lds);                               // [BM_C][P]: the rows of the chunk, `ident` where nothing counts
+    float* const ring = reinterpret_cast<float*>(bm_lds + bm_tin_bytes(0));            // [BM_RING][BM_FP]: row-window extrema of the strip's columns
+    const int x0 = blockIdx.x * BM_W;
+    const int ya = blockIdx.y * SH, yb = min(Y, ya + SH);
+    if(ya >= yb) return;
+    const int tid = threadIdx.x;
+    const int yl0 = ya - hw;
+    const int nchunk = (yb - 1 + hw - yl0) / BM_C + 1;
+    constexpr int Wt = BM_W + 2 * hw;
+    const int clo = max(0, hw - x0), chi = min(Wt, X - x0 + hw);
+    constexpr int NR = BM_C / 8, NCc = (BM_W + 2 * BM_MAXHW + 31) / 32;
+    float v[NR][NCc];
+    int xo[NCc]; bool colok[NCc];
+#pragma unroll
+    for(int j = 0; j < NCc; j++) { const int c = (tid & 31) + 32 * j; xo[j] = min(max(x0 - hw + c, 0), X - 1); colok[j] = c >= clo && c < chi; }
+    auto fetch = [&](const int k) {
+#pragma unroll
+        for(int i = 0; i < NR; i++) {
+            const int y = yl0 + k * BM_C + (tid >> 5) + 8 * i;
+            const bool rowok = y >= 0 && y < Y;
+            const float* const row = in + (long)min(max(y, 0), Y - 1) * X;
+#pragma unroll
+            for(int j = 0; j < NCc; j++) {
+                const float t = row[xo[j]];
+                v[i][j] = (rowok && colok[j] && nv(t)) ? t : ident;
+            }
+        }
+    };
+    fetch(0);
+    int ynext = ya;
+    float po[8];
+    int py8 = 0, pnrow = 0;
+    const int pc = tid & 63, px = x0 + pc;
+    auto flush = [&]() {
+        if(pnrow == 8) {
+            float* const o8 = out + (long)py8 * X + px;
+#pragma unroll
+            for(int j = 0; j < 8; j++) o8[(long)j * X] = po[j];
+        }
+        else {
+#pragma unroll
+            for(int j = 0; j < 8; j++) if(j < pnrow) out[(long)(py8 + j) * X + px] = po[j];
+        }
+        pnrow = 0;
+    };
+    for(int k = 0; k < nchunk; k++) {
+#pragma unroll
+        for(int i = 0; i < NR; i++)
+#pragma unroll
+            for(int j = 0; j < NCc; j++) tin[((tid >> 5) + 8 * i) * P + (tid & 31) + 32 * j] = v[i][j];
+        bm_lds_barrier();                                           // the chunk is in LDS, and the previous chunk's outputs are finished
+        flush();
+        if(k + 1 < nchunk) fetch(k + 1);
+        {
+            const int r = tid >> 3, sg = tid & 7;
+            const int slot = (k * BM_C + r) & (BM_RING - 1);
+            const float* const t = tin + r * P + 8 * sg;
+            float tv[8 + 2 * HW], o[8];
+#pragma unroll
+            for(int q = 0; q < 8 + 2 * HW; q++) tv[q] = t[q];
+            bm_window_extrema<HW, IS_MAX>(tv, o);
+            float* const rs = ring + slot * BM_FP + 8 * sg;
+#pragma unroll
+            for(int j = 0; j < 8; j++) rs[j] = o[j];
+        }
+        bm_lds_barrier();
+        const int ytop = yl0 + (k + 1) * BM_C - 1;
+        const int ylim = min(yb, ytop - hw + 1);
+        {
+            const int y8 = ynext + (tid >> 6) * 8;
+            if(px < X && y8 < ylim) {
+                py8 = y8; pnrow = min(8, ylim - y8);
+                const float* const rp = ring + pc;
+                const int stop = (y8 - hw - yl0) & (BM_RING - 1);
+                float rv[8 + 2 * HW], o[8];
+#pragma unroll
+                for(int q = 0; q < 8 + 2 * HW; q++) rv[q] = rp[((stop + q) & (BM_RING - 1)) * BM_FP];   // (rows behind ylim + hw: not used)
+                bm_window_extrema<HW, IS_MAX>(rv, o);
+#pragma unroll
+                for(int j = 0; j < 8; j++) po[j] = (o[j] == ident) ? NAN : o[j];
+            }
+        }
+        ynext = max(ynext, ylim);
+    }
+    flush();
+}
 // separable min / max ignoring non-finite values (dir 0: along x, dir 1: along y)
 __global__ __launch_bounds__(256) void k_minmax_pass(const float* __restrict__ in, int Y, int X, int hw, int is_max, int dir, float* __restrict__ out, int ybase) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -1127,6 +1252,24 @@ void brute(const float* d_in, int Y, int X, int E, int hw, int statistic, float 
 void neighbourhood2d(const float* d_in, int Y, int X, int hw, int statistic, float* d_out) {
     long C = (long)Y * X;
     if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT) box_stat(d_in, Y, X, 1, hw, statistic, d_out);
+    else if((statistic == GPP_MIN || statistic == GPP_MAX) && hw <= BM_MAXHW && !path_env("GPP_BOX_TWO_PASS")) {   // both passes in one kernel (k_minmax_march)
+        const int strips = (X + BM_W - 1) / BM_W;
+        const long fill = path_env("GPP_BM_FILL") ? std::max(1, atoi(path_env("GPP_BM_FILL"))) : 1280;
+        const long want = std::max<long>(1, fill / strips);
+        const int segs = (int)std::min<long>(want, (Y + BM_C - 1) / BM_C);
+        int SH = ((Y + segs - 1) / segs + BM_C - 1) / BM_C * BM_C;
+        while((Y + SH - 1) / SH > 65535) SH += BM_C;
+        const dim3 grid(strips, (Y + SH - 1) / SH);
+        const bool mx = statistic == GPP_MAX;
+        switch(hw) {
+#define BM_CASE(n) case n: if(mx) hipLaunchKernelGGL((k_minmax_march<n, true>), grid, dim3(256), bm_minmax_lds_bytes(), stream(), d_in, Y, X, d_out, SH); \
+                           else hipLaunchKernelGGL((k_minmax_march<n, false>), grid, dim3(256), bm_minmax_lds_bytes(), stream(), d_in, Y, X, d_out, SH); break;
+            BM_CASE(0) BM_CASE(1) BM_CASE(2) BM_CASE(3) BM_CASE(4) BM_CASE(5) BM_CASE(6) BM_CASE(7) BM_CASE(8)
+            BM_CASE(9) BM_CASE(10) BM_CASE(11) BM_CASE(12) BM_CASE(13) BM_CASE(14) BM_CASE(15) BM_CASE(16)
+#undef BM_CASE
+        }
+        GPP_HIP(hipGetLastError());
+    }
     else if(statistic == GPP_MIN || statistic == GPP_MAX) {
         float* t = g_nb.tmp.get(C);
         for(int dir = 1; dir >= 0; --dir)

@@ -221,7 +221,7 @@ def test_fused_box_pass_against_the_two_pass_form(api, shape):
         holes[Y // 2, X // 2] = np.inf
     for f in (clean, holes):
         for hw in list(range(0, 17)):
-            for stat in (gridpp.Mean, gridpp.Sum, gridpp.Count) + ((gridpp.Variance,) if hw in (3, 16) else ()):
+            for stat in (gridpp.Mean, gridpp.Sum, gridpp.Count, gridpp.Min, gridpp.Max) + ((gridpp.Variance,) if hw in (3, 16) else ()):
                 fused = gridpp.neighbourhood(f, hw, stat)
                 gridpp.set_path_override("GPP_BOX_TWO_PASS", "1")
                 try:
@@ -230,7 +230,7 @@ def test_fused_box_pass_against_the_two_pass_form(api, shape):
                     gridpp.set_path_override("GPP_BOX_TWO_PASS", None)
                 assert (np.isnan(fused) == np.isnan(two)).all()
                 m = ~np.isnan(two)
-                if stat == gridpp.Count:
+                if stat in (gridpp.Count, gridpp.Min, gridpp.Max):     # (k_minmax_march: extrema are exact in any order)
                     assert (fused[m] == two[m]).all()
                     close(fused, O.neighbourhood(f, hw, stat), exact=True)
                 elif stat == gridpp.Variance:
@@ -266,7 +266,7 @@ def test_fused_box_pass_marching_through_many_chunks(api, shape):
     gridpp.set_path_override("GPP_BM_FILL", "1")
     try:
         for hw in (0, 1, 5, 8, 15, 16):
-            for stat in (gridpp.Mean, gridpp.Sum, gridpp.Count):
+            for stat in (gridpp.Mean, gridpp.Sum, gridpp.Count, gridpp.Min, gridpp.Max):
                 fused = gridpp.neighbourhood(f, hw, stat)
                 gridpp.set_path_override("GPP_BOX_TWO_PASS", "1")
                 try:
@@ -275,10 +275,11 @@ def test_fused_box_pass_marching_through_many_chunks(api, shape):
                     gridpp.set_path_override("GPP_BOX_TWO_PASS", None)
                 assert (np.isnan(fused) == np.isnan(two)).all()
                 m = ~np.isnan(two)
-                if stat == gridpp.Count:
+                exact = stat in (gridpp.Count, gridpp.Min, gridpp.Max)
+                if exact:
                     assert (fused[m] == two[m]).all()
                 else:
                     assert (np.abs(fused[m].astype(np.float64) - two[m]) <= 1e-6 * np.maximum(np.abs(two[m]), 1e-3)).all(), (hw, stat)
-                close(fused, O.neighbourhood(f, hw, stat), exact=(stat == gridpp.Count))
+                close(fused, O.neighbourhood(f, hw, stat), exact=exact)
     finally:
         gridpp.set_path_override("GPP_BM_FILL", None)
