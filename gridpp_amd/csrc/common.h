@@ -116,14 +116,44 @@ static __global__ void k_stage_f64(const double* __restrict__ in, size_t n, floa
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(i < n) out[i] = (float)in[i];   // the rounding of the reference's PyArray_CastToType (swig/vector.i:42-55)
 }
+// Staging buffers of the host-side fields of a call (round 5): borrowed from a small pool (runtime.hip) instead of one hipMalloc + hipFree per field and
+// call -- for a 1000 x 1000 field those cost as much as the two copies over PCIe.  All work of the library goes to its one stream in call order, so a buffer
+// returned at the end of a call (even one that failed) is not written by the next borrower before its last reader has run.  Buffers of up to 256 MiB are
+// kept, 1 GiB in all (the largest go first); gpp_release_workspaces() and gpp_set_device() empty the pool.
+void* stage_borrow(size_t bytes, size_t* cap);
+void stage_return(void* p, size_t cap);
+void stage_release_all();
+template <class T>
+struct Staged {
+    T* p = nullptr;
+    size_t capb = 0;
+    Staged() = default;
+    Staged(const Staged&) = delete;
+    Staged& operator=(const Staged&) = delete;
+    ~Staged() { if(p) stage_return(p, capb); }
+    T* get(size_t n) {
+        const size_t bytes = (n ? n : 1) * sizeof(T);
+        if(bytes > capb) {
+            if(p) stage_return(p, capb);
+            p = nullptr; capb = 0;
+            p = static_cast<T*>(stage_borrow(bytes, &capb));
+        }
+        return p;
+    }
+    void upload(const T* h, size_t n) {
+        get(n);
+        if(n) GPP_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, stream()));
+    }
+};
+
 struct InField {
-    DevBuf<float> staged;
+    Staged<float> staged;
     const float* d = nullptr;
     void bind(const float* src, size_t n, int mem) {
         if(!src) { d = nullptr; return; }
         if(mem & GPP_MEM_DEVICE) d = src;
         else if(mem & GPP_HOST_F64) {   // the host array holds doubles: one upload + a cast on the device
-            DevBuf<double> wide;
+            Staged<double> wide;
             wide.upload(reinterpret_cast<const double*>(src), n);
             staged.get(n);
             if(n) hipLaunchKernelGGL(k_stage_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), wide.p, n, staged.p);
@@ -135,7 +165,7 @@ struct InField {
     }
 };
 struct OutField {
-    DevBuf<float> staged;
+    Staged<float> staged;
     float* d = nullptr;
     float* host = nullptr;
     size_t n = 0;

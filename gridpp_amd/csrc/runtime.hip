@@ -129,11 +129,64 @@ extern "C" int gpp_debug_poison_workspaces(int byte, int keep_padding) {
 }
 #endif
 
+// ---- the pool of staging buffers (common.h: Staged) -- touched under the API lock only ----------------------------------------------------
+namespace gpp {
+namespace {
+struct StageSlot { void* p; size_t cap; };
+std::vector<StageSlot> g_stage_free;
+size_t g_stage_bytes = 0;
+constexpr size_t STAGE_KEEP_ONE = (size_t)256 << 20, STAGE_KEEP_ALL = (size_t)1 << 30;
+}
+void* stage_borrow(size_t bytes, size_t* cap) {
+    int best = -1;
+    for(int i = 0; i < (int)g_stage_free.size(); i++)   // the smallest kept buffer that holds the request (and is not more than four times too large)
+        if(g_stage_free[i].cap >= bytes && g_stage_free[i].cap <= 4 * bytes + 4096 && (best < 0 || g_stage_free[i].cap < g_stage_free[best].cap)) best = i;
+    void* p = nullptr;
+    if(best >= 0) {
+        p = g_stage_free[best].p; *cap = g_stage_free[best].cap;
+        g_stage_bytes -= *cap;
+        g_stage_free.erase(g_stage_free.begin() + best);
+    }
+    else {
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        if(hipMalloc(&p, want) != hipSuccess) {   // out of memory with buffers lying idle in the pool: give them back and try again
+            (void)hipGetLastError();
+            stage_release_all();
+            GPP_HIP(hipMalloc(&p, want));
+        }
+        *cap = want;
+    }
+#ifdef GPP_POISON
+    GPP_HIP(hipMemsetAsync(p, 0xFF, *cap, stream()));   // (diagnostic build: whatever the last borrower left is as hostile as a fresh allocation's 0xFF)
+#endif
+    return p;
+}
+void stage_return(void* p, size_t cap) {
+    if(!p) return;
+    if(cap > STAGE_KEEP_ONE) { (void)hipFree(p); return; }
+    g_stage_free.push_back({p, cap});
+    g_stage_bytes += cap;
+    while(g_stage_bytes > STAGE_KEEP_ALL || g_stage_free.size() > 24) {   // the largest goes first
+        int big = 0;
+        for(int i = 1; i < (int)g_stage_free.size(); i++) if(g_stage_free[i].cap > g_stage_free[big].cap) big = i;
+        (void)hipFree(g_stage_free[big].p);
+        g_stage_bytes -= g_stage_free[big].cap;
+        g_stage_free.erase(g_stage_free.begin() + big);
+    }
+}
+void stage_release_all() {
+    for(auto& sl : g_stage_free) (void)hipFree(sl.p);
+    g_stage_free.clear();
+    g_stage_bytes = 0;
+}
+}   // namespace gpp
+
 // frees the thread's large call-to-call workspaces (they grow on demand and are otherwise kept for the next call)
 extern "C" int gpp_release_workspaces(void) {
     GPP_TRY
     gpp_oi_drain_pending();
     GPP_HIP(hipStreamSynchronize(stream()));
+    stage_release_all();
     gpp_release_ensi_workspace();
     gpp_release_oi_workspace();
     return GPP_OK;
@@ -160,6 +213,7 @@ extern "C" int gpp_set_device(int device) {
         // every handle, workspace and the stream live on the device that was current at the first call: moving to another one
         // afterwards would mix pointers of two devices
         if(g_stream && g_live_handles.load() > 0) invalid("gpp_set_device: the device cannot change while point sets / fields created on the current one are alive");
+        stage_release_all();   // (staging buffers of the device that is left)
         if(g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
         if(g_stream2) { (void)hipStreamDestroy(g_stream2); g_stream2 = nullptr; }
         if(g_stream3) { (void)hipStreamDestroy(g_stream3); g_stream3 = nullptr; }
