@@ -77,7 +77,8 @@ int gpp_device_count(int* count);
  * terminated); returns how many -- a benchmark must run with none.  No counterpart in the reference. */
 int gpp_set_path_override(const char* name, const char* value);
 int gpp_active_overrides(char* buf, int len);
-/* releases the calling thread's large call-to-call device workspaces (kept otherwise for the next call) */
+/* releases the library's large call-to-call device workspaces (kept otherwise for the next call) and the pool of staging buffers that the
+ * host-side fields of a call are copied through (buffers of up to 256 MiB, at most 1 GiB in all) */
 int gpp_release_workspaces(void);
 int gpp_set_device(int device);           /* one process per GPU: call once with LOCAL_RANK */
 int gpp_get_stream(void** hip_stream);    /* the hipStream_t all kernels are launched on */
