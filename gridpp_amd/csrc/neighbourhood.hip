@@ -858,23 +858,27 @@ __device__ __forceinline__ void bm_window_extrema(const float (&t)[8 + 2 * HW], 
         }
     }
 }
-#define BM_FP (BM_W + 1)     // pitch of the float ring rows
-__host__ __device__ inline size_t bm_minmax_lds_bytes() { return bm_tin_bytes(0) + (size_t)BM_RING * BM_FP * sizeof(float); }
+// Halfwidths 17 .. 32 run the same kernel over strips of 32 columns with a ring of 128 rows (the loaded row is 32 + 2 hw <= 96 values wide either way).
+#define BM_MM_MAXHW 32
+template <int HW> struct MinMaxGeom { static constexpr int W = HW <= BM_MAXHW ? BM_W : BM_W / 2, RING = HW <= BM_MAXHW ? BM_RING : 2 * BM_RING, FP = W + 1; };
+template <int HW> __host__ __device__ inline size_t bm_minmax_lds_bytes() { return bm_tin_bytes(0) + (size_t)MinMaxGeom<HW>::RING * MinMaxGeom<HW>::FP * sizeof(float); }
 template <int HW, bool IS_MAX>
 __global__ __launch_bounds__(256) void k_minmax_march(const float* __restrict__ in, int Y, int X, float* __restrict__ out, int SH) {
     constexpr int hw = HW;
+    constexpr int BM_W_ = MinMaxGeom<HW>::W, BM_RING_ = MinMaxGeom<HW>::RING, BM_FP = MinMaxGeom<HW>::FP;
+    static_assert(BM_W_ + 2 * HW <= BM_P - 1 && BM_C + 2 * HW <= BM_RING_, "the chunk's rows and the ring hold the windows");
     extern __shared__ __attribute__((aligned(16))) unsigned char bm_lds[];
     constexpr int P = BM_P;
     const float ident = IS_MAX ? -INFINITY : INFINITY;
     float* const tin = reinterpret_cast<float*>(bm_lds);                               // [BM_C][P]: the rows of the chunk, `ident` where nothing counts
     float* const ring = reinterpret_cast<float*>(bm_lds + bm_tin_bytes(0));            // [BM_RING][BM_FP]: row-window extrema of the strip's columns
-    const int x0 = blockIdx.x * BM_W;
+    const int x0 = blockIdx.x * BM_W_;
     const int ya = blockIdx.y * SH, yb = min(Y, ya + SH);
     if(ya >= yb) return;
     const int tid = threadIdx.x;
     const int yl0 = ya - hw;
     const int nchunk = (yb - 1 + hw - yl0) / BM_C + 1;
-    constexpr int Wt = BM_W + 2 * hw;
+    constexpr int Wt = BM_W_ + 2 * hw;
     const int clo = max(0, hw - x0), chi = min(Wt, X - x0 + hw);
     constexpr int NR = BM_C / 8, NCc = (BM_W + 2 * BM_MAXHW + 31) / 32;
     float v[NR][NCc];
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(256) void k_minmax_march(const float* __restrict__ 
     int ynext = ya;
     float po[8];
     int py8 = 0, pnrow = 0;
-    const int pc = tid & 63, px = x0 + pc;
+    const int pc = tid % BM_W_, px = x0 + pc;
     auto flush = [&]() {
         if(pnrow == 8) {
             float* const o8 = out + (long)py8 * X + px;
@@ -920,29 +924,31 @@ __global__ __launch_bounds__(256) void k_minmax_march(const float* __restrict__ 
         flush();
         if(k + 1 < nchunk) fetch(k + 1);
         {
-            const int r = tid >> 3, sg = tid & 7;
-            const int slot = (k * BM_C + r) & (BM_RING - 1);
-            const float* const t = tin + r * P + 8 * sg;
-            float tv[8 + 2 * HW], o[8];
+            const int r = tid / (BM_W_ / 8), sg = tid % (BM_W_ / 8);
+            if(r < BM_C) {
+                const int slot = (k * BM_C + r) & (BM_RING_ - 1);
+                const float* const t = tin + r * P + 8 * sg;
+                float tv[8 + 2 * HW], o[8];
 #pragma unroll
-            for(int q = 0; q < 8 + 2 * HW; q++) tv[q] = t[q];
-            bm_window_extrema<HW, IS_MAX>(tv, o);
-            float* const rs = ring + slot * BM_FP + 8 * sg;
+                for(int q = 0; q < 8 + 2 * HW; q++) tv[q] = t[q];
+                bm_window_extrema<HW, IS_MAX>(tv, o);
+                float* const rs = ring + slot * BM_FP + 8 * sg;
 #pragma unroll
-            for(int j = 0; j < 8; j++) rs[j] = o[j];
+                for(int j = 0; j < 8; j++) rs[j] = o[j];
+            }
         }
         bm_lds_barrier();
         const int ytop = yl0 + (k + 1) * BM_C - 1;
         const int ylim = min(yb, ytop - hw + 1);
         {
-            const int y8 = ynext + (tid >> 6) * 8;
+            const int y8 = ynext + (tid / BM_W_) * 8;
             if(px < X && y8 < ylim) {
                 py8 = y8; pnrow = min(8, ylim - y8);
                 const float* const rp = ring + pc;
-                const int stop = (y8 - hw - yl0) & (BM_RING - 1);
+                const int stop = (y8 - hw - yl0) & (BM_RING_ - 1);
                 float rv[8 + 2 * HW], o[8];
 #pragma unroll
-                for(int q = 0; q < 8 + 2 * HW; q++) rv[q] = rp[((stop + q) & (BM_RING - 1)) * BM_FP];   // (rows behind ylim + hw: not used)
+                for(int q = 0; q < 8 + 2 * HW; q++) rv[q] = rp[((stop + q) & (BM_RING_ - 1)) * BM_FP];   // (rows behind ylim + hw: not used)
                 bm_window_extrema<HW, IS_MAX>(rv, o);
 #pragma unroll
                 for(int j = 0; j < 8; j++) po[j] = (o[j] == ident) ? NAN : o[j];
@@ -1252,8 +1258,9 @@ void brute(const float* d_in, int Y, int X, int E, int hw, int statistic, float 
 void neighbourhood2d(const float* d_in, int Y, int X, int hw, int statistic, float* d_out) {
     long C = (long)Y * X;
     if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT) box_stat(d_in, Y, X, 1, hw, statistic, d_out);
-    else if((statistic == GPP_MIN || statistic == GPP_MAX) && hw <= BM_MAXHW && !path_env("GPP_BOX_TWO_PASS")) {   // both passes in one kernel (k_minmax_march)
-        const int strips = (X + BM_W - 1) / BM_W;
+    else if((statistic == GPP_MIN || statistic == GPP_MAX) && hw <= BM_MM_MAXHW && !path_env("GPP_BOX_TWO_PASS")) {   // both passes in one kernel (k_minmax_march)
+        const int W = hw <= BM_MAXHW ? BM_W : BM_W / 2;
+        const int strips = (X + W - 1) / W;
         const long fill = path_env("GPP_BM_FILL") ? std::max(1, atoi(path_env("GPP_BM_FILL"))) : 1280;
         const long want = std::max<long>(1, fill / strips);
         const int segs = (int)std::min<long>(want, (Y + BM_C - 1) / BM_C);
@@ -1262,10 +1269,12 @@ void neighbourhood2d(const float* d_in, int Y, int X, int hw, int statistic, flo
         const dim3 grid(strips, (Y + SH - 1) / SH);
         const bool mx = statistic == GPP_MAX;
         switch(hw) {
-#define BM_CASE(n) case n: if(mx) hipLaunchKernelGGL((k_minmax_march<n, true>), grid, dim3(256), bm_minmax_lds_bytes(), stream(), d_in, Y, X, d_out, SH); \
-                           else hipLaunchKernelGGL((k_minmax_march<n, false>), grid, dim3(256), bm_minmax_lds_bytes(), stream(), d_in, Y, X, d_out, SH); break;
+#define BM_CASE(n) case n: if(mx) hipLaunchKernelGGL((k_minmax_march<n, true>), grid, dim3(256), bm_minmax_lds_bytes<n>(), stream(), d_in, Y, X, d_out, SH); \
+                           else hipLaunchKernelGGL((k_minmax_march<n, false>), grid, dim3(256), bm_minmax_lds_bytes<n>(), stream(), d_in, Y, X, d_out, SH); break;
             BM_CASE(0) BM_CASE(1) BM_CASE(2) BM_CASE(3) BM_CASE(4) BM_CASE(5) BM_CASE(6) BM_CASE(7) BM_CASE(8)
             BM_CASE(9) BM_CASE(10) BM_CASE(11) BM_CASE(12) BM_CASE(13) BM_CASE(14) BM_CASE(15) BM_CASE(16)
+            BM_CASE(17) BM_CASE(18) BM_CASE(19) BM_CASE(20) BM_CASE(21) BM_CASE(22) BM_CASE(23) BM_CASE(24)
+            BM_CASE(25) BM_CASE(26) BM_CASE(27) BM_CASE(28) BM_CASE(29) BM_CASE(30) BM_CASE(31) BM_CASE(32)
 #undef BM_CASE
         }
         GPP_HIP(hipGetLastError());

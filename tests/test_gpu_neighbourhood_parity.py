@@ -220,8 +220,8 @@ def test_fused_box_pass_against_the_two_pass_form(api, shape):
         holes[2:6, 1:7] = np.nan
         holes[Y // 2, X // 2] = np.inf
     for f in (clean, holes):
-        for hw in list(range(0, 17)):
-            for stat in (gridpp.Mean, gridpp.Sum, gridpp.Count, gridpp.Min, gridpp.Max) + ((gridpp.Variance,) if hw in (3, 16) else ()):
+        for hw in list(range(0, 33)):     # (17 .. 32: Min / Max only -- k_minmax_march over strips of 32 columns; the box statistics keep their two passes there)
+            for stat in ((gridpp.Mean, gridpp.Sum, gridpp.Count) if hw <= 16 else ()) + (gridpp.Min, gridpp.Max) + ((gridpp.Variance,) if hw in (3, 16) else ()):
                 fused = gridpp.neighbourhood(f, hw, stat)
                 gridpp.set_path_override("GPP_BOX_TWO_PASS", "1")
                 try:
@@ -265,8 +265,8 @@ def test_fused_box_pass_marching_through_many_chunks(api, shape):
     f[Y - 1, 0] = np.nan
     gridpp.set_path_override("GPP_BM_FILL", "1")
     try:
-        for hw in (0, 1, 5, 8, 15, 16):
-            for stat in (gridpp.Mean, gridpp.Sum, gridpp.Count, gridpp.Min, gridpp.Max):
+        for hw in (0, 1, 5, 8, 15, 16, 17, 24, 32):
+            for stat in ((gridpp.Mean, gridpp.Sum, gridpp.Count) if hw <= 16 else ()) + (gridpp.Min, gridpp.Max):
                 fused = gridpp.neighbourhood(f, hw, stat)
                 gridpp.set_path_override("GPP_BOX_TWO_PASS", "1")
                 try:

@@ -1,6 +1,6 @@
 """Randomised soak of the marching neighbourhood kernels (k_box_march, k_minmax_march: halfwidth <= 16) against the two-pass kernels they replace
 (GPP_BOX_TWO_PASS, themselves held to the oracle by tests/ and tools/neighbourhood_soak.py): fields of up to 1500 x 1500 cells (2-D, device resident),
-every halfwidth 0 .. 16, Mean / Sum / Count / Min / Max, missing values scattered, in bands of rows, in blocks, infinite values, fields without a
+every halfwidth 0 .. 16 (Min / Max: 0 .. 32), Mean / Sum / Count / Min / Max, missing values scattered, in bands of rows, in blocks, infinite values, fields without a
 valid value; the launch geometry varied with GPP_BM_FILL (one row segment per strip .. segments of one chunk).  Count, Min and Max must agree bit
 for bit, Mean and Sum to 1e-6 (the same doubles added in another order).   python tools/march_soak.py [seconds]"""
 import os, sys, time
@@ -34,8 +34,8 @@ while time.time() - t0 < budget:
         f[...] = np.nan
     d = torch.from_numpy(f).cuda()
     fill = str(int(rng.choice([1, 64, 768, 4096])))
-    for hw in ([int(rng.integers(0, 17))] if big else [int(h) for h in rng.choice(17, 3, replace=False)]):
-        for stat in stats:
+    for hw in ([int(rng.integers(0, 33))] if big else [int(h) for h in rng.choice(33, 3, replace=False)]):
+        for stat in (stats if hw <= 16 else [gridpp.Min, gridpp.Max]):     # (17 .. 32: k_minmax_march over strips of 32 columns)
             gridpp.set_path_override("GPP_BM_FILL", fill)
             a = gridpp.neighbourhood(d, hw, stat).cpu().numpy()
             gridpp.set_path_override("GPP_BM_FILL", None)
