@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
     }
     flush();
 }
-// Min / Max for halfwidths up to BM_MAXHW in the same marching form (round 5): the row-window extrema of every new row go into a ring of floats,
+// Min / Max for halfwidths up to BM_MM_MAXHW in the same marching form (round 5): the row-window extrema of every new row go into a ring of floats,
 // the outputs are the extrema of 2 hw + 1 ring rows.  Values that do not count (missing, infinite, outside the field) enter as the identity of
 // the operation (+inf for Min, -inf for Max -- no valid value is infinite), a window that holds nothing else gives NaN (neighbourhood.cpp:144-196).
 // The eight windows of a segment share the values [7, 2 hw]: their extremum once, then the running extrema of the values below and above it.
