@@ -1698,10 +1698,17 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             ws.fb_list.get((size_t)a.ntiles); ws.fb_list2.get(2 * (size_t)a.ntiles + 64);
             ws.fb_list3.get(std::max<size_t>(4 * (size_t)a.ntiles, (size_t)SHORT_ITEMS) + 64);
             const dim3 block(64 * UnionCfg<32>::WPB);
+            const bool pair_tiles = path_env("GPP_OI_PAIR_TILES") != nullptr;   // (off: measured 3 % slower than one tile per wave -- the waiting wave of a pair)
+            a.pair_solo = path_env("GPP_OI_PAIR_SOLO") ? 1 : 0;
             auto launch_union = [&](const long items, const bool list) {   // one wave per work item
                 const long nb = (items + WPB - 1) / WPB;
                 const dim3 grid((unsigned)std::min<long>(nb, 0x7fffffffL));
                 if(N != 32) gpp_launch_union64(a, grid.x, plain, list, cur);
+                // (round 6: the first pass of the 32-column form shares one factorisation between the two tiles of a pair)
+                else if(!list && pair_tiles) {
+                    const dim3 pgrid((unsigned)std::min<long>(union_pair_count(a), 0x7fffffffL)), pblock(128);
+                    if(plain) hipLaunchKernelGGL(k_oi_union_pair<true>, pgrid, pblock, 0, cur, a); else hipLaunchKernelGGL(k_oi_union_pair<false>, pgrid, pblock, 0, cur, a);
+                }
                 // (the first pass is persistent: a grid that fills the chip, every wave strides over the tiles)
                 else if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true, 32>), grid, block, 0, cur, a); else hipLaunchKernelGGL((k_oi_union<true, false, 32>), UnionCfg<32>::persistent<true>() ? dim3(union_persist_grid<k_oi_union<true, false, 32>>(block.x, nb)) : grid, block, 0, cur, a); }
                 else { if(list) hipLaunchKernelGGL((k_oi_union<false, true, 32>), grid, block, 0, cur, a); else hipLaunchKernelGGL((k_oi_union<false, false, 32>), grid, block, 0, cur, a); }
@@ -1990,9 +1997,13 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     for(int k = 0; k < GPP_NSLOT; k++) { g_stats.cells_updated += (long long)counters[80 + 2 * k]; g_stats.solves += (long long)counters[81 + 2 * k]; }
     if(timing_env("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);
 #ifdef GPP_UNION_PROFILE
-    { const char* nm[12] = {"cell loads", "bbox+init", "phase-1 loads", "ring loop", "phase 2", "classify", "union records", "P build", "eliminate", "export", "per-lane", "-"};
-      double tot = 0; for(int i = 0; i < 12; i++) tot += (double)counters[20 + i];
-      fprintf(stderr, "[gpp] union phases (shader clocks per tile, %%):"); for(int i = 0; i < 11; i++) fprintf(stderr, " %s %.0f (%.1f%%);", nm[i], counters[20 + i] / (double)a.ntiles, 100.0 * counters[20 + i] / tot); fprintf(stderr, "\n"); }
+    { const char* nm[24] = {"cell loads", "bbox+init", "phase-1 loads", "rings", "phase 2", "classify", "union records", "P build", "eliminate", "export", "per-lane",
+                            "own classify", "B1 wait", "merge", "B2 wait", "B3 wait", "bisection", "bulk evaluations", "end_bulk", "-", "-", "-", "-", "-"};
+      const bool two = counters[20 + 24] != 0;
+      for(int w = 0; w < 2; w++) {
+          double tot = 0; for(int i = 0; i < 24; i++) tot += (double)counters[20 + 24 * w + i];
+          if(tot == 0) continue;
+          fprintf(stderr, "[gpp] union phases, wave %d (shader clocks per tile, %%):", w); for(int i = 0; i < 19; i++) fprintf(stderr, " %s %.0f (%.1f%%);", nm[i], counters[20 + 24 * w + i] / (double)a.ntiles * (two ? 2 : 1), 100.0 * counters[20 + 24 * w + i] / tot); fprintf(stderr, " total %.0f\n", tot / (double)a.ntiles * (two ? 2 : 1)); } }
 #endif
 #ifdef GPP_UNION_STATS
     fprintf(stderr, "[gpp] union: fallback reasons: slots %llu, union>40 %llu, extras>12 %llu, layout %llu, per-cell extras>6 %llu; per tile: insertions %.1f, evictions %.1f, candidates evaluated outside the bulk disc %.1f, records loaded in phase 2 %.1f\n",

@@ -48,6 +48,7 @@ struct OiArgs {
     int level;               // k_oi_union<., true>: 1 or 2 (see there)
     const int* parent_count; // level 2: length of the level-1 input list (how many tiles were split)
     int debug;               // GPP_OI_DEBUG: bit0 = skip the solve (timing experiments only)
+    int pair_solo;           // k_oi_union_pair: never merge (A/B: what the two-wave workgroups cost by themselves)
     // k_oi -> k_oi_big: cells with more usable observations than the 62-row register tile holds
     int* big_list;           // cell indices
     int* big_count;
@@ -89,7 +90,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int m) {
 #define UNION_STATS false
 #endif
 #ifdef GPP_UNION_PROFILE   // diagnostic build: per-phase shader-clock totals in counters[20..]
-#define UPROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[i] += t_ - tprev; tprev = t_; } while(0)
+#define UPROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if(lane == 0) L.prof[i] += (unsigned)(t_ - tprev); tprev = t_; } while(0)
 #else
 #define UPROF(i) do { } while(0)
 #endif
@@ -109,7 +110,8 @@ template <> struct UnionCfg<32> {
 #define GPP_UNION_PERSIST 0
 #endif
 #ifndef GPP_UNION_WPB
-#define GPP_UNION_WPB 4   // (tools/ab_bench.sh, round 4: 3 waves per workgroup -- four workgroups per CU, the same twelve waves, finer release -- 4.52 ms per step
+#define GPP_UNION_WPB 2   // (round 6, after `late` went over the observation records: two waves per workgroup, six workgroups per CU, 4.36 ms per step against 4.41 with
+                        //  four -- the LDS of a workgroup is released when its slower tile is done.  tools/ab_bench.sh, round 4: 3 waves per workgroup -- four workgroups per CU, the same twelve waves, finer release -- 4.52 ms per step
                         //  against 4.47; 6: 7.5 ms, one workgroup per CU)
 #endif
     static constexpr int WPB = GPP_UNION_WPB;       // waves (work items) per workgroup
@@ -137,11 +139,35 @@ struct UnionLds {
     };
     int wpos[U_WCAP];          // slot -> sorted position of the observation
     int worig[U_WCAP];         // slot -> observation index (tie-break); later: obs - background of the extras (float bits)
-    float4 orec[U_MAXU];       // solve: x, y, z, elevation of the observation of every matrix row
-    float olaf[U_MAXU];        //        its land area fraction
-    double late[8][9];         //        (P+R | d) entries of columns 32..39: rows 32..39 and the obs - background row
+#ifdef GPP_UNION_PROFILE
+    unsigned prof[24];
+#endif
+    union {
+        struct {
+            float4 orec[U_MAXU];   // solve, P build: x, y, z, elevation of the observation of every matrix row
+            float olaf[U_MAXU];    //                 its land area fraction
+        };
+        double late[8][9];         // solve, behind the P build (the records are dead then): (P+R | d) entries of columns 32..39: rows 32..39 and
+                                   // the obs - background row  (round 6: overlaid -- 576 B per wave; two waves + the pair block must stay under
+                                   // 21 LDS granules of 1 280 B for six workgroups of k_oi_union_pair per CU)
+    };
 };
 
+// k_oi_union_pair: what the two waves of a workgroup (two neighbouring tiles) tell each other.  See `PAIR` in union_item.
+struct PairLds {
+    int pos[2][UnionCfg<32>::WCAP];   // wave w, slot s: sorted position of the observation some cell of that tile still holds; -1: slot not live
+    unsigned long long core[2];       // slots selected by every updating cell of the wave's own tile
+    int state[2];                     // 0: the tile has cells to update and its scan fitted the slots; 1: nothing to update; 2: declined by the scan
+    int ok[2];                        // the merged union fits and no cell of this wave has more than U_MAXM extras
+    float dmax, dmin;                 // extremes of obs - background over the shared core (oi.cpp:318-334), from the eliminating wave
+};
+
+// doubles of the shared-factor area a union of c core and nE extras rows needs (layouts: see the solve)
+template <int NC>
+__device__ __forceinline__ int union_solve_doubles(const int c, const int nE) {
+    if constexpr(NC == 32) return c * (c + nE + 1) - c * (c - 1) / 2 + c + nE * nE + nE;   // packed columns, 1/diag, Schur complement, d'
+    else return c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE + 3;                  // (+ 3: the padding reads of the per-cell finish behind the last row of B)
+}
 __device__ __forceinline__ double rsqrt_nr(const double a) {
     double rs = __builtin_amdgcn_rsq(a);
     rs = rs * (1.5 - 0.5 * a * rs * rs);
@@ -156,12 +182,24 @@ __device__ __forceinline__ double rsqrt_nr(const double a) {
 // List entries: tile (produced by the first pass); tile * 32 + code with code 16..19 = 16-cell item, 0..15 = 4-cell item;
 // ~tile = whole tile forwarded unsplit because splitting would not pay (see `forward` below).
 // One work item (a tile, or a 16-cell / 4-cell part of one) on one wave.
-template <bool PLAIN, bool LIST, int NC>
-__device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, const int shift, UnionLds<NC>& L, const int lane) {
+//
+// PAIR (round 6, k_oi_union_pair: first pass, NC = 32): the two waves of a workgroup run two NEIGHBOURING tiles and share ONE factorisation.
+// Each wave scans its own tile as before; then both publish which observations their slots hold, both derive the same merged union (core = the
+// observations every updating cell of BOTH tiles selected, first; extras behind), and when that fits the limits of the shared factorisation
+// (95 % of the headline's pairs: profiles/r05_two_tile_unions.txt) wave 0 loads the records, builds P, eliminates and exports the factor into
+// ITS solve area while wave 1 only gathers its cells' G vectors; after a barrier the lanes of both waves finish their cells against that one
+// factor.  A pair that does not fit -- or whose partner is absent (odd tile count, a tile the first pass leaves to the list passes), has nothing
+// to update, or was declined by its scan -- goes on as two independent single-tile items, exactly the code below without PAIR.
+// Barriers (workgroup = the pair): B1 behind the scans (only when both waves run), B2 behind the merge (only when both states are 0), B3 behind
+// the export (only when paired); every condition is computed from values both waves read identically, so the counts always agree.
+template <bool PLAIN, bool LIST, int NC, bool PAIR = false>
+__device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, const int shift, UnionLds<NC>& L, const int lane,
+                                           const bool partner = false, const int pw = 0, const int lead = 0, UnionLds<NC>* const Lall = nullptr, PairLds* const PP = nullptr) {
     constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE;
+    static_assert(!PAIR || (NC == 32 && !LIST), "the pair form exists for the first pass of the 32-column kernel only");
     tile = __builtin_amdgcn_readfirstlane(tile); sub = __builtin_amdgcn_readfirstlane(sub);
 #ifdef GPP_UNION_PROFILE
-    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if(lane < 24) L.prof[lane] = 0u;   // (in LDS: sixteen accumulators in scalar registers spill the kernel into another one)
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
     int cell = -1;
@@ -348,6 +386,63 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             return rho;
         };
 
+        // PLAIN: EV candidates at once.  One candidate is a chain of ~35 dependent operations (chord, correctly rounded root and quotient, the
+        // table exp with its LDS lookup): evaluated one after the other a wave spends the scan waiting for its own results -- the per-phase
+        // clocks did not change when the other waves of the SIMD idled (round 6, the pair kernel's waiting wave).  Independent chains side by
+        // side fill those slots.  Same values as eval().
+#ifndef GPP_UNION_EV
+#define GPP_UNION_EV 2    // (measured: 4 side by side changes nothing -- 28.6 k clocks for the ~30 bulk candidates of a tile either way, profiles/r06_union_phases.txt:
+                          //  with three waves per SIMD the scan is bound by instruction issue, not by the chains -- and costs 24 registers)
+#endif
+        constexpr int EV = GPP_UNION_EV;
+        auto eval_n = [&](const float4& rec, const float2& met, const int (&cc)[EV], float (&rho)[EV]) {
+            float dist[EV];
+            bool ok[EV];
+            bool anynear = false;
+#pragma unroll
+            for(int q = 0; q < EV; ++q) {
+                const float ox = readlane_f(rec.x, cc[q]), oy = readlane_f(rec.y, cc[q]), oz = readlane_f(rec.z, cc[q]);
+                const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
+                float d2 = dx * dx + dy * dy;
+                d2 = d2 + dz * dz;
+                dist[q] = d_sqrt_cr(d2);
+                ok[q] = d2 <= thr2 && dist[q] <= R;
+                anynear = anynear || (ok[q] && dist[q] > near_r);
+            }
+            if(wave_ballot(anynear) != 0ull) {   // (see eval: the strictly-inside box of the radius query, only for candidates within ulps of R)
+#pragma unroll
+                for(int q = 0; q < EV; ++q) {
+                    const float ox = readlane_f(rec.x, cc[q]), oy = readlane_f(rec.y, cc[q]), oz = readlane_f(rec.z, cc[q]);
+                    ok[q] = ok[q] && ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;
+                }
+            }
+            // (the wave-uniform tests around whole groups of EV chains, not inside them: a branch ends the block the scheduler interleaves in)
+#pragma unroll
+            for(int q = 0; q < EV; ++q) rho[q] = 1.0f;
+            if(hh) {
+#pragma unroll
+                for(int q = 0; q < EV; ++q) rho[q] = d_barnes_rho_flat(dist[q], rh);
+            }
+            if(hv) {
+#pragma unroll
+                for(int q = 0; q < EV; ++q) {
+                    const float oe = readlane_f(rec.w, cc[q]);
+                    const float f = d_barnes_rho_flat(d_valid(oe) ? ge - oe : 0.0f, rv_);
+                    rho[q] = (d_valid(oe) && d_valid(ge)) ? rho[q] * f : rho[q];
+                }
+            }
+            if(hw) {
+#pragma unroll
+                for(int q = 0; q < EV; ++q) {
+                    const float ol = readlane_f(met.x, cc[q]);
+                    const float f = d_barnes_rho_flat(d_valid(ol) ? gl - ol : 0.0f, rw_);
+                    rho[q] = (d_valid(ol) && d_valid(gl)) ? rho[q] * f : rho[q];
+                }
+            }
+#pragma unroll
+            for(int q = 0; q < EV; ++q) rho[q] = ok[q] ? rho[q] : 0.0f;
+        };
+
         // the candidates `mask` of one chunk of 64 records (lane c holds record c: rec, met, sorted position posv)
         auto run_chunk = [&](const float4 rec, const float2 met, const int posv, unsigned long long mask) {
             while(mask != 0ull && !fb) {
@@ -501,6 +596,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                         }
                     }
                 }
+                UPROF(16);  // bisection
                 for(int ring = -1; ring < NR && !fb; ++ring) {   // ring -1: the bulk disc
                     const float hi = d_sqrt_raw(tlo) + (float)(ring + 1) * sa.ring_dr;
                     const float hi2 = ring < 0 ? tlo : ((ring == NR - 1) ? INFINITY : hi * hi);
@@ -510,7 +606,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                     const unsigned long long m0 = wave_ballot(pd0 > lo2 && pd0 <= hi2 && keep(pd0, rec0, met0, lim2, B2));
                     const unsigned long long m1 = wave_ballot(pd1 > lo2 && pd1 <= hi2 && keep(pd1, rec1, met1, lim2, B2));
                     const unsigned long long m2 = wave_ballot(pd2 > lo2 && pd2 <= hi2 && keep(pd2, rec2, met2, lim2, B2));
-                    if(ring >= 0 && bulk) end_bulk();
+                    if(ring >= 0 && bulk) { UPROF(17); end_bulk(); UPROF(18); }   // 17: bulk evaluations, 18: end_bulk
                     for(int k = 0; k < nchunk && !fb; ++k) {
                         const float4 rec = k == 0 ? rec0 : (k == 1 ? rec1 : rec2);
                         const float2 met = k == 0 ? met0 : (k == 1 ? met1 : met2);
@@ -523,6 +619,29 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                                 L.wpos[slot] = posv;
                                 L.worig[slot] = __float_as_int(met.y);
                             }
+                            if constexpr(PLAIN && EV > 1) {
+                                for(unsigned long long mm = mk; mm != 0ull;) {
+                                    int cc[EV], n = 0;
+#pragma unroll
+                                    for(int q = 0; q < EV; ++q) {
+                                        cc[q] = mm != 0ull ? __builtin_ctzll(mm) : cc[0];   // (a short last group evaluates its first candidate again)
+                                        n += mm != 0ull ? 1 : 0;
+                                        mm &= mm - 1ull;
+                                    }
+                                    float rho[EV];
+                                    eval_n(rec, met, cc, rho);
+#pragma unroll
+                                    for(int q = 0; q < EV; ++q) {
+                                        if(q < n) {
+                                            const bool ok = rho[q] > 0.0f;   // oi.cpp:253
+                                            L.rho[nb][lane] = ok ? rho[q] : INFINITY;
+                                            cnt += ok ? 1 : 0;
+                                            nb++;
+                                        }
+                                    }
+                                }
+                            }
+                            else
                             for(unsigned long long mm = mk; mm != 0ull; mm &= mm - 1ull) {
                                 const int c = __builtin_ctzll(mm);
                                 const float rho = eval(rec, met, c);
@@ -536,7 +655,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                     }
                     lo2 = hi2;
                 }
-                if(bulk) end_bulk();
+                if(bulk) { UPROF(17); end_bulk(); UPROF(18); }
             }
         }
 
@@ -625,9 +744,79 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             coreM |= isc << w;
             extM |= ise << w;
         }
+    }
+    // row i of the shared factorisation = lane i: the slot of THIS wave that holds its observation (-1: no cell of this tile selected it;
+    // pairs only) and the observation's sorted position
+    int myslot = 0, mypos = 0;
+    bool paired = false;
+    if constexpr(PAIR) {
+        if(partner) {
+            PairLds& P = *PP;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if(lane < U_WCAP) P.pos[pw][lane] = (((coreM | extM) >> lane) & 1ull) ? L.wpos[lane] : -1;
+            if(lane == 0) { P.core[pw] = coreM; P.state[pw] = fb ? 2 : (upd == 0ull ? 1 : 0); }
+            UPROF(11);  // (classification of the own slots, publishing)
+            __syncthreads();                                                                      // B1
+            UPROF(12);  // B1 wait
+            if(P.state[0] == 0 && P.state[1] == 0) {
+                // the same merge on both waves.  Lane s looks at slot s of wave 0 (A) and slot s of wave 1 (B).
+                const int pa = lane < U_WCAP ? P.pos[0][lane] : -1, pb = lane < U_WCAP ? P.pos[1][lane] : -1;
+                int partB = -1, partA = -1;   // the slot of B that holds the observation of A's slot `lane`, and the other way round
+#pragma unroll
+                for(int t = 0; t < U_WCAP; ++t) {
+                    const int qa = P.pos[0][t], qb = P.pos[1][t];
+                    partB = (qb == pa) ? t : partB;
+                    partA = (qa == pb) ? t : partA;
+                }
+                partB = pa >= 0 ? partB : -1;
+                partA = pb >= 0 ? partA : -1;
+                const unsigned long long coreA = P.core[0], coreB = P.core[1];
+                const unsigned long long liveA = wave_ballot(pa >= 0);
+                // core of the pair: selected by every updating cell of both tiles; extras: the other live slots of A, then what only B holds
+                const unsigned long long pcore = wave_ballot(pa >= 0 && ((coreA >> lane) & 1ull) != 0ull && partB >= 0 && ((coreB >> (partB & 63)) & 1ull) != 0ull);
+                const unsigned long long pextA = liveA & ~pcore;
+                const unsigned long long bonly = wave_ballot(pb >= 0 && partA < 0);
+                const int c2 = __popcll(pcore), nEa = __popcll(pextA), nE2 = nEa + __popcll(bonly), u2 = c2 + nE2;
+                const bool fits = u2 <= U_MAXU && nE2 <= U_MAXE && union_solve_doubles<NC>(c2, nE2) <= U_SOLVE;
+                int sA = -1, sB = -1;
+                {
+                    const unsigned long long mk = lane < c2 ? pcore : (lane < c2 + nEa ? pextA : bonly);
+                    const int idx = lane < c2 ? lane : (lane < c2 + nEa ? lane - c2 : lane - c2 - nEa);
+                    const int sl = nth_set_bit(mk, idx);
+                    if(lane < c2 + nEa) sA = sl; else if(lane < u2) sB = sl;
+                }
+                const int pbs = __shfl(partB, sA < 0 ? 0 : sA);
+                if(sA >= 0) sB = pbs;
+                const int posA = P.pos[0][sA < 0 ? 0 : sA], posB = P.pos[1][sB < 0 ? 0 : sB];
+                const int slot2 = pw == 0 ? sA : sB, pos2 = sA >= 0 ? posA : posB;
+                // this cell's extras among the rows c2 .. u2 - 1
+                int m2 = 0;
+                unsigned el2 = 0u;
+                if(fits) {
+#pragma unroll
+                    for(int ai = 0; ai < U_MAXE; ++ai) {
+                        if(ai < nE2) {
+                            const int sl = __builtin_amdgcn_readlane(slot2, c2 + ai);
+                            const bool sel = sl >= 0 && L.rho[sl < 0 ? 0 : sl][lane] < INFINITY;
+                            if(sel) { el2 |= (unsigned)ai << (4 * (m2 & 7)); m2++; }
+                        }
+                    }
+                }
+                const bool ok = fits && wave_ballot(m2 > U_MAXM) == 0ull;
+                if(lane == 0) P.ok[pw] = ok ? 1 : 0;
+                UPROF(13);  // merge
+                __syncthreads();                                                                  // B2
+                UPROF(14);  // B2 wait
+                paired = P.ok[0] != 0 && P.ok[1] != 0;
+                if(paired) { c = c2; nE = nE2; u = u2; m = m2; elist = el2; myslot = slot2; mypos = pos2; }
+            }
+        }
+    }
+    if(!paired && !fb && upd != 0ull) {
         c = __popcll(coreM); nE = __popcll(extM); u = c + nE;
-        // (+ 3: the padding reads of the per-cell finish behind the last row of B, see `brow` below)
-        if(u > U_MAXU || nE > U_MAXE || c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE + 3 > U_SOLVE) {
+        if(u > U_MAXU || nE > U_MAXE || union_solve_doubles<NC>(c, nE) > U_SOLVE) {
             fb = true;
             if(UNION_STATS && lane == 0) atomicAdd(&a.counters[u > U_MAXU ? 5 : (nE > U_MAXE ? 6 : 7)], 1ull);
         }
@@ -644,16 +833,20 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         if(lane == 0) a.out_list[atomicAdd(a.out_count, 1)] = !LIST ? tile : (tile * 32 + (a.level == 1 ? 16 + sub : sub));
         return;
     }
+    const bool solver = !PAIR || !paired || pw == lead;         // this wave builds and eliminates (wave-uniform)
+    UnionLds<NC>& LS = (PAIR && paired) ? Lall[lead] : L;      // where the shared factor lives
     UPROF(5);   // classification
     float res_out = bg, res_var = bvar;   // oi.cpp:198-199
     if(upd != 0ull && !GPP_DBG(a, 1)) {
         // ============= shared factorisation: rows 0..c-1 core, c..u-1 extras, lane 63 = obs - background ==========
-        const int myslot = lane < c ? nth_set_bit(coreM, lane) : (lane < u ? nth_set_bit(extM, lane - c) : 0);
+        if(!paired) {
+            myslot = lane < c ? nth_set_bit(coreM, lane) : (lane < u ? nth_set_bit(extM, lane - c) : 0);
+            mypos = L.wpos[myslot];
+        }
         float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
-        if(lane < u) {
-            const int pos = L.wpos[myslot];
-            o0 = sa.pgeo[pos];
-            o1 = a.saux[pos];
+        if(solver && lane < u) {
+            o0 = sa.pgeo[mypos];
+            o1 = a.saux[mypos];
         }
         const float dpf = (float)((double)o1.y - (double)o1.z);   // obs - background at the observation (oi.cpp:293)
         // this cell's rho for every row of the union (lG, oi.cpp:296); afterwards the rho slots are dead and the
@@ -662,36 +855,104 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         {
             constexpr int NLATE = U_MAXU > NC ? U_MAXU - NC : 1;
             float gx8[NLATE];   // rows NC.. are always extras (c <= NC): they only pass through
+            // (PAIR: a row no cell of this tile selected has no slot here; it is an extras row none of these cells lists)
+            auto rho_of_row = [&](const int k) {
+                const int sl = __builtin_amdgcn_readlane(myslot, k);
+                if constexpr(PAIR) return sl >= 0 ? L.rho[sl][lane] : 0.0f;
+                else return L.rho[sl][lane];
+            };
 #pragma unroll
-            for(int k = 0; k < NC; ++k) gf[k] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
+            for(int k = 0; k < NC; ++k) gf[k] = (k < u) ? rho_of_row(k) : 0.0f;
 #pragma unroll
-            for(int k = NC; k < U_MAXU; ++k) gx8[k - NC] = (k < u) ? L.rho[__builtin_amdgcn_readlane(myslot, k)][lane] : 0.0f;
+            for(int k = NC; k < U_MAXU; ++k) gx8[k - NC] = (k < u) ? rho_of_row(k) : 0.0f;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for(int k = 0; k < NC; ++k) if(k >= c && k < u) L.f.erho[k - c][lane] = gf[k];
 #pragma unroll
             for(int k = NC; k < U_MAXU; ++k) if(k < u) L.f.erho[k - c][lane] = gx8[k - NC];
         }
-        if(lane >= c && lane < u) L.worig[lane - c] = __float_as_int(dpf);
+        if(solver && lane >= c && lane < u) L.worig[lane - c] = __float_as_int(dpf);
         UPROF(6);   // observation records of the union
+        // layout of the shared-factor area (doubles).
+        // NC = 64 (rows packed): L_C rows, 1/diag, L_C^-1 d, B rows (stride bs), Schur complement, d'.
+        // NC = 32 (round 6, COLUMNS packed): column j < c of the factor of [core | extras | obs - background] as the elimination leaves it --
+        //   rows j .. u-1, then the entry of the obs - background row -- at CO(j) = j (u + 1) - j (j - 1) / 2; behind the columns 1/diag, the Schur
+        //   complement of the extras, d'.  The elimination writes every column ONCE, to its place (it has to go through LDS anyway, for the
+        //   broadcast of the rank-1 update), and the per-cell substitution walks the columns: no export pass, no dependent dot product per row.
+        // Built and measured in round 6 (GPP_UNION_COLS=1, with the two-column elimination steps and the column sweep of the per-cell finish below):
+        // 5.05 ms per headline step against 4.42 with the row form -- elimination 28.6 k instead of 21.9 k clocks per tile, per-cell finish 21.7 k
+        // instead of 14.3 k (profiles/r06_union_phases.txt).  Half as many serial steps bought nothing: the kernel is bound by the instructions it
+        // issues (VALU 78 % busy), and the column forms issue more of them (496 instead of 378 multiply-adds in the sweep, a per-lane LDS read per
+        // extra and column).  The row form stays the product.
+#ifndef GPP_UNION_COLS
+#define GPP_UNION_COLS 0
+#endif
+        constexpr bool COLS = NC == 32 && GPP_UNION_COLS != 0;
+        const int FAC = c * (u + 1) - c * (c - 1) / 2;
+        const int oL = 0, oI = COLS ? FAC : c * (c + 1) / 2, oZ = oI + c, oB = oZ + c, bs = c | 1, oS = COLS ? oI + c : oB + nE * bs, oD = oS + nE * nE;
+        double* const sv = LS.f.solve;
+        bool bad = false;
+        float maxInc = -INFINITY, minInc = INFINITY;
+        if(solver) {
         // lower triangle of P (oi.cpp:304-312), one entry per lane and pass: entry e = i (i + 1) / 2 + p, p <= i
         if(lane < u) { L.orec[lane] = o0; L.olaf[lane] = o1.x; }
         float* colbuf = reinterpret_cast<float*>(L.f.solve);   // [u][U_MAXU]
         const int ntri = u * (u + 1) / 2;
-        for(int e0 = 0; e0 < ntri; e0 += 64) {
-            const int e = e0 + lane;
-            int i = (int)((d_sqrt_raw(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);   // (the two tests below put an estimate one off right)
-            if(i * (i + 1) / 2 > e) i--;
-            if((i + 1) * (i + 2) / 2 <= e) i++;
-            const int pcol = e - i * (i + 1) / 2;
-            if(e < ntri) {
-                const float4 ri = L.orec[i], rp = L.orec[pcol];
-                const float cv = d_corr_t<PLAIN>(st, ri.x, ri.y, ri.z, ri.w, L.olaf[i], rp.x, rp.y, rp.z, rp.w, L.olaf[pcol], false);
-                colbuf[pcol * U_MAXU + i] = cv;
+        // (PLAIN: PB entries per lane and pass, their chains side by side -- chord, correctly rounded root and quotient, table exp: ~35 dependent
+        //  operations each; the nine passes of a 33-row union one after the other were a wave waiting for itself, see eval_n)
+#ifndef GPP_UNION_PB
+#define GPP_UNION_PB 1     // (measured: 3 entries side by side 7.1 k clocks per tile, one at a time 7.2 k -- the same, for eight more registers)
+#endif
+        constexpr int PB = PLAIN ? GPP_UNION_PB : 1;
+        const bool hh = d_valid(st.h) && st.h != 0.0f, hv = d_valid(st.v) && st.v != 0.0f, hw = d_valid(st.w) && st.w != 0.0f;
+        const double rh = hh ? 1.0 / (double)st.h : 0.0, rv_ = hv ? 1.0 / (double)st.v : 0.0, rw_ = hw ? 1.0 / (double)st.w : 0.0;
+        for(int e0 = 0; e0 < ntri; e0 += 64 * PB) {
+            int ti[PB], tp[PB];
+            float4 ri[PB], rp[PB];
+            float li[PB], lp[PB];
+#pragma unroll
+            for(int q = 0; q < PB; ++q) {
+                const int e = min(e0 + 64 * q + lane, ntri - 1);
+                int i = (int)((d_sqrt_raw(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);   // (the two tests below put an estimate one off right)
+                if(i * (i + 1) / 2 > e) i--;
+                if((i + 1) * (i + 2) / 2 <= e) i++;
+                ti[q] = i; tp[q] = e - i * (i + 1) / 2;
+                ri[q] = L.orec[ti[q]]; rp[q] = L.orec[tp[q]];
+                li[q] = L.olaf[ti[q]]; lp[q] = L.olaf[tp[q]];
             }
+            float cv[PB];
+            if constexpr(PLAIN) {
+                // d_barnes_corr_flat for PB pairs, the uniform tests around the groups of chains
+                float hd[PB];
+#pragma unroll
+                for(int q = 0; q < PB; ++q) { hd[q] = d_chord(ri[q].x, ri[q].y, ri[q].z, rp[q].x, rp[q].y, rp[q].z); cv[q] = 1.0f; }
+                if(hh) {
+#pragma unroll
+                    for(int q = 0; q < PB; ++q) cv[q] = d_barnes_rho_flat(hd[q], rh);
+                }
+                if(hv) {
+#pragma unroll
+                    for(int q = 0; q < PB; ++q) { const float f = d_barnes_rho_flat(ri[q].w - rp[q].w, rv_); cv[q] = (d_valid(ri[q].w) && d_valid(rp[q].w)) ? cv[q] * f : cv[q]; }
+                }
+                if(hw) {
+#pragma unroll
+                    for(int q = 0; q < PB; ++q) { const float f = d_barnes_rho_flat(li[q] - lp[q], rw_); cv[q] = (d_valid(li[q]) && d_valid(lp[q])) ? cv[q] * f : cv[q]; }
+                }
+#pragma unroll
+                for(int q = 0; q < PB; ++q) cv[q] = hd[q] > st.R ? 0.0f : cv[q];
+            }
+            else {
+#pragma unroll
+                for(int q = 0; q < PB; ++q) cv[q] = d_corr_t<PLAIN>(st, ri[q].x, ri[q].y, ri[q].z, ri[q].w, li[q], rp[q].x, rp[q].y, rp[q].z, rp[q].w, lp[q], false);
+            }
+#pragma unroll
+            for(int q = 0; q < PB; ++q) if(e0 + 64 * q + lane < ntri) colbuf[tp[q] * U_MAXU + ti[q]] = cv[q];
         }
         // obs - background of every row (oi.cpp:293) for the row of lane 63: through the (still free) column staging area
         double* const colL = L.f.solve + (U_SOLVE - 64);   // free until the export (the P staging and 1/diag live below it)
+        // (round 6: its address in a register of its own -- as "wave base + 7680 + 8 p" every pair of broadcast reads of the elimination costs an
+        //  address addition, 122 of the elimination's ~1 200 vector instructions -- makes the scheduler keep more reads in flight: 168 registers
+        //  and 20 bytes of scratch instead of 150 and none.  Left as it was.)
         if(lane < u) colL[lane] = (double)o1.y - (double)o1.z;                                             // lObs - lY
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -727,10 +988,82 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // layout of the shared-factor area (doubles)
-        const int oL = 0, oI = c * (c + 1) / 2, oZ = oI + c, oB = oZ + c, bs = c | 1, oS = oB + nE * bs, oD = oS + nE * nE;
-        double* const sv = L.f.solve;
-        bool bad = false;
+        if constexpr(COLS) {
+        // Right-looking Cholesky over the core columns, TWO columns per step.  The 2 x 2 pivot block [a b; b cc] gives both reciprocal roots side
+        // by side -- 1/sqrt(a) and 1/sqrt(a cc - b^2) are independent chains, 1/l22 = sqrt(a) / sqrt(a cc - b^2) -- where one column at a time
+        // waits for the first root, the broadcast of column j through LDS and the update of column j + 1 before the second can start: half
+        // as many serial steps (the per-phase clocks of this kernel do not change when the other waves of the SIMD idle: it waits for its
+        // own chains, profiles/r06_union_phases.txt).  The multiply-adds are the ones of the one-column form, in the same order.
+        // An odd core ends in a step whose second column is switched off (multiplier 0; its column of the matrix -- the first extras column --
+        // only takes the update of column j).
+        int co = 0;   // CO(j)
+#pragma unroll
+        for(int j = 0; j < NC; j += 2) {
+            if(j < c) {
+                const bool two = j + 1 < c;
+                const double pa = readlane_d(row[j], j), pb = readlane_d(row[j], j + 1), pc = readlane_d(row[j + 1], j + 1);
+                const double det = two ? __builtin_fma(pa, pc, -(pb * pb)) : 1.0;
+                if(!(pa > 0.0) || !(det > 0.0)) bad = true;
+                const double r1 = rsqrt_nr(pa), rd = rsqrt_nr(det);
+                const double l21 = pb * r1, i22 = two ? rd * (pa * r1) : 0.0;
+                const double c1 = row[j] * r1;
+                const double t2 = __builtin_fma(-c1, l21, row[j + 1]);
+                const double c2 = t2 * i22;
+                row[j] = c1;
+                row[j + 1] = two ? c2 : t2;
+                const int co1 = co + (u + 1 - j);   // CO(j + 1)
+                if(lane == 0) { sv[oI + j] = r1; if(two) sv[oI + j + 1] = i22; }
+                {   // the columns to their place: row r at CO + r - j, the obs - background row behind row u - 1
+                    const int r = lane == 63 ? u : lane;
+                    if((lane >= j && lane < u) || lane == 63) sv[co + r - j] = c1;
+                    if(two && ((lane > j && lane < u) || lane == 63)) sv[co1 + r - (j + 1)] = c2;
+                }
+                // rank-2 update of the register columns behind the pair: broadcast reads (rows >= u read what lies behind the column: their
+                // registers are never used; a switched-off second column reads the first one's entries again, times 0)
+                const double* const q1 = sv + co - j;
+                const double* const q2 = two ? sv + co1 - (j + 1) : q1;
+#pragma unroll
+                for(int p = j + 2; p < NC; ++p) {
+                    row[p] = __builtin_fma(-c1, q1[p], row[p]);
+                    row[p] = __builtin_fma(-c2, q2[p], row[p]);
+                }
+                co = co1 + (u - j);   // CO(j + 2)
+            }
+        }
+        UPROF(8);   // row load + elimination
+        // what is left in the register columns c .. of the extras rows and of the obs - background row: the Schur complement and d'
+        const int ea = lane - c;   // extras row index of this lane
+        {
+            const bool erow = lane >= c && lane < u;
+            const int bse = (erow ? oS + ea * nE : oD) - c;
+#pragma unroll
+            for(int p = 0; p < NC; ++p) {
+                if(p >= c && p < u) { if((erow && p <= lane) || lane == 63) sv[bse + p] = row[p]; }
+            }
+        }
+        if(u > 32 && !GPP_DBG(a, 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for(int b = 0; b < 8; ++b) {
+                const int p = 32 + b;
+                if(p < u) {
+                    const bool mine = (lane >= p && lane < u) || lane == 63;
+                    double acc = mine ? L.late[b][lidx] : 0.0;
+                    int ck = p;   // CO(k) + p - k: entry (row p, column k)
+#pragma unroll
+                    for(int k = 0; k < 32; ++k) {
+                        if(k < c) acc = __builtin_fma(-row[k], sv[ck], acc);
+                        ck += u - k;
+                    }
+                    if(lane >= p && lane < u) sv[oS + ea * nE + (p - c)] = acc;
+                    else if(lane == 63) sv[oD + (p - c)] = acc;
+                }
+            }
+        }
+        }
+        else {
         // right-looking Cholesky over the core columns; the trailing rows/columns end as B, the Schur complement, L_C^-1 d, d'
 #pragma unroll
         for(int j = 0; j < NC; ++j) {
@@ -790,14 +1123,110 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         // whatever the last workgroup on this CU left in LDS, and 0 x NaN = NaN (an all-ones sentinel key of k_oi's scan is such a pattern).
         // That was the intermittent failure of the max_points 33..62 soak (seed 5019: c = 61, one extra).
         if(lane < 3) sv[oD + nE + lane] = 0.0;
+        }
+        if(!a.allow_extrap) {   // oi.cpp:318-334: extremes of obs - background over the core (every cell selects it)
+            maxInc = wave_max(lane < c ? dpf : -INFINITY);
+            minInc = wave_min(lane < c ? dpf : INFINITY);
+        }
+        if constexpr(PAIR) {
+            if(paired) {
+                if(lane == 0) { PP->dmax = maxInc; PP->dmin = minInc; }
+                if(bad && lane == 0) atomicOr(a.err, ERR_SINGULAR);   // (both tiles have cells to update)
+                bad = false;
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }   // solver
+        if constexpr(PAIR) {
+            if(paired) {
+                UPROF(9);
+                __syncthreads();                                                                  // B3: the factor of wave 0 is complete
+                UPROF(15);  // B3 wait
+                if(!solver) { maxInc = PP->dmax; minInc = PP->dmin; }
+            }
+        }
 
         UPROF(9);   // export
         // ============= per cell (lane): forward substitution of G against L_C, then its own extras ==================
-        double z[NC];
         double inc = 0.0, a00 = 0.0;
+        const int mmax = __builtin_amdgcn_readfirstlane((int)wave_max((float)m));
+        if constexpr(COLS) {
+        // Column sweep: z_k = z_k / l_kk is final once the columns before k have been applied; column k then updates every later row at once --
+        // independent multiply-adds behind ONE dependent pair per column, where the row form had a dot product of k terms in front of every
+        // z_k.  The rows of this cell's own extras ride along (their entries of column k at per-lane addresses): they end as L_E-ready
+        // right-hand sides B z, which the row form computed afterwards as one more dot product per extra.
+        double z[NC];
+#pragma unroll
+        for(int k = 0; k < NC; ++k) z[k] = (double)gf[k];
+        double qx[U_MAXM];
+        const double* xp[U_MAXM];   // the entry of this cell's i-th extras row in the column walked (per lane; advanced with the column)
+#pragma unroll
+        for(int i = 0; i < U_MAXM; ++i) {
+            const int ai = (elist >> (4 * i)) & 15;
+            qx[i] = (i < mmax) ? (double)L.f.erho[ai][lane] : 0.0;
+            xp[i] = sv + c + ai;
+        }
+        {
+            int co = 0;
+#pragma unroll
+            for(int k = 0; k < NC; ++k) {
+                if(k < c && !GPP_DBG(a, 32)) {
+                    const double* const col = sv + co - k;      // col[r]: entry (row r, column k), col[u]: the obs - background row
+                    const double zk = z[k] * sv[oI + k];
+                    inc = __builtin_fma(zk, col[u], inc);
+                    a00 = __builtin_fma(zk, zk, a00);
+#pragma unroll
+                    for(int i = k + 1; i < NC; ++i) z[i] = __builtin_fma(-col[i], zk, z[i]);
+#pragma unroll
+                    for(int i = 0; i < U_MAXM; ++i) if(i < mmax) { qx[i] = __builtin_fma(-*xp[i], zk, qx[i]); xp[i] += u - k; }
+                    co += u + 1 - k;
+                }
+            }
+        }
+        if(mmax > 0 && !GPP_DBG(a, 64)) {
+            double ll[U_MAXM * (U_MAXM + 1) / 2], qv[U_MAXM], tv[U_MAXM], il[U_MAXM];
+#pragma unroll
+            for(int i = 0; i < U_MAXM; ++i) {
+                if(i < mmax) {
+                    const int ai = (elist >> (4 * i)) & 15;
+                    const bool valid = i < m;
+                    double gq = qx[i];
+                    double dq = sv[oD + ai];
+                    double sii = sv[oS + ai * nE + ai];
+#pragma unroll
+                    for(int jj = 0; jj < i; ++jj) {
+                        const int aj = (elist >> (4 * jj)) & 15;
+                        double sij = sv[oS + ai * nE + aj];
+#pragma unroll
+                        for(int k = 0; k < jj; ++k) sij = __builtin_fma(-ll[i * (i + 1) / 2 + k], ll[jj * (jj + 1) / 2 + k], sij);
+                        const double lij = sij * il[jj];
+                        ll[i * (i + 1) / 2 + jj] = lij;
+                        sii = __builtin_fma(-lij, lij, sii);
+                        gq = __builtin_fma(-lij, qv[jj], gq);
+                        dq = __builtin_fma(-lij, tv[jj], dq);
+                    }
+                    if(valid && !(sii > 0.0)) bad = true;
+                    const double rs = rsqrt_nr(valid ? sii : 1.0);
+                    il[i] = rs;
+                    qv[i] = gq * rs;
+                    tv[i] = dq * rs;
+                    if(valid) {
+                        inc = __builtin_fma(qv[i], tv[i], inc);
+                        a00 = __builtin_fma(qv[i], qv[i], a00);
+                        if(!a.allow_extrap) {
+                            const float de = __int_as_float(LS.worig[ai]);
+                            maxInc = fmaxf(maxInc, de); minInc = fminf(minInc, de);
+                        }
+                    }
+                }
+            }
+        }
+        }
+        else {
+        // ============= per cell (lane): forward substitution of G against L_C, then its own extras ==================
+        double z[NC];
 #pragma unroll
         for(int k = 0; k < NC; ++k) {
             double zk = 0.0;
@@ -816,12 +1245,6 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             }
             z[k] = zk;
         }
-        float maxInc = -INFINITY, minInc = INFINITY;
-        if(!a.allow_extrap) {   // oi.cpp:318-334: extremes of obs - background over this cell's selection
-            maxInc = wave_max(lane < c ? dpf : -INFINITY);
-            minInc = wave_min(lane < c ? dpf : INFINITY);
-        }
-        const int mmax = __builtin_amdgcn_readfirstlane((int)wave_max((float)m));
         if(mmax > 0 && !GPP_DBG(a, 64)) {
             double ll[U_MAXM * (U_MAXM + 1) / 2], qv[U_MAXM], tv[U_MAXM], il[U_MAXM];
 #pragma unroll
@@ -865,12 +1288,13 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                         inc = __builtin_fma(qv[i], tv[i], inc);
                         a00 = __builtin_fma(qv[i], qv[i], a00);
                         if(!a.allow_extrap) {
-                            const float de = __int_as_float(L.worig[ai]);
+                            const float de = __int_as_float(LS.worig[ai]);
                             maxInc = fmaxf(maxInc, de); minInc = fminf(minInc, de);
                         }
                     }
                 }
             }
+        }
         }
         UPROF(10);  // per-lane finish
         if(cnt > 0) {
@@ -888,11 +1312,11 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         if(lane == 0 && a.counters) {
             unsigned long long* cs = a.counters + 80 + 2 * (blockIdx.x % GPP_NSLOT);
             atomicAdd(&cs[0], (unsigned long long)__popcll(upd));
-            atomicAdd(&cs[1], 1ull);
+            if(solver) atomicAdd(&cs[1], 1ull);
         }
     }
 #ifdef GPP_UNION_PROFILE
-    if(lane == 0) for(int i = 0; i < 12; ++i) atomicAdd(&a.counters[20 + i], prof[i]);
+    if(lane < 24) atomicAdd(&a.counters[20 + 24 * pw + lane], (unsigned long long)L.prof[lane]);   // (pairs: the phases of wave 1 apart)
 #endif
     if(cell >= 0) {
         a.out[cell] = res_out;
@@ -975,6 +1399,33 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
     }
 }
 
+// First pass with ONE factorisation per PAIR of neighbouring tiles (round 6; see PAIR in union_item): a workgroup is the two waves of a pair.
+// Grid: tiles (2 px, 2 px + 1) of one tile row -- 8 x 16 cells on an isotropic grid; a row with an odd number of tiles ends in a single.
+// Points (no 2-D tiling): chunks 2 p and 2 p + 1 of 64 consecutive points.  A wave whose tile does not exist or is left to the list passes
+// (skip_flags) ends at once; its partner then runs as a single-tile item and meets no barrier.
+inline long union_pair_count(const OiArgs& a) { return a.tiled2d ? (long)((a.tiles_x + 1) / 2) * (a.ntiles / a.tiles_x) : ((long)a.ntiles + 1) / 2; }
+template <bool PLAIN>
+__global__ __launch_bounds__(128, PLAIN ? 3 : 2) void k_oi_union_pair(OiArgs a) {
+    __shared__ UnionLds<32> s_u[2];
+    __shared__ PairLds s_p;
+    if constexpr(PLAIN) { d_exptab_fill<128>(); __syncthreads(); }
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int t0, n;      // first tile of the pair, tiles it has (1 or 2)
+    if(a.tiled2d) {
+        const int px2 = (a.tiles_x + 1) >> 1;
+        const int ty = (int)blockIdx.x / px2, px = (int)blockIdx.x - ty * px2;
+        t0 = ty * a.tiles_x + 2 * px; n = 2 * px + 1 < a.tiles_x ? 2 : 1;
+    }
+    else { t0 = 2 * (int)blockIdx.x; n = t0 + 1 < a.ntiles ? 2 : 1; }
+    const bool run0 = !(a.skip_flags && a.skip_flags[t0]);
+    const bool run1 = n == 2 && !(a.skip_flags && a.skip_flags[t0 + 1]);
+    if(!(wid == 0 ? run0 : run1)) return;
+    // Which wave eliminates: the hardware places wave 0 of every workgroup on one pair of SIMDs and wave 1 on the other, so with a fixed role two
+    // SIMDs of a CU would do all the factorisations while the other two wait (measured: no gain at all from the halved number of
+    // factorisations).  A bit of the workgroup index that changes between the workgroups resident on a CU spreads the role.
+    const int lead = (int)(__builtin_popcount(blockIdx.x * 2654435761u) & 1);
+    union_item<PLAIN, false, 32, true>(a, t0 + wid, -1, 0, s_u[wid], lane, run0 && run1 && !a.pair_solo, wid, lead, s_u, &s_p);
+}
 
 // grid of the persistent first pass: as many workgroups as the chip holds of this kernel at once (asked once per kernel), at most one per WPB tiles
 template <void (*K)(OiArgs)>

@@ -23,6 +23,37 @@ def test_random_configurations(seed):
     _random_configuration(seed, [1, 2, 7, 20, 30, 32])
 
 
+@pytest.mark.parametrize("seed", range(500, 512))
+def test_random_configurations_one_factorisation_per_pair_of_tiles(seed, monkeypatch):
+    """k_oi_union_pair (round 6, behind GPP_OI_PAIR_TILES: measured slower than one tile per wave): the two waves of a workgroup merge the unions
+    of two neighbouring tiles and share one factorisation; pairs that do not fit, odd tile counts, tiles without cells to update and
+    tiles the scan declines all go on as single tiles."""
+    monkeypatch.setenv("GPP_OI_PAIR_TILES", "1")
+    _random_configuration(seed, [1, 2, 7, 20, 30, 32])
+
+
+def test_pair_of_tiles_halves_the_factorisations_on_a_regular_case(monkeypatch):
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    Y, X, S = 96, 128, 60     # (observations much sparser than tiles, as on the headline: neighbouring tiles select the same ones)
+    lats, lons = np.meshgrid(np.linspace(60, 60.6, Y), np.linspace(10, 11.6, X), indexing="ij")
+    plat, plon = 60 + 0.6 * rng.random(S), 10 + 1.6 * rng.random(S)
+    bg = rng.normal(0, 1, (Y, X)).astype(np.float32)
+    obs, pbg = rng.normal(0, 1, S).astype(np.float32), rng.normal(0, 1, S).astype(np.float32)
+    ratios = rng.uniform(0.1, 1, S).astype(np.float32)
+    grid, points, st = gridpp.Grid(lats, lons), gridpp.Points(plat, plon), gridpp.BarnesStructure(10000)
+    single = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 10)
+    n_single = gridpp.oi_last_stats()["solves"]
+    monkeypatch.setenv("GPP_OI_PAIR_TILES", "1")
+    paired = gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 10)
+    n_pair = gridpp.oi_last_stats()["solves"]
+    assert n_pair < 0.7 * n_single, (n_pair, n_single)
+    ref = O.oi(O.Pts(lats.ravel(), lons.ravel()), bg.ravel(), O.Pts(plat, plon), obs, ratios, pbg, O.Barnes(10000), 10).reshape(Y, X)
+    _check(paired, ref)
+    _check(single, ref)
+
+
 @pytest.mark.parametrize("seed", range(100, 112))
 def test_random_configurations_62_row_tile(seed):
     """max_points 33..62: the 64-column form of k_oi_union (two waves per workgroup) and k_oi<62> behind its work lists."""
