@@ -741,12 +741,17 @@ def _oi_common(bg, background, bvariance, points, pobs, obs_variance, pbackgroun
         if mem != _capi.MEM_DEVICE:
             raise ValueError("optimal_interpolation_async takes device-resident fields (torch tensors on the GPU)")
         mem |= _capi.ASYNC
-    check(lib().gpp_optimal_interpolation_full(bg._h, _ptr(background), _ptr(bvariance), points._h, _ptr(pobs),
-                                               _ptr(obs_variance), _ptr(pbackground), _ptr(bvariance_at_points),
-                                               _structure(structure), int(max_points), int(bool(allow_extrapolation)),
-                                               _ptr(out), _ptr(var), mem))
+    rc = lib().gpp_optimal_interpolation_full(bg._h, _ptr(background), _ptr(bvariance), points._h, _ptr(pobs),
+                                              _ptr(obs_variance), _ptr(pbackground), _ptr(bvariance_at_points),
+                                              _structure(structure), int(max_points), int(bool(allow_extrapolation)),
+                                              _ptr(out), _ptr(var), mem)
     if deferred:   # (the inputs, the handles and the structure stay referenced until the wait)
-        return PendingAnalysis(out, var, (bg, background, bvariance, points, pobs, obs_variance, pbackground, bvariance_at_points, structure))
+        # The library queues EVERY GPP_ASYNC call, also one that failed at submission (as a completed call that reports its error again): the
+        # mirror keeps its queue aligned with that one -- the entry of a failed submission is simply dropped when it reaches the front.
+        pending = PendingAnalysis(out, var, (bg, background, bvariance, points, pobs, obs_variance, pbackground, bvariance_at_points, structure))
+        check(rc)
+        return pending
+    check(rc)
     return out, var
 
 
@@ -1191,15 +1196,22 @@ def neighbourhood_quantile_fast(input, quantile, halfwidth, thresholds):
         if _shape(q) not in ((1, 1), (ny, nx)):
             raise ValueError("Quantile must be the same size as input, or size (1, 1)")
     thr = _vec(thresholds, 1, "thresholds")
+    nq = int(np.prod(_shape(q)))
+    q_host = False
     if mem == _capi.MEM_DEVICE:
         import torch
-        q = q if _is_dev(q) else torch.from_numpy(np.asarray(q)).to(arr.device)
+        if not _is_dev(q) and nq == 1:
+            q_host = True        # (a scalar beside a device-resident field stays on the host: GPP_Q_HOST)
+            q = np.ascontiguousarray(q, np.float32)
+        else:
+            q = q if _is_dev(q) else torch.from_numpy(np.asarray(q)).to(arr.device)
         thr = thr if _is_dev(thr) else torch.from_numpy(np.asarray(thr)).to(arr.device)
     _sync_if_dev(mem)
-    nq = int(np.prod(_shape(q)))
     out = _empty_like_field((ny, nx), arr)
     if not _is_dev(arr) and arr.dtype == np.float64:
         mem |= _capi.HOST_F64
+    if q_host:
+        mem |= _capi.Q_HOST
     check(lib().gpp_neighbourhood_quantile_fast(_ptr(arr), ny, nx, ne, is3d, _ptr(q), nq, int(halfwidth), _ptr(thr),
                                                 int(_shape(thr)[0]), _ptr(out), mem))
     return out

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPP_LIB") or os.path.join(_HERE, "lib", "libgridpp_hip.so")   # GPP_LIB: A/B timing of two builds
 
 GPP_OK, GPP_EINVAL, GPP_ERUNTIME, GPP_ENODEVICE = 0, -1, -2, -3
-MEM_HOST, MEM_DEVICE, ASYNC, HOST_F64 = 0, 1, 2, 4
+MEM_HOST, MEM_DEVICE, ASYNC, HOST_F64, Q_HOST = 0, 1, 2, 4, 8
 
 
 class gpp_structure(C.Structure):

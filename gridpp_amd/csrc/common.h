@@ -70,6 +70,7 @@ hipStream_t stream3();  // and a third (status copies of deferred calls)
 hipStream_t stream2();  // a second one: work that runs BESIDE the library stream inside one call (ordered against it with events)
 void ensure_device();   // throws GPP_ENODEVICE when no GPU is visible
 
+void stage_release_all();   // (runtime.hip: the pool of staging buffers, see Staged below)
 template <class T>
 struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
     T* p = nullptr;
@@ -85,7 +86,12 @@ struct DevBuf {   // owning HBM buffer, grows on demand, never shrinks
             p = nullptr;
             cap = 0;   // (a failed hipMalloc below must not leave a capacity behind a null pointer)
             if(old) GPP_HIP(hipFree(old));
-            GPP_HIP(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
+            if(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)) != hipSuccess) {   // out of memory while the staging pool holds idle buffers (up to 1 GiB): give them back, once
+                (void)hipGetLastError();
+                p = nullptr;
+                stage_release_all();
+                GPP_HIP(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
+            }
             cap = n;
             gen++;
 #ifdef GPP_POISON

@@ -284,18 +284,10 @@ __global__ __launch_bounds__(256) void k_ensi_multi(MultiArgs ma) {
         __syncthreads();
         // cyclic Jacobi on the nV x nV matrix (as k_ensi_big)
         const int mm = nV + (nV & 1), half = mm >> 1;
-        double tr = 0.0;
-        if(tid < nV) tr = fabs(s_B[tid * EP + tid]);
-        s_off[tid] = tr;
-        __syncthreads();
-        for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
-        tr = s_off[0];
-        (void)tr;
-        __syncthreads();
         for(int sweep = 0; sweep < 40 && nV > 1; ++sweep) {
             double off2 = 0.0;
             // (scaled measure, see k_ensi_huge in ensi.hip)
-            for(int e2 = tid; e2 < nV * nV; e2 += 256) { const int i = e2 / nV, j = e2 - i * nV; if(j < i) { const double vv = s_B[i * EP + j]; off2 += vv * vv / fabs(s_B[i * EP + i] * s_B[j * EP + j]); } }
+            for(int e2 = tid; e2 < nV * nV; e2 += 256) { const int i = e2 / nV, j = e2 - i * nV; if(j < i) { const double vv = s_B[i * EP + j]; off2 += vv * vv / fmax(fabs(s_B[i * EP + i] * s_B[j * EP + j]), 1e-300); } }
             s_off[tid] = off2;
             __syncthreads();
             for(int off = 128; off > 0; off >>= 1) { if(tid < off) s_off[tid] += s_off[tid + off]; __syncthreads(); }
@@ -646,17 +638,14 @@ __global__ __launch_bounds__(256) void k_ensi_multi_huge(MultiArgs ma, const int
         __threadfence_block();
         __syncthreads();
         const int mm = nV + (nV & 1), half = mm >> 1;
-        double trl = 0.0;
-        for(int k = tid; k < nV; k += 256) trl += fabs(B[(size_t)k * nV + k]);
-        const double tr = block_sum(trl);
-        (void)tr;
         for(int sweep = 0; sweep < 60 && nV > 1; ++sweep) {
             double off2 = 0.0;
+            // (the products of diagonals floored at 1e-300: a zero or denormal diagonal must read as "not converged", not as 0 / 0 = NaN = stop)
             // Stopping test in the SCALED measure sum (b_ij^2 / |b_ii b_jj|) <= 1e-26 (Demmel / Veselic: every eigenvalue and eigenvector of a positive
             // definite matrix to high RELATIVE accuracy).  Until round 5 the test was |off|_F <= 1e-11 trace: with observation sigmas x 0.01 the
             // spectrum of Pinv spans c ... 1e7 and the eigenvectors of the SMALL eigenvalues -- the ones that carry the weight in sqrt(c / D) --
             // were left with errors of 1e-5 (36 % of the float32 outputs off by an ulp, 1.5e-4 in the plain measure; k_ensi_huge, ensi.hip)
-            for(long e = tid; e < (long)nV * nV; e += 256) { const int i = (int)(e / nV), j = (int)(e - (long)i * nV); if(j < i) { const double v = B[e]; off2 += v * v / fabs(B[(size_t)i * nV + i] * B[(size_t)j * nV + j]); } }
+            for(long e = tid; e < (long)nV * nV; e += 256) { const int i = (int)(e / nV), j = (int)(e - (long)i * nV); if(j < i) { const double v = B[e]; off2 += v * v / fmax(fabs(B[(size_t)i * nV + i] * B[(size_t)j * nV + j]), 1e-300); } }
             off2 = block_sum(off2);
             if(!(off2 > 1e-26)) break;   // (also on NaN: a non-finite matrix)
             for(int step = 0; step < mm - 1; ++step) {

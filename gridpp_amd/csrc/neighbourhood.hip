@@ -242,7 +242,10 @@ struct QfLut {
 __device__ __forceinline__ unsigned qf_bucket_into(const float v, const float scale, const float off, const unsigned sel, const unsigned old) {
     return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v, scale, off), sel, old);
 }
-__global__ __launch_bounds__(QF_NB) void k_qf_lut(const float* __restrict__ thr, int T, QfLut* __restrict__ L) {
+__global__ __launch_bounds__(QF_NB) void k_qf_lut(const float* __restrict__ thr, int T, QfLut* __restrict__ L, int* __restrict__ rowflag, int nflags) {
+    // (round 6: also clears the row flags of the count planes -- [Y] "some row is flagged", [Y + 1] "the count pass was launched for another
+    //  number of distinct thresholds than this table has" -- which were two fill launches of their own in front of the count pass)
+    for(int k = threadIdx.x; k < nflags; k += QF_NB) rowflag[k] = 0;
     __shared__ float u[16], st[16];
     __shared__ int ub[16], srank[16];
     __shared__ int s_U, s_flag;
@@ -292,7 +295,14 @@ __global__ __launch_bounds__(QF_NB) void k_qf_lut(const float* __restrict__ thr,
 
 template <int NL>
 __global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, long C, int E, const float* __restrict__ thr, int T,
-                                                 const QfLut* __restrict__ L, unsigned char* __restrict__ out8, const QfGeom g) {
+                                                 const QfLut* __restrict__ L, unsigned char* __restrict__ out8, const QfGeom g, const int Uexp) {
+    // Uexp >= 0: the host chose this instantiation from the LAST call's number of distinct thresholds without waiting for this call's table
+    // (one host round trip less per call).  A table that says otherwise stops the pass and, through rowflag[Y + 1], the box pass behind it;
+    // the host sees it in the one read-back at the end of the call and runs the call again the slow way.
+    if(Uexp >= 0 && (L->U != Uexp || L->flag != 0)) {
+        if(blockIdx.x == 0 && threadIdx.x == 0) g.rowflag[g.Y + 1] = 1;
+        return;
+    }
     extern __shared__ unsigned qc_lds[];
     uint2* const lut = reinterpret_cast<uint2*>(qc_lds);          // [QF_NB]
     unsigned* const ranks = qc_lds + 2 * QF_NB;                    // [16 E] rank bytes of a tile, four members per dword, cell-major
@@ -1130,6 +1140,8 @@ struct NbWorkspace {
     const void* pad_ptr = nullptr;   // the padding of the quantile_fast count planes is in place for this buffer (this ALLOCATION of it) and shape
     unsigned long long pad_gen = 0;
     int pad_y = 0, pad_x = 0, pad_t = 0, pad_e = 0;
+    int spec_nt = -1, spec_U = -1;   // quantile_fast: the number of distinct thresholds the last call with spec_nt thresholds had (its table was usable)
+    int* h_pin = nullptr;            // a few page-locked words for the read-back at the end of such a call
 };
 thread_local NbWorkspace g_nb;
 
@@ -1184,17 +1196,17 @@ void member_pass(const float* d_in, long C, int E, int mode, int statistic, cons
 }
 // byte counts of quantile_fast by ranks (k_qf_count<U + 2>)
 template <int NL>
-void qf_count_launch_nl(const float* d_in, long C, int E, const float* d_thr, int T, const QfLut* lut, unsigned char* cnt8, const QfGeom& g) {
+void qf_count_launch_nl(const float* d_in, long C, int E, const float* d_thr, int T, const QfLut* lut, unsigned char* cnt8, const QfGeom& g, const int Uexp) {
     const size_t lds = (size_t)(2 * QF_NB + std::max(16 * E, NL * 64)) * sizeof(unsigned) + (size_t)(T + 1) * 256;
     int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(24, (160 * 1024) / lds));
     if(path_env("GPP_QF_WAVES")) waves_per_cu = std::max(1, std::min(waves_per_cu, atoi(path_env("GPP_QF_WAVES"))));   // (A/B: fewer, longer streams)
     const long grid = std::max<long>(1, std::min<long>((C / 64 + 3) / 4, (long)256 * waves_per_cu));
-    hipLaunchKernelGGL((k_qf_count<NL>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, d_thr, T, lut, cnt8, g);
+    hipLaunchKernelGGL((k_qf_count<NL>), dim3((unsigned)grid), dim3(64), lds, stream(), d_in, C, E, d_thr, T, lut, cnt8, g, Uexp);
     GPP_HIP(hipGetLastError());
 }
-void qf_count_launch(const float* d_in, long C, int E, const float* d_thr, int T, const QfLut* lut, int U, unsigned char* cnt8, const QfGeom& g) {
+void qf_count_launch(const float* d_in, long C, int E, const float* d_thr, int T, const QfLut* lut, int U, unsigned char* cnt8, const QfGeom& g, const int Uexp) {
     switch(U + 2) {
-#define QF_NL_CASE(n) case n: qf_count_launch_nl<n>(d_in, C, E, d_thr, T, lut, cnt8, g); break;
+#define QF_NL_CASE(n) case n: qf_count_launch_nl<n>(d_in, C, E, d_thr, T, lut, cnt8, g, Uexp); break;
         QF_NL_CASE(3) QF_NL_CASE(4) QF_NL_CASE(5) QF_NL_CASE(6) QF_NL_CASE(7) QF_NL_CASE(8) QF_NL_CASE(9) QF_NL_CASE(10)
         QF_NL_CASE(11) QF_NL_CASE(12) QF_NL_CASE(13) QF_NL_CASE(14) QF_NL_CASE(15) QF_NL_CASE(16) QF_NL_CASE(17) QF_NL_CASE(18)
 #undef QF_NL_CASE
@@ -1374,29 +1386,56 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
     const bool fused = nt > 0 && is3d && ne <= 254 && nt <= 16 && halfwidth <= QF_MAXHW && C < (1L << 31) && !path_env("GPP_QF_NO_FUSED");
     bool ranked = fused && (ne & 3) == 0 && (reinterpret_cast<size_t>(in.d) & 15) == 0 && !path_env("GPP_QF_NO_RANKS");
     if(nt > 0) th.bind(thresholds, nt, mem & ~GPP_HOST_F64);   // GPP_HOST_F64 applies to `input` only: quantile / thresholds stay float32
-    QfLut* lut = nullptr;
-    int lut_head[5] = {0, 0, 0, 1, 0};   // scale, off, U, flag, ident
-    if(ranked) {
-        lut = reinterpret_cast<QfLut*>(g_nb.qf.get((sizeof(QfLut) + 3) / 4));
-        hipLaunchKernelGGL(k_qf_lut, dim3(1), dim3(QF_NB), 0, stream(), th.d, nt, lut);
-        GPP_HIP(hipGetLastError());
-        GPP_HIP(hipMemcpyAsync(lut_head, lut, sizeof(lut_head), hipMemcpyDeviceToHost, stream()));
-    }
-    // quantile validation (:315-321) needs the values on the host
-    std::vector<float> hq(nq);
-    if(mem & GPP_MEM_DEVICE) { GPP_HIP(hipMemcpyAsync(hq.data(), quantile, sizeof(float) * nq, hipMemcpyDeviceToHost, stream())); GPP_HIP(hipStreamSynchronize(stream())); }
-    else { memcpy(hq.data(), quantile, sizeof(float) * nq); if(ranked) GPP_HIP(hipStreamSynchronize(stream())); }
-    for(int i = 0; i < nq; i++)
-        if(is_valid(hq[i]) && (hq[i] < 0 || hq[i] > 1)) invalid("All quantiles must be >= 0 and <= 1");
+    // GPP_Q_HOST: the quantile argument is host memory although the field is in HBM (the scalar quantile of a script beside a device-resident
+    // cube: uploaded by the caller and read back here for its validation it cost two transfers and a host round trip per call)
+    const int qmem = (mem & GPP_Q_HOST) ? GPP_MEM_HOST : (mem & ~GPP_HOST_F64);
+    auto check_q = [&](const float* hq) {   // :315-321
+        for(int i = 0; i < nq; i++)
+            if(is_valid(hq[i]) && (hq[i] < 0 || hq[i] > 1)) invalid("All quantiles must be >= 0 and <= 1");
+    };
+    const bool q_on_device = (qmem & GPP_MEM_DEVICE) != 0;
+    if(!q_on_device) check_q(quantile);
     if(nt == 0) {   // :330-331: all missing
+        if(q_on_device) {
+            std::vector<float> hq(nq);
+            GPP_HIP(hipMemcpyAsync(hq.data(), quantile, sizeof(float) * nq, hipMemcpyDeviceToHost, stream())); GPP_HIP(hipStreamSynchronize(stream()));
+            check_q(hq.data());
+        }
         hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream(), o.d, C);
         o.finish();
         GPP_HIP(hipStreamSynchronize(stream()));
         return GPP_OK;
     }
-    qf.bind(quantile, nq, mem & ~GPP_HOST_F64);
-    if(ranked && lut_head[3]) ranked = false;   // two thresholds in one bucket / a non-finite threshold: the compare-per-threshold pass
-    if(fused) {
+    qf.bind(quantile, nq, qmem);
+    if(!g_nb.h_pin) GPP_HIP(hipHostMalloc((void**)&g_nb.h_pin, 64, hipHostMallocDefault));
+    // Two rounds at most: the first may launch the count pass for the number of distinct thresholds the LAST call had (no host round trip in
+    // front of the kernels: the table's head and the quantile are read back once, behind the box pass); a table that turns out different
+    // stops the passes on the device and the second round does what every call did until round 5 -- wait for the table, then launch.
+    for(int round = 0; round < 2; round++) {
+        QfLut* lut = nullptr;
+        int lut_head[5] = {0, 0, 0, 1, 0};   // scale, off, U, flag, ident
+        int* rowflag = nullptr;
+        const bool spec = fused && ranked && round == 0 && g_nb.spec_nt == nt && g_nb.spec_U >= 0 && !path_env("GPP_QF_NO_SPEC");
+        if(fused) rowflag = g_nb.plane_flags.get(ny + 2);
+        if(ranked) {
+            lut = reinterpret_cast<QfLut*>(g_nb.qf.get((sizeof(QfLut) + 3) / 4));
+            hipLaunchKernelGGL(k_qf_lut, dim3(1), dim3(QF_NB), 0, stream(), th.d, nt, lut, rowflag, fused ? ny + 2 : 0);
+            GPP_HIP(hipGetLastError());
+            if(!spec) GPP_HIP(hipMemcpyAsync(lut_head, lut, sizeof(lut_head), hipMemcpyDeviceToHost, stream()));
+        }
+        else if(fused) GPP_HIP(hipMemsetAsync(rowflag, 0, sizeof(int) * (ny + 2), stream()));
+        std::vector<float> hq;
+        if(q_on_device && !spec) {   // quantile validation needs the values on the host
+            hq.resize(nq);
+            GPP_HIP(hipMemcpyAsync(hq.data(), quantile, sizeof(float) * nq, hipMemcpyDeviceToHost, stream()));
+        }
+        if(!spec && (ranked || q_on_device)) GPP_HIP(hipStreamSynchronize(stream()));
+        if(q_on_device && !spec) check_q(hq.data());
+        if(!spec && ranked) {
+            if(lut_head[3]) ranked = false;   // two thresholds in one bucket / a non-finite threshold: the compare-per-threshold pass
+            else { g_nb.spec_nt = nt; g_nb.spec_U = lut_head[2]; }
+        }
+        if(!fused) break;
         QfGeom g = qf_geom(ny, nx);
         unsigned char* cnt8 = reinterpret_cast<unsigned char*>(g_nb.planes.get(((size_t)(nt + 1) * g.Pp + 3) / 4));
         if(g_nb.pad_ptr != cnt8 || g_nb.pad_gen != g_nb.planes.gen || g_nb.pad_y != ny || g_nb.pad_x != nx || g_nb.pad_t != nt || g_nb.pad_e != ne) {
@@ -1406,15 +1445,24 @@ extern "C" int gpp_neighbourhood_quantile_fast(const float* input, int ny, int n
             GPP_HIP(hipMemsetAsync(cnt8 + (size_t)nt * g.Pp, ne, (size_t)g.Pp, stream()));
             g_nb.pad_ptr = cnt8; g_nb.pad_gen = g_nb.planes.gen; g_nb.pad_y = ny; g_nb.pad_x = nx; g_nb.pad_t = nt; g_nb.pad_e = ne;
         }
-        g.rowflag = g_nb.plane_flags.get(ny + 1);
-        GPP_HIP(hipMemsetAsync(g.rowflag, 0, sizeof(int) * (ny + 1), stream()));
-        if(ranked) qf_count_launch(in.d, C, ne, th.d, nt, lut, lut_head[2], cnt8, g);
+        g.rowflag = rowflag;
+        if(ranked) qf_count_launch(in.d, C, ne, th.d, nt, lut, spec ? g_nb.spec_U : lut_head[2], cnt8, g, spec ? g_nb.spec_U : -1);
         else member_pass(in.d, C, ne, 2, 0, th.d, nt, reinterpret_cast<float*>(cnt8), g);
 #ifdef QF_SIDE_EXPERIMENT   // timing experiment only: the box pass on the second stream WITHOUT waiting for the counts (wrong results)
         if(path_env("GPP_QF_SIDE")) { qf_box_launch(cnt8, g, ne, halfwidth, nt, th.d, qf.d, nq == 1 ? 0 : 1, o.d, stream2()); GPP_HIP(hipStreamSynchronize(stream2())); }
         else
 #endif
         qf_box_launch(cnt8, g, ne, halfwidth, nt, th.d, qf.d, nq == 1 ? 0 : 1, o.d);
+        if(spec) {   // the one read-back of the call: did the count pass run, and the quantile(s) for the validation the slow round does first
+            GPP_HIP(hipMemcpyAsync(g_nb.h_pin, rowflag + ny + 1, sizeof(int), hipMemcpyDeviceToHost, stream()));
+            if(q_on_device) {
+                if(nq == 1) GPP_HIP(hipMemcpyAsync(g_nb.h_pin + 1, quantile, sizeof(float), hipMemcpyDeviceToHost, stream()));
+                else { hq.resize(nq); GPP_HIP(hipMemcpyAsync(hq.data(), quantile, sizeof(float) * nq, hipMemcpyDeviceToHost, stream())); }
+            }
+            GPP_HIP(hipStreamSynchronize(stream()));
+            if(q_on_device) check_q(nq == 1 ? reinterpret_cast<const float*>(g_nb.h_pin + 1) : hq.data());
+            if(g_nb.h_pin[0] != 0) { g_nb.spec_nt = -1; g_nb.spec_U = -1; continue; }   // other thresholds than the last call's: once more, the slow way
+        }
         o.finish();
         GPP_HIP(hipStreamSynchronize(stream()));
         return GPP_OK;

@@ -1195,8 +1195,30 @@ struct OiWorkspace {
     DevBuf<unsigned> pair_sel;   // k_oi -> k_oi_pairs: 128 B per cell
     DevBuf<int> pair_n;
     hipEvent_t e0 = nullptr, e1 = nullptr, eu = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    // banded host path (round 6): upload / first pass / download per band of tile rows, and the patch of the tiles the first pass left to the list passes
+    static constexpr int MAXB = 8;
+    hipEvent_t ev_up[MAXB] = {}, ev_k[MAXB] = {}, ev_band0 = nullptr;
+    DevBuf<float> patch;          // [tiles][64] analysis (+ [tiles][64] variance behind it)
+    float* h_patch = nullptr;     // pinned mirror, then the tile ids
+    size_t h_patch_cap = 0;
 };
 thread_local OiWorkspace g_ws;
+
+// banded host path: the cells of the listed tiles, tile-major (lane order of the tile kernels), for the host to put in place
+__global__ void k_gather_tiles(const int* __restrict__ l0, int n0, const int* __restrict__ l1, int n1, int ny, int nx, int tiles_x, int wshift,
+                               const float* __restrict__ out, const float* __restrict__ var, float* __restrict__ p_out, float* __restrict__ p_var, int* __restrict__ p_ids) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if(i >= n0 + n1) return;
+    int tile = i < n0 ? l0[i] : l1[i - n0];
+    if(tile < 0) tile = ~tile;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y = ty * (64 >> wshift) + (lane >> wshift), x = (tx << wshift) + (lane & ((1 << wshift) - 1));
+    float v = 0.0f, w = 0.0f;
+    if(y < ny && x < nx) { v = out[(size_t)y * nx + x]; if(var) w = var[(size_t)y * nx + x]; }
+    p_out[(size_t)i * 64 + lane] = v;
+    if(p_var) p_var[(size_t)i * 64 + lane] = w;
+    if(lane == 0) p_ids[i] = tile;
+}
 thread_local gpp_oi_stats g_stats;
 
 // ---- asynchronous calls (GPP_MEM_DEVICE | GPP_ASYNC; round 5) ----------------------------------------------------------------------
@@ -1498,8 +1520,18 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     OiWorkspace& ws = g_ws;
     InField f_bg, f_bvar, f_obs, f_ov, f_pbg, f_bvp;
     OutField f_out, f_var;
-    f_bg.bind(background, C, mem);
-    f_bvar.bind(bvariance, C, mem);
+    // Host arrays of a large grid (what a gridpp script passes, swig/vector.i:42-55,172-180): the background goes up, and the analysis comes
+    // down, in bands of tile rows beside the first pass when the call takes the tile kernel (`banded` below) -- 64 MB each way over PCIe ran
+    // strictly before and behind a 4.3 ms kernel.  Until that is known the upload is only prepared.
+    const bool band_candidate = !(mem & (GPP_MEM_DEVICE | GPP_HOST_F64)) && C >= (1 << 20) && S > 0 && !path_env("GPP_OI_NO_BANDS");
+    if(band_candidate) {
+        f_bg.d = f_bg.staged.get(C);
+        if(bvariance) f_bvar.d = f_bvar.staged.get(C);
+    }
+    else {
+        f_bg.bind(background, C, mem);
+        f_bvar.bind(bvariance, C, mem);
+    }
     f_out.bind(out, C, mem);
     f_var.bind(out_variance, C, mem);
 
@@ -1534,19 +1566,18 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         for(int k = 0; k < 2; k++) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_pack[k], hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_join2[k], hipEventDisableTiming)); }
         (void)stream2(); (void)stream3();
     }
-    ws.slot ^= 1;
-    const int wsl = ws.slot;
-    DevBuf<float4>& pgeo = ws.pgeo_s[wsl]; DevBuf<float4>& oaux = ws.oaux_s[wsl]; DevBuf<float4>& saux = ws.saux_s[wsl];
-    DevBuf<unsigned long long>& status = ws.status_s[wsl];
-    pgeo.get(S); oaux.get(S); saux.get(S);
-    status.get(SB);
-    if(!ws.h_status) GPP_HIP(hipHostMalloc((void**)&ws.h_status, (SB + 1) * sizeof(unsigned long long), hipHostMallocDefault));
-    int* const d_ints = reinterpret_cast<int*>(status.p);
-    int* const d_err = d_ints, *const d_fb_count = d_ints + 1, *const d_big_count = d_ints + 4, *const d_huge_count = d_ints + 5;
-    unsigned long long* const d_counters = status.p + 8;
+    // The workspace of this call -- the slot's observation block and status block -- is bound BELOW, behind the decision whether the call is deferred:
+    // a call that is not completes the deferred calls of the thread first, and one of those may need its synchronous re-run, i.e. a nested
+    // oi_full_impl that flips the slot, reallocates the slot buffers for its own observation count and overwrites the statistics.
+    // Nothing of the workspace is touched, and no pointer into it is held, before that drain.
+    int wsl = 0;
+    DevBuf<float4>* pgeo_b = nullptr; DevBuf<float4>* oaux_b = nullptr; DevBuf<float4>* saux_b = nullptr;
+    DevBuf<unsigned long long>* status_b = nullptr;
+    int* d_ints = nullptr, *d_err = nullptr, *d_fb_count = nullptr, *d_big_count = nullptr, *d_huge_count = nullptr;
+    unsigned long long* d_counters = nullptr;
     auto launch_pack = [&](hipStream_t on) {   // the observation block of this call (also clears the status block)
         hipLaunchKernelGGL(k_pack_obs, dim3((S + 255) / 256), dim3(256), 0, on, S, ix->d_sgeo.p, ix->d_pos.p, ix->d_olaf.p,
-                           f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, pgeo.p, oaux.p, saux.p, status.p, (int)SB);
+                           f_obs.d, f_ov.d, f_pbg.d, f_bvp.d, 1, pgeo_b->p, oaux_b->p, saux_b->p, status_b->p, (int)SB);
         GPP_HIP(hipGetLastError());
     };
 
@@ -1565,8 +1596,8 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         a.tiles_x = (a.nx + tw - 1) / tw; a.ntiles = a.tiles_x * ((a.ny + th - 1) / th);
     }
     else { a.tiles_x = 0; a.ntiles = (C + 63) / 64; }
-    a.s.pgeo = pgeo.p; a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
-    a.ogeo = ix->d_ogeo.p; a.oaux = oaux.p; a.saux = saux.p;
+    a.s.smeta = ix->d_smeta.p; a.s.bin_start = ix->d_bin_start.p;
+    a.ogeo = ix->d_ogeo.p;
     a.S = S; a.s.axis_a = ix->axis_a; a.s.axis_b = ix->axis_b; a.s.nbx = ix->nbx; a.s.nby = ix->nby;
     a.s.amin = ix->amin; a.s.bmin = ix->bmin; a.s.inv_s = ix->inv_s;
     a.s.st = gpp_resolve_structure(st);
@@ -1580,9 +1611,8 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
       // visits rings 0.15x wide
       const double r_k = std::sqrt(kk / (3.14159265358979 * std::max(occ, 1e-3))) / ix->inv_s;
       a.s.ring_r0 = (float)(1.5 * r_k); a.s.ring_dr = (float)(0.15 * r_k); }
-    a.s.scan_stats = timing_env("GPP_SCAN_STATS") ? d_counters + 2 : nullptr; a.allow_extrap = allow_extrapolation ? 1 : 0;
+    a.allow_extrap = allow_extrapolation ? 1 : 0;
     a.s.K = (max_points > 0 && max_points <= N) ? max_points : N;
-    a.err = d_err; a.counters = d_counters; a.tail_count = d_ints + 6;
     a.debug = timing_env("GPP_OI_DEBUG") ? atoi(timing_env("GPP_OI_DEBUG")) : 0;
 
     // Cholesky needs a symmetric positive definite P+R: true for every kernel on distances and for the even vertical / laf
@@ -1629,9 +1659,9 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         GPP_HIP(hipGetLastError());
         a.pair_sel = nullptr; a.pair_n = nullptr;
     };
-    const int* const h_ints = reinterpret_cast<const int*>(ws.h_status);
+    const int* h_ints = nullptr;   // (the page-locked mirror of the status block: bound with the workspace below)
     auto fetch = [&]() {   // the whole status block in one copy
-        GPP_HIP(hipMemcpyAsync(ws.h_status, status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
+        GPP_HIP(hipMemcpyAsync(ws.h_status, status_b->p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
         GPP_HIP(hipStreamSynchronize(stream()));
         err = h_ints[0];
         memcpy(counters, ws.h_status + 8, sizeof(counters));
@@ -1648,14 +1678,33 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     // (the 62-row form only for 33 <= max_points <= 62: with max_points = 0 a cell may hold more than any tile kernel can)
     const bool use_union = !use_lu && (N == 32 || (max_points > 32 && max_points <= 62)) && want_union && !memo_says_no && !path_env("GPP_OI_NO_UNION");
     const int WPB = N == 32 ? UnionCfg<32>::WPB : UnionCfg<64>::WPB;   // work items (waves) per workgroup of k_oi_union
+    // ---- the banded host path (see band_candidate above) --------------------------------------------------------------------------------
+    a.tile0 = 0; a.tile_n = a.ntiles;
+    const bool banded = band_candidate && a.tiled2d && use_union && N == 32 && !path_env("GPP_OI_PAIR_TILES") && a.ntiles / std::max(a.tiles_x, 1) >= 2 * OiWorkspace::MAXB;
+    if(band_candidate && !banded) {   // whole arrays, as InField::bind does
+        GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bg.d), background, sizeof(float) * C, hipMemcpyHostToDevice, stream()));
+        if(bvariance) GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bvar.d), bvariance, sizeof(float) * C, hipMemcpyHostToDevice, stream()));
+    }
+    // The analysis comes down per band only into page-locked memory (the Python mirror's result arrays, gpp_host_alloc): a copy into pageable
+    // memory blocks the host until it is done, i.e. until the band's kernel has run -- nothing behind it would be enqueued in time.
+    bool band_down = false;
+    if(banded) {
+        hipPointerAttribute_t at;
+        band_down = hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if(band_down && out_variance) { band_down = hipPointerGetAttributes(&at, out_variance) == hipSuccess && at.type == hipMemoryTypeHost; (void)hipGetLastError(); }
+        if(!ws.ev_band0) GPP_HIP(hipEventCreateWithFlags(&ws.ev_band0, hipEventDisableTiming));
+        for(int b = 0; b < OiWorkspace::MAXB; b++) if(!ws.ev_up[b]) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_up[b], hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_k[b], hipEventDisableTiming)); }
+    }
+    struct BandGuard {   // whatever ends the call: no copy of it stays in flight on the side streams (into arrays the caller may free)
+        bool on;
+        ~BandGuard() { if(on) { (void)hipStreamSynchronize(stream2()); (void)hipStreamSynchronize(stream3()); } }
+    } band_guard{banded};
+    bool bands_down_done = false;   // the band downloads of this call are enqueued: the end of the call patches the declined tiles instead of copying everything
     // cells with more usable observations than the 62-row tile holds are listed: symmetric systems go to k_oi_big (Cholesky, up
     // to BIG_N observations), what that kernel cannot hold and every listed cell of a non-symmetric or spatially varying
     // structure to k_oi_huge (pivoted elimination in HBM scratch, no capacity of its own)
     const bool big_ok = N == 62;
-    if(big_ok) {
-        ws.big_list.get((size_t)C);
-        a.big_list = ws.big_list.p; a.big_count = d_big_count;
-    }
     auto run_huge = [&](const int* d_list, const int* d_count, const int ncells) {
         // scratch for the worst case of this call: every observation a candidate, max_points (or all of them) selected
         size_t kcap = 1; while(kcap < (size_t)S) kcap <<= 1;
@@ -1686,8 +1735,32 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         for(const PendingOi& q : g_pending) if(!q.done && q.slot == async_slot) { async_slot = -1; break; }   // (all slots in flight: this call runs synchronously)
         if(async_slot < 0) steady = false;
     }
-    if(!steady) { gpp_oi_drain_pending(); launch_pack(stream()); GPP_HIP(hipEventRecord(ws.e0, stream())); }
+    if(!steady) {
+        gpp_oi_drain_pending();
+        g_stats = gpp_oi_stats();      // (a re-run inside the drain left its own)
+        g_stats.cells = C;
+    }
+    ws.slot ^= 1;
+    wsl = ws.slot;
+    pgeo_b = &ws.pgeo_s[wsl]; oaux_b = &ws.oaux_s[wsl]; saux_b = &ws.saux_s[wsl]; status_b = &ws.status_s[wsl];
+    pgeo_b->get(S); oaux_b->get(S); saux_b->get(S);
+    status_b->get(SB);
+    if(!ws.h_status) GPP_HIP(hipHostMalloc((void**)&ws.h_status, (SB + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+    h_ints = reinterpret_cast<const int*>(ws.h_status);
+    d_ints = reinterpret_cast<int*>(status_b->p);
+    d_err = d_ints; d_fb_count = d_ints + 1; d_big_count = d_ints + 4; d_huge_count = d_ints + 5;
+    d_counters = status_b->p + 8;
+    a.s.pgeo = pgeo_b->p; a.oaux = oaux_b->p; a.saux = saux_b->p;
+    a.s.scan_stats = timing_env("GPP_SCAN_STATS") ? d_counters + 2 : nullptr;
+    a.err = d_err; a.counters = d_counters; a.tail_count = d_ints + 6;
+    if(big_ok) {
+        ws.big_list.get((size_t)C);
+        a.big_list = ws.big_list.p; a.big_count = d_big_count;
+    }
+    if(!steady) { launch_pack(stream()); GPP_HIP(hipEventRecord(ws.e0, stream())); }
     int overlap_left = 0, overlap_new = 0, overlap_remembered = 0;
+    const int* patch_l0 = nullptr; const int* patch_l1 = nullptr;
+    int patch_n0 = 0, patch_n1 = 0;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
         ran_union = false; ran_overlap = false;
@@ -1713,6 +1786,41 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 else if(plain) { if(list) hipLaunchKernelGGL((k_oi_union<true, true, 32>), grid, block, 0, cur, a); else hipLaunchKernelGGL((k_oi_union<true, false, 32>), UnionCfg<32>::persistent<true>() ? dim3(union_persist_grid<k_oi_union<true, false, 32>>(block.x, nb)) : grid, block, 0, cur, a); }
                 else { if(list) hipLaunchKernelGGL((k_oi_union<false, true, 32>), grid, block, 0, cur, a); else hipLaunchKernelGGL((k_oi_union<false, false, 32>), grid, block, 0, cur, a); }
                 GPP_HIP(hipGetLastError());
+            };
+            // The first pass over all tiles -- on the banded host path as one launch per band of tile rows: the band's rows of the background
+            // (and of its variance) go up on the second stream, the band's launch waits for them, the band's rows of the analysis come down on
+            // the third behind it.  Bands: 1 : 2 : 3 : 3 : 2 : 1 of the tile rows -- a short first upload and a short last download are what is
+            // not hidden; every launch costs its last, partly filled round of workgroups (~45 us).  The tiles the first pass leaves to the
+            // list passes are final only behind those: their cells are patched at the end of the call (k_gather_tiles).
+            auto first_pass = [&]() {
+                if(!banded) { launch_union(a.ntiles, false); return; }
+                static const int share[6] = {1, 2, 3, 3, 2, 1};
+                const int th = 64 >> a.wshift, trows = a.ntiles / a.tiles_x;
+                const hipStream_t sUp = stream2(), sDown = stream3();
+                GPP_HIP(hipEventRecord(ws.ev_band0, stream()));
+                GPP_HIP(hipStreamWaitEvent(sUp, ws.ev_band0, 0));    // (the staging buffers' previous readers are behind the library stream)
+                int ty0 = 0, acc = 0;
+                for(int b = 0; b < 6; b++) {
+                    acc += share[b];
+                    const int ty1 = b == 5 ? trows : std::max(ty0 + 1, (int)((long)trows * acc / 12));
+                    const size_t r0 = (size_t)ty0 * th, r1 = std::min<size_t>((size_t)a.ny, (size_t)ty1 * th);
+                    const size_t off = r0 * a.nx, cnt = (r1 - r0) * a.nx;
+                    GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bg.d) + off, background + off, cnt * sizeof(float), hipMemcpyHostToDevice, sUp));
+                    if(bvariance) GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bvar.d) + off, bvariance + off, cnt * sizeof(float), hipMemcpyHostToDevice, sUp));
+                    GPP_HIP(hipEventRecord(ws.ev_up[b], sUp));
+                    GPP_HIP(hipStreamWaitEvent(stream(), ws.ev_up[b], 0));
+                    a.tile0 = ty0 * a.tiles_x; a.tile_n = (ty1 - ty0) * a.tiles_x;
+                    launch_union(a.tile_n, false);
+                    if(band_down) {
+                        GPP_HIP(hipEventRecord(ws.ev_k[b], stream()));
+                        GPP_HIP(hipStreamWaitEvent(sDown, ws.ev_k[b], 0));
+                        GPP_HIP(hipMemcpyAsync(out + off, f_out.d + off, cnt * sizeof(float), hipMemcpyDeviceToHost, sDown));
+                        if(out_variance) GPP_HIP(hipMemcpyAsync(out_variance + off, f_var.d + off, cnt * sizeof(float), hipMemcpyDeviceToHost, sDown));
+                    }
+                    ty0 = ty1;
+                }
+                a.tile0 = 0; a.tile_n = a.ntiles;
+                bands_down_done = band_down;
             };
             // The tiles it declined.  The usual case is a short list (or none): it is taken WITHOUT asking the host how long it
             // is -- the short-list pass and the k_oi pass behind it are launched with fixed small grids and read the lengths
@@ -1803,7 +1911,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 GPP_HIP(hipEventRecord(sl.e1, sA));      // (one timestamp behind the first pass: every command between two first passes is a gap on the GPU)
                 GPP_HIP(hipStreamWaitEvent(sC, sl.e1, 0));
                 GPP_HIP(hipStreamWaitEvent(sC, ws.ev_join2[wsl], 0));
-                GPP_HIP(hipMemcpyAsync(sl.h, status.p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, sC));
+                GPP_HIP(hipMemcpyAsync(sl.h, status_b->p, SB * sizeof(unsigned long long), hipMemcpyDeviceToHost, sC));
                 GPP_HIP(hipEventRecord(sl.ec, sC));
                 ws.slot_e1[wsl] = sl.e1; ws.slot_ec[wsl] = sl.ec;
                 PendingOi pc;
@@ -1821,7 +1929,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 GPP_HIP(hipEventRecord(ws.ev_fork, stream()));             // (behind k_pack_obs, which also cleared the status block)
                 a.skip_flags = memo.flags.p;
                 a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
-                launch_union(a.ntiles, false);                             // pass 1 on the library stream
+                first_pass();                                              // pass 1 on the library stream
                 GPP_HIP(hipEventRecord(ws.eu, stream()));
                 a.skip_flags = nullptr;
                 cur = stream2();
@@ -1858,7 +1966,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             else if(!expect_long) {
                 if(steady) return defer();      // (nothing declined the last time: the first pass alone, deferred)
                 a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
-                launch_union(a.ntiles, false);                             // pass 1: every tile
+                first_pass();                                              // pass 1: every tile
                 GPP_HIP(hipEventRecord(ws.eu, stream()));
                 // (a geometry that declined no tile the last time: not even the two empty launches; the read-back says if that was wrong)
                 const bool expect_none = memo_hit && memo.declined == 0.0f;
@@ -1874,7 +1982,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             }
             else {
                 a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
-                launch_union(a.ntiles, false);                             // pass 1: every tile
+                first_pass();                                              // pass 1: every tile
                 GPP_HIP(hipEventRecord(ws.eu, stream()));
                 // A long list is expected, and the same geometry declines the same tiles: the two-level passes are launched for the length
                 // of the last call (+ 1/8) without asking the host first -- they read the true length on the device.  Only if MORE tiles were
@@ -1917,6 +2025,9 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         const int nfb[3] = {ran_overlap ? overlap_remembered + overlap_new : n_listed, ran_union ? h_ints[2] : 0, ran_overlap ? overlap_left : (ran_union ? h_ints[3] : 0)};
         g_stats.fallback_tiles = nfb[0];
         g_stats.fallback_subtiles = nfb[2];
+        // (banded host path: the tiles whose cells the band downloads took too early -- everything the first pass did not finish itself)
+        if(ran_overlap) { patch_l0 = memo.list.p; patch_n0 = overlap_remembered; patch_l1 = ws.fb_list.p; patch_n1 = overlap_new; }
+        else { patch_l0 = ws.fb_list.p; patch_n0 = ran_union ? std::min(n_listed, a.ntiles) : 0; patch_l1 = nullptr; patch_n1 = 0; }
         if(ran_union) {
             if(!memo_hit) { memo.nlist = 0; memo.list_ntiles = 0; }
             memo.points_id = points->serial; memo.h = a.s.st.h; memo.v = a.s.st.v; memo.w = a.s.st.w; memo.max_points = max_points;
@@ -1979,12 +2090,49 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
             g_stats.fallback_tiles = a.ntiles;
-            GPP_HIP(hipMemsetAsync(status.p, 0, SB * sizeof(unsigned long long), stream()));
+            GPP_HIP(hipMemsetAsync(status_b->p, 0, SB * sizeof(unsigned long long), stream()));
             continue;
         }
         break;
     }
-    if(f_out.host || f_var.host) {   // (device outputs: the stream is already idle after the status read-back)
+    if(bands_down_done && !use_lu && !(err & (ERR_SINGULAR | ERR_OVERFLOW))) {
+        // the bands of the analysis are on their way down (third stream); what the list passes finished after the band of its tile left:
+        // those tiles' cells, tile-major, through a page-locked block, put in place by the host
+        const int np = patch_n0 + patch_n1;
+        if(np > 0) {
+            const size_t words = (size_t)np * 64 * (f_var.d ? 2 : 1) + (size_t)np;
+            float* const d_patch = ws.patch.get(words);
+            if(words > ws.h_patch_cap) {
+                if(ws.h_patch) GPP_HIP(hipHostFree(ws.h_patch));
+                ws.h_patch = nullptr; ws.h_patch_cap = 0;
+                GPP_HIP(hipHostMalloc((void**)&ws.h_patch, words * sizeof(float), hipHostMallocDefault));
+                ws.h_patch_cap = words;
+            }
+            float* const d_pv = f_var.d ? d_patch + (size_t)np * 64 : nullptr;
+            int* const d_ids = reinterpret_cast<int*>(d_patch + (size_t)np * 64 * (f_var.d ? 2 : 1));
+            hipLaunchKernelGGL(k_gather_tiles, dim3(np), dim3(64), 0, stream(), patch_l0, patch_n0, patch_l1, patch_n1, a.ny, a.nx, a.tiles_x, a.wshift,
+                               (const float*)f_out.d, (const float*)f_var.d, d_patch, d_pv, d_ids);
+            GPP_HIP(hipGetLastError());
+            GPP_HIP(hipMemcpyAsync(ws.h_patch, d_patch, words * sizeof(float), hipMemcpyDeviceToHost, stream()));
+        }
+        GPP_HIP(hipStreamSynchronize(stream()));
+        GPP_HIP(hipStreamSynchronize(stream3()));      // the bands are in `out`
+        if(np > 0) {
+            const float* const hp = ws.h_patch;
+            const float* const hv = f_var.d ? hp + (size_t)np * 64 : nullptr;
+            const int* const ids = reinterpret_cast<const int*>(hp + (size_t)np * 64 * (f_var.d ? 2 : 1));
+            const int th = 64 >> a.wshift, tw = 1 << a.wshift;
+            for(int i = 0; i < np; i++) {
+                const int ty = ids[i] / a.tiles_x, tx = ids[i] - ty * a.tiles_x;
+                for(int l = 0; l < 64; l++) {
+                    const int y = ty * th + (l >> a.wshift), x = tx * tw + (l & (tw - 1));
+                    if(y < a.ny && x < a.nx) { out[(size_t)y * a.nx + x] = hp[(size_t)i * 64 + l]; if(hv) out_variance[(size_t)y * a.nx + x] = hv[(size_t)i * 64 + l]; }
+                }
+            }
+        }
+    }
+    else if(f_out.host || f_var.host) {   // (device outputs: the stream is already idle after the status read-back)
+        if(bands_down_done) GPP_HIP(hipStreamSynchronize(stream3()));   // (a second run of the call -- pivoted LU -- wrote everything again: the early bands must not land on top of the full copy)
         f_out.finish(); f_var.finish();
         GPP_HIP(hipStreamSynchronize(stream()));
     }
@@ -2026,9 +2174,10 @@ extern "C" int gpp_optimal_interpolation_full(gpp_points* bgrid, const float* ba
     const size_t before = g_pending.size();
     const int rc = oi_full_impl(bgrid, background, bvariance, points, obs, obs_variance, background_at_points, bvariance_at_points, st, max_points,
                                 allow_extrapolation, out, out_variance, mem);
-    if(async_req && rc == GPP_OK && g_pending.size() == before) {   // it ran synchronously: queued as complete, so that the call pairs with a gpp_wait()
-        PendingOi pc;
+    if(async_req && g_pending.size() == before) {   // it ran synchronously -- or failed before anything was enqueued: queued as complete, so that EVERY
+        PendingOi pc;                               // GPP_ASYNC call pairs with one gpp_wait(), which reports the same code and message again
         pc.done = true; pc.rc = rc; pc.stats = g_stats;
+        if(rc != GPP_OK) pc.msg = gpp_last_error();
         g_pending.push_back(pc);
     }
     return rc;

@@ -42,6 +42,7 @@ struct OiArgs {
     int* out_list;
     int* out_count;
     int nrun;                // tiles to run when in_list is NULL
+    int tile0, tile_n;       // first pass of k_oi_union: the tiles [tile0, tile0 + tile_n) (all of them unless the host path runs the grid in bands of tile rows)
     int* tail_count;         // persistent first pass: counter of its dynamic tail (cleared with the status block)
     const unsigned char* skip_flags;   // first pass: tiles it leaves alone (NULL: none) -- the tiles this geometry declined in earlier calls, which the
                                        // list passes take from the remembered list on a second stream WHILE the first pass runs (oi.hip, `overlap`)
@@ -1364,8 +1365,8 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
         union_item<PLAIN, true, NC>(a, tile, sub, shift, s_u[wid], lane);
     }
     else if constexpr(!UnionCfg<NC>::template persistent<PLAIN>()) {   // (the other forms keep one tile per wave: the loop costs them registers they do not have)
-        const int tile = blockIdx.x * WPB + wid;
-        if(tile < a.ntiles && !(a.skip_flags && a.skip_flags[tile])) union_item<PLAIN, false, NC>(a, tile, -1, 0, s_u[wid], lane);
+        const int t = blockIdx.x * WPB + wid, tile = a.tile0 + t;   // (tile0 / tile_n: the band of tile rows this launch covers -- all tiles, or one band of the banded host path, oi.hip)
+        if(t < a.tile_n && !(a.skip_flags && a.skip_flags[tile])) union_item<PLAIN, false, NC>(a, tile, -1, 0, s_u[wid], lane);
     }
     else {
         // static part: whole rounds of the grid; dynamic tail: the remaining tiles one by one from a counter (a wave whose tiles were

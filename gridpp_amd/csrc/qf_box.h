@@ -13,7 +13,7 @@
 struct QfGeom {
     int Y, X, Xp, Yp;
     long Pp;              // bytes per plane (Yp * Xp, a multiple of 16)
-    int* rowflag;         // [Y + 1]; rowflag[Y] != 0: some row is flagged
+    int* rowflag;         // [Y + 2]; rowflag[Y] != 0: some row is flagged; rowflag[Y + 1] != 0: the count pass did not run (k_qf_count, Uexp)
 };
 inline QfGeom qf_geom(int Y, int X) {
     QfGeom g;

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
     float* const sthr = reinterpret_cast<float*>(tab + 256);                // [16]
     float* const ya = sthr + 16;                                            // [2][T][QB_SW] clamped means of the current / previous step
     if((unsigned)(size_t)(__attribute__((address_space(3))) double*)qb_lds != 0u) __builtin_trap();   // see qb_tab()
+    if(g.rowflag[g.Y + 1] != 0) return;      // (the count pass did not run: launched for another table than this call's, see k_qf_count)
     if((g.rowflag[g.Y] != 0) != GENERAL) return;
     const int tid = threadIdx.x;
     const int p = tid / (QB_SW / QB_SEG), s = tid % (QB_SW / QB_SEG);

@@ -185,7 +185,10 @@ void stage_release_all() {
 extern "C" int gpp_release_workspaces(void) {
     GPP_TRY
     gpp_oi_drain_pending();
+    // (deferred calls of ANOTHER thread are not in this thread's queue: everything in flight on the three streams ends before a buffer goes)
     GPP_HIP(hipStreamSynchronize(stream()));
+    if(g_stream2) GPP_HIP(hipStreamSynchronize(g_stream2));
+    if(g_stream3) GPP_HIP(hipStreamSynchronize(g_stream3));
     stage_release_all();
     gpp_release_ensi_workspace();
     gpp_release_oi_workspace();
@@ -213,6 +216,9 @@ extern "C" int gpp_set_device(int device) {
         // every handle, workspace and the stream live on the device that was current at the first call: moving to another one
         // afterwards would mix pointers of two devices
         if(g_stream && g_live_handles.load() > 0) invalid("gpp_set_device: the device cannot change while point sets / fields created on the current one are alive");
+        if(g_stream) (void)hipStreamSynchronize(g_stream);
+        if(g_stream2) (void)hipStreamSynchronize(g_stream2);
+        if(g_stream3) (void)hipStreamSynchronize(g_stream3);
         stage_release_all();   // (staging buffers of the device that is left)
         if(g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
         if(g_stream2) { (void)hipStreamDestroy(g_stream2); g_stream2 = nullptr; }
@@ -539,6 +545,14 @@ extern "C" int gpp_grid_create_f64(const double* lats, const double* lons, const
 extern "C" int gpp_points_destroy(gpp_points* p) {
     GPP_TRY
     gpp_oi_drain_pending();   // (a pending GPP_ASYNC call of this thread may still use the handle)
+    // A deferred call of another thread is not in this thread's queue, and its kernels read the handle's arrays and its remembered list of
+    // declined tiles: whatever is in flight on the three streams ends before they are freed (a handle nothing was enqueued
+    // for costs three calls that return at once).
+    if(p && g_stream) {
+        GPP_HIP(hipStreamSynchronize(g_stream));
+        if(g_stream2) GPP_HIP(hipStreamSynchronize(g_stream2));
+        if(g_stream3) GPP_HIP(hipStreamSynchronize(g_stream3));
+    }
     delete p;
     return GPP_OK;
     GPP_CATCH

@@ -43,6 +43,9 @@ extern "C" {
 #define GPP_MEM_HOST 0
 #define GPP_MEM_DEVICE 1
 #define GPP_ASYNC 2
+/* With GPP_MEM_DEVICE, gpp_neighbourhood_quantile_fast only: the `quantile` argument is in HOST memory although the fields are in HBM -- the
+ * scalar quantile of a script (include/gridpp.h:469-486 takes it by value) beside a device-resident cube. */
+#define GPP_Q_HOST 8
 /* With GPP_MEM_HOST: the float INPUT fields of the call hold float64 values (numpy's default dtype); they are uploaded as
  * they are and cast to float32 on the device -- the rounding the reference's typemap applies on the host
  * (swig/vector.i:42-55).  Outputs stay float32.  Honoured by gpp_optimal_interpolation_full,
@@ -364,7 +367,9 @@ int gpp_oi_last_stats(gpp_oi_stats* stats);
  * when it returns GPP_OK; gpp_oi_last_stats() then describes that call).  Only a call in the steady state of a repeated analysis (the same
  * Grid / Points handles as the call before) is really deferred; any other runs synchronously at once and its gpp_wait() returns immediately.
  * Until the wait returns the caller keeps inputs, outputs and handles alive and unchanged; at most 4 calls are deferred at a time (further
- * ones run synchronously).  gpp_pending() tells how many waits are outstanding. */
+ * ones run synchronously).  gpp_pending() tells how many waits are outstanding.  A GPP_ASYNC call that returns an error (bad arguments, out
+ * of memory: nothing was enqueued) is queued as a completed call too, so a caller may pair one gpp_wait() with every submission without looking
+ * at the return code of the submission; that wait returns the same code and message again. */
 int gpp_wait(void);
 int gpp_pending(int* count);
 

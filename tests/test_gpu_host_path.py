@@ -38,3 +38,58 @@ def test_staging_pool_reuse_matches_the_device_path():
         assert (host.view(np.uint32) == dev.view(np.uint32)).all() and (host64.astype(np.float32).view(np.uint32) == dev.view(np.uint32)).all()
         if k in (2, 5):
             gridpp.release_workspaces()     # the pool is emptied; the next call allocates again
+
+
+@pytest.mark.parametrize("shape", [(1031, 1100), (1283, 1021), (2050, 640)])
+@pytest.mark.parametrize("variance", [False, True], ids=["analysis", "analysis+variance"])
+def test_banded_host_path_is_bit_identical_to_the_unbanded_one(shape, variance, monkeypatch):
+    """Round 6: host arrays of a large grid go up, and the analysis comes down, in six bands of tile rows beside the first pass; the tiles the
+    first pass leaves to the list passes are patched in by the host at the end.  Same bits as one upload / one download around the kernels
+    (GPP_OI_NO_BANDS), with odd row and column counts (partial tiles, bands that do not divide the tile rows), on the first call of a
+    geometry (read-back + serial list passes) and on the repeated one (list passes beside the first pass), with and without the variance,
+    into the mirror's page-locked result arrays and into pageable ones (bands up only)."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(shape[0])
+    Y, X = shape
+    S = 4000     # dense enough for a few hundred declined tiles (unions beyond 40 rows where observations cluster)
+    lats, lons = np.meshgrid(np.linspace(60, 61.5, Y), np.linspace(10, 13, X), indexing="ij")
+    plat = np.concatenate([rng.uniform(60, 61.5, S - 600), rng.normal(60.7, 0.02, 600)])
+    plon = np.concatenate([rng.uniform(10, 13, S - 600), rng.normal(11.3, 0.04, 600)])
+    bg = rng.normal(0, 1, (Y, X)).astype(np.float32)
+    bvar = rng.uniform(0.5, 2, (Y, X)).astype(np.float32)
+    obs, pbg = rng.normal(0, 1, S).astype(np.float32), rng.normal(0, 1, S).astype(np.float32)
+    ovar, bvp = rng.uniform(0.1, 1, S).astype(np.float32), rng.uniform(0.5, 2, S).astype(np.float32)
+    grid, points, st = gridpp.Grid(lats, lons), gridpp.Points(plat, plon), gridpp.BarnesStructure(8000)
+
+    def call():
+        if variance:
+            a, v = gridpp.optimal_interpolation_full(grid, bg, bvar, points, obs, ovar, pbg, bvp, st, 25)
+            return np.array(a), np.array(v)
+        return np.array(gridpp.optimal_interpolation(grid, bg, points, obs, ovar, pbg, st, 25)), None
+
+    monkeypatch.setenv("GPP_OI_NO_BANDS", "1")
+    ref_a, ref_v = call()
+    declined = gridpp.oi_last_stats()["fallback_tiles"]
+    assert declined > 20, declined     # (the patch must have something to do)
+    monkeypatch.delenv("GPP_OI_NO_BANDS")
+    for grid_fresh in (True, False, False):      # first call of a geometry, then the remembered-list path twice
+        if grid_fresh:
+            grid = gridpp.Grid(lats, lons)
+        a, v = call()
+        assert (a.view(np.uint32) == ref_a.view(np.uint32)).all(), int((a.view(np.uint32) != ref_a.view(np.uint32)).sum())
+        if variance:
+            assert (v.view(np.uint32) == ref_v.view(np.uint32)).all()
+    monkeypatch.setenv("GPP_PAGEABLE_RESULTS", "1")   # (the mirror then hands out ordinary numpy arrays: bands up, one copy down)
+    a, v = call()
+    assert (a.view(np.uint32) == ref_a.view(np.uint32)).all()
+    if variance:
+        assert (v.view(np.uint32) == ref_v.view(np.uint32)).all()
+    if variance:
+        return
+    # and the unbanded result against the oracle on a sample of rows
+    rows = rng.choice(Y, 6, replace=False)
+    og = O.Pts(lats[rows].ravel(), lons[rows].ravel())
+    ref = O.oi(og, bg[rows].ravel(), O.Pts(plat, plon), obs, ovar, pbg, O.Barnes(8000), 25).reshape(len(rows), X)
+    err = np.abs(ref_a[rows] - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-5, err.max()
