@@ -67,6 +67,7 @@ inline const char* path_env(const char* n) { return path_override(n); }
 // ---- device runtime ----------------------------------------------------------
 hipStream_t stream();   // library stream (created on first use, after the device is chosen)
 hipStream_t stream3();  // and a third (status copies of deferred calls)
+hipStream_t stream4();  // and a fourth (every other band of the banded host path of optimal_interpolation: the last, partly filled round of a band's workgroups beside the next band)
 hipStream_t stream2();  // a second one: work that runs BESIDE the library stream inside one call (ordered against it with events)
 void ensure_device();   // throws GPP_ENODEVICE when no GPU is visible
 

@@ -1698,7 +1698,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     }
     struct BandGuard {   // whatever ends the call: no copy of it stays in flight on the side streams (into arrays the caller may free)
         bool on;
-        ~BandGuard() { if(on) { (void)hipStreamSynchronize(stream2()); (void)hipStreamSynchronize(stream3()); } }
+        ~BandGuard() { if(on) { (void)hipStreamSynchronize(stream2()); (void)hipStreamSynchronize(stream3()); (void)hipStreamSynchronize(stream4()); } }
     } band_guard{banded};
     bool bands_down_done = false;   // the band downloads of this call are enqueued: the end of the call patches the declined tiles instead of copying everything
     // cells with more usable observations than the 62-row tile holds are listed: symmetric systems go to k_oi_big (Cholesky, up
@@ -1796,9 +1796,13 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 if(!banded) { launch_union(a.ntiles, false); return; }
                 static const int share[6] = {1, 2, 3, 3, 2, 1};
                 const int th = 64 >> a.wshift, trows = a.ntiles / a.tiles_x;
-                const hipStream_t sUp = stream2(), sDown = stream3();
+                const hipStream_t sUp = stream2(), sDown = stream3(), sOdd = stream4();
+                const bool two_streams = path_env("GPP_OI_BANDS_TWO_STREAMS") != nullptr;
+                // (the bands alternate between the library stream and a fourth one: the last round of a band's workgroups fills a fraction of the
+                //  chip, and in one stream the next band waits behind it -- six times ~45 us)
                 GPP_HIP(hipEventRecord(ws.ev_band0, stream()));
                 GPP_HIP(hipStreamWaitEvent(sUp, ws.ev_band0, 0));    // (the staging buffers' previous readers are behind the library stream)
+                GPP_HIP(hipStreamWaitEvent(sOdd, ws.ev_band0, 0));   // (and so is the status block the kernels count in, cleared by k_pack_obs)
                 int ty0 = 0, acc = 0;
                 for(int b = 0; b < 6; b++) {
                     acc += share[b];
@@ -1808,17 +1812,21 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                     GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bg.d) + off, background + off, cnt * sizeof(float), hipMemcpyHostToDevice, sUp));
                     if(bvariance) GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bvar.d) + off, bvariance + off, cnt * sizeof(float), hipMemcpyHostToDevice, sUp));
                     GPP_HIP(hipEventRecord(ws.ev_up[b], sUp));
-                    GPP_HIP(hipStreamWaitEvent(stream(), ws.ev_up[b], 0));
+                    const hipStream_t sK = ((b & 1) && two_streams) ? sOdd : stream();
+                    GPP_HIP(hipStreamWaitEvent(sK, ws.ev_up[b], 0));
                     a.tile0 = ty0 * a.tiles_x; a.tile_n = (ty1 - ty0) * a.tiles_x;
+                    cur = sK;
                     launch_union(a.tile_n, false);
+                    cur = stream();
+                    GPP_HIP(hipEventRecord(ws.ev_k[b], sK));
                     if(band_down) {
-                        GPP_HIP(hipEventRecord(ws.ev_k[b], stream()));
                         GPP_HIP(hipStreamWaitEvent(sDown, ws.ev_k[b], 0));
                         GPP_HIP(hipMemcpyAsync(out + off, f_out.d + off, cnt * sizeof(float), hipMemcpyDeviceToHost, sDown));
                         if(out_variance) GPP_HIP(hipMemcpyAsync(out_variance + off, f_var.d + off, cnt * sizeof(float), hipMemcpyDeviceToHost, sDown));
                     }
                     ty0 = ty1;
                 }
+                GPP_HIP(hipStreamWaitEvent(stream(), ws.ev_k[5], 0));   // (what follows on the library stream -- the list passes, the read-back -- is behind every band: 5 is the last of the fourth stream)
                 a.tile0 = 0; a.tile_n = a.ntiles;
                 bands_down_done = band_down;
             };

@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-static hipStream_t g_stream = nullptr, g_stream2 = nullptr, g_stream3 = nullptr;
+static hipStream_t g_stream = nullptr, g_stream2 = nullptr, g_stream3 = nullptr, g_stream4 = nullptr;
 static std::atomic<unsigned long long> g_next_serial{1};   // one counter for every instantiation of make_points<T>
 static std::atomic<int> g_live_handles{0};   // gpp_points alive (gpp_set_device refuses to switch under them)
 static int g_device = -1;
@@ -53,6 +53,12 @@ hipStream_t stream3() {
     std::lock_guard<std::mutex> lock(g_mutex);
     if(!g_stream3) GPP_HIP(hipStreamCreateWithFlags(&g_stream3, hipStreamNonBlocking));
     return g_stream3;
+}
+hipStream_t stream4() {
+    ensure_device();
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if(!g_stream4) GPP_HIP(hipStreamCreateWithFlags(&g_stream4, hipStreamNonBlocking));
+    return g_stream4;
 }
 
 }   // namespace gpp
@@ -189,6 +195,7 @@ extern "C" int gpp_release_workspaces(void) {
     GPP_HIP(hipStreamSynchronize(stream()));
     if(g_stream2) GPP_HIP(hipStreamSynchronize(g_stream2));
     if(g_stream3) GPP_HIP(hipStreamSynchronize(g_stream3));
+    if(g_stream4) GPP_HIP(hipStreamSynchronize(g_stream4));
     stage_release_all();
     gpp_release_ensi_workspace();
     gpp_release_oi_workspace();
@@ -219,10 +226,12 @@ extern "C" int gpp_set_device(int device) {
         if(g_stream) (void)hipStreamSynchronize(g_stream);
         if(g_stream2) (void)hipStreamSynchronize(g_stream2);
         if(g_stream3) (void)hipStreamSynchronize(g_stream3);
+        if(g_stream4) (void)hipStreamSynchronize(g_stream4);
         stage_release_all();   // (staging buffers of the device that is left)
         if(g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
         if(g_stream2) { (void)hipStreamDestroy(g_stream2); g_stream2 = nullptr; }
         if(g_stream3) { (void)hipStreamDestroy(g_stream3); g_stream3 = nullptr; }
+        if(g_stream4) { (void)hipStreamDestroy(g_stream4); g_stream4 = nullptr; }
         g_device = device;
         GPP_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     }
@@ -260,6 +269,7 @@ extern "C" int gpp_synchronize(void) {
     // (the streams beside the library stream carry work of deferred optimal-interpolation calls only; created on first use)
     if(g_stream2) GPP_HIP(hipStreamSynchronize(g_stream2));
     if(g_stream3) GPP_HIP(hipStreamSynchronize(g_stream3));
+    if(g_stream4) GPP_HIP(hipStreamSynchronize(g_stream4));
     return GPP_OK;
     GPP_CATCH
 }
@@ -552,6 +562,7 @@ extern "C" int gpp_points_destroy(gpp_points* p) {
         GPP_HIP(hipStreamSynchronize(g_stream));
         if(g_stream2) GPP_HIP(hipStreamSynchronize(g_stream2));
         if(g_stream3) GPP_HIP(hipStreamSynchronize(g_stream3));
+        if(g_stream4) GPP_HIP(hipStreamSynchronize(g_stream4));
     }
     delete p;
     return GPP_OK;

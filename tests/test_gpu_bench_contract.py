@@ -79,3 +79,58 @@ def test_other_cases_two_rank_logic(case, extra):
     assert out.returncode == 0, out.stderr[-3000:]
     r = _json_line(out.stdout)
     assert KEYS <= set(r) and r["n_gpus"] == 2 and r["value"] > 0 and r["roofline"]["achieved"] > 0
+
+
+def _torchrun(n, args, env_extra=None, timeout=1500):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GPP_BENCH_SHARE_GPU="1", GPP_BENCH_BACKEND="gloo", **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-other-configs"] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return _json_line(out.stdout)
+
+
+@pytest.mark.parametrize("mode", ["equal-tiles", "rebalanced"])
+def test_eight_rank_logic_on_one_gpu_oi(mode):
+    """The rank logic of the 8-GPU run as it will run on the node -- eight processes, eight row tiles of 500 rows, the three-slot observation
+    stream with one analysis ahead, max-over-ranks timing -- on ONE GPU over gloo (no RCCL: logic, not speed).  `rebalanced`: the row tiles
+    cut again by measured kernel time (forced: ranks sharing a device are further apart than the 50 % that normally rules a workload out)."""
+    args = ["--ny", "4000", "--nx", "512", "--obs", "2000"]
+    if mode == "equal-tiles":
+        r = _torchrun(8, args + ["--equal-tiles"])
+        assert r["kernel"]["cells_per_launch"] == 500 * 512
+    else:
+        r = _torchrun(8, args, {"GPP_BENCH_FORCE_REBALANCE": "1"})
+        note = r["config"]["row_tiles"]
+        assert len(note["equal_tiles_kernel_ms"]) == 8 and note["rebalanced"]
+        tiles = note["row_tiles"]
+        assert tiles[0][0] == 0 and tiles[-1][1] == 4000 and all(tiles[k][1] == tiles[k + 1][0] for k in range(7)) and all(t1 - t0 >= 8 for t0, t1 in tiles)
+        assert r["kernel"]["cells_per_launch"] == (tiles[0][1] - tiles[0][0]) * 512
+    assert KEYS <= set(r) and r["n_gpus"] == 8 and r["scaling"] == "strong" and r["value"] > 0
+    assert r["n_ranks_seen"] == {"env_WORLD_SIZE": 8, "torch_distributed": 8} or r["n_ranks_seen"]["torch_distributed"] == 8
+    assert "one analysis ahead" in r["config"]["calls"]
+
+
+@pytest.mark.parametrize("case,extra", [("ensi", ["--ny", "512", "--nx", "128", "--obs", "400"]), ("nbh", ["--ny", "4000", "--nx", "128"])])
+def test_eight_rank_logic_on_one_gpu_other_cases(case, extra):
+    """--case ensi (block broadcast) and nbh (4000 rows in eight tiles of 500 + 15 halo rows on either side: the 530-row tiles of the node)."""
+    r = _torchrun(8, ["--case", case] + extra)
+    assert KEYS <= set(r) and r["n_gpus"] == 8 and r["value"] > 0 and r["roofline"]["achieved"] > 0
+    assert r["n_ranks_seen"]["torch_distributed"] == 8
+
+
+def test_launch_scale_emits_one_line_per_rank_count():
+    """tools/launch_scale.sh -- the command sequence of the driver's scaling run -- leaves exactly one JSON line per N = 1, 2, 4, 8, each from a
+    run that saw N ranks (here all on GPU 0 over gloo, on a small grid)."""
+    env = dict(os.environ, GPP_BENCH_SHARE_GPU="1", GPP_BENCH_BACKEND="gloo", GPP_BENCH_EXTRA="--ny 1600 --nx 512 --obs 1500 --equal-tiles")
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "launch_scale.sh"), "oi", "2", "1"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=2400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rows = [json.loads(l) for l in open(os.path.join(ROOT, "gpurun_out", "scale_oi.jsonl")) if l.strip()]
+    assert [r["n_gpus"] for r in rows] == [1, 2, 4, 8], [r["n_gpus"] for r in rows]
+    for r in rows:
+        assert r["n_ranks_seen"]["torch_distributed"] == r["n_gpus"] and r["value"] > 0
+        assert "GPP_BENCH_SHARE_GPU" in r["env_overrides"]       # (recorded: such a line can never pass for a measurement)

@@ -13,13 +13,17 @@ mkdir -p gpurun_out
 OUT=gpurun_out/scale_$CASE.jsonl
 : > $OUT
 NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
+# GPP_BENCH_SHARE_GPU=1 (with GPP_BENCH_BACKEND=gloo): every rank on GPU 0 -- the logic test of a one-GPU box (tests/test_gpu_bench_contract.py),
+# never a measurement; GPP_BENCH_EXTRA: extra bench.py arguments for it (a smaller grid)
+[ "${GPP_BENCH_SHARE_GPU:-0}" = 1 ] && NGPU=8
+EXTRA=${GPP_BENCH_EXTRA:-}
 for N in 1 2 4 8; do
   [ "$N" -le "$NGPU" ] || { echo "skipping N=$N: $NGPU GPUs visible" >&2; continue; }
   if [ "$N" -eq 1 ]; then
-    python bench.py --gpus 1 --steps $STEPS --warmup $WARMUP --case $CASE --no-cpu-baseline --no-other-configs | tail -1 >> $OUT
+    python bench.py --gpus 1 --steps $STEPS --warmup $WARMUP --case $CASE --no-cpu-baseline --no-other-configs $EXTRA | grep '^{' | tail -1 >> $OUT
   else
     python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
-        bench.py --gpus $N --steps $STEPS --warmup $WARMUP --case $CASE --no-cpu-baseline --no-other-configs | grep '^{' | tail -1 >> $OUT
+        bench.py --gpus $N --steps $STEPS --warmup $WARMUP --case $CASE --no-cpu-baseline --no-other-configs $EXTRA | grep '^{' | tail -1 >> $OUT
   fi
 done
 python - "$OUT" <<'PY'
