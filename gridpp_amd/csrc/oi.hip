@@ -1722,6 +1722,9 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         GPP_HIP(hipGetLastError());
     };
     bool ran_union = false, ran_overlap = false;
+    // spatially varying Barnes structure on the tile path (round 6; no variance output: that needs a second substitution per cell)
+    const bool sp_union = spatial && plain && N == 32 && !f_var.d && !path_env("GPP_OI_NO_SP_UNION");
+    bool sp_failed = false, ran_sp = false;
     const bool async_req = (mem & GPP_ASYNC) && (mem & GPP_MEM_DEVICE) && !path_env("GPP_OI_NO_ASYNC");
     int async_slot = -1;
     // `steady`: a GPP_ASYNC call that will take the overlapped branch below (the conditions of `overlap`): it is deferred, and its observation
@@ -1763,7 +1766,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     int patch_n0 = 0, patch_n1 = 0;
     for(int attempt = 0; attempt < 2; ++attempt) {
         a.in_list = nullptr; a.in_count = nullptr; a.out_list = nullptr; a.out_count = nullptr; a.nrun = a.ntiles;
-        ran_union = false; ran_overlap = false;
+        ran_union = false; ran_overlap = false; ran_sp = false;
         if(use_union && !use_lu) {
             // worst case per list: every tile declined and split into 4 (level 1) resp. 16 (level 2) items
             const int SHORT_ITEMS = 3072;   // as many work items as the chip holds waves of this kernel
@@ -2020,6 +2023,45 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             }
             ran_union = true;
         }
+        else if(sp_union && !sp_failed) {
+            // spatially varying Barnes structure: one LU per tile (k_oi_union_sp), the tiles it declines to k_oi's pivoted LU as whole tiles
+            ws.fb_list.get((size_t)a.ntiles);
+            a.out_list = ws.fb_list.p; a.out_count = d_fb_count;
+            a.tile0 = 0; a.tile_n = a.ntiles;
+            hipLaunchKernelGGL(k_oi_union_sp<0>, dim3((unsigned)((a.ntiles + 1) / 2)), dim3(128), 0, stream(), a);
+            GPP_HIP(hipGetLastError());
+            GPP_HIP(hipEventRecord(ws.eu, stream()));
+            GPP_HIP(hipEventRecord(ws.e1, stream()));
+            fetch();
+            const int n1 = h_ints[1];
+            if(n1 > 0) {
+                // the declined tiles as smaller items (smaller unions), as on the scalar path: a short list straight to its 4-cell items, a long one
+                // through the 16-cell level; what is still left to k_oi's pivoted LU
+                ws.fb_list2.get(2 * (size_t)a.ntiles + 64);
+                ws.fb_list3.get(std::max<size_t>(4 * (size_t)a.ntiles, (size_t)3072) + 64);
+                auto launch_sp_list = [&](const long items) {
+                    const long nb = (items + UnionCfg<32>::WPB - 1) / UnionCfg<32>::WPB;
+                    hipLaunchKernelGGL((k_oi_union<true, true, 32, true>), dim3((unsigned)std::min<long>(nb, 0x7fffffffL)), dim3(64 * UnionCfg<32>::WPB), 0, stream(), a);
+                    GPP_HIP(hipGetLastError());
+                };
+                if(16 * (long)n1 <= 3072) {
+                    a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 3;
+                    launch_sp_list(16 * (long)n1);
+                }
+                else {
+                    a.in_list = ws.fb_list.p; a.in_count = d_fb_count; a.out_list = ws.fb_list2.p; a.out_count = d_fb_count + 1; a.level = 1;
+                    launch_sp_list(4 * (long)n1);
+                    a.in_list = ws.fb_list2.p; a.in_count = d_fb_count + 1; a.out_list = ws.fb_list3.p; a.out_count = d_fb_count + 2; a.level = 2;
+                    a.parent_count = d_fb_count;
+                    launch_sp_list(16 * (long)n1);
+                }
+                a.in_list = ws.fb_list3.p; a.in_count = d_fb_count + 2; a.out_list = nullptr; a.out_count = nullptr; a.nrun = 4 * 512;
+                launch_k_oi(true);
+                GPP_HIP(hipEventRecord(ws.e1, stream()));
+                fetch();
+            }
+            ran_sp = true;
+        }
         else {
             const bool pairs = pairs_ok && !use_lu;
             if(pairs) park_on(false);    // (k_oi visits every cell)
@@ -2031,7 +2073,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
         // (with the list passes beside the first pass its out_list holds only the tiles the memory did not know: overlap_new of them)
         const int n_listed = ran_union ? h_ints[1] : 0;             // entries of ws.fb_list written by this call's first pass
         const int nfb[3] = {ran_overlap ? overlap_remembered + overlap_new : n_listed, ran_union ? h_ints[2] : 0, ran_overlap ? overlap_left : (ran_union ? h_ints[3] : 0)};
-        g_stats.fallback_tiles = nfb[0];
+        g_stats.fallback_tiles = ran_sp ? h_ints[1] : nfb[0];
         g_stats.fallback_subtiles = nfb[2];
         // (banded host path: the tiles whose cells the band downloads took too early -- everything the first pass did not finish itself)
         if(ran_overlap) { patch_l0 = memo.list.p; patch_n0 = overlap_remembered; patch_l1 = ws.fb_list.p; patch_n1 = overlap_new; }
@@ -2095,6 +2137,12 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 g_stats.big_cells = nbig;
             }
         }
+        if((err & ERR_SINGULAR) && ran_sp && !sp_failed) {   // a pivot of the unpivoted tile LU vanished: the whole call on the pivoted LU of k_oi
+            sp_failed = true;
+            g_stats.fallback_tiles = a.ntiles;
+            GPP_HIP(hipMemsetAsync(status_b->p, 0, SB * sizeof(unsigned long long), stream()));
+            continue;
+        }
         if((err & ERR_SINGULAR) && !use_lu) {   // a pivot was not positive: redo the call with the pivoted LU, as LAPACK would
             use_lu = true;
             g_stats.fallback_tiles = a.ntiles;
@@ -2148,7 +2196,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     GPP_HIP(hipEventElapsedTime(&ms, ws.e0, ws.e1));
     g_stats.kernel_ms = ms;
     g_stats.union_kernel_ms = 0;
-    if(ran_union) GPP_HIP(hipEventElapsedTime(&g_stats.union_kernel_ms, ws.e0, ws.eu));
+    if(ran_union || (ran_sp && !sp_failed)) GPP_HIP(hipEventElapsedTime(&g_stats.union_kernel_ms, ws.e0, ws.eu));
     g_stats.cells_updated = 0; g_stats.solves = 0;
     for(int k = 0; k < GPP_NSLOT; k++) { g_stats.cells_updated += (long long)counters[80 + 2 * k]; g_stats.solves += (long long)counters[81 + 2 * k]; }
     if(timing_env("GPP_SCAN_STATS")) fprintf(stderr, "[gpp] scan: %llu candidates iterated, %llu survivor-branch executions, %d tiles\n", counters[2], counters[3], a.ntiles);

@@ -163,11 +163,15 @@ struct PairLds {
     float dmax, dmin;                 // extremes of obs - background over the shared core (oi.cpp:318-334), from the eliminating wave
 };
 
-// doubles of the shared-factor area a union of c core and nE extras rows needs (layouts: see the solve)
-template <int NC>
+// doubles of the shared-factor area a union of c core and nE extras rows needs (layouts: see the solve).  COLS: the packed-column / packed-row
+// layouts (GPP_UNION_COLS, and the LU of the spatially varying form); else the row-packed Cholesky layout of the product.
+#ifndef GPP_UNION_COLS
+#define GPP_UNION_COLS 0
+#endif
+template <int NC, bool COLS>
 __device__ __forceinline__ int union_solve_doubles(const int c, const int nE) {
-    if constexpr(NC == 32) return c * (c + nE + 1) - c * (c - 1) / 2 + c + nE * nE + nE;   // packed columns, 1/diag, Schur complement, d'
-    else return c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE + 3;                  // (+ 3: the padding reads of the per-cell finish behind the last row of B)
+    if constexpr(COLS) return c * (c + nE + 1) - c * (c - 1) / 2 + c + nE * nE + nE;   // packed columns (rows of U), 1/diag, Schur complement, d'
+    else return c * (c + 1) / 2 + 2 * c + nE * (c | 1) + nE * nE + nE + 3;             // (+ 3: the padding reads of the per-cell finish behind the last row of B)
 }
 __device__ __forceinline__ double rsqrt_nr(const double a) {
     double rs = __builtin_amdgcn_rsq(a);
@@ -193,11 +197,20 @@ __device__ __forceinline__ double rsqrt_nr(const double a) {
 // to update, or was declined by its scan -- goes on as two independent single-tile items, exactly the code below without PAIR.
 // Barriers (workgroup = the pair): B1 behind the scans (only when both waves run), B2 behind the merge (only when both states are 0), B3 behind
 // the export (only when paired); every condition is computed from values both waves read identically, so the counts always agree.
-template <bool PLAIN, bool LIST, int NC, bool PAIR = false>
+//
+// SP (round 6, k_oi_union_sp): a spatially varying Barnes structure -- h, v, w and the localization distance looked up at the FIRST point of
+// corr(p1, p2) (src/api/structure.cpp:188-214).  The cells of a tile still select almost the same observations, but P is not symmetric
+// (row i carries the scales at observation i, oi.cpp:304-312), so the shared factor is an LU of the core block: rows in lanes as before, no
+// pivoting (P + R of a correlation function with mildly varying scales; a vanishing pivot raises the error flag and the call is redone by the
+// pivoted LU of k_oi, like a non-positive pivot of the Cholesky form), the rows of U dumped to LDS as they become final -- which is also the
+// broadcast of the rank-1 update --, late columns and obs - background substituted against L afterwards, and the per-cell finish sweeps the
+// rows of U: increment = (U^-T g) . (L^-1 d).  No variance output (it needs L^-1 g as well: those calls stay on k_oi).
+template <bool PLAIN, bool LIST, int NC, bool PAIR = false, bool SP = false>
 __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, const int shift, UnionLds<NC>& L, const int lane,
                                            const bool partner = false, const int pw = 0, const int lead = 0, UnionLds<NC>* const Lall = nullptr, PairLds* const PP = nullptr) {
     constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE;
     static_assert(!PAIR || (NC == 32 && !LIST), "the pair form exists for the first pass of the 32-column kernel only");
+    static_assert(!SP || (PLAIN && NC == 32 && !PAIR), "the spatially varying form exists for the 32-column Barnes kernel only");
     tile = __builtin_amdgcn_readfirstlane(tile); sub = __builtin_amdgcn_readfirstlane(sub);
 #ifdef GPP_UNION_PROFILE
     if(lane < 24) L.prof[lane] = 0u;   // (in LDS: sixteen accumulators in scalar registers spill the kernel into another one)
@@ -226,7 +239,8 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
     DevStructure st = a.s.st;
     const ScanArgs& sa = a.s;
     float sa_inv_s = sa.inv_s;
-    if constexpr(!LIST) asm volatile("" : "+s"(st.h), "+s"(st.v), "+s"(st.w), "+s"(st.R), "+s"(sa_inv_s));
+    if constexpr(SP) { if(cell >= 0) d_structure_at(st, st.cell_idx ? st.cell_idx[cell] : cell); }   // this cell's scales: rho(cell, observation) takes them at the cell
+    else if constexpr(!LIST) asm volatile("" : "+s"(st.h), "+s"(st.v), "+s"(st.w), "+s"(st.R), "+s"(sa_inv_s));
 
     // ================= candidate scan (the walk of scan_tile; selections kept as rho[slot][lane]) =================
     UPROF(0);   // cell loads issued
@@ -243,7 +257,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
     // terrain the worst kept rho of a cell is small, so the horizontal cut alone let 5 x as many candidates through as on flat ground, each
     // evaluated for all 64 cells).  A cell without elevation takes the factor 1: then there is no extent.
     float emin_t = -INFINITY, emax_t = INFINITY, lmin_t = -INFINITY, lmax_t = INFINITY, kv2 = 0.0f, kw2 = 0.0f;
-    if constexpr(PLAIN) {
+    if constexpr(PLAIN && !SP) {   // (SP: the ratios differ from cell to cell; the horizontal prune alone)
         if(d_valid(st.v) && st.v != 0.0f && d_valid(st.h) && st.h != 0.0f) {
             emin_t = wave_min(active ? (d_valid(ge) ? ge : -INFINITY) : INFINITY); emax_t = wave_max(active ? (d_valid(ge) ? ge : INFINITY) : -INFINITY);
             kv2 = (st.h / st.v) * (st.h / st.v) * 0.9999f;
@@ -352,6 +366,8 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         // PLAIN: straight-line code (selects instead of branches) so that two candidates evaluated back to back interleave.
         const bool hv = d_valid(st.v) && st.v != 0.0f, hw = d_valid(st.w) && st.w != 0.0f, hh = d_valid(st.h) && st.h != 0.0f;
         const double rh = hh ? 1.0 / (double)st.h : 0.0, rv_ = hv ? 1.0 / (double)st.v : 0.0, rw_ = hw ? 1.0 / (double)st.w : 0.0;
+        // (SP: the scales are this lane's; the tests around the vertical / laf factors stay wave-uniform -- "some cell has one")
+        const bool hvu = SP ? wave_ballot(hv) != 0ull : hv, hwu = SP ? wave_ballot(hw) != 0ull : hw;
         auto eval = [&](const float4& rec, const float2& met, const int c) {
             const float ox = readlane_f(rec.x, c), oy = readlane_f(rec.y, c), oz = readlane_f(rec.z, c);
             const float dx = ox - gx, dy = oy - gy, dz = oz - gz;
@@ -368,13 +384,13 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             float rho = 0.0f;
             if constexpr(PLAIN) {
                 rho = hh ? d_barnes_rho_flat(dist, rh) : 1.0f;
-                if(hv) {
+                if(hvu) {
                     const float oe = readlane_f(rec.w, c);
-                    if(d_valid(oe)) { const float f = d_barnes_rho_flat(ge - oe, rv_); rho = d_valid(ge) ? rho * f : rho; }
+                    if(d_valid(oe)) { const float f = d_barnes_rho_flat(ge - oe, rv_); rho = (hv && d_valid(ge)) ? rho * f : rho; }
                 }
-                if(hw) {
+                if(hwu) {
                     const float ol = readlane_f(met.x, c);
-                    if(d_valid(ol)) { const float f = d_barnes_rho_flat(gl - ol, rw_); rho = d_valid(gl) ? rho * f : rho; }
+                    if(d_valid(ol)) { const float f = d_barnes_rho_flat(gl - ol, rw_); rho = (hw && d_valid(gl)) ? rho * f : rho; }
                 }
                 rho = ok ? rho : 0.0f;
             }
@@ -420,24 +436,24 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             // (the wave-uniform tests around whole groups of EV chains, not inside them: a branch ends the block the scheduler interleaves in)
 #pragma unroll
             for(int q = 0; q < EV; ++q) rho[q] = 1.0f;
-            if(hh) {
+            if(SP ? wave_ballot(hh) != 0ull : hh) {
 #pragma unroll
-                for(int q = 0; q < EV; ++q) rho[q] = d_barnes_rho_flat(dist[q], rh);
+                for(int q = 0; q < EV; ++q) { const float f = d_barnes_rho_flat(dist[q], rh); rho[q] = hh ? f : 1.0f; }
             }
-            if(hv) {
+            if(hvu) {
 #pragma unroll
                 for(int q = 0; q < EV; ++q) {
                     const float oe = readlane_f(rec.w, cc[q]);
                     const float f = d_barnes_rho_flat(d_valid(oe) ? ge - oe : 0.0f, rv_);
-                    rho[q] = (d_valid(oe) && d_valid(ge)) ? rho[q] * f : rho[q];
+                    rho[q] = (hv && d_valid(oe) && d_valid(ge)) ? rho[q] * f : rho[q];
                 }
             }
-            if(hw) {
+            if(hwu) {
 #pragma unroll
                 for(int q = 0; q < EV; ++q) {
                     const float ol = readlane_f(met.x, cc[q]);
                     const float f = d_barnes_rho_flat(d_valid(ol) ? gl - ol : 0.0f, rw_);
-                    rho[q] = (d_valid(ol) && d_valid(gl)) ? rho[q] * f : rho[q];
+                    rho[q] = (hw && d_valid(ol) && d_valid(gl)) ? rho[q] * f : rho[q];
                 }
             }
 #pragma unroll
@@ -780,7 +796,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                 const unsigned long long pextA = liveA & ~pcore;
                 const unsigned long long bonly = wave_ballot(pb >= 0 && partA < 0);
                 const int c2 = __popcll(pcore), nEa = __popcll(pextA), nE2 = nEa + __popcll(bonly), u2 = c2 + nE2;
-                const bool fits = u2 <= U_MAXU && nE2 <= U_MAXE && union_solve_doubles<NC>(c2, nE2) <= U_SOLVE;
+                const bool fits = u2 <= U_MAXU && nE2 <= U_MAXE && union_solve_doubles<NC, (NC == 32 && GPP_UNION_COLS != 0) || SP>(c2, nE2) <= U_SOLVE;
                 int sA = -1, sB = -1;
                 {
                     const unsigned long long mk = lane < c2 ? pcore : (lane < c2 + nEa ? pextA : bonly);
@@ -817,7 +833,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
     }
     if(!paired && !fb && upd != 0ull) {
         c = __popcll(coreM); nE = __popcll(extM); u = c + nE;
-        if(u > U_MAXU || nE > U_MAXE || union_solve_doubles<NC>(c, nE) > U_SOLVE) {
+        if(u > U_MAXU || nE > U_MAXE || union_solve_doubles<NC, (NC == 32 && GPP_UNION_COLS != 0) || SP>(c, nE) > U_SOLVE) {
             fb = true;
             if(UNION_STATS && lane == 0) atomicAdd(&a.counters[u > U_MAXU ? 5 : (nE > U_MAXE ? 6 : 7)], 1ull);
         }
@@ -844,6 +860,8 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             myslot = lane < c ? nth_set_bit(coreM, lane) : (lane < u ? nth_set_bit(extM, lane - c) : 0);
             mypos = L.wpos[myslot];
         }
+        int oorig = 0;     // SP: the observation (original order) of this row -- its scales are looked up there
+        if constexpr(SP) oorig = L.worig[myslot];
         float4 o0 = make_float4(0, 0, 0, NAN), o1 = make_float4(NAN, 0, 0, 0);
         if(solver && lane < u) {
             o0 = sa.pgeo[mypos];
@@ -885,15 +903,197 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         // instead of 14.3 k (profiles/r06_union_phases.txt).  Half as many serial steps bought nothing: the kernel is bound by the instructions it
         // issues (VALU 78 % busy), and the column forms issue more of them (496 instead of 378 multiply-adds in the sweep, a per-lane LDS read per
         // extra and column).  The row form stays the product.
-#ifndef GPP_UNION_COLS
-#define GPP_UNION_COLS 0
-#endif
         constexpr bool COLS = NC == 32 && GPP_UNION_COLS != 0;
         const int FAC = c * (u + 1) - c * (c - 1) / 2;
-        const int oL = 0, oI = COLS ? FAC : c * (c + 1) / 2, oZ = oI + c, oB = oZ + c, bs = c | 1, oS = COLS ? oI + c : oB + nE * bs, oD = oS + nE * nE;
+        const int oL = 0, oI = (COLS || SP) ? FAC : c * (c + 1) / 2, oZ = oI + c, oB = oZ + c, bs = c | 1, oS = (COLS || SP) ? oI + c : oB + nE * bs, oD = oS + nE * nE;
         double* const sv = LS.f.solve;
         bool bad = false;
         float maxInc = -INFINITY, minInc = INFINITY;
+        double inc = 0.0, a00 = 0.0;
+        const int mmax = __builtin_amdgcn_readfirstlane((int)wave_max((float)m));
+        if constexpr(SP) {
+            // ================= spatially varying structure: LU of the core block, rows of U in LDS (layout: row j < c of U -- columns j .. u-1, then
+            // (L^-1 d)_j -- at CO(j) = j (u + 1) - j (j - 1) / 2; behind the rows 1 / u_jj, the Schur complement of the extras (nE x nE, both
+            // triangles), d') ====================================================================================================================
+            const DevStructure& su = a.s.st;
+            float* const colbuf = reinterpret_cast<float*>(L.f.solve);     // [u][U_MAXU] floats: P(row i, column p) at [p][i]  (6 400 B)
+            double* const rsc = L.f.solve + 800;                           // reciprocal scales of every row: 1/h [40], 1/v [40], 1/w [40] (0: that factor is 1)
+            float* const rR = reinterpret_cast<float*>(L.f.solve + 920);   // localization distance of every row [40]
+            if(lane < u) {
+                const int fi = su.obs_idx[oorig];
+                const float h_i = su.fh[fi], v_i = su.fv[fi], w_i = su.fw[fi];
+                rsc[lane] = (d_valid(h_i) && h_i != 0.0f) ? 1.0 / (double)h_i : 0.0;
+                rsc[40 + lane] = (d_valid(v_i) && v_i != 0.0f) ? 1.0 / (double)v_i : 0.0;
+                rsc[80 + lane] = (d_valid(w_i) && w_i != 0.0f) ? 1.0 / (double)w_i : 0.0;
+                rR[lane] = su.fR[fi];
+                L.orec[lane] = o0; L.olaf[lane] = o1.x;
+            }
+            const bool anyv = wave_ballot(lane < u && rsc[40 + (lane < u ? lane : 0)] != 0.0) != 0ull, anyw = wave_ballot(lane < u && rsc[80 + (lane < u ? lane : 0)] != 0.0) != 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // P(i, p) = corr(observation i, observation p) with the scales AT OBSERVATION i (oi.cpp:304-312, structure.cpp:188-214): every entry of
+            // the u x u matrix, one per lane and pass
+            const int nent = u * u;
+            for(int e0 = 0; e0 < nent; e0 += 64) {
+                const int e = min(e0 + lane, nent - 1);
+                const int i = (int)(((float)e + 0.5f) / (float)u), pcol = e - i * u;
+                const float4 ri = L.orec[i], rp = L.orec[pcol];
+                const float hd = d_chord(ri.x, ri.y, ri.z, rp.x, rp.y, rp.z);
+                float cv = d_barnes_rho_flat(hd, rsc[i]);
+                if(anyv) { const float f = d_barnes_rho_flat((d_valid(ri.w) && d_valid(rp.w)) ? ri.w - rp.w : 0.0f, rsc[40 + i]); cv = (d_valid(ri.w) && d_valid(rp.w)) ? cv * f : cv; }
+                if(anyw) { const float li = L.olaf[i], lp = L.olaf[pcol]; const float f = d_barnes_rho_flat((d_valid(li) && d_valid(lp)) ? li - lp : 0.0f, rsc[80 + i]); cv = (d_valid(li) && d_valid(lp)) ? cv * f : cv; }
+                cv = hd > rR[i] ? 0.0f : cv;
+                if(e0 + lane < nent) colbuf[pcol * U_MAXU + i] = cv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            UPROF(7);   // P build
+            // rows in lanes: the 32 register columns, the late columns 32 .. 39 (as they are: substituted behind the elimination), obs - background
+            double row[NC];
+#pragma unroll
+            for(int p = 0; p < NC; ++p) {
+                double v = 0.0;
+                if(p < u && lane < u) { v = (double)colbuf[p * U_MAXU + lane]; if(lane == p) v += (double)o1.w; }     // lP + lR
+                row[p] = v;
+            }
+            float lt[8];
+#pragma unroll
+            for(int b = 0; b < 8; ++b) lt[b] = (32 + b < u && lane < u) ? colbuf[(32 + b) * U_MAXU + lane] : 0.0f;
+            const double dcol = lane < u ? (double)o1.y - (double)o1.z : 0.0;                                           // lObs - lY
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            auto rcp_nr = [](const double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); r = r * (2.0 - x * r); return r; };
+            {
+                int co = 0;
+#pragma unroll
+                for(int j = 0; j < NC; ++j) {
+                    if(j < c) {
+                        const double piv = readlane_d(row[j], j);
+                        if(!(fabs(piv) > 1e-290)) bad = true;     // (also NaN)
+                        const double rp = rcp_nr(piv);
+                        if(lane == j) {   // row j of U is final: to its place -- which is also where the rank-1 update below reads it
+                            sv[oI + j] = rp;
+#pragma unroll
+                            for(int p = j; p < NC; ++p) if(p < u) sv[co + p - j] = row[p];
+                        }
+                        const double mlt = lane > j ? row[j] * rp : 0.0;     // (rows >= u hold zeros)
+                        if(lane > j) row[j] = mlt;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const double* const q = sv + co - j;
+#pragma unroll
+                        for(int p = j + 1; p < NC; ++p) row[p] = __builtin_fma(-mlt, q[p], row[p]);     // (p >= u: registers nobody reads)
+                        co += u + 1 - j;
+                    }
+                }
+            }
+            UPROF(8);   // row load + elimination
+            // late columns and obs - background against L: a core lane ends with its entry of U resp. of L^-1 d, an extras lane with its entry of
+            // the Schur complement resp. of d'
+            const int ea = lane - c;
+            const int myco = lane * (u + 1) - lane * (lane - 1) / 2;     // CO(lane)
+            auto subst = [&](double t) {
+#pragma unroll
+                for(int j = 0; j < NC; ++j) {
+                    if(j < c) { const double tj = readlane_d(t, j); t = lane > j ? __builtin_fma(-row[j], tj, t) : t; }
+                }
+                return t;
+            };
+#pragma unroll
+            for(int b = 0; b < 8; ++b) {
+                const int p = 32 + b;
+                if(p < u) {
+                    const double t = subst((double)lt[b] + (lane == p ? (double)o1.w : 0.0));
+                    if(lane < c) sv[myco + p - lane] = t;
+                    else if(lane < u) sv[oS + ea * nE + (p - c)] = t;
+                }
+            }
+            {
+                const double t = subst(dcol);
+                if(lane < c) sv[myco + u - lane] = t;
+                else if(lane < u) sv[oD + ea] = t;
+            }
+#pragma unroll
+            for(int p = 0; p < NC; ++p) {
+                if(p >= c && p < u) { if(lane >= c && lane < u) sv[oS + ea * nE + (p - c)] = row[p]; }
+            }
+            if(!a.allow_extrap) {   // oi.cpp:318-334: extremes of obs - background over the core (every cell selects it)
+                maxInc = wave_max(lane < c ? dpf : -INFINITY);
+                minInc = wave_min(lane < c ? dpf : INFINITY);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            UPROF(9);   // export
+            // ---- per cell: t = U^-T g by sweeping the rows of U (row j updates every later entry at once; the entries of this cell's own extras
+            //      ride along: they end as g_X - B_col^T t_C), then the LU of the cell's own block of the Schur complement
+            double z[NC];
+#pragma unroll
+            for(int k = 0; k < NC; ++k) z[k] = (double)gf[k];
+            double qx[U_MAXM];
+            const double* xp[U_MAXM];
+#pragma unroll
+            for(int i = 0; i < U_MAXM; ++i) {
+                const int ai = (elist >> (4 * i)) & 15;
+                qx[i] = (i < mmax) ? (double)L.f.erho[ai][lane] : 0.0;
+                xp[i] = sv + c + ai;
+            }
+            {
+                int co = 0;
+#pragma unroll
+                for(int j = 0; j < NC; ++j) {
+                    if(j < c) {
+                        const double* const ur = sv + co - j;      // ur[k]: U(j, k); ur[u]: (L^-1 d)_j
+                        const double zj = z[j] * sv[oI + j];
+                        inc = __builtin_fma(zj, ur[u], inc);
+#pragma unroll
+                        for(int k = j + 1; k < NC; ++k) z[k] = __builtin_fma(-ur[k], zj, z[k]);
+#pragma unroll
+                        for(int i = 0; i < U_MAXM; ++i) if(i < mmax) { qx[i] = __builtin_fma(-*xp[i], zj, qx[i]); xp[i] += u - j; }
+                        co += u + 1 - j;
+                    }
+                }
+            }
+            if(mmax > 0) {
+                double lu[U_MAXM][U_MAXM], iu[U_MAXM], tq[U_MAXM], yd[U_MAXM];
+#pragma unroll
+                for(int i = 0; i < U_MAXM; ++i) {
+                    if(i < mmax) {
+                        const int ai = (elist >> (4 * i)) & 15;
+                        const bool valid = i < m;
+#pragma unroll
+                        for(int jj = 0; jj < U_MAXM; ++jj) {
+                            if(jj < mmax) {
+                                const int aj = (elist >> (4 * jj)) & 15;
+                                double sij = sv[oS + ai * nE + aj];
+#pragma unroll
+                                for(int k = 0; k < (i < jj ? i : jj); ++k) sij = __builtin_fma(-lu[i][k], lu[k][jj], sij);
+                                lu[i][jj] = jj < i ? sij * iu[jj] : sij;
+                            }
+                        }
+                        if(valid && !(fabs(lu[i][i]) > 1e-290)) bad = true;
+                        iu[i] = rcp_nr(valid ? lu[i][i] : 1.0);
+                        double y = sv[oD + ai], t = qx[i];
+#pragma unroll
+                        for(int k = 0; k < i; ++k) { y = __builtin_fma(-lu[i][k], yd[k], y); t = __builtin_fma(-lu[k][i], tq[k], t); }
+                        yd[i] = y;
+                        tq[i] = t * iu[i];
+                        if(valid) {
+                            inc = __builtin_fma(tq[i], yd[i], inc);
+                            if(!a.allow_extrap) {
+                                const float de = __int_as_float(LS.worig[ai]);
+                                maxInc = fmaxf(maxInc, de); minInc = fminf(minInc, de);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        else {
         if(solver) {
         // lower triangle of P (oi.cpp:304-312), one entry per lane and pass: entry e = i (i + 1) / 2 + p, p <= i
         if(lane < u) { L.orec[lane] = o0; L.olaf[lane] = o1.x; }
@@ -1151,8 +1351,6 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
 
         UPROF(9);   // export
         // ============= per cell (lane): forward substitution of G against L_C, then its own extras ==================
-        double inc = 0.0, a00 = 0.0;
-        const int mmax = __builtin_amdgcn_readfirstlane((int)wave_max((float)m));
         if constexpr(COLS) {
         // Column sweep: z_k = z_k / l_kk is final once the columns before k have been applied; column k then updates every later row at once --
         // independent multiply-adds behind ONE dependent pair per column, where the row form had a dot product of k terms in front of every
@@ -1297,6 +1495,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             }
         }
         }
+        }   // !SP
         UPROF(10);  // per-lane finish
         if(cnt > 0) {
             float increment = (float)inc;   // oi.cpp:317
@@ -1329,8 +1528,8 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
 // one tile per wave and four waves per workgroup the LDS of a workgroup stayed allocated until its slowest tile was done (the other
 // three waves idle: tile times differ by their evictions and ring work), and the next workgroup could not start before.
 // LIST = true: one item per wave, the grid sized by the host for the longest list that can arrive.
-template <bool PLAIN, bool LIST, int NC>
-__global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
+template <bool PLAIN, bool LIST, int NC, bool SP = false>   // (SP: only its list passes run through this kernel; its first pass is k_oi_union_sp)
+__global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : ((PLAIN && !SP) ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
     constexpr int WPB = UnionCfg<NC>::WPB;
     __shared__ UnionLds<NC> s_u[WPB];
     if constexpr(PLAIN) { d_exptab_fill<64 * WPB>(); __syncthreads(); }   // 2^(j/128) for d_exp_core
@@ -1362,7 +1561,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : (PLAIN ? 3 :
             if(a.level == 1) { tile = e; sub = child; shift = 4; }
             else { tile = e >> 5; sub = ((e & 31) - 16) * 4 + child; shift = 2; }
         }
-        union_item<PLAIN, true, NC>(a, tile, sub, shift, s_u[wid], lane);
+        union_item<PLAIN, true, NC, false, SP>(a, tile, sub, shift, s_u[wid], lane);
     }
     else if constexpr(!UnionCfg<NC>::template persistent<PLAIN>()) {   // (the other forms keep one tile per wave: the loop costs them registers they do not have)
         const int t = blockIdx.x * WPB + wid, tile = a.tile0 + t;   // (tile0 / tile_n: the band of tile rows this launch covers -- all tiles, or one band of the banded host path, oi.hip)
@@ -1426,6 +1625,18 @@ __global__ __launch_bounds__(128, PLAIN ? 3 : 2) void k_oi_union_pair(OiArgs a) 
     // factorisations).  A bit of the workgroup index that changes between the workgroups resident on a CU spreads the role.
     const int lead = (int)(__builtin_popcount(blockIdx.x * 2654435761u) & 1);
     union_item<PLAIN, false, 32, true>(a, t0 + wid, -1, 0, s_u[wid], lane, run0 && run1 && !a.pair_solo, wid, lead, s_u, &s_p);
+}
+
+// First pass for a spatially varying Barnes structure (round 6; see SP in union_item): one LU per tile.  What it declines goes through the list
+// passes (k_oi_union<true, true, 32, true>: 16-cell and 4-cell items) and, what those decline, to k_oi (pivoted LU per distinct selection).
+template <int V>      // (a template only so that the header can be included by two translation units)
+__global__ __launch_bounds__(128, 2) void k_oi_union_sp(OiArgs a) {
+    __shared__ UnionLds<32> s_u[2];
+    d_exptab_fill<128>();
+    __syncthreads();
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 2 + wid;
+    if(t < a.tile_n) union_item<true, false, 32, false, true>(a, a.tile0 + t, -1, 0, s_u[wid], lane);
 }
 
 // grid of the persistent first pass: as many workgroups as the chip holds of this kernel at once (asked once per kernel), at most one per WPB tiles

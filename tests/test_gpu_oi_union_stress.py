@@ -461,3 +461,60 @@ def test_anisotropic_grids_pick_a_matching_tile_shape(shape):
         finally:
             del os.environ["GPP_TILE_WSHIFT"]
         _check(out_w, ref)
+
+
+@pytest.mark.parametrize("seed", range(600, 616))
+def test_random_configurations_spatially_varying_barnes_on_the_tile_path(seed, monkeypatch):
+    """k_oi_union_sp (round 6): a Barnes structure whose scales vary in space -- P is not symmetric (corr(p1, p2) takes the scales at p1,
+    structure.cpp:188-214), the shared factor of a tile is an unpivoted LU of its core block.  Random grids and densities (partial tiles, unions
+    from a handful to far beyond the 40-row limit: the 16-cell / 4-cell list passes and the pivoted LU of k_oi behind them), smooth and
+    white-noise scale fields of +-30 %, with and without vertical / laf scales, missing elevations, anti-extrapolation, max_points 1..32 --
+    against the oracle, and bit for bit nothing: the pivoted LU per selection (GPP_OI_NO_SP_UNION) is a different elimination order."""
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    rng = np.random.default_rng(9000 + seed)
+    Y, X = int(rng.integers(9, 70)), int(rng.integers(9, 70))
+    S = int(rng.choice([12, 60, 250, 900]))
+    base = float(rng.choice([4000.0, 9000.0, 20000.0]))
+    mp = int(rng.choice([1, 3, 10, 20, 30, 32]))
+    ext = float(rng.choice([0.2, 0.5, 1.0]))
+    lats, lons = np.meshgrid(np.linspace(60, 60 + ext, Y), np.linspace(10, 10 + 2 * ext, X), indexing="ij")
+    with_v = seed % 3 != 0
+    ge = (200 + 150 * np.sin(7 * lats) * np.cos(5 * lons)).astype(np.float32) if with_v else np.zeros((Y, X), np.float32)
+    gl = np.clip(0.5 + 0.5 * np.sin(11 * lons), 0, 1).astype(np.float32) if with_v else np.zeros((Y, X), np.float32)
+    plat, plon = 60 + ext * rng.random(S), 10 + 2 * ext * rng.random(S)
+    pe = rng.uniform(50, 350, S).astype(np.float32) if with_v else np.zeros(S, np.float32)
+    pl = rng.uniform(0, 1, S).astype(np.float32) if with_v else np.zeros(S, np.float32)
+    if with_v and seed % 4 == 1:
+        pe[rng.random(S) < 0.1] = np.nan
+    if seed % 2:
+        hf = (base * rng.uniform(0.7, 1.3, (Y, X))).astype(np.float32)
+    else:
+        hf = (base * (1 + 0.3 * np.sin(9 * lats) * np.cos(6 * lons))).astype(np.float32)
+    vf = (300 * rng.uniform(0.8, 1.2, (Y, X))).astype(np.float32) if with_v else np.zeros((Y, X), np.float32)
+    wf = (0.6 * rng.uniform(0.8, 1.2, (Y, X))).astype(np.float32) if (with_v and seed % 2) else np.zeros((Y, X), np.float32)
+    bg = rng.normal(0, 2, (Y, X)).astype(np.float32)
+    if seed % 5 == 2:
+        bg[rng.random((Y, X)) < 0.02] = np.nan
+    obs, pbg = rng.normal(0, 2, S).astype(np.float32), rng.normal(0, 2, S).astype(np.float32)
+    ratios = rng.uniform(0.05, 2, S).astype(np.float32)
+    allow = bool(seed % 2)
+    min_rho = 0.0013
+    grid = gridpp.Grid(lats, lons, ge, gl)
+    points = gridpp.Points(plat, plon, pe, pl)
+    st = gridpp.BarnesStructure(grid, hf, vf, wf, min_rho)
+    out = np.asarray(gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, mp, allow))
+    stats = gridpp.oi_last_stats()
+    og = O.Pts(lats.ravel(), lons.ravel(), ge.ravel(), gl.ravel())
+    op = O.Pts(plat, plon, pe, pl)
+    ci, oi = np.arange(Y * X), O.nearest_indices(og, op)
+    Rf = np.array([O.structure_localization("Barnes", h, min_rho) for h in hf.ravel()], np.float32)
+    cp = [a.ravel()[ci] for a in (hf, vf, wf)] + [Rf[ci]]
+    opar = [a.ravel()[oi] for a in (hf, vf, wf)] + [Rf[oi]]
+    ones_g, ones_p = np.ones(Y * X, np.float32), np.ones(S, np.float32)
+    ref, _ = O.oi_full_generic(og, bg.ravel(), ones_g, op, obs, ratios, pbg, ones_p, O.Struct("Barnes", base), mp, allow, cp, opar)
+    _check(out, ref.reshape(Y, X))
+    assert stats["union_kernel_ms"] > 0          # (the tile path ran)
+    monkeypatch.setenv("GPP_OI_NO_SP_UNION", "1")
+    out2 = np.asarray(gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, mp, allow))
+    _check(out2, ref.reshape(Y, X))
