@@ -1270,7 +1270,7 @@ extern "C" int gpp_debug_poison_oi_workspace(int byte) {
     w.cell_idx.poison(byte); w.obs_idx.poison(byte);
     w.fb_list.poison(byte); w.fb_list2.poison(byte); w.fb_list3.poison(byte); w.big_list.poison(byte); w.huge_list.poison(byte);
     w.big_keys.poison(byte); w.huge_keys.poison(byte); w.big_mat.poison(byte); w.huge_mat.poison(byte);
-    w.pair_sel.poison(byte); w.pair_n.poison(byte);
+    w.pair_sel.poison(byte); w.pair_n.poison(byte); w.patch.poison(byte);
     g_mfw.mh.poison(byte); g_mfw.mv.poison(byte); g_mfw.mw.poison(byte); g_mfw.mR.poison(byte); g_mfw.tmpi.poison(byte);
     GPP_HIP(hipStreamSynchronize(stream()));
     if(w.h_status) memset(w.h_status, byte, (8 + 80 + 2 * GPP_NSLOT) * sizeof(unsigned long long));

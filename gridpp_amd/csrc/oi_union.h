@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(128, PLAIN ? 3 : 2) void k_oi_union_pair(OiArgs a) 
 // First pass for a spatially varying Barnes structure (round 6; see SP in union_item): one LU per tile.  What it declines goes through the list
 // passes (k_oi_union<true, true, 32, true>: 16-cell and 4-cell items) and, what those decline, to k_oi (pivoted LU per distinct selection).
 template <int V>      // (a template only so that the header can be included by two translation units)
-__global__ __launch_bounds__(128, 2) void k_oi_union_sp(OiArgs a) {
+__global__ __launch_bounds__(128, 3) void k_oi_union_sp(OiArgs a) {
     __shared__ UnionLds<32> s_u[2];
     d_exptab_fill<128>();
     __syncthreads();

@@ -1,6 +1,6 @@
 """Hostile soak of the randomised OI parity test (tests/test_gpu_oi_union_stress.py::_random_inputs) against the CPU oracle.
 
-    python tools/oi_hostile_soak.py LO HI REPEATS [62] [poison] [reuse] [dump=DIR]
+    python tools/oi_hostile_soak.py LO HI REPEATS [62] [poison] [reuse] [spatial] [pairs] [dump=DIR]
 
 What is hostile about it (round-3 verdict, item 1: one unreproduced failure of the max_points 33..62 sequence):
   * the oracle's answers are computed once per seed and cached, so REPEATS passes over the sequence cost GPU time only;
@@ -32,6 +32,9 @@ flags = args[3:]
 mps = [33, 40, 50, 62] if "62" in flags else [1, 2, 7, 20, 30, 32]
 poison = "poison" in flags
 reuse = "reuse" in flags
+spatial = "spatial" in flags     # round 6: additionally a spatially varying Barnes structure on the same inputs (k_oi_union_sp + its list passes)
+if "pairs" in flags:             # round 6: the first pass with one factorisation per pair of tiles (k_oi_union_pair, behind its switch)
+    os.environ["GPP_OI_PAIR_TILES"] = "1"
 dump = next((f.split("=", 1)[1] for f in flags if f.startswith("dump=")), os.path.join(ROOT, "gpurun_out", "hostile"))
 from tools.hostile.harness import Hostile                      # noqa: E402  (sets GPP_LIB for the poisoned build before gridpp_amd loads)
 H = Hostile(poison)
@@ -74,6 +77,14 @@ def reference(seed):
         ref = O.oi(og, c["bg"].ravel(), op, c["obs"], c["ratios"], c["pbg"], ost, c["mp"], c["allow"])
         shp = (c["Y"], c["X"])
         refs[seed] = (c, ref.reshape(shp), ref2.reshape(shp), rvar.reshape(shp))
+        if spatial:   # scales +-25 % over the domain, looked up at the first point of corr(p1, p2)
+            hf = (c["h"] * (1 + 0.25 * np.sin(9 * c["lats"]) * np.cos(7 * c["lons"]))).astype(np.float32)
+            Rf = np.array([O.structure_localization("Barnes", h, 0.0013) for h in hf.ravel()], np.float32)
+            oi_ = O.nearest_indices(og, op)
+            z_g, z_p = np.zeros(hf.size, np.float32), np.zeros(c["S"], np.float32)
+            refsp, _ = O.oi_full_generic(og, c["bg"].ravel(), np.ones(hf.size, np.float32), op, c["obs"], c["ratios"], c["pbg"], np.ones(c["S"], np.float32),
+                                         O.Struct("Barnes", c["h"]), c["mp"], c["allow"], [hf.ravel(), z_g, z_g, Rf], [hf.ravel()[oi_], z_p, z_p, Rf[oi_]])
+            refs[seed] += (hf, refsp.reshape(shp))
     return refs[seed]
 
 
@@ -91,7 +102,7 @@ def record(seed, what, detail, c, arrays, stats):
 
 
 def one(seed):
-    c, ref, ref2, rvar = reference(seed)
+    c, ref, ref2, rvar = reference(seed)[:4]
     if reuse:
         if seed not in handles:
             handles[seed] = (gridpp.Grid(c["lats"], c["lons"]), gridpp.Points(c["plat"], c["plon"]))
@@ -132,6 +143,22 @@ def one(seed):
         if not (np.array_equal(oa, out, equal_nan=True) and np.array_equal(ob, out, equal_nan=True)):
             record(seed, "deferred call differs", "%d / %d values" % (int((~((oa == out) | (np.isnan(oa) & np.isnan(out)))).sum()), int((~((ob == out) | (np.isnan(ob) & np.isnan(out)))).sum())),
                    c, dict(out=out, deferred=oa, deferred2=ob, ref=ref), gridpp.oi_last_stats())
+    if spatial:
+        hf, refsp = reference(seed)[4:]
+        z = np.zeros_like(hf)
+        sst = gridpp.BarnesStructure(grid, hf, z, z, 0.0013)
+        hostile()
+        o1 = gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], sst, c["mp"], c["allow"])
+        ss = gridpp.oi_last_stats()
+        d = compare(o1, refsp)
+        if d:
+            record(seed, "analysis (spatially varying)", d, c, dict(out=o1, ref=refsp, hf=hf), ss)
+        if not ss["union_kernel_ms"] > 0:
+            record(seed, "tile path did not run (spatially varying)", "", c, dict(out=o1, ref=refsp, hf=hf), ss)
+        hostile()
+        o2 = gridpp.optimal_interpolation(grid, c["bg"], points, c["obs"], c["ratios"], c["pbg"], sst, c["mp"], c["allow"])
+        if not np.array_equal(o1, o2, equal_nan=True):
+            record(seed, "repeat differs (spatially varying)", "%d values" % int((~((o1 == o2) | (np.isnan(o1) & np.isnan(o2)))).sum()), c, dict(out=o1, out_again=o2, ref=refsp, hf=hf), ss)
     if not (np.array_equal(out2, out3, equal_nan=True) and np.array_equal(var, var3, equal_nan=True)):
         nd = int((~((out2 == out3) | (np.isnan(out2) & np.isnan(out3)))).sum()) + int((~((var == var3) | (np.isnan(var) & np.isnan(var3)))).sum())
         record(seed, "repeat differs", "%d values; second call: %s" % (nd, s3), c, dict(out=out2, out_again=out3, var=var, var_again=var3, ref=ref2), s2)

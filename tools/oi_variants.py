@@ -17,8 +17,8 @@ variants = [
     ("CrossValidation(Barnes, 2000), max_points 30", gridpp.CrossValidation(gridpp.BarnesStructure(10000), 2000), 30),
     ("Barnes(10000), max_points 50 (k_oi<62>)", gridpp.BarnesStructure(10000), 50),
     ("Barnes(grid, h * ones, 0, 0): the 'var len scale' row of the reference's benchmark (tests/benchmark.py:66,294), max_points 30", gridpp.BarnesStructure(grid, h, z, z), 30),
-    ("Barnes(grid, h, 0, 0) smoothly varying h (+-20 % over ~50 km), max_points 30 (k_oi LU)", gridpp.BarnesStructure(grid, (h * (1 + 0.2 * np.sin(12 * lats) * np.cos(9 * lons))).astype(np.float32), z, z), 30),
-    ("Barnes(grid, h, 0, 0) white-noise h (+-20 % per cell), max_points 30 (k_oi LU)", gridpp.BarnesStructure(grid, (h * np.random.default_rng(3).uniform(0.8, 1.2, h.shape)).astype(np.float32), z, z), 30),
+    ("Barnes(grid, h, 0, 0) smoothly varying h (+-20 % over ~50 km), max_points 30 (k_oi_union_sp)", gridpp.BarnesStructure(grid, (h * (1 + 0.2 * np.sin(12 * lats) * np.cos(9 * lons))).astype(np.float32), z, z), 30),
+    ("Barnes(grid, h, 0, 0) white-noise h (+-20 % per cell), max_points 30 (k_oi_union_sp)", gridpp.BarnesStructure(grid, (h * np.random.default_rng(3).uniform(0.8, 1.2, h.shape)).astype(np.float32), z, z), 30),
 ]
 for name, st, mp in variants:
     f = lambda: gridpp.optimal_interpolation(grid, d[0], points, d[1], d[2], d[3], st, mp)
