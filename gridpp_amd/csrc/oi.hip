@@ -1523,7 +1523,9 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     // Host arrays of a large grid (what a gridpp script passes, swig/vector.i:42-55,172-180): the background goes up, and the analysis comes
     // down, in bands of tile rows beside the first pass when the call takes the tile kernel (`banded` below) -- 64 MB each way over PCIe ran
     // strictly before and behind a 4.3 ms kernel.  Until that is known the upload is only prepared.
-    const bool band_candidate = !(mem & (GPP_MEM_DEVICE | GPP_HOST_F64)) && C >= (1 << 20) && S > 0 && !path_env("GPP_OI_NO_BANDS");
+    const bool band_candidate = !(mem & GPP_MEM_DEVICE) && C >= (1 << 20) && S > 0 && !path_env("GPP_OI_NO_BANDS");
+    const bool band_f64 = (mem & GPP_HOST_F64) != 0;     // float64 host arrays (numpy's default): a band goes up as doubles and is cast on the upload stream
+    Staged<double> wide_bg, wide_bv;                     // (returned to the pool at the end of the call: everything that reads them is behind the call's last synchronisation)
     if(band_candidate) {
         f_bg.d = f_bg.staged.get(C);
         if(bvariance) f_bvar.d = f_bvar.staged.get(C);
@@ -1681,10 +1683,11 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     // ---- the banded host path (see band_candidate above) --------------------------------------------------------------------------------
     a.tile0 = 0; a.tile_n = a.ntiles;
     const bool banded = band_candidate && a.tiled2d && use_union && N == 32 && !path_env("GPP_OI_PAIR_TILES") && a.ntiles / std::max(a.tiles_x, 1) >= 2 * OiWorkspace::MAXB;
-    if(band_candidate && !banded) {   // whole arrays, as InField::bind does
-        GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bg.d), background, sizeof(float) * C, hipMemcpyHostToDevice, stream()));
-        if(bvariance) GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bvar.d), bvariance, sizeof(float) * C, hipMemcpyHostToDevice, stream()));
+    if(band_candidate && !banded) {   // whole arrays after all
+        f_bg.bind(background, C, mem);
+        f_bvar.bind(bvariance, C, mem);
     }
+    if(banded && band_f64) { wide_bg.get(C); if(bvariance) wide_bv.get(C); }
     // The analysis comes down per band only into page-locked memory (the Python mirror's result arrays, gpp_host_alloc): a copy into pageable
     // memory blocks the host until it is done, i.e. until the band's kernel has run -- nothing behind it would be enqueued in time.
     bool band_down = false;
@@ -1812,8 +1815,15 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                     const int ty1 = b == 5 ? trows : std::max(ty0 + 1, (int)((long)trows * acc / 12));
                     const size_t r0 = (size_t)ty0 * th, r1 = std::min<size_t>((size_t)a.ny, (size_t)ty1 * th);
                     const size_t off = r0 * a.nx, cnt = (r1 - r0) * a.nx;
-                    GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bg.d) + off, background + off, cnt * sizeof(float), hipMemcpyHostToDevice, sUp));
-                    if(bvariance) GPP_HIP(hipMemcpyAsync(const_cast<float*>(f_bvar.d) + off, bvariance + off, cnt * sizeof(float), hipMemcpyHostToDevice, sUp));
+                    auto up = [&](const float* src, const float* dst, Staged<double>& wide) {
+                        if(!band_f64) { GPP_HIP(hipMemcpyAsync(const_cast<float*>(dst) + off, src + off, cnt * sizeof(float), hipMemcpyHostToDevice, sUp)); return; }
+                        // (the rounding of the reference's PyArray_CastToType, swig/vector.i:42-55, on the device: k_stage_f64)
+                        GPP_HIP(hipMemcpyAsync(wide.p + off, reinterpret_cast<const double*>(src) + off, cnt * sizeof(double), hipMemcpyHostToDevice, sUp));
+                        hipLaunchKernelGGL(k_stage_f64, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, sUp, (const double*)(wide.p + off), cnt, const_cast<float*>(dst) + off);
+                        GPP_HIP(hipGetLastError());
+                    };
+                    up(background, f_bg.d, wide_bg);
+                    if(bvariance) up(bvariance, f_bvar.d, wide_bv);
                     GPP_HIP(hipEventRecord(ws.ev_up[b], sUp));
                     const hipStream_t sK = ((b & 1) && two_streams) ? sOdd : stream();
                     GPP_HIP(hipStreamWaitEvent(sK, ws.ev_up[b], 0));

@@ -63,6 +63,7 @@ def test_banded_host_path_is_bit_identical_to_the_unbanded_one(shape, variance, 
     grid, points, st = gridpp.Grid(lats, lons), gridpp.Points(plat, plon), gridpp.BarnesStructure(8000)
 
     def call():
+        nonlocal bg, bvar, obs, ovar, pbg, bvp
         if variance:
             a, v = gridpp.optimal_interpolation_full(grid, bg, bvar, points, obs, ovar, pbg, bvp, st, 25)
             return np.array(a), np.array(v)
@@ -85,8 +86,15 @@ def test_banded_host_path_is_bit_identical_to_the_unbanded_one(shape, variance, 
     assert (a.view(np.uint32) == ref_a.view(np.uint32)).all()
     if variance:
         assert (v.view(np.uint32) == ref_v.view(np.uint32)).all()
+    monkeypatch.delenv("GPP_PAGEABLE_RESULTS")
+    # float64 arrays (numpy's default dtype): the bands go up as doubles and are cast on the upload stream -- the same float32 values, the same bits
+    bg, bvar, obs, ovar, pbg, bvp = (x.astype(np.float64) for x in (bg, bvar, obs, ovar, pbg, bvp))
+    a, v = call()
+    assert a.dtype == np.float32 and (a.view(np.uint32) == ref_a.view(np.uint32)).all()
     if variance:
+        assert (v.view(np.uint32) == ref_v.view(np.uint32)).all()
         return
+    bg = bg.astype(np.float32)
     # and the unbanded result against the oracle on a sample of rows
     rows = rng.choice(Y, 6, replace=False)
     og = O.Pts(lats[rows].ravel(), lons[rows].ravel())
