@@ -24,6 +24,11 @@ print("| C3, smooth terrain (elev + laf, v = 200 m, w = 0.5) | — | %.0f Mcells
 print("| C3, white-noise terrain | — | %.0f Mcells/s (%.1f ms) | %.1f | %.2f %% | — |" % (c3n["Mcells/s"], c3n["ms"], c3n["GB/s_algorithmic"], 100 * c3n["frac_hbm"]))
 for o, nm in ((c4m, "C4 4000²×100, hw=15, Mean"), (c4q, "C4 4000²×100, hw=15, quantile_fast (11 thresholds)")):
     print("| %s | %s | %.0f Mcells/s (%.2f ms) | %.0f | %.0f %% | %.0f × |" % (nm, cpu(o), o["Mcells/s"], o["ms"], o["GB/s_algorithmic"], 100 * o["frac_hbm"], o.get("speedup_vs_cpu_baseline", float("nan"))))
-print("| C5 EnSI 2500²×50, 5k obs, mp=30 | %s | %.1f Mcells/s (%.1f ms default mode; %.1f ms with the sweeps run to convergence = %.1f Mcells/s; %.1f TFLOP/s executed FP64 = %.0f %% of peak) | %.1f | %.1f %% | %.0f × (1 thread) |"
+print("| C5 EnSI 2500²×50, 5k obs, mp=30 | %s | %.1f Mcells/s (%.1f ms default mode; %.1f ms with the sweeps run to convergence = %.1f Mcells/s; %.1f TFLOP/s executed FP64 = %.0f %% of peak) | %.1f | %.1f %% | %.0f × (1 thread); see the line below |"
       % (cpu(c5), c5["Mcells/s"], c5["ms"], c5.get("ms_converged", float("nan")), c5.get("Mcells/s_converged", float("nan")), c5.get("fp64_TFLOPs_executed", float("nan")),
          100 * c5.get("frac_fp64_peak_executed", float("nan")), c5["GB/s_algorithmic"], 100 * c5["frac_hbm"], c5.get("speedup_vs_cpu_baseline", float("nan"))))
+# (round 6: the C5 ratio against BOTH thread counts -- the 1-thread figure is the reference's own serial loop, the all-threads figure what its commented-out pragma would give)
+cb5 = c5.get("cpu_baseline") or {}
+if "all_threads_value" in cb5:
+    print("C5 GPU / CPU: %.0f x against 1 thread (%.0f cells/s), %.0f x against %d threads (%.0f cells/s)" % (
+        c5["Mcells/s"] * 1e6 / cb5["value"], cb5["value"], c5["Mcells/s"] * 1e6 / cb5["all_threads_value"], cb5["all_threads_cores"], cb5["all_threads_value"]))
