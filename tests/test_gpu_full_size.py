@@ -210,3 +210,49 @@ def test_config3_terrain_variants(elev, monkeypatch):
         np.testing.assert_array_equal(out2, out)
     else:
         assert stats["union_kernel_ms"] > 0 and stats["fallback_tiles"] < 0.05 * 250000
+
+
+def test_spatially_varying_barnes_2000x2000_on_the_tile_path():
+    """Round 6: the reference's "var len scale" benchmark shape with a length scale that really varies (+-20 % smoothly over ~50 km), 2000 x 2000 grid, 2 500
+    observations, max_points 30 -- k_oi_union_sp (one unpivoted LU per tile).  (a) 400 sampled cells against the oracle's generic form with the scales at the
+    first point of corr(p1, p2); (b) the pivoted LU per distinct selection (GPP_OI_NO_SP_UNION, round 5's path) within 1e-5 on every cell of a band of rows;
+    (c) linearity in the innovations."""
+    import os
+    import gridpp_amd as gridpp
+    from oracle import oracle as O
+    lats, lons, bg, plat, plon, obs, ratios, pbg = _headline(2000, 2000, 2500)
+    hf = (10000.0 * (1 + 0.2 * np.sin(12 * lats) * np.cos(9 * lons))).astype(np.float32)
+    z = np.zeros_like(hf)
+    grid, points = gridpp.Grid(lats, lons), gridpp.Points(plat, plon)
+    st = gridpp.BarnesStructure(grid, hf, z, z)
+    out = np.asarray(gridpp.optimal_interpolation(grid, bg, points, obs, ratios, pbg, st, 30))
+    s = gridpp.oi_last_stats()
+    assert s["union_kernel_ms"] > 0 and s["solves"] < 80000, s          # one factorisation per tile (62 500 tiles), not per distinct selection (~300 000)
+    rng = np.random.default_rng(7)
+    iy, ix = rng.integers(0, 2000, 400), rng.integers(0, 2000, 400)
+    og, op = O.Pts(lats[iy, ix], lons[iy, ix]), O.Pts(plat, plon)
+    min_rho = 0.0013
+    loc = lambda h: np.array([O.structure_localization("Barnes", v, min_rho) for v in h], np.float32)
+    # (the scales at the observations: the field at the nearest grid point -- the library's own `nearest`, bit-exact against the oracle in
+    #  tests/test_gpu_nearest_parity.py; the oracle's brute force over 4 M x 2 500 pairs would take minutes)
+    hc, ho = hf[iy, ix], np.asarray(gridpp.nearest(grid, points, hf)).astype(np.float32)
+    zc, zo = np.zeros(400, np.float32), np.zeros(plat.size, np.float32)
+    ref, _ = O.oi_full_generic(og, bg[iy, ix], np.ones(400, np.float32), op, obs, ratios, pbg, np.ones(plat.size, np.float32), O.Struct("Barnes", 10000.0), 30, True,
+                               [hc, zc, zc, loc(hc)], [ho, zo, zo, loc(ho)])
+    err = np.abs(out[iy, ix].astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 1e-5, err.max()
+    rows = slice(992, 1008)
+    g16 = gridpp.Grid(lats[rows], lons[rows])
+    st16 = gridpp.BarnesStructure(g16, hf[rows], z[rows], z[rows])
+    a_tile = np.asarray(gridpp.optimal_interpolation(g16, bg[rows], points, obs, ratios, pbg, st16, 30))
+    os.environ["GPP_OI_NO_SP_UNION"] = "1"
+    try:
+        a_lu = np.asarray(gridpp.optimal_interpolation(g16, bg[rows], points, obs, ratios, pbg, st16, 30))
+    finally:
+        del os.environ["GPP_OI_NO_SP_UNION"]
+    e2 = np.abs(a_tile.astype(np.float64) - a_lu) / np.maximum(np.abs(a_lu), 1e-3)
+    assert e2.max() < 1e-5, e2.max()
+    z_g, z_p = np.zeros_like(bg[rows]), np.zeros_like(pbg)
+    a1 = np.asarray(gridpp.optimal_interpolation(g16, z_g, points, obs, ratios, z_p, st16, 30))
+    a2 = np.asarray(gridpp.optimal_interpolation(g16, z_g, points, 2 * obs, ratios, z_p, st16, 30))
+    np.testing.assert_allclose(a2, 2 * a1, rtol=2e-6, atol=1e-6)

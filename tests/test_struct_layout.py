@@ -58,3 +58,15 @@ def test_integration_md_stub_matches_the_header(tmp_path):
     lay = c_layout(tmp_path)
     assert C.sizeof(ns["gpp_structure"]) == lay["gpp_structure"]
     assert [f[0] for f in ns["gpp_structure"]._fields_] == [k.split(".")[1] for k in lay if k.startswith("gpp_structure.")]
+
+
+def test_memory_flags_of_the_header_match_the_mirror(tmp_path):
+    """GPP_MEM_* / GPP_ASYNC / GPP_HOST_F64 / GPP_Q_HOST (round 6) as the C preprocessor sees them == gridpp_amd._capi's constants."""
+    from gridpp_amd import _capi
+    src = tmp_path / "flags.c"
+    src.write_text('#include <stdio.h>\n#include "gridpp_hip.h"\nint main(void) { printf("%d %d %d %d %d\\n", GPP_MEM_HOST, GPP_MEM_DEVICE, GPP_ASYNC, GPP_HOST_F64, GPP_Q_HOST); return 0; }\n')
+    exe = tmp_path / "flags"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert vals == [_capi.MEM_HOST, _capi.MEM_DEVICE, _capi.ASYNC, _capi.HOST_F64, _capi.Q_HOST]
+    assert len(set(vals[1:])) == 4 and all(v & (v - 1) == 0 for v in vals[1:])      # distinct single bits
