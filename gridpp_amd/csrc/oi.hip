@@ -1690,12 +1690,29 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
     if(banded && band_f64) { wide_bg.get(C); if(bvariance) wide_bv.get(C); }
     // The analysis comes down per band only into page-locked memory (the Python mirror's result arrays, gpp_host_alloc): a copy into pageable
     // memory blocks the host until it is done, i.e. until the band's kernel has run -- nothing behind it would be enqueued in time.
-    bool band_down = false;
+    bool band_down = false, zero_copy_out = false;
     if(banded) {
         hipPointerAttribute_t at;
         band_down = hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeHost;
         (void)hipGetLastError();
         if(band_down && out_variance) { band_down = hipPointerGetAttributes(&at, out_variance) == hipSuccess && at.type == hipMemoryTypeHost; (void)hipGetLastError(); }
+        // Round 6, second step: a page-locked result array is WRITTEN BY THE KERNELS THEMSELVES (it is mapped into the device's address space: the
+        // stores of a tile travel over PCIe as posted writes while the kernel goes on) -- no download at all.  The per-band device-to-host copies
+        // of the first step turned out to be copy KERNELS of the runtime (`__amd_rocclr_copyBuffer`) that do not run beside the first pass but
+        // between its workgroups: every band's launch grew by the duration of the copy it overlapped with (tools/host_path_trace.py,
+        // profiles/r06_host_path_trace.txt).  GPP_OI_BANDS_COPY_DOWN keeps that form for the comparison.
+        if(band_down && !path_env("GPP_OI_BANDS_COPY_DOWN")) {
+            void* dp = nullptr; void* dv = nullptr;
+            bool okp = hipHostGetDevicePointer(&dp, out, 0) == hipSuccess && dp != nullptr;
+            if(okp && out_variance) okp = hipHostGetDevicePointer(&dv, out_variance, 0) == hipSuccess && dv != nullptr;
+            (void)hipGetLastError();
+            if(okp) {
+                zero_copy_out = true;
+                band_down = false;
+                a.out = static_cast<float*>(dp);
+                if(out_variance) a.out_var = static_cast<float*>(dv);
+            }
+        }
         if(!ws.ev_band0) GPP_HIP(hipEventCreateWithFlags(&ws.ev_band0, hipEventDisableTiming));
         for(int b = 0; b < OiWorkspace::MAXB; b++) if(!ws.ev_up[b]) { GPP_HIP(hipEventCreateWithFlags(&ws.ev_up[b], hipEventDisableTiming)); GPP_HIP(hipEventCreateWithFlags(&ws.ev_k[b], hipEventDisableTiming)); }
     }
@@ -1800,7 +1817,14 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             // list passes are final only behind those: their cells are patched at the end of the call (k_gather_tiles).
             auto first_pass = [&]() {
                 if(!banded) { launch_union(a.ntiles, false); return; }
-                static const int share[6] = {1, 2, 3, 3, 2, 1};
+                // (GPP_OI_BAND_SHARES="a,b,c,...": another split for A/B runs, at most MAXB bands)
+                int share[OiWorkspace::MAXB] = {1, 2, 3, 3, 2, 1, 0, 0};
+                int nband = 6, total_share = 12;
+                if(const char* e = path_env("GPP_OI_BAND_SHARES")) {
+                    nband = 0; total_share = 0;
+                    for(const char* q = e; *q && nband < OiWorkspace::MAXB; ) { const int v = atoi(q); if(v > 0) { share[nband++] = v; total_share += v; } while(*q && *q != ',') q++; if(*q == ',') q++; }
+                    if(nband == 0) { nband = 1; share[0] = 1; total_share = 1; }
+                }
                 const int th = 64 >> a.wshift, trows = a.ntiles / a.tiles_x;
                 const hipStream_t sUp = stream2(), sDown = stream3(), sOdd = stream4();
                 const bool two_streams = path_env("GPP_OI_BANDS_TWO_STREAMS") != nullptr;
@@ -1810,9 +1834,9 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                 GPP_HIP(hipStreamWaitEvent(sUp, ws.ev_band0, 0));    // (the staging buffers' previous readers are behind the library stream)
                 GPP_HIP(hipStreamWaitEvent(sOdd, ws.ev_band0, 0));   // (and so is the status block the kernels count in, cleared by k_pack_obs)
                 int ty0 = 0, acc = 0;
-                for(int b = 0; b < 6; b++) {
+                for(int b = 0; b < nband; b++) {
                     acc += share[b];
-                    const int ty1 = b == 5 ? trows : std::max(ty0 + 1, (int)((long)trows * acc / 12));
+                    const int ty1 = b == nband - 1 ? trows : std::max(ty0 + 1, (int)((long)trows * acc / total_share));
                     const size_t r0 = (size_t)ty0 * th, r1 = std::min<size_t>((size_t)a.ny, (size_t)ty1 * th);
                     const size_t off = r0 * a.nx, cnt = (r1 - r0) * a.nx;
                     auto up = [&](const float* src, const float* dst, Staged<double>& wide) {
@@ -1839,7 +1863,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
                     }
                     ty0 = ty1;
                 }
-                GPP_HIP(hipStreamWaitEvent(stream(), ws.ev_k[5], 0));   // (what follows on the library stream -- the list passes, the read-back -- is behind every band: 5 is the last of the fourth stream)
+                for(int b = std::max(0, nband - 2); b < nband; b++) GPP_HIP(hipStreamWaitEvent(stream(), ws.ev_k[b], 0));   // (what follows on the library stream -- the list passes, the read-back -- is behind every band, whichever stream ran the last ones)
                 a.tile0 = 0; a.tile_n = a.ntiles;
                 bands_down_done = band_down;
             };
@@ -2197,6 +2221,7 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             }
         }
     }
+    else if(zero_copy_out) GPP_HIP(hipStreamSynchronize(stream()));   // (the kernels wrote the caller's page-locked arrays themselves)
     else if(f_out.host || f_var.host) {   // (device outputs: the stream is already idle after the status read-back)
         if(bands_down_done) GPP_HIP(hipStreamSynchronize(stream3()));   // (a second run of the call -- pivoted LU -- wrote everything again: the early bands must not land on top of the full copy)
         f_out.finish(); f_var.finish();
