@@ -356,7 +356,7 @@ def main():
             achieved = cells_rank * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
             prof = pmc_profile(workload, world)
             res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": prof["traffic_bytes"] if prof else None,
+                               "traffic": prof.get("traffic_bytes") if prof else None,
                                "note": "OI is instruction-issue-bound by construction (observations stay on-chip): see roofline_compute; algorithmic bytes = 28 B/cell (x, y, z, elev, laf, background read; analysis written); traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/)"}
             if prof and "SQ_INSTS_VALU" in prof:
                 # issue cycles = FP64 instructions x 4 + the other VALU instructions x 2, against every SIMD issuing every cycle

@@ -128,6 +128,18 @@ template <> struct UnionCfg<64> {
 constexpr int U_MAXE = 12;     // union minus core
 constexpr int U_MAXM = 6;      // extras of one cell
 
+// Workgroup index -> position in the tile order, XCD-aware.  The hardware hands consecutive workgroups to the eight XCDs in turn (each XCD has its own
+// L2), and with two tiles per workgroup a 128-byte line of a grid row (four 8-cell tiles) is shared by TWO consecutive workgroups: in launch order they sit
+// on different XCDs and every line of the six cell arrays is fetched from HBM twice (FETCH_SIZE 379 MB per launch instead of 191: measured after
+// GPP_UNION_WPB went from 4 to 2).  Inside every group of sixteen workgroups, workgroup b takes position 2 (b mod 8) + (b div 8 mod 2): positions 2 x and
+// 2 x + 1 -- the two halves of a line -- run on XCD x.  (The last, partial group of a grid keeps its order.)
+__device__ __forceinline__ unsigned union_xcd_order(const unsigned b, const unsigned nblocks) {
+    const unsigned g = b & ~15u;
+    if(g + 16u > nblocks) return b;
+    const unsigned r = b & 15u;
+    return g + ((r & 7u) << 1) + (r >> 3);
+}
+
 template <int NC>
 struct UnionLds {
     static constexpr int U_WCAP = UnionCfg<NC>::WCAP, U_MAXU = UnionCfg<NC>::MAXU, U_SOLVE = UnionCfg<NC>::SOLVE;
@@ -1564,7 +1576,7 @@ __global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : ((PLAIN && !
         union_item<PLAIN, true, NC, false, SP>(a, tile, sub, shift, s_u[wid], lane);
     }
     else if constexpr(!UnionCfg<NC>::template persistent<PLAIN>()) {   // (the other forms keep one tile per wave: the loop costs them registers they do not have)
-        const int t = blockIdx.x * WPB + wid, tile = a.tile0 + t;   // (tile0 / tile_n: the band of tile rows this launch covers -- all tiles, or one band of the banded host path, oi.hip)
+        const int t = (int)union_xcd_order(blockIdx.x, gridDim.x) * WPB + wid, tile = a.tile0 + t;   // (tile0 / tile_n: the band of tile rows this launch covers -- all tiles, or one band of the banded host path, oi.hip)
         if(t < a.tile_n && !(a.skip_flags && a.skip_flags[tile])) union_item<PLAIN, false, NC>(a, tile, -1, 0, s_u[wid], lane);
     }
     else {
@@ -1635,7 +1647,7 @@ __global__ __launch_bounds__(128, 3) void k_oi_union_sp(OiArgs a) {
     d_exptab_fill<128>();
     __syncthreads();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 2 + wid;
+    const int t = (int)union_xcd_order(blockIdx.x, gridDim.x) * 2 + wid;
     if(t < a.tile_n) union_item<true, false, 32, false, true>(a, a.tile0 + t, -1, 0, s_u[wid], lane);
 }
 

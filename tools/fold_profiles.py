@@ -40,9 +40,9 @@ def total(name, kernel_parts, counter):
 out = {"_comment": "per-launch counters of the dominant kernels from the rocprofv3 PMC passes of tools/profile_r04.sh (separate --pmc runs; summaries in "
                    "profiles/" + TAG + "_*_pmc_*.csv).  FETCH_SIZE / WRITE_SIZE in KiB; traffic = FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section). "
                    "Folded by tools/fold_profiles.py."}
-U = "k_oi_union<true, false, 32>"
+U = "k_oi_union<true, false, 32"     # (the name as rocprofv3 prints it carries every template argument: <true, false, 32, false> since round 6; the largest grid = the launch over all tiles)
 fs, wsz = pick("oi_pmc_fetch", U, "FETCH_SIZE"), pick("oi_pmc_write", U, "WRITE_SIZE")
-oi = {"kernel": U + " (first pass, all tiles)", "workload": "optimal_interpolation 4000x4000 grid, 10000 obs, BarnesStructure(10000), max_points=30", "n_gpus": 1,
+oi = {"kernel": "k_oi_union<true, false, 32> (first pass, all tiles)", "workload": "optimal_interpolation 4000x4000 grid, 10000 obs, BarnesStructure(10000), max_points=30", "n_gpus": 1,
       "_source": "profiles/" + TAG + "_oi_pmc_*.csv"}
 if fs is not None and wsz is not None:
     oi.update({"FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": wsz, "traffic_bytes": int((2 * fs + wsz) * 1024), "algorithmic_bytes": 16000000 * 28})
