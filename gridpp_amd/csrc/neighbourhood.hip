@@ -641,7 +641,7 @@ __device__ __forceinline__ void bm_lds_barrier() {
 __host__ __device__ inline size_t bm_tin_bytes(int) { return (((size_t)BM_C * BM_P * sizeof(float)) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t bm_lds_bytes(int hw) { return bm_tin_bytes(hw) + (size_t)BM_RING * (BM_RP * sizeof(double) + BM_W + 1) + 2 * sizeof(int); }
 template <int HW>
-__global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in, int Y, int X, int statistic, float* __restrict__ out, int qf_reps, int SH) {
+__global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in, int Y, int X, int statistic, float* __restrict__ out, int qf_reps, int SH, int seg0) {
     constexpr int hw = HW;   // (a template parameter: every window loop unrolls, its LDS reads are issued together and waited for once)
     extern __shared__ __attribute__((aligned(16))) unsigned char bm_lds[];
     constexpr int Wt = BM_W + 2 * hw, P = BM_P;
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void k_box_march(const float* __restrict__ in,
     int* const bflag = reinterpret_cast<int*>(rflag + BM_RING);                                // [2]: chunk k (slot k % 2) holds a missing value
     const long plane = (long)blockIdx.z * Y * X;
     const int x0 = blockIdx.x * BM_W;
-    const int ya = blockIdx.y * SH, yb = min(Y, ya + SH);          // this workgroup's output rows
+    const int ya = (seg0 + (int)blockIdx.y) * SH, yb = min(Y, ya + SH);          // this workgroup's output rows (seg0: the launch covers a band of the row segments, banded host path)
     if(ya >= yb) return;
     const int tid = threadIdx.x;
     const int yl0 = ya - hw;                                        // first row it loads; ring slot of field row y: (y - yl0) % BM_RING
@@ -873,7 +873,7 @@ __device__ __forceinline__ void bm_window_extrema(const float (&t)[8 + 2 * HW], 
 template <int HW> struct MinMaxGeom { static constexpr int W = HW <= BM_MAXHW ? BM_W : BM_W / 2, RING = HW <= BM_MAXHW ? BM_RING : 2 * BM_RING, FP = W + 1; };
 template <int HW> __host__ __device__ inline size_t bm_minmax_lds_bytes() { return bm_tin_bytes(0) + (size_t)MinMaxGeom<HW>::RING * MinMaxGeom<HW>::FP * sizeof(float); }
 template <int HW, bool IS_MAX>
-__global__ __launch_bounds__(256) void k_minmax_march(const float* __restrict__ in, int Y, int X, float* __restrict__ out, int SH) {
+__global__ __launch_bounds__(256) void k_minmax_march(const float* __restrict__ in, int Y, int X, float* __restrict__ out, int SH, int seg0) {
     constexpr int hw = HW;
     constexpr int BM_W_ = MinMaxGeom<HW>::W, BM_RING_ = MinMaxGeom<HW>::RING, BM_FP = MinMaxGeom<HW>::FP;
     static_assert(BM_W_ + 2 * HW <= BM_P - 1 && BM_C + 2 * HW <= BM_RING_, "the chunk's rows and the ring hold the windows");
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void k_minmax_march(const float* __restrict__ 
     float* const tin = reinterpret_cast<float*>(bm_lds);                               // [BM_C][P]: the rows of the chunk, `ident` where nothing counts
     float* const ring = reinterpret_cast<float*>(bm_lds + bm_tin_bytes(0));            // [BM_RING][BM_FP]: row-window extrema of the strip's columns
     const int x0 = blockIdx.x * BM_W_;
-    const int ya = blockIdx.y * SH, yb = min(Y, ya + SH);
+    const int ya = (seg0 + (int)blockIdx.y) * SH, yb = min(Y, ya + SH);
     if(ya >= yb) return;
     const int tid = threadIdx.x;
     const int yl0 = ya - hw;
@@ -1140,6 +1140,7 @@ struct NbWorkspace {
     const void* pad_ptr = nullptr;   // the padding of the quantile_fast count planes is in place for this buffer (this ALLOCATION of it) and shape
     unsigned long long pad_gen = 0;
     int pad_y = 0, pad_x = 0, pad_t = 0, pad_e = 0;
+    hipEvent_t ev_band0 = nullptr, ev_up[6] = {};   // banded host path of gpp_neighbourhood
     int spec_nt = -1, spec_U = -1;   // quantile_fast: the number of distinct thresholds the last call with spec_nt thresholds had (its table was usable)
     int* h_pin = nullptr;            // a few page-locked words for the read-back at the end of such a call
 };
@@ -1214,18 +1215,44 @@ void qf_count_launch(const float* d_in, long C, int E, const float* d_thr, int T
     }
 }
 // Mean / Sum / Count of `nplanes` [Y][X] planes
-void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statistic, float* d_out, int qf_reps = 0) {
-    if(hw <= BM_MAXHW && nplanes <= 65535 && !path_env("GPP_BOX_TWO_PASS")) {   // both passes in one kernel (k_box_march)
-        // about three workgroups per CU: strips x row segments x planes; a segment is a whole number of chunks (its first chunk is run-in: 2 hw rows)
+// The launch geometry of the marching kernels for a [Y][X] plane: row segments of SH rows, `segs` of them.  (seg0, nseg): the band of segments a launch covers --
+// all of them, or one band of the banded host path of gpp_neighbourhood.
+struct MarchGeom { int SH = 0, segs = 0; bool ok = false; };
+MarchGeom march_geom(int Y, int X, int hw, int statistic, int nplanes = 1) {
+    MarchGeom g;
+    if(path_env("GPP_BOX_TWO_PASS")) return g;
+    if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT) {
+        if(hw > BM_MAXHW || nplanes > 65535) return g;
         const int strips = (X + BM_W - 1) / BM_W;
         const long fill = path_env("GPP_BM_FILL") ? std::max(1, atoi(path_env("GPP_BM_FILL"))) : 768;   // (A/B: workgroups the launch aims for)
         const long want = std::max<long>(1, fill / std::max<long>(1, (long)strips * nplanes));
         const int segs = (int)std::min<long>(want, (Y + BM_C - 1) / BM_C);
-        int SH = ((Y + segs - 1) / segs + BM_C - 1) / BM_C * BM_C;
-        while((Y + SH - 1) / SH > 65535) SH += BM_C;
-        const dim3 grid(strips, (Y + SH - 1) / SH, nplanes);
+        g.SH = ((Y + segs - 1) / segs + BM_C - 1) / BM_C * BM_C;
+    }
+    else if(statistic == GPP_MIN || statistic == GPP_MAX) {
+        if(hw > BM_MM_MAXHW) return g;
+        const int W = hw <= BM_MAXHW ? BM_W : BM_W / 2;
+        const int strips = (X + W - 1) / W;
+        const long fill = path_env("GPP_BM_FILL") ? std::max(1, atoi(path_env("GPP_BM_FILL"))) : 1280;
+        const long want = std::max<long>(1, fill / strips);
+        const int segs = (int)std::min<long>(want, (Y + BM_C - 1) / BM_C);
+        g.SH = ((Y + segs - 1) / segs + BM_C - 1) / BM_C * BM_C;
+    }
+    else return g;
+    while((Y + g.SH - 1) / g.SH > 65535) g.SH += BM_C;
+    g.segs = (Y + g.SH - 1) / g.SH;
+    g.ok = true;
+    return g;
+}
+void box_stat(const float* d_in, int Y, int X, int nplanes, int hw, int statistic, float* d_out, int qf_reps = 0, int seg0 = 0, int nseg = -1) {
+    if(hw <= BM_MAXHW && nplanes <= 65535 && !path_env("GPP_BOX_TWO_PASS")) {   // both passes in one kernel (k_box_march)
+        // about three workgroups per CU: strips x row segments x planes; a segment is a whole number of chunks (its first chunk is run-in: 2 hw rows)
+        const int strips = (X + BM_W - 1) / BM_W;
+        const MarchGeom mg = march_geom(Y, X, hw, GPP_MEAN, nplanes);
+        const int SH = mg.SH;
+        const dim3 grid(strips, nseg < 0 ? mg.segs : nseg, nplanes);
         switch(hw) {
-#define BM_CASE(n) case n: hipLaunchKernelGGL(k_box_march<n>, grid, dim3(256), bm_lds_bytes(n), stream(), d_in, Y, X, statistic, d_out, qf_reps, SH); break;
+#define BM_CASE(n) case n: hipLaunchKernelGGL(k_box_march<n>, grid, dim3(256), bm_lds_bytes(n), stream(), d_in, Y, X, statistic, d_out, qf_reps, SH, seg0); break;
             BM_CASE(0) BM_CASE(1) BM_CASE(2) BM_CASE(3) BM_CASE(4) BM_CASE(5) BM_CASE(6) BM_CASE(7) BM_CASE(8)
             BM_CASE(9) BM_CASE(10) BM_CASE(11) BM_CASE(12) BM_CASE(13) BM_CASE(14) BM_CASE(15) BM_CASE(16)
 #undef BM_CASE
@@ -1267,22 +1294,19 @@ void brute(const float* d_in, int Y, int X, int E, int hw, int statistic, float 
     GPP_HIP(hipGetLastError());
 }
 // neighbourhood(vec2, hw, stat) on a device-resident plane (neighbourhood.cpp:28-242)
-void neighbourhood2d(const float* d_in, int Y, int X, int hw, int statistic, float* d_out) {
+void neighbourhood2d(const float* d_in, int Y, int X, int hw, int statistic, float* d_out, int seg0 = 0, int nseg = -1) {
     long C = (long)Y * X;
-    if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT) box_stat(d_in, Y, X, 1, hw, statistic, d_out);
+    if(statistic == GPP_MEAN || statistic == GPP_SUM || statistic == GPP_COUNT) box_stat(d_in, Y, X, 1, hw, statistic, d_out, 0, seg0, nseg);
     else if((statistic == GPP_MIN || statistic == GPP_MAX) && hw <= BM_MM_MAXHW && !path_env("GPP_BOX_TWO_PASS")) {   // both passes in one kernel (k_minmax_march)
         const int W = hw <= BM_MAXHW ? BM_W : BM_W / 2;
         const int strips = (X + W - 1) / W;
-        const long fill = path_env("GPP_BM_FILL") ? std::max(1, atoi(path_env("GPP_BM_FILL"))) : 1280;
-        const long want = std::max<long>(1, fill / strips);
-        const int segs = (int)std::min<long>(want, (Y + BM_C - 1) / BM_C);
-        int SH = ((Y + segs - 1) / segs + BM_C - 1) / BM_C * BM_C;
-        while((Y + SH - 1) / SH > 65535) SH += BM_C;
-        const dim3 grid(strips, (Y + SH - 1) / SH);
+        const MarchGeom mg = march_geom(Y, X, hw, statistic);
+        const int SH = mg.SH;
+        const dim3 grid(strips, nseg < 0 ? mg.segs : nseg);
         const bool mx = statistic == GPP_MAX;
         switch(hw) {
-#define BM_CASE(n) case n: if(mx) hipLaunchKernelGGL((k_minmax_march<n, true>), grid, dim3(256), bm_minmax_lds_bytes<n>(), stream(), d_in, Y, X, d_out, SH); \
-                           else hipLaunchKernelGGL((k_minmax_march<n, false>), grid, dim3(256), bm_minmax_lds_bytes<n>(), stream(), d_in, Y, X, d_out, SH); break;
+#define BM_CASE(n) case n: if(mx) hipLaunchKernelGGL((k_minmax_march<n, true>), grid, dim3(256), bm_minmax_lds_bytes<n>(), stream(), d_in, Y, X, d_out, SH, seg0); \
+                           else hipLaunchKernelGGL((k_minmax_march<n, false>), grid, dim3(256), bm_minmax_lds_bytes<n>(), stream(), d_in, Y, X, d_out, SH, seg0); break;
             BM_CASE(0) BM_CASE(1) BM_CASE(2) BM_CASE(3) BM_CASE(4) BM_CASE(5) BM_CASE(6) BM_CASE(7) BM_CASE(8)
             BM_CASE(9) BM_CASE(10) BM_CASE(11) BM_CASE(12) BM_CASE(13) BM_CASE(14) BM_CASE(15) BM_CASE(16)
             BM_CASE(17) BM_CASE(18) BM_CASE(19) BM_CASE(20) BM_CASE(21) BM_CASE(22) BM_CASE(23) BM_CASE(24)
@@ -1332,6 +1356,57 @@ extern "C" int gpp_neighbourhood(const float* input, int ny, int nx, int ne, int
     ensure_device();
     const long C = (long)ny * nx;
     InField in; OutField o;
+    // Round 6: a large 2-D plane in host memory (numpy in, numpy out: 64 MB up, a 0.07 ms kernel, 64 MB down -- 2.4 ms for a 4000 x 4000 plane) travels in
+    // bands of the marching kernels' row segments: a band's rows (+ the halfwidth rows below it) go up on the second stream, the band's launch waits for
+    // them, and a page-locked result array is written by the kernels themselves (mapped host memory: optimal_interpolation's host path, oi.hip).
+    if(!is3d && !(mem & GPP_MEM_DEVICE) && C >= (1L << 20) && !path_env("GPP_NBH_NO_BANDS")) {
+        const MarchGeom mg = march_geom(ny, nx, halfwidth, statistic);
+        hipPointerAttribute_t at;
+        void* dp = nullptr;
+        bool okp = mg.ok && mg.segs >= 4 && hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeHost && hipHostGetDevicePointer(&dp, out, 0) == hipSuccess && dp != nullptr;
+        (void)hipGetLastError();
+        if(okp) {
+            const bool f64 = (mem & GPP_HOST_F64) != 0;
+            float* const d_in = in.staged.get((size_t)C);
+            Staged<double> wide;
+            if(f64) wide.get((size_t)C);
+            if(!g_nb.ev_band0) {
+                GPP_HIP(hipEventCreateWithFlags(&g_nb.ev_band0, hipEventDisableTiming));
+                for(int b = 0; b < 6; b++) GPP_HIP(hipEventCreateWithFlags(&g_nb.ev_up[b], hipEventDisableTiming));
+            }
+            struct Guard { ~Guard() { (void)hipStreamSynchronize(stream2()); (void)hipStreamSynchronize(stream()); } } guard;   // (nothing of the call stays in flight, whatever ends it)
+            const hipStream_t sUp = stream2();
+            GPP_HIP(hipEventRecord(g_nb.ev_band0, stream()));
+            GPP_HIP(hipStreamWaitEvent(sUp, g_nb.ev_band0, 0));     // (the staging buffer's previous readers are behind the library stream)
+            static const int share[6] = {1, 2, 3, 3, 2, 1};
+            const int nband = std::min(6, mg.segs);
+            int s0 = 0, acc = 0, tot = 0;
+            for(int b = 0; b < nband; b++) tot += share[b];
+            long up = 0;    // rows uploaded so far
+            for(int b = 0; b < nband; b++) {
+                acc += share[b];
+                const int s1 = b == nband - 1 ? mg.segs : std::max(s0 + 1, (int)((long)mg.segs * acc / tot));
+                const long need = std::min<long>(ny, (long)s1 * mg.SH + halfwidth);       // the band's windows reach `halfwidth` rows below its last row
+                if(need > up) {
+                    const size_t off = (size_t)up * nx, cnt = (size_t)(need - up) * nx;
+                    if(!f64) GPP_HIP(hipMemcpyAsync(d_in + off, input + off, cnt * sizeof(float), hipMemcpyHostToDevice, sUp));
+                    else {
+                        GPP_HIP(hipMemcpyAsync(wide.p + off, reinterpret_cast<const double*>(input) + off, cnt * sizeof(double), hipMemcpyHostToDevice, sUp));
+                        hipLaunchKernelGGL(k_stage_f64, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, sUp, (const double*)(wide.p + off), cnt, d_in + off);
+                        GPP_HIP(hipGetLastError());
+                    }
+                    up = need;
+                }
+                GPP_HIP(hipEventRecord(g_nb.ev_up[b], sUp));
+                GPP_HIP(hipStreamWaitEvent(stream(), g_nb.ev_up[b], 0));
+                neighbourhood2d(d_in, ny, nx, halfwidth, statistic, static_cast<float*>(dp), s0, s1 - s0);
+                s0 = s1;
+            }
+            GPP_HIP(hipStreamSynchronize(stream()));
+            GPP_HIP(hipStreamSynchronize(sUp));
+            return GPP_OK;
+        }
+    }
     in.bind(input, (size_t)C * ne, mem);
     o.bind(out, C, mem);
     const float* plane = in.d;

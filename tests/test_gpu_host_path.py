@@ -101,3 +101,30 @@ def test_banded_host_path_is_bit_identical_to_the_unbanded_one(shape, variance, 
     ref = O.oi(og, bg[rows].ravel(), O.Pts(plat, plon), obs, ovar, pbg, O.Barnes(8000), 25).reshape(len(rows), X)
     err = np.abs(ref_a[rows] - ref) / np.maximum(np.abs(ref), 1e-3)
     assert err.max() < 1e-5, err.max()
+
+
+@pytest.mark.parametrize("shape", [(1100, 1031), (4000, 300), (1027, 2050)])
+def test_banded_neighbourhood_host_path_is_bit_identical(shape, monkeypatch):
+    """Round 6: a large 2-D plane from numpy goes up in bands of the marching kernels' row segments beside their launches and the kernels write the page-locked
+    result array themselves.  Same bits as one upload / the kernel / one download (GPP_NBH_NO_BANDS) for every marching statistic and halfwidths from 0 to the
+    kernels' limits, with missing values, from float32 and float64 arrays, and into a pageable result array (no bands then)."""
+    import gridpp_amd as gridpp
+    rng = np.random.default_rng(shape[1])
+    Y, X = shape
+    f = rng.uniform(-5, 10, (Y, X)).astype(np.float32)
+    f[rng.random((Y, X)) < 0.003] = np.nan
+    f[Y // 2:Y // 2 + 40, X // 3:X // 3 + 50] = np.nan          # a block of missing values (the counted chunks of the box kernel)
+    cases = [(gridpp.Mean, 0), (gridpp.Mean, 3), (gridpp.Mean, 16), (gridpp.Sum, 7), (gridpp.Count, 5), (gridpp.Min, 1), (gridpp.Max, 15), (gridpp.Max, 32), (gridpp.Min, 20)]
+    for stat, hw in cases:
+        monkeypatch.setenv("GPP_NBH_NO_BANDS", "1")
+        ref = np.array(gridpp.neighbourhood(f, hw, stat))
+        monkeypatch.delenv("GPP_NBH_NO_BANDS")
+        for arr in (f, f.astype(np.float64)):
+            out = np.array(gridpp.neighbourhood(arr, hw, stat))
+            assert out.dtype == np.float32 and out.shape == ref.shape
+            assert (out.view(np.uint32) == ref.view(np.uint32)).all(), (stat, hw, arr.dtype, int((out.view(np.uint32) != ref.view(np.uint32)).sum()))
+    monkeypatch.setenv("GPP_PAGEABLE_RESULTS", "1")
+    out = np.array(gridpp.neighbourhood(f, 7, gridpp.Mean))
+    monkeypatch.setenv("GPP_NBH_NO_BANDS", "1")
+    ref = np.array(gridpp.neighbourhood(f, 7, gridpp.Mean))
+    assert (out.view(np.uint32) == ref.view(np.uint32)).all()
