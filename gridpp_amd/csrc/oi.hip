@@ -21,6 +21,7 @@
 #include "oi_union.h"
 
 void gpp_launch_union64(const OiArgs& a, unsigned nblocks, bool plain, bool list, hipStream_t stream);   // oi_union64.hip
+void gpp_launch_union48(const OiArgs& a, unsigned nblocks, bool plain, bool list, hipStream_t stream);   // oi_union48.hip
 #include <rocprim/rocprim.hpp>
 #include <cfloat>
 #include <algorithm>
@@ -1799,7 +1800,9 @@ static int oi_full_impl(gpp_points* bgrid, const float* background, const float*
             auto launch_union = [&](const long items, const bool list) {   // one wave per work item
                 const long nb = (items + WPB - 1) / WPB;
                 const dim3 grid((unsigned)std::min<long>(nb, 0x7fffffffL));
-                if(N != 32) gpp_launch_union64(a, grid.x, plain, list, cur);
+                // (max_points 33 .. 48: the 48-column form at two waves per SIMD; 49 .. 62: the 64-column form)
+                if(N != 32 && max_points <= 48 && !path_env("GPP_OI_NO_UNION48")) gpp_launch_union48(a, grid.x, plain, list, cur);
+                else if(N != 32) gpp_launch_union64(a, grid.x, plain, list, cur);
                 // (round 6: the first pass of the 32-column form shares one factorisation between the two tiles of a pair)
                 else if(!list && pair_tiles) {
                     const dim3 pgrid((unsigned)std::min<long>(union_pair_count(a), 0x7fffffffL)), pblock(128);

@@ -118,6 +118,15 @@ template <> struct UnionCfg<32> {
     static constexpr int WPB = GPP_UNION_WPB;       // waves (work items) per workgroup
     template <bool PLAIN> static constexpr bool persistent() { return PLAIN && GPP_UNION_PERSIST != 0; }   // first pass as a persistent grid (see k_oi_union)
 };
+// NC = 48 (round 6): max_points 33 .. 46 -- 48 register columns + 8 late columns, 56 slots; 19 KB of LDS per wave and ~200 registers: TWO waves per SIMD
+// where the 64-column form has 1.5 (its 22.8 KB per wave leave room for three two-wave workgroups per CU), and a quarter fewer multiply-adds.
+template <> struct UnionCfg<48> {
+    static constexpr int WCAP = 56;
+    static constexpr int MAXU = 56;
+    static constexpr int SOLVE = 1792;  // c = 46, 10 extras: 1756 doubles
+    static constexpr int WPB = 2;
+    template <bool PLAIN> static constexpr bool persistent() { return false; }
+};
 template <> struct UnionCfg<64> {
     static constexpr int WCAP = 64;
     static constexpr int MAXU = 62;     // lane 63 carries obs - background
@@ -1186,10 +1195,10 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
         }
         // columns 32..u-1 do not fit the 32-column register tile: their entries (rows >= 32 and the obs - background row) wait
         // in LDS and are reduced after the elimination
-        const int lidx = lane == 63 ? 8 : lane - 32;
+        const int lidx = lane == 63 ? 8 : lane - NC;
 #pragma unroll
         for(int b = 0; b < (U_MAXU > NC ? 8 : 0); ++b) {
-            const int p = 32 + b;
+            const int p = NC + b;
             if(p < u) {
                 double v = 0.0;
                 if(lane < u && lane >= p) {
@@ -1309,7 +1318,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
                 if(p <= maxp) sv[bse + p] = row[p];
             }
         }
-        if(U_MAXU > NC && u > 32 && !GPP_DBG(a, 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
+        if(U_MAXU > NC && u > NC && !GPP_DBG(a, 16)) {   // Schur complement / d' of the late columns: entry - (row of B or L_C^-1 d) . (row p of B)
             // (row p of B has just been exported: it comes back as LDS broadcasts, one read per two multiply-adds, instead of a
             //  v_readlane pair per multiply-add; columns c.. of the padded row are multiplied by zeros)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1317,13 +1326,13 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for(int b = 0; b < 8; ++b) {
-                const int p = 32 + b;
+                const int p = NC + b;
                 if(p < u) {
                     const bool mine = (lane >= p && lane < u) || lane == 63;
                     double acc = mine ? L.late[b][lidx] : 0.0;
                     const double* const bp = sv + oB + (p - c) * bs;
 #pragma unroll
-                    for(int k = 0; k < 32; ++k) if(k < c) acc = __builtin_fma(-row[k], bp[k], acc);
+                    for(int k = 0; k < NC; ++k) if(k < c) acc = __builtin_fma(-row[k], bp[k], acc);
                     if(lane >= p && lane < u) sv[oS + ea * nE + (p - c)] = acc;
                     else if(lane == 63) sv[oD + (p - c)] = acc;
                 }
@@ -1541,7 +1550,7 @@ __device__ __forceinline__ void union_item(const OiArgs& a, int tile, int sub, c
 // three waves idle: tile times differ by their evictions and ring work), and the next workgroup could not start before.
 // LIST = true: one item per wave, the grid sized by the host for the longest list that can arrive.
 template <bool PLAIN, bool LIST, int NC, bool SP = false>   // (SP: only its list passes run through this kernel; its first pass is k_oi_union_sp)
-__global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : ((PLAIN && !SP) ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
+__global__ __launch_bounds__(64 * UnionCfg<NC>::WPB, NC == 64 ? 1 : ((NC == 32 && PLAIN && !SP) ? 3 : 2)) void k_oi_union(OiArgs a) {   // the generic structure functions need more registers: never spill (see build())
     constexpr int WPB = UnionCfg<NC>::WPB;
     __shared__ UnionLds<NC> s_u[WPB];
     if constexpr(PLAIN) { d_exptab_fill<64 * WPB>(); __syncthreads(); }   // 2^(j/128) for d_exp_core

@@ -60,6 +60,15 @@ def test_random_configurations_62_row_tile(seed):
     _random_configuration(seed, [33, 40, 50, 62], cressman=seed % 5 == 0)
 
 
+@pytest.mark.parametrize("seed", range(700, 712))
+def test_random_configurations_48_column_tile(seed, monkeypatch):
+    """max_points 33..48 (round 6): the 48-column form of k_oi_union (48 register columns + 8 late columns, 56 slots, two waves per SIMD) -- at its upper end,
+    where unions reach its 56 rows and the lists fill -- against the oracle, and the 64-column form (GPP_OI_NO_UNION48) on the same inputs."""
+    _random_configuration(seed, [41, 44, 46, 47, 48], cressman=seed % 5 == 0)
+    monkeypatch.setenv("GPP_OI_NO_UNION48", "1")
+    _random_configuration(seed, [41, 44, 46, 47, 48], cressman=seed % 5 == 0)
+
+
 @pytest.mark.parametrize("seed", range(200, 212))
 def test_random_configurations_rough_terrain(seed):
     """White-noise elevations / land fractions with elevation and laf dependent rho: every cell has its own observation set, the
