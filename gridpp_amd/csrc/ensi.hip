@@ -148,6 +148,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 
 #include "ensi_pair.h"
+#include "ensi_members3.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Grid points with more than 32 usable observations (max_points == 0 or > 32): one 256-thread workgroup per cell, the E x E formulation
@@ -989,7 +990,9 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
             a.tile0 = t0;
             if(a.s.st.fh) hipLaunchKernelGGL(k_ensi_pair<true>, dim3(nt), dim3(64), 0, stream(), a);
             else hipLaunchKernelGGL(k_ensi_pair<false>, dim3(nt), dim3(64), 0, stream(), a);
-            if(a.nV <= 64) hipLaunchKernelGGL(k_ensi_members<true>, dim3((unsigned)nt * 64u), dim3(64), 0, stream(), a);
+            // (at most 64 valid members: the three-waves-per-SIMD form, ensi_members3.h; GPP_ENSI_MEMBERS2: the two-area kernel it replaced)
+            if(a.nV <= 64 && !path_env("GPP_ENSI_MEMBERS2")) hipLaunchKernelGGL(k_ensi_members3, dim3((unsigned)nt * 64u), dim3(64), 0, stream(), a);
+            else if(a.nV <= 64) hipLaunchKernelGGL(k_ensi_members<true>, dim3((unsigned)nt * 64u), dim3(64), 0, stream(), a);
             else hipLaunchKernelGGL(k_ensi_members<false>, dim3((unsigned)nt * 64u), dim3(64), 0, stream(), a);
             GPP_HIP(hipGetLastError());
         }
