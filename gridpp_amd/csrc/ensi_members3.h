@@ -244,20 +244,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const bool tail = mraw >= 1 && mraw <= 4 && nfull >= 1;
     const int nt = tail ? nfull : (nV + 15) >> 4;
     float yop[8][4];
+    {
+        // (unconditional loads from clamped addresses, the value masked afterwards -- bitwise: a select of a loaded value becomes a branch around
+        //  the load, one round trip to memory after the other)
+        long rbase[8];
+        unsigned rmask[8];
 #pragma unroll
-    for(int t = 0; t < 4; ++t) {
-        if(16 * t < nV) {
+        for(int ks = 0; ks < 8; ++ks) {
+            const int row = 4 * ks + kq;
+            const unsigned sr = s_sel[row];
+            rbase[ks] = (long)(row < n ? sr : 0u) * nV;
+            rmask[ks] = row < n ? 0xffffffffu : 0u;
+        }
+#pragma unroll
+        for(int t = 0; t < 4; ++t) {
+            const int col = 16 * t + r16;
+            const unsigned cmask = col < nV ? 0xffffffffu : 0u;
+            const int colc = min(col, nV - 1);
 #pragma unroll
             for(int ks = 0; ks < 8; ++ks) {
-                const int row = 4 * ks + kq, col = 16 * t + r16;
-                const bool on = row < n && col < nV;
-                const float v = a.gY[on ? (long)s_sel[row] * nV + col : 0];
-                yop[ks][t] = on ? v : 0.0f;
+                if(16 * t < nV) yop[ks][t] = __uint_as_float(__float_as_uint(a.gY[rbase[ks] + colc]) & (rmask[ks] & cmask));
+                else yop[ks][t] = 0.0f;
             }
-        }
-        else {
-#pragma unroll
-            for(int ks = 0; ks < 8; ++ks) yop[ks][t] = 0.0f;
         }
     }
     if(tail) {
@@ -265,8 +273,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         for(int q = 0; q < 2; ++q) {
             const int row = (lane + 64 * q) >> 2, j = lane & 3;
             const bool on = row < n && j < mraw;
-            const float v = a.gY[on ? (long)s_sel[row] * nV + 16 * nfull + j : 0];
-            s_yt[row * 4 + j] = on ? v : 0.0f;
+            const unsigned sr = s_sel[row];
+            const float v = a.gY[(long)(row < n ? sr : 0u) * nV + min(16 * nfull + j, nV - 1)];
+            s_yt[row * 4 + j] = __uint_as_float(__float_as_uint(v) & (on ? 0xffffffffu : 0u));
         }
     }
 #pragma unroll 1
@@ -444,6 +453,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
         const double* const src0 = (lane < NB || !tail) ? s_ar + lane * 17 : s_tail + min(lane - NB, 3) * 64;
         const int sstep = (lane < NB || !tail) ? 0 : 16;
+        // W' = Y^T M' Y is symmetric: with NT <= 3 the tiles below the diagonal are not computed -- tile (tk, te), te > tk, stays in its registers until
+        // slab te and goes into it transposed (a third of this product's matrix-core time with three tiles a side; with four the six kept tiles
+        // do not fit the register budget of three waves)
+        constexpr bool SYMW = NT <= 3;
+        v4d keep[NT][NT];
 #pragma unroll
         for(int tk = 0; tk < NT; ++tk) {
             v4d wt[NT];
@@ -453,13 +467,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for(int ks = 0; ks < 8; ++ks) {
                 const double aop = yd(yop[ks][tk]);   // Y(i = 4 ks + kq, k = 16 tk + r16)
 #pragma unroll
-                for(int te = 0; te < NT; ++te) wt[te] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, qa[ks >> 2][te][ks & 3], wt[te], 0, 0, 0);
+                for(int te = (SYMW ? tk : 0); te < NT; ++te) wt[te] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, qa[ks >> 2][te][ks & 3], wt[te], 0, 0, 0);
             }
             if(tk > 0) __syncthreads();   // (the previous slab has been read; before the first one: the barrier above)
 #pragma unroll
-            for(int te = 0; te < NT; ++te)
+            for(int te = 0; te < NT; ++te) {
+                if(SYMW && te < tk) {
 #pragma unroll
-                for(int r = 0; r < 4; ++r) s_ar[(16 * te + r16) * 17 + kq + 4 * r] = wt[te][r];   // W'(k = 16 tk + kq + 4 r, e = 16 te + r16)
+                    for(int r = 0; r < 4; ++r) s_ar[(16 * te + kq + 4 * r) * 17 + r16] = keep[te][tk][r];   // W'(k = 16 tk + r16, e = 16 te + kq + 4 r) = W'(e, k)
+                }
+                else {
+#pragma unroll
+                    for(int r = 0; r < 4; ++r) s_ar[(16 * te + r16) * 17 + kq + 4 * r] = wt[te][r];   // W'(k = 16 tk + kq + 4 r, e = 16 te + r16)
+                    if(SYMW && te > tk) keep[tk][te] = wt[te];
+                }
+            }
             __syncthreads();
             const double* const src = src0 + sstep * tk;
 #pragma unroll
