@@ -42,9 +42,9 @@ __device__ __forceinline__ double yd(float y) { asm volatile("" : "+v"(y)); retu
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ensi_members3(EnsiArgs a) {
     __shared__ __attribute__((aligned(16))) double s_ar[32 * PP];   // THE staging area (8704 bytes)
-    __shared__ __attribute__((aligned(16))) double s_small[6 * 32];
+    __shared__ __attribute__((aligned(16))) double s_small[7 * 32];
     double* const s_sD1 = s_small, * const s_z1 = s_small + 32, * const s_t = s_small + 64, * const s_r1 = s_small + 96, * const s_dw = s_small + 128,
-          * const s_rt = s_small + 160;
+          * const s_rt = s_small + 160, * const s_g = s_small + 192;
     double* const s_qt = s_t;                                     // member update: the Q columns of up to four tail members, [pair][row][2] (s_t .. s_rt are free then)
     __shared__ int s_i[160];                                      // perm[32] | obs[32] | yhat[32] | selection[32] | rho[32] (floats)
     __shared__ float s_v0[64];                                    // the members' values wait here through the spectral part
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const double dwv = -1.0 / (rt * (rt + sqc));      // W_sym = I + A^T g(B) A,  g(S) = -1 / (a (a + sqrt(c))),  a = sqrt(c + S)
     const double inv = 1.0 / (c + S);
     s_v0[lane] = v0_ld;
-    if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = p_sD; s_r1[i] = p_r1; s_dw[i] = dwv; s_rt[i] = rt; s_ob[i] = o1.y; s_yh[i] = o1.z; s_rho[i] = rho; }
+    if(h == 0) { s_sel[i] = orig_i; s_sD1[i] = p_sD; s_r1[i] = p_r1; s_dw[i] = dwv; s_g[i] = sqrt(-dwv); s_rt[i] = rt; s_ob[i] = o1.y; s_yh[i] = o1.z; s_rho[i] = rho; }
     // rows of U (lanes 32..63) -> the area
     if(h == 1) {
 #pragma unroll
@@ -211,22 +211,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
         __syncthreads();   // (the operands are read)
     }
-    // F = E + sqrt(c) R;  F' = F diag(dw) -> second half of the area, T0 = H = diag(dw) F' -> first half, running sum: diag(dw) + T0
+    // F = E + sqrt(c) R.  g(D + E) = -(P + F)^-1 = diag(dw) sum_j (F diag(dw))^j = -G (sum_j Xs^j) G with diag(dw) = -G^2, Xs = -G F G SYMMETRIC:
+    // the orders 0 .. 5 that k_ensi_members takes as T0 .. T4 (four products) come out of THREE here,
+    //      X2 = Xs Xs,   X3 = X2 Xs,   sum = I + Xs + X2 + X3 + (Xs + X2) X3
+    // (powers of one symmetric matrix commute: every product is symmetric and only its tiles on and above the diagonal are computed).
+    // Orders 0 and 1 entry by entry in double precision as before; running sum: diag(dw) + diag(dw) F diag(dw).
+    float xsf[3][4];
 #pragma unroll
     for(int t = 0; t < 3; ++t) {
         const int ti = t >> 1, tj = (t + 1) >> 1;
-        const double dwc = s_dw[16 * tj + tr16];
+        const double dwc = s_dw[16 * tj + tr16], gc = s_g[16 * tj + tr16];
 #pragma unroll
         for(int r = 0; r < 4; ++r) {
             const int row = 16 * ti + 4 * tkq + r, col = 16 * tj + tr16;
             const bool isd = ti == tj && row == col;
             const double dwr = s_dw[row];
             const double fv = (isd ? 0.0 : et[t][r]) + sqc * ft[t][r];
-            const double t0 = dwr * fv * dwc;
-            sBf2[row * PPF + col] = (float)(fv * dwc);
-            if(t == 1) sBf2[col * PPF + row] = (float)(fv * dwr);      // (F is symmetric, F' is not)
-            stage_sym(sAf, t, r, (float)t0);
-            ft[t][r] = (isd ? dwr : 0.0) + t0;
+            xsf[t][r] = (float)(-(s_g[row] * fv * gc));
+            stage_sym(sAf, t, r, xsf[t][r]);
+            ft[t][r] = (isd ? dwr : 0.0) + dwr * fv * dwc;
         }
     }
     __syncthreads();
@@ -247,23 +250,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     {
         // (unconditional loads from clamped addresses, the value masked afterwards -- bitwise: a select of a loaded value becomes a branch around
         //  the load, one round trip to memory after the other)
-        long rbase[8];
-        unsigned rmask[8];
+        int colc[4];
+        unsigned cmask[4];
+#pragma unroll
+        for(int t = 0; t < 4; ++t) { const int col = 16 * t + r16; cmask[t] = col < nV ? 0xffffffffu : 0u; colc[t] = min(col, nV - 1); }
 #pragma unroll
         for(int ks = 0; ks < 8; ++ks) {
             const int row = 4 * ks + kq;
             const unsigned sr = s_sel[row];
-            rbase[ks] = (long)(row < n ? sr : 0u) * nV;
-            rmask[ks] = row < n ? 0xffffffffu : 0u;
-        }
+            const float* const yrow = a.gY + (long)(row < n ? sr : 0u) * nV;
+            const unsigned rmask = row < n ? 0xffffffffu : 0u;
 #pragma unroll
-        for(int t = 0; t < 4; ++t) {
-            const int col = 16 * t + r16;
-            const unsigned cmask = col < nV ? 0xffffffffu : 0u;
-            const int colc = min(col, nV - 1);
-#pragma unroll
-            for(int ks = 0; ks < 8; ++ks) {
-                if(16 * t < nV) yop[ks][t] = __uint_as_float(__float_as_uint(a.gY[rbase[ks] + colc]) & (rmask[ks] & cmask));
+            for(int t = 0; t < 4; ++t) {
+                if(16 * t < nV) yop[ks][t] = __uint_as_float(__float_as_uint(yrow[colc[t]]) & (rmask & cmask[t]));
                 else yop[ks][t] = 0.0f;
             }
         }
@@ -278,21 +277,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             s_yt[row * 4 + j] = __uint_as_float(__float_as_uint(v) & (on ? 0xffffffffu : 0u));
         }
     }
-#pragma unroll 1
-    for(int term = 0; term < GPP_ENSI_NNEU; ++term) {   // T(k+1) = T(k) F'
-        const Acc32f tt = mfma_32_f32<true>(lane, [&](int r, int k) { return sAf[r * PPF + k]; }, [&](int k, int cc) { return sBf2[k * PPF + cc]; });
+    {
+        const Acc32f x2 = mfma_32_f32<true>(lane, [&](int r, int k) { return sAf[r * PPF + k]; }, [&](int k, int cc) { return sAf[k * PPF + cc]; });    // Xs Xs
 #pragma unroll
         for(int t = 0; t < 3; ++t)
 #pragma unroll
-            for(int r = 0; r < 4; ++r) ft[t][r] += (double)tt.t[t >> 1][(t + 1) >> 1][r];
-        __syncthreads();   // (T(k) is read)
-        if(term + 1 < GPP_ENSI_NNEU) {
-#pragma unroll
-            for(int t = 0; t < 3; ++t)
-#pragma unroll
-                for(int r = 0; r < 4; ++r) stage_sym(sAf, t, r, tt.t[t >> 1][(t + 1) >> 1][r]);
-        }
+            for(int r = 0; r < 4; ++r) stage_sym(sBf2, t, r, x2.t[t >> 1][(t + 1) >> 1][r]);
         __syncthreads();
+        const Acc32f x3 = mfma_32_f32<true>(lane, [&](int r, int k) { return sBf2[r * PPF + k]; }, [&](int k, int cc) { return sAf[k * PPF + cc]; });   // X2 Xs
+        __syncthreads();   // (both operands are read)
+#pragma unroll
+        for(int t = 0; t < 3; ++t)
+#pragma unroll
+            for(int r = 0; r < 4; ++r) {
+                stage_sym(sAf, t, r, xsf[t][r] + x2.t[t >> 1][(t + 1) >> 1][r]);
+                stage_sym(sBf2, t, r, x3.t[t >> 1][(t + 1) >> 1][r]);
+                xsf[t][r] = x2.t[t >> 1][(t + 1) >> 1][r] + x3.t[t >> 1][(t + 1) >> 1][r];   // (from here on: X2 + X3 -- a float sum of terms <= 1e-3, like their staging)
+            }
+        __syncthreads();
+        const Acc32f p3 = mfma_32_f32<true>(lane, [&](int r, int k) { return sAf[r * PPF + k]; }, [&](int k, int cc) { return sBf2[k * PPF + cc]; });   // (Xs + X2) X3
+#pragma unroll
+        for(int t = 0; t < 3; ++t) {
+            const int ti = t >> 1, tj = (t + 1) >> 1;
+            const double gc = s_g[16 * tj + tr16];
+#pragma unroll
+            for(int r = 0; r < 4; ++r) {
+                const double hs = (double)xsf[t][r] + (double)p3.t[ti][tj][r];
+                ft[t][r] -= (s_g[16 * ti + 4 * tkq + r] * gc) * hs;
+            }
+        }
+        __syncthreads();   // (the operands are read)
     }
     // the middle matrix of W_sym -> the area (doubles, row major)
 #pragma unroll
