@@ -970,13 +970,14 @@ extern "C" int gpp_optimal_interpolation_ensi(gpp_points* bgrid, const float* ba
         if(nV <= 1) hipLaunchKernelGGL(k_ensi_count_cells, dim3(256), dim3(256), 0, stream(), (const unsigned*)a.meta, (long)a.ntiles * 64, ws.counters.p + 72);
         // spectral side (pairs of cells, warm-started along a tile) and ensemble side (one wave per cell) in batches of tiles: what
         // the second kernel needs of a cell (17 KB) waits in HBM.  The park is kept between calls (freeing and re-allocating tens of
-        // GB costs seconds) and is therefore bounded: a quarter of the device memory (72 GB of 288: config 5 runs in two batches,
-        // +1 % over one), never more than half of what is free right now; gpp_release_workspaces() gives it back (GPP_ENSI_PARK_MB)
+        // GB costs seconds) and is therefore bounded: two fifths of the device memory (115 GB of 288: config 5's 110 GB go through in one
+        // batch; every batch boundary costs the tails of both kernels, 1.5 ms on config 5 -- a quarter = two batches until round 6), never more
+        // than half of what is free right now; gpp_release_workspaces() gives it back (GPP_ENSI_PARK_MB)
         size_t park_bytes = (size_t)72 << 30;
         {
             size_t free_b = 0, total_b = 0;
             if(hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                park_bytes = std::min(total_b / 4, std::max<size_t>((free_b + ws.cpark.cap * sizeof(double)) / 2, (size_t)64 << 20));
+                park_bytes = std::min(total_b / 5 * 2, std::max<size_t>((free_b + ws.cpark.cap * sizeof(double)) / 2, (size_t)64 << 20));
         }
         if(path_env("GPP_ENSI_PARK_MB")) park_bytes = (size_t)atol(path_env("GPP_ENSI_PARK_MB")) << 20;
         const size_t per_tile = (size_t)64 * ENSI_PARK_D * sizeof(double);

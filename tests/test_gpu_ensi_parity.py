@@ -168,6 +168,22 @@ def test_ensi_member_counts_around_the_tiles_of_sixteen(E, allow):
     assert plain_err(out, ref).max() < 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("E", [16, 20, 33, 47, 50, 52, 64])
+@pytest.mark.parametrize("allow", [True, False])
+def test_ensi_two_area_member_kernel_behind_its_switch(E, allow, monkeypatch):
+    """Round 6: up to 64 valid members go through `k_ensi_members3` (one staging area, U and Y in matrix-core operand layout in registers:
+    three waves per SIMD, ensi_members3.h).  The kernel it replaced stays behind GPP_ENSI_MEMBERS2: same oracle, same measure, and the two
+    kernels within float32 rounding of each other (they order some double-precision sums differently)."""
+    c = case(300 + E, 12, 11, E, 40, nan_member=1 if E == 52 else None)
+    new, ref = run(c, 20000, 30, allow=allow)
+    monkeypatch.setenv("GPP_ENSI_MEMBERS2", "1")
+    old, _ = run(c, 20000, 30, allow=allow)
+    check(old, ref, c[2])
+    assert plain_err(old, ref).max() < 1e-5 and plain_err(new, ref).max() < 1e-5
+    assert plain_err(new, old).max() < 1e-5
+
+
 def test_ensi_no_extrapolation_nan_obs_invalid_member():
     c = case(7, 20, 24, 8, 50, nan_member=2, nan_obs=True)
     out, ref = run(c, 20000, 12, allow=False)
