@@ -64,7 +64,7 @@ def plain_err(out, ref):
 def test_strict_measure_with_converged_sweeps_and_count_for_the_fast_path():
     """Config-5-like inputs (E = 50, max_points 30, h = 10 km on a 1 x 1 degree domain, dense observations).
     (a) gpp_ensi_set_convergence(1): the Jacobi sweeps run to convergence and the PLAIN 1e-5 measure holds for every value.
-    (b) default (sweeps stopped at 0.040 c + the seven-product float32 perturbation series of round 4): the PLAIN measure holds as well (round 3,
+    (b) default (sweeps stopped at 0.040 c + the float32 perturbation series of round 4 (six products since round 6)): the PLAIN measure holds as well (round 3,
         with three products and 0.010 c, left about one value in 10^6 outside it by one float32 ulp of a term: DESIGN.md 4.2)."""
     import gridpp_amd as gridpp
     c = case(4242, 56, 60, 50, 1200)
