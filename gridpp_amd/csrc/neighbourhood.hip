@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, l
     const float4* in4 = reinterpret_cast<const float4*>(in);
     const unsigned zero = 0;
     __syncthreads();
-    const int ng = E4 / QC_G;
+    const int ng = (E4 + QC_G - 1) / QC_G;   // groups of QC_G loads (the last one may be shorter)
     float4 cur[QC_G], nxt[QC_G];
     // A workgroup takes super-tiles of four consecutive tiles (256 cells): the counts of a super-tile leave through an LDS
     // buffer as one dword store per lane and plane (256 contiguous bytes per instruction instead of four times 64)
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, l
     if(ng > 0 && (long)blockIdx.x < nsuper) {
         const float4* src0 = in4 + (long)blockIdx.x * 4 * 16 * E + lane;
 #pragma unroll
-        for(int i = 0; i < QC_G; i++) cur[i] = src0[i * 64];
+        for(int i = 0; i < QC_G; i++) if(i < E4) cur[i] = src0[i * 64];
     }
     for(long st = blockIdx.x; st < nsuper; st += gridDim.x) {
       const int nsub = (int)min(4L, nfull - st * 4);
@@ -374,19 +374,18 @@ __global__ __launch_bounds__(64) void k_qf_count(const float* __restrict__ in, l
         for(int g0 = 0; g0 < ng; g0++) {
             if(g0 + 1 < ng) {
 #pragma unroll
-                for(int i = 0; i < QC_G; i++) nxt[i] = src[((g0 + 1) * QC_G + i) * 64];
+                for(int i = 0; i < QC_G; i++) if((g0 + 1) * QC_G + i < E4) nxt[i] = src[((g0 + 1) * QC_G + i) * 64];
             }
             else if(next_tile >= 0) {
                 const float4* nsrc = in4 + next_tile * 16 * E + lane;
 #pragma unroll
-                for(int i = 0; i < QC_G; i++) nxt[i] = nsrc[i * 64];
+                for(int i = 0; i < QC_G; i++) if(i < E4) nxt[i] = nsrc[i * 64];
             }
 #pragma unroll
-            for(int i = 0; i < QC_G; i++) quad(cur[i], g0 * QC_G + i);
+            for(int i = 0; i < QC_G; i++) if(g0 * QC_G + i < E4) quad(cur[i], g0 * QC_G + i);
 #pragma unroll
             for(int i = 0; i < QC_G; i++) cur[i] = nxt[i];
         }
-        for(int k = ng * QC_G; k < E4; k++) quad(src[k * 64], k);
         __syncthreads();
         unsigned f[NL];
 #pragma unroll

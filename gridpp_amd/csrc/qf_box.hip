@@ -32,6 +32,14 @@ namespace {
 #define QB_SH 64        // output rows per workgroup (plus 2 HW + 1 rows of run-in)
 #endif
 
+// a workgroup barrier that orders LDS accesses only (the threads of a workgroup share nothing else; __syncthreads also waits for the global
+// stores of the interpolation stage)
+__device__ __forceinline__ void qb_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ bool qb_nv(float v) { return !isnan(v) && !isinf(v); }
 
 // 8 * byte I of the dword array w (I is a constant after unrolling): one instruction, the byte offset of a table entry
@@ -89,6 +97,89 @@ __device__ float qb_interp(const float* __restrict__ ya, const int stride, const
     if(i0 < 0) i0 = 0;
     if(i1 < 0) i1 = T - 1;
     const float x0 = ya[i0 * stride], x1 = ya[i1 * stride], t0 = thr[i0], t1 = thr[i1];
+    if(x0 == x1) {
+        if(i0 == 0 && i1 == T - 1) return (t0 + t1) / 2;
+        if(i0 == 0) return t1;
+        if(i1 == T - 1) return t0;
+        return (t0 + t1) / 2;
+    }
+    return t0 + (t1 - t0) * (x - x0) / (x1 - x0);
+}
+
+// F(o): what the reference makes of a window mean o before it interpolates -- `sum += o` E times in float, / E, clamped to [0, 1]
+// (neighbourhood.cpp:494-506).  acc = the E-fold sum.
+__device__ __forceinline__ float qb_fold_finish(const float acc, const float o, const int reps, const double rreps) {
+    // acc / E through the double reciprocal: exact for E < 2^8 (acc / E can neither hit nor come within 2^-41 of a float32
+    // rounding boundary, the double product is within 2^-52 of it)
+    const float yv = reps > 1 ? (float)((double)acc * rreps) : o;
+    return yv > 1 ? 1.0f : (yv < 0 ? 0.0f : yv);
+}
+
+#ifndef QB_LAZY
+#define QB_LAZY 1
+#endif
+// Round 6: the E-fold sums where interpolate() looks.  The threads (p, s) leave the window MEANS o in LDS, not F(o); thread c of the
+// interpolation stage needs F only at the two thresholds that bracket its quantile: the comparisons of interpolate() (util.cpp:339-389,
+// neighbourhood.cpp:508-513) come out the same on o as on F(o) whenever o is CLEARLY on one side of x, because F is monotone and stays
+// close to o:  s_E = fl(... fl(o + o) ... + o) differs from E o by at most u o (E (E + 1) / 2 - 1) (1 + 2e-5), u = 2^-24 (every addition
+// rounds the running sum, which is <= k o (1 + 2e-5) after k terms), the division and the rounding to float add 2^-24 + 2^-52:
+//      |F(o) - o| <= 7.7e-6 o   for E <= 255 (the byte planes hold no more);   F(0) = 0 and F(1) = 1 exactly; the clamp only moves F towards o.
+// "Clearly": o (1 + 1.2e-5) < x or o (1 - 1.2e-5) > x (or o is exactly 0 or 1, or E = 1: then F(o) = o and the comparison itself is
+// exact).  A column with a threshold that is NOT clearly on one side takes all its F(o) the slow way and then the unchanged interpolate().
+// Per row of a strip: 256 x 2 sums instead of 256 x T (config 4: k_qf_box<15> 0.96 -> 0.86 ms; vector instructions 322 M -> 216 M -- DESIGN 4.3).
+__device__ float qb_interp_lazy(float* __restrict__ ya, const int stride, const int T, const float* __restrict__ thr, const float x,
+                                const int reps, const double rreps) {
+    bool missing = false;
+    unsigned done = 0, amb = 0;          // bit t: ya[t] holds F(o_t) / o_t is not clearly on one side of x
+    for(int t = 0; t < T; t++) {
+        const float v = ya[t * stride];
+        if(!qb_nv(v)) missing = true;
+        if(v == 0.0f || v == 1.0f || reps <= 1) done |= 1u << t;
+        else if(!(v * 1.000012f < x) && !(v * 0.999988f > x)) amb |= 1u << t;   // (a NaN quantile lands here too)
+    }
+    if(missing) return NAN;
+    // a threshold that is not clearly on one side: F itself there and at both neighbours (one of them is the other end of the bracket), three sums
+    // side by side, written back over the means.  (Config 4 with the quantile ON a threshold's expected rank -- q = 0.5, thresholds 0 .. 10 over
+    // uniform [0, 10) members: the window means of that plane scatter around q itself -- has such a column in every fifth wave.)
+    while(__any(amb != 0u)) {
+        const int a = amb ? __builtin_ctz(amb) : 0;
+        const int ia = max(a - 1, 0), ib = min(a + 1, T - 1);
+        const float va = ya[ia * stride], vm = ya[a * stride], vb = ya[ib * stride];
+        float sa = 0.0f, sm = 0.0f, sb = 0.0f;
+#pragma unroll 4
+        for(int e = 0; e < reps; e++) { sa += va; sm += vm; sb += vb; }
+        if(amb) {
+            if(!((done >> ia) & 1u)) ya[ia * stride] = qb_fold_finish(sa, va, reps, rreps);
+            if(!((done >> a) & 1u)) ya[a * stride] = qb_fold_finish(sm, vm, reps, rreps);
+            if(!((done >> ib) & 1u)) ya[ib * stride] = qb_fold_finish(sb, vb, reps, rreps);
+            const unsigned bits = (1u << ia) | (1u << a) | (1u << ib);
+            done |= bits; amb &= ~bits;
+        }
+    }
+    // interpolate() on the column: every comparison below has the outcome it has on F(o)
+    const float y0a = ya[0], yLa = ya[(T - 1) * stride];
+    if(x == 1 && y0a == 1) return thr[0];                     // neighbourhood.cpp:508-513
+    if(x == 0 && yLa == 0) return thr[T - 1];
+    if(!qb_nv(x)) return NAN;                                  // interpolate(): util.cpp:378-379
+    if(x > yLa) return thr[T - 1];                             // util.cpp:386-389
+    if(x < y0a) return thr[0];
+    int i0 = -1, i1 = -1;                                      // get_lower_index / get_upper_index (util.cpp:339-376)
+    for(int i = 0; i < T; i++) { const float cv = ya[i * stride]; if(cv < x) i0 = i; else if(cv == x) { i0 = i; break; } else break; }
+    for(int i = T - 1; i >= 0; i--) { const float cv = ya[i * stride]; if(cv > x) i1 = i; else if(cv == x) { i1 = i; break; } else break; }
+    if(i0 < 0) i0 = 0;
+    if(i1 < 0) i1 = T - 1;
+    // ... and F itself at the two thresholds the result is interpolated between
+    const float o0 = ya[i0 * stride], o1 = ya[i1 * stride];
+    const bool have0 = ((done >> i0) & 1u) != 0u, have1 = ((done >> i1) & 1u) != 0u;
+    float x0 = o0, x1 = o1;
+    if(__any(!have0 || !have1)) {
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll 4
+        for(int e = 0; e < reps; e++) { a0 += o0; a1 += o1; }
+        if(!have0) x0 = qb_fold_finish(a0, o0, reps, rreps);
+        if(!have1) x1 = qb_fold_finish(a1, o1, reps, rreps);
+    }
+    const float t0 = thr[i0], t1 = thr[i1];
     if(x0 == x1) {
         if(i0 == 0 && i1 == T - 1) return (t0 + t1) / 2;
         if(i0 == 0) return t1;
@@ -236,6 +327,12 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
                     acc[j] = 0.0f;
                 }
             }
+#if QB_LAZY
+#pragma unroll
+            for(int j = 0; j < QB_SEG; j++) yab[p * QB_SW + s * QB_SEG + j] = qb_nv(o[j]) ? o[j] : NAN;   // the means: F where interpolate() looks, qb_interp_lazy
+            (void)acc;
+        }
+#else
             // (a wave whose means are all 0 or 1 -- a threshold below or above everything in sight -- has nothing to add up:
             //  E * 0 and E * 1 are exact, and so is every partial sum)
             bool plain01 = true;
@@ -273,7 +370,8 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
                 yab[p * QB_SW + s * QB_SEG + j] = qb_nv(o[j]) ? yv : NAN;
             }
         }
-        __syncthreads();
+#endif
+        qb_lds_barrier();
         for(int c = tid; c < QB_SW; c += blockDim.x) {
             const int x = xs + c;
             if(x < X) {
@@ -281,7 +379,11 @@ __global__ __launch_bounds__(512) void k_qf_box(const unsigned char* __restrict_
 #if defined(QB_ABL) && (QB_ABL & 2)      // timing experiment: no interpolation
                 out[cell] = yab[c] + yab[c + (T - 1) * QB_SW];
 #else
+#if QB_LAZY
+                out[cell] = qb_interp_lazy(yab + c, QB_SW, T, sthr, qfield ? q[cell] : q[0], reps, rreps);
+#else
                 out[cell] = qb_interp(yab + c, QB_SW, T, sthr, qfield ? q[cell] : q[0]);
+#endif
 #endif
             }
         }
