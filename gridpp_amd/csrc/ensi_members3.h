@@ -1,7 +1,8 @@
 // k_ensi_members3: the ensemble side of optimal_interpolation_ensi at THREE waves per SIMD (included by ensi.hip after ensi_pair.h).
 //
-// Same arithmetic as k_ensi_members<true> (ensi_pair.h; oi_ensi.cpp:379-553 -- see there for the series and its error bounds), one wave per
-// cell, at most 64 valid members.  k_ensi_members holds two 8.7 KB double-precision staging areas (19.8 KB of LDS per cell, 201 VGPRs): two
+// The mathematics of k_ensi_members<true> (ensi_pair.h; oi_ensi.cpp:379-553 -- see there for the series and its error bounds), one wave per
+// cell, at most 64 valid members; two things are computed differently: the Neumann series of the inverse in its symmetric form (three products
+// instead of four, below) and W' = Y^T M' Y by symmetry (its tiles on and above the diagonal).  k_ensi_members holds two 8.7 KB double-precision staging areas (19.8 KB of LDS per cell, 201 VGPRs): two
 // waves per SIMD.  A third needs <= 13.3 KB and <= 168 VGPRs per wave.  Here ONE staging area serves every phase in turn
 //      rows of U (z = U (C + E)^-1 U^T r)  ->  rows of U^T B U (the entries of the series)  ->  float operands of the series' products
 //      ->  Mmid  ->  U Mmid  ->  M' = sD (U Mmid U^T) sD  ->  the 16-member slabs of W' = Y^T Q
@@ -11,6 +12,8 @@
 // Sums over the rows of Y that k_ensi_members took per member (lane = member reads its column of the Y tile) are taken per operand lane -- the rows
 // 4 ks + kq of four members 16 t + r16 -- and put together over kq with a transposing reduction (member_reduce): the order of these double-precision
 // sums differs from k_ensi_members', everything that is rounded to float32 on the way (oi_ensi.cpp:505-511) is accumulated in the same order.
+// The operand loads are issued in front of the Neumann products (the square-root steps before them need the registers) and arrive behind them.
+// Config 5: 98.8 -> 79 ms for this kernel; 6 values in 10^6 one float32 ulp away from k_ensi_members' (tools/ensi_members_ab.py).
 #pragma once
 
 // lanes 0..31: x of the own lane; lanes 32..63: y of lane - 32
